@@ -1,0 +1,554 @@
+"""Generate the golden vectors in this directory by IMPORTING the reference.
+
+Run in the build container only (the reference lives at /root/reference and
+never travels):
+
+    python tests/golden/make_golden.py
+
+Every .npz stores inputs (data, prior + posterior standard parameters before
+the step) and the reference's outputs.  Nothing of the reference's source is
+stored -- only arrays.  See SURVEY.md section 8c for the case list G1..G11.
+"""
+
+import os
+import sys
+import types
+import warnings
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, '/root/reference')
+sys.modules['natsort'] = types.SimpleNamespace(natsorted=sorted)
+warnings.filterwarnings('ignore')
+
+import numpy as np
+import torch
+
+import beer
+from beer.cli.subcommands.hmm import mkphones, mkaligraph, mkdecodegraph
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+STD_NAMES = {
+    'NormalWishart': ('mean', 'scale', 'scale_matrix', 'dof'),
+    'NormalGamma': ('mean', 'scale', 'shape', 'rates'),
+    'IsotropicNormalGamma': ('mean', 'scale', 'shape', 'rate'),
+    'Dirichlet': ('concentrations',),
+    'Gamma': ('shape', 'rate'),
+}
+
+
+def npy(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy().copy()
+    return np.asarray(t)
+
+
+def dump_dist(out, prefix, dist):
+    cls = dist.__class__.__qualname__
+    out[prefix + '.cls'] = np.array(cls)
+    for name in STD_NAMES[cls]:
+        out[f'{prefix}.{name}'] = npy(getattr(dist.params, name))
+
+
+def dump_param(out, prefix, param):
+    dump_dist(out, prefix + '.prior', param.prior)
+    dump_dist(out, prefix + '.posterior', param.posterior)
+
+
+def dump_params(out, prefix, model):
+    'Dump every Bayesian parameter in mean-field order: <prefix>.p<i>.*'
+    for i, p in enumerate(model.bayesian_parameters()):
+        dump_param(out, f'{prefix}.p{i}', p)
+
+
+def dump_graph(out, prefix, g):
+    out[prefix + '.init'] = npy(g.init_log_probs)
+    out[prefix + '.final'] = npy(g.final_log_probs)
+    out[prefix + '.trans'] = npy(g.trans_log_probs)
+    out[prefix + '.pdf_id_mapping'] = np.asarray(g.pdf_id_mapping, dtype=np.int64)
+
+
+def dump_acc(out, prefix, model, acc_stats):
+    for i, p in enumerate(model.bayesian_parameters()):
+        out[f'{prefix}.p{i}'] = npy(acc_stats[p])
+
+
+def save(name, out):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def make_gmm(X, K, cov_type, dtype, seed, noise_std=1.):
+    torch.manual_seed(seed)
+    ns = beer.NormalSet.create(X.mean(0), X.var(0), size=K, prior_strength=1.,
+                               noise_std=noise_std, cov_type=cov_type)
+    m = beer.Mixture.create(ns, prior_strength=1.)
+    return m.double() if dtype == torch.float64 else m.float()
+
+
+def gmm_case(name, X, K, cov_type, niter, dtype, seed, detail=False):
+    X = X.to(dtype)
+    model = make_gmm(X, K, cov_type, dtype, seed)
+    out = {'X': npy(X), 'cov_type': np.array(cov_type), 'niter': np.array(niter)}
+    dump_params(out, 'init', model)
+    optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.)
+    elbos = []
+    for it in range(niter):
+        optim.init_step()
+        if detail and it == 0:
+            stats = model.sufficient_statistics(X)
+            ns = model.modelset
+            out['exp_T'] = npy(ns.means_precisions.natural_form())
+            out['pc_llh'] = npy(ns.expected_log_likelihood(stats))
+            out['log_weights'] = npy(model._log_weights({'dtype': dtype}))
+            out['per_frame'] = npy(model.expected_log_likelihood(stats))
+            out['resps'] = npy(model.cache['resps'])
+            model.clear_cache()
+            out['kl'] = npy(model.kl_div_posterior_prior())
+            out['nat_post'] = npy(ns.means_precisions.posterior.natural_parameters())
+            out['nat_prior'] = npy(ns.means_precisions.prior.natural_parameters())
+            out['lognorm_post'] = npy(ns.means_precisions.posterior.log_norm())
+        elbo = beer.evidence_lower_bound(model, X)
+        if it == 0:
+            dump_acc(out, 'acc0', model, elbo._acc_stats)
+        elbo.backward()
+        optim.step()
+        elbos.append(float(elbo))
+        dump_params(out, f'it{it}', model)
+    out['elbos'] = np.asarray(elbos)
+    save(name, out)
+
+
+def g1_g3_g11():
+    torch.manual_seed(0)
+    X = torch.randn(1000, 2, dtype=torch.float64)
+    X[:500] += torch.tensor([3., -2.], dtype=torch.float64)
+    gmm_case('g01_gmm_diag_c1', X, 8, 'diagonal', 5, torch.float64, 10, detail=True)
+    gmm_case('g11_gmm_diag_c1_f32', X, 8, 'diagonal', 5, torch.float32, 10, detail=True)
+
+    rng = np.random.RandomState(1)
+    means = rng.randn(16, 40) * 2
+    Xf = np.concatenate([means[k] + rng.randn(32, 40) @ (np.eye(40) + .1 * rng.randn(40, 40))
+                         for k in range(16)])
+    rng.shuffle(Xf)
+    Xf = torch.from_numpy(Xf)
+    gmm_case('g02_gmm_full', Xf, 16, 'full', 2, torch.float64, 11, detail=True)
+    gmm_case('g11_gmm_full_f32', Xf, 16, 'full', 2, torch.float32, 11, detail=True)
+
+    Xi = torch.from_numpy(rng.randn(300, 5) * 1.5 + rng.randn(5))
+    gmm_case('g03_gmm_iso', Xi, 8, 'isotropic', 3, torch.float64, 12, detail=True)
+
+    # labels= branch of Mixture.expected_log_likelihood (mixture.py:85-87).
+    X = torch.randn(64, 3, dtype=torch.float64)
+    model = make_gmm(X, 4, 'full', torch.float64, 13)
+    labels = torch.from_numpy(rng.randint(0, 4, size=64))
+    out = {'X': npy(X), 'labels': npy(labels), 'cov_type': np.array('full')}
+    dump_params(out, 'init', model)
+    elbo = beer.evidence_lower_bound(model, X, labels=labels)
+    out['elbo'] = np.asarray(float(elbo))
+    dump_acc(out, 'acc0', model, elbo._acc_stats)
+    save('g01_gmm_labels', out)
+
+
+def notebook_graph():
+    graph = beer.graph.Graph()
+    s0 = graph.add_state()
+    s4 = graph.add_state()
+    graph.start_state = s0
+    graph.end_state = s4
+    s1 = graph.add_state(pdf_id=0)
+    s2 = graph.add_state(pdf_id=1)
+    s3 = graph.add_state(pdf_id=2)
+    for a, b in [(s0, s1), (s1, s1), (s1, s2), (s2, s2), (s2, s3), (s3, s3),
+                 (s3, s1), (s1, s4), (s2, s4), (s3, s4)]:
+        graph.add_arc(a, b)
+    graph.normalize()
+    return graph.compile()
+
+
+def hmm_data(rng, nsamples=200):
+    trans = np.array([[.5, .5, 0], [0, .5, .5], [.5, 0, .5]])
+    means = [np.array([-3., 8.]), np.array([10., 10.]), np.array([1., -2.])]
+    covs = [np.array([[.75, -.5], [-.5, 2.]]), np.array([[2., 1.], [1., .75]]), np.eye(2)]
+    states = np.zeros(nsamples, dtype=int)
+    data = np.zeros((nsamples, 2))
+    data[0] = rng.multivariate_normal(means[0], covs[0])
+    for n in range(1, nsamples):
+        states[n] = rng.choice(3, p=trans[states[n - 1]])
+        data[n] = rng.multivariate_normal(means[states[n]], covs[states[n]])
+    return data, states
+
+
+def g4(dtype, suffix):
+    rng = np.random.RandomState(4)
+    data, _ = hmm_data(rng)
+    X = torch.from_numpy(data).to(dtype)
+    for cov_type in ('full', 'diagonal', 'isotropic'):
+        cgraph = notebook_graph()
+        torch.manual_seed(40)
+        ns = beer.NormalSet.create(torch.from_numpy(data.mean(0)).float(),
+                                   torch.from_numpy(np.cov(data.T)).float(),
+                                   size=3, prior_strength=1., noise_std=.5,
+                                   cov_type=cov_type)
+        hmm = beer.HMM.create(cgraph, ns)
+        hmm = hmm.double() if dtype == torch.float64 else hmm.float()
+        out = {'X': npy(X), 'cov_type': np.array(cov_type)}
+        dump_graph(out, 'graph', hmm.graph)
+        dump_params(out, 'init', hmm)
+        stats = hmm.sufficient_statistics(X)
+        pc = hmm._pc_llhs(stats, hmm.graph)
+        out['pc_llhs'] = npy(pc)
+        out['log_alphas'] = npy(hmm.graph._baum_welch_forward(pc))
+        out['log_betas'] = npy(hmm.graph._baum_welch_backward(pc))
+        (gamma, xi), lognorm = hmm.graph.posteriors(pc, trans_posteriors=True)
+        out['gamma'], out['xi_sum'], out['lognorm_mean'] = npy(gamma), npy(xi.sum(0)), npy(lognorm)
+        out['xi_first'] = npy(xi[:3])
+        hmm.clear_cache()
+        optim = beer.VBConjugateOptimizer(hmm.mean_field_factorization(), 1.)
+        elbos = []
+        for it in range(3):
+            optim.init_step()
+            elbo = beer.evidence_lower_bound(hmm, X, datasize=len(X), viterbi=False)
+            if it == 0:
+                dump_acc(out, 'acc0', hmm, elbo._acc_stats)
+            elbo.backward()
+            optim.step()
+            elbos.append(float(elbo))
+            dump_params(out, f'it{it}', hmm)
+        out['elbos'] = np.asarray(elbos)
+        out['decode'] = npy(hmm.decode(X))
+        out['posteriors'] = npy(hmm.posteriors(X))
+        save(f'g04_hmm_{cov_type}{suffix}', out)
+
+
+HMM_CONF = [
+    {'group_name': 'sil', 'n_normal_per_state': 3, 'prior_strength': 1.,
+     'noise_std': .5, 'cov_type': 'diagonal', 'shared_cov': False,
+     'topology': [
+         {'start_id': 0, 'end_id': 1, 'trans_prob': 1.0},
+         {'start_id': 1, 'end_id': 1, 'trans_prob': 0.5},
+         {'start_id': 1, 'end_id': 2, 'trans_prob': 0.5},
+         {'start_id': 2, 'end_id': 2, 'trans_prob': 0.5},
+         {'start_id': 2, 'end_id': 1, 'trans_prob': 0.25},
+         {'start_id': 2, 'end_id': 3, 'trans_prob': 0.25}]},
+    {'group_name': 'speech', 'n_normal_per_state': 4, 'prior_strength': 1.,
+     'noise_std': .5, 'cov_type': 'diagonal', 'shared_cov': False,
+     'topology': [
+         {'start_id': 0, 'end_id': 1, 'trans_prob': 1.0},
+         {'start_id': 1, 'end_id': 1, 'trans_prob': 0.75},
+         {'start_id': 1, 'end_id': 2, 'trans_prob': 0.25},
+         {'start_id': 2, 'end_id': 2, 'trans_prob': 0.75},
+         {'start_id': 2, 'end_id': 3, 'trans_prob': 0.25},
+         {'start_id': 3, 'end_id': 3, 'trans_prob': 0.75},
+         {'start_id': 3, 'end_id': 4, 'trans_prob': 0.25}]},
+]
+UNITS = [('sil', 'sil'), ('a', 'speech'), ('b', 'speech'), ('c', 'speech'), ('d', 'speech')]
+
+
+def build_phoneloop(prior, D, cov_type, seed, dtype):
+    'mkphones + mkphoneloopgraph + mkdecodegraph + mkphoneloop, in memory.'
+    torch.manual_seed(seed)
+    conf = {g['group_name']: dict(g, cov_type=cov_type) for g in HMM_CONF}
+    mean, var = torch.zeros(D).float(), torch.ones(D).float()
+    start_pdf_id, pdfs, units = 0, [], {}
+    grouped = {g: [n for n, gg in UNITS if gg == g] for g in conf}
+    for group in grouped:
+        tot = 0
+        for name in grouped[group]:
+            graph, start_pdf_id = mkphones.create_unit_graph(conf[group]['topology'], start_pdf_id)
+            units[name] = graph
+            tot += mkphones.count_emitting_state(graph)
+        pdfs.append(mkphones.create_pdfs(mean, var, tot, conf[group]))
+    emissions = beer.JointModelSet(pdfs)
+
+    graph = beer.graph.Graph()
+    graph.start_state = graph.add_state()
+    graph.end_state = graph.add_state()
+    pivot = graph.add_state()
+    unit2state = {'<s>': graph.start_state, '</s>': graph.end_state, '#1': pivot}
+    unit2state.update({name: graph.add_state() for name, _ in UNITS})
+    graph.add_arc(graph.start_state, unit2state['sil'])
+    graph.add_arc(unit2state['sil'], graph.end_state)
+    for name, _ in UNITS:
+        graph.add_arc(pivot, unit2state[name])
+        graph.add_arc(unit2state[name], pivot)
+    graph.symbols = {s: u for u, s in unit2state.items()}
+    graph.normalize()
+    for phone, hmm in units.items():
+        graph.replace_state(unit2state[phone], hmm)
+    graph.normalize()
+    start_pdf, end_pdf = {}, {}
+    for phone, hmm in units.items():
+        start_pdf[phone] = mkdecodegraph.get_first_emitting_state_pdf(hmm)
+        end_pdf[phone] = mkdecodegraph.get_last_emitting_state_pdf(hmm)
+    cgraph = graph.compile()
+    P = len(start_pdf)
+    if prior == 'dirichlet':
+        cat = beer.Categorical.create(torch.ones(P) / P, prior_strength=P / 2)
+    elif prior == 'dirichlet_process':
+        cat = beer.SBCategorical.create(truncation=P, prior_strength=P / 2)
+    else:
+        cat = beer.SBCategoricalHyperPrior.create(truncation=P, prior_strength=P / 2,
+                                                  hyper_prior_strength=1.)
+    ploop = beer.PhoneLoop.create(cgraph, start_pdf, end_pdf, emissions, cat)
+    ploop = ploop.double() if dtype == torch.float64 else ploop.float()
+    return ploop, units, start_pdf, end_pdf
+
+
+def dump_ploop_meta(out, ploop, start_pdf, end_pdf):
+    out['start_idxs'] = np.asarray(list(start_pdf.values()), dtype=np.int64)
+    out['end_idxs'] = np.asarray(list(end_pdf.values()), dtype=np.int64)
+    out['group_sizes'] = np.asarray([len(ms) for ms in ploop.modelset.original_modelset.modelsets])
+    out['group_ncomp'] = np.asarray([ms.n_comp_per_mixture
+                                     for ms in ploop.modelset.original_modelset.modelsets])
+
+
+def ploop_data(rng, T, D):
+    return rng.randn(T, D) * 1.3 + np.where(np.arange(T)[:, None] % 50 < 25, 1.5, -1.)
+
+
+def g5():
+    D = 4
+    rng = np.random.RandomState(5)
+    Xn = ploop_data(rng, 120, D)
+    for prior in ('dirichlet', 'dirichlet_process', 'gamma_dirichlet_process'):
+        ploop, units, start_pdf, end_pdf = build_phoneloop(prior, D, 'diagonal', 50, torch.float64)
+        X = torch.from_numpy(Xn)
+        out = {'X': Xn, 'prior_kind': np.array(prior), 'cov_type': np.array('diagonal')}
+        dump_ploop_meta(out, ploop, start_pdf, end_pdf)
+        dump_graph(out, 'graph', ploop.graph)
+        dump_params(out, 'init', ploop)
+        if prior == 'gamma_dirichlet_process':
+            dump_param(out, 'init.concentration', ploop.categorical.concentration)
+        optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.)
+        elbos = []
+        for it in range(2):
+            optim.init_step()
+            if it == 0:
+                stats = ploop.sufficient_statistics(X)
+                exp_llh = ploop.expected_log_likelihood(stats)
+                out['exp_llh'] = npy(exp_llh)
+                out['gamma'] = npy(ploop.cache['resps'])
+                out['xi_sum'] = npy(ploop.cache['trans_resps'].sum(0))
+                ploop.clear_cache()
+            elbo = beer.evidence_lower_bound(ploop, X, datasize=len(X))
+            dump_acc(out, f'acc{it}', ploop, elbo._acc_stats)
+            elbo.backward()
+            optim.step()
+            elbos.append(float(elbo))
+            dump_params(out, f'it{it}', ploop)
+            out[f'it{it}.trans'] = npy(ploop.graph.trans_log_probs)
+            if prior != 'dirichlet':
+                out[f'it{it}.ordering'] = npy(ploop.categorical.ordering)
+            if prior == 'gamma_dirichlet_process':
+                dump_param(out, f'it{it}.concentration', ploop.categorical.concentration)
+        out['elbos'] = np.asarray(elbos)
+        out['decode'] = npy(ploop.decode(X))
+        save(f'g05_phoneloop_{prior}', out)
+
+
+def g6_g8():
+    D = 4
+    rng = np.random.RandomState(6)
+    ploop, units, start_pdf, end_pdf = build_phoneloop('dirichlet', D, 'diagonal', 60, torch.float64)
+    Xn = ploop_data(rng, 90, D)
+    X = torch.from_numpy(Xn)
+    ali = mkaligraph.create_graph_from_seq(['sil', 'b', 'a', 'b', 'sil'], units).double()
+    out = {'X': Xn, 'cov_type': np.array('diagonal'), 'scale': np.array(.5)}
+    dump_ploop_meta(out, ploop, start_pdf, end_pdf)
+    dump_graph(out, 'graph', ploop.graph)
+    dump_graph(out, 'ali', ali)
+    dump_params(out, 'init', ploop)
+    stats = ploop.sufficient_statistics(X)
+    # G8: JointModelSet of two MixtureSets with different G (per-pdf log-norms).
+    out['joint_pc_llh'] = npy(ploop.modelset.original_modelset.expected_log_likelihood(stats))
+    ploop.clear_cache()
+    exp_llh = ploop.expected_log_likelihood(stats, inference_graph=ali, scale=.5)
+    out['exp_llh'] = npy(exp_llh)
+    out['gamma'] = npy(ploop.cache['resps'])
+    ploop.clear_cache()
+    optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.)
+    optim.init_step()
+    elbo = beer.evidence_lower_bound(ploop, X, datasize=1000, inference_graph=ali, scale=.5)
+    out['elbo'] = np.asarray(float(elbo))
+    dump_acc(out, 'acc0', ploop, elbo._acc_stats)
+    elbo.backward()
+    optim.step()
+    dump_params(out, 'it0', ploop)
+    out['it0.trans'] = npy(ploop.graph.trans_log_probs)
+    out['decode_ali'] = npy(ploop.decode(X, inference_graph=ali, scale=.5))
+    out['posteriors_ali'] = npy(ploop.posteriors(X, inference_graph=ali, scale=.5))
+    save('g06_phoneloop_ali', out)
+
+
+def g7():
+    ninf = -float('inf')
+    init = torch.tensor([0., ninf, ninf, ninf]).double().exp().log()
+    init = torch.tensor([np.log(.5), np.log(.5), ninf, ninf]).double()
+    final = torch.tensor([ninf, ninf, np.log(.5), np.log(.5)]).double()
+    trans = torch.tensor([[.5, .25, .25, 0.], [0., .5, .25, .25],
+                          [0., 0., .5, .5], [.25, 0., .25, .5]]).double().log()
+    g = beer.graph.CompiledGraph(init, final, trans, pdf_id_mapping=[0, 1, 2, 3])
+    rng = np.random.RandomState(7)
+    cases = []
+    # exact ties: integer-valued llhs; one with -inf entries; one random.
+    l1 = np.zeros((12, 4))
+    l2 = rng.randint(-3, 1, size=(25, 4)).astype(float)
+    l3 = rng.randn(40, 4) * 3
+    l3[5:9, 1] = ninf
+    l3[20, :3] = ninf
+    for l in (l1, l2, l3):
+        cases.append(l)
+    out = {}
+    dump_graph(out, 'graph', g)
+    for i, l in enumerate(cases):
+        lt = torch.from_numpy(l)
+        out[f'llhs{i}'] = l
+        out[f'path{i}'] = npy(g.best_path(lt))
+        (gamma, xi), ln = g.posteriors(lt, trans_posteriors=True)
+        out[f'gamma{i}'], out[f'xi_sum{i}'] = npy(gamma), npy(xi.sum(0))
+    save('g07_viterbi_ties', out)
+
+    # viterbi=True and state_path= training branches (hmm.py:42-58).
+    data, states = hmm_data(np.random.RandomState(8), 150)
+    X = torch.from_numpy(data)
+    for branch in ('viterbi', 'state_path'):
+        cgraph = notebook_graph()
+        torch.manual_seed(70)
+        ns = beer.NormalSet.create(X.mean(0).float(), torch.from_numpy(np.cov(data.T)).float(),
+                                   size=3, prior_strength=1., noise_std=.5, cov_type='full')
+        hmm = beer.HMM.create(cgraph, ns).double()
+        out = {'X': data, 'cov_type': np.array('full')}
+        dump_graph(out, 'graph', hmm.graph)
+        dump_params(out, 'init', hmm)
+        kwargs = {'viterbi': True} if branch == 'viterbi' else \
+                 {'state_path': torch.from_numpy(states)}
+        if branch == 'state_path':
+            out['state_path'] = states
+        elbo = beer.evidence_lower_bound(hmm, X, datasize=len(X), **kwargs)
+        out['elbo'] = np.asarray(float(elbo))
+        dump_acc(out, 'acc0', hmm, elbo._acc_stats)
+        save(f'g07_hmm_{branch}', out)
+
+
+def g9():
+    rng = np.random.RandomState(9)
+    D, K = 3, 5
+    Xs = [rng.randn(T, D) + 1. for T in (40, 25, 60)]
+    Xall = torch.from_numpy(np.concatenate(Xs))
+    N = 1000
+    out = {'X': npy(Xall), 'lens': np.asarray([len(x) for x in Xs]), 'datasize': np.asarray(N),
+           'cov_type': np.array('diagonal')}
+    model = make_gmm(Xall, K, 'diagonal', torch.float64, 90)
+    dump_params(out, 'init', model)
+    optim = beer.VBConjugateOptimizer(model.conjugate_bayesian_parameters(keepgroups=True), 1.)
+    optim.init_step()
+    elbo = beer.evidence_lower_bound(datasize=N)
+    vals = []
+    for x in Xs:
+        e = beer.evidence_lower_bound(model, torch.from_numpy(x), datasize=N)
+        vals.append(float(e))
+        elbo += e
+    out['utt_values'] = np.asarray(vals)
+    out['sum_value'] = np.asarray(float(elbo))
+    out['logged'] = np.asarray(float(elbo) / (len(Xs) * N))
+    one = beer.evidence_lower_bound(model, Xall, datasize=N)
+    out['single_call_value'] = np.asarray(float(one))
+    dump_acc(out, 'acc_sum', model, elbo._acc_stats)
+    elbo.backward()
+    for i, p in enumerate(model.bayesian_parameters()):
+        out[f'stored.p{i}'] = npy(p.stats)
+    optim.step()
+    dump_params(out, 'it0', model)
+    # lrate != 1
+    optim2 = beer.VBConjugateOptimizer(model.conjugate_bayesian_parameters(keepgroups=True), .3)
+    optim2.init_step()
+    e = beer.evidence_lower_bound(model, Xall, datasize=N)
+    e.backward()
+    optim2.step()
+    dump_params(out, 'it1_lr03', model)
+    save('g09_elbo_bookkeeping', out)
+
+
+def g10():
+    rng = np.random.RandomState(10)
+    K, D = 6, 5
+    out = {}
+    A = rng.randn(K, D, D)
+    W = A @ A.transpose(0, 2, 1) / D + .2 * np.eye(D)
+    dists = {
+        'nw': beer.dists.NormalWishart.from_std_parameters(
+            torch.from_numpy(rng.randn(K, D)), torch.from_numpy(rng.rand(K, 1) * 3 + .5),
+            torch.from_numpy(W), torch.from_numpy(rng.rand(K, 1) * 5 + D)),
+        'ng': beer.dists.NormalGamma.from_std_parameters(
+            torch.from_numpy(rng.randn(K, D)), torch.from_numpy(rng.rand(K, 1) * 3 + .5),
+            torch.from_numpy(rng.rand(K, 1) * 4 + .5), torch.from_numpy(rng.rand(K, D) * 3 + .2)),
+        'ing': beer.dists.IsotropicNormalGamma.from_std_parameters(
+            torch.from_numpy(rng.randn(K, D)), torch.from_numpy(rng.rand(K, 1) * 3 + .5),
+            torch.from_numpy(rng.rand(K, 1) * 4 + .5), torch.from_numpy(rng.rand(K, 1) * 3 + .2)),
+        'dir': beer.dists.Dirichlet.from_std_parameters(torch.from_numpy(rng.rand(7) * 4 + .3)),
+        'dirset': beer.dists.Dirichlet.from_std_parameters(torch.from_numpy(rng.rand(K, 4) * 4 + .3)),
+    }
+    dists2 = {
+        'nw': beer.dists.NormalWishart.from_std_parameters(
+            torch.from_numpy(rng.randn(K, D)), torch.from_numpy(rng.rand(K, 1) * 3 + .5),
+            torch.from_numpy(W * 1.3 + .1 * np.eye(D)), torch.from_numpy(rng.rand(K, 1) * 5 + D)),
+        'ng': beer.dists.NormalGamma.from_std_parameters(
+            torch.from_numpy(rng.randn(K, D)), torch.from_numpy(rng.rand(K, 1) * 3 + .5),
+            torch.from_numpy(rng.rand(K, 1) * 4 + .5), torch.from_numpy(rng.rand(K, D) * 3 + .2)),
+        'ing': beer.dists.IsotropicNormalGamma.from_std_parameters(
+            torch.from_numpy(rng.randn(K, D)), torch.from_numpy(rng.rand(K, 1) * 3 + .5),
+            torch.from_numpy(rng.rand(K, 1) * 4 + .5), torch.from_numpy(rng.rand(K, 1) * 3 + .2)),
+        'dir': beer.dists.Dirichlet.from_std_parameters(torch.from_numpy(rng.rand(7) * 4 + .3)),
+        'dirset': beer.dists.Dirichlet.from_std_parameters(torch.from_numpy(rng.rand(K, 4) * 4 + .3)),
+    }
+    for name, d in dists.items():
+        dump_dist(out, f'{name}.q', d)
+        dump_dist(out, f'{name}.p', dists2[name])
+        out[f'{name}.natural'] = npy(d.natural_parameters())
+        out[f'{name}.exp_stats'] = npy(d.expected_sufficient_statistics())
+        out[f'{name}.log_norm'] = npy(d.log_norm())
+        out[f'{name}.kl'] = npy(beer.dists.kl_div(d, dists2[name]))
+        rt = d.params.from_natural_parameters(d.natural_parameters())
+        for pn in STD_NAMES[d.__class__.__qualname__]:
+            out[f'{name}.roundtrip.{pn}'] = npy(getattr(rt, pn))
+    g = beer.dists.Gamma.from_std_parameters(torch.tensor([2.5]).double(), torch.tensor([1.7]).double())
+    g2 = beer.dists.Gamma.from_std_parameters(torch.tensor([1.5]).double(), torch.tensor([.7]).double())
+    dump_dist(out, 'gamma.q', g)
+    dump_dist(out, 'gamma.p', g2)
+    out['gamma.natural'] = npy(g.natural_parameters())
+    out['gamma.exp_stats'] = npy(g.expected_sufficient_statistics())
+    out['gamma.log_norm'] = npy(g.log_norm())
+    out['gamma.kl'] = npy(beer.dists.kl_div(g, g2))
+    # sufficient statistics of the three likelihoods
+    X = torch.from_numpy(rng.randn(9, D))
+    out['X'] = npy(X)
+    out['stats.full'] = npy(dists['nw'].conjugate().sufficient_statistics(X))
+    out['stats.diagonal'] = npy(dists['ng'].conjugate().sufficient_statistics(X))
+    out['stats.isotropic'] = npy(dists['ing'].conjugate().sufficient_statistics(X))
+    save('g10_dists', out)
+
+
+def g_graph():
+    'Graph builder / compile semantics (graph.py:103-240): arrays only.'
+    ploop, units, start_pdf, end_pdf = build_phoneloop('dirichlet', 3, 'diagonal', 1, torch.float32)
+    out = {}
+    dump_graph(out, 'ploop', ploop.graph)
+    ali = mkaligraph.create_graph_from_seq(['sil', 'a', 'c', 'a', 'sil'], units)
+    dump_graph(out, 'ali', ali)
+    dump_graph(out, 'notebook', notebook_graph())
+    out['start_idxs'] = np.asarray(list(start_pdf.values()), dtype=np.int64)
+    out['end_idxs'] = np.asarray(list(end_pdf.values()), dtype=np.int64)
+    save('g12_graph_compile', out)
+
+
+if __name__ == '__main__':
+    g1_g3_g11()
+    g4(torch.float64, '')
+    g4(torch.float32, '_f32')
+    g5()
+    g6_g8()
+    g7()
+    g9()
+    g10()
+    g_graph()

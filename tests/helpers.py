@@ -1,0 +1,63 @@
+"""Shared helpers for the test-suite (golden loading, oracle import)."""
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import beer_oracle as orc  # noqa: E402  (tests may use the oracle)
+
+STD_NAMES = {
+    'NormalWishart': ('mean', 'scale', 'scale_matrix', 'dof'),
+    'NormalGamma': ('mean', 'scale', 'shape', 'rates'),
+    'IsotropicNormalGamma': ('mean', 'scale', 'shape', 'rate'),
+    'Dirichlet': ('concentrations',),
+    'Gamma': ('shape', 'rate'),
+}
+COV_OF = {'NormalWishart': 'full', 'NormalGamma': 'diagonal',
+          'IsotropicNormalGamma': 'isotropic'}
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False) as f:
+        return {k: f[k] for k in f.files}
+
+
+def dist_cls(g, prefix):
+    return str(g[prefix + '.cls'])
+
+
+def std_params(g, prefix):
+    'Tuple of standard-parameter arrays of the distribution at `prefix`.'
+    return tuple(g[f'{prefix}.{n}'].copy() for n in STD_NAMES[dist_cls(g, prefix)])
+
+
+def n_params(g, prefix):
+    i = 0
+    while f'{prefix}.p{i}.prior.cls' in g:
+        i += 1
+    return i
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    same = (a == b) | (np.isnan(a) & np.isnan(b))     # equal infinities match
+    if np.any(~np.isfinite(a) & ~same) or np.any(~np.isfinite(b) & ~same):
+        return np.inf
+    fin = np.isfinite(b)
+    if not fin.any():
+        return 0.
+    denom = np.maximum(np.abs(b[fin]).max(), 1e-300)
+    return np.abs(np.where(same, 0., a - np.where(same, a, b))).max() / denom
+
+
+def assert_close(a, b, tol, what=''):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, f'{what}: shape {a.shape} != {b.shape}'
+    err = rel_err(a, b)
+    assert err <= tol, f'{what}: rel err {err:.3e} > {tol:.1e}'

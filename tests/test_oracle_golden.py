@@ -1,0 +1,331 @@
+"""Pin the CPU oracle (`oracle/beer_oracle.py`) against golden vectors produced
+by importing the reference (tests/golden/make_golden.py).  CPU only."""
+
+import numpy as np
+import pytest
+
+from helpers import (COV_OF, assert_close, dist_cls, load_golden, n_params,
+                     orc, std_params)
+
+TOL64 = 1e-10
+TOL32 = 2e-4      # fp32 goldens: the reference's own fp32 rounding band
+
+
+# --- G10: distribution level -------------------------------------------------
+
+@pytest.mark.parametrize('name,fam', [('nw', 'full'), ('ng', 'diagonal'),
+                                      ('ing', 'isotropic')])
+def test_g10_normal_families(name, fam):
+    g = load_golden('g10_dists')
+    f = orc.FAMILIES[fam]
+    q, p = std_params(g, f'{name}.q'), std_params(g, f'{name}.p')
+    assert_close(f['nat'](*q), g[f'{name}.natural'], TOL64, 'natural')
+    assert_close(f['exp'](*q), g[f'{name}.exp_stats'], TOL64, 'E[T]')
+    assert_close(f['lnorm'](*q), g[f'{name}.log_norm'], TOL64, 'log_norm')
+    assert_close(orc.family_kl(fam, q, p), g[f'{name}.kl'], 1e-9, 'kl')
+    rt = f['from_nat'](f['nat'](*q))
+    for arr, pn in zip(rt, f['names']):
+        assert_close(arr.reshape(g[f'{name}.roundtrip.{pn}'].shape),
+                     g[f'{name}.roundtrip.{pn}'], 1e-9, 'roundtrip ' + pn)
+
+
+@pytest.mark.parametrize('name', ['dir', 'dirset'])
+def test_g10_dirichlet(name):
+    g = load_golden('g10_dists')
+    (q,), (p,) = std_params(g, f'{name}.q'), std_params(g, f'{name}.p')
+    assert_close(orc.dir_natural(q), g[f'{name}.natural'], TOL64)
+    assert_close(orc.dir_expected_stats(q), g[f'{name}.exp_stats'], TOL64)
+    assert_close(orc.dir_log_norm(q), g[f'{name}.log_norm'], TOL64)
+    assert_close(orc.dir_kl(q, p), g[f'{name}.kl'], 1e-9)
+    assert_close(orc.dir_from_natural(orc.dir_natural(q)),
+                 g[f'{name}.roundtrip.concentrations'], TOL64)
+
+
+def test_g10_gamma_and_stats():
+    g = load_golden('g10_dists')
+    q, p = std_params(g, 'gamma.q'), std_params(g, 'gamma.p')
+    assert_close(orc.gamma_natural(*q), g['gamma.natural'], TOL64)
+    assert_close(orc.gamma_expected_stats(*q), g['gamma.exp_stats'], TOL64)
+    assert_close(orc.gamma_log_norm(*q), g['gamma.log_norm'], TOL64)
+    kl = orc.kl_div(orc.gamma_expected_stats(*q), orc.gamma_natural(*q),
+                    orc.gamma_natural(*p), orc.gamma_log_norm(*q),
+                    orc.gamma_log_norm(*p))
+    assert_close(kl, g['gamma.kl'], 1e-9)
+    for cov in ('full', 'diagonal', 'isotropic'):
+        assert_close(orc.SUFFSTATS[cov](g['X']), g[f'stats.{cov}'], 1e-15)
+
+
+# --- G1/G2/G3/G11: GMM VB iterations -----------------------------------------
+
+GMM_CASES = [('g01_gmm_diag_c1', TOL64), ('g02_gmm_full', 1e-9),
+             ('g03_gmm_iso', TOL64), ('g11_gmm_diag_c1_f32', TOL32),
+             ('g11_gmm_full_f32', 2e-3)]
+
+
+@pytest.mark.parametrize('name,tol', GMM_CASES)
+def test_gmm_iterations(name, tol):
+    g = load_golden(name)
+    cov = str(g['cov_type'])
+    X = g['X']
+    f = orc.FAMILIES[cov]
+    post, prior = std_params(g, 'init.p0.posterior'), std_params(g, 'init.p0.prior')
+    (w_post,), (w_prior,) = std_params(g, 'init.p1.posterior'), std_params(g, 'init.p1.prior')
+    D = X.shape[1]
+
+    # detailed first-step intermediates
+    stats = orc.SUFFSTATS[cov](X)
+    exp_T = f['exp'](*post)
+    assert_close(exp_T, g['exp_T'], tol, 'E[T]')
+    assert_close(orc.normal_llh(stats, exp_T, D), g['pc_llh'], tol, 'pc_llh')
+    lw = orc.log_weights(w_post)
+    assert_close(lw, g['log_weights'].reshape(-1), tol, 'log_weights')
+    per_frame, resps = orc.mixture_estep(stats, exp_T, D, lw)
+    assert_close(per_frame, g['per_frame'], tol, 'per_frame')
+    assert_close(resps, g['resps'], tol * 10, 'resps')
+    assert_close(f['nat'](*post), g['nat_post'], tol, 'nat_post')
+    assert_close(f['lnorm'](*post), g['lognorm_post'], tol, 'lognorm')
+
+    for it in range(int(g['niter'])):
+        r = orc.gmm_elbo_step(X, cov, post, prior, w_post, w_prior)
+        if it == 0:
+            assert_close(r['kl'], g['kl'], max(tol, 1e-9) * 10, 'kl')
+            assert_close(r['acc_normal'], g['acc0.p0'], tol, 'acc normal')
+            assert_close(r['acc_weights'], g['acc0.p1'], tol, 'acc weights')
+        assert_close(r['value'], g['elbos'][it], tol, f'elbo it{it}')
+        post, w_post = orc.gmm_mstep(cov, post, prior, w_post, w_prior,
+                                     r['acc_normal'], r['acc_weights'])
+        if X.dtype == np.float32 and it > 0:
+            continue        # fp32 trajectories diverge; per-step parity only
+        for arr, ref in zip(post, std_params(g, f'it{it}.p0.posterior')):
+            assert_close(arr.reshape(ref.shape), ref, tol * 100, f'post it{it}')
+        assert_close(w_post, g[f'it{it}.p1.posterior.concentrations'], tol * 10)
+        if X.dtype == np.float32:
+            # restart from the reference's posterior: per-step parity
+            post = std_params(g, f'it{it}.p0.posterior')
+            w_post = g[f'it{it}.p1.posterior.concentrations']
+
+
+def test_gmm_labels_branch():
+    g = load_golden('g01_gmm_labels')
+    post, prior = std_params(g, 'init.p0.posterior'), std_params(g, 'init.p0.prior')
+    (w_post,), (w_prior,) = std_params(g, 'init.p1.posterior'), std_params(g, 'init.p1.prior')
+    r = orc.gmm_elbo_step(g['X'], 'full', post, prior, w_post, w_prior,
+                          labels=g['labels'])
+    assert_close(r['value'], g['elbo'], TOL64)
+    assert_close(r['acc_normal'], g['acc0.p0'], TOL64)
+    assert_close(r['acc_weights'], g['acc0.p1'], TOL64)
+
+
+# --- G4/G7: HMM ---------------------------------------------------------------
+
+def _graph(g, prefix):
+    return dict(init=g[prefix + '.init'], final=g[prefix + '.final'],
+                trans=g[prefix + '.trans'].copy(),
+                order=g[prefix + '.pdf_id_mapping'])
+
+
+def _normal_group(g, prefix, i=0):
+    cov = COV_OF[dist_cls(g, f'{prefix}.p{i}.posterior')]
+    post = std_params(g, f'{prefix}.p{i}.posterior')
+    return dict(cov_type=cov, post=post, prior=std_params(g, f'init.p{i}.prior'),
+                S=len(post[0]), G=0)
+
+
+@pytest.mark.parametrize('cov', ['full', 'diagonal', 'isotropic'])
+@pytest.mark.parametrize('suffix,tol', [('', 1e-9), ('_f32', 2e-3)])
+def test_g4_hmm(cov, suffix, tol):
+    g = load_golden(f'g04_hmm_{cov}{suffix}')
+    X, graph = g['X'], _graph(g, 'graph')
+    groups = [_normal_group(g, 'init')]
+    pc_all, _ = orc.emissions_estep(X, groups)
+    assert_close(pc_all, g['pc_llhs'], tol, 'pc_llhs')
+    pc = g['pc_llhs']
+    assert_close(orc.forward(pc, graph['init'], graph['trans']), g['log_alphas'], tol)
+    assert_close(orc.backward(pc, graph['final'], graph['trans']), g['log_betas'], tol)
+    gamma, xi, lnm = orc.posteriors(pc, graph['init'], graph['final'], graph['trans'], True)
+    assert_close(gamma, g['gamma'], tol * 10, 'gamma')
+    assert_close(xi.sum(0), g['xi_sum'], tol * 10, 'xi_sum')
+    assert_close(xi[:3], g['xi_first'], tol * 10, 'xi_first')
+    assert_close(lnm, g['lognorm_mean'], tol)
+    np.testing.assert_array_equal(
+        orc.best_path(pc, graph['init'], graph['final'], graph['trans']),
+        orc.best_path(pc, graph['init'], graph['final'], graph['trans']))
+    for it in range(3):
+        r = orc.hmm_elbo_step(X, groups, graph, datasize=len(X), trans_posteriors=True)
+        assert_close(r['value'], g['elbos'][it], tol * 10, f'elbo {it}')
+        if it == 0:
+            assert_close(r['acc'][0][0], g['acc0.p0'], tol * 10, 'acc')
+        groups = orc.emissions_mstep(groups, r['acc'], 1.)
+        if suffix:
+            groups = [_normal_group(g, f'it{it}')]
+            continue
+        for arr, ref in zip(groups[0]['post'], std_params(g, f'it{it}.p0.posterior')):
+            assert_close(arr.reshape(ref.shape), ref, 1e-7, f'post it{it}')
+    if not suffix:
+        # decode after 3 iterations (bit-exact target: int64 path)
+        pc_all, _ = orc.emissions_estep(X, groups)
+        path = orc.best_path(pc_all[:, graph['order']], graph['init'],
+                             graph['final'], graph['trans'])
+        np.testing.assert_array_equal(graph['order'][path], g['decode'])
+        post, _ = orc.posteriors(pc_all[:, graph['order']], graph['init'],
+                                 graph['final'], graph['trans'])
+        assert_close(post, g['posteriors'], 1e-6)
+
+
+def test_g7_viterbi_ties():
+    g = load_golden('g07_viterbi_ties')
+    graph = _graph(g, 'graph')
+    for i in range(3):
+        l = g[f'llhs{i}']
+        np.testing.assert_array_equal(
+            orc.best_path(l, graph['init'], graph['final'], graph['trans']), g[f'path{i}'])
+        gamma, xi, _ = orc.posteriors(l, graph['init'], graph['final'], graph['trans'], True)
+        assert_close(gamma, g[f'gamma{i}'], 1e-12)
+        assert_close(xi.sum(0), g[f'xi_sum{i}'], 1e-12)
+
+
+@pytest.mark.parametrize('branch', ['viterbi', 'state_path'])
+def test_g7_hmm_hard_alignment(branch):
+    g = load_golden(f'g07_hmm_{branch}')
+    groups = [_normal_group(g, 'init')]
+    kw = {'viterbi': True} if branch == 'viterbi' else {'state_path': g['state_path']}
+    r = orc.hmm_elbo_step(g['X'], groups, _graph(g, 'graph'), datasize=len(g['X']),
+                          trans_posteriors=True, **kw)
+    assert_close(r['value'], g['elbo'], 1e-10)
+    assert_close(r['acc'][0][0], g['acc0.p0'], 1e-10)
+
+
+# --- G5/G6/G8: PhoneLoop ------------------------------------------------------
+
+def _ploop_groups(g, prefix):
+    groups, i = [], 0
+    for S, G in zip(g['group_sizes'], g['group_ncomp']):
+        cov = COV_OF[dist_cls(g, f'{prefix}.p{i}.posterior')]
+        groups.append(dict(
+            cov_type=cov, S=int(S), G=int(G),
+            post=std_params(g, f'{prefix}.p{i}.posterior'),
+            prior=std_params(g, f'init.p{i}.prior'),
+            w_post=g[f'{prefix}.p{i + 1}.posterior.concentrations'],
+            w_prior=g[f'init.p{i + 1}.prior.concentrations']))
+        i += 2
+    return groups, i
+
+
+@pytest.mark.parametrize('kind', ['dirichlet', 'dirichlet_process',
+                                  'gamma_dirichlet_process'])
+def test_g5_phoneloop(kind):
+    g = load_golden(f'g05_phoneloop_{kind}')
+    X, graph = g['X'], _graph(g, 'graph')
+    groups, ci = _ploop_groups(g, 'init')
+    start, end = g['start_idxs'], g['end_idxs']
+    P = len(start)
+    state = dict(post=g[f'init.p{ci}.posterior.concentrations'],
+                 prior=g[f'init.p{ci}.prior.concentrations'].copy(),
+                 ordering=np.arange(P))
+    if kind == 'gamma_dirichlet_process':
+        state.update(g_prior_shape=g['init.concentration.prior.shape'],
+                     g_prior_rate=g['init.concentration.prior.rate'],
+                     g_post_shape=g['init.concentration.posterior.shape'],
+                     g_post_rate=g['init.concentration.posterior.rate'])
+    for it in range(2):
+        r = orc.hmm_elbo_step(X, groups, graph, datasize=len(X), trans_posteriors=True,
+                              extra_kl=orc.categorical_kl(kind, state))
+        if it == 0:
+            assert_close(r['exp_llh'], g['exp_llh'], 1e-9, 'exp_llh')
+            assert_close(r['resps'], g['gamma'], 1e-8, 'gamma')
+            assert_close(r['trans_resps'].sum(0), g['xi_sum'], 1e-8, 'xi_sum')
+        assert_close(r['value'], g['elbos'][it], 1e-9, f'elbo {it}')
+        counts = orc.phone_counts(r['trans_resps'], r['resps'], start, end)
+        cstats = orc.cat_suffstats(counts.reshape(1, -1)).sum(0) if kind == 'dirichlet' \
+            else counts
+        assert_close(cstats, g[f'acc{it}.p{ci}'], 1e-8, 'phone stats')
+        for k, (ns, ws) in enumerate(r['acc']):
+            assert_close(ns, g[f'acc{it}.p{2 * k}'], 1e-8, f'acc normal {k}')
+            assert_close(ws, g[f'acc{it}.p{2 * k + 1}'], 1e-8, f'acc weights {k}')
+        groups = orc.emissions_mstep(groups, r['acc'], 1.)
+        state = orc.categorical_mstep(kind, state, cstats)
+        lw = orc.categorical_log_weights(kind, state)
+        graph['trans'] = orc.phoneloop_update_trans(graph['trans'], lw, start, end)
+        assert_close(state['post'], g[f'it{it}.p{ci}.posterior.concentrations'], 1e-9)
+        assert_close(np.exp(graph['trans']), np.exp(g[f'it{it}.trans']), 1e-9, 'trans')
+        if kind != 'dirichlet':
+            np.testing.assert_array_equal(state['ordering'], g[f'it{it}.ordering'])
+        if kind == 'gamma_dirichlet_process':
+            assert_close(state['g_post_rate'], g[f'it{it}.concentration.posterior.rate'], 1e-10)
+            assert_close(state['g_post_shape'], g[f'it{it}.concentration.posterior.shape'], 1e-10)
+        for k, grp in enumerate(groups):
+            for arr, ref in zip(grp['post'], std_params(g, f'it{it}.p{2 * k}.posterior')):
+                assert_close(arr.reshape(ref.shape), ref, 1e-8)
+    pc_all, _ = orc.emissions_estep(X, groups)
+    path = orc.best_path(pc_all[:, graph['order']], graph['init'], graph['final'],
+                         graph['trans'])
+    np.testing.assert_array_equal(graph['order'][path], g['decode'])
+
+
+def test_g6_alignment_graph_and_g8_joint():
+    g = load_golden('g06_phoneloop_ali')
+    X = g['X']
+    groups, ci = _ploop_groups(g, 'init')
+    pc_all, _ = orc.emissions_estep(X, groups)
+    assert_close(pc_all, g['joint_pc_llh'], 1e-10, 'G8 joint pc llh')
+    ali = _graph(g, 'ali')
+    assert len(set(ali['order'].tolist())) < len(ali['order'])   # repeated pdf ids
+    scale = float(g['scale'])
+    w_post = g[f'init.p{ci}.posterior.concentrations']
+    w_prior = g[f'init.p{ci}.prior.concentrations']
+    r = orc.hmm_elbo_step(X, groups, ali, datasize=1000, scale=scale,
+                          extra_kl=orc.dir_kl(w_post, w_prior).sum())
+    assert_close(r['exp_llh'], g['exp_llh'], 1e-9)
+    assert_close(r['resps'], g['gamma'], 1e-8)
+    assert_close(r['value'], g['elbo'], 1e-9)
+    for k, (ns, ws) in enumerate(r['acc']):
+        assert_close(ns, g[f'acc0.p{2 * k}'], 1e-8)
+        assert_close(ws, g[f'acc0.p{2 * k + 1}'], 1e-8)
+    assert np.all(g[f'acc0.p{ci}'] == 0)          # phoneloop.py:98-100
+    # decode / posteriors were taken after the update (make_golden.py g6_g8)
+    groups = orc.emissions_mstep(groups, r['acc'], r['value'] * 0 + 1000. / len(X))
+    for k, grp in enumerate(groups):
+        for arr, ref in zip(grp['post'], std_params(g, f'it0.p{2 * k}.posterior')):
+            assert_close(arr.reshape(ref.shape), ref, 1e-8)
+    pc_all, _ = orc.emissions_estep(X, groups)
+    pc = pc_all.dtype.type(scale) * pc_all[:, ali['order']]
+    path = orc.best_path(pc, ali['init'], ali['final'], ali['trans'])
+    np.testing.assert_array_equal(ali['order'][path], g['decode_ali'])
+    pc_all, _ = orc.emissions_estep(X, groups, stats_scale=scale)    # Q5
+    post, _ = orc.posteriors(pc_all[:, ali['order']], ali['init'], ali['final'],
+                             ali['trans'])
+    assert_close(post, g['posteriors_ali'], 1e-8)
+
+
+# --- G9: ELBO bookkeeping -------------------------------------------------------
+
+def test_g9_bookkeeping():
+    g = load_golden('g09_elbo_bookkeeping')
+    X, lens, N = g['X'], g['lens'], int(g['datasize'])
+    post, prior = std_params(g, 'init.p0.posterior'), std_params(g, 'init.p0.prior')
+    (w_post,), (w_prior,) = std_params(g, 'init.p1.posterior'), std_params(g, 'init.p1.prior')
+    off = np.concatenate([[0], np.cumsum(lens)])
+    total, acc_n, acc_w = 0., 0., 0.
+    for u in range(len(lens)):
+        r = orc.gmm_elbo_step(X[off[u]:off[u + 1]], 'diagonal', post, prior,
+                              w_post, w_prior, datasize=N)
+        assert_close(r['value'], g['utt_values'][u], 1e-10)
+        total += r['value']
+        acc_n, acc_w = acc_n + r['acc_normal'], acc_w + r['acc_weights']
+    assert_close(total, g['sum_value'], 1e-10)                        # Q1: -U*KL
+    assert_close(total / (len(lens) * N), g['logged'], 1e-10)
+    assert_close(acc_n, g['acc_sum.p0'], 1e-10)
+    scale = N / float(lens.sum())                                     # Q2
+    assert_close(scale * acc_n, g['stored.p0'], 1e-10)
+    assert_close(scale * acc_w, g['stored.p1'], 1e-10)
+    post1, w1 = orc.gmm_mstep('diagonal', post, prior, w_post, w_prior,
+                              scale * acc_n, scale * acc_w)
+    for arr, ref in zip(post1, std_params(g, 'it0.p0.posterior')):
+        assert_close(arr.reshape(ref.shape), ref, 1e-9)
+    r = orc.gmm_elbo_step(X, 'diagonal', post1, prior, w1, w_prior, datasize=N)
+    post2, w2 = orc.gmm_mstep('diagonal', post1, prior, w1, w_prior,
+                              r['scale'] * r['acc_normal'],
+                              r['scale'] * r['acc_weights'], lrate=.3)
+    for arr, ref in zip(post2, std_params(g, 'it1_lr03.p0.posterior')):
+        assert_close(arr.reshape(ref.shape), ref, 1e-9)
+    assert_close(w2, g['it1_lr03.p1.posterior.concentrations'], 1e-9)
