@@ -1,0 +1,12 @@
+'''beer_amd -- MI355X-native variational-Bayes hot path of beer, behind
+beer's own model API (`import beer_amd as beer`).'''
+
+from .models import *
+from .inference import *
+from . import dists
+from . import graph
+from . import utils
+from . import vbi
+from .stats import FrameStats
+
+__version__ = '0.1.0'

@@ -1,0 +1,155 @@
+"""ctypes binding of the C ABI declared in include/beer_hip.h.
+
+torch is used here for what the design allows it to do: own device memory
+(`tensor.data_ptr()`), name the current HIP stream and move bytes.  Every
+numerical step of the hot path is a call into libbeer_hip.so; there is NO CPU
+fallback -- without the library or without a GPU the calls raise.
+"""
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libbeer_hip.so')
+
+F32, F64 = 0, 1
+FULL, DIAG, ISO = 0, 1, 2
+COV_CODE = {'full': FULL, 'diagonal': DIAG, 'isotropic': ISO}
+EINVAL = -100000
+
+
+class HipUnavailable(RuntimeError):
+    'Raised when the HIP extension or the GPU is missing (no CPU fallback).'
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    'The loaded shared library (loaded once; raises if it was not built).'
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipUnavailable(
+                f'{LIB_PATH} is missing: build it with `python -m beer_amd.build` '
+                '(beer_amd has no CPU fallback)')
+        _lib = ctypes.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+c_p, c_i, c_l, c_d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+
+
+class Graph(ctypes.Structure):
+    'beer_graph of include/beer_hip.h.'
+    _fields_ = [('n_states', ctypes.c_int32), ('n_arcs', ctypes.c_int32),
+                ('init', c_p), ('final', c_p),
+                ('in_ptr', c_p), ('in_src', c_p), ('in_w', c_p),
+                ('out_ptr', c_p), ('out_dst', c_p), ('out_w', c_p)]
+
+
+class Batch(ctypes.Structure):
+    'beer_batch of include/beer_hip.h.'
+    _fields_ = [('nutt', ctypes.c_int32), ('max_states', ctypes.c_int32),
+                ('max_arcs', ctypes.c_int32), ('n_graphs', ctypes.c_int32),
+                ('frame_off', c_p), ('llh_off', c_p), ('graph_id', c_p),
+                ('graphs', c_p), ('pdf_off', c_p), ('pdf_ids', c_p)]
+
+
+# name -> argument ctypes (return type is always int)
+_four = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]          # dtype,K,D,4 in,out,stream
+_from = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]          # dtype,K,D,eta,4 out,stream
+_dir = [c_i, c_i, c_i, c_p, c_p, c_p]
+_gam = [c_i, c_i, c_p, c_p, c_p, c_p]
+SIGNATURES = {
+    'beer_hip_version': [],
+    'beer_hip_device_count': [],
+    'beer_nw_expected_stats': _four, 'beer_nw_log_norm': _four, 'beer_nw_natural': _four,
+    'beer_nw_from_natural': _from,
+    'beer_ng_expected_stats': _four, 'beer_ng_log_norm': _four, 'beer_ng_natural': _four,
+    'beer_ng_from_natural': _from,
+    'beer_ing_expected_stats': _four, 'beer_ing_log_norm': _four, 'beer_ing_natural': _four,
+    'beer_ing_from_natural': _from,
+    'beer_dirichlet_expected_stats': _dir, 'beer_dirichlet_log_norm': _dir,
+    'beer_dirichlet_natural': _dir, 'beer_dirichlet_from_natural': _dir,
+    'beer_dirichlet_log_weights': _dir,
+    'beer_gamma_expected_stats': _gam, 'beer_gamma_log_norm': _gam,
+    'beer_gamma_natural': _gam,
+    'beer_gamma_from_natural': [c_i, c_i, c_p, c_p, c_p, c_p],
+    'beer_kl_div': [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'beer_natural_grad_step': [c_i, c_l, c_p, c_p, c_p, c_d, c_p, c_p],
+    'beer_suffstats_expand': [c_i, c_i, c_l, c_i, c_p, c_p, c_p],
+    'beer_mixtureset_estep': [c_i, c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d,
+                              c_p, c_p, c_p, c_p, c_p],
+    'beer_normal_accumulate': [c_i, c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+    'beer_weights_from_acc': [c_i, c_i, c_i, c_p, c_p, c_p],
+    'beer_hmm_gather': [c_i, c_p, c_i, c_p, c_d, c_p, c_p],
+    'beer_hmm_forward_backward': [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'beer_hmm_viterbi': [c_i, c_p, c_p, c_p, c_p, c_i, c_p],
+    'beer_hmm_path_posteriors': [c_i, c_p, c_p, c_p, c_p, c_p, c_p],
+    'beer_hmm_scatter': [c_i, c_p, c_i, c_p, c_p, c_d, c_p, c_p, c_p, c_p],
+    'beer_segment_sum': [c_i, ctypes.c_int32, c_p, c_p, c_p, c_p],
+}
+
+
+def _declare(l):
+    for name, args in SIGNATURES.items():
+        fn = getattr(l, name)
+        fn.argtypes = args
+        fn.restype = c_i
+
+
+def dtype_code(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.float64:
+        return F64
+    raise TypeError(f'beer_amd kernels take float32 or float64 tensors, got {dtype}')
+
+
+def require_device():
+    'Device to compute on.  Raises when there is no GPU: no CPU fallback.'
+    if not torch.cuda.is_available():
+        raise HipUnavailable('beer_amd needs an AMD GPU (gfx950); there is no CPU fallback')
+    lib()
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def on_device(t, dtype=None):
+    '''Contiguous device view/copy of `t` (H2D copy for host tensors: data
+    movement only, the arithmetic always runs in the HIP kernels).'''
+    dev = require_device()
+    if t.device.type != 'cuda':
+        t = t.to(dev)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    'Call an entry point on the current torch stream and check its status.'
+    rc = getattr(lib(), name)(*args, stream())
+    if rc != 0:
+        what = 'invalid argument' if rc == EINVAL else f'hipError {-rc}'
+        raise HipError(f'{name} failed: {what}')
+
+
+def struct_to_device(obj, device):
+    'Copy a ctypes structure (or array of them) to device memory as bytes.'
+    buf = torch.frombuffer(bytearray(bytes(obj)), dtype=torch.uint8)
+    return buf.to(device)

@@ -1,0 +1,419 @@
+// Generic (any D, K, covariance type, fp32 / fp64) E-step kernels:
+//   * per-component expected log-likelihood straight from the frames -- the
+//     [T, Q] statistics tensor of the reference is never formed,
+//   * per-state mixture normaliser + component responsibilities,
+//   * responsibility-weighted sufficient statistics, accumulated in fp64.
+// The MFMA fast path for full covariance lives in estep_mfma.hip and is
+// selected by the C entry points below when its shape constraints hold.
+//
+// Reference restated: beer/models/normalset.py:117-123, mixture.py:70-102,
+// mixtureset.py:85-112, dists/normalwishart.py:30-38,88-92 (and the
+// normalgamma / isonormalgamma equivalents).
+
+#include "common.h"
+#include "estep_mfma.h"
+
+using namespace beer;
+
+namespace {
+
+constexpr int kFrameTile = 64;      // frames per workgroup tile (lane = frame)
+constexpr int kLlhThreads = 256;    // 4 waves, each walks a share of the comps
+constexpr int kCompChunk = 64;      // components per workgroup
+
+// ---------------------------------------------------------------------------
+// Pass 1: w[t,k] = stat_scale * phi(x_t) . E[T]_k - D/2 ln2pi (+ log_weights)
+// Lane = frame, the component's parameters are wave-uniform (scalar loads).
+// Results are staged through LDS so that global writes are row-contiguous.
+// ---------------------------------------------------------------------------
+template <typename T, int COV>
+__global__ __launch_bounds__(kLlhThreads) void llh_kernel(
+    int64_t nframes, int D, int K, const T* __restrict__ X, const T* __restrict__ expT,
+    const T* __restrict__ logw, double stat_scale, T* __restrict__ pc_llh,
+    T* __restrict__ w_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ldx = D + 1;
+    T* xs = reinterpret_cast<T*>(smem);                 // [64][D+1]
+    T* outs = xs + kFrameTile * ldx;                    // [64][kCompChunk+1]
+    const int ldo = kCompChunk + 1;
+    const int Q = stats_dim(COV, D);
+    const int64_t t0 = (int64_t)blockIdx.x * kFrameTile;
+    const int k0 = blockIdx.y * kCompChunk;
+    const int nk = min(kCompChunk, K - k0);
+    const int nt = (int)min<int64_t>(kFrameTile, nframes - t0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int idx = tid; idx < nt * D; idx += kLlhThreads)
+        xs[(idx / D) * ldx + idx % D] = X[t0 * D + idx];
+    __syncthreads();
+
+    const T* x = xs + lane * ldx;
+    const double base = -0.5 * (double)D * kLog2Pi;
+    if (lane < nt) {
+        for (int kk = wave; kk < nk; kk += kLlhThreads / 64) {
+            const T* e = expT + (size_t)(k0 + kk) * Q;
+            double acc = 0.0;
+            if (COV == BEER_FULL) {
+                const T* L = e + D;
+                for (int i = 0; i < D; ++i) {
+                    T s = 0;
+                    const T* Li = L + i * D;
+                    for (int j = 0; j < D; ++j) s += Li[j] * x[j];
+                    acc += (double)x[i] * ((double)e[i] - 0.5 * (double)s);
+                }
+            } else if (COV == BEER_DIAG) {
+                for (int i = 0; i < D; ++i) {
+                    const double xi = (double)x[i];
+                    acc += xi * ((double)e[i] - 0.5 * (double)e[D + i] * xi);
+                }
+            } else {
+                double x2 = 0.0;
+                for (int i = 0; i < D; ++i) {
+                    const double xi = (double)x[i];
+                    acc += xi * (double)e[i];
+                    x2 += xi * xi;
+                }
+                acc -= 0.5 * (double)e[D] * x2;
+            }
+            const double zero = (COV == BEER_ISO) ? 0.5 * (double)D : 0.5;
+            acc += -0.5 * (double)e[Q - 2] + zero * (double)e[Q - 1];
+            outs[lane * ldo + kk] = (T)(stat_scale * acc + base);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nt * nk; idx += kLlhThreads) {
+        const int t = idx / nk, kk = idx % nk;
+        const T v = outs[t * ldo + kk];
+        const size_t o = (size_t)(t0 + t) * K + k0 + kk;
+        if (pc_llh) pc_llh[o] = v;
+        if (w_out) w_out[o] = logw ? (T)(v + logw[k0 + kk]) : v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Pass 2: per (frame, state) logsumexp over the G components, responsibilities
+// in place.  One thread per (t, s).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void normalise_kernel(int64_t nframes, int S, int G, T* __restrict__ w,
+                                 T* __restrict__ log_norm, bool write_resps,
+                                 double* __restrict__ llh_sum) {
+    __shared__ double red[8];
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double mine = 0.0;
+    if (idx < nframes * S) {
+        T* row = w + idx * G;
+        T m = row[0];
+        for (int g = 1; g < G; ++g) m = row[g] > m ? row[g] : m;
+        T ln;
+        if (m == -INFINITY || m == INFINITY) {
+            ln = m;
+        } else {
+            double s = 0.0;
+            for (int g = 0; g < G; ++g) s += exp((double)row[g] - (double)m);
+            ln = (T)((double)m + log(s));
+        }
+        if (write_resps)
+            for (int g = 0; g < G; ++g) row[g] = (T)exp((double)row[g] - (double)ln);
+        if (log_norm) log_norm[idx] = ln;
+        mine = (double)ln;
+    }
+    if (llh_sum) {
+        const double tot = block_sum(mine, red);
+        if (threadIdx.x == 0) atomicAdd(llh_sum, tot);
+    }
+}
+
+// labels= branch of Mixture.expected_log_likelihood (mixture.py:85-87).
+template <typename T>
+__global__ void labels_kernel(int64_t nframes, int K, const int64_t* __restrict__ labels,
+                              const T* __restrict__ pc, T* __restrict__ resps,
+                              T* __restrict__ log_norm, double* __restrict__ llh_sum) {
+    __shared__ double red[8];
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double mine = 0.0;
+    if (t < nframes) {
+        const int64_t lab = labels[t];
+        const T v = pc[t * K + lab];          // read before the row is overwritten
+        if (resps)
+            for (int k = 0; k < K; ++k) resps[t * K + k] = (T)(k == lab ? 1 : 0);
+        if (log_norm) log_norm[t] = v;
+        mine = (double)v;
+    }
+    if (llh_sum) {
+        const double tot = block_sum(mine, red);
+        if (threadIdx.x == 0) atomicAdd(llh_sum, tot);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Accumulation: acc[k, q] += sum_t r[t,k] * phi_q(x_t).  Lane = statistic q,
+// each lane keeps KB components in registers; the responsibilities are
+// wave-uniform scalars.  fp32 partial sums are flushed to fp64 every frame
+// tile, fp64 atomics at the end of the block's frame range.
+// ---------------------------------------------------------------------------
+constexpr int kAccThreads = 256;
+constexpr int kAccKB = 8;
+constexpr int kAccTile = 64;
+
+template <typename T, int COV>
+__global__ __launch_bounds__(kAccThreads) void accumulate_kernel(
+    int64_t nframes, int D, int S, int G, const T* __restrict__ X,
+    const T* __restrict__ comp_resps, const T* __restrict__ state_resps,
+    int64_t frames_per_block, double* __restrict__ acc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* xs = reinterpret_cast<T*>(smem);                // [kAccTile][D]
+    T* ws = xs + kAccTile * D;                          // [kAccTile][kAccKB]
+    const int K = S * G, Q = stats_dim(COV, D);
+    const int q = blockIdx.x * kAccThreads + threadIdx.x;
+    const int k0 = blockIdx.y * kAccKB;
+    const int nkb = min(kAccKB, K - k0);
+    const int64_t tb = (int64_t)blockIdx.z * frames_per_block;
+    const int64_t te = min(nframes, tb + frames_per_block);
+
+    // which statistic this lane owns
+    int qi = 0, qj = 0, kind;    // kind 0: x_i, 1: x_i*x_j*-.5, 2: -.5, 3: +.5 (iso .5 D), 4: -.5|x|^2
+    if (q < D) { kind = 0; qi = q; }
+    else if (q == Q - 2) kind = 2;
+    else if (q == Q - 1) kind = 3;
+    else if (q >= Q) kind = -1;
+    else if (COV == BEER_FULL) { kind = 1; qi = (q - D) / D; qj = (q - D) % D; }
+    else if (COV == BEER_DIAG) { kind = 1; qi = qj = q - D; }
+    else kind = 4;
+
+    double dacc[kAccKB];
+#pragma unroll
+    for (int b = 0; b < kAccKB; ++b) dacc[b] = 0.0;
+
+    for (int64_t t0 = tb; t0 < te; t0 += kAccTile) {
+        const int nt = (int)min<int64_t>(kAccTile, te - t0);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < nt * D; idx += kAccThreads) xs[idx] = X[t0 * D + idx];
+        for (int idx = threadIdx.x; idx < nt * kAccKB; idx += kAccThreads) {
+            const int t = idx / kAccKB, b = idx % kAccKB;
+            T w = 0;
+            if (b < nkb) {
+                const int k = k0 + b;
+                w = comp_resps ? comp_resps[(t0 + t) * K + k] : (T)1;
+                if (state_resps) w *= state_resps[(t0 + t) * S + k / G];
+            }
+            ws[idx] = w;
+        }
+        __syncthreads();
+        if (kind < 0) continue;
+        T facc[kAccKB];
+#pragma unroll
+        for (int b = 0; b < kAccKB; ++b) facc[b] = 0;
+        for (int t = 0; t < nt; ++t) {
+            const T* x = xs + t * D;
+            T phi;
+            if (kind == 0) phi = x[qi];
+            else if (kind == 1) phi = (T)-0.5 * (x[qi] * x[qj]);
+            else if (kind == 2) phi = (T)-0.5;
+            else if (kind == 3) phi = (COV == BEER_ISO) ? (T)(0.5 * D) : (T)0.5;
+            else {
+                T s = 0;
+                for (int d = 0; d < D; ++d) s += x[d] * x[d];
+                phi = (T)-0.5 * s;
+            }
+            const T* w = ws + t * kAccKB;
+#pragma unroll
+            for (int b = 0; b < kAccKB; ++b) facc[b] += w[b] * phi;
+        }
+#pragma unroll
+        for (int b = 0; b < kAccKB; ++b) dacc[b] += (double)facc[b];
+    }
+    if (kind < 0) return;
+#pragma unroll
+    for (int b = 0; b < kAccKB; ++b)
+        if (b < nkb) atomicAdd(acc + (size_t)(k0 + b) * Q + q, dacc[b]);
+}
+
+__global__ void weights_from_acc_kernel(int S, int G, int Q, const double* __restrict__ acc,
+                                        double* __restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    double tot = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const double n = -2.0 * acc[(size_t)(s * G + g) * Q + Q - 2];
+        tot += n;
+        if (g < G - 1) out[s * G + g] += n;
+    }
+    out[s * G + G - 1] += tot;
+}
+
+template <typename T>
+__global__ void segment_sum_kernel(const int64_t* __restrict__ frame_off,
+                                   const T* __restrict__ v, double* __restrict__ out) {
+    __shared__ double red[8];
+    const int u = blockIdx.x;
+    const int64_t b = frame_off[u], e = frame_off[u + 1];
+    double s = 0.0;
+    for (int64_t t = b + threadIdx.x; t < e; t += blockDim.x) s += (double)v[t];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[u] += s;
+}
+
+// ---- launchers -------------------------------------------------------------
+
+template <typename T, int COV>
+int llh_launch(int64_t nframes, int D, int K, const void* X, const void* expT, const void* logw,
+               double stat_scale, void* pc_llh, void* w_out, hipStream_t s) {
+    const size_t lds = ((size_t)kFrameTile * (D + 1) + (size_t)kFrameTile * (kCompChunk + 1)) * sizeof(T);
+    const int64_t tiles = (nframes + kFrameTile - 1) / kFrameTile;
+    // gridDim.x is 2^31-1 on gfx950; frames beyond that would need a loop.
+    BEER_REQUIRE(tiles < (int64_t)2147483647);
+    const dim3 grid((unsigned)tiles, (unsigned)((K + kCompChunk - 1) / kCompChunk));
+    hipLaunchKernelGGL((llh_kernel<T, COV>), grid, dim3(kLlhThreads), lds, s, nframes, D, K,
+                       (const T*)X, (const T*)expT, (const T*)logw, stat_scale, (T*)pc_llh,
+                       (T*)w_out);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+template <typename T>
+int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, const void* expT,
+                 const void* logw, const int64_t* labels, double stat_scale, void* pc_llh,
+                 void* log_norm, void* comp_resps, double* llh_sum, void* stream) {
+    BEER_REQUIRE(nframes >= 0 && D >= 1 && S >= 1 && G >= 1 && cov >= 0 && cov <= 2);
+    BEER_REQUIRE(X && expT);
+    BEER_REQUIRE(!labels || S == 1);
+    if (nframes == 0) return BEER_OK;
+    hipStream_t s = as_stream(stream);
+    const int K = S * G;
+    // The normaliser works in place on the responsibilities buffer; without one
+    // (pc_llh only, or G == 1 log_norm only) pass 1 alone is enough.
+    const bool need_norm = (log_norm || comp_resps || llh_sum) && !labels;
+    void* w_buf = comp_resps;
+    if (need_norm && !w_buf) {
+        // G == 1: log_norm == w; let pass 1 write into log_norm directly.
+        BEER_REQUIRE(G == 1 && log_norm);
+        w_buf = log_norm;
+    }
+    int rc;
+    void* pc_arg = labels ? (pc_llh ? pc_llh : comp_resps) : pc_llh;
+    BEER_REQUIRE(!labels || pc_arg);
+    void* w_arg = labels ? nullptr : (need_norm ? w_buf : nullptr);
+
+    if (!labels && cov == BEER_FULL && beer_mfma::supported(D, K) && w_arg && !pc_arg &&
+        stat_scale == 1.0) {
+        // fast path (gfx950 MFMA), full covariance
+        rc = sizeof(T) == 4
+                 ? beer_mfma::llh_full_f32(nframes, D, K, (const float*)X, (const float*)expT,
+                                           (const float*)logw, (float*)w_arg, s)
+                 : beer_mfma::llh_full_f64(nframes, D, K, (const double*)X, (const double*)expT,
+                                           (const double*)logw, (double*)w_arg, s);
+    } else if (cov == BEER_FULL)
+        rc = llh_launch<T, BEER_FULL>(nframes, D, K, X, expT, logw, stat_scale, pc_arg, w_arg, s);
+    else if (cov == BEER_DIAG)
+        rc = llh_launch<T, BEER_DIAG>(nframes, D, K, X, expT, logw, stat_scale, pc_arg, w_arg, s);
+    else
+        rc = llh_launch<T, BEER_ISO>(nframes, D, K, X, expT, logw, stat_scale, pc_arg, w_arg, s);
+    if (rc != BEER_OK) return rc;
+
+    if (labels) {
+        const T* pc = (const T*)pc_arg;
+        // when pc aliases comp_resps the kernel reads pc[t,label] before it
+        // overwrites the row: one thread owns the whole row.
+        hipLaunchKernelGGL(labels_kernel<T>, dim3((unsigned)((nframes + 255) / 256)), dim3(256), 0,
+                           s, nframes, K, labels, pc, (T*)comp_resps, (T*)log_norm, llh_sum);
+        BEER_LAUNCH_CHECK();
+        return BEER_OK;
+    }
+    if (need_norm) {
+        const int64_t n = nframes * S;
+        const bool alias = (w_buf == log_norm);
+        hipLaunchKernelGGL(normalise_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                           nframes, S, G, (T*)w_buf, alias ? (T*)nullptr : (T*)log_norm,
+                           comp_resps != nullptr, llh_sum);
+        BEER_LAUNCH_CHECK();
+    }
+    return BEER_OK;
+}
+
+template <typename T, int COV>
+int acc_launch(int64_t nframes, int D, int S, int G, const void* X, const void* cr,
+               const void* sr, double* acc, hipStream_t s) {
+    const int K = S * G, Q = stats_dim(COV, D);
+    const int gx = (Q + kAccThreads - 1) / kAccThreads, gy = (K + kAccKB - 1) / kAccKB;
+    // aim for ~4 workgroups per CU, at least 512 frames per workgroup
+    int64_t gz = (256LL * 4 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy);
+    const int64_t max_z = (nframes + 511) / 512;
+    if (gz > max_z) gz = max_z;
+    if (gz < 1) gz = 1;
+    if (gz > 65535) gz = 65535;
+    int64_t fpb = (nframes + gz - 1) / gz;
+    fpb = (fpb + kAccTile - 1) / kAccTile * kAccTile;
+    gz = (nframes + fpb - 1) / fpb;
+    const size_t lds = ((size_t)kAccTile * D + (size_t)kAccTile * kAccKB) * sizeof(T);
+    hipLaunchKernelGGL((accumulate_kernel<T, COV>), dim3(gx, gy, (unsigned)gz), dim3(kAccThreads),
+                       lds, s, nframes, D, S, G, (const T*)X, (const T*)cr, (const T*)sr, fpb, acc);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+template <typename T>
+int accumulate_launch(int cov, int64_t nframes, int D, int S, int G, const void* X,
+                      const void* cr, const void* sr, double* acc, void* stream) {
+    BEER_REQUIRE(nframes >= 0 && D >= 1 && S >= 1 && G >= 1 && cov >= 0 && cov <= 2);
+    BEER_REQUIRE(X && acc);
+    if (nframes == 0) return BEER_OK;
+    hipStream_t s = as_stream(stream);
+    if (cov == BEER_FULL && beer_mfma::supported(D, S * G) && cr) {
+        return sizeof(T) == 4
+                   ? beer_mfma::acc_full_f32(nframes, D, S, G, (const float*)X, (const float*)cr,
+                                             (const float*)sr, acc, s)
+                   : beer_mfma::acc_full_f64(nframes, D, S, G, (const double*)X,
+                                             (const double*)cr, (const double*)sr, acc, s);
+    }
+    if (cov == BEER_FULL) return acc_launch<T, BEER_FULL>(nframes, D, S, G, X, cr, sr, acc, s);
+    if (cov == BEER_DIAG) return acc_launch<T, BEER_DIAG>(nframes, D, S, G, X, cr, sr, acc, s);
+    return acc_launch<T, BEER_ISO>(nframes, D, S, G, X, cr, sr, acc, s);
+}
+
+template <typename T>
+int segment_sum_launch(int32_t nutt, const int64_t* frame_off, const void* v, double* out,
+                       void* stream) {
+    BEER_REQUIRE(nutt >= 0);
+    if (nutt == 0) return BEER_OK;
+    hipLaunchKernelGGL(segment_sum_kernel<T>, dim3(nutt), dim3(256), 0, as_stream(stream),
+                       frame_off, (const T*)v, out);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int beer_mixtureset_estep(int dtype, int cov, int64_t T, int D, int S, int G, const void* X,
+                          const void* exp_stats, const void* log_weights,
+                          const int64_t* labels, double stat_scale, void* pc_llh,
+                          void* log_norm, void* comp_resps, double* llh_sum, void* stream) {
+    BEER_DISPATCH(dtype, estep_launch, cov, T, D, S, G, X, exp_stats, log_weights, labels,
+                  stat_scale, pc_llh, log_norm, comp_resps, llh_sum, stream);
+}
+
+int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G, const void* X,
+                           const void* comp_resps, const void* state_resps, double* acc,
+                           void* stream) {
+    BEER_DISPATCH(dtype, accumulate_launch, cov, T, D, S, G, X, comp_resps, state_resps, acc,
+                  stream);
+}
+
+int beer_weights_from_acc(int S, int G, int Q, const double* acc, double* out, void* stream) {
+    BEER_REQUIRE(S >= 0 && G >= 1 && Q >= 3 && acc && out);
+    if (S == 0) return BEER_OK;
+    hipLaunchKernelGGL(weights_from_acc_kernel, dim3((S + 63) / 64), dim3(64), 0,
+                       as_stream(stream), S, G, Q, acc, out);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+int beer_segment_sum(int dtype, int32_t nutt, const int64_t* frame_off, const void* v,
+                     double* out, void* stream) {
+    BEER_DISPATCH(dtype, segment_sum_launch, nutt, frame_off, v, out, stream);
+}
+
+}  // extern "C"

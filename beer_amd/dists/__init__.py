@@ -1,0 +1,4 @@
+'''Exponential-family priors / posteriors and their conjugate likelihoods.'''
+
+from .expfam import *
+from .families import *

@@ -1,0 +1,254 @@
+"""HMM topology: the Python graph builder and the compiled inference graph.
+
+API mirror of beer/graph.py (Graph 61-240, CompiledGraph 243-344).  Building
+and compiling a graph is host-side bookkeeping and stays in Python; inference
+(`posteriors`, `best_path`) runs the HIP kernels of beer_amd/csrc/hmm.hip on a
+CSR image of the transition matrix that `CompiledGraph` keeps on the device.
+"""
+
+import ctypes
+from collections import OrderedDict
+
+import torch
+
+from . import _hip
+
+__all__ = ['Graph', 'CompiledGraph']
+
+
+class State:
+    __slots__ = ('id', 'pdf_id')
+
+    def __init__(self, id, pdf_id):
+        self.id, self.pdf_id = id, pdf_id
+
+    def __repr__(self):
+        return f'State(id={self.id}, pdf_id={self.pdf_id})'
+
+
+class Arc:
+    'Weighted arc; identity (hash / equality) is the (start, end) pair.'
+    __slots__ = ('start', 'end', 'weight')
+
+    def __init__(self, start, end, weight=1.0):
+        self.start, self.end, self.weight = start, end, weight
+
+    def __hash__(self):
+        return hash((self.start, self.end))
+
+    def __eq__(self, other):
+        return (self.start, self.end) == (other.start, other.end)
+
+    def __repr__(self):
+        return f'Arc(start={self.start}, end={self.end}, weight={self.weight})'
+
+
+class Graph:
+    'Directed graph of emitting (pdf_id set) and non-emitting states.'
+
+    def __init__(self):
+        self._state_count = 0
+        self._states = OrderedDict()
+        self._arcs = set()
+        self.symbols = {}
+        self.start_state = None
+        self.end_state = None
+
+    def states(self):
+        return self._states.keys()
+
+    def state_from_id(self, state_id):
+        return self._states[state_id]
+
+    def arcs(self, state_id=None, incoming=False):
+        'All arcs, or the outgoing / incoming arcs of `state_id`.'
+        for arc in self._arcs:
+            if state_id is None or (arc.end if incoming else arc.start) == state_id:
+                yield arc
+
+    def add_state(self, pdf_id=None):
+        state_id = self._state_count
+        self._state_count += 1
+        self._states[state_id] = State(state_id, pdf_id)
+        return state_id
+
+    def add_arc(self, start, end, weight=1.0):
+        arc = Arc(start, end, weight)
+        self._arcs.add(arc)
+        return arc
+
+    def normalize(self):
+        'Make the outgoing weights of every state sum to one.'
+        for state_id in self.states():
+            out = list(self.arcs(state_id))
+            total = 0.
+            for arc in out:
+                total += arc.weight
+            for arc in out:
+                arc.weight /= total
+
+    def replace_state(self, old_state_id, graph):
+        'Substitute a whole (unit) graph for one state.'
+        new_ids = {}
+        for state_id in graph.states():
+            new_ids[state_id] = self.add_state(pdf_id=graph._states[state_id].pdf_id)
+        for arc in graph.arcs():
+            self.add_arc(new_ids[arc.start], new_ids[arc.end], arc.weight)
+        stale, fresh = [], []
+        for arc in self.arcs(old_state_id):
+            stale.append(arc)
+            fresh.append((new_ids[graph.end_state], arc.end, arc.weight))
+        for arc in self.arcs(old_state_id, incoming=True):
+            stale.append(arc)
+            fresh.append((arc.start, new_ids[graph.start_state], arc.weight))
+        for start, end, weight in fresh:
+            self.add_arc(start, end, weight)
+        for arc in stale:
+            self._arcs.remove(arc)
+        del self._states[old_state_id]
+
+    def _walk(self, start_state, init_weight, incoming):
+        'Follow non-emitting states until emitting ones; yields (state, weight).'
+        frontier = [(arc, init_weight) for arc in self.arcs(start_state, incoming=incoming)]
+        visited = {start_state}
+        while frontier:
+            arc, weight = frontier.pop()
+            nxt = arc.start if incoming else arc.end
+            if self._states[nxt].pdf_id is not None:
+                yield nxt, weight * arc.weight
+            elif nxt not in visited:
+                frontier += [(a, arc.weight * weight)
+                             for a in self.arcs(nxt, incoming=incoming)]
+                visited.add(nxt)
+
+    def find_next_pdf_ids(self, start_state, init_weight=1.0):
+        return self._walk(start_state, init_weight, incoming=False)
+
+    def find_previous_pdf_ids(self, start_state, init_weight=1.0):
+        return self._walk(start_state, init_weight, incoming=True)
+
+    def compile(self):
+        '''Remove the non-emitting states: initial / final / transition
+        probabilities between emitting states (graph.py:185-240), rows
+        renormalised without changing the self-loop probability.'''
+        index, pdf_id_mapping = {}, []
+        for state_id, state in self._states.items():
+            if state.pdf_id is not None:
+                index[state_id] = len(pdf_id_mapping)
+                pdf_id_mapping.append(state.pdf_id)
+        n = len(pdf_id_mapping)
+        init_probs, final_probs = torch.zeros(n), torch.zeros(n)
+        trans_probs = torch.zeros(n, n)
+        for state_id, weight in self.find_next_pdf_ids(self.start_state, 1.0):
+            init_probs[index[state_id]] += weight
+        init_probs /= init_probs.sum()
+        for state_id, weight in self.find_previous_pdf_ids(self.end_state, 1.0):
+            final_probs[index[state_id]] += weight
+        final_probs /= final_probs.sum()
+        for arc in self.arcs():
+            if self._states[arc.start].pdf_id is None:
+                continue                           # handled by init_probs
+            src = index[arc.start]
+            if self._states[arc.end].pdf_id is None:
+                for state_id, weight in self.find_next_pdf_ids(arc.end, arc.weight):
+                    trans_probs[src, index[state_id]] += weight
+            else:
+                trans_probs[src, index[arc.end]] += arc.weight
+        for i in range(n):
+            diag = trans_probs[i, i].clone()
+            off_diag = trans_probs[i, :].sum() - diag
+            if diag > 0. and off_diag > 0:
+                trans_probs[i, :] /= off_diag / (1 - diag)
+                trans_probs[i, i] = diag
+        return CompiledGraph(init_probs.log(), final_probs.log(), trans_probs.log(),
+                             pdf_id_mapping)
+
+
+class DeviceGraph:
+    'CSR image of a CompiledGraph in device memory + its beer_graph struct.'
+
+    def __init__(self, init, final, trans, device, dtype):
+        trans_h = trans.detach().to('cpu', torch.float64)
+        S = trans_h.shape[0]
+        finite = trans_h > -float('inf')
+        # by destination, sources ascending (Viterbi's first-index tie-break)
+        dst, src = torch.nonzero(finite.t(), as_tuple=True)
+        in_ptr = torch.zeros(S + 1, dtype=torch.int32)
+        in_ptr[1:] = torch.cumsum(torch.bincount(dst, minlength=S), 0).to(torch.int32)
+        in_w = trans.detach().to('cpu')[src, dst]
+        # by source, destinations ascending
+        src2, dst2 = torch.nonzero(finite, as_tuple=True)
+        out_ptr = torch.zeros(S + 1, dtype=torch.int32)
+        out_ptr[1:] = torch.cumsum(torch.bincount(src2, minlength=S), 0).to(torch.int32)
+        out_w = trans.detach().to('cpu')[src2, dst2]
+        self.n_states, self.n_arcs = S, int(src.numel())
+        self.bufs = dict(
+            init=init.detach().to(device, dtype).contiguous(),
+            final=final.detach().to(device, dtype).contiguous(),
+            in_ptr=in_ptr.to(device), in_src=src.to(torch.int32).to(device),
+            in_w=in_w.to(device, dtype).contiguous(),
+            out_ptr=out_ptr.to(device), out_dst=dst2.to(torch.int32).to(device),
+            out_w=out_w.to(device, dtype).contiguous())
+        b = self.bufs
+        self.struct = _hip.Graph(S, self.n_arcs, b['init'].data_ptr(), b['final'].data_ptr(),
+                                 b['in_ptr'].data_ptr(), b['in_src'].data_ptr(),
+                                 b['in_w'].data_ptr(), b['out_ptr'].data_ptr(),
+                                 b['out_dst'].data_ptr(), b['out_w'].data_ptr())
+
+
+class CompiledGraph(torch.nn.Module):
+    'Inference graph of an HMM: initial, final and transition log-probabilities.'
+
+    def __init__(self, init_log_probs, final_log_probs, trans_log_probs, pdf_id_mapping=None):
+        super().__init__()
+        self.register_buffer('init_log_probs', init_log_probs)
+        self.register_buffer('final_log_probs', final_log_probs)
+        self.register_buffer('trans_log_probs', trans_log_probs)
+        self.pdf_id_mapping = pdf_id_mapping
+
+    def __repr__(self):
+        return '<CompiledGraph>'
+
+    @property
+    def n_states(self):
+        return len(self.trans_log_probs)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop('_device_memo', None)
+        return state
+
+    def device_graph(self, dtype):
+        '''CSR copy on the GPU in `dtype`, rebuilt when a buffer is replaced
+        or written in place (PhoneLoop rewrites trans_log_probs after every
+        update, phoneloop.py:53-65).'''
+        tensors = (self.init_log_probs, self.final_log_probs, self.trans_log_probs)
+        sig = tuple(t._version for t in tensors)
+        memo = self.__dict__.get('_device_memo')
+        if memo is not None and memo[0] == dtype and memo[2] == sig and \
+                all(a is b for a, b in zip(memo[1], tensors)):
+            return memo[3]
+        dg = DeviceGraph(*tensors, device=_hip.require_device(), dtype=dtype)
+        self.__dict__['_device_memo'] = (dtype, tensors, sig, dg)
+        return dg
+
+    def posteriors(self, llhs, trans_posteriors=False):
+        '''State posteriors [N, K] (and, summed over time instead of the
+        reference's [N-1, K, K] tensor, transition posteriors [K, K]) from
+        per-frame, per-state log-likelihoods.  Returns (posteriors,
+        mean per-frame log-normaliser) like graph.py:289-326.'''
+        from .hmm_kernels import HmmBatch, forward_backward
+        batch = HmmBatch([self], [0], [len(llhs)], llhs.dtype, with_pdf_ids=False)
+        llhs_d = _hip.on_device(llhs)
+        gamma, xi_sum, _, lognorm = forward_backward(batch, llhs_d, want_xi=trans_posteriors,
+                                                     want_lognorm=True)
+        gamma = gamma.view(len(llhs), -1)
+        if trans_posteriors:
+            return (gamma, xi_sum.to(llhs.dtype)), lognorm[0]
+        return gamma, lognorm[0]
+
+    def best_path(self, llhs):
+        'Viterbi state path, int64 [N] (graph.py:329-344).'
+        from .hmm_kernels import HmmBatch, viterbi
+        batch = HmmBatch([self], [0], [len(llhs)], llhs.dtype, with_pdf_ids=False)
+        return viterbi(batch, _hip.on_device(llhs), map_pdf=False)

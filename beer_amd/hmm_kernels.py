@@ -1,0 +1,171 @@
+"""Python faces of the HMM entry points of include/beer_hip.h: ragged-batch
+descriptors, pdf-id gather / scatter, forward-backward, Viterbi."""
+
+import ctypes
+
+import torch
+
+from . import _hip
+
+__all__ = ['HmmBatch', 'gather', 'forward_backward', 'viterbi', 'path_posteriors',
+           'scatter', 'gather_columns', 'scatter_columns', 'segment_sum']
+
+
+class HmmBatch:
+    '''beer_batch descriptor: `graphs` are the distinct CompiledGraph objects
+    of the batch, `graph_ids[u]` the one utterance u uses, `lengths[u]` its
+    number of frames.  Packed per-state buffers hold utterance u at element
+    offset `llh_off[u]` as a row-major [T_u, S_u] block.'''
+
+    def __init__(self, graphs, graph_ids, lengths, dtype, with_pdf_ids=True):
+        dev = _hip.require_device()
+        self.dtype, self.device = dtype, dev
+        self.nutt = len(lengths)
+        self.dgraphs = [g.device_graph(dtype) for g in graphs]
+        n_states = [dg.n_states for dg in self.dgraphs]
+        lengths_t = torch.as_tensor(lengths, dtype=torch.int64)
+        gid_t = torch.as_tensor(graph_ids, dtype=torch.int64)
+        states_t = torch.as_tensor(n_states, dtype=torch.int64)[gid_t] \
+            if self.nutt else torch.zeros(0, dtype=torch.int64)
+        frame_off = torch.zeros(self.nutt + 1, dtype=torch.int64)
+        frame_off[1:] = torch.cumsum(lengths_t, 0)
+        sizes = lengths_t * states_t
+        llh_off = torch.zeros(self.nutt + 1, dtype=torch.int64)
+        llh_off[1:] = torch.cumsum(sizes, 0)
+        self.n_frames = int(frame_off[-1])
+        self.n_elems = int(llh_off[-1])
+        self.frame_off_h, self.llh_off_h = frame_off, llh_off
+        self.n_states = n_states
+        self.graph_ids = list(graph_ids)
+        pdf_off = [0]
+        pdf_ids = []
+        for g in graphs:
+            ids = list(g.pdf_id_mapping) if (with_pdf_ids and g.pdf_id_mapping is not None) \
+                else list(range(g.n_states))
+            pdf_ids += [int(i) for i in ids]
+            pdf_off.append(len(pdf_ids))
+        arr = (_hip.Graph * len(graphs))(*[dg.struct for dg in self.dgraphs])
+        self.bufs = dict(
+            frame_off=frame_off.to(dev), llh_off=llh_off[:-1].contiguous().to(dev),
+            graph_id=gid_t.to(torch.int32).to(dev),
+            graphs=_hip.struct_to_device(arr, dev),
+            pdf_off=torch.as_tensor(pdf_off, dtype=torch.int32).to(dev),
+            pdf_ids=torch.as_tensor(pdf_ids, dtype=torch.int32).to(dev))
+        b = self.bufs
+        self.struct = _hip.Batch(
+            self.nutt, max(n_states) if n_states else 1,
+            max([dg.n_arcs for dg in self.dgraphs] + [1]), len(graphs),
+            b['frame_off'].data_ptr(), b['llh_off'].data_ptr(), b['graph_id'].data_ptr(),
+            b['graphs'].data_ptr(), b['pdf_off'].data_ptr(), b['pdf_ids'].data_ptr())
+        self.shared_graph = len(graphs) == 1
+
+    def ref(self):
+        return ctypes.byref(self.struct)
+
+
+def gather(batch, pc_all, scale=1.):
+    'pc_llhs (packed, [n_elems]) = scale * pc_all[frame, pdf_id].'
+    pc_all = _hip.on_device(pc_all, batch.dtype)
+    out = torch.empty(batch.n_elems, dtype=batch.dtype, device=batch.device)
+    _hip.call('beer_hmm_gather', _hip.dtype_code(batch.dtype), batch.ref(), pc_all.shape[1],
+              _hip.ptr(pc_all), float(scale), _hip.ptr(out))
+    return out
+
+
+def forward_backward(batch, pc_llhs, want_xi=False, want_lognorm=False):
+    '''(gamma packed, xi_sum [S,S] fp64 or None, gamma0_sum [S] fp64 or None,
+    lognorm_mean [nutt] or None).  xi / gamma0 need a batch sharing one graph.'''
+    dt, dev = batch.dtype, batch.device
+    gamma = torch.empty(batch.n_elems, dtype=dt, device=dev)
+    alpha = torch.empty(batch.n_elems, dtype=torch.float64, device=dev)
+    xi = g0 = ln = None
+    if want_xi:
+        if not batch.shared_graph:
+            raise ValueError('transition posteriors need one graph for the whole batch')
+        S = batch.n_states[0]
+        xi = torch.zeros(S, S, dtype=torch.float64, device=dev)
+        g0 = torch.zeros(S, dtype=torch.float64, device=dev)
+    if want_lognorm:
+        ln = torch.empty(batch.nutt, dtype=dt, device=dev)
+    _hip.call('beer_hmm_forward_backward', _hip.dtype_code(dt), batch.ref(),
+              _hip.ptr(pc_llhs), _hip.ptr(alpha), _hip.ptr(gamma), _hip.ptr(xi),
+              _hip.ptr(g0), _hip.ptr(ln))
+    return gamma, xi, g0, ln
+
+
+def viterbi(batch, pc_llhs, map_pdf=False):
+    'int64 state (or pdf id) path for every frame of the batch.'
+    bt = torch.empty(batch.n_elems, dtype=torch.int32, device=batch.device)
+    path = torch.empty(batch.n_frames, dtype=torch.int64, device=batch.device)
+    _hip.call('beer_hmm_viterbi', _hip.dtype_code(batch.dtype), batch.ref(),
+              _hip.ptr(pc_llhs), _hip.ptr(bt), _hip.ptr(path), 1 if map_pdf else 0)
+    return path
+
+
+def path_posteriors(batch, path, want_xi=False):
+    dt, dev = batch.dtype, batch.device
+    path = _hip.on_device(torch.as_tensor(path)).to(torch.int64).contiguous()
+    gamma = torch.empty(batch.n_elems, dtype=dt, device=dev)
+    xi = g0 = None
+    if want_xi:
+        S = batch.n_states[0]
+        xi = torch.zeros(S, S, dtype=torch.float64, device=dev)
+        g0 = torch.zeros(S, dtype=torch.float64, device=dev)
+    _hip.call('beer_hmm_path_posteriors', _hip.dtype_code(dt), batch.ref(), _hip.ptr(path),
+              _hip.ptr(gamma), _hip.ptr(xi), _hip.ptr(g0))
+    return gamma, xi, g0
+
+
+def scatter(batch, pc_llhs, gamma, S_total, scale=1., want_resps=True, want_exp_llh=True,
+            utt_llh=None):
+    '(state_resps [n_frames, S_total] or None, exp_llh [n_frames] or None).'
+    dt, dev = batch.dtype, batch.device
+    sr = torch.zeros(batch.n_frames, S_total, dtype=dt, device=dev) if want_resps else None
+    el = torch.empty(batch.n_frames, dtype=dt, device=dev) if want_exp_llh else None
+    _hip.call('beer_hmm_scatter', _hip.dtype_code(dt), batch.ref(), S_total,
+              _hip.ptr(pc_llhs), _hip.ptr(gamma), float(scale), _hip.ptr(sr), _hip.ptr(el),
+              _hip.ptr(utt_llh))
+    return sr, el
+
+
+def segment_sum(values, frame_off_dev, nutt, out=None):
+    'out[u] += sum of values over the frames of utterance u (fp64).'
+    values = values.contiguous()
+    if out is None:
+        out = torch.zeros(nutt, dtype=torch.float64, device=values.device)
+    _hip.call('beer_segment_sum', _hip.dtype_code(values.dtype), nutt,
+              _hip.ptr(frame_off_dev), _hip.ptr(values), _hip.ptr(out))
+    return out
+
+
+class _Columns:
+    'Minimal stand-in for a graph: only n_states / pdf ids matter for gather.'
+
+    def __init__(self, order):
+        self.pdf_id_mapping = [int(i) for i in order]
+        self.n_states = len(self.pdf_id_mapping)
+        self._dg = None
+
+    def device_graph(self, dtype):
+        if self._dg is None:
+            self._dg = type('DG', (), {})()
+            self._dg.n_states, self._dg.n_arcs = self.n_states, 0
+            self._dg.struct = _hip.Graph(self.n_states, 0, None, None, None, None, None,
+                                         None, None, None)
+        return self._dg
+
+
+def gather_columns(matrix, order):
+    'matrix[:, order] on the GPU (modelset.py:140-146).'
+    matrix = _hip.on_device(matrix)
+    batch = HmmBatch([_Columns(order)], [0], [matrix.shape[0]], matrix.dtype)
+    return gather(batch, matrix, 1.).view(matrix.shape[0], len(order))
+
+
+def scatter_columns(resps, order, n_total):
+    'out[:, order[i]] += resps[:, i] (repeated ids add, modelset.py:148-154).'
+    resps = _hip.on_device(resps)
+    batch = HmmBatch([_Columns(order)], [0], [resps.shape[0]], resps.dtype)
+    flat = resps.reshape(-1)
+    sr, _ = scatter(batch, flat, flat, n_total, 1., want_exp_llh=False)
+    return sr

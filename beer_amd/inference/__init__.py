@@ -1,0 +1,3 @@
+from .objectives import *
+from .optimizers import *
+from .batch import *

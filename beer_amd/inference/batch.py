@@ -1,0 +1,294 @@
+"""Batched E-step: the MI355X-first counterpart of the reference's
+per-utterance accumulation loop.
+
+The reference's data-parallel "map" step (`beer hmm accumulate`,
+beer/cli/subcommands/hmm/accumulate.py:39-59) calls `evidence_lower_bound`
+once per utterance -- a Python loop over ~300-frame utterances with tens of
+torch ops each.  `accumulate_elbo` does the same work for a whole shard in a
+handful of kernel launches over a ragged batch and returns the SAME object the
+loop would have produced:
+
+    elbo = evidence_lower_bound(datasize=N)
+    for utt in shard:
+        elbo += evidence_lower_bound(model, utt, datasize=N, ...)
+
+i.e. value = sum_u (N / T_u) sum_t l_ut - U * KL(q || p)   (quirk Q1),
+acc_stats = sum_u acc_u, minibatchsize = sum_u T_u.  The KL term is computed
+once.  Sufficient statistics are accumulated in fp64 across the whole shard.
+"""
+
+import torch
+
+from .. import _hip, hmm_kernels as hk, kernels
+from ..models.gaussians import NormalSet
+from ..models.mixtures import Mixture, MixtureSet
+from ..models.modelset import JointModelSet
+from ..models.sequence import HMM, PhoneLoop
+from ..models.weights import SBCategorical
+from ..stats import FrameStats
+from .objectives import EvidenceLowerBoundInstance
+
+__all__ = ['accumulate_elbo', 'pack_utterances', 'decode_batch']
+
+# Responsibilities [frames, K] are the largest scratch buffer; bound it.
+_SCRATCH_BYTES = 6 << 30
+
+
+def pack_utterances(utterances):
+    '''(X [sum T_u, D] on the GPU, lengths list).  Accepts a list of [T_u, D]
+    tensors or an already packed `(X, lengths)` pair.'''
+    if isinstance(utterances, tuple) and len(utterances) == 2 and \
+            isinstance(utterances[0], torch.Tensor):
+        X, lengths = utterances
+        return _hip.on_device(X), [int(n) for n in lengths]
+    utterances = list(utterances)
+    lengths = [len(u) for u in utterances]
+    dev = _hip.require_device()
+    X = torch.cat([u.to(dev) for u in utterances], dim=0).contiguous()
+    return X, lengths
+
+
+def _groups(emissions):
+    'Flatten an emission model into [(MixtureSet | NormalSet, S, G)].'
+    if isinstance(emissions, JointModelSet):
+        out = []
+        for m in emissions.modelsets:
+            out += _groups(m)
+        return out
+    if isinstance(emissions, MixtureSet):
+        if not isinstance(emissions.modelset, NormalSet):
+            raise NotImplementedError('MixtureSet components must be a NormalSet')
+        return [(emissions, len(emissions), emissions.n_comp_per_mixture)]
+    if isinstance(emissions, NormalSet):
+        return [(emissions, len(emissions), 1)]
+    raise NotImplementedError(f'unsupported emission model {type(emissions).__name__}')
+
+
+def _normalset(group):
+    return group.modelset if isinstance(group, MixtureSet) else group
+
+
+def _sub_batches(lengths, bytes_per_frame, max_frames):
+    'Split utterance indices into runs whose scratch fits the budget.'
+    budget = max(1, min(max_frames, _SCRATCH_BYTES // max(1, bytes_per_frame)))
+    runs, cur, n = [], [], 0
+    for u, T in enumerate(lengths):
+        if cur and n + T > budget:
+            runs.append(cur)
+            cur, n = [], 0
+        cur.append(u)
+        n += T
+    if cur:
+        runs.append(cur)
+    return runs
+
+
+def _finish(model, value_terms, kl, nutt, acc, datasize, total_frames):
+    value = value_terms - float(nutt) * kl.to(value_terms.device, torch.float64)
+    return EvidenceLowerBoundInstance(value, acc, model.bayesian_parameters(),
+                                      total_frames, datasize)
+
+
+def _like(param, t):
+    return t.to(dtype=param.stats.dtype, device=param.stats.device)
+
+
+def _mixture_batch(model, X, lengths, datasize, labels, max_frames):
+    ns = model.modelset
+    K, cov = len(ns), ns.cov_type
+    dev, dtype = X.device, X.dtype
+    exp_T = ns.means_precisions.natural_form()
+    lw = model._log_weights().view(1, K)
+    Q = FrameStats(X[:1], cov).shape[1]
+    acc = torch.zeros(K, Q, dtype=torch.float64, device=dev)
+    utt_llh = torch.zeros(len(lengths), dtype=torch.float64, device=dev)
+    off = torch.zeros(len(lengths) + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(torch.as_tensor(lengths, dtype=torch.int64), 0)
+    for run in _sub_batches(lengths, K * X.element_size(), max_frames):
+        f0, f1 = int(off[run[0]]), int(off[run[-1] + 1])
+        stats = FrameStats(X[f0:f1], cov)
+        lab = None if labels is None else labels[f0:f1]
+        log_norm, resps = kernels.mixtureset_estep(stats, exp_T, lw, 1, K, cov, labels=lab)
+        seg = (off[run[0]:run[-1] + 2] - f0).to(dev)
+        hk.segment_sum(log_norm.view(-1), seg, len(run), out=utt_llh[run[0]:run[-1] + 1])
+        kernels.normal_accumulate(stats, resps, None, K, 1, cov, acc=acc)
+    scales = torch.as_tensor([datasize / float(T) for T in lengths], dtype=torch.float64,
+                             device=dev)
+    value_terms = (scales * utt_llh).sum()
+    wparam = model.categorical.mean_field_factorization()[0][0]
+    if isinstance(model.categorical, SBCategorical):
+        wacc = -2. * acc[:, -2]
+    else:
+        wacc = kernels.weights_from_acc(acc, 1, K).view(-1)
+    out = {wparam: _like(wparam, wacc), ns.means_precisions: _like(ns.means_precisions, acc)}
+    return value_terms, out
+
+
+def _emission_estep(groups, stats, dtype):
+    'pc_all [T, S_total] + per-group component responsibilities.'
+    cols, comps = [], []
+    for grp, S, G in groups:
+        ns = _normalset(grp)
+        lw = grp._log_weights() if isinstance(grp, MixtureSet) else None
+        log_norm, resps = kernels.mixtureset_estep(
+            stats, ns.means_precisions.natural_form(), lw, S, G, ns.cov_type,
+            want_resps=False)
+        cols.append(log_norm)
+        comps.append(resps)
+    pc_all = cols[0] if len(cols) == 1 else torch.cat(cols, dim=-1)
+    return pc_all, comps
+
+
+def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths, max_frames):
+    emissions = model._emissions()
+    groups = _groups(emissions)
+    S_total = sum(S for _, S, _ in groups)
+    K_max = sum(S * G for _, S, G in groups)
+    dev, dtype = X.device, X.dtype
+    free_loop = graphs is None
+    accs = []
+    for grp, S, G in groups:
+        ns = _normalset(grp)
+        Q = FrameStats(X[:1], ns.cov_type).shape[1]
+        accs.append(torch.zeros(S * G, Q, dtype=torch.float64, device=dev))
+    nutt = len(lengths)
+    utt_llh = torch.zeros(nutt, dtype=torch.float64, device=dev)
+    off = torch.zeros(nutt + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(torch.as_tensor(lengths, dtype=torch.int64), 0)
+    xi_tot = g0_tot = None
+    max_S = model.graph.n_states if free_loop else max(g.n_states for g in graphs)
+    bpf = (K_max + 2 * S_total) * X.element_size() + max_S * (3 * X.element_size() + 8)
+    for run in _sub_batches(lengths, bpf, max_frames):
+        f0, f1 = int(off[run[0]]), int(off[run[-1] + 1])
+        run_lengths = [lengths[u] for u in run]
+        stats = FrameStats(X[f0:f1], _normalset(groups[0][0]).cov_type)
+        pc_all, comps = _emission_estep(groups, stats, dtype)
+        if free_loop:
+            batch = hk.HmmBatch([model.graph], [0] * len(run), run_lengths, dtype)
+        else:
+            uniq, ids, seen = [], [], {}
+            for u in run:
+                g = graphs[u]
+                if id(g) not in seen:
+                    seen[id(g)] = len(uniq)
+                    uniq.append(g)
+                ids.append(seen[id(g)])
+            batch = hk.HmmBatch(uniq, ids, run_lengths, dtype)
+        pc_llhs = hk.gather(batch, pc_all, scale)
+        if viterbi or state_paths is not None:
+            if state_paths is None:
+                path = hk.viterbi(batch, pc_llhs)
+            else:
+                path = torch.cat([torch.as_tensor(state_paths[u]).reshape(-1) for u in run])
+            gamma, xi, g0 = hk.path_posteriors(batch, path, want_xi=free_loop)
+        else:
+            gamma, xi, g0, _ = hk.forward_backward(batch, pc_llhs, want_xi=free_loop)
+        if free_loop:
+            xi_tot = xi if xi_tot is None else xi_tot + xi
+            g0_tot = g0 if g0_tot is None else g0_tot + g0
+        sr, _ = hk.scatter(batch, pc_llhs, gamma, S_total, scale, want_exp_llh=False,
+                           utt_llh=utt_llh[run[0]:run[-1] + 1])
+        first = 0
+        for (grp, S, G), comp, acc in zip(groups, comps, accs):
+            ns = _normalset(grp)
+            sr_g = sr if len(groups) == 1 else sr[:, first:first + S].contiguous()
+            first += S
+            gstats = FrameStats(X[f0:f1], ns.cov_type)
+            if G == 1:
+                kernels.normal_accumulate(gstats, sr_g, None, S, 1, ns.cov_type, acc=acc)
+            else:
+                kernels.normal_accumulate(gstats, comp, sr_g, S, G, ns.cov_type, acc=acc)
+    scales = torch.as_tensor([datasize / float(T) for T in lengths], dtype=torch.float64,
+                             device=dev)
+    value_terms = (scales * utt_llh).sum()
+    out = {}
+    for (grp, S, G), acc in zip(groups, accs):
+        ns = _normalset(grp)
+        out[ns.means_precisions] = _like(ns.means_precisions, acc)
+        if isinstance(grp, MixtureSet):
+            wparam = grp.categoricalset.weights
+            out[wparam] = _like(wparam, kernels.weights_from_acc(acc, S, G))
+    if isinstance(model, PhoneLoop):
+        wparam = model.categorical.mean_field_factorization()[0][0]
+        ref = wparam.stats
+        if free_loop:
+            counts = model.phone_counts(xi_tot, g0_tot).to(dtype=ref.dtype, device=ref.device)
+            # per-utterance `sufficient_statistics` (last <- sum) then sum over
+            # utterances == the same map applied to the summed counts.
+            cstats = model.categorical.sufficient_statistics(counts.view(1, -1))
+            out.update(model.categorical.accumulate(cstats))
+        else:
+            fake = torch.zeros(len(model.start_pdf), dtype=ref.dtype, device=ref.device)
+            out.update(model.categorical.accumulate(fake[None, :]))
+    return value_terms, out
+
+
+def accumulate_elbo(model, utterances, datasize=-1, inference_graphs=None, scale=1.,
+                    viterbi=False, state_paths=None, labels=None, max_frames=1 << 20):
+    '''ELBO + accumulated statistics of a shard of utterances, identical to the
+    sum of per-utterance `evidence_lower_bound(model, utt, datasize=datasize,
+    inference_graph=..., scale=..., viterbi=...)` calls.
+
+    Args:
+        model: `Mixture`, `HMM` or `PhoneLoop`.
+        utterances: list of [T_u, D] tensors, or `(X_packed, lengths)`.
+        datasize: frames in the whole training set (<= 0: this shard).
+        inference_graphs: optional list of per-utterance `CompiledGraph`
+            (alignment graphs); None = the model's own graph.
+        scale: acoustic scale (HMM only).
+        viterbi / state_paths: hard-alignment training branches (HMM only).
+        labels: optional int64 [sum T_u] component labels (Mixture only).
+    '''
+    X, lengths = pack_utterances(utterances)
+    if any(T <= 0 for T in lengths):
+        raise ValueError('empty utterance in the batch')
+    total = sum(lengths)
+    if datasize <= 0:
+        datasize = total
+    if len(lengths) == 0:
+        return EvidenceLowerBoundInstance(0., {}, [], 0, datasize)
+    kl = torch.as_tensor(model.kl_div_posterior_prior())
+    if isinstance(model, Mixture):
+        value_terms, acc = _mixture_batch(model, X, lengths, datasize, labels, max_frames)
+    elif isinstance(model, HMM):
+        value_terms, acc = _hmm_batch(model, X, lengths, datasize, inference_graphs, scale,
+                                      viterbi, state_paths, max_frames)
+    else:
+        raise NotImplementedError(f'no batched E-step for {type(model).__name__}')
+    model.clear_cache()
+    return _finish(model, value_terms, kl, len(lengths), acc, datasize, total)
+
+
+def decode_batch(model, utterances, inference_graphs=None, scale=1., max_frames=1 << 20):
+    '''Viterbi pdf-id paths for a shard: list of int64 tensors, one per
+    utterance (`HMM.decode`, beer/models/hmm.py:105-114, batched).'''
+    X, lengths = pack_utterances(utterances)
+    groups = _groups(model._emissions())
+    S_total = sum(S for _, S, _ in groups)
+    K_max = sum(S * G for _, S, G in groups)
+    off = [0]
+    for T in lengths:
+        off.append(off[-1] + T)
+    paths = []
+    max_S = model.graph.n_states if inference_graphs is None \
+        else max(g.n_states for g in inference_graphs)
+    bpf = (K_max + S_total) * X.element_size() + max_S * (X.element_size() + 4)
+    for run in _sub_batches(lengths, bpf, max_frames):
+        f0, f1 = off[run[0]], off[run[-1] + 1]
+        stats = FrameStats(X[f0:f1], _normalset(groups[0][0]).cov_type)
+        pc_all, _ = _emission_estep(groups, stats, X.dtype)
+        run_lengths = [lengths[u] for u in run]
+        if inference_graphs is None:
+            batch = hk.HmmBatch([model.graph], [0] * len(run), run_lengths, X.dtype)
+        else:
+            uniq, ids, seen = [], [], {}
+            for u in run:
+                g = inference_graphs[u]
+                if id(g) not in seen:
+                    seen[id(g)] = len(uniq)
+                    uniq.append(g)
+                ids.append(seen[id(g)])
+            batch = hk.HmmBatch(uniq, ids, run_lengths, X.dtype)
+        path = hk.viterbi(batch, hk.gather(batch, pc_all, scale), map_pdf=True)
+        paths += list(torch.split(path, run_lengths))
+    return paths

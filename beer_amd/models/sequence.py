@@ -1,0 +1,170 @@
+"""HMM and PhoneLoop.
+
+API mirror of beer/models/hmm.py:13-121 and beer/models/phoneloop.py:13-101.
+The per-utterance methods below drive the same ragged-batch kernels as the
+batched accumulator (beer_amd/inference/batch.py) with a batch of one.
+"""
+
+import torch
+
+from .. import _hip, hmm_kernels as hk
+from .basemodel import DiscreteLatentModel
+from .modelset import DynamicallyOrderedModelSet
+from .weights import Categorical, SBCategorical
+
+__all__ = ['HMM', 'PhoneLoop']
+
+
+class HMM(DiscreteLatentModel):
+    'Hidden Markov Model with fixed transition probabilities.'
+
+    @classmethod
+    def create(cls, graph, modelset):
+        return cls(graph, modelset)
+
+    def __init__(self, graph, modelset):
+        super().__init__(DynamicallyOrderedModelSet(modelset))
+        self.graph = graph
+
+    # -- helpers ---------------------------------------------------------------
+    def _emissions(self):
+        return self.modelset.original_modelset
+
+    def _pc_llhs(self, stats, inference_graph):
+        order = inference_graph.pdf_id_mapping
+        return self.modelset.expected_log_likelihood(stats, order)
+
+    def _batch_of_one(self, graph, n_frames, dtype):
+        return hk.HmmBatch([graph], [0], [n_frames], dtype)
+
+    def _inference(self, pc_llhs, inference_graph, viterbi=False, state_path=None,
+                   trans_posteriors=False):
+        '''State posteriors (+ summed transition posteriors) from per-state
+        log-likelihoods [T, S]; hmm.py:40-62.'''
+        pc = _hip.on_device(pc_llhs)
+        batch = self._batch_of_one(inference_graph, len(pc), pc.dtype)
+        flat = pc.reshape(-1)
+        if viterbi or state_path is not None:
+            path = hk.viterbi(batch, flat) if state_path is None else state_path
+            gamma, xi, g0 = hk.path_posteriors(batch, path, want_xi=trans_posteriors)
+        else:
+            gamma, xi, g0, _ = hk.forward_backward(batch, flat, want_xi=trans_posteriors)
+        gamma = gamma.view(len(pc), -1)
+        return ((gamma, xi) if trans_posteriors else gamma), None
+
+    # -- Model interface ---------------------------------------------------------
+    def mean_field_factorization(self):
+        return self.modelset.mean_field_factorization()
+
+    def sufficient_statistics(self, data):
+        return self.modelset.sufficient_statistics(data)
+
+    def expected_log_likelihood(self, stats, inference_graph=None, viterbi=False,
+                                state_path=None, scale=1.):
+        '''sum_s gamma_ts * scale * l_ts per frame (hmm.py:73-92).  Without an
+        inference graph the model's own graph is used and the transition
+        posteriors are kept (PhoneLoop needs them).'''
+        trans_posts = inference_graph is None
+        graph = self.graph if inference_graph is None else inference_graph
+        pc_all = self._emissions().expected_log_likelihood(stats)      # [T, S_total]
+        self.modelset.cache['order'] = graph.pdf_id_mapping
+        T, S_total = pc_all.shape
+        batch = self._batch_of_one(graph, T, pc_all.dtype)
+        pc_llhs = hk.gather(batch, pc_all, scale)
+        if viterbi or state_path is not None:
+            path = hk.viterbi(batch, pc_llhs) if state_path is None else state_path
+            gamma, xi, g0 = hk.path_posteriors(batch, path, want_xi=trans_posts)
+        else:
+            gamma, xi, g0, _ = hk.forward_backward(batch, pc_llhs, want_xi=trans_posts)
+        state_resps, exp_llh = hk.scatter(batch, pc_llhs, gamma, S_total, scale)
+        self.cache['resps'] = gamma.view(T, -1)
+        if trans_posts:
+            self.cache['trans_resps'] = xi          # summed over time: [S, S]
+        self.cache['scaled_pdf_resps'] = state_resps
+        self.cache['scale'] = scale
+        return exp_llh
+
+    def accumulate(self, stats, parent_msg=None):
+        # scale * resps scattered back to pdf ids was produced with the E-step.
+        return {**self._emissions().accumulate(stats, self.cache['scaled_pdf_resps'])}
+
+    # -- DiscreteLatentModel interface ------------------------------------------------
+    def decode(self, data, inference_graph=None, scale=1.):
+        'Viterbi path mapped to pdf ids, LongTensor on the host (hmm.py:105-114).'
+        graph = self.graph if inference_graph is None else inference_graph
+        stats = self.sufficient_statistics(data)
+        pc_all = self._emissions().expected_log_likelihood(stats)
+        batch = self._batch_of_one(graph, len(stats), pc_all.dtype)
+        pc_llhs = hk.gather(batch, pc_all, scale)
+        return hk.viterbi(batch, pc_llhs, map_pdf=True).cpu()
+
+    def posteriors(self, data, inference_graph=None, scale=1.0):
+        'State posteriors; `scale` multiplies the statistics (hmm.py:116-121).'
+        graph = self.graph if inference_graph is None else inference_graph
+        stats = self.modelset.sufficient_statistics(data) * scale
+        pc_all = self._emissions().expected_log_likelihood(stats)
+        batch = self._batch_of_one(graph, len(stats), pc_all.dtype)
+        gamma, _, _, _ = hk.forward_backward(batch, hk.gather(batch, pc_all, 1.))
+        return gamma.view(len(stats), -1)
+
+
+class PhoneLoop(HMM):
+    'Phone-loop HMM with a prior over the phone (unigram) weights.'
+
+    @classmethod
+    def create(cls, graph, start_pdf, end_pdf, modelset, categorical=None,
+               prior_strength=1.0):
+        tensor = modelset.mean_field_factorization()[0][0].prior._tensors()[0]
+        if categorical is None:
+            weights = torch.ones(len(start_pdf), dtype=tensor.dtype, device=tensor.device)
+            weights /= len(start_pdf)
+            categorical = Categorical.create(weights, prior_strength)
+        return cls(graph, modelset, start_pdf, end_pdf, categorical)
+
+    def __init__(self, graph, modelset, start_pdf, end_pdf, categorical):
+        super().__init__(graph, modelset)
+        self.start_pdf = start_pdf
+        self.end_pdf = end_pdf
+        self.categorical = categorical
+        param = self.categorical.mean_field_factorization()[0][0]
+        param.register_callback(self._on_weights_update)
+        self._on_weights_update()
+
+    def _on_weights_update(self):
+        '''Rewrite the phone-exit transitions with E[ln w] (phoneloop.py:53-65).
+        Host-side callback over P x P entries; the CSR copy on the device is
+        rebuilt at the next inference (CompiledGraph.device_graph).'''
+        trans = self.graph.trans_log_probs
+        log_weights = self.categorical.log_weights().to(dtype=trans.dtype,
+                                                        device=trans.device)
+        start_idxs = list(self.start_pdf.values())
+        for end_idx in self.end_pdf.values():
+            loop_prob = trans[end_idx, end_idx].exp()
+            trans[end_idx, start_idxs] = (1 - loop_prob).log() + log_weights
+
+    def mean_field_factorization(self):
+        from .mixtures import _merge_groups
+        return _merge_groups(self.modelset.mean_field_factorization(),
+                             self.categorical.mean_field_factorization())
+
+    def phone_counts(self, xi_sum, gamma0):
+        'sum_t xi_t[ends, starts] summed over ends + gamma_0[starts] (88-95).'
+        start_idxs = list(self.start_pdf.values())
+        end_idxs = list(self.end_pdf.values())
+        counts = xi_sum[:, start_idxs][end_idxs, :].sum(dim=0)
+        return counts + gamma0[start_idxs].to(counts.dtype)
+
+    def accumulate(self, stats, parent_msg=None):
+        retval = super().accumulate(stats, parent_msg)
+        wparam = self.categorical.mean_field_factorization()[0][0]
+        ref = wparam.stats
+        if 'trans_resps' in self.cache:
+            counts = self.phone_counts(self.cache['trans_resps'], self.cache['resps'][0])
+            counts = counts.to(dtype=ref.dtype, device=ref.device)
+            resps_stats = self.categorical.sufficient_statistics(counts.view(1, -1))
+            retval.update(self.categorical.accumulate(resps_stats))
+        else:
+            # trained with forced alignments: the phone weights get no counts
+            fake = torch.zeros(len(self.start_pdf), dtype=ref.dtype, device=ref.device)
+            retval.update(self.categorical.accumulate(fake[None, :]))
+        return retval

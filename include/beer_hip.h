@@ -1,0 +1,297 @@
+/*
+ * beer_hip.h -- C ABI of the MI355X (gfx950) implementation of beer's
+ * variational-Bayes hot path.
+ *
+ * The reference (beer-asr/beer) is pure Python on torch and has no FFI of its
+ * own; the seam is its Python `Model` protocol.  Every
+ * entry point below names the reference function it replaces (paths relative
+ * to the reference root).  The Python host layer `beer_amd` binds these with
+ * ctypes (beer_amd/_hip.py); INTEGRATION.md shows the stub a maintainer of
+ * the reference would add to call them from beer itself.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch is only
+ *     the allocator) unless the name ends in `_h` (host);
+ *   - `dtype`: BEER_F32 / BEER_F64 is the element type of every `void*`
+ *     floating-point buffer of the call; `double*` buffers are always fp64
+ *     (cross-frame accumulators are fp64 whatever the model dtype is);
+ *   - matrices are row-major and dense, no padding;
+ *   - `stream` is a hipStream_t (0 = default stream); calls are asynchronous,
+ *     never synchronise, never allocate, keep no global state and are
+ *     re-entrant per stream;
+ *   - return value: 0 on success, BEER_EINVAL for a bad argument, or
+ *     -(hipError_t) if a launch failed.  Nothing throws.
+ *   - `cov`: BEER_FULL / BEER_DIAG / BEER_ISO selects the layout of the
+ *     sufficient statistics, Q = D*D+D+2 | 2D+2 | D+3
+ *     (beer/dists/normalwishart.py:30-38, normalgamma.py:20-27,
+ *     isonormalgamma.py:21-30).
+ */
+#ifndef BEER_HIP_H
+#define BEER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEER_F32 0
+#define BEER_F64 1
+
+#define BEER_FULL 0
+#define BEER_DIAG 1
+#define BEER_ISO 2
+
+#define BEER_OK 0
+#define BEER_EINVAL (-100000)
+
+/* Library / device probes (no reference counterpart). */
+int beer_hip_version(void);
+int beer_hip_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * Exponential-family parameter kernels (once per VB iteration, K = number of
+ * distributions in the set, D = feature dimension).
+ * ---------------------------------------------------------------------- */
+
+/* E_q[T(theta)], the "natural form" every E-step consumes.
+ * Replaces NormalWishart.expected_sufficient_statistics
+ * (beer/dists/normalwishart.py:170-210) reached through
+ * ConjugateBayesianParameter.natural_form (beer/models/parameters.py:131-132).
+ * mean [K,D], scale [K], scale_matrix [K,D,D], dof [K] -> out [K, D*D+D+2]. */
+int beer_nw_expected_stats(int dtype, int K, int D, const void* mean,
+                           const void* scale, const void* scale_matrix,
+                           const void* dof, void* out, void* stream);
+/* NormalWishart.log_norm (normalwishart.py:219-236) -> out [K]. */
+int beer_nw_log_norm(int dtype, int K, int D, const void* mean,
+                     const void* scale, const void* scale_matrix,
+                     const void* dof, void* out, void* stream);
+/* NormalWishart.natural_parameters (normalwishart.py:242-269) -> [K,Q]. */
+int beer_nw_natural(int dtype, int K, int D, const void* mean,
+                    const void* scale, const void* scale_matrix,
+                    const void* dof, void* out, void* stream);
+/* NormalWishartStdParams.from_natural_parameters (normalwishart.py:110-141). */
+int beer_nw_from_natural(int dtype, int K, int D, const void* eta, void* mean,
+                         void* scale, void* scale_matrix, void* dof,
+                         void* stream);
+
+/* NormalGamma (diagonal covariance), beer/dists/normalgamma.py:118-146,
+ * 151-157, 163-180, 77-94.  mean [K,D], scale [K], shape [K], rates [K,D]. */
+int beer_ng_expected_stats(int dtype, int K, int D, const void* mean,
+                           const void* scale, const void* shape,
+                           const void* rates, void* out, void* stream);
+int beer_ng_log_norm(int dtype, int K, int D, const void* mean,
+                     const void* scale, const void* shape, const void* rates,
+                     void* out, void* stream);
+int beer_ng_natural(int dtype, int K, int D, const void* mean,
+                    const void* scale, const void* shape, const void* rates,
+                    void* out, void* stream);
+int beer_ng_from_natural(int dtype, int K, int D, const void* eta, void* mean,
+                         void* scale, void* shape, void* rates, void* stream);
+
+/* IsotropicNormalGamma, beer/dists/isonormalgamma.py:119-157, 163-168,
+ * 174-192, 78-95.  mean [K,D], scale [K], shape [K], rate [K]. */
+int beer_ing_expected_stats(int dtype, int K, int D, const void* mean,
+                            const void* scale, const void* shape,
+                            const void* rate, void* out, void* stream);
+int beer_ing_log_norm(int dtype, int K, int D, const void* mean,
+                      const void* scale, const void* shape, const void* rate,
+                      void* out, void* stream);
+int beer_ing_natural(int dtype, int K, int D, const void* mean,
+                     const void* scale, const void* shape, const void* rate,
+                     void* out, void* stream);
+int beer_ing_from_natural(int dtype, int K, int D, const void* eta, void* mean,
+                          void* scale, void* shape, void* rate, void* stream);
+
+/* Dirichlet (set of S pdfs over G categories), beer/dists/dirichlet.py:
+ * 106-128 (E[T]), 135-138 (log_norm), 144-159 (natural), 71-81 (from). */
+int beer_dirichlet_expected_stats(int dtype, int S, int G, const void* conc,
+                                  void* out, void* stream);
+int beer_dirichlet_log_norm(int dtype, int S, int G, const void* conc,
+                            void* out, void* stream);
+int beer_dirichlet_natural(int dtype, int S, int G, const void* conc,
+                           void* out, void* stream);
+int beer_dirichlet_from_natural(int dtype, int S, int G, const void* eta,
+                                void* conc, void* stream);
+/* E[ln pi] of S categoricals: the `eye -> sufficient_statistics -> stats @
+ * E[T]` sequence of Mixture._log_weights (beer/models/mixture.py:45-48) and
+ * MixtureSet._log_weights (mixtureset.py:64-67) -> out [S,G]. */
+int beer_dirichlet_log_weights(int dtype, int S, int G, const void* conc,
+                               void* out, void* stream);
+
+/* Gamma (n independent pdfs), beer/dists/gamma.py:112-124, 129-131,
+ * 137-140, 68-77.  shape [n], rate [n]; E[T] / natural are [2n]. */
+int beer_gamma_expected_stats(int dtype, int n, const void* shape,
+                              const void* rate, void* out, void* stream);
+int beer_gamma_log_norm(int dtype, int n, const void* shape, const void* rate,
+                        void* out /*[1]*/, void* stream);
+int beer_gamma_natural(int dtype, int n, const void* shape, const void* rate,
+                       void* out, void* stream);
+int beer_gamma_from_natural(int dtype, int n, const void* eta, void* shape,
+                            void* rate, void* stream);
+
+/* KL(q || p) of K same-family members from their expected statistics,
+ * natural parameters and log-normalisers: beer/dists/basedist.py:243-263.
+ * out [K]. */
+int beer_kl_div(int dtype, int K, int Q, const void* exp_stats_q,
+                const void* eta_q, const void* eta_p, const void* lnorm_q,
+                const void* lnorm_p, void* out, void* stream);
+
+/* eta <- eta_q + lrate * (eta_p + stats - eta_q): the body of
+ * ConjugateBayesianParameter.natural_grad_update
+ * (beer/models/parameters.py:134-141).  n elements. */
+int beer_natural_grad_step(int dtype, int64_t n, const void* eta_prior,
+                           const void* eta_post, const void* stats,
+                           double lrate, void* out, void* stream);
+
+/* Dense statistics phi(X) [T,Q] exactly as the reference materialises them
+ * (normalwishart.py:30-38 etc.).  Only for callers that ask for the tensor
+ * (Model.sufficient_statistics(...).dense()); the E-step never forms it. */
+int beer_suffstats_expand(int dtype, int cov, int64_t T, int D, const void* X,
+                          void* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * E-step: expected log-likelihoods and responsibilities
+ * ---------------------------------------------------------------------- */
+
+/* Per-component expected log-likelihood + per-state mixture normaliser +
+ * component responsibilities for S states of G Gaussians each (K = S*G):
+ *   l[t,s,g]  = stat_scale * phi(x_t) . E[T]_{s,g} - D/2 ln 2pi
+ *   w         = l + log_weights[s,g]
+ *   log_norm[t,s]     = logsumexp_g w            (nullable)
+ *   comp_resps[t,s,g] = exp(w - log_norm[t,s])   (nullable)
+ *   pc_llh[t,s,g]     = l                         (nullable)
+ * Replaces NormalLikelihood.__call__ (normalwishart.py:88-92; diag
+ * normalgamma.py:55-59; iso isonormalgamma.py:56-60) through
+ * NormalSet.expected_log_likelihood (beer/models/normalset.py:117-119),
+ * Mixture.expected_log_likelihood (mixture.py:70-93: S = 1) and
+ * MixtureSet.expected_log_likelihood (mixtureset.py:85-98).  With
+ * `labels` (int64 [T], S must be 1) responsibilities are one-hot and
+ * log_norm[t] = l[t, label] (mixture.py:85-87).  `log_weights` nullable
+ * (= 0).  `stat_scale` reproduces HMM.posteriors' scaling of the statistics
+ * (beer/models/hmm.py:119); pass 1.  `llh_sum` (nullable) += sum_t,s log_norm
+ * in fp64. */
+int beer_mixtureset_estep(int dtype, int cov, int64_t T, int D, int S, int G,
+                          const void* X, const void* exp_stats,
+                          const void* log_weights, const int64_t* labels,
+                          double stat_scale, void* pc_llh, void* log_norm,
+                          void* comp_resps, double* llh_sum, void* stream);
+
+/* gamma-weighted sufficient statistics (N_k, sum r x, sum r xx^T) packed as
+ * the reference packs them, [K,Q] = resps^T @ phi(X), accumulated (+=) in
+ * fp64:  acc[k,:] += sum_t comp_resps[t,k] * state_resps[t, k / G] * phi(x_t).
+ * Replaces NormalSet.accumulate (beer/models/normalset.py:121-123) with the
+ * joint responsibilities of MixtureSet.accumulate (mixtureset.py:100-112);
+ * `state_resps` [T,S] nullable (= 1), `comp_resps` [T,K] nullable (= 1). */
+int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G,
+                           const void* X, const void* comp_resps,
+                           const void* state_resps, double* acc, void* stream);
+
+/* Mixture-weight statistics from the accumulated Gaussian statistics: the
+ * zero-order count is N_k = -2 * acc[k, Q-2]; out[s,g] = N_{s,g} for
+ * g < G-1 and out[s,G-1] = sum_g N_{s,g} -- the "last column <- row sum"
+ * convention of CategoricalLikelihood.sufficient_statistics
+ * (beer/dists/dirichlet.py:18-21) summed over frames as in
+ * Categorical.accumulate (categorical.py:78-79) and
+ * CategoricalSet.accumulate_from_jointresps (categoricalset.py:57-58). */
+int beer_weights_from_acc(int S, int G, int Q, const double* acc,
+                          double* out /*[S,G] +=*/, void* stream);
+
+/* ------------------------------------------------------------------------
+ * HMM inference over a ragged batch of utterances
+ * ---------------------------------------------------------------------- */
+
+/* Inference graph in device memory (CompiledGraph, beer/graph.py:243-268):
+ * dense init/final log-probabilities plus the finite transitions in two
+ * CSR forms (by destination for the forward / Viterbi recursions, by source
+ * for the backward recursion).  Arcs inside a row are sorted by the other
+ * end's index (ascending) -- Viterbi's first-index tie-break relies on it.
+ * Built on the host by beer_amd.graph.CompiledGraph; -inf transitions are
+ * simply absent. */
+typedef struct {
+    int32_t n_states;
+    int32_t n_arcs;
+    const void* init;          /* [S]  */
+    const void* final;         /* [S]  */
+    const int32_t* in_ptr;     /* [S+1] arcs grouped by destination */
+    const int32_t* in_src;     /* [nnz] source state               */
+    const void* in_w;          /* [nnz] log-probability             */
+    const int32_t* out_ptr;    /* [S+1] arcs grouped by source      */
+    const int32_t* out_dst;    /* [nnz] destination state           */
+    const void* out_w;         /* [nnz] */
+} beer_graph;
+
+/* Ragged batch: utterance u owns frames [frame_off[u], frame_off[u+1]) of the
+ * packed feature matrix and rows [llh_off[u], ...) (in elements) of the
+ * packed per-state buffers, whose row length is graphs[graph_id[u]].n_states.
+ * All arrays are device arrays of length nutt (+1 for frame_off). */
+typedef struct {
+    int32_t nutt;
+    int32_t max_states;        /* max n_states over the batch's graphs (LDS sizing) */
+    int32_t max_arcs;          /* max n_arcs over the batch's graphs   (LDS sizing) */
+    int32_t n_graphs;
+    const int64_t* frame_off;  /* [nutt+1] */
+    const int64_t* llh_off;    /* [nutt]   element offsets */
+    const int32_t* graph_id;   /* [nutt]   */
+    const beer_graph* graphs;  /* device array of graph descriptors */
+    const int32_t* pdf_off;    /* [n_graphs+1] offsets into pdf_ids */
+    const int32_t* pdf_ids;    /* concatenated pdf_id_mapping of every graph */
+} beer_batch;
+
+/* pc_llhs[u][t,s] = scale * pc_all[frame_off[u]+t, pdf_id[s]]: the gather of
+ * DynamicallyOrderedModelSet.expected_log_likelihood
+ * (beer/models/modelset.py:140-146) and the acoustic scale of
+ * HMM.expected_log_likelihood (beer/models/hmm.py:79). */
+int beer_hmm_gather(int dtype, const beer_batch* batch_h, int S_total,
+                    const void* pc_all, double scale, void* pc_llhs,
+                    void* stream);
+
+/* Log-space forward-backward, per-frame-normalised state posteriors and
+ * (optional) summed transition posteriors:
+ * CompiledGraph._baum_welch_forward/_backward/posteriors
+ * (beer/graph.py:270-326).  gamma has the layout of pc_llhs.  `alpha_ws` is
+ * caller-provided fp64 scratch with as many elements.  `xi_sum` (nullable, [S,S]
+ * fp64, +=) receives sum_u sum_t xi_t -- every utterance must then use
+ * graph 0; `gamma0_sum` (nullable, [S] fp64, +=) receives sum_u gamma_0.
+ * `lognorm_mean` (nullable, [nutt]) receives mean_t lognorm_t
+ * (graph.py:326). */
+int beer_hmm_forward_backward(int dtype, const beer_batch* batch_h,
+                              const void* pc_llhs, double* alpha_ws, void* gamma,
+                              double* xi_sum, double* gamma0_sum,
+                              void* lognorm_mean, void* stream);
+
+/* Viterbi + backtrack, CompiledGraph.best_path (beer/graph.py:329-344):
+ * first-index tie-break, -inf safe, int64 state path per frame (packed like
+ * the frames).  `bt_ws` is int32 scratch with the layout of pc_llhs.  With `map_pdf` != 0 the path is mapped through pdf_id_mapping as
+ * HMM.decode does (beer/models/hmm.py:105-114). */
+int beer_hmm_viterbi(int dtype, const beer_batch* batch_h, const void* pc_llhs,
+                     int32_t* bt_ws, int64_t* path, int map_pdf, void* stream);
+
+/* One-hot posteriors of a given state path (hmm.py:42-58: viterbi=True /
+ * state_path= branches): gamma one-hot, xi_sum[p_t, p_t+1] += 1,
+ * gamma0_sum[p_0] += 1. */
+int beer_hmm_path_posteriors(int dtype, const beer_batch* batch_h,
+                             const int64_t* path, void* gamma, double* xi_sum,
+                             double* gamma0_sum, void* stream);
+
+/* Scatter the (scaled) state posteriors back to pdf ids, repeated ids add
+ * (DynamicallyOrderedModelSet.accumulate, beer/models/modelset.py:148-154,
+ * with the scale of HMM.accumulate, hmm.py:95), and the per-frame expected
+ * log-likelihood exp_llh[t] = sum_s gamma[t,s] * pc_llhs[t,s] (hmm.py:87).
+ * state_resps [Ttot, S_total] must be zeroed by the caller; `exp_llh`
+ * nullable [Ttot]; `utt_llh` nullable fp64 [nutt] (+= sum_t exp_llh). */
+int beer_hmm_scatter(int dtype, const beer_batch* batch_h, int S_total,
+                     const void* pc_llhs, const void* gamma, double scale,
+                     void* state_resps, void* exp_llh, double* utt_llh,
+                     void* stream);
+
+/* Per-utterance sums of a per-frame quantity: out[u] += sum_t v[t]
+ * (the `exp_llh.sum()` of evidence_lower_bound,
+ * beer/inference/objectives.py:184, for every utterance of a batch). */
+int beer_segment_sum(int dtype, int32_t nutt, const int64_t* frame_off,
+                     const void* v, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEER_HIP_H */

@@ -1,0 +1,447 @@
+"""Parity of the HIP path (through the C ABI and the drop-in Python layer)
+against the golden vectors of the reference and against the CPU oracle.
+Needs a real MI355X: `pytest -m gpu`."""
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import COV_OF, assert_close, dist_cls, load_golden, orc, std_params
+
+pytestmark = pytest.mark.gpu
+
+import beer_amd as beer                       # noqa: E402
+from gpu_helpers import (DEV, build_dist, build_graph, build_hmm, build_mixture,   # noqa: E402
+                         build_param, build_phoneloop, check_posterior, npy, params_of, tt)
+
+# Tolerances (relative to the largest reference entry).  fp64 models: every
+# kernel computes in fp64.  fp32 models: north-star bound 1e-5 on ELBO and
+# posterior parameters, checked against the reference's fp64 result computed
+# from the same fp32 inputs.
+T64 = 1e-9
+T32_ELBO = 1e-5
+
+
+def test_native_library_is_loaded():
+    from beer_amd import _hip
+    assert _hip.lib().beer_hip_version() >= 100
+    assert _hip.lib().beer_hip_device_count() >= 1
+
+
+# --- G10: distribution kernels ------------------------------------------------
+
+@pytest.mark.parametrize('name', ['nw', 'ng', 'ing', 'dir', 'dirset'])
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-10), (torch.float32, 2e-5)])
+def test_g10_dists(name, dtype, tol):
+    g = load_golden('g10_dists')
+    q, p = build_dist(g, f'{name}.q', dtype), build_dist(g, f'{name}.p', dtype)
+    assert_close(npy(q.natural_parameters()), g[f'{name}.natural'], tol, 'natural')
+    assert_close(npy(q.expected_sufficient_statistics()), g[f'{name}.exp_stats'], tol, 'E[T]')
+    assert_close(npy(q.log_norm()), g[f'{name}.log_norm'], tol, 'log_norm')
+    assert_close(npy(beer.dists.kl_div(q, p)), g[f'{name}.kl'], max(tol * 50, 1e-9), 'kl')
+    rt = q.params.from_natural_parameters(q.natural_parameters())
+    for pn in q._std_params_def:
+        ref = g[f'{name}.roundtrip.{pn}']
+        assert_close(npy(getattr(rt, pn)).reshape(ref.shape), ref, tol * 20, 'roundtrip ' + pn)
+
+
+def test_g10_gamma_and_dense_stats():
+    g = load_golden('g10_dists')
+    q, p = build_dist(g, 'gamma.q'), build_dist(g, 'gamma.p')
+    assert_close(npy(q.natural_parameters()), g['gamma.natural'], 1e-12)
+    assert_close(npy(q.expected_sufficient_statistics()), g['gamma.exp_stats'], 1e-12)
+    assert_close(npy(q.log_norm()), g['gamma.log_norm'], 1e-12)
+    assert_close(npy(beer.dists.kl_div(q, p)), g['gamma.kl'].reshape(()), 1e-10)
+    X = tt(g['X'])
+    for cov, cls in (('full', beer.dists.NormalLikelihood),
+                     ('diagonal', beer.dists.NormalDiagonalLikelihood),
+                     ('isotropic', beer.dists.IsotropicNormalLikelihood)):
+        assert_close(npy(cls.sufficient_statistics(X).dense()), g[f'stats.{cov}'], 1e-15)
+
+
+# --- G1/G2/G3/G11: GMM ----------------------------------------------------------
+
+@pytest.mark.parametrize('name,tol', [('g01_gmm_diag_c1', T64), ('g02_gmm_full', T64),
+                                      ('g03_gmm_iso', T64)])
+def test_gmm_fp64_iterations(name, tol):
+    g = load_golden(name)
+    X = tt(g['X'])
+    model = build_mixture(g)
+    ns = model.modelset
+    stats = model.sufficient_statistics(X)
+    assert_close(npy(ns.means_precisions.natural_form()), g['exp_T'], tol, 'E[T]')
+    assert_close(npy(ns.expected_log_likelihood(stats)), g['pc_llh'], tol, 'pc_llh')
+    assert_close(npy(model._log_weights()), g['log_weights'].reshape(-1), tol, 'log weights')
+    assert_close(npy(model.expected_log_likelihood(stats)), g['per_frame'], tol, 'per frame')
+    assert_close(npy(model.cache['resps']), g['resps'], tol * 10, 'resps')
+    model.clear_cache()
+    assert_close(npy(model.kl_div_posterior_prior()), g['kl'], 1e-8, 'kl')
+    optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.)
+    for it in range(int(g['niter'])):
+        optim.init_step()
+        elbo = beer.evidence_lower_bound(model, X)
+        if it == 0:
+            p0, p1 = params_of(model)
+            assert_close(npy(elbo._acc_stats[p0]), g['acc0.p0'], tol, 'acc normal')
+            assert_close(npy(elbo._acc_stats[p1]), g['acc0.p1'], tol, 'acc weights')
+        assert_close(float(elbo), g['elbos'][it], tol, f'elbo {it}')
+        elbo.backward()
+        optim.step()
+        p0, p1 = params_of(model)
+        check_posterior(p0, g, f'it{it}.p0.posterior', 1e-7, assert_close)
+        check_posterior(p1, g, f'it{it}.p1.posterior', 1e-8, assert_close)
+
+
+@pytest.mark.parametrize('name', ['g11_gmm_diag_c1_f32', 'g11_gmm_full_f32'])
+def test_gmm_fp32_one_step_vs_fp64_truth(name):
+    '''fp32 model and data (what the reference CLI runs).  The HIP result must
+    match the exact (fp64) result of the same fp32 inputs to 1e-5 -- a tighter
+    statement than matching the reference's own fp32 rounding.'''
+    g = load_golden(name)
+    cov = str(g['cov_type'])
+    X32 = g['X']
+    model = build_mixture(g)
+    assert next(model.parameters(), None) is None
+    X = tt(X32)
+    post = [a.astype(np.float64) for a in std_params(g, 'init.p0.posterior')]
+    prior = [a.astype(np.float64) for a in std_params(g, 'init.p0.prior')]
+    w_post = g['init.p1.posterior.concentrations'].astype(np.float64)
+    w_prior = g['init.p1.prior.concentrations'].astype(np.float64)
+    truth = orc.gmm_elbo_step(X32.astype(np.float64), cov, post, prior, w_post, w_prior)
+    optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.)
+    optim.init_step()
+    elbo = beer.evidence_lower_bound(model, X)
+    assert_close(float(elbo), truth['value'], T32_ELBO, 'elbo vs fp64 truth')
+    assert_close(float(elbo), g['elbos'][0], 1e-4, 'elbo vs reference fp32')
+    p0, p1 = params_of(model)
+    assert_close(npy(elbo._acc_stats[p0]), truth['acc_normal'], 1e-5, 'acc normal')
+    elbo.backward()
+    optim.step()
+    new_post, new_w = orc.gmm_mstep(cov, post, prior, w_post, w_prior, truth['acc_normal'],
+                                    truth['acc_weights'])
+    for name_, ref in zip(p0.posterior._std_params_def, new_post):
+        got = npy(getattr(p0.posterior.params, name_))
+        assert_close(got.reshape(ref.shape), ref, 1e-5, 'posterior ' + name_)
+    assert_close(npy(p1.posterior.params.concentrations), new_w, 1e-5)
+
+
+def test_gmm_labels_branch():
+    g = load_golden('g01_gmm_labels')
+    model = build_mixture(g)
+    elbo = beer.evidence_lower_bound(model, tt(g['X']), labels=tt(g['labels']))
+    assert_close(float(elbo), g['elbo'], T64)
+    p0, p1 = params_of(model)
+    assert_close(npy(elbo._acc_stats[p0]), g['acc0.p0'], T64)
+    assert_close(npy(elbo._acc_stats[p1]), g['acc0.p1'], T64)
+
+
+# --- G4/G7: HMM -------------------------------------------------------------------
+
+@pytest.mark.parametrize('cov', ['full', 'diagonal', 'isotropic'])
+def test_g4_hmm_fp64(cov):
+    g = load_golden(f'g04_hmm_{cov}')
+    X = tt(g['X'])
+    hmm = build_hmm(g)
+    stats = hmm.sufficient_statistics(X)
+    pc = hmm._pc_llhs(stats, hmm.graph)
+    assert_close(npy(pc), g['pc_llhs'], T64, 'pc_llhs')
+    (gamma, xi_sum), lognorm = hmm.graph.posteriors(tt(g['pc_llhs']), trans_posteriors=True)
+    assert_close(npy(gamma), g['gamma'], 1e-8, 'gamma')
+    assert_close(npy(xi_sum), g['xi_sum'], 1e-8, 'xi_sum')
+    assert_close(float(lognorm), g['lognorm_mean'], 1e-10, 'lognorm mean')
+    hmm.clear_cache()
+    optim = beer.VBConjugateOptimizer(hmm.mean_field_factorization(), 1.)
+    for it in range(3):
+        optim.init_step()
+        elbo = beer.evidence_lower_bound(hmm, X, datasize=len(X), viterbi=False)
+        assert_close(float(elbo), g['elbos'][it], 1e-8, f'elbo {it}')
+        if it == 0:
+            assert_close(npy(elbo._acc_stats[params_of(hmm)[0]]), g['acc0.p0'], 1e-8, 'acc')
+        elbo.backward()
+        optim.step()
+        check_posterior(params_of(hmm)[0], g, f'it{it}.p0.posterior', 1e-6, assert_close)
+    np.testing.assert_array_equal(npy(hmm.decode(X)), g['decode'])
+    assert_close(npy(hmm.posteriors(X)), g['posteriors'], 1e-6)
+
+
+@pytest.mark.parametrize('cov', ['full', 'diagonal', 'isotropic'])
+def test_g4_hmm_fp32(cov):
+    g = load_golden(f'g04_hmm_{cov}_f32')
+    g64 = load_golden(f'g04_hmm_{cov}')
+    X = tt(g['X'])
+    hmm = build_hmm(g)
+    elbo = beer.evidence_lower_bound(hmm, X, datasize=len(X))
+    # same fp32 inputs (up to the cast of the fp64 golden's data) -> compare
+    # with the reference's fp32 run at its own rounding band, and with the
+    # fp64 run at the north-star band.
+    assert_close(float(elbo), g['elbos'][0], 1e-4)
+    assert_close(float(elbo), g64['elbos'][0], 1e-4)
+    # Viterbi on the reference's own fp32 per-state llhs: bit-exact path.
+    path = hmm.graph.best_path(tt(g['pc_llhs']))
+    ref = orc.best_path(g['pc_llhs'], g['graph.init'], g['graph.final'], g['graph.trans'])
+    np.testing.assert_array_equal(npy(path), ref)
+
+
+def test_g7_viterbi_ties_bit_exact():
+    g = load_golden('g07_viterbi_ties')
+    graph = build_graph(g, 'graph')
+    for i in range(3):
+        l = tt(g[f'llhs{i}'])
+        np.testing.assert_array_equal(npy(graph.best_path(l)), g[f'path{i}'])
+        (gamma, xi_sum), _ = graph.posteriors(l, trans_posteriors=True)
+        assert_close(npy(gamma), g[f'gamma{i}'], 1e-12)
+        assert_close(npy(xi_sum), g[f'xi_sum{i}'], 1e-12)
+
+
+@pytest.mark.parametrize('branch', ['viterbi', 'state_path'])
+def test_g7_hard_alignment_training(branch):
+    g = load_golden(f'g07_hmm_{branch}')
+    hmm = build_hmm(g)
+    kw = {'viterbi': True} if branch == 'viterbi' else {'state_path': tt(g['state_path'])}
+    elbo = beer.evidence_lower_bound(hmm, tt(g['X']), datasize=len(g['X']), **kw)
+    assert_close(float(elbo), g['elbo'], 1e-10)
+    assert_close(npy(elbo._acc_stats[params_of(hmm)[0]]), g['acc0.p0'], 1e-10)
+
+
+def test_viterbi_random_large_bit_exact():
+    'S = 120 phone-loop-like sparse graph, 300 frames, fp32 and fp64.'
+    rng = np.random.RandomState(0)
+    S, T = 120, 300
+    trans = np.full((S, S), -np.inf)
+    for i in range(S):
+        nxt = [i, (i + 1) % S] + list(rng.choice(S, 3, replace=False))
+        p = rng.dirichlet(np.ones(len(set(nxt))))
+        for j, pj in zip(sorted(set(nxt)), p):
+            trans[i, j] = np.log(pj)
+    init = np.log(rng.dirichlet(np.ones(S)))
+    final = np.log(rng.dirichlet(np.ones(S)))
+    for dt in (np.float64, np.float32):
+        llhs = (rng.randn(T, S) * 5).astype(dt)
+        graph = beer.graph.CompiledGraph(tt(init.astype(dt)), tt(final.astype(dt)),
+                                         tt(trans.astype(dt)), list(range(S)))
+        ref = orc.best_path(llhs, init.astype(dt), final.astype(dt), trans.astype(dt))
+        np.testing.assert_array_equal(npy(graph.best_path(tt(llhs))), ref)
+        if dt == np.float64:
+            gam, xi, _ = orc.posteriors(llhs, init, final, trans, True)
+            (gamma, xi_sum), _ = graph.posteriors(tt(llhs), trans_posteriors=True)
+            assert_close(npy(gamma), gam, 1e-9)
+            assert_close(npy(xi_sum), xi.sum(0), 1e-9)
+
+
+# --- G5/G6/G8: PhoneLoop ----------------------------------------------------------------
+
+@pytest.mark.parametrize('kind', ['dirichlet', 'dirichlet_process', 'gamma_dirichlet_process'])
+def test_g5_phoneloop(kind):
+    g = load_golden(f'g05_phoneloop_{kind}')
+    X = tt(g['X'])
+    ploop, ci = build_phoneloop(g, kind)
+    assert_close(npy(ploop.graph.trans_log_probs.exp()), np.exp(g['graph.trans']), 1e-12)
+    stats = ploop.sufficient_statistics(X)
+    assert_close(npy(ploop.expected_log_likelihood(stats)), g['exp_llh'], 1e-9, 'exp_llh')
+    assert_close(npy(ploop.cache['resps']), g['gamma'], 1e-8, 'gamma')
+    assert_close(npy(ploop.cache['trans_resps']), g['xi_sum'], 1e-8, 'xi_sum')
+    ploop.clear_cache()
+    optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.)
+    for it in range(2):
+        optim.init_step()
+        elbo = beer.evidence_lower_bound(ploop, X, datasize=len(X))
+        assert_close(float(elbo), g['elbos'][it], 1e-9, f'elbo {it}')
+        for i, p in enumerate(params_of(ploop)):
+            assert_close(npy(elbo._acc_stats[p]), g[f'acc{it}.p{i}'], 1e-8, f'acc{it}.p{i}')
+        elbo.backward()
+        optim.step()
+        for i, p in enumerate(params_of(ploop)):
+            check_posterior(p, g, f'it{it}.p{i}.posterior', 1e-7, assert_close)
+        assert_close(npy(ploop.graph.trans_log_probs.exp()), np.exp(g[f'it{it}.trans']), 1e-9)
+        if kind != 'dirichlet':
+            np.testing.assert_array_equal(npy(ploop.categorical.ordering), g[f'it{it}.ordering'])
+        if kind == 'gamma_dirichlet_process':
+            check_posterior(ploop.categorical.concentration, g,
+                            f'it{it}.concentration.posterior', 1e-10, assert_close)
+    np.testing.assert_array_equal(npy(ploop.decode(X)), g['decode'])
+
+
+def test_g6_alignment_graph_scale_and_g8_joint():
+    g = load_golden('g06_phoneloop_ali')
+    X = tt(g['X'])
+    ploop, ci = build_phoneloop(g, 'dirichlet')
+    ali = build_graph(g, 'ali')
+    stats = ploop.sufficient_statistics(X)
+    joint = ploop.modelset.original_modelset.expected_log_likelihood(stats)
+    assert_close(npy(joint), g['joint_pc_llh'], 1e-10, 'G8 joint llh')
+    ploop.clear_cache()
+    scale = float(g['scale'])
+    exp_llh = ploop.expected_log_likelihood(stats, inference_graph=ali, scale=scale)
+    assert_close(npy(exp_llh), g['exp_llh'], 1e-9)
+    assert_close(npy(ploop.cache['resps']), g['gamma'], 1e-8)
+    ploop.clear_cache()
+    optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.)
+    optim.init_step()
+    elbo = beer.evidence_lower_bound(ploop, X, datasize=1000, inference_graph=ali, scale=scale)
+    assert_close(float(elbo), g['elbo'], 1e-9)
+    for i, p in enumerate(params_of(ploop)):
+        assert_close(npy(elbo._acc_stats[p]), g[f'acc0.p{i}'], 1e-8, f'acc0.p{i}')
+    elbo.backward()
+    optim.step()
+    for i, p in enumerate(params_of(ploop)):
+        check_posterior(p, g, f'it0.p{i}.posterior', 1e-7, assert_close)
+    np.testing.assert_array_equal(npy(ploop.decode(X, inference_graph=ali, scale=scale)),
+                                  g['decode_ali'])
+    assert_close(npy(ploop.posteriors(X, inference_graph=ali, scale=scale)),
+                 g['posteriors_ali'], 1e-8)
+
+
+# --- G9: bookkeeping + the batched accumulator --------------------------------------------------
+
+def test_g9_bookkeeping_and_batch_equivalence():
+    g = load_golden('g09_elbo_bookkeeping')
+    X, lens, N = tt(g['X']), g['lens'], int(g['datasize'])
+    model = build_mixture(g)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    optim = beer.VBConjugateOptimizer(model.conjugate_bayesian_parameters(keepgroups=True), 1.)
+    optim.init_step()
+    elbo = beer.evidence_lower_bound(datasize=N)
+    for u in range(len(lens)):
+        e = beer.evidence_lower_bound(model, X[off[u]:off[u + 1]], datasize=N)
+        assert_close(float(e), g['utt_values'][u], 1e-10)
+        elbo += e
+    assert_close(float(elbo), g['sum_value'], 1e-10)
+    assert_close(float(elbo) / (len(lens) * N), g['logged'], 1e-10)
+    batched = beer.accumulate_elbo(model, (X, lens.tolist()), datasize=N)
+    assert_close(float(batched), g['sum_value'], 1e-10, 'batched value')
+    for i, p in enumerate(params_of(model)):
+        assert_close(npy(elbo._acc_stats[p]), g[f'acc_sum.p{i}'], 1e-10)
+        assert_close(npy(batched._acc_stats[p]), g[f'acc_sum.p{i}'], 1e-10, 'batched acc')
+    with pytest.raises(ValueError):
+        elbo + beer.evidence_lower_bound(datasize=N + 1)
+    batched.backward()
+    for i, p in enumerate(params_of(model)):
+        assert_close(npy(p.stats), g[f'stored.p{i}'], 1e-10)
+    optim.step()
+    for i, p in enumerate(params_of(model)):
+        check_posterior(p, g, f'it0.p{i}.posterior', 1e-8, assert_close)
+    optim2 = beer.VBConjugateOptimizer(model.conjugate_bayesian_parameters(keepgroups=True), .3)
+    optim2.init_step()
+    e = beer.evidence_lower_bound(model, X, datasize=N)
+    e.backward()
+    optim2.step()
+    for i, p in enumerate(params_of(model)):
+        check_posterior(p, g, f'it1_lr03.p{i}.posterior', 1e-8, assert_close)
+
+
+@pytest.mark.parametrize('mode', ['free', 'ali'])
+def test_phoneloop_batch_equals_per_utterance_loop(mode):
+    g = load_golden('g06_phoneloop_ali')
+    ploop, _ = build_phoneloop(g, 'dirichlet')
+    rng = np.random.RandomState(3)
+    lens = [37, 90, 52, 41]
+    utts = [tt(rng.randn(T, g['X'].shape[1]) * 1.5) for T in lens]
+    N = 5000
+    ali = build_graph(g, 'ali')
+    graphs = [ali, ploop.graph, ali, ali] if mode == 'ali' else None
+    loop = beer.evidence_lower_bound(datasize=N)
+    for u, x in enumerate(utts):
+        kw = {'inference_graph': graphs[u]} if graphs else {}
+        loop += beer.evidence_lower_bound(ploop, x, datasize=N, scale=.7, **kw)
+    batched = beer.accumulate_elbo(ploop, utts, datasize=N, inference_graphs=graphs, scale=.7)
+    assert_close(float(batched), float(loop), 1e-11)
+    assert batched._minibatchsize == loop._minibatchsize == sum(lens)
+    for p in params_of(ploop):
+        assert_close(npy(batched._acc_stats[p]), npy(loop._acc_stats[p]), 1e-10)
+    paths = beer.decode_batch(ploop, utts, inference_graphs=graphs, scale=.7)
+    for u, x in enumerate(utts):
+        kw = {'inference_graph': graphs[u]} if graphs else {}
+        np.testing.assert_array_equal(npy(paths[u]), npy(ploop.decode(x, scale=.7, **kw)))
+
+
+# --- config-2 shape against the oracle + size-independent properties --------------------------------
+
+def _c2_model(K, D, dtype, seed=7):
+    torch.manual_seed(seed)
+    rng = np.random.RandomState(1)
+    means = rng.randn(K, D) * 2
+    return means, rng
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-5)])
+def test_c2_shape_one_step_vs_oracle(dtype, tol):
+    'K=256 full-covariance, D=40, 8192 frames: E-step + M-step vs the oracle.'
+    K, D, T = 256, 40, 8192
+    rng = np.random.RandomState(1)
+    means = rng.randn(K, D) * 2
+    A = rng.randn(D, D) * .2 + np.eye(D)
+    Xn = (means[rng.randint(0, K, T)] + rng.randn(T, D) @ A)
+    Xn = Xn.astype(np.float32 if dtype == torch.float32 else np.float64)
+    X = torch.from_numpy(Xn)
+    torch.manual_seed(7)
+    ns = beer.NormalSet.create(X.mean(0), torch.from_numpy(np.cov(Xn.T)).to(dtype), size=K,
+                               prior_strength=1., noise_std=1., cov_type='full')
+    model = beer.Mixture.create(ns, prior_strength=1.).to(DEV)
+    p0, p1 = params_of(model)
+    as64 = lambda d: [npy(getattr(d.params, n)).astype(np.float64) for n in d._std_params_def]
+    post, prior = as64(p0.posterior), as64(p0.prior)
+    (w_post,), (w_prior,) = as64(p1.posterior), as64(p1.prior)
+    truth = orc.gmm_elbo_step(Xn.astype(np.float64), 'full', post, prior, w_post, w_prior)
+    optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), 1.)
+    optim.init_step()
+    elbo = beer.evidence_lower_bound(model, X.to(DEV))
+    assert_close(float(elbo), truth['value'], tol, 'elbo')
+    acc = npy(elbo._acc_stats[p0]).astype(np.float64)
+    assert_close(acc, truth['acc_normal'], tol, 'acc')
+    # properties: counts sum to T; second-moment block symmetric
+    assert abs(-2 * acc[:, -2].sum() - T) <= 1e-6 * T
+    S2 = acc[:, D:D + D * D].reshape(K, D, D)
+    assert np.abs(S2 - S2.transpose(0, 2, 1)).max() <= 1e-6 * np.abs(S2).max()
+    elbo.backward()
+    optim.step()
+    new_post, new_w = orc.gmm_mstep('full', post, prior, w_post, w_prior, truth['acc_normal'],
+                                    truth['acc_weights'])
+    for n, ref in zip(p0.posterior._std_params_def, new_post):
+        got = npy(getattr(p0.posterior.params, n)).astype(np.float64)
+        assert_close(got.reshape(ref.shape), ref, tol * 10, 'posterior ' + n)
+
+
+def test_full_size_properties_linearity_and_monotone_elbo():
+    '''BASELINE config-2 size per GPU-second budget: 262,144 frames, K=256,
+    D=40 fp32.  (i) accumulating two halves == accumulating the whole,
+    (ii) sum_k N_k == T, (iii) the ELBO does not decrease over VB iterations.'''
+    K, D, T = 256, 40, 1 << 18
+    g = torch.Generator(device='cpu').manual_seed(5)
+    means = torch.randn(K, D, generator=g) * 2
+    X = (means[torch.randint(0, K, (T,), generator=g)] + torch.randn(T, D, generator=g)).to(DEV)
+    torch.manual_seed(11)
+    ns = beer.NormalSet.create(X.mean(0).cpu(), X.var(0).cpu(), size=K, prior_strength=1.,
+                               noise_std=1., cov_type='full')
+    model = beer.Mixture.create(ns).to(DEV)
+    p0, p1 = params_of(model)
+    whole = beer.accumulate_elbo(model, (X, [T]), datasize=T)
+    halves = beer.accumulate_elbo(model, (X, [T // 2, T // 2]), datasize=T)
+    a, b = npy(whole._acc_stats[p0]).astype(np.float64), npy(halves._acc_stats[p0]).astype(np.float64)
+    assert_close(a, b, 1e-6, 'linearity')
+    assert abs(-2 * a[:, -2].sum() - T) <= 1e-5 * T
+    assert_close(npy(whole._acc_stats[p1])[-1], float(T), 1e-6)
+    optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), 1.)
+    prev = -np.inf
+    for _ in range(4):
+        optim.init_step()
+        elbo = beer.accumulate_elbo(model, (X, [T]), datasize=T)
+        val = float(elbo) / T
+        assert val >= prev - 1e-6 * abs(val)
+        prev = val
+        elbo.backward()
+        optim.step()
+
+
+def test_empty_and_ragged_inputs():
+    g = load_golden('g09_elbo_bookkeeping')
+    model = build_mixture(g)
+    X = tt(g['X'])
+    with pytest.raises(ValueError):
+        beer.accumulate_elbo(model, (X, [0, len(X)]), datasize=10)
+    one = beer.accumulate_elbo(model, (X[:1], [1]), datasize=10)     # 1-frame utterance
+    ref = beer.evidence_lower_bound(model, X[:1], datasize=10)
+    assert_close(float(one), float(ref), 1e-12)
+    # host tensors are accepted (copied to the GPU, never computed on the CPU)
+    cpu = beer.evidence_lower_bound(model, X.cpu(), datasize=10)
+    dev = beer.evidence_lower_bound(model, X, datasize=10)
+    assert float(cpu) == float(dev)

@@ -1,0 +1,242 @@
+"""CPU-only checks: the C-ABI library builds, loads and exports every symbol
+include/beer_hip.h declares; host-side logic (graph compilation, mean-field
+grouping, optimizer round-robin, ELBO bookkeeping); and the product path fails
+loudly -- never falls back to the CPU -- when there is no GPU."""
+
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, assert_close, load_golden
+
+import beer_amd as beer
+from beer_amd import _hip, build as beer_build
+
+HAS_GPU = torch.cuda.is_available()
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'beer_hip.h')).read()
+    return sorted(set(re.findall(r'^int (beer_\w+)\(', text, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    beer_build.build(verbose=False)
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 35
+    for name in names:
+        assert hasattr(lib, name), f'{name} is declared but not exported'
+    assert sorted(_hip.SIGNATURES) == names, 'ctypes table and header disagree'
+    assert lib.beer_hip_version() >= 100
+
+
+def test_struct_layouts_match_header():
+    # 2 int32 + 8 pointers; 4 int32 + 6 pointers (LP64)
+    assert ctypes.sizeof(_hip.Graph) == 8 + 8 * 8
+    assert ctypes.sizeof(_hip.Batch) == 16 + 6 * 8
+
+
+@pytest.mark.skipif(HAS_GPU, reason='checks behaviour on a GPU-less host')
+def test_product_path_fails_loudly_without_gpu():
+    X = torch.randn(20, 3)
+    ns = beer.NormalSet.create(X.mean(0), X.var(0), size=4, cov_type='diagonal')
+    model = beer.Mixture.create(ns)
+    with pytest.raises(_hip.HipUnavailable):
+        beer.evidence_lower_bound(model, X)
+    with pytest.raises(_hip.HipUnavailable):
+        ns.means_precisions.posterior.expected_sufficient_statistics()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'beer_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in text.replace('the oracle', ''), f
+
+
+def _notebook_graph():
+    graph = beer.graph.Graph()
+    s0, s4 = graph.add_state(), graph.add_state()
+    graph.start_state, graph.end_state = s0, s4
+    s1, s2, s3 = (graph.add_state(pdf_id=i) for i in range(3))
+    for a, b in [(s0, s1), (s1, s1), (s1, s2), (s2, s2), (s2, s3), (s3, s3), (s3, s1),
+                 (s1, s4), (s2, s4), (s3, s4)]:
+        graph.add_arc(a, b)
+    graph.normalize()
+    return graph.compile()
+
+
+def _unit(topology, start_pdf_id):
+    'Left-to-right unit HMM as `beer hmm mkphones` builds it.'
+    ids = sorted({a for a, _, _ in topology} | {b for _, b, _ in topology})
+    graph = beer.graph.Graph()
+    count = 0
+    for sid in range(len(ids)):
+        if sid in (ids[0], ids[-1]):
+            graph.add_state()
+        else:
+            graph.add_state(pdf_id=start_pdf_id + count)
+            count += 1
+    graph.start_state, graph.end_state = ids[0], ids[-1]
+    for arc in topology:
+        graph.add_arc(*arc)
+    return graph, start_pdf_id + count
+
+
+SIL = [(0, 1, 1.), (1, 1, .5), (1, 2, .5), (2, 2, .5), (2, 1, .25), (2, 3, .25)]
+SPEECH = [(0, 1, 1.), (1, 1, .75), (1, 2, .25), (2, 2, .75), (2, 3, .25), (3, 3, .75),
+          (3, 4, .25)]
+
+
+def _units():
+    units, pdf = {}, 0
+    units['sil'], pdf = _unit(SIL, pdf)
+    for name in 'abcd':
+        units[name], pdf = _unit(SPEECH, pdf)
+    return units
+
+
+def test_graph_compile_matches_reference():
+    g = load_golden('g12_graph_compile')
+    nb = _notebook_graph()
+    assert_close(nb.init_log_probs.numpy(), g['notebook.init'], 1e-7)
+    assert_close(nb.final_log_probs.numpy(), g['notebook.final'], 1e-7)
+    assert_close(nb.trans_log_probs.exp().numpy(), np.exp(g['notebook.trans']), 1e-7)
+    assert nb.pdf_id_mapping == g['notebook.pdf_id_mapping'].tolist()
+
+    units = _units()
+    # alignment graph of `sil a c a sil` (mkaligraph.create_graph_from_seq)
+    graph = beer.graph.Graph()
+    graph.start_state = graph.add_state()
+    last, phone_states = graph.start_state, []
+    seq = ['sil', 'a', 'c', 'a', 'sil']
+    for phone in seq:
+        state = graph.add_state()
+        phone_states.append(state)
+        graph.add_arc(last, state)
+        last = state
+    graph.end_state = graph.add_state()
+    graph.add_arc(last, graph.end_state)
+    for state, phone in zip(phone_states, seq):
+        graph.replace_state(state, units[phone])
+    graph.normalize()
+    ali = graph.compile()
+    assert ali.pdf_id_mapping == g['ali.pdf_id_mapping'].tolist()
+    assert_close(ali.init_log_probs.exp().numpy(), np.exp(g['ali.init']), 1e-7)
+    assert_close(ali.final_log_probs.exp().numpy(), np.exp(g['ali.final']), 1e-7)
+    assert_close(ali.trans_log_probs.exp().numpy(), np.exp(g['ali.trans']), 1e-6)
+
+    # phone-loop decoding graph (mkphoneloopgraph + mkdecodegraph)
+    graph = beer.graph.Graph()
+    graph.start_state, graph.end_state = graph.add_state(), graph.add_state()
+    pivot = graph.add_state()
+    u2s = {name: graph.add_state() for name in units}
+    graph.add_arc(graph.start_state, u2s['sil'])
+    graph.add_arc(u2s['sil'], graph.end_state)
+    for name in units:
+        graph.add_arc(pivot, u2s[name])
+        graph.add_arc(u2s[name], pivot)
+    graph.normalize()
+    for name, hmm in units.items():
+        graph.replace_state(u2s[name], hmm)
+    graph.normalize()
+    loop = graph.compile()
+    assert loop.pdf_id_mapping == g['ploop.pdf_id_mapping'].tolist()
+    assert_close(loop.init_log_probs.exp().numpy(), np.exp(g['ploop.init']), 1e-7)
+    assert_close(loop.final_log_probs.exp().numpy(), np.exp(g['ploop.final']), 1e-7)
+    # (the golden's loop-back entries were rewritten by PhoneLoop's callback;
+    #  compare everything else)
+    ref = np.exp(g['ploop.trans'])
+    got = loop.trans_log_probs.exp().numpy()
+    mask = np.ones_like(ref, dtype=bool)
+    for e in g['end_idxs']:
+        mask[e, g['start_idxs']] = False
+    assert_close(got[mask], ref[mask], 1e-6)
+
+
+def test_mean_field_grouping_and_round_robin():
+    X = torch.randn(50, 3)
+    ns = beer.NormalSet.create(X.mean(0), X.var(0), size=4, cov_type='diagonal')
+    model = beer.Mixture.create(ns)
+    groups = model.mean_field_factorization()
+    assert len(groups) == 1 and len(groups[0]) == 2                 # Q7: one merged group
+    assert list(model.bayesian_parameters()) == groups[0]
+    assert [len(g) for g in model.conjugate_bayesian_parameters(keepgroups=True)] == [2]
+
+    class Fake:
+        def __init__(self):
+            self.updates, self.zeroed = 0, 0
+
+        def natural_grad_update(self, lrate):
+            self.updates += 1
+
+        def zero_stats(self):
+            self.zeroed += 1
+
+    a, b, c = Fake(), Fake(), Fake()
+    optim = beer.VBConjugateOptimizer([[a, b], [c]], lrate=.5)
+    optim.init_step()
+    assert (a.zeroed, b.zeroed, c.zeroed) == (1, 1, 1)
+    optim.step()
+    assert (a.updates, b.updates, c.updates) == (1, 1, 0)
+    optim.step()
+    assert (a.updates, b.updates, c.updates) == (1, 1, 1)
+    state = optim.state_dict()
+    assert state == {'lrate': .5, 'update_count': 2}
+    other = beer.VBConjugateOptimizer([[a, b], [c]])
+    other.load_state_dict(state)
+    other.step()
+    assert a.updates == 2 and c.updates == 1
+
+
+def test_elbo_object_bookkeeping():
+    X = torch.randn(50, 3)
+    ns = beer.NormalSet.create(X.mean(0), X.var(0), size=4, cov_type='diagonal')
+    p = ns.means_precisions
+    q = beer.Mixture.create(ns).categorical.weights
+    E = beer.EvidenceLowerBoundInstance
+    e1 = E(torch.tensor(-3.), {p: torch.ones(4, 8)}, [p], 10, 100)
+    e2 = E(torch.tensor(-4.), {p: torch.ones(4, 8), q: torch.ones(4)}, [p, q], 30, 100)
+    s = beer.evidence_lower_bound(datasize=100) + e1 + e2
+    assert float(s) == -7. and s._minibatchsize == 40
+    assert torch.equal(s._acc_stats[p], 2 * torch.ones(4, 8))
+    s.backward()                                                     # Q2: scale N / sum T_b
+    assert torch.equal(p.stats, 5. * torch.ones(4, 8))
+    assert torch.equal(q.stats, 2.5 * torch.ones(4))
+    with pytest.raises(ValueError):
+        e1 + E(torch.tensor(0.), {}, [], 1, 99)
+    with pytest.raises(ValueError):
+        beer.evidence_lower_bound(None, X)
+    # parameters are keyed by a uuid that survives pickling (elbo.sync)
+    p2 = pickle.loads(pickle.dumps(p))
+    assert p2 == p and hash(p2) == hash(p)
+
+
+def test_default_priors_follow_the_reference_recipe():
+    torch.manual_seed(0)
+    mean, var = torch.tensor([1., -2., .5]), torch.tensor([2., .5, 1.])
+    ns = beer.NormalSet.create(mean, var, size=5, prior_strength=2., noise_std=0.,
+                               cov_type='full')
+    pr = ns.means_precisions.prior.params
+    assert pr.scale.shape == (5, 1) and float(pr.scale[0]) == 2.
+    assert float(pr.dof[0]) == 2. + 3 - 1
+    assert torch.allclose(pr.scale_matrix[0], torch.diag(1 / var) / 4.)
+    assert torch.equal(ns.means_precisions.posterior.params.mean, pr.mean)
+    nd = beer.NormalSet.create(mean, var, size=5, prior_strength=2., cov_type='diagonal')
+    assert torch.allclose(nd.means_precisions.prior.params.rates[0], 2. * var)
+    ni = beer.NormalSet.create(mean, var, size=5, prior_strength=2., cov_type='isotropic')
+    assert float(ni.means_precisions.prior.params.rate[0]) == 4.
+    assert ni.means_precisions.stats.shape == (5, 6)
+    assert nd.means_precisions.stats.shape == (5, 8)
+    assert ns.means_precisions.stats.shape == (5, 14)
+    m = beer.Mixture.create(ns, prior_strength=3.)
+    assert torch.allclose(m.categorical.weights.prior.params.concentrations,
+                          torch.full((5,), 3. / 5))
