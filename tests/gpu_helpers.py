@@ -62,9 +62,18 @@ def build_phoneloop(g, kind, prefix='init'):
         cat = beer.SBCategorical(wparam)
     else:
         cat = beer.SBCategoricalHyperPrior(wparam, build_param(g, f'{prefix}.concentration'))
+        # the constructor's callback recomputed prior[:, 1] = E[concentration] in
+        # fp64; the reference did it in fp32 before .double(): restore its value.
+        cat.stickbreaking.prior.params.concentrations.copy_(
+            tt(g[f'{prefix}.p{i}.prior.concentrations']))
     start = {f'p{j}': int(v) for j, v in enumerate(g['start_idxs'])}
     end = {f'p{j}': int(v) for j, v in enumerate(g['end_idxs'])}
-    return beer.PhoneLoop(build_graph(g, 'graph'), emissions, start, end, cat), i
+    ploop = beer.PhoneLoop(build_graph(g, 'graph'), emissions, start, end, cat)
+    # The reference built its model in fp32 and then called .double(): the
+    # loop-back transitions written by the constructor's callback carry fp32
+    # rounding.  Start from exactly the reference's state.
+    ploop.graph.trans_log_probs.copy_(tt(g['graph.trans']))
+    return ploop, i
 
 
 def params_of(model):
