@@ -45,6 +45,7 @@ def lib():
 
 
 c_p, c_i, c_l, c_d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+c_z = ctypes.c_size_t
 
 
 class Graph(ctypes.Structure):
@@ -87,8 +88,9 @@ SIGNATURES = {
     'beer_natural_grad_step': [c_i, c_l, c_p, c_p, c_p, c_d, c_p, c_p],
     'beer_suffstats_expand': [c_i, c_i, c_l, c_i, c_p, c_p, c_p],
     'beer_mixtureset_estep': [c_i, c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_d,
-                              c_p, c_p, c_p, c_p, c_p],
-    'beer_normal_accumulate': [c_i, c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+                              c_p, c_p, c_p, c_p, c_p, c_z, c_p],
+    'beer_normal_accumulate': [c_i, c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_z,
+                               c_p],
     'beer_weights_from_acc': [c_i, c_i, c_i, c_p, c_p, c_p],
     'beer_hmm_gather': [c_i, c_p, c_i, c_p, c_d, c_p, c_p],
     'beer_hmm_forward_backward': [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
@@ -99,11 +101,22 @@ SIGNATURES = {
 }
 
 
+# size queries: return a byte count, take no stream
+SIZE_QUERIES = {
+    'beer_estep_workspace_bytes': [c_i, c_i, c_i, c_i, c_i],
+    'beer_accumulate_workspace_bytes': [c_i, c_i, c_i, c_i, c_i],
+}
+
+
 def _declare(l):
     for name, args in SIGNATURES.items():
         fn = getattr(l, name)
         fn.argtypes = args
         fn.restype = c_i
+    for name, args in SIZE_QUERIES.items():
+        fn = getattr(l, name)
+        fn.argtypes = args
+        fn.restype = c_z
 
 
 def dtype_code(dtype):
@@ -147,6 +160,24 @@ def call(name, *args):
     if rc != 0:
         what = 'invalid argument' if rc == EINVAL else f'hipError {-rc}'
         raise HipError(f'{name} failed: {what}')
+
+
+_workspaces = {}
+
+
+def workspace(query, dtype, cov, D, S, G, device):
+    '''(tensor, nbytes) scratch for the MFMA implementation of a call, or
+    (None, 0) when the shape has none.  One buffer per (query, shape, stream)
+    is kept and reused: the kernels leave no state in it.'''
+    nbytes = getattr(lib(), query)(dtype_code(dtype), cov, D, S, G)
+    if nbytes == 0:
+        return None, 0
+    key = (query, dtype, cov, D, S, G, device, torch.cuda.current_stream().cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf, nbytes
 
 
 def struct_to_device(obj, device):

@@ -275,7 +275,8 @@ int llh_launch(int64_t nframes, int D, int K, const void* X, const void* expT, c
 template <typename T>
 int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, const void* expT,
                  const void* logw, const int64_t* labels, double stat_scale, void* pc_llh,
-                 void* log_norm, void* comp_resps, double* llh_sum, void* stream) {
+                 void* log_norm, void* comp_resps, double* llh_sum, void* ws, size_t ws_bytes,
+                 void* stream) {
     BEER_REQUIRE(nframes >= 0 && D >= 1 && S >= 1 && G >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(X && expT);
     BEER_REQUIRE(!labels || S == 1);
@@ -296,14 +297,19 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
     BEER_REQUIRE(!labels || pc_arg);
     void* w_arg = labels ? nullptr : (need_norm ? w_buf : nullptr);
 
-    if (!labels && cov == BEER_FULL && beer_mfma::supported(D, K) && w_arg && !pc_arg &&
-        stat_scale == 1.0) {
-        // fast path (gfx950 MFMA), full covariance
-        rc = sizeof(T) == 4
-                 ? beer_mfma::llh_full_f32(nframes, D, K, (const float*)X, (const float*)expT,
-                                           (const float*)logw, (float*)w_arg, s)
-                 : beer_mfma::llh_full_f64(nframes, D, K, (const double*)X, (const double*)expT,
-                                           (const double*)logw, (double*)w_arg, s);
+    if (!labels && cov == BEER_FULL && S == 1 && !pc_llh && stat_scale == 1.0 && ws &&
+        beer_mfma::supported_llh(D, K) &&
+        ws_bytes >= beer_mfma::estep_workspace_bytes(sizeof(T), D, K) &&
+        (log_norm || comp_resps || llh_sum)) {
+        // gfx950 matrix-core path: GEMM + softmax fused, one kernel
+        return sizeof(T) == 4
+                   ? beer_mfma::estep_full_f32(nframes, D, K, (const float*)X, (const float*)expT,
+                                               (const float*)logw, (float*)comp_resps,
+                                               (float*)log_norm, llh_sum, ws, ws_bytes, s)
+                   : beer_mfma::estep_full_f64(nframes, D, K, (const double*)X,
+                                               (const double*)expT, (const double*)logw,
+                                               (double*)comp_resps, (double*)log_norm, llh_sum,
+                                               ws, ws_bytes, s);
     } else if (cov == BEER_FULL)
         rc = llh_launch<T, BEER_FULL>(nframes, D, K, X, expT, logw, stat_scale, pc_arg, w_arg, s);
     else if (cov == BEER_DIAG)
@@ -355,17 +361,20 @@ int acc_launch(int64_t nframes, int D, int S, int G, const void* X, const void* 
 
 template <typename T>
 int accumulate_launch(int cov, int64_t nframes, int D, int S, int G, const void* X,
-                      const void* cr, const void* sr, double* acc, void* stream) {
+                      const void* cr, const void* sr, double* acc, void* ws, size_t ws_bytes,
+                      void* stream) {
     BEER_REQUIRE(nframes >= 0 && D >= 1 && S >= 1 && G >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(X && acc);
     if (nframes == 0) return BEER_OK;
     hipStream_t s = as_stream(stream);
-    if (cov == BEER_FULL && beer_mfma::supported(D, S * G) && cr) {
+    if (cov == BEER_FULL && cr && ws && beer_mfma::supported_acc(D, S * G) &&
+        ws_bytes >= beer_mfma::acc_workspace_bytes(D, S * G)) {
         return sizeof(T) == 4
                    ? beer_mfma::acc_full_f32(nframes, D, S, G, (const float*)X, (const float*)cr,
-                                             (const float*)sr, acc, s)
+                                             (const float*)sr, acc, ws, ws_bytes, s)
                    : beer_mfma::acc_full_f64(nframes, D, S, G, (const double*)X,
-                                             (const double*)cr, (const double*)sr, acc, s);
+                                             (const double*)cr, (const double*)sr, acc, ws,
+                                             ws_bytes, s);
     }
     if (cov == BEER_FULL) return acc_launch<T, BEER_FULL>(nframes, D, S, G, X, cr, sr, acc, s);
     if (cov == BEER_DIAG) return acc_launch<T, BEER_DIAG>(nframes, D, S, G, X, cr, sr, acc, s);
@@ -390,16 +399,29 @@ extern "C" {
 int beer_mixtureset_estep(int dtype, int cov, int64_t T, int D, int S, int G, const void* X,
                           const void* exp_stats, const void* log_weights,
                           const int64_t* labels, double stat_scale, void* pc_llh,
-                          void* log_norm, void* comp_resps, double* llh_sum, void* stream) {
+                          void* log_norm, void* comp_resps, double* llh_sum, void* workspace,
+                          size_t workspace_bytes, void* stream) {
     BEER_DISPATCH(dtype, estep_launch, cov, T, D, S, G, X, exp_stats, log_weights, labels,
-                  stat_scale, pc_llh, log_norm, comp_resps, llh_sum, stream);
+                  stat_scale, pc_llh, log_norm, comp_resps, llh_sum, workspace, workspace_bytes,
+                  stream);
+}
+
+size_t beer_estep_workspace_bytes(int dtype, int cov, int D, int S, int G) {
+    if (cov != BEER_FULL || S != 1) return 0;
+    return beer_mfma::estep_workspace_bytes(dtype == BEER_F64 ? 8 : 4, D, S * G);
+}
+
+size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G) {
+    (void)dtype;
+    if (cov != BEER_FULL) return 0;
+    return beer_mfma::acc_workspace_bytes(D, S * G);
 }
 
 int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G, const void* X,
                            const void* comp_resps, const void* state_resps, double* acc,
-                           void* stream) {
+                           void* workspace, size_t workspace_bytes, void* stream) {
     BEER_DISPATCH(dtype, accumulate_launch, cov, T, D, S, G, X, comp_resps, state_resps, acc,
-                  stream);
+                  workspace, workspace_bytes, stream);
 }
 
 int beer_weights_from_acc(int S, int G, int Q, const double* acc, double* out, void* stream) {

@@ -1,12 +1,511 @@
-// Placeholder until the MFMA path lands: nothing is supported, the generic
-// kernels of estep.hip serve every shape.
+// MFMA (matrix-core) E-step for full-covariance Gaussians on gfx950.
+//
+// Both halves of the E-step are GEMMs against the per-frame statistics
+// phi(x) = [x, vec(x x^T), 1], which are generated on the fly from the frame
+// and never stored:
+//
+//   K1  llh[T, K]   = PHI(X)[T, q] . P[q, K]        then row softmax (in
+//                     registers) -> responsibilities + per-frame log-norm
+//   K2  S[K, q]     = R^T[K, T] . PHI(X)[T, q]       gamma-weighted statistics
+//
+// The symmetric quadratic form is contracted over the D(D+1)/2 products
+// x_a x_b, a <= b (off-diagonal coefficients doubled), i.e. about half the
+// multiply-adds of the reference's dense [T, D^2+D+2] formulation.
+//
+// "Slab" enumeration of the contraction index (4 consecutive q = one MFMA
+// k-step of v_mfma_*_16x16x4): with xe = [x_0..x_{D-1}, 0-pad to Dp = 4*D4,
+// 1, 0, 0, 0] every slab is a pair (a, j) and its 4 entries are
+// xe[a] * xe[4j + g], g = 0..3:
+//     quadratic  a = 0..D-1, j = a/4 .. D4-1     (entries with 4j+g < a: 0)
+//     linear     a = Dp ("1"), j = 0 .. D4-1
+//     constant   a = Dp,      j = D4            -> (1, 0, 0, 0)
+// so one uniform loop covers quadratic, linear and constant terms.
+//
+// Operand mapping of v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64
+// (lane l: i = l & 15, g = l >> 4):  A[i][k=g], B[k=g][n=i], and C/D
+// row(l, r) = 4 g + r (f32) | g + 4 r (f64), col = i.
+//
+// Reference restated: beer/dists/normalwishart.py:30-38, 88-92,
+// beer/models/mixture.py:79-93, beer/models/normalset.py:117-123.
+
 #include "estep_mfma.h"
-#include "beer_hip.h"
+
+#include "common.h"
+
+using namespace beer;
 
 namespace beer_mfma {
-bool supported(int, int) { return false; }
-int llh_full_f32(int64_t, int, int, const float*, const float*, const float*, float*, hipStream_t) { return BEER_EINVAL; }
-int llh_full_f64(int64_t, int, int, const double*, const double*, const double*, double*, hipStream_t) { return BEER_EINVAL; }
-int acc_full_f32(int64_t, int, int, int, const float*, const float*, const float*, double*, hipStream_t) { return BEER_EINVAL; }
-int acc_full_f64(int64_t, int, int, int, const double*, const double*, const double*, double*, hipStream_t) { return BEER_EINVAL; }
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+    using acc_t = f32x4;
+    using vec4_t = f32x4;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int g, int r) { return 4 * g + r; }
+};
+template <> struct Mma<double> {
+    using acc_t = f64x4;
+    using vec4_t = f64x4;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int g, int r) { return g + 4 * r; }
+};
+
+__host__ __device__ inline int d4_of(int D) { return (D + 3) / 4; }
+__host__ __device__ inline int nslab_of(int D) {
+    const int D4 = d4_of(D);
+    int n = D4 + 1;                                   // linear + constant
+    for (int a = 0; a < D; ++a) n += D4 - a / 4;
+    return n;
+}
+// index of slab (a, j), a < D quadratic; a == Dp: linear/constant
+__host__ __device__ inline int slab_index(int D, int a, int j) {
+    const int D4 = d4_of(D);
+    if (a >= D) return nslab_of(D) - (D4 + 1) + j;
+    // sum_{a' < a} (D4 - a'/4): full groups of 4 then remainder
+    const int q = a / 4, r = a % 4;
+    const int before = 4 * (q * D4 - q * (q - 1) / 2) + r * (D4 - q);
+    return before + (j - q);
+}
+
+constexpr int kThreads = 256;
+constexpr double kPadLogit = -1.0e30;
+
+// ---------------------------------------------------------------------------
+// Parameter packing: E[T] [K, Q] (+ log weights) -> P[nslab][64 lanes][NT]
+// (each lane's NT B-fragment values contiguous) and the slab table
+// tab[s] = a | (4j << 8).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_kernel(int D, int K, int NT, const T* __restrict__ E,
+                            const T* __restrict__ logw, T* __restrict__ P,
+                            int* __restrict__ tab) {
+    const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(D);
+    const int Q = D * D + D + 2;
+    const int64_t total = (int64_t)nslab * 64 * NT;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % NT);
+        const int lane = (int)((idx / NT) % 64);
+        const int s = (int)(idx / ((int64_t)NT * 64));
+        const int i = lane & 15, g = lane >> 4;
+        const int k = c * 16 + i;
+        // decode slab s -> (a, j)
+        int a, j;
+        const int nq = nslab - (D4 + 1);
+        if (s >= nq) { a = Dp; j = s - nq; }
+        else {
+            // invert slab_index: walk groups (cheap: D4 <= 16)
+            int rem = s; a = 0;
+            for (;;) { const int len = D4 - a / 4; if (rem < len) break; rem -= len; ++a; }
+            j = a / 4 + rem;
+        }
+        if (c == 0 && lane == 0) tab[s] = a | ((4 * j) << 8);
+        const int b = 4 * j + g;
+        double v = 0.0;
+        if (k < K) {
+            const T* e = E + (size_t)k * Q;
+            if (a < D) {
+                if (b < D && b >= a)
+                    v = (b == a) ? -0.5 * (double)e[D + a * D + a]
+                                 : -0.5 * ((double)e[D + a * D + b] + (double)e[D + b * D + a]);
+            } else if (j < D4) {
+                if (b < D) v = (double)e[b];
+            } else if (g == 0) {
+                v = -0.5 * (double)e[Q - 2] + 0.5 * (double)e[Q - 1] - 0.5 * (double)D * kLog2Pi +
+                    (logw ? (double)logw[k] : 0.0);
+            }
+        } else if (a == Dp && j == D4 && g == 0) {
+            v = kPadLogit;                          // padded component: exp() -> 0
+        }
+        P[idx] = (T)v;
+    }
+}
+
+__global__ void tab_kernel(int D, int* __restrict__ tab) {
+    const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(D);
+    const int nq = nslab - (D4 + 1);
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nslab; s += gridDim.x * blockDim.x) {
+        int a, j;
+        if (s >= nq) { a = Dp; j = s - nq; }
+        else {
+            int rem = s; a = 0;
+            for (;;) { const int len = D4 - a / 4; if (rem < len) break; rem -= len; ++a; }
+            j = a / 4 + rem;
+        }
+        tab[s] = a | ((4 * j) << 8);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1: fused log-likelihood GEMM + softmax.  One wave owns 16*MT frames and
+// all K (<= 16*NT) components.
+// ---------------------------------------------------------------------------
+template <typename T, int NT, int MT>
+__global__ __launch_bounds__(kThreads) void llh_kernel(
+    int64_t nframes, int D, int K, int nslab, const T* __restrict__ X,
+    const T* __restrict__ P, const int* __restrict__ tab, T* __restrict__ resps,
+    T* __restrict__ log_norm, double* __restrict__ llh_sum) {
+    using M = Mma<T>;
+    using acc_t = typename M::acc_t;
+    using vec4_t = typename M::vec4_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D4 = d4_of(D), Dp = 4 * D4, LD = Dp + 5;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    constexpr int FW = 16 * MT;                       // frames per wave
+    T* xw = reinterpret_cast<T*>(smem) + wave * (FW * LD);
+    const int64_t fb = ((int64_t)blockIdx.x * (kThreads / 64) + wave) * FW;
+
+    for (int idx = lane; idx < FW * LD; idx += 64) {
+        const int r = idx / LD, c = idx - r * LD;
+        const int64_t f = fb + r;
+        T v = 0;
+        if (c < D) { if (f < nframes) v = X[f * D + c]; }
+        else if (c == Dp) v = 1;
+        xw[idx] = v;
+    }
+    __syncthreads();
+
+    acc_t acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[m][c] = acc_t{0, 0, 0, 0};
+
+    const T* xrow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xrow[m] = xw + (m * 16 + i) * LD;
+
+    const vec4_t* Pl = reinterpret_cast<const vec4_t*>(P) + (size_t)lane * (NT / 4);
+    for (int s = 0; s < nslab; ++s) {
+        const int t = tab[s];
+        const int a = t & 0xff, jb = t >> 8;
+        vec4_t b4[NT / 4];
+#pragma unroll
+        for (int c4 = 0; c4 < NT / 4; ++c4) b4[c4] = Pl[(size_t)s * 64 * (NT / 4) + c4];
+        T av[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = xrow[m][a] * xrow[m][jb + g];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const T bv = b4[c / 4][c % 4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][c] = M::mma(av[m], bv, acc[m][c]);
+        }
+    }
+
+    // ---- epilogue: per-frame logsumexp over the K components ----
+    double llh_local = 0.0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            T mx = acc[m][0][r];
+#pragma unroll
+            for (int c = 1; c < NT; ++c) mx = acc[m][c][r] > mx ? acc[m][c][r] : mx;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const T w = __shfl_xor(mx, o, 64);
+                mx = w > mx ? w : mx;
+            }
+            T sum = 0;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) sum += exp(acc[m][c][r] - mx);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            const T lse = mx + log(sum);
+            const int64_t f = fb + m * 16 + M::row(g, r);
+            if (f < nframes) {
+                if (resps) {
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {
+                        const int k = c * 16 + i;
+                        if (k < K) resps[f * K + k] = exp(acc[m][c][r] - lse);
+                    }
+                }
+                if (i == 0) {
+                    if (log_norm) log_norm[f] = lse;
+                    llh_local += (double)lse;
+                }
+            }
+        }
+    }
+    if (llh_sum) {
+        llh_local = wave_sum(llh_local);
+        if (lane == 0) atomicAdd(llh_sum, llh_local);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2: S[k, q] += sum_t r[t,k] * PHI_q(x_t).  Workgroup tile: 64 components x
+// 64 slabs (256 q), 4 waves splitting the q range; grid.z splits the frames.
+// Two-level fp32 accumulation (MFMA chain over kFlush frames, then a VALU
+// add into a second register set) keeps the rounding error at the 1e-7
+// level; the cross-workgroup reduction is fp64 atomics.
+// ---------------------------------------------------------------------------
+constexpr int kAccMC = 4;        // component tiles per wave (shared by the 4 waves)
+constexpr int kAccNQ = 4;        // q tiles (of 16) per wave
+constexpr int kAccFT = 64;       // frames per LDS tile
+constexpr int kFlush = 256;      // frames per MFMA accumulation chain
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void acc_kernel(
+    int64_t nframes, int D, int K, int G, int S, int nslab, const T* __restrict__ X,
+    const T* __restrict__ R, const T* __restrict__ SR, const int* __restrict__ tab,
+    int64_t frames_per_block, double* __restrict__ Sp) {
+    using M = Mma<T>;
+    using acc_t = typename M::acc_t;
+    using vec4_t = typename M::vec4_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D4 = d4_of(D), Dp = 4 * D4, LD = Dp + 5;
+    T* xs = reinterpret_cast<T*>(smem);                      // [kAccFT][LD]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int kc0 = blockIdx.y * (16 * kAccMC);
+    const int u0 = (blockIdx.x * (kThreads / 64) + wave) * kAccNQ;     // first q tile
+    const int64_t tb = (int64_t)blockIdx.z * frames_per_block;
+    const int64_t te = min(nframes, tb + frames_per_block);
+    const int nq = nslab * 4;
+
+    // LDS columns of the two factors of this lane's statistic in each q tile
+    int ca[kAccNQ], cb[kAccNQ];
+#pragma unroll
+    for (int uu = 0; uu < kAccNQ; ++uu) {
+        const int slab = 4 * (u0 + uu) + (i >> 2);
+        if (slab < nslab) {
+            const int t = tab[slab];
+            ca[uu] = t & 0xff;
+            cb[uu] = (t >> 8) + (i & 3);
+        } else {
+            ca[uu] = cb[uu] = Dp + 1;                         // a zero column
+        }
+    }
+    // fp32: second-level accumulators (see above); fp64 needs none.
+    constexpr bool kTwoLevel = sizeof(T) == 4;
+    acc_t acc[kAccMC][kAccNQ], mid[kTwoLevel ? kAccMC : 1][kTwoLevel ? kAccNQ : 1];
+#pragma unroll
+    for (int c = 0; c < kAccMC; ++c)
+#pragma unroll
+        for (int uu = 0; uu < kAccNQ; ++uu) {
+            acc[c][uu] = acc_t{0, 0, 0, 0};
+            if (kTwoLevel) mid[c][uu] = acc_t{0, 0, 0, 0};
+        }
+
+    const bool comps_ok = (kc0 + 4 * i + 3) < K;
+    int since_flush = 0;
+    for (int64_t t0 = tb; t0 < te; t0 += kAccFT) {
+        __syncthreads();
+        for (int idx = tid; idx < kAccFT * LD; idx += kThreads) {
+            const int r = idx / LD, c = idx - r * LD;
+            const int64_t f = t0 + r;
+            T v = 0;
+            if (c < D) { if (f < te) v = X[f * D + c]; }
+            else if (c == Dp) v = 1;
+            xs[idx] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < kAccFT / 4; ++kk) {
+            const int64_t f = t0 + 4 * kk + g;
+            vec4_t a4 = vec4_t{0, 0, 0, 0};
+            if (f < te && comps_ok) {
+                a4 = *reinterpret_cast<const vec4_t*>(R + f * K + kc0 + 4 * i);
+                if (SR) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a4[c] *= SR[f * S + (kc0 + 4 * i + c) / G];
+                }
+            }
+            const T* xr = xs + (4 * kk + g) * LD;
+            T bq[kAccNQ];
+#pragma unroll
+            for (int uu = 0; uu < kAccNQ; ++uu) bq[uu] = xr[ca[uu]] * xr[cb[uu]];
+#pragma unroll
+            for (int c = 0; c < kAccMC; ++c)
+#pragma unroll
+                for (int uu = 0; uu < kAccNQ; ++uu)
+                    acc[c][uu] = M::mma(a4[c], bq[uu], acc[c][uu]);
+        }
+        since_flush += kAccFT;
+        if (kTwoLevel && since_flush >= kFlush) {
+            since_flush = 0;
+#pragma unroll
+            for (int c = 0; c < kAccMC; ++c)
+#pragma unroll
+                for (int uu = 0; uu < kAccNQ; ++uu) {
+                    mid[c][uu] += acc[c][uu];
+                    acc[c][uu] = acc_t{0, 0, 0, 0};
+                }
+        }
+    }
+    // rows of the C tile are component slots i' -> component kc0 + 4 i' + c
+#pragma unroll
+    for (int c = 0; c < kAccMC; ++c)
+#pragma unroll
+        for (int uu = 0; uu < kAccNQ; ++uu) {
+            const int q = (u0 + uu) * 16 + i;
+            if (q >= nq) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = kc0 + 4 * M::row(g, r) + c;
+                if (k < K)
+                    atomicAdd(Sp + (size_t)k * nq + q,
+                              kTwoLevel ? (double)(mid[c][uu][r] + acc[c][uu][r])
+                                        : (double)acc[c][uu][r]);
+            }
+        }
+}
+
+// Sp [K][nslab*4] (packed symmetric sums) -> acc [K][Q] += in the reference's
+// layout [sum r x, -.5 sum r x x^T (dense D x D), -.5 N, +.5 N].
+__global__ void unpack_kernel(int D, int K, const double* __restrict__ Sp,
+                              double* __restrict__ acc) {
+    const int D4 = d4_of(D), Dp = 4 * D4, nq = nslab_of(D) * 4;
+    const int Q = D * D + D + 2;
+    const int64_t total = (int64_t)K * Q;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx / Q), q = (int)(idx % Q);
+        const double* s = Sp + (size_t)k * nq;
+        double v;
+        if (q < D) {
+            v = s[slab_index(D, Dp, q / 4) * 4 + q % 4];
+        } else if (q < D + D * D) {
+            int a = (q - D) / D, b = (q - D) % D;
+            if (a > b) { const int t = a; a = b; b = t; }
+            v = -0.5 * s[slab_index(D, a, b / 4) * 4 + b % 4];
+        } else {
+            const double n = s[slab_index(D, Dp, D4) * 4];
+            v = (q == Q - 2) ? -0.5 * n : 0.5 * n;
+        }
+        acc[idx] += v;
+    }
+}
+
+template <typename T>
+size_t align_up(size_t n) { return (n + 255) / 256 * 256; }
+
+inline int nt_for(int K) { return K <= 64 ? 4 : (K <= 128 ? 8 : 16); }
+
+template <typename T, int NT, int MT>
+int launch_llh(int64_t nframes, int D, int K, int nslab, const T* X, const T* P, const int* tab,
+               T* resps, T* log_norm, double* llh_sum, hipStream_t s) {
+    const int D4 = d4_of(D), LD = 4 * D4 + 5;
+    constexpr int FB = 16 * MT * (kThreads / 64);
+    const size_t lds = (size_t)FB * LD * sizeof(T);
+    const int64_t blocks = (nframes + FB - 1) / FB;
+    hipLaunchKernelGGL((llh_kernel<T, NT, MT>), dim3((unsigned)blocks), dim3(kThreads), lds, s,
+                       nframes, D, K, nslab, X, P, tab, resps, log_norm, llh_sum);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+template <typename T>
+int estep_impl(int64_t nframes, int D, int K, const T* X, const T* expT, const T* logw,
+               T* resps, T* log_norm, double* llh_sum, void* ws, size_t ws_bytes,
+               hipStream_t s) {
+    if (!supported_llh(D, K) || ws_bytes < estep_workspace_bytes(sizeof(T), D, K)) return BEER_EINVAL;
+    const int NT = nt_for(K), nslab = nslab_of(D);
+    T* P = reinterpret_cast<T*>(ws);
+    int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) +
+                                      align_up<T>((size_t)nslab * 64 * NT * sizeof(T)));
+    const int64_t total = (int64_t)nslab * 64 * NT;
+    hipLaunchKernelGGL(pack_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, D,
+                       K, NT, expT, logw, P, tab);
+    BEER_LAUNCH_CHECK();
+    constexpr int MT = sizeof(T) == 4 ? 2 : 1;
+    if (NT == 4) return launch_llh<T, 4, MT>(nframes, D, K, nslab, X, P, tab, resps, log_norm, llh_sum, s);
+    if (NT == 8) return launch_llh<T, 8, MT>(nframes, D, K, nslab, X, P, tab, resps, log_norm, llh_sum, s);
+    return launch_llh<T, 16, MT>(nframes, D, K, nslab, X, P, tab, resps, log_norm, llh_sum, s);
+}
+
+template <typename T>
+int acc_impl(int64_t nframes, int D, int S, int G, const T* X, const T* R, const T* SR,
+             double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
+    const int K = S * G;
+    if (!supported_acc(D, K) || ws_bytes < acc_workspace_bytes(D, K)) return BEER_EINVAL;
+    const int nslab = nslab_of(D), nq = nslab * 4;
+    double* Sp = reinterpret_cast<double*>(ws);
+    int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) +
+                                      align_up<T>((size_t)K * nq * sizeof(double)));
+    hipLaunchKernelGGL(tab_kernel, dim3(1), dim3(256), 0, s, D, tab);
+    BEER_LAUNCH_CHECK();
+    hipError_t e = hipMemsetAsync(Sp, 0, (size_t)K * nq * sizeof(double), s);
+    if (e != hipSuccess) return -(int)e;
+    const int gx = (nslab + 4 * kAccNQ * (kThreads / 64) - 1) / (4 * kAccNQ * (kThreads / 64));
+    const int gy = (K + 16 * kAccMC - 1) / (16 * kAccMC);
+    int64_t gz = (1024 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy);
+    const int64_t max_z = (nframes + 1023) / 1024;
+    if (gz > max_z) gz = max_z;
+    if (gz < 1) gz = 1;
+    int64_t fpb = (nframes + gz - 1) / gz;
+    fpb = (fpb + kAccFT - 1) / kAccFT * kAccFT;
+    gz = (nframes + fpb - 1) / fpb;
+    const int LD = 4 * d4_of(D) + 5;
+    const size_t lds = (size_t)kAccFT * LD * sizeof(T);
+    hipLaunchKernelGGL(acc_kernel<T>, dim3(gx, gy, (unsigned)gz), dim3(kThreads), lds, s, nframes,
+                       D, K, G, S, nslab, X, R, SR, tab, fpb, Sp);
+    BEER_LAUNCH_CHECK();
+    const int64_t total = (int64_t)K * (D * D + D + 2);
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, D, K,
+                       Sp, acc);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+}  // namespace
+
+bool supported_llh(int D, int K) {
+    // 8-bit slab-table fields: Dp + 4 <= 255; K <= 256 keeps a whole softmax
+    // row inside one wave's accumulators (padded to 64 / 128 / 256 columns).
+    return D >= 1 && D <= 64 && K >= 16 && K <= 256;
+}
+
+bool supported_acc(int D, int K) {
+    return D >= 1 && D <= 64 && K >= 16 && K % 4 == 0;
+}
+
+size_t estep_workspace_bytes(size_t elem, int D, int K) {
+    if (!supported_llh(D, K)) return 0;
+    const int nslab = nslab_of(D);
+    return (size_t)(((size_t)nslab * 64 * nt_for(K) * elem + 255) / 256 * 256) +
+           (size_t)nslab * sizeof(int) + 256;
+}
+
+size_t acc_workspace_bytes(int D, int K) {
+    if (!supported_acc(D, K)) return 0;
+    const int nslab = nslab_of(D);
+    return (size_t)(((size_t)K * nslab * 4 * sizeof(double) + 255) / 256 * 256) +
+           (size_t)nslab * sizeof(int) + 256;
+}
+
+int estep_full_f32(int64_t T, int D, int K, const float* X, const float* expT, const float* logw,
+                   float* resps, float* log_norm, double* llh_sum, void* ws, size_t ws_bytes,
+                   hipStream_t s) {
+    return estep_impl<float>(T, D, K, X, expT, logw, resps, log_norm, llh_sum, ws, ws_bytes, s);
+}
+int estep_full_f64(int64_t T, int D, int K, const double* X, const double* expT,
+                   const double* logw, double* resps, double* log_norm, double* llh_sum,
+                   void* ws, size_t ws_bytes, hipStream_t s) {
+    return estep_impl<double>(T, D, K, X, expT, logw, resps, log_norm, llh_sum, ws, ws_bytes, s);
+}
+int acc_full_f32(int64_t T, int D, int S, int G, const float* X, const float* R, const float* SR,
+                 double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
+    return acc_impl<float>(T, D, S, G, X, R, SR, acc, ws, ws_bytes, s);
+}
+int acc_full_f64(int64_t T, int D, int S, int G, const double* X, const double* R,
+                 const double* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
+    return acc_impl<double>(T, D, S, G, X, R, SR, acc, ws, ws_bytes, s);
+}
+
 }  // namespace beer_mfma

@@ -31,7 +31,7 @@ def normal_llh(stats, exp_stats, cov_type):
     out = torch.empty(T, K, dtype=X.dtype, device=X.device)
     _hip.call('beer_mixtureset_estep', _hip.dtype_code(X.dtype), _hip.COV_CODE[cov_type],
               T, D, K, 1, _hip.ptr(X), _hip.ptr(E), None, None, st.scale,
-              _hip.ptr(out), None, None, None)
+              _hip.ptr(out), None, None, None, None, 0)
     return out
 
 
@@ -53,9 +53,12 @@ def mixtureset_estep(stats, exp_stats, log_weights, S, G, cov_type, labels=None,
     lab = None
     if labels is not None:
         lab = _hip.on_device(torch.as_tensor(labels)).to(torch.int64).contiguous()
+    ws, ws_bytes = _hip.workspace('beer_estep_workspace_bytes', X.dtype,
+                                  _hip.COV_CODE[cov_type], D, S, G, X.device)
     _hip.call('beer_mixtureset_estep', _hip.dtype_code(X.dtype), _hip.COV_CODE[cov_type],
               T, D, S, G, _hip.ptr(X), _hip.ptr(E), _hip.ptr(lw), _hip.ptr(lab), st.scale,
-              None, _hip.ptr(log_norm), _hip.ptr(resps), _hip.ptr(llh_sum))
+              None, _hip.ptr(log_norm), _hip.ptr(resps), _hip.ptr(llh_sum), _hip.ptr(ws),
+              ws_bytes)
     return log_norm, resps
 
 
@@ -73,8 +76,11 @@ def normal_accumulate(stats, comp_resps, state_resps, S, G, cov_type, acc=None):
         acc = torch.zeros(K, Q, dtype=torch.float64, device=X.device)
     cr = None if comp_resps is None else _hip.on_device(comp_resps, X.dtype)
     sr = None if state_resps is None else _hip.on_device(state_resps, X.dtype)
+    ws, ws_bytes = _hip.workspace('beer_accumulate_workspace_bytes', X.dtype,
+                                  _hip.COV_CODE[cov_type], D, S, G, X.device)
     _hip.call('beer_normal_accumulate', _hip.dtype_code(X.dtype), _hip.COV_CODE[cov_type],
-              T, D, S, G, _hip.ptr(X), _hip.ptr(cr), _hip.ptr(sr), _hip.ptr(acc))
+              T, D, S, G, _hip.ptr(X), _hip.ptr(cr), _hip.ptr(sr), _hip.ptr(acc),
+              _hip.ptr(ws), ws_bytes)
     return acc
 
 

@@ -29,6 +29,7 @@
 #ifndef BEER_HIP_H
 #define BEER_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -175,7 +176,16 @@ int beer_mixtureset_estep(int dtype, int cov, int64_t T, int D, int S, int G,
                           const void* X, const void* exp_stats,
                           const void* log_weights, const int64_t* labels,
                           double stat_scale, void* pc_llh, void* log_norm,
-                          void* comp_resps, double* llh_sum, void* stream);
+                          void* comp_resps, double* llh_sum, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* Scratch the matrix-core (MFMA) implementations of the two calls around
+ * this comment need (packed parameter / partial-sum images).  0 = the shape
+ * has no MFMA implementation.  With `workspace` NULL or too small the calls
+ * run the generic kernels -- same results, slower.  The workspace holds no
+ * state between calls. */
+size_t beer_estep_workspace_bytes(int dtype, int cov, int D, int S, int G);
+size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G);
 
 /* gamma-weighted sufficient statistics (N_k, sum r x, sum r xx^T) packed as
  * the reference packs them, [K,Q] = resps^T @ phi(X), accumulated (+=) in
@@ -185,7 +195,8 @@ int beer_mixtureset_estep(int dtype, int cov, int64_t T, int D, int S, int G,
  * `state_resps` [T,S] nullable (= 1), `comp_resps` [T,K] nullable (= 1). */
 int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G,
                            const void* X, const void* comp_resps,
-                           const void* state_resps, double* acc, void* stream);
+                           const void* state_resps, double* acc, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* Mixture-weight statistics from the accumulated Gaussian statistics: the
  * zero-order count is N_k = -2 * acc[k, Q-2]; out[s,g] = N_{s,g} for

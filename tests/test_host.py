@@ -22,7 +22,7 @@ HAS_GPU = torch.cuda.is_available()
 
 def _declared():
     text = open(os.path.join(ROOT, 'include', 'beer_hip.h')).read()
-    return sorted(set(re.findall(r'^int (beer_\w+)\(', text, flags=re.M)))
+    return sorted(set(re.findall(r'^(?:int|size_t) (beer_\w+)\(', text, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 35
     for name in names:
         assert hasattr(lib, name), f'{name} is declared but not exported'
-    assert sorted(_hip.SIGNATURES) == names, 'ctypes table and header disagree'
+    assert sorted(list(_hip.SIGNATURES) + list(_hip.SIZE_QUERIES)) == names, \
+        'ctypes table and header disagree'
     assert lib.beer_hip_version() >= 100
 
 

@@ -329,3 +329,22 @@ def test_g9_bookkeeping():
     for arr, ref in zip(post2, std_params(g, 'it1_lr03.p0.posterior')):
         assert_close(arr.reshape(ref.shape), ref, 1e-9)
     assert_close(w2, g['it1_lr03.p1.posterior.concentrations'], 1e-9)
+
+
+# --- the torch-CPU timing port agrees with the numpy oracle ------------------------
+
+def test_torch_port_matches_oracle():
+    import torch
+    from oracle import torch_port as tp
+    g = load_golden('g02_gmm_full')
+    X = g['X']
+    post, prior = std_params(g, 'init.p0.posterior'), std_params(g, 'init.p0.prior')
+    (w_post,), (w_prior,) = std_params(g, 'init.p1.posterior'), std_params(g, 'init.p1.prior')
+    tt = lambda arrs: tuple(torch.from_numpy(a.copy()) for a in arrs)
+    value, new_post, new_w = tp.gmm_iteration(torch.from_numpy(X), tt(post), tt(prior),
+                                              torch.from_numpy(w_post.copy()),
+                                              torch.from_numpy(w_prior.copy()), chunk=len(X))
+    assert_close(value, g['elbos'][0], 1e-10, 'torch port elbo vs reference')
+    for arr, ref in zip(new_post, std_params(g, 'it0.p0.posterior')):
+        assert_close(arr.numpy().reshape(ref.shape), ref, 1e-8)
+    assert_close(new_w.numpy(), g['it0.p1.posterior.concentrations'], 1e-10)
