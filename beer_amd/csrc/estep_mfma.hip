@@ -76,6 +76,10 @@ __host__ __device__ inline int slab_index(int D, int a, int j) {
     return before + (j - q);
 }
 
+// slabs in the packed parameter image: an even count (the K1 loop is unrolled
+// by two) plus one look-ahead slab, all zero beyond nslab_of(D).
+__host__ __device__ inline int nslab_padded(int D) { return (nslab_of(D) + 1) / 2 * 2 + 1; }
+
 constexpr int kThreads = 256;
 constexpr double kPadLogit = -1.0e30;
 
@@ -90,7 +94,7 @@ __global__ void pack_kernel(int D, int K, int NT, const T* __restrict__ E,
                             int* __restrict__ tab) {
     const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(D);
     const int Q = D * D + D + 2;
-    const int64_t total = (int64_t)nslab * 64 * NT;
+    const int64_t total = (int64_t)nslab_padded(D) * 64 * NT;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % NT);
@@ -98,6 +102,11 @@ __global__ void pack_kernel(int D, int K, int NT, const T* __restrict__ E,
         const int s = (int)(idx / ((int64_t)NT * 64));
         const int i = lane & 15, g = lane >> 4;
         const int k = c * 16 + i;
+        if (s >= nslab) {                           // look-ahead padding: zero slabs
+            if (c == 0 && lane == 0) tab[s] = (Dp + 1) | ((Dp) << 8);
+            P[idx] = (T)0;
+            continue;
+        }
         // decode slab s -> (a, j)
         int a, j;
         const int nq = nslab - (D4 + 1);
@@ -186,22 +195,47 @@ __global__ __launch_bounds__(kThreads) void llh_kernel(
 #pragma unroll
     for (int m = 0; m < MT; ++m) xrow[m] = xw + (m * 16 + i) * LD;
 
+    // Software pipeline: everything slab s+1 needs (its B fragments from the
+    // packed parameter image, its two x factors from LDS, its table entry) is
+    // fetched while the MFMAs of slab s run.  P and tab are padded with zero
+    // slabs up to an even count + 1, so the look-ahead never branches.
     const vec4_t* Pl = reinterpret_cast<const vec4_t*>(P) + (size_t)lane * (NT / 4);
-    for (int s = 0; s < nslab; ++s) {
+    auto fetch = [&](int s, vec4_t (&b4)[NT / 4], T (&xa)[MT], T (&xb)[MT]) {
         const int t = tab[s];
-        const int a = t & 0xff, jb = t >> 8;
-        vec4_t b4[NT / 4];
+        const int a = t & 0xff, jb = (t >> 8) + g;
 #pragma unroll
         for (int c4 = 0; c4 < NT / 4; ++c4) b4[c4] = Pl[(size_t)s * 64 * (NT / 4) + c4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { xa[m] = xrow[m][a]; xb[m] = xrow[m][jb]; }
+    };
+    auto compute = [&](const vec4_t (&b4)[NT / 4], const T (&xa)[MT], const T (&xb)[MT]) {
         T av[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) av[m] = xrow[m][a] * xrow[m][jb + g];
+        for (int m = 0; m < MT; ++m) av[m] = xa[m] * xb[m];
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
             const T bv = b4[c / 4][c % 4];
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m][c] = M::mma(av[m], bv, acc[m][c]);
         }
+    };
+    vec4_t b0[NT / 4], b1[NT / 4];
+    T xa0[MT], xb0[MT], xa1[MT], xb1[MT];
+    fetch(0, b0, xa0, xb0);
+    for (int s = 0; s < nslab; s += 2) {           // nslab_padded is even
+        // sched_group_barrier: issue the look-ahead loads BEFORE the MFMA block
+        // (hipcc otherwise sinks them next to their first use and exposes the
+        // whole L2 latency on every slab).
+        fetch(s + 1, b1, xa1, xb1);
+        compute(b0, xa0, xb0);
+        __builtin_amdgcn_sched_group_barrier(0x020, NT / 4, 0);     // VMEM reads
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);     // DS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);    // MFMA
+        fetch(s + 2, b0, xa0, xb0);
+        compute(b1, xa1, xb1);
+        __builtin_amdgcn_sched_group_barrier(0x020, NT / 4, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 1);
     }
 
     // ---- epilogue: per-frame logsumexp over the K components ----
@@ -259,7 +293,7 @@ constexpr int kAccFT = 64;       // frames per LDS tile
 constexpr int kFlush = 256;      // frames per MFMA accumulation chain
 
 template <typename T>
-__global__ __launch_bounds__(kThreads) void acc_kernel(
+__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
     int64_t nframes, int D, int K, int G, int S, int nslab, const T* __restrict__ X,
     const T* __restrict__ R, const T* __restrict__ SR, const int* __restrict__ tab,
     int64_t frames_per_block, double* __restrict__ Sp) {
@@ -267,29 +301,39 @@ __global__ __launch_bounds__(kThreads) void acc_kernel(
     using acc_t = typename M::acc_t;
     using vec4_t = typename M::vec4_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int D4 = d4_of(D), Dp = 4 * D4, LD = Dp + 5;
-    T* xs = reinterpret_cast<T*>(smem);                      // [kAccFT][LD]
+    const int Dp = 4 * d4_of(D);
+    constexpr int RC = 16 * kAccMC;                          // components per workgroup
+    // LDS, two buffers of { x tile [kAccFT][D] (raw rows), 1, 0, pad; r tile [kAccFT][RC] }
+    const int xs_elems = (kAccFT * D + 2 + 3) / 4 * 4;
+    const int buf_elems = xs_elems + kAccFT * RC;
+    T* const lds = reinterpret_cast<T*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int kc0 = blockIdx.y * (16 * kAccMC);
+    const int kc0 = blockIdx.y * RC;
     const int u0 = (blockIdx.x * (kThreads / 64) + wave) * kAccNQ;     // first q tile
     const int64_t tb = (int64_t)blockIdx.z * frames_per_block;
     const int64_t te = min(nframes, tb + frames_per_block);
     const int nq = nslab * 4;
 
-    // LDS columns of the two factors of this lane's statistic in each q tile
-    int ca[kAccNQ], cb[kAccNQ];
+    // The two factors of this lane's statistic in each of its q tiles, as LDS
+    // offsets: a real column c is relative to the frame's row (mask = ~0), the
+    // constants 1 / 0 live once per buffer behind the rows (mask = 0).
+    int ca[kAccNQ], cb[kAccNQ], ma[kAccNQ], mb[kAccNQ];
+    const int one_off = kAccFT * D, zero_off = kAccFT * D + 1;
 #pragma unroll
     for (int uu = 0; uu < kAccNQ; ++uu) {
         const int slab = 4 * (u0 + uu) + (i >> 2);
+        int a = Dp + 1, b = Dp + 1;
         if (slab < nslab) {
             const int t = tab[slab];
-            ca[uu] = t & 0xff;
-            cb[uu] = (t >> 8) + (i & 3);
-        } else {
-            ca[uu] = cb[uu] = Dp + 1;                         // a zero column
+            a = t & 0xff;
+            b = (t >> 8) + (i & 3);
         }
+        ma[uu] = a < D ? -1 : 0;
+        ca[uu] = a < D ? a : (a == Dp ? one_off : zero_off);
+        mb[uu] = b < D ? -1 : 0;
+        cb[uu] = b < D ? b : (b == Dp ? one_off : zero_off);
     }
     // fp32: second-level accumulators (see above); fp64 needs none.
     constexpr bool kTwoLevel = sizeof(T) == 4;
@@ -302,34 +346,74 @@ __global__ __launch_bounds__(kThreads) void acc_kernel(
             if (kTwoLevel) mid[c][uu] = acc_t{0, 0, 0, 0};
         }
 
-    const bool comps_ok = (kc0 + 4 * i + 3) < K;
-    int since_flush = 0;
-    for (int64_t t0 = tb; t0 < te; t0 += kAccFT) {
-        __syncthreads();
-        for (int idx = tid; idx < kAccFT * LD; idx += kThreads) {
-            const int r = idx / LD, c = idx - r * LD;
-            const int64_t f = t0 + r;
-            T v = 0;
-            if (c < D) { if (f < te) v = X[f * D + c]; }
-            else if (c == Dp) v = 1;
-            xs[idx] = v;
+    // Staging registers: the next tile is loaded from global memory while the
+    // MFMAs of the current tile run, then written to the other LDS buffer.
+    constexpr int XPT = kAccFT * 64 / kThreads;                     // D <= 64
+    constexpr int RPT = kAccFT * RC / 4 / kThreads;                 // vec4 per thread
+    const int xcount = kAccFT * D;
+    T xreg[XPT];
+    vec4_t rreg[RPT];
+    auto load_tile = [&](int64_t t0) {
+        const T* xsrc = X + t0 * D;
+        const int64_t xvalid = (te - t0) * D;
+#pragma unroll
+        for (int v = 0; v < XPT; ++v) {
+            const int idx = tid + v * kThreads;
+            xreg[v] = (idx < xcount && idx < xvalid) ? xsrc[idx] : (T)0;
         }
-        __syncthreads();
-#pragma unroll 4
-        for (int kk = 0; kk < kAccFT / 4; ++kk) {
-            const int64_t f = t0 + 4 * kk + g;
-            vec4_t a4 = vec4_t{0, 0, 0, 0};
-            if (f < te && comps_ok) {
-                a4 = *reinterpret_cast<const vec4_t*>(R + f * K + kc0 + 4 * i);
+#pragma unroll
+        for (int v = 0; v < RPT; ++v) {
+            const int e = tid + v * kThreads;
+            const int r = e / (RC / 4), c4 = e % (RC / 4);
+            const int64_t f = t0 + r;
+            vec4_t val = vec4_t{0, 0, 0, 0};
+            const int k = kc0 + 4 * c4;
+            if (f < te && k + 3 < K) {
+                val = *reinterpret_cast<const vec4_t*>(R + f * K + k);
                 if (SR) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) a4[c] *= SR[f * S + (kc0 + 4 * i + c) / G];
+                    for (int c = 0; c < 4; ++c) val[c] *= SR[f * S + (k + c) / G];
                 }
             }
-            const T* xr = xs + (4 * kk + g) * LD;
+            rreg[v] = val;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        T* xs = lds + buf * buf_elems;
+        T* rs = xs + xs_elems;
+#pragma unroll
+        for (int v = 0; v < XPT; ++v) {
+            const int idx = tid + v * kThreads;
+            if (idx < xcount) xs[idx] = xreg[v];
+        }
+#pragma unroll
+        for (int v = 0; v < RPT; ++v)
+            *reinterpret_cast<vec4_t*>(rs + (size_t)(tid + v * kThreads) * 4) = rreg[v];
+    };
+
+    if (tid < 2) {                                          // the constants, both buffers
+        lds[one_off + tid] = (T)(1 - tid);
+        lds[buf_elems + one_off + tid] = (T)(1 - tid);
+    }
+    const int64_t ntiles = (te - tb + kAccFT - 1) / kAccFT;
+    if (ntiles > 0) { load_tile(tb); store_tile(0); }
+    __syncthreads();
+    int since_flush = 0;
+    for (int64_t tile = 0; tile < ntiles; ++tile) {
+        const int buf = (int)(tile & 1);
+        const T* xs = lds + buf * buf_elems;
+        const T* rs = xs + xs_elems;
+        if (tile + 1 < ntiles) load_tile(tb + (tile + 1) * kAccFT);
+#pragma unroll 2
+        for (int kk = 0; kk < kAccFT / 4; ++kk) {
+            // A fragments: r[frame 4kk+g][component slot 4i..4i+3] -- the 64 lanes
+            // read one contiguous 1 KiB row group: conflict-free ds_read_b128.
+            const vec4_t a4 = *reinterpret_cast<const vec4_t*>(rs + (4 * kk + g) * RC + 4 * i);
+            const int xr = (4 * kk + g) * D;
             T bq[kAccNQ];
 #pragma unroll
-            for (int uu = 0; uu < kAccNQ; ++uu) bq[uu] = xr[ca[uu]] * xr[cb[uu]];
+            for (int uu = 0; uu < kAccNQ; ++uu)
+                bq[uu] = xs[(xr & ma[uu]) + ca[uu]] * xs[(xr & mb[uu]) + cb[uu]];
 #pragma unroll
             for (int c = 0; c < kAccMC; ++c)
 #pragma unroll
@@ -347,6 +431,8 @@ __global__ __launch_bounds__(kThreads) void acc_kernel(
                     acc[c][uu] = acc_t{0, 0, 0, 0};
                 }
         }
+        if (tile + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
     }
     // rows of the C tile are component slots i' -> component kc0 + 4 i' + c
 #pragma unroll
@@ -415,11 +501,11 @@ int estep_impl(int64_t nframes, int D, int K, const T* X, const T* expT, const T
                T* resps, T* log_norm, double* llh_sum, void* ws, size_t ws_bytes,
                hipStream_t s) {
     if (!supported_llh(D, K) || ws_bytes < estep_workspace_bytes(sizeof(T), D, K)) return BEER_EINVAL;
-    const int NT = nt_for(K), nslab = nslab_of(D);
+    const int NT = nt_for(K), nslab = nslab_padded(D) - 1;       // even, >= nslab_of(D)
     T* P = reinterpret_cast<T*>(ws);
     int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) +
-                                      align_up<T>((size_t)nslab * 64 * NT * sizeof(T)));
-    const int64_t total = (int64_t)nslab * 64 * NT;
+                                      align_up<T>((size_t)nslab_padded(D) * 64 * NT * sizeof(T)));
+    const int64_t total = (int64_t)nslab_padded(D) * 64 * NT;
     hipLaunchKernelGGL(pack_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, D,
                        K, NT, expT, logw, P, tab);
     BEER_LAUNCH_CHECK();
@@ -451,8 +537,10 @@ int acc_impl(int64_t nframes, int D, int S, int G, const T* X, const T* R, const
     int64_t fpb = (nframes + gz - 1) / gz;
     fpb = (fpb + kAccFT - 1) / kAccFT * kAccFT;
     gz = (nframes + fpb - 1) / fpb;
-    const int LD = 4 * d4_of(D) + 5;
-    const size_t lds = (size_t)kAccFT * LD * sizeof(T);
+    const size_t lds = 2 * ((size_t)(kAccFT * D + 2 + 3) / 4 * 4 + (size_t)kAccFT * 16 * kAccMC) *
+                       sizeof(T);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc_kernel<T>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(acc_kernel<T>, dim3(gx, gy, (unsigned)gz), dim3(kThreads), lds, s, nframes,
                        D, K, G, S, nslab, X, R, SR, tab, fpb, Sp);
     BEER_LAUNCH_CHECK();
@@ -477,7 +565,7 @@ bool supported_acc(int D, int K) {
 
 size_t estep_workspace_bytes(size_t elem, int D, int K) {
     if (!supported_llh(D, K)) return 0;
-    const int nslab = nslab_of(D);
+    const int nslab = nslab_padded(D);
     return (size_t)(((size_t)nslab * 64 * nt_for(K) * elem + 255) / 256 * 256) +
            (size_t)nslab * sizeof(int) + 256;
 }
