@@ -230,17 +230,19 @@ __global__ __launch_bounds__(kAccThreads) void accumulate_kernel(
         if (b < nkb) atomicAdd(acc + (size_t)(k0 + b) * Q + q, dacc[b]);
 }
 
-__global__ void weights_from_acc_kernel(int S, int G, int Q, const double* __restrict__ acc,
-                                        double* __restrict__ out) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
+// One wave per state; lanes stride over its G components.
+__global__ __launch_bounds__(64) void weights_from_acc_kernel(int S, int G, int Q,
+                                                              const double* __restrict__ acc,
+                                                              double* __restrict__ out) {
+    const int s = blockIdx.x, lane = threadIdx.x;
     double tot = 0.0;
-    for (int g = 0; g < G; ++g) {
+    for (int g = lane; g < G; g += 64) {
         const double n = -2.0 * acc[(size_t)(s * G + g) * Q + Q - 2];
         tot += n;
         if (g < G - 1) out[s * G + g] += n;
     }
-    out[s * G + G - 1] += tot;
+    tot = wave_sum(tot);
+    if (lane == 0) out[s * G + G - 1] += tot;
 }
 
 template <typename T>
@@ -427,7 +429,7 @@ int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G, c
 int beer_weights_from_acc(int S, int G, int Q, const double* acc, double* out, void* stream) {
     BEER_REQUIRE(S >= 0 && G >= 1 && Q >= 3 && acc && out);
     if (S == 0) return BEER_OK;
-    hipLaunchKernelGGL(weights_from_acc_kernel, dim3((S + 63) / 64), dim3(64), 0,
+    hipLaunchKernelGGL(weights_from_acc_kernel, dim3(S), dim3(64), 0,
                        as_stream(stream), S, G, Q, acc, out);
     BEER_LAUNCH_CHECK();
     return BEER_OK;

@@ -316,51 +316,56 @@ __global__ void ng_from_natural_kernel(int K, int D, const T* eta, T* mean, T* s
 // Dirichlet / Gamma: one thread per pdf.
 // ---------------------------------------------------------------------------
 
+// One wave per pdf (row); lanes stride over the G categories.
 // mode 0: E[T]; 1: natural; 2: from_natural; 3: log weights (eye @ E[T]).
 template <typename T, int MODE>
-__global__ void dirichlet_kernel(int S, int G, const T* in, T* out) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
+__global__ __launch_bounds__(64) void dirichlet_kernel(int S, int G, const T* in, T* out) {
+    const int s = blockIdx.x, lane = threadIdx.x;
     const T* c = in + (size_t)s * G;
     T* o = out + (size_t)s * G;
     if (MODE == 0 || MODE == 3) {
-        double tot = 0.0;
-        for (int g = 0; g < G; ++g) tot += (double)c[g];
+        double part = 0.0;
+        for (int g = lane; g < G; g += 64) part += (double)c[g];
+        const double tot = wave_sum(part);
         const double psi_last = digamma((double)c[G - 1]);
         const double last = psi_last - digamma(tot);
-        for (int g = 0; g < G - 1; ++g) {
+        for (int g = lane; g < G - 1; g += 64) {
             const double e = digamma((double)c[g]) - psi_last;
             o[g] = (T)(MODE == 0 ? e : e + last);
         }
-        o[G - 1] = (T)last;
+        if (lane == 0) o[G - 1] = (T)last;
     } else if (MODE == 1) {
-        double tot = 0.0;
-        for (int g = 0; g < G; ++g) {
-            tot += (double)c[g] - 1.0;
+        double part = 0.0;
+        for (int g = lane; g < G; g += 64) {
+            part += (double)c[g] - 1.0;
             if (g < G - 1) o[g] = (T)((double)c[g] - 1.0);
         }
-        o[G - 1] = (T)tot;
+        const double tot = wave_sum(part);
+        if (lane == 0) o[G - 1] = (T)tot;
     } else {
-        double tot = 0.0;
-        for (int g = 0; g < G - 1; ++g) {
-            tot += (double)c[g];
+        double part = 0.0;
+        for (int g = lane; g < G - 1; g += 64) {
+            part += (double)c[g];
             o[g] = (T)((double)c[g] + 1.0);
         }
-        o[G - 1] = (T)((double)c[G - 1] - tot + 1.0);
+        const double tot = wave_sum(part);
+        if (lane == 0) o[G - 1] = (T)((double)c[G - 1] - tot + 1.0);
     }
 }
 
 template <typename T>
-__global__ void dirichlet_log_norm_kernel(int S, int G, const T* conc, T* out) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
+__global__ __launch_bounds__(64) void dirichlet_log_norm_kernel(int S, int G, const T* conc,
+                                                                T* out) {
+    const int s = blockIdx.x, lane = threadIdx.x;
     double tot = 0.0, lg = 0.0;
-    for (int g = 0; g < G; ++g) {
+    for (int g = lane; g < G; g += 64) {
         const double c = (double)conc[(size_t)s * G + g];
         tot += c;
         lg += lgamma(c);
     }
-    out[s] = (T)(lg - lgamma(tot));
+    tot = wave_sum(tot);
+    lg = wave_sum(lg);
+    if (lane == 0) out[s] = (T)(lg - lgamma(tot));
 }
 
 // mode 0: E[T] [2n]; 1: natural [2n]; 2: from natural; 3: log_norm [1].
@@ -526,7 +531,7 @@ int dirichlet_launch(int mode, int S, int G, const void* in, void* out, void* st
     BEER_REQUIRE(S >= 0 && G >= 1);
     if (S == 0) return BEER_OK;
     hipStream_t s = as_stream(stream);
-    const dim3 g(blocks_for(S, 64)), b(64);
+    const dim3 g(S), b(64);
     switch (mode) {
         case 0: hipLaunchKernelGGL((dirichlet_kernel<T, 0>), g, b, 0, s, S, G, (const T*)in, (T*)out); break;
         case 1: hipLaunchKernelGGL((dirichlet_kernel<T, 1>), g, b, 0, s, S, G, (const T*)in, (T*)out); break;
