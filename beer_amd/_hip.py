@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libbeer_hip.so')
 
 F32, F64 = 0, 1
 FULL, DIAG, ISO = 0, 1, 2
+SEG = 8                     # BEER_SEG of include/beer_hip.h
 COV_CODE = {'full': FULL, 'diagonal': DIAG, 'isotropic': ISO}
 EINVAL = -100000
 
@@ -51,15 +52,19 @@ c_z = ctypes.c_size_t
 class Graph(ctypes.Structure):
     'beer_graph of include/beer_hip.h.'
     _fields_ = [('n_states', ctypes.c_int32), ('n_arcs', ctypes.c_int32),
+                ('n_in_seg', ctypes.c_int32), ('n_out_seg', ctypes.c_int32),
                 ('init', c_p), ('final', c_p),
-                ('in_ptr', c_p), ('in_src', c_p), ('in_w', c_p),
-                ('out_ptr', c_p), ('out_dst', c_p), ('out_w', c_p)]
+                ('in_ptr', c_p), ('in_src', c_p), ('in_dst', c_p), ('in_w', c_p),
+                ('in_seg', c_p), ('in_row_seg', c_p),
+                ('out_ptr', c_p), ('out_dst', c_p), ('out_src', c_p), ('out_w', c_p),
+                ('out_seg', c_p), ('out_row_seg', c_p)]
 
 
 class Batch(ctypes.Structure):
     'beer_batch of include/beer_hip.h.'
     _fields_ = [('nutt', ctypes.c_int32), ('max_states', ctypes.c_int32),
-                ('max_arcs', ctypes.c_int32), ('n_graphs', ctypes.c_int32),
+                ('max_arcs', ctypes.c_int32), ('max_segs', ctypes.c_int32),
+                ('reserved', ctypes.c_int32), ('n_graphs', ctypes.c_int32),
                 ('frame_off', c_p), ('llh_off', c_p), ('graph_id', c_p),
                 ('graphs', c_p), ('pdf_off', c_p), ('pdf_ids', c_p)]
 

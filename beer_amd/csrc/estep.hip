@@ -26,11 +26,15 @@ constexpr int kCompChunk = 64;      // components per workgroup
 // Lane = frame, the component's parameters are wave-uniform (scalar loads).
 // Results are staged through LDS so that global writes are row-contiguous.
 // ---------------------------------------------------------------------------
+// With `fuse_G` > 0 (G divides the component chunk) the per-state logsumexp and
+// the responsibilities are finished here, from the LDS tile, and the separate
+// normalisation pass (one more read + write of the [T, K] buffer) is skipped.
 template <typename T, int COV>
 __global__ __launch_bounds__(kLlhThreads) void llh_kernel(
     int64_t nframes, int D, int K, const T* __restrict__ X, const T* __restrict__ expT,
     const T* __restrict__ logw, double stat_scale, T* __restrict__ pc_llh,
-    T* __restrict__ w_out) {
+    T* __restrict__ w_out, int fuse_G, T* __restrict__ log_norm,
+    double* __restrict__ llh_sum) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ldx = D + 1;
     T* xs = reinterpret_cast<T*>(smem);                 // [64][D+1]
@@ -82,12 +86,47 @@ __global__ __launch_bounds__(kLlhThreads) void llh_kernel(
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < nt * nk; idx += kLlhThreads) {
-        const int t = idx / nk, kk = idx % nk;
-        const T v = outs[t * ldo + kk];
-        const size_t o = (size_t)(t0 + t) * K + k0 + kk;
-        if (pc_llh) pc_llh[o] = v;
-        if (w_out) w_out[o] = logw ? (T)(v + logw[k0 + kk]) : v;
+    if (fuse_G == 0) {
+        for (int idx = tid; idx < nt * nk; idx += kLlhThreads) {
+            const int t = idx / nk, kk = idx % nk;
+            const T v = outs[t * ldo + kk];
+            const size_t o = (size_t)(t0 + t) * K + k0 + kk;
+            if (pc_llh) pc_llh[o] = v;
+            if (w_out) w_out[o] = logw ? (T)(v + logw[k0 + kk]) : v;
+        }
+        return;
+    }
+    __shared__ double red[8];
+    const int G = fuse_G, ngrp = nk / G, S = K / G;
+    double mine = 0.0;
+    for (int idx = tid; idx < nt * ngrp; idx += kLlhThreads) {
+        const int t = idx / ngrp, grp = idx % ngrp;
+        const T* row = outs + t * ldo + grp * G;
+        const T* lw = logw ? logw + k0 + grp * G : nullptr;
+        T m = row[0] + (lw ? lw[0] : (T)0);
+        for (int gi = 1; gi < G; ++gi) {
+            const T w = row[gi] + (lw ? lw[gi] : (T)0);
+            m = w > m ? w : m;
+        }
+        T ln = m;
+        if (m != (T)-INFINITY && m != (T)INFINITY) {
+            double sum = 0.0;
+            for (int gi = 0; gi < G; ++gi)
+                sum += exp((double)(row[gi] + (lw ? lw[gi] : (T)0)) - (double)m);
+            ln = (T)((double)m + log(sum));
+        }
+        const size_t o = (size_t)(t0 + t) * K + k0 + grp * G;
+        for (int gi = 0; gi < G; ++gi) {
+            if (pc_llh) pc_llh[o + gi] = row[gi];
+            if (w_out)
+                w_out[o + gi] = (T)exp((double)(row[gi] + (lw ? lw[gi] : (T)0)) - (double)ln);
+        }
+        if (log_norm) log_norm[(size_t)(t0 + t) * S + (k0 / G) + grp] = ln;
+        mine += (double)ln;
+    }
+    if (llh_sum) {
+        const double tot = block_sum(mine, red);
+        if (threadIdx.x == 0) atomicAdd(llh_sum, tot);
     }
 }
 
@@ -261,7 +300,8 @@ __global__ void segment_sum_kernel(const int64_t* __restrict__ frame_off,
 
 template <typename T, int COV>
 int llh_launch(int64_t nframes, int D, int K, const void* X, const void* expT, const void* logw,
-               double stat_scale, void* pc_llh, void* w_out, hipStream_t s) {
+               double stat_scale, void* pc_llh, void* w_out, int fuse_G, void* log_norm,
+               double* llh_sum, hipStream_t s) {
     const size_t lds = ((size_t)kFrameTile * (D + 1) + (size_t)kFrameTile * (kCompChunk + 1)) * sizeof(T);
     const int64_t tiles = (nframes + kFrameTile - 1) / kFrameTile;
     // gridDim.x is 2^31-1 on gfx950; frames beyond that would need a loop.
@@ -269,7 +309,7 @@ int llh_launch(int64_t nframes, int D, int K, const void* X, const void* expT, c
     const dim3 grid((unsigned)tiles, (unsigned)((K + kCompChunk - 1) / kCompChunk));
     hipLaunchKernelGGL((llh_kernel<T, COV>), grid, dim3(kLlhThreads), lds, s, nframes, D, K,
                        (const T*)X, (const T*)expT, (const T*)logw, stat_scale, (T*)pc_llh,
-                       (T*)w_out);
+                       (T*)w_out, fuse_G, (T*)log_norm, llh_sum);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }
@@ -312,13 +352,25 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
                                                (const double*)expT, (const double*)logw,
                                                (double*)comp_resps, (double*)log_norm, llh_sum,
                                                ws, ws_bytes, s);
-    } else if (cov == BEER_FULL)
-        rc = llh_launch<T, BEER_FULL>(nframes, D, K, X, expT, logw, stat_scale, pc_arg, w_arg, s);
+    }
+    // generic kernels; the normalisation is fused when a component chunk holds
+    // whole states
+    const bool fuse = need_norm && !labels && (kCompChunk % G == 0) && (comp_resps || G == 1);
+    const int fuse_G = fuse ? G : 0;
+    void* ln_arg = fuse ? log_norm : nullptr;
+    double* sum_arg = fuse ? llh_sum : nullptr;
+    if (fuse && w_buf == log_norm) w_arg = nullptr;      // G == 1, no resps wanted
+    if (cov == BEER_FULL)
+        rc = llh_launch<T, BEER_FULL>(nframes, D, K, X, expT, logw, stat_scale, pc_arg, w_arg,
+                                      fuse_G, ln_arg, sum_arg, s);
     else if (cov == BEER_DIAG)
-        rc = llh_launch<T, BEER_DIAG>(nframes, D, K, X, expT, logw, stat_scale, pc_arg, w_arg, s);
+        rc = llh_launch<T, BEER_DIAG>(nframes, D, K, X, expT, logw, stat_scale, pc_arg, w_arg,
+                                      fuse_G, ln_arg, sum_arg, s);
     else
-        rc = llh_launch<T, BEER_ISO>(nframes, D, K, X, expT, logw, stat_scale, pc_arg, w_arg, s);
+        rc = llh_launch<T, BEER_ISO>(nframes, D, K, X, expT, logw, stat_scale, pc_arg, w_arg,
+                                     fuse_G, ln_arg, sum_arg, s);
     if (rc != BEER_OK) return rc;
+    if (fuse) return BEER_OK;
 
     if (labels) {
         const T* pc = (const T*)pc_arg;

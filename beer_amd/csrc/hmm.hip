@@ -25,6 +25,12 @@ constexpr int kHmmThreads = 256;
 template <typename T>
 __device__ __forceinline__ T ninf() { return (T)-INFINITY; }
 
+// exp / log of the forward-backward recursions in the model's own precision
+// (an fp64 exp costs ~8x an fp32 one on the VALU and the recursion is
+// transcendental-bound); maxima, sums and the trellis itself stay fp64.
+template <typename T> __device__ __forceinline__ double fexp(double x) { return (double)exp((T)x); }
+template <typename T> __device__ __forceinline__ double flog(double x) { return (double)log((T)x); }
+
 // ---------------------------------------------------------------------------
 // gather: pc_llhs[u][t,s] = scale * pc_all[frame_off[u]+t, pdf_ids[...]]
 // ---------------------------------------------------------------------------
@@ -81,15 +87,46 @@ __global__ void scatter_kernel(beer_batch b, int S_total, const T* __restrict__ 
 // ---------------------------------------------------------------------------
 // forward-backward
 // ---------------------------------------------------------------------------
+// The recursions are parallel over ARCS and row SEGMENTS, not states: a
+// phone-loop graph has a few states with ~P incoming (phone starts) or outgoing
+// (phone ends) arcs, and a thread-per-state loop would serialise P dependent
+// steps behind one lane.  Each log-sum-exp is five short phases over LDS:
+// partial max per segment (<= BEER_SEG arcs), max per state, p_e = exp(v_e - max)
+// per arc, partial sum per segment, sum + log per state.  The graph (CSR
+// indices as int16, weights) is copied into LDS once per utterance, so the
+// T sequential steps never touch global memory for the topology.  The
+// transition posteriors reuse the backward pass's p_e:
+//   xi_t(i,j) = p_e * gamma_t(i) / s_i,   s_i = sum_e p_e,
+// and cost no transcendental at all.
+constexpr int kFbThreads = 512;
+
+struct FbLayout {            // byte offsets into dynamic LDS, from the batch maxima
+    size_t cur, nxt, lb, mx, red, v, xi, pseg, w_in, w_out, src_in, dst_in, dst_out, src_out,
+        seg_in, rseg_in, seg_out, rseg_out, total;
+    __host__ __device__ FbLayout(int S, int A, int G, bool has_xi, size_t elem) {
+        size_t o = 0;
+        auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) / 16 * 16; return r; };
+        cur = take(8 * (size_t)S); nxt = take(8 * (size_t)S); lb = take(8 * (size_t)S);
+        mx = take(8 * (size_t)S); red = take(8 * 16);
+        v = take(8 * (size_t)A); xi = take(has_xi ? 8 * (size_t)A : 0); pseg = take(8 * (size_t)G);
+        w_in = take(elem * A); w_out = take(elem * A);
+        src_in = take(2 * (size_t)A); dst_in = take(2 * (size_t)A);
+        dst_out = take(2 * (size_t)A); src_out = take(2 * (size_t)A);
+        seg_in = take(4 * (size_t)(G + 1)); rseg_in = take(4 * (size_t)(S + 1));
+        seg_out = take(4 * (size_t)(G + 1)); rseg_out = take(4 * (size_t)(S + 1));
+        total = o;
+    }
+};
+
 template <typename T>
-__global__ __launch_bounds__(kHmmThreads) void fb_kernel(
+__global__ __launch_bounds__(kFbThreads) void fb_kernel(
     beer_batch b, const T* __restrict__ pc_llhs, double* __restrict__ alpha_ws,
     T* __restrict__ gamma, double* __restrict__ xi_sum, double* __restrict__ gamma0_sum,
     T* __restrict__ lognorm_mean) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int u = blockIdx.x, tid = threadIdx.x, nt_ = blockDim.x;
     const beer_graph g = b.graphs[b.graph_id[u]];
-    const int S = g.n_states, nnz = g.n_arcs;
+    const int S = g.n_states, nnz = g.n_arcs, nsi = g.n_in_seg, nso = g.n_out_seg;
     const int64_t T_ = b.frame_off[u + 1] - b.frame_off[u];
     if (T_ <= 0) return;
     const T* llh = pc_llhs + b.llh_off[u];
@@ -97,14 +134,41 @@ __global__ __launch_bounds__(kHmmThreads) void fb_kernel(
     T* gam = gamma + b.llh_off[u];
     const T* init = (const T*)g.init;
     const T* fin = (const T*)g.final;
-    const T* in_w = (const T*)g.in_w;
-    const T* out_w = (const T*)g.out_w;
 
-    double* cur = reinterpret_cast<double*>(smem);     // [S] column being read
-    double* nxt = cur + S;                              // [S] column being written
-    double* lb = nxt + S;                               // [S] llh_{t+1} + beta_{t+1}
-    double* red = lb + S;                               // [8]
-    double* xi = red + 8;                               // [nnz] (only if xi_sum)
+    const FbLayout L(b.max_states, b.max_arcs, b.max_segs, xi_sum != nullptr, sizeof(T));
+    double* cur = reinterpret_cast<double*>(smem + L.cur);      // alpha_{t-1} / beta_t
+    double* nxt = reinterpret_cast<double*>(smem + L.nxt);      // alpha_t / s_i / gamma_t/s_i
+    double* lb = reinterpret_cast<double*>(smem + L.lb);        // llh_{t+1} + beta_{t+1}
+    double* mx = reinterpret_cast<double*>(smem + L.mx);        // per-state max
+    double* red = reinterpret_cast<double*>(smem + L.red);
+    double* v = reinterpret_cast<double*>(smem + L.v);          // per-arc scratch
+    double* xi = reinterpret_cast<double*>(smem + L.xi);
+    double* pseg = reinterpret_cast<double*>(smem + L.pseg);    // per-segment partials
+    T* w_in = reinterpret_cast<T*>(smem + L.w_in);
+    T* w_out = reinterpret_cast<T*>(smem + L.w_out);
+    int16_t* src_in = reinterpret_cast<int16_t*>(smem + L.src_in);
+    int16_t* dst_in = reinterpret_cast<int16_t*>(smem + L.dst_in);
+    int16_t* dst_out = reinterpret_cast<int16_t*>(smem + L.dst_out);
+    int16_t* src_out = reinterpret_cast<int16_t*>(smem + L.src_out);
+    int* seg_in = reinterpret_cast<int*>(smem + L.seg_in);
+    int* rseg_in = reinterpret_cast<int*>(smem + L.rseg_in);
+    int* seg_out = reinterpret_cast<int*>(smem + L.seg_out);
+    int* rseg_out = reinterpret_cast<int*>(smem + L.rseg_out);
+    const double NINF = neg_inf(), PINF = __builtin_huge_val();
+
+    // ---- topology -> LDS ----
+    for (int e = tid; e < nnz; e += nt_) {
+        w_in[e] = ((const T*)g.in_w)[e];
+        w_out[e] = ((const T*)g.out_w)[e];
+        src_in[e] = (int16_t)g.in_src[e];
+        dst_in[e] = (int16_t)g.in_dst[e];
+        dst_out[e] = (int16_t)g.out_dst[e];
+        src_out[e] = (int16_t)g.out_src[e];
+        if (xi_sum) xi[e] = 0.0;
+    }
+    for (int k = tid; k <= nsi; k += nt_) seg_in[k] = g.in_seg[k];
+    for (int k = tid; k <= nso; k += nt_) seg_out[k] = g.out_seg[k];
+    for (int k = tid; k <= S; k += nt_) { rseg_in[k] = g.in_row_seg[k]; rseg_out[k] = g.out_row_seg[k]; }
 
     // ---- forward ----
     for (int j = tid; j < S; j += nt_) {
@@ -114,18 +178,39 @@ __global__ __launch_bounds__(kHmmThreads) void fb_kernel(
     }
     __syncthreads();
     for (int64_t t = 1; t < T_; ++t) {
-        for (int j = tid; j < S; j += nt_) {
-            const int e0 = g.in_ptr[j], e1 = g.in_ptr[j + 1];
-            double m = neg_inf();
-            for (int e = e0; e < e1; ++e) {
-                const double v = cur[g.in_src[e]] + (double)in_w[e];
-                m = v > m ? v : m;
+        for (int k = tid; k < nsi; k += nt_) {                // partial max per segment
+            double m = NINF;
+            for (int e = seg_in[k]; e < seg_in[k + 1]; ++e) {
+                const double w = cur[src_in[e]] + (double)w_in[e];
+                m = w > m ? w : m;
             }
+            pseg[k] = m;
+        }
+        __syncthreads();
+        for (int j = tid; j < S; j += nt_) {                  // max per state
+            double m = NINF;
+            for (int k = rseg_in[j]; k < rseg_in[j + 1]; ++k) m = pseg[k] > m ? pseg[k] : m;
+            mx[j] = m;
+        }
+        __syncthreads();
+        for (int e = tid; e < nnz; e += nt_) {                // exp per arc
+            const double m = mx[dst_in[e]];
+            v[e] = (m > NINF && m < PINF) ? fexp<T>(cur[src_in[e]] + (double)w_in[e] - m) : 0.0;
+        }
+        __syncthreads();
+        for (int k = tid; k < nsi; k += nt_) {                // partial sum per segment
+            double sm = 0.0;
+            for (int e = seg_in[k]; e < seg_in[k + 1]; ++e) sm += v[e];
+            pseg[k] = sm;
+        }
+        __syncthreads();
+        for (int j = tid; j < S; j += nt_) {                  // sum + log per state
+            const double m = mx[j];
             double lse = m;
-            if (m > neg_inf() && m < __builtin_huge_val()) {
-                double s = 0.0;
-                for (int e = e0; e < e1; ++e) s += exp(cur[g.in_src[e]] + (double)in_w[e] - m);
-                lse = m + log(s);
+            if (m > NINF && m < PINF) {
+                double sm = 0.0;
+                for (int k = rseg_in[j]; k < rseg_in[j + 1]; ++k) sm += pseg[k];
+                lse = m + flog<T>(sm);
             }
             const double a = (double)llh[t * S + j] + lse;
             nxt[j] = a;
@@ -136,71 +221,92 @@ __global__ __launch_bounds__(kHmmThreads) void fb_kernel(
     }
 
     // ---- backward + posteriors ----
-    if (xi_sum) for (int e = tid; e < nnz; e += nt_) xi[e] = 0.0;
-    // beta_{T-1} = final; `cur` holds beta_t, `lb` holds llh_{t+1}+beta_{t+1}.
-    for (int j = tid; j < S; j += nt_) cur[j] = (double)fin[j];
+    for (int j = tid; j < S; j += nt_) cur[j] = (double)fin[j];      // beta_{T-1}
     __syncthreads();
     double ln_acc = 0.0;
     for (int64_t t = T_ - 1; t >= 0; --t) {
-        if (t < T_ - 1) {
-            // beta_t(i) = lse_j(A_ij + llh_{t+1}(j) + beta_{t+1}(j))
-            for (int i = tid; i < S; i += nt_) {
-                const int e0 = g.out_ptr[i], e1 = g.out_ptr[i + 1];
-                double m = neg_inf();
-                for (int e = e0; e < e1; ++e) {
-                    const double v = (double)out_w[e] + lb[g.out_dst[e]];
-                    m = v > m ? v : m;
+        const bool inner = t < T_ - 1;
+        if (inner) {
+            // beta_t(i) = lse_j(A_ij + llh_{t+1}(j) + beta_{t+1}(j)); keep p_e, s_i
+            for (int k = tid; k < nso; k += nt_) {
+                double m = NINF;
+                for (int e = seg_out[k]; e < seg_out[k + 1]; ++e) {
+                    const double w = (double)w_out[e] + lb[dst_out[e]];
+                    m = w > m ? w : m;
                 }
-                double lse = m;
-                if (m > neg_inf() && m < __builtin_huge_val()) {
-                    double s = 0.0;
-                    for (int e = e0; e < e1; ++e) s += exp((double)out_w[e] + lb[g.out_dst[e]] - m);
-                    lse = m + log(s);
+                pseg[k] = m;
+            }
+            __syncthreads();
+            for (int i = tid; i < S; i += nt_) {
+                double m = NINF;
+                for (int k = rseg_out[i]; k < rseg_out[i + 1]; ++k) m = pseg[k] > m ? pseg[k] : m;
+                mx[i] = m;
+            }
+            __syncthreads();
+            for (int e = tid; e < nnz; e += nt_) {
+                const double m = mx[src_out[e]];
+                v[e] = (m > NINF && m < PINF)
+                           ? fexp<T>((double)w_out[e] + lb[dst_out[e]] - m) : 0.0;
+            }
+            __syncthreads();
+            for (int k = tid; k < nso; k += nt_) {
+                double sm = 0.0;
+                for (int e = seg_out[k]; e < seg_out[k + 1]; ++e) sm += v[e];
+                pseg[k] = sm;
+            }
+            __syncthreads();
+            for (int i = tid; i < S; i += nt_) {
+                const double m = mx[i];
+                double sm = 0.0, lse = m;
+                if (m > NINF && m < PINF) {
+                    for (int k = rseg_out[i]; k < rseg_out[i + 1]; ++k) sm += pseg[k];
+                    lse = m + flog<T>(sm);
                 }
                 cur[i] = lse;
+                nxt[i] = sm;                                 // s_i, replaced by gamma/s below
             }
             __syncthreads();
         }
         // lognorm_t = lse_i(alpha_t(i) + beta_t(i)); gamma_t
-        double m = neg_inf();
+        double m = NINF;
         for (int j = tid; j < S; j += nt_) {
-            const double v = alpha[t * S + j] + cur[j];
-            m = v > m ? v : m;
+            const double w = alpha[t * S + j] + cur[j];
+            m = w > m ? w : m;
         }
         m = block_max(m, red);
         double lognorm = m;
-        if (m > neg_inf() && m < __builtin_huge_val()) {
-            double s = 0.0;
-            for (int j = tid; j < S; j += nt_) s += exp(alpha[t * S + j] + cur[j] - m);
-            s = block_sum(s, red);
-            lognorm = m + log(s);
+        double mine = 0.0;
+        const bool finite = m > NINF && m < PINF;
+        if (finite) {
+            for (int j = tid; j < S; j += nt_) mine += fexp<T>(alpha[t * S + j] + cur[j] - m);
+            const double sm = block_sum(mine, red);
+            lognorm = m + flog<T>(sm);
         }
         ln_acc += lognorm;
         for (int j = tid; j < S; j += nt_) {
-            const double gv = exp(alpha[t * S + j] + cur[j] - lognorm);   // NaN if -inf - -inf
+            // NaN when alpha + beta and lognorm are both -inf, as in the reference
+            const double gv = fexp<T>(alpha[t * S + j] + cur[j] - lognorm);
             gam[t * S + j] = (T)gv;
             if (t == 0 && gamma0_sum) atomicAdd(gamma0_sum + j, gv);
-        }
-        // xi_t(i,j) for the arcs t -> t+1 (graph.py:308-323), NaN -> 0.
-        if (xi_sum && t < T_ - 1 && lognorm > neg_inf()) {
-            for (int i = tid; i < S; i += nt_) {
-                const double ai = alpha[t * S + i] - lognorm;
-                for (int e = g.out_ptr[i]; e < g.out_ptr[i + 1]; ++e) {
-                    const double v = exp(ai + (double)out_w[e] + lb[g.out_dst[e]]);
-                    if (v == v) xi[e] += v;
-                }
+            if (inner) {
+                const double sm = nxt[j];
+                nxt[j] = (sm > 0.0 && gv == gv) ? gv / sm : 0.0;           // NaN -> 0
             }
+            lb[j] = (double)llh[t * S + j] + cur[j];                      // for frame t-1
         }
         __syncthreads();
-        // lb <- llh_t + beta_t for the next (earlier) frame
-        for (int j = tid; j < S; j += nt_) lb[j] = (double)llh[t * S + j] + cur[j];
-        __syncthreads();
+        // xi_t(i,j) for the arcs t -> t+1 (graph.py:308-323)
+        if (xi_sum && inner && lognorm > NINF) {
+            for (int e = tid; e < nnz; e += nt_) xi[e] += v[e] * nxt[src_out[e]];
+        }
+        // (v / nxt are next written after barriers of the next frame's backward
+        //  step: no hazard with the xi loop)
     }
     if (lognorm_mean && tid == 0) lognorm_mean[u] = (T)(ln_acc / (double)T_);
     if (xi_sum) {
-        for (int i = tid; i < S; i += nt_)
-            for (int e = g.out_ptr[i]; e < g.out_ptr[i + 1]; ++e)
-                atomicAdd(xi_sum + (size_t)i * S + g.out_dst[e], xi[e]);
+        __syncthreads();
+        for (int e = tid; e < nnz; e += nt_)
+            atomicAdd(xi_sum + (size_t)src_out[e] * S + dst_out[e], xi[e]);
     }
 }
 
@@ -327,26 +433,26 @@ int beer_hmm_scatter(int dtype, const beer_batch* batch_h, int S_total, const vo
 int beer_hmm_forward_backward(int dtype, const beer_batch* b, const void* pc_llhs,
                               double* alpha_ws, void* gamma, double* xi_sum, double* gamma0_sum,
                               void* lognorm_mean, void* stream) {
-    BEER_REQUIRE(b && b->nutt >= 0 && b->max_states >= 1);
+    BEER_REQUIRE(b && b->nutt >= 0 && b->max_states >= 1 && b->max_states <= 32767);
+    BEER_REQUIRE(dtype == BEER_F32 || dtype == BEER_F64);
     if (b->nutt == 0) return BEER_OK;
-    const size_t lds = ((size_t)3 * b->max_states + 8 + (xi_sum ? (size_t)b->max_arcs : 0)) *
-                       sizeof(double);
-    BEER_REQUIRE(lds <= 160 * 1024);
+    const FbLayout L(b->max_states, b->max_arcs, b->max_segs, xi_sum != nullptr,
+                     dtype == BEER_F32 ? 4 : 8);
+    const size_t lds = L.total;
+    BEER_REQUIRE(lds <= 160 * 1024);          // graph too large for one CU's LDS
     hipStream_t s = as_stream(stream);
     if (dtype == BEER_F32) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fb_kernel<float>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(fb_kernel<float>, dim3(b->nutt), dim3(kHmmThreads), lds, s, *b,
+        hipLaunchKernelGGL(fb_kernel<float>, dim3(b->nutt), dim3(kFbThreads), lds, s, *b,
                            (const float*)pc_llhs, alpha_ws, (float*)gamma, xi_sum,
                            gamma0_sum, (float*)lognorm_mean);
-    } else if (dtype == BEER_F64) {
+    } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fb_kernel<double>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(fb_kernel<double>, dim3(b->nutt), dim3(kHmmThreads), lds, s, *b,
+        hipLaunchKernelGGL(fb_kernel<double>, dim3(b->nutt), dim3(kFbThreads), lds, s, *b,
                            (const double*)pc_llhs, alpha_ws, (double*)gamma, xi_sum,
                            gamma0_sum, (double*)lognorm_mean);
-    } else {
-        return BEER_EINVAL;
     }
     BEER_LAUNCH_CHECK();
     return BEER_OK;

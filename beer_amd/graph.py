@@ -182,18 +182,40 @@ class DeviceGraph:
         out_ptr[1:] = torch.cumsum(torch.bincount(src2, minlength=S), 0).to(torch.int32)
         out_w = trans.detach().to('cpu')[src2, dst2]
         self.n_states, self.n_arcs = S, int(src.numel())
+        in_seg, in_row_seg = self._segments(in_ptr)
+        out_seg, out_row_seg = self._segments(out_ptr)
+        self.n_in_seg, self.n_out_seg = len(in_seg) - 1, len(out_seg) - 1
         self.bufs = dict(
             init=init.detach().to(device, dtype).contiguous(),
             final=final.detach().to(device, dtype).contiguous(),
             in_ptr=in_ptr.to(device), in_src=src.to(torch.int32).to(device),
+            in_dst=dst.to(torch.int32).to(device),
             in_w=in_w.to(device, dtype).contiguous(),
+            in_seg=in_seg.to(device), in_row_seg=in_row_seg.to(device),
             out_ptr=out_ptr.to(device), out_dst=dst2.to(torch.int32).to(device),
-            out_w=out_w.to(device, dtype).contiguous())
+            out_src=src2.to(torch.int32).to(device),
+            out_w=out_w.to(device, dtype).contiguous(),
+            out_seg=out_seg.to(device), out_row_seg=out_row_seg.to(device))
         b = self.bufs
-        self.struct = _hip.Graph(S, self.n_arcs, b['init'].data_ptr(), b['final'].data_ptr(),
-                                 b['in_ptr'].data_ptr(), b['in_src'].data_ptr(),
-                                 b['in_w'].data_ptr(), b['out_ptr'].data_ptr(),
-                                 b['out_dst'].data_ptr(), b['out_w'].data_ptr())
+        p = lambda name: b[name].data_ptr()                     # noqa: E731
+        self.struct = _hip.Graph(S, self.n_arcs, self.n_in_seg, self.n_out_seg,
+                                 p('init'), p('final'),
+                                 p('in_ptr'), p('in_src'), p('in_dst'), p('in_w'),
+                                 p('in_seg'), p('in_row_seg'),
+                                 p('out_ptr'), p('out_dst'), p('out_src'), p('out_w'),
+                                 p('out_seg'), p('out_row_seg'))
+
+    @staticmethod
+    def _segments(ptr):
+        'Cut every CSR row into runs of <= SEG arcs: (arc offsets, row -> seg range).'
+        ptr = ptr.tolist()
+        seg, row_seg = [], [0]
+        for r in range(len(ptr) - 1):
+            for beg in range(ptr[r], ptr[r + 1], _hip.SEG):
+                seg.append(beg)
+            row_seg.append(len(seg))
+        seg.append(ptr[-1])
+        return (torch.tensor(seg, dtype=torch.int32), torch.tensor(row_seg, dtype=torch.int32))
 
 
 class CompiledGraph(torch.nn.Module):

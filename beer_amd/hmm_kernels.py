@@ -54,7 +54,8 @@ class HmmBatch:
         b = self.bufs
         self.struct = _hip.Batch(
             self.nutt, max(n_states) if n_states else 1,
-            max([dg.n_arcs for dg in self.dgraphs] + [1]), len(graphs),
+            max([dg.n_arcs for dg in self.dgraphs] + [1]),
+            max([max(dg.n_in_seg, dg.n_out_seg) for dg in self.dgraphs] + [1]), 0, len(graphs),
             b['frame_off'].data_ptr(), b['llh_off'].data_ptr(), b['graph_id'].data_ptr(),
             b['graphs'].data_ptr(), b['pdf_off'].data_ptr(), b['pdf_ids'].data_ptr())
         self.shared_graph = len(graphs) == 1
@@ -150,8 +151,8 @@ class _Columns:
         if self._dg is None:
             self._dg = type('DG', (), {})()
             self._dg.n_states, self._dg.n_arcs = self.n_states, 0
-            self._dg.struct = _hip.Graph(self.n_states, 0, None, None, None, None, None,
-                                         None, None, None)
+            self._dg.n_in_seg = self._dg.n_out_seg = 0
+            self._dg.struct = _hip.Graph(self.n_states, 0, 0, 0, *([None] * 14))
         return self._dg
 
 

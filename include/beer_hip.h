@@ -218,18 +218,30 @@ int beer_weights_from_acc(int S, int G, int Q, const double* acc,
  * for the backward recursion).  Arcs inside a row are sorted by the other
  * end's index (ascending) -- Viterbi's first-index tie-break relies on it.
  * Built on the host by beer_amd.graph.CompiledGraph; -inf transitions are
- * simply absent. */
+ * simply absent.  Rows are additionally cut into segments of at most
+ * BEER_SEG arcs so that the log-sum-exp of a high-degree state (a phone
+ * start in a phone loop has one incoming arc per phone) is reduced by
+ * several lanes instead of one. */
+#define BEER_SEG 8
 typedef struct {
     int32_t n_states;
     int32_t n_arcs;
+    int32_t n_in_seg;          /* segments (<= BEER_SEG arcs of one row) by destination */
+    int32_t n_out_seg;         /* ... by source */
     const void* init;          /* [S]  */
     const void* final;         /* [S]  */
     const int32_t* in_ptr;     /* [S+1] arcs grouped by destination */
     const int32_t* in_src;     /* [nnz] source state               */
+    const int32_t* in_dst;     /* [nnz] destination state (row id)  */
     const void* in_w;          /* [nnz] log-probability             */
+    const int32_t* in_seg;     /* [n_in_seg+1] arc offsets of the segments  */
+    const int32_t* in_row_seg; /* [S+1] segment range of every destination  */
     const int32_t* out_ptr;    /* [S+1] arcs grouped by source      */
     const int32_t* out_dst;    /* [nnz] destination state           */
+    const int32_t* out_src;    /* [nnz] source state (row id)       */
     const void* out_w;         /* [nnz] */
+    const int32_t* out_seg;    /* [n_out_seg+1] */
+    const int32_t* out_row_seg;/* [S+1] */
 } beer_graph;
 
 /* Ragged batch: utterance u owns frames [frame_off[u], frame_off[u+1]) of the
@@ -240,6 +252,8 @@ typedef struct {
     int32_t nutt;
     int32_t max_states;        /* max n_states over the batch's graphs (LDS sizing) */
     int32_t max_arcs;          /* max n_arcs over the batch's graphs   (LDS sizing) */
+    int32_t max_segs;          /* max(n_in_seg, n_out_seg) over the graphs          */
+    int32_t reserved;
     int32_t n_graphs;
     const int64_t* frame_off;  /* [nutt+1] */
     const int64_t* llh_off;    /* [nutt]   element offsets */

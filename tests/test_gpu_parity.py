@@ -444,3 +444,92 @@ def test_empty_and_ragged_inputs():
     cpu = beer.evidence_lower_bound(model, X.cpu(), datasize=10)
     dev = beer.evidence_lower_bound(model, X, datasize=10)
     assert float(cpu) == float(dev)
+
+
+# --- config-3 shape: phone loop with GMM emissions, batched, vs the oracle -----------------------
+
+def _phone_loop(P, G, D, cov, dtype, seed):
+    'P phones x 3 left-to-right states, G Gaussians per state (beer hmm mk* in memory).'
+    topo = [(0, 1, 1.), (1, 1, .75), (1, 2, .25), (2, 2, .75), (2, 3, .25), (3, 3, .75),
+            (3, 4, .25)]
+    units, pdf = {}, 0
+    for p in range(P):
+        g = beer.graph.Graph()
+        for sid in range(5):
+            g.add_state(pdf_id=None if sid in (0, 4) else pdf + sid - 1)
+        g.start_state, g.end_state = 0, 4
+        for arc in topo:
+            g.add_arc(*arc)
+        units[p] = g
+        pdf += 3
+    graph = beer.graph.Graph()
+    graph.start_state, graph.end_state = graph.add_state(), graph.add_state()
+    pivot = graph.add_state()
+    u2s = {p: graph.add_state() for p in units}
+    graph.add_arc(graph.start_state, pivot)
+    graph.add_arc(pivot, graph.end_state)
+    for p in units:
+        graph.add_arc(pivot, u2s[p])
+        graph.add_arc(u2s[p], pivot)
+    graph.normalize()
+    for p, hmm in units.items():
+        graph.replace_state(u2s[p], hmm)
+    graph.normalize()
+    torch.manual_seed(seed)
+    S = 3 * P
+    ns = beer.NormalSet.create(torch.zeros(D), torch.ones(D), size=S * G, prior_strength=1.,
+                               noise_std=1., cov_type=cov)
+    emissions = beer.JointModelSet([beer.MixtureSet.create(S, ns, prior_strength=1.)])
+    ploop = beer.PhoneLoop.create(graph.compile(), {p: 3 * p for p in units},
+                                  {p: 3 * p + 2 for p in units}, emissions)
+    ploop = ploop.double() if dtype == torch.float64 else ploop.float()
+    return ploop.to(DEV)
+
+
+def _oracle_groups(ploop):
+    ms = ploop.modelset.original_modelset.modelsets[0]
+    ns = ms.modelset
+    as64 = lambda d: [npy(getattr(d.params, n)).astype(np.float64) for n in d._std_params_def]
+    p = ns.means_precisions
+    w = ms.categoricalset.weights
+    return [dict(cov_type=ns.cov_type, S=len(ms), G=ms.n_comp_per_mixture,
+                 post=as64(p.posterior), prior=as64(p.prior),
+                 w_post=as64(w.posterior)[0], w_prior=as64(w.prior)[0])]
+
+
+@pytest.mark.parametrize('cov,dtype,tol', [('full', torch.float64, 1e-8),
+                                           ('full', torch.float32, 1e-5),
+                                           ('diagonal', torch.float64, 1e-8),
+                                           ('diagonal', torch.float32, 1e-5)])
+def test_c3_shape_batched_phone_loop_vs_oracle(cov, dtype, tol):
+    P, G, D = 8, 8, 12                       # S = 24 states, K = 192 Gaussians
+    ploop = _phone_loop(P, G, D, cov, dtype, seed=21)
+    rng = np.random.RandomState(8)
+    lens = [64, 120, 75]
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    utts = [(rng.randn(T, D) * 1.3).astype(npdt) for T in lens]
+    N = 20000
+    groups = _oracle_groups(ploop)
+    gr = ploop.graph
+    graph = dict(init=npy(gr.init_log_probs).astype(np.float64),
+                 final=npy(gr.final_log_probs).astype(np.float64),
+                 trans=npy(gr.trans_log_probs).astype(np.float64),
+                 order=np.asarray(gr.pdf_id_mapping))
+    cat = ploop.categorical.weights
+    extra_kl = orc.dir_kl(npy(cat.posterior.params.concentrations).astype(np.float64),
+                          npy(cat.prior.params.concentrations).astype(np.float64)).sum()
+    value, acc_n, acc_w, counts = 0., 0., 0., 0.
+    starts, ends = list(ploop.start_pdf.values()), list(ploop.end_pdf.values())
+    for x in utts:
+        r = orc.hmm_elbo_step(x.astype(np.float64), groups, graph, datasize=N,
+                              trans_posteriors=True, extra_kl=extra_kl)
+        value += r['value']
+        acc_n, acc_w = acc_n + r['acc'][0][0], acc_w + r['acc'][0][1]
+        counts = counts + orc.cat_suffstats(
+            orc.phone_counts(r['trans_resps'], r['resps'], starts, ends).reshape(1, -1)).sum(0)
+    elbo = beer.accumulate_elbo(ploop, [tt(x) for x in utts], datasize=N)
+    assert_close(float(elbo), value, tol, 'elbo')
+    ms = ploop.modelset.original_modelset.modelsets[0]
+    assert_close(npy(elbo._acc_stats[ms.modelset.means_precisions]), acc_n, tol * 10, 'acc normal')
+    assert_close(npy(elbo._acc_stats[ms.categoricalset.weights]), acc_w, tol * 10, 'acc weights')
+    assert_close(npy(elbo._acc_stats[cat]), counts, tol * 10, 'phone counts')

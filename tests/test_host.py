@@ -38,9 +38,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    # 2 int32 + 8 pointers; 4 int32 + 6 pointers (LP64)
-    assert ctypes.sizeof(_hip.Graph) == 8 + 8 * 8
-    assert ctypes.sizeof(_hip.Batch) == 16 + 6 * 8
+    # 4 int32 + 14 pointers; 6 int32 + 6 pointers (LP64)
+    assert ctypes.sizeof(_hip.Graph) == 16 + 14 * 8
+    assert ctypes.sizeof(_hip.Batch) == 24 + 6 * 8
 
 
 @pytest.mark.skipif(HAS_GPU, reason='checks behaviour on a GPU-less host')
