@@ -159,7 +159,7 @@ __global__ void tab_kernel(int D, int* __restrict__ tab) {
 // all K (<= 16*NT) components.
 // ---------------------------------------------------------------------------
 template <typename T, int NT, int MT>
-__global__ __launch_bounds__(kThreads) void llh_kernel(
+__global__ __launch_bounds__(kThreads, (sizeof(T) == 4 && MT * NT <= 32) ? 2 : 1) void llh_kernel(
     int64_t nframes, int D, int K, int nslab, const T* __restrict__ X,
     const T* __restrict__ P, const int* __restrict__ tab, T* __restrict__ resps,
     T* __restrict__ log_norm, double* __restrict__ llh_sum) {
@@ -404,6 +404,8 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
         const T* xs = lds + buf * buf_elems;
         const T* rs = xs + xs_elems;
         if (tile + 1 < ntiles) load_tile(tb + (tile + 1) * kAccFT);
+        // waves whose statistics lie entirely beyond the last slab only help staging
+        if (u0 * 16 < nq)
 #pragma unroll 2
         for (int kk = 0; kk < kAccFT / 4; ++kk) {
             // A fragments: r[frame 4kk+g][component slot 4i..4i+3] -- the 64 lanes
