@@ -339,16 +339,17 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
     BEER_REQUIRE(!labels || pc_arg);
     void* w_arg = labels ? nullptr : (need_norm ? w_buf : nullptr);
 
-    if (!labels && cov == BEER_FULL && S == 1 && !pc_llh && stat_scale == 1.0 && ws &&
-        beer_mfma::supported_llh(D, K) &&
-        ws_bytes >= beer_mfma::estep_workspace_bytes(sizeof(T), D, K) &&
+    if (!labels && cov == BEER_FULL && !pc_llh && stat_scale == 1.0 && ws &&
+        beer_mfma::supported_llh(D, S, G) &&
+        ws_bytes >= beer_mfma::estep_workspace_bytes(sizeof(T), D, S, G) &&
         (log_norm || comp_resps || llh_sum)) {
-        // gfx950 matrix-core path: GEMM + softmax fused, one kernel
+        // gfx950 matrix-core path: GEMM + (grouped) softmax fused, one kernel
         return sizeof(T) == 4
-                   ? beer_mfma::estep_full_f32(nframes, D, K, (const float*)X, (const float*)expT,
-                                               (const float*)logw, (float*)comp_resps,
-                                               (float*)log_norm, llh_sum, ws, ws_bytes, s)
-                   : beer_mfma::estep_full_f64(nframes, D, K, (const double*)X,
+                   ? beer_mfma::estep_full_f32(nframes, D, S, G, (const float*)X,
+                                               (const float*)expT, (const float*)logw,
+                                               (float*)comp_resps, (float*)log_norm, llh_sum, ws,
+                                               ws_bytes, s)
+                   : beer_mfma::estep_full_f64(nframes, D, S, G, (const double*)X,
                                                (const double*)expT, (const double*)logw,
                                                (double*)comp_resps, (double*)log_norm, llh_sum,
                                                ws, ws_bytes, s);
@@ -461,8 +462,8 @@ int beer_mixtureset_estep(int dtype, int cov, int64_t T, int D, int S, int G, co
 }
 
 size_t beer_estep_workspace_bytes(int dtype, int cov, int D, int S, int G) {
-    if (cov != BEER_FULL || S != 1) return 0;
-    return beer_mfma::estep_workspace_bytes(dtype == BEER_F64 ? 8 : 4, D, S * G);
+    if (cov != BEER_FULL) return 0;
+    return beer_mfma::estep_workspace_bytes(dtype == BEER_F64 ? 8 : 4, D, S, G);
 }
 
 size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G) {

@@ -9,15 +9,15 @@
 
 namespace beer_mfma {
 
-bool supported_llh(int D, int K);
+bool supported_llh(int D, int S, int G);
 bool supported_acc(int D, int K);
-size_t estep_workspace_bytes(size_t elem, int D, int K);
+size_t estep_workspace_bytes(size_t elem, int D, int S, int G);
 size_t acc_workspace_bytes(int D, int K);
 
-int estep_full_f32(int64_t T, int D, int K, const float* X, const float* expT, const float* logw,
-                   float* resps, float* log_norm, double* llh_sum, void* ws, size_t ws_bytes,
-                   hipStream_t s);
-int estep_full_f64(int64_t T, int D, int K, const double* X, const double* expT,
+int estep_full_f32(int64_t T, int D, int S, int G, const float* X, const float* expT,
+                   const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
+                   size_t ws_bytes, hipStream_t s);
+int estep_full_f64(int64_t T, int D, int S, int G, const double* X, const double* expT,
                    const double* logw, double* resps, double* log_norm, double* llh_sum,
                    void* ws, size_t ws_bytes, hipStream_t s);
 int acc_full_f32(int64_t T, int D, int S, int G, const float* X, const float* R, const float* SR,

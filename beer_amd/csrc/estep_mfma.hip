@@ -89,21 +89,24 @@ constexpr double kPadLogit = -1.0e30;
 // tab[s] = a | (4j << 8).
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ void pack_kernel(int D, int K, int NT, const T* __restrict__ E,
+__global__ void pack_kernel(int D, int K, int NT, int nchunks, const T* __restrict__ E,
                             const T* __restrict__ logw, T* __restrict__ P,
                             int* __restrict__ tab) {
     const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(D);
     const int Q = D * D + D + 2;
-    const int64_t total = (int64_t)nslab_padded(D) * 64 * NT;
+    const int64_t per_chunk = (int64_t)nslab_padded(D) * 64 * NT;
+    const int64_t total = per_chunk * nchunks;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % NT);
-        const int lane = (int)((idx / NT) % 64);
-        const int s = (int)(idx / ((int64_t)NT * 64));
+        const int chunk = (int)(idx / per_chunk);
+        const int64_t rem_idx = idx - (int64_t)chunk * per_chunk;
+        const int c = (int)(rem_idx % NT);
+        const int lane = (int)((rem_idx / NT) % 64);
+        const int s = (int)(rem_idx / ((int64_t)NT * 64));
         const int i = lane & 15, g = lane >> 4;
-        const int k = c * 16 + i;
+        const int k = chunk * NT * 16 + c * 16 + i;
         if (s >= nslab) {                           // look-ahead padding: zero slabs
-            if (c == 0 && lane == 0) tab[s] = (Dp + 1) | ((Dp) << 8);
+            if (c == 0 && lane == 0 && chunk == 0) tab[s] = (Dp + 1) | ((Dp) << 8);
             P[idx] = (T)0;
             continue;
         }
@@ -117,7 +120,7 @@ __global__ void pack_kernel(int D, int K, int NT, const T* __restrict__ E,
             for (;;) { const int len = D4 - a / 4; if (rem < len) break; rem -= len; ++a; }
             j = a / 4 + rem;
         }
-        if (c == 0 && lane == 0) tab[s] = a | ((4 * j) << 8);
+        if (c == 0 && lane == 0 && chunk == 0) tab[s] = a | ((4 * j) << 8);
         const int b = 4 * j + g;
         double v = 0.0;
         if (k < K) {
@@ -155,13 +158,16 @@ __global__ void tab_kernel(int D, int* __restrict__ tab) {
 }
 
 // ---------------------------------------------------------------------------
-// K1: fused log-likelihood GEMM + softmax.  One wave owns 16*MT frames and
-// all K (<= 16*NT) components.
+// K1: fused log-likelihood GEMM + softmax.  One wave owns 16*MT frames and a
+// chunk of 16*NT components (blockIdx.y); the softmax runs over groups of
+// G = 16*GT components (GT column tiles; for G < 16, `gl` = G lanes of one
+// tile): the whole mixture for a GMM (S = 1, one chunk, GT = NT), one state's
+// mixture for the GMM emissions of an HMM (S > 1, G a power of two).
 // ---------------------------------------------------------------------------
-template <typename T, int NT, int MT>
+template <typename T, int NT, int MT, int GT>
 __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 && MT * NT <= 32) ? 2 : 1) void llh_kernel(
-    int64_t nframes, int D, int K, int nslab, const T* __restrict__ X,
-    const T* __restrict__ P, const int* __restrict__ tab, T* __restrict__ resps,
+    int64_t nframes, int D, int K, int S, int G, int gl, int nslab, const T* __restrict__ X,
+    const T* __restrict__ Pall, const int* __restrict__ tab, T* __restrict__ resps,
     T* __restrict__ log_norm, double* __restrict__ llh_sum) {
     using M = Mma<T>;
     using acc_t = typename M::acc_t;
@@ -199,6 +205,8 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 && MT * NT <= 32) ? 2 : 1
     // packed parameter image, its two x factors from LDS, its table entry) is
     // fetched while the MFMAs of slab s run.  P and tab are padded with zero
     // slabs up to an even count + 1, so the look-ahead never branches.
+    const int kbase = blockIdx.y * (16 * NT);
+    const T* P = Pall + (size_t)blockIdx.y * (size_t)(nslab + 1) * 64 * NT;
     const vec4_t* Pl = reinterpret_cast<const vec4_t*>(P) + (size_t)lane * (NT / 4);
     auto fetch = [&](int s, vec4_t (&b4)[NT / 4], T (&xa)[MT], T (&xb)[MT]) {
         const int t = tab[s];
@@ -238,38 +246,47 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 && MT * NT <= 32) ? 2 : 1
         __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 1);
     }
 
-    // ---- epilogue: per-frame logsumexp over the K components ----
+    // ---- epilogue: logsumexp over each group of G components ----
     double llh_local = 0.0;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            T mx = acc[m][0][r];
-#pragma unroll
-            for (int c = 1; c < NT; ++c) mx = acc[m][c][r] > mx ? acc[m][c][r] : mx;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                const T w = __shfl_xor(mx, o, 64);
-                mx = w > mx ? w : mx;
-            }
-            T sum = 0;
-#pragma unroll
-            for (int c = 0; c < NT; ++c) sum += exp(acc[m][c][r] - mx);
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
-            const T lse = mx + log(sum);
             const int64_t f = fb + m * 16 + M::row(g, r);
-            if (f < nframes) {
-                if (resps) {
 #pragma unroll
-                    for (int c = 0; c < NT; ++c) {
-                        const int k = c * 16 + i;
-                        if (k < K) resps[f * K + k] = exp(acc[m][c][r] - lse);
+            for (int tg = 0; tg < NT / GT; ++tg) {
+                T mx = acc[m][tg * GT][r];
+#pragma unroll
+                for (int c = 1; c < GT; ++c)
+                    mx = acc[m][tg * GT + c][r] > mx ? acc[m][tg * GT + c][r] : mx;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    if (o < gl) {
+                        const T w = __shfl_xor(mx, o, 64);
+                        mx = w > mx ? w : mx;
                     }
                 }
-                if (i == 0) {
-                    if (log_norm) log_norm[f] = lse;
-                    llh_local += (double)lse;
+                T sum = 0;
+#pragma unroll
+                for (int c = 0; c < GT; ++c) sum += exp(acc[m][tg * GT + c][r] - mx);
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1)
+                    if (o < gl) sum += __shfl_xor(sum, o, 64);
+                const T lse = mx + log(sum);
+                const int k0 = kbase + tg * GT * 16 + (i & ~(gl - 1));     // group's first comp
+                const int state = k0 / G;
+                if (f < nframes && state < S) {
+                    if (resps) {
+#pragma unroll
+                        for (int c = 0; c < GT; ++c) {
+                            const int k = kbase + (tg * GT + c) * 16 + i;
+                            if (k < K) resps[f * K + k] = exp(acc[m][tg * GT + c][r] - lse);
+                        }
+                    }
+                    if ((i & (gl - 1)) == 0) {
+                        if (log_norm) log_norm[f * S + state] = lse;
+                        llh_local += (double)lse;
+                    }
                 }
             }
         }
@@ -483,38 +500,63 @@ __global__ void unpack_kernel(int D, int K, const double* __restrict__ Sp,
 template <typename T>
 size_t align_up(size_t n) { return (n + 255) / 256 * 256; }
 
-inline int nt_for(int K) { return K <= 64 ? 4 : (K <= 128 ? 8 : 16); }
+inline int nt_for(int S, int K) { return S > 1 ? 16 : (K <= 64 ? 4 : (K <= 128 ? 8 : 16)); }
+inline int nchunks_for(int S, int K) { return S > 1 ? (K + 255) / 256 : 1; }
 
-template <typename T, int NT, int MT>
-int launch_llh(int64_t nframes, int D, int K, int nslab, const T* X, const T* P, const int* tab,
-               T* resps, T* log_norm, double* llh_sum, hipStream_t s) {
+template <typename T, int NT, int MT, int GT>
+int launch_llh(int64_t nframes, int D, int K, int S, int G, int gl, int nchunks, int nslab,
+               const T* X, const T* P, const int* tab, T* resps, T* log_norm, double* llh_sum,
+               hipStream_t s) {
     const int D4 = d4_of(D), LD = 4 * D4 + 5;
     constexpr int FB = 16 * MT * (kThreads / 64);
     const size_t lds = (size_t)FB * LD * sizeof(T);
     const int64_t blocks = (nframes + FB - 1) / FB;
-    hipLaunchKernelGGL((llh_kernel<T, NT, MT>), dim3((unsigned)blocks), dim3(kThreads), lds, s,
-                       nframes, D, K, nslab, X, P, tab, resps, log_norm, llh_sum);
+    hipLaunchKernelGGL((llh_kernel<T, NT, MT, GT>), dim3((unsigned)blocks, (unsigned)nchunks),
+                       dim3(kThreads), lds, s, nframes, D, K, S, G, gl, nslab, X, P, tab, resps,
+                       log_norm, llh_sum);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }
 
 template <typename T>
-int estep_impl(int64_t nframes, int D, int K, const T* X, const T* expT, const T* logw,
+int estep_impl(int64_t nframes, int D, int S, int G, const T* X, const T* expT, const T* logw,
                T* resps, T* log_norm, double* llh_sum, void* ws, size_t ws_bytes,
                hipStream_t s) {
-    if (!supported_llh(D, K) || ws_bytes < estep_workspace_bytes(sizeof(T), D, K)) return BEER_EINVAL;
-    const int NT = nt_for(K), nslab = nslab_padded(D) - 1;       // even, >= nslab_of(D)
+    const int K = S * G;
+    if (!supported_llh(D, S, G) || ws_bytes < estep_workspace_bytes(sizeof(T), D, S, G))
+        return BEER_EINVAL;
+    const int NT = nt_for(S, K), nchunks = nchunks_for(S, K);
+    const int nslab = nslab_padded(D) - 1;                      // even, >= nslab_of(D)
     T* P = reinterpret_cast<T*>(ws);
-    int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) +
-                                      align_up<T>((size_t)nslab_padded(D) * 64 * NT * sizeof(T)));
-    const int64_t total = (int64_t)nslab_padded(D) * 64 * NT;
-    hipLaunchKernelGGL(pack_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, D,
-                       K, NT, expT, logw, P, tab);
+    const size_t p_bytes = (size_t)nchunks * nslab_padded(D) * 64 * NT * sizeof(T);
+    int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + align_up<T>(p_bytes));
+    const int64_t total = (int64_t)nchunks * nslab_padded(D) * 64 * NT;
+    int64_t pblocks = (total + 255) / 256;
+    if (pblocks > 65535) pblocks = 65535;
+    hipLaunchKernelGGL(pack_kernel<T>, dim3((unsigned)pblocks), dim3(256), 0, s, D, K, NT, nchunks,
+                       expT, logw, P, tab);
     BEER_LAUNCH_CHECK();
     constexpr int MT = sizeof(T) == 4 ? 2 : 1;
-    if (NT == 4) return launch_llh<T, 4, MT>(nframes, D, K, nslab, X, P, tab, resps, log_norm, llh_sum, s);
-    if (NT == 8) return launch_llh<T, 8, MT>(nframes, D, K, nslab, X, P, tab, resps, log_norm, llh_sum, s);
-    return launch_llh<T, 16, MT>(nframes, D, K, nslab, X, P, tab, resps, log_norm, llh_sum, s);
+#define BEER_LLH(NT_, GT_) \
+    return launch_llh<T, NT_, MT, GT_>(nframes, D, K, S, G, gl, nchunks, nslab, X, P, tab, resps, \
+                                       log_norm, llh_sum, s)
+    if (S == 1) {                                               // one group = the whole chunk
+        const int gl = 16;
+        if (NT == 4) BEER_LLH(4, 4);
+        if (NT == 8) BEER_LLH(8, 8);
+        // K (not a power of two in general) is the group: state = k0 / G must be 0
+        BEER_LLH(16, 16);
+    }
+    const int gl = G < 16 ? G : 16;
+    const int gt = G < 16 ? 1 : G / 16;
+    switch (gt) {
+        case 1: BEER_LLH(16, 1);
+        case 2: BEER_LLH(16, 2);
+        case 4: BEER_LLH(16, 4);
+        case 8: BEER_LLH(16, 8);
+        default: BEER_LLH(16, 16);
+    }
+#undef BEER_LLH
 }
 
 template <typename T>
@@ -555,20 +597,26 @@ int acc_impl(int64_t nframes, int D, int S, int G, const T* X, const T* R, const
 
 }  // namespace
 
-bool supported_llh(int D, int K) {
-    // 8-bit slab-table fields: Dp + 4 <= 255; K <= 256 keeps a whole softmax
-    // row inside one wave's accumulators (padded to 64 / 128 / 256 columns).
-    return D >= 1 && D <= 64 && K >= 16 && K <= 256;
+bool supported_llh(int D, int S, int G) {
+    // 8-bit slab-table fields: Dp + 4 <= 255.  GMM (S = 1): any K in [16, 256]
+    // (a whole softmax row inside one wave's accumulators, padded to 64 / 128 /
+    // 256 columns).  Mixture set (S > 1): G a power of two <= 256 so that the
+    // groups align with lanes / column tiles; K is cut into chunks of 256.
+    if (D < 1 || D > 64 || S < 1 || G < 1) return false;
+    const int K = S * G;
+    if (S == 1) return K >= 16 && K <= 256;
+    return K >= 16 && G <= 256 && (G & (G - 1)) == 0;
 }
 
 bool supported_acc(int D, int K) {
     return D >= 1 && D <= 64 && K >= 16 && K % 4 == 0;
 }
 
-size_t estep_workspace_bytes(size_t elem, int D, int K) {
-    if (!supported_llh(D, K)) return 0;
-    const int nslab = nslab_padded(D);
-    return (size_t)(((size_t)nslab * 64 * nt_for(K) * elem + 255) / 256 * 256) +
+size_t estep_workspace_bytes(size_t elem, int D, int S, int G) {
+    if (!supported_llh(D, S, G)) return 0;
+    const int nslab = nslab_padded(D), K = S * G;
+    return (size_t)(((size_t)nchunks_for(S, K) * nslab * 64 * nt_for(S, K) * elem + 255) / 256 *
+                    256) +
            (size_t)nslab * sizeof(int) + 256;
 }
 
@@ -579,15 +627,16 @@ size_t acc_workspace_bytes(int D, int K) {
            (size_t)nslab * sizeof(int) + 256;
 }
 
-int estep_full_f32(int64_t T, int D, int K, const float* X, const float* expT, const float* logw,
-                   float* resps, float* log_norm, double* llh_sum, void* ws, size_t ws_bytes,
-                   hipStream_t s) {
-    return estep_impl<float>(T, D, K, X, expT, logw, resps, log_norm, llh_sum, ws, ws_bytes, s);
+int estep_full_f32(int64_t T, int D, int S, int G, const float* X, const float* expT,
+                   const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
+                   size_t ws_bytes, hipStream_t s) {
+    return estep_impl<float>(T, D, S, G, X, expT, logw, resps, log_norm, llh_sum, ws, ws_bytes, s);
 }
-int estep_full_f64(int64_t T, int D, int K, const double* X, const double* expT,
+int estep_full_f64(int64_t T, int D, int S, int G, const double* X, const double* expT,
                    const double* logw, double* resps, double* log_norm, double* llh_sum,
                    void* ws, size_t ws_bytes, hipStream_t s) {
-    return estep_impl<double>(T, D, K, X, expT, logw, resps, log_norm, llh_sum, ws, ws_bytes, s);
+    return estep_impl<double>(T, D, S, G, X, expT, logw, resps, log_norm, llh_sum, ws, ws_bytes,
+                              s);
 }
 int acc_full_f32(int64_t T, int D, int S, int G, const float* X, const float* R, const float* SR,
                  double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
