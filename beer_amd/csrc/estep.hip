@@ -339,20 +339,19 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
     BEER_REQUIRE(!labels || pc_arg);
     void* w_arg = labels ? nullptr : (need_norm ? w_buf : nullptr);
 
-    if (!labels && cov == BEER_FULL && !pc_llh && stat_scale == 1.0 && ws &&
-        beer_mfma::supported_llh(D, S, G) &&
-        ws_bytes >= beer_mfma::estep_workspace_bytes(sizeof(T), D, S, G) &&
+    if (!labels && !pc_llh && stat_scale == 1.0 && ws && beer_mfma::supported_llh(D, S, G) &&
+        ws_bytes >= beer_mfma::estep_workspace_bytes(sizeof(T), cov, D, S, G) &&
         (log_norm || comp_resps || llh_sum)) {
         // gfx950 matrix-core path: GEMM + (grouped) softmax fused, one kernel
         return sizeof(T) == 4
-                   ? beer_mfma::estep_full_f32(nframes, D, S, G, (const float*)X,
-                                               (const float*)expT, (const float*)logw,
-                                               (float*)comp_resps, (float*)log_norm, llh_sum, ws,
-                                               ws_bytes, s)
-                   : beer_mfma::estep_full_f64(nframes, D, S, G, (const double*)X,
-                                               (const double*)expT, (const double*)logw,
-                                               (double*)comp_resps, (double*)log_norm, llh_sum,
-                                               ws, ws_bytes, s);
+                   ? beer_mfma::estep_f32(cov, nframes, D, S, G, (const float*)X,
+                                          (const float*)expT, (const float*)logw,
+                                          (float*)comp_resps, (float*)log_norm, llh_sum, ws,
+                                          ws_bytes, s)
+                   : beer_mfma::estep_f64(cov, nframes, D, S, G, (const double*)X,
+                                          (const double*)expT, (const double*)logw,
+                                          (double*)comp_resps, (double*)log_norm, llh_sum, ws,
+                                          ws_bytes, s);
     }
     // generic kernels; the normalisation is fused when a component chunk holds
     // whole states
@@ -422,14 +421,14 @@ int accumulate_launch(int cov, int64_t nframes, int D, int S, int G, const void*
     BEER_REQUIRE(X && acc);
     if (nframes == 0) return BEER_OK;
     hipStream_t s = as_stream(stream);
-    if (cov == BEER_FULL && cr && ws && beer_mfma::supported_acc(D, S * G) &&
-        ws_bytes >= beer_mfma::acc_workspace_bytes(D, S * G)) {
+    if (cr && ws && beer_mfma::supported_acc(D, S * G) &&
+        ws_bytes >= beer_mfma::acc_workspace_bytes(cov, D, S * G)) {
         return sizeof(T) == 4
-                   ? beer_mfma::acc_full_f32(nframes, D, S, G, (const float*)X, (const float*)cr,
-                                             (const float*)sr, acc, ws, ws_bytes, s)
-                   : beer_mfma::acc_full_f64(nframes, D, S, G, (const double*)X,
-                                             (const double*)cr, (const double*)sr, acc, ws,
-                                             ws_bytes, s);
+                   ? beer_mfma::acc_f32(cov, nframes, D, S, G, (const float*)X, (const float*)cr,
+                                        (const float*)sr, acc, ws, ws_bytes, s)
+                   : beer_mfma::acc_f64(cov, nframes, D, S, G, (const double*)X,
+                                        (const double*)cr, (const double*)sr, acc, ws, ws_bytes,
+                                        s);
     }
     if (cov == BEER_FULL) return acc_launch<T, BEER_FULL>(nframes, D, S, G, X, cr, sr, acc, s);
     if (cov == BEER_DIAG) return acc_launch<T, BEER_DIAG>(nframes, D, S, G, X, cr, sr, acc, s);
@@ -462,14 +461,14 @@ int beer_mixtureset_estep(int dtype, int cov, int64_t T, int D, int S, int G, co
 }
 
 size_t beer_estep_workspace_bytes(int dtype, int cov, int D, int S, int G) {
-    if (cov != BEER_FULL) return 0;
-    return beer_mfma::estep_workspace_bytes(dtype == BEER_F64 ? 8 : 4, D, S, G);
+    if (cov < 0 || cov > 2) return 0;
+    return beer_mfma::estep_workspace_bytes(dtype == BEER_F64 ? 8 : 4, cov, D, S, G);
 }
 
 size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G) {
     (void)dtype;
-    if (cov != BEER_FULL) return 0;
-    return beer_mfma::acc_workspace_bytes(D, S * G);
+    if (cov < 0 || cov > 2) return 0;
+    return beer_mfma::acc_workspace_bytes(cov, D, S * G);
 }
 
 int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G, const void* X,

@@ -1,6 +1,6 @@
-// MFMA (matrix-core) fast path for the full-covariance E-step on gfx950.
-// See estep_mfma.hip for the design; estep.hip routes to it when the shape is
-// supported and the caller provides the scratch workspace.
+// MFMA (matrix-core) fast path of the E-step on gfx950 (all three covariance
+// types).  See estep_mfma.hip for the design; estep.hip routes to it when the
+// shape is supported and the caller provides the scratch workspace.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -11,18 +11,18 @@ namespace beer_mfma {
 
 bool supported_llh(int D, int S, int G);
 bool supported_acc(int D, int K);
-size_t estep_workspace_bytes(size_t elem, int D, int S, int G);
-size_t acc_workspace_bytes(int D, int K);
+size_t estep_workspace_bytes(size_t elem, int cov, int D, int S, int G);
+size_t acc_workspace_bytes(int cov, int D, int K);
 
-int estep_full_f32(int64_t T, int D, int S, int G, const float* X, const float* expT,
-                   const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
-                   size_t ws_bytes, hipStream_t s);
-int estep_full_f64(int64_t T, int D, int S, int G, const double* X, const double* expT,
-                   const double* logw, double* resps, double* log_norm, double* llh_sum,
-                   void* ws, size_t ws_bytes, hipStream_t s);
-int acc_full_f32(int64_t T, int D, int S, int G, const float* X, const float* R, const float* SR,
-                 double* acc, void* ws, size_t ws_bytes, hipStream_t s);
-int acc_full_f64(int64_t T, int D, int S, int G, const double* X, const double* R,
-                 const double* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s);
+int estep_f32(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
+              const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
+              size_t ws_bytes, hipStream_t s);
+int estep_f64(int cov, int64_t T, int D, int S, int G, const double* X, const double* expT,
+              const double* logw, double* resps, double* log_norm, double* llh_sum, void* ws,
+              size_t ws_bytes, hipStream_t s);
+int acc_f32(int cov, int64_t T, int D, int S, int G, const float* X, const float* R,
+            const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s);
+int acc_f64(int cov, int64_t T, int D, int S, int G, const double* X, const double* R,
+            const double* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s);
 
 }  // namespace beer_mfma

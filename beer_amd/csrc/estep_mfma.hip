@@ -60,41 +60,60 @@ template <> struct Mma<double> {
 };
 
 __host__ __device__ inline int d4_of(int D) { return (D + 3) / 4; }
-__host__ __device__ inline int nslab_of(int D) {
+
+// Slab enumeration per covariance type (see the header comment).  Diagonal and
+// isotropic models only have D4 "square" slabs xe[4j+g]^2 (flag bit 16 in the
+// table), D4 linear slabs and the constant slab.
+__host__ __device__ inline int nslab_of(int cov, int D) {
     const int D4 = d4_of(D);
     int n = D4 + 1;                                   // linear + constant
+    if (cov != BEER_FULL) return n + D4;
     for (int a = 0; a < D; ++a) n += D4 - a / 4;
     return n;
 }
-// index of slab (a, j), a < D quadratic; a == Dp: linear/constant
-__host__ __device__ inline int slab_index(int D, int a, int j) {
+// slab s -> table entry  a | (4j << 8) | (square << 16)
+__host__ __device__ inline int slab_entry(int cov, int D, int s) {
+    const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(cov, D);
+    const int nquad = nslab - (D4 + 1);
+    if (s >= nslab) return (Dp + 1) | (Dp << 8);          // padding: zero column
+    if (s >= nquad) return Dp | ((4 * (s - nquad)) << 8);  // linear / constant
+    if (cov != BEER_FULL) return Dp | ((4 * s) << 8) | (1 << 16);
+    int rem = s, a = 0;
+    for (;;) { const int len = D4 - a / 4; if (rem < len) break; rem -= len; ++a; }
+    return a | ((4 * (a / 4 + rem)) << 8);
+}
+// index of the quadratic slab holding x_a * x_b (a <= b), of linear slab j
+// (a == Dp) and of the constant slab (a == Dp, j == D4)
+__host__ __device__ inline int slab_index(int cov, int D, int a, int j) {
     const int D4 = d4_of(D);
-    if (a >= D) return nslab_of(D) - (D4 + 1) + j;
-    // sum_{a' < a} (D4 - a'/4): full groups of 4 then remainder
+    if (a >= D) return nslab_of(cov, D) - (D4 + 1) + j;
+    if (cov != BEER_FULL) return j;                       // square slab of x_{4j..4j+3}
     const int q = a / 4, r = a % 4;
     const int before = 4 * (q * D4 - q * (q - 1) / 2) + r * (D4 - q);
     return before + (j - q);
 }
 
 // slabs in the packed parameter image: an even count (the K1 loop is unrolled
-// by two) plus one look-ahead slab, all zero beyond nslab_of(D).
-__host__ __device__ inline int nslab_padded(int D) { return (nslab_of(D) + 1) / 2 * 2 + 1; }
+// by two) plus one look-ahead slab, all zero beyond nslab_of().
+__host__ __device__ inline int nslab_padded(int cov, int D) {
+    return (nslab_of(cov, D) + 1) / 2 * 2 + 1;
+}
 
 constexpr int kThreads = 256;
 constexpr double kPadLogit = -1.0e30;
 
 // ---------------------------------------------------------------------------
-// Parameter packing: E[T] [K, Q] (+ log weights) -> P[nslab][64 lanes][NT]
-// (each lane's NT B-fragment values contiguous) and the slab table
-// tab[s] = a | (4j << 8).
+// Parameter packing: E[T] [K, Q] (+ log weights) ->
+// P[chunk][slab][64 lanes][NT] (each lane's NT B-fragment values contiguous)
+// and the slab table.
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ void pack_kernel(int D, int K, int NT, int nchunks, const T* __restrict__ E,
-                            const T* __restrict__ logw, T* __restrict__ P,
-                            int* __restrict__ tab) {
-    const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(D);
-    const int Q = D * D + D + 2;
-    const int64_t per_chunk = (int64_t)nslab_padded(D) * 64 * NT;
+__global__ void pack_kernel(int cov, int D, int K, int NT, int nchunks,
+                            const T* __restrict__ E, const T* __restrict__ logw,
+                            T* __restrict__ P, int* __restrict__ tab) {
+    const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(cov, D);
+    const int Q = stats_dim(cov, D);
+    const int64_t per_chunk = (int64_t)nslab_padded(cov, D) * 64 * NT;
     const int64_t total = per_chunk * nchunks;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -105,56 +124,38 @@ __global__ void pack_kernel(int D, int K, int NT, int nchunks, const T* __restri
         const int s = (int)(rem_idx / ((int64_t)NT * 64));
         const int i = lane & 15, g = lane >> 4;
         const int k = chunk * NT * 16 + c * 16 + i;
-        if (s >= nslab) {                           // look-ahead padding: zero slabs
-            if (c == 0 && lane == 0 && chunk == 0) tab[s] = (Dp + 1) | ((Dp) << 8);
-            P[idx] = (T)0;
-            continue;
-        }
-        // decode slab s -> (a, j)
-        int a, j;
-        const int nq = nslab - (D4 + 1);
-        if (s >= nq) { a = Dp; j = s - nq; }
-        else {
-            // invert slab_index: walk groups (cheap: D4 <= 16)
-            int rem = s; a = 0;
-            for (;;) { const int len = D4 - a / 4; if (rem < len) break; rem -= len; ++a; }
-            j = a / 4 + rem;
-        }
-        if (c == 0 && lane == 0 && chunk == 0) tab[s] = a | ((4 * j) << 8);
-        const int b = 4 * j + g;
+        const int t = slab_entry(cov, D, s);
+        if (c == 0 && lane == 0 && chunk == 0) tab[s] = t;
+        const int a = t & 0xff, b = ((t >> 8) & 0xff) + g, sq = t >> 16;
         double v = 0.0;
-        if (k < K) {
+        if (s >= nslab) {
+            // look-ahead padding
+        } else if (k < K) {
             const T* e = E + (size_t)k * Q;
-            if (a < D) {
+            if (sq) {                                     // diag / iso: -.5 prec_b x_b^2
+                if (b < D) v = -0.5 * (double)e[cov == BEER_ISO ? D : D + b];
+            } else if (a < D) {                           // full: x_a x_b, a <= b
                 if (b < D && b >= a)
                     v = (b == a) ? -0.5 * (double)e[D + a * D + a]
                                  : -0.5 * ((double)e[D + a * D + b] + (double)e[D + b * D + a]);
-            } else if (j < D4) {
+            } else if (b - g < Dp) {                      // linear
                 if (b < D) v = (double)e[b];
-            } else if (g == 0) {
-                v = -0.5 * (double)e[Q - 2] + 0.5 * (double)e[Q - 1] - 0.5 * (double)D * kLog2Pi +
-                    (logw ? (double)logw[k] : 0.0);
+            } else if (g == 0) {                          // constant
+                const double zero = cov == BEER_ISO ? 0.5 * (double)D : 0.5;
+                v = -0.5 * (double)e[Q - 2] + zero * (double)e[Q - 1] -
+                    0.5 * (double)D * kLog2Pi + (logw ? (double)logw[k] : 0.0);
             }
-        } else if (a == Dp && j == D4 && g == 0) {
+        } else if (a == Dp && b - g == Dp && g == 0) {
             v = kPadLogit;                          // padded component: exp() -> 0
         }
         P[idx] = (T)v;
     }
 }
 
-__global__ void tab_kernel(int D, int* __restrict__ tab) {
-    const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(D);
-    const int nq = nslab - (D4 + 1);
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nslab; s += gridDim.x * blockDim.x) {
-        int a, j;
-        if (s >= nq) { a = Dp; j = s - nq; }
-        else {
-            int rem = s; a = 0;
-            for (;;) { const int len = D4 - a / 4; if (rem < len) break; rem -= len; ++a; }
-            j = a / 4 + rem;
-        }
-        tab[s] = a | ((4 * j) << 8);
-    }
+__global__ void tab_kernel(int cov, int D, int* __restrict__ tab) {
+    const int nslab = nslab_of(cov, D);
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nslab; s += gridDim.x * blockDim.x)
+        tab[s] = slab_entry(cov, D, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -210,7 +211,8 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 && MT * NT <= 32) ? 2 : 1
     const vec4_t* Pl = reinterpret_cast<const vec4_t*>(P) + (size_t)lane * (NT / 4);
     auto fetch = [&](int s, vec4_t (&b4)[NT / 4], T (&xa)[MT], T (&xb)[MT]) {
         const int t = tab[s];
-        const int a = t & 0xff, jb = (t >> 8) + g;
+        const int jb = ((t >> 8) & 0xff) + g;
+        const int a = (t >> 16) ? jb : (t & 0xff);          // square slab: xe[4j+g]^2
 #pragma unroll
         for (int c4 = 0; c4 < NT / 4; ++c4) b4[c4] = Pl[(size_t)s * 64 * (NT / 4) + c4];
 #pragma unroll
@@ -344,8 +346,8 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
         int a = Dp + 1, b = Dp + 1;
         if (slab < nslab) {
             const int t = tab[slab];
-            a = t & 0xff;
-            b = (t >> 8) + (i & 3);
+            b = ((t >> 8) & 0xff) + (i & 3);
+            a = (t >> 16) ? b : (t & 0xff);                   // square slab
         }
         ma[uu] = a < D ? -1 : 0;
         ca[uu] = a < D ? a : (a == Dp ? one_off : zero_off);
@@ -471,12 +473,14 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
         }
 }
 
-// Sp [K][nslab*4] (packed symmetric sums) -> acc [K][Q] += in the reference's
-// layout [sum r x, -.5 sum r x x^T (dense D x D), -.5 N, +.5 N].
-__global__ void unpack_kernel(int D, int K, const double* __restrict__ Sp,
+// Sp [K][nslab*4] (packed sums) -> acc [K][Q] += in the reference's layout:
+// full [sum r x, -.5 sum r x x^T (dense D x D), -.5 N, +.5 N], diagonal
+// [sum r x, -.5 sum r x^2, -.5 N, +.5 N], isotropic [sum r x, -.5 sum r |x|^2,
+// -.5 N, +.5 D N].
+__global__ void unpack_kernel(int cov, int D, int K, const double* __restrict__ Sp,
                               double* __restrict__ acc) {
-    const int D4 = d4_of(D), Dp = 4 * D4, nq = nslab_of(D) * 4;
-    const int Q = D * D + D + 2;
+    const int D4 = d4_of(D), Dp = 4 * D4, nq = nslab_of(cov, D) * 4;
+    const int Q = stats_dim(cov, D);
     const int64_t total = (int64_t)K * Q;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -484,14 +488,21 @@ __global__ void unpack_kernel(int D, int K, const double* __restrict__ Sp,
         const double* s = Sp + (size_t)k * nq;
         double v;
         if (q < D) {
-            v = s[slab_index(D, Dp, q / 4) * 4 + q % 4];
-        } else if (q < D + D * D) {
+            v = s[slab_index(cov, D, Dp, q / 4) * 4 + q % 4];
+        } else if (q >= Q - 2) {
+            const double n = s[slab_index(cov, D, Dp, D4) * 4];
+            v = (q == Q - 2) ? -0.5 * n : (cov == BEER_ISO ? 0.5 * (double)D * n : 0.5 * n);
+        } else if (cov == BEER_FULL) {
             int a = (q - D) / D, b = (q - D) % D;
             if (a > b) { const int t = a; a = b; b = t; }
-            v = -0.5 * s[slab_index(D, a, b / 4) * 4 + b % 4];
+            v = -0.5 * s[slab_index(cov, D, a, b / 4) * 4 + b % 4];
+        } else if (cov == BEER_DIAG) {
+            const int d = q - D;
+            v = -0.5 * s[slab_index(cov, D, d, d / 4) * 4 + d % 4];
         } else {
-            const double n = s[slab_index(D, Dp, D4) * 4];
-            v = (q == Q - 2) ? -0.5 * n : 0.5 * n;
+            double tot = 0.0;
+            for (int d = 0; d < D; ++d) tot += s[slab_index(cov, D, d, d / 4) * 4 + d % 4];
+            v = -0.5 * tot;
         }
         acc[idx] += v;
     }
@@ -519,22 +530,23 @@ int launch_llh(int64_t nframes, int D, int K, int S, int G, int gl, int nchunks,
 }
 
 template <typename T>
-int estep_impl(int64_t nframes, int D, int S, int G, const T* X, const T* expT, const T* logw,
-               T* resps, T* log_norm, double* llh_sum, void* ws, size_t ws_bytes,
+int estep_impl(int cov, int64_t nframes, int D, int S, int G, const T* X, const T* expT,
+               const T* logw, T* resps, T* log_norm, double* llh_sum, void* ws, size_t ws_bytes,
                hipStream_t s) {
     const int K = S * G;
-    if (!supported_llh(D, S, G) || ws_bytes < estep_workspace_bytes(sizeof(T), D, S, G))
+    if (!supported_llh(D, S, G) || ws_bytes < estep_workspace_bytes(sizeof(T), cov, D, S, G))
         return BEER_EINVAL;
     const int NT = nt_for(S, K), nchunks = nchunks_for(S, K);
-    const int nslab = nslab_padded(D) - 1;                      // even, >= nslab_of(D)
+    const int nsp = nslab_padded(cov, D);
+    const int nslab = nsp - 1;                                  // even, >= nslab_of()
     T* P = reinterpret_cast<T*>(ws);
-    const size_t p_bytes = (size_t)nchunks * nslab_padded(D) * 64 * NT * sizeof(T);
+    const size_t p_bytes = (size_t)nchunks * nsp * 64 * NT * sizeof(T);
     int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + align_up<T>(p_bytes));
-    const int64_t total = (int64_t)nchunks * nslab_padded(D) * 64 * NT;
+    const int64_t total = (int64_t)nchunks * nsp * 64 * NT;
     int64_t pblocks = (total + 255) / 256;
     if (pblocks > 65535) pblocks = 65535;
-    hipLaunchKernelGGL(pack_kernel<T>, dim3((unsigned)pblocks), dim3(256), 0, s, D, K, NT, nchunks,
-                       expT, logw, P, tab);
+    hipLaunchKernelGGL(pack_kernel<T>, dim3((unsigned)pblocks), dim3(256), 0, s, cov, D, K, NT,
+                       nchunks, expT, logw, P, tab);
     BEER_LAUNCH_CHECK();
     constexpr int MT = sizeof(T) == 4 ? 2 : 1;
 #define BEER_LLH(NT_, GT_) \
@@ -560,15 +572,15 @@ int estep_impl(int64_t nframes, int D, int S, int G, const T* X, const T* expT, 
 }
 
 template <typename T>
-int acc_impl(int64_t nframes, int D, int S, int G, const T* X, const T* R, const T* SR,
+int acc_impl(int cov, int64_t nframes, int D, int S, int G, const T* X, const T* R, const T* SR,
              double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
     const int K = S * G;
-    if (!supported_acc(D, K) || ws_bytes < acc_workspace_bytes(D, K)) return BEER_EINVAL;
-    const int nslab = nslab_of(D), nq = nslab * 4;
+    if (!supported_acc(D, K) || ws_bytes < acc_workspace_bytes(cov, D, K)) return BEER_EINVAL;
+    const int nslab = nslab_of(cov, D), nq = nslab * 4;
     double* Sp = reinterpret_cast<double*>(ws);
     int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) +
                                       align_up<T>((size_t)K * nq * sizeof(double)));
-    hipLaunchKernelGGL(tab_kernel, dim3(1), dim3(256), 0, s, D, tab);
+    hipLaunchKernelGGL(tab_kernel, dim3(1), dim3(256), 0, s, cov, D, tab);
     BEER_LAUNCH_CHECK();
     hipError_t e = hipMemsetAsync(Sp, 0, (size_t)K * nq * sizeof(double), s);
     if (e != hipSuccess) return -(int)e;
@@ -588,9 +600,9 @@ int acc_impl(int64_t nframes, int D, int S, int G, const T* X, const T* R, const
     hipLaunchKernelGGL(acc_kernel<T>, dim3(gx, gy, (unsigned)gz), dim3(kThreads), lds, s, nframes,
                        D, K, G, S, nslab, X, R, SR, tab, fpb, Sp);
     BEER_LAUNCH_CHECK();
-    const int64_t total = (int64_t)K * (D * D + D + 2);
-    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, D, K,
-                       Sp, acc);
+    const int64_t total = (int64_t)K * stats_dim(cov, D);
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cov,
+                       D, K, Sp, acc);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }
@@ -612,39 +624,40 @@ bool supported_acc(int D, int K) {
     return D >= 1 && D <= 64 && K >= 16 && K % 4 == 0;
 }
 
-size_t estep_workspace_bytes(size_t elem, int D, int S, int G) {
+size_t estep_workspace_bytes(size_t elem, int cov, int D, int S, int G) {
     if (!supported_llh(D, S, G)) return 0;
-    const int nslab = nslab_padded(D), K = S * G;
+    const int nslab = nslab_padded(cov, D), K = S * G;
     return (size_t)(((size_t)nchunks_for(S, K) * nslab * 64 * nt_for(S, K) * elem + 255) / 256 *
                     256) +
            (size_t)nslab * sizeof(int) + 256;
 }
 
-size_t acc_workspace_bytes(int D, int K) {
+size_t acc_workspace_bytes(int cov, int D, int K) {
     if (!supported_acc(D, K)) return 0;
-    const int nslab = nslab_of(D);
+    const int nslab = nslab_of(cov, D);
     return (size_t)(((size_t)K * nslab * 4 * sizeof(double) + 255) / 256 * 256) +
            (size_t)nslab * sizeof(int) + 256;
 }
 
-int estep_full_f32(int64_t T, int D, int S, int G, const float* X, const float* expT,
-                   const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
-                   size_t ws_bytes, hipStream_t s) {
-    return estep_impl<float>(T, D, S, G, X, expT, logw, resps, log_norm, llh_sum, ws, ws_bytes, s);
+int estep_f32(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
+              const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
+              size_t ws_bytes, hipStream_t s) {
+    return estep_impl<float>(cov, T, D, S, G, X, expT, logw, resps, log_norm, llh_sum, ws,
+                             ws_bytes, s);
 }
-int estep_full_f64(int64_t T, int D, int S, int G, const double* X, const double* expT,
-                   const double* logw, double* resps, double* log_norm, double* llh_sum,
-                   void* ws, size_t ws_bytes, hipStream_t s) {
-    return estep_impl<double>(T, D, S, G, X, expT, logw, resps, log_norm, llh_sum, ws, ws_bytes,
-                              s);
+int estep_f64(int cov, int64_t T, int D, int S, int G, const double* X, const double* expT,
+              const double* logw, double* resps, double* log_norm, double* llh_sum, void* ws,
+              size_t ws_bytes, hipStream_t s) {
+    return estep_impl<double>(cov, T, D, S, G, X, expT, logw, resps, log_norm, llh_sum, ws,
+                              ws_bytes, s);
 }
-int acc_full_f32(int64_t T, int D, int S, int G, const float* X, const float* R, const float* SR,
-                 double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
-    return acc_impl<float>(T, D, S, G, X, R, SR, acc, ws, ws_bytes, s);
+int acc_f32(int cov, int64_t T, int D, int S, int G, const float* X, const float* R,
+            const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
+    return acc_impl<float>(cov, T, D, S, G, X, R, SR, acc, ws, ws_bytes, s);
 }
-int acc_full_f64(int64_t T, int D, int S, int G, const double* X, const double* R,
-                 const double* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
-    return acc_impl<double>(T, D, S, G, X, R, SR, acc, ws, ws_bytes, s);
+int acc_f64(int cov, int64_t T, int D, int S, int G, const double* X, const double* R,
+            const double* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
+    return acc_impl<double>(cov, T, D, S, G, X, R, SR, acc, ws, ws_bytes, s);
 }
 
 }  // namespace beer_mfma

@@ -533,3 +533,29 @@ def test_c3_shape_batched_phone_loop_vs_oracle(cov, dtype, tol):
     assert_close(npy(elbo._acc_stats[ms.modelset.means_precisions]), acc_n, tol * 10, 'acc normal')
     assert_close(npy(elbo._acc_stats[ms.categoricalset.weights]), acc_w, tol * 10, 'acc weights')
     assert_close(npy(elbo._acc_stats[cat]), counts, tol * 10, 'phone counts')
+
+
+@pytest.mark.parametrize('cov', ['diagonal', 'isotropic', 'full'])
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-5)])
+@pytest.mark.parametrize('K,D', [(32, 13), (48, 40)])
+def test_gmm_matrix_core_path_all_cov_types_vs_oracle(cov, dtype, tol, K, D):
+    'K >= 16 takes the MFMA kernels for every covariance type; odd D exercises padding.'
+    T = 3000
+    rng = np.random.RandomState(K + D)
+    means = rng.randn(K, D) * 2
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    Xn = (means[rng.randint(0, K, T)] + rng.randn(T, D) * (1 + rng.rand(D))).astype(npdt)
+    X = torch.from_numpy(Xn)
+    torch.manual_seed(5)
+    ns = beer.NormalSet.create(X.mean(0), X.var(0), size=K, prior_strength=1., noise_std=1.,
+                               cov_type=cov)
+    model = beer.Mixture.create(ns).to(DEV)
+    p0, p1 = params_of(model)
+    as64 = lambda d: [npy(getattr(d.params, n)).astype(np.float64) for n in d._std_params_def]
+    post, prior = as64(p0.posterior), as64(p0.prior)
+    (w_post,), (w_prior,) = as64(p1.posterior), as64(p1.prior)
+    truth = orc.gmm_elbo_step(Xn.astype(np.float64), cov, post, prior, w_post, w_prior)
+    elbo = beer.evidence_lower_bound(model, X.to(DEV))
+    assert_close(float(elbo), truth['value'], tol, 'elbo')
+    assert_close(npy(elbo._acc_stats[p0]), truth['acc_normal'], tol * 5, 'acc normal')
+    assert_close(npy(elbo._acc_stats[p1]), truth['acc_weights'], tol * 5, 'acc weights')
