@@ -14,7 +14,10 @@ CSRC = os.path.join(HERE, 'csrc')
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, 'libbeer_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+# -pragma-unroll-threshold: the softmax epilogue of the MFMA E-step must be fully
+# unrolled (128 groups) or its accumulators fall out of registers into scratch.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall',
+         '-mllvm', '-pragma-unroll-threshold=262144',
          '-Wno-unused-function', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
 
 

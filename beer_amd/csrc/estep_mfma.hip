@@ -30,6 +30,8 @@
 
 #include "estep_mfma.h"
 
+#include <type_traits>
+
 #include "common.h"
 
 using namespace beer;
@@ -58,6 +60,39 @@ template <> struct Mma<double> {
     }
     static __device__ __forceinline__ int row(int g, int r) { return g + 4 * r; }
 };
+
+// All-reduce across the 16 lanes that hold one row of a 16x16 C tile, with
+// DPP (VALU, no LDS round trip): xor-1 / xor-2 inside a quad, then the two
+// mirrors (values are uniform inside a quad / half-row by then, so mirroring
+// equals the xor-4 / xor-8 exchange).  `gl` = lanes per group (1,2,4,8,16).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+        0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename T>
+__device__ __forceinline__ T group_max(T v, int gl) {
+    if (gl > 1) { const T w = dpp_move<0xB1>(v); v = w > v ? w : v; }      // quad_perm [1,0,3,2]
+    if (gl > 2) { const T w = dpp_move<0x4E>(v); v = w > v ? w : v; }      // quad_perm [2,3,0,1]
+    if (gl > 4) { const T w = dpp_move<0x141>(v); v = w > v ? w : v; }     // row_half_mirror
+    if (gl > 8) { const T w = dpp_move<0x140>(v); v = w > v ? w : v; }     // row_mirror
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T group_sum(T v, int gl) {
+    if (gl > 1) v += dpp_move<0xB1>(v);
+    if (gl > 2) v += dpp_move<0x4E>(v);
+    if (gl > 4) v += dpp_move<0x141>(v);
+    if (gl > 8) v += dpp_move<0x140>(v);
+    return v;
+}
 
 __host__ __device__ inline int d4_of(int D) { return (D + 3) / 4; }
 
@@ -254,6 +289,9 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 && MT * NT <= 32) ? 2 : 1
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            // one row at a time: without the barrier hipcc interleaves all
+            // 8 rows x NT/GT groups and spills the accumulators to scratch
+            __builtin_amdgcn_sched_barrier(0);
             const int64_t f = fb + m * 16 + M::row(g, r);
 #pragma unroll
             for (int tg = 0; tg < NT / GT; ++tg) {
@@ -261,20 +299,17 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 && MT * NT <= 32) ? 2 : 1
 #pragma unroll
                 for (int c = 1; c < GT; ++c)
                     mx = acc[m][tg * GT + c][r] > mx ? acc[m][tg * GT + c][r] : mx;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    if (o < gl) {
-                        const T w = __shfl_xor(mx, o, 64);
-                        mx = w > mx ? w : mx;
-                    }
-                }
+                mx = group_max(mx, gl);
+                T e[GT];
                 T sum = 0;
 #pragma unroll
-                for (int c = 0; c < GT; ++c) sum += exp(acc[m][tg * GT + c][r] - mx);
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1)
-                    if (o < gl) sum += __shfl_xor(sum, o, 64);
+                for (int c = 0; c < GT; ++c) {
+                    e[c] = exp(acc[m][tg * GT + c][r] - mx);
+                    sum += e[c];
+                }
+                sum = group_sum(sum, gl);
                 const T lse = mx + log(sum);
+                const T inv = (T)1 / sum;
                 const int k0 = kbase + tg * GT * 16 + (i & ~(gl - 1));     // group's first comp
                 const int state = k0 / G;
                 if (f < nframes && state < S) {
@@ -282,7 +317,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 && MT * NT <= 32) ? 2 : 1
 #pragma unroll
                         for (int c = 0; c < GT; ++c) {
                             const int k = kbase + (tg * GT + c) * 16 + i;
-                            if (k < K) resps[f * K + k] = exp(acc[m][tg * GT + c][r] - lse);
+                            if (k < K) resps[f * K + k] = e[c] * inv;
                         }
                     }
                     if ((i & (gl - 1)) == 0) {
@@ -307,11 +342,10 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 && MT * NT <= 32) ? 2 : 1
 // level; the cross-workgroup reduction is fp64 atomics.
 // ---------------------------------------------------------------------------
 constexpr int kAccMC = 4;        // component tiles per wave (shared by the 4 waves)
-constexpr int kAccNQ = 4;        // q tiles (of 16) per wave
 constexpr int kAccFT = 64;       // frames per LDS tile
 constexpr int kFlush = 256;      // frames per MFMA accumulation chain
 
-template <typename T>
+template <typename T, int NQ>
 __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
     int64_t nframes, int D, int K, int G, int S, int nslab, const T* __restrict__ X,
     const T* __restrict__ R, const T* __restrict__ SR, const int* __restrict__ tab,
@@ -330,7 +364,11 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     const int kc0 = blockIdx.y * RC;
-    const int u0 = (blockIdx.x * (kThreads / 64) + wave) * kAccNQ;     // first q tile
+    // q tiles are dealt to the 4 waves round-robin (tile = first + 4 uu + wave) so
+    // that a short statistics vector (diagonal models: 6 tiles, NQ = 2) still
+    // spreads over all SIMDs.
+    constexpr int kAccNQ = NQ;
+    const int tile0 = blockIdx.x * (kAccNQ * (kThreads / 64)) + wave;
     const int64_t tb = (int64_t)blockIdx.z * frames_per_block;
     const int64_t te = min(nframes, tb + frames_per_block);
     const int nq = nslab * 4;
@@ -342,7 +380,7 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
     const int one_off = kAccFT * D, zero_off = kAccFT * D + 1;
 #pragma unroll
     for (int uu = 0; uu < kAccNQ; ++uu) {
-        const int slab = 4 * (u0 + uu) + (i >> 2);
+        const int slab = 4 * (tile0 + 4 * uu) + (i >> 2);
         int a = Dp + 1, b = Dp + 1;
         if (slab < nslab) {
             const int t = tab[slab];
@@ -423,8 +461,6 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
         const T* xs = lds + buf * buf_elems;
         const T* rs = xs + xs_elems;
         if (tile + 1 < ntiles) load_tile(tb + (tile + 1) * kAccFT);
-        // waves whose statistics lie entirely beyond the last slab only help staging
-        if (u0 * 16 < nq)
 #pragma unroll 2
         for (int kk = 0; kk < kAccFT / 4; ++kk) {
             // A fragments: r[frame 4kk+g][component slot 4i..4i+3] -- the 64 lanes
@@ -460,7 +496,7 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
     for (int c = 0; c < kAccMC; ++c)
 #pragma unroll
         for (int uu = 0; uu < kAccNQ; ++uu) {
-            const int q = (u0 + uu) * 16 + i;
+            const int q = (tile0 + 4 * uu) * 16 + i;
             if (q >= nq) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -584,7 +620,9 @@ int acc_impl(int cov, int64_t nframes, int D, int S, int G, const T* X, const T*
     BEER_LAUNCH_CHECK();
     hipError_t e = hipMemsetAsync(Sp, 0, (size_t)K * nq * sizeof(double), s);
     if (e != hipSuccess) return -(int)e;
-    const int gx = (nslab + 4 * kAccNQ * (kThreads / 64) - 1) / (4 * kAccNQ * (kThreads / 64));
+    const int ntiles = (nq + 15) / 16;
+    const int NQ = ntiles > 8 ? 4 : (ntiles > 4 ? 2 : 1);       // q tiles per wave
+    const int gx = (ntiles + NQ * (kThreads / 64) - 1) / (NQ * (kThreads / 64));
     const int gy = (K + 16 * kAccMC - 1) / (16 * kAccMC);
     int64_t gz = (1024 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy);
     const int64_t max_z = (nframes + 1023) / 1024;
@@ -595,10 +633,18 @@ int acc_impl(int cov, int64_t nframes, int D, int S, int G, const T* X, const T*
     gz = (nframes + fpb - 1) / fpb;
     const size_t lds = 2 * ((size_t)(kAccFT * D + 2 + 3) / 4 * 4 + (size_t)kAccFT * 16 * kAccMC) *
                        sizeof(T);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc_kernel<T>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(acc_kernel<T>, dim3(gx, gy, (unsigned)gz), dim3(kThreads), lds, s, nframes,
-                       D, K, G, S, nslab, X, R, SR, tab, fpb, Sp);
+    const dim3 grid(gx, gy, (unsigned)gz);
+#define BEER_ACC(NQ_)                                                                           \
+    do {                                                                                        \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc_kernel<T, NQ_>),            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        hipLaunchKernelGGL((acc_kernel<T, NQ_>), grid, dim3(kThreads), lds, s, nframes, D, K, G, \
+                           S, nslab, X, R, SR, tab, fpb, Sp);                                   \
+    } while (0)
+    if (NQ == 4) BEER_ACC(4);
+    else if (NQ == 2) BEER_ACC(2);
+    else BEER_ACC(1);
+#undef BEER_ACC
     BEER_LAUNCH_CHECK();
     const int64_t total = (int64_t)K * stats_dim(cov, D);
     hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cov,
