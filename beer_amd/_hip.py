@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libbeer_hip.so')
 F32, F64 = 0, 1
 FULL, DIAG, ISO = 0, 1, 2
 SEG = 8                     # BEER_SEG of include/beer_hip.h
+MAX_HUBS = 4                # kMaxHubs of csrc/hmm.hip
 COV_CODE = {'full': FULL, 'diagonal': DIAG, 'isotropic': ISO}
 EINVAL = -100000
 
@@ -57,14 +58,24 @@ class Graph(ctypes.Structure):
                 ('in_ptr', c_p), ('in_src', c_p), ('in_dst', c_p), ('in_w', c_p),
                 ('in_seg', c_p), ('in_row_seg', c_p),
                 ('out_ptr', c_p), ('out_dst', c_p), ('out_src', c_p), ('out_w', c_p),
-                ('out_seg', c_p), ('out_row_seg', c_p)]
+                ('out_seg', c_p), ('out_row_seg', c_p), ('lowdeg', c_p)]
+
+
+class GraphLowDeg(ctypes.Structure):
+    'beer_graph_lowdeg of include/beer_hip.h.'
+    _fields_ = [('n_arcs', ctypes.c_int32), ('n_hubs', ctypes.c_int32),
+                ('in_ptr', c_p), ('in_src', c_p), ('in_w', c_p),
+                ('out_ptr', c_p), ('out_dst', c_p), ('out_w', c_p),
+                ('hub_src_id', c_p), ('hub_src_w', c_p), ('hub_dst_id', c_p),
+                ('hub_dst_w', c_p), ('src_ptr', c_p), ('src_list', c_p),
+                ('dst_ptr', c_p), ('dst_list', c_p)]
 
 
 class Batch(ctypes.Structure):
     'beer_batch of include/beer_hip.h.'
     _fields_ = [('nutt', ctypes.c_int32), ('max_states', ctypes.c_int32),
                 ('max_arcs', ctypes.c_int32), ('max_segs', ctypes.c_int32),
-                ('reserved', ctypes.c_int32), ('n_graphs', ctypes.c_int32),
+                ('all_lowdeg', ctypes.c_int32), ('n_graphs', ctypes.c_int32),
                 ('frame_off', c_p), ('llh_off', c_p), ('graph_id', c_p),
                 ('graphs', c_p), ('pdf_off', c_p), ('pdf_ids', c_p)]
 
@@ -98,7 +109,7 @@ SIGNATURES = {
                                c_p],
     'beer_weights_from_acc': [c_i, c_i, c_i, c_p, c_p, c_p],
     'beer_hmm_gather': [c_i, c_p, c_i, c_p, c_d, c_p, c_p],
-    'beer_hmm_forward_backward': [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'beer_hmm_forward_backward': [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     'beer_hmm_viterbi': [c_i, c_p, c_p, c_p, c_p, c_i, c_p],
     'beer_hmm_path_posteriors': [c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     'beer_hmm_scatter': [c_i, c_p, c_i, c_p, c_p, c_d, c_p, c_p, c_p, c_p],

@@ -311,6 +311,243 @@ __global__ __launch_bounds__(kFbThreads) void fb_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// forward-backward, low-degree + hub variant (see beer_graph_lowdeg).  Every
+// state has <= BEER_SEG sparse arcs, so one thread per state finishes its
+// log-sum-exp alone; a hub (the eliminated pivot of a phone loop) is one
+// log-sum-exp over <= a few dozen sources done by wave 0 with shuffles while
+// the other waves work on the sparse arcs.  Barriers per frame: 2 forward,
+// 4 backward (the general kernel above needs 5 + 9).
+// ---------------------------------------------------------------------------
+constexpr int kLdThreads = 256;
+constexpr int kMaxHubs = 4;
+
+template <typename T>
+__device__ __forceinline__ double logaddexp2(double a, double b) {
+    const double m = a > b ? a : b;
+    if (!(m > neg_inf())) return m;                       // both -inf
+    return m + flog<T>(fexp<T>(a - m) + fexp<T>(b - m));
+}
+
+template <typename T>
+__global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
+    beer_batch b, const T* __restrict__ pc_llhs, double* __restrict__ alpha_ws,
+    T* __restrict__ gamma, double* __restrict__ xi_sum, double* __restrict__ gamma0_sum,
+    double* __restrict__ hub_flow, T* __restrict__ lognorm_mean) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int u = blockIdx.x, tid = threadIdx.x, nt_ = blockDim.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const beer_graph g = b.graphs[b.graph_id[u]];
+    const beer_graph_lowdeg L = *g.lowdeg;
+    const int S = g.n_states, H = L.n_hubs;
+    const int64_t T_ = b.frame_off[u + 1] - b.frame_off[u];
+    if (T_ <= 0) return;
+    const T* llh = pc_llhs + b.llh_off[u];
+    double* alpha = alpha_ws + b.llh_off[u];
+    T* gam = gamma + b.llh_off[u];
+    const T* in_w = (const T*)L.in_w;
+    const T* out_w = (const T*)L.out_w;
+    const T* hsw = (const T*)L.hub_src_w;
+    const T* hdw = (const T*)L.hub_dst_w;
+    const double NINF = neg_inf(), PINF = __builtin_huge_val();
+
+    double* cur = reinterpret_cast<double*>(smem);       // [S] alpha_{t-1} / beta_t
+    double* lb = cur + b.max_states;                     // [S] llh_{t+1} + beta_{t+1}
+    // hub[0..kMaxHubs): hub value of the running recursion; hub[kMaxHubs]:
+    // lognorm_t; hub[kMaxHubs+1 ..): forward hub values H_h(t), recomputed in the
+    // backward pass from alpha_t by wave 1 (needed for the hub flows)
+    double* hub = lb + b.max_states;
+
+    // One state per thread (S <= blockDim is required by the launcher).
+    const int j = tid;
+    const bool st = j < S;
+    // this state's sparse arcs, weights and hub links in registers
+    int in_beg = 0, in_end = 0, out_beg = 0, out_end = 0, hs = -1, hd = -1;
+    double hs_w = 0.0, hd_w = 0.0;
+    if (st) {
+        in_beg = L.in_ptr[j]; in_end = L.in_ptr[j + 1];
+        out_beg = L.out_ptr[j]; out_end = L.out_ptr[j + 1];
+        hs = L.hub_src_id[j]; hd = L.hub_dst_id[j];
+        if (hs >= 0) hs_w = (double)hsw[j];
+        if (hd >= 0) hd_w = (double)hdw[j];
+    }
+    int isrc[BEER_SEG], odst[BEER_SEG];
+    double iw[BEER_SEG], ow[BEER_SEG], xi_r[BEER_SEG];
+#pragma unroll
+    for (int k = 0; k < BEER_SEG; ++k) {
+        const bool a = in_beg + k < in_end, o = out_beg + k < out_end;
+        isrc[k] = a ? L.in_src[in_beg + k] : 0;
+        iw[k] = a ? (double)in_w[in_beg + k] : NINF;
+        odst[k] = o ? L.out_dst[out_beg + k] : 0;
+        ow[k] = o ? (double)out_w[out_beg + k] : NINF;
+        xi_r[k] = 0.0;
+    }
+    double flow_r = 0.0;                                  // hub -> this state
+
+    // wave 0: log-sum-exp over the members of every hub
+    // (vals[] are read from LDS `cur` or `lb` + per-member weight)
+    auto hub_lse = [&](const double* col, const int32_t* ptr, const int32_t* list,
+                       const T* w) {
+        for (int h = 0; h < H; ++h) {
+            const int beg = ptr[h], end = ptr[h + 1];
+            double m = NINF;
+            for (int p = beg + lane; p < end; p += 64) {
+                const double val = col[list[p]] + (double)w[list[p]];
+                m = val > m ? val : m;
+            }
+            m = wave_max(m);
+            double r = m;
+            if (m > NINF && m < PINF) {
+                double sm = 0.0;
+                for (int p = beg + lane; p < end; p += 64)
+                    sm += fexp<T>(col[list[p]] + (double)w[list[p]] - m);
+                sm = wave_sum(sm);
+                r = m + flog<T>(sm);
+            }
+            if (lane == 0) hub[h] = r;
+        }
+    };
+
+    // ---- forward ----
+    if (st) {
+        const double a = (double)llh[j] + (double)((const T*)g.init)[j];
+        cur[j] = a;
+        alpha[j] = a;
+    }
+    __syncthreads();
+    for (int64_t t = 1; t < T_; ++t) {
+        if (wave == 0 && H > 0) hub_lse(cur, L.src_ptr, L.src_list, hsw);
+        double m = NINF, sm = 0.0;
+        if (st) {
+#pragma unroll
+            for (int k = 0; k < BEER_SEG; ++k) {
+                const double val = cur[isrc[k]] + iw[k];
+                m = val > m ? val : m;
+            }
+            if (m > NINF && m < PINF) {
+#pragma unroll
+                for (int k = 0; k < BEER_SEG; ++k)
+                    if (iw[k] > NINF) sm += fexp<T>(cur[isrc[k]] + iw[k] - m);
+            }
+        }
+        __syncthreads();                                  // hub values visible; cur fully read
+        if (st) {
+            double lse = (m > NINF && m < PINF) ? m + flog<T>(sm) : m;
+            if (hd >= 0) lse = logaddexp2<T>(lse, hub[hd] + hd_w);
+            const double a = (double)llh[t * S + j] + lse;
+            cur[j] = a;
+            alpha[t * S + j] = a;
+        }
+        __syncthreads();
+    }
+
+    // ---- backward + posteriors ----
+    if (st) cur[j] = (double)((const T*)g.final)[j];     // beta_{T-1}
+    __syncthreads();
+    double ln_acc = 0.0;
+    for (int64_t t = T_ - 1; t >= 0; --t) {
+        const bool inner = t < T_ - 1;
+        if (inner) {
+            // beta_t(i) = lse(sparse: A_ij + lb_j ; hub: r_i + lse_s(w_s + lb_s))
+            if (wave == 0 && H > 0) hub_lse(lb, L.dst_ptr, L.dst_list, hdw);
+            double m = NINF, sm = 0.0;
+            if (st) {
+#pragma unroll
+                for (int k = 0; k < BEER_SEG; ++k) {
+                    const double val = ow[k] + lb[odst[k]];
+                    m = val > m ? val : m;
+                }
+                if (m > NINF && m < PINF) {
+#pragma unroll
+                    for (int k = 0; k < BEER_SEG; ++k)
+                        if (ow[k] > NINF) sm += fexp<T>(ow[k] + lb[odst[k]] - m);
+                }
+            }
+            __syncthreads();
+            if (st) {
+                double lse = (m > NINF && m < PINF) ? m + flog<T>(sm) : m;
+                if (hs >= 0) lse = logaddexp2<T>(lse, hs_w + hub[hs]);
+                cur[j] = lse;
+            }
+            __syncthreads();
+        }
+        // lognorm_t = lse_i(alpha_t(i) + beta_t(i)) by wave 0; forward hub values
+        // H_h(t) = lse_e(alpha_t(e) + r_e) (for the hub flows) by wave 1
+        const double ab = st ? alpha[t * S + j] + cur[j] : NINF;
+        if (wave == 0) {
+            double m = NINF;
+            for (int p = lane; p < S; p += 64) {
+                const double val = alpha[t * S + p] + cur[p];
+                m = val > m ? val : m;
+            }
+            m = wave_max(m);
+            double r = m;
+            if (m > NINF && m < PINF) {
+                double sm = 0.0;
+                for (int p = lane; p < S; p += 64) sm += fexp<T>(alpha[t * S + p] + cur[p] - m);
+                sm = wave_sum(sm);
+                r = m + flog<T>(sm);
+            }
+            if (lane == 0) hub[kMaxHubs] = r;
+        } else if (wave == 1 && inner && xi_sum && H > 0) {
+            for (int h = 0; h < H; ++h) {
+                const int beg = L.src_ptr[h], end = L.src_ptr[h + 1];
+                double m = NINF;
+                for (int p = beg + lane; p < end; p += 64) {
+                    const int e = L.src_list[p];
+                    const double val = alpha[t * S + e] + (double)hsw[e];
+                    m = val > m ? val : m;
+                }
+                m = wave_max(m);
+                double r = m;
+                if (m > NINF && m < PINF) {
+                    double sm = 0.0;
+                    for (int p = beg + lane; p < end; p += 64) {
+                        const int e = L.src_list[p];
+                        sm += fexp<T>(alpha[t * S + e] + (double)hsw[e] - m);
+                    }
+                    sm = wave_sum(sm);
+                    r = m + flog<T>(sm);
+                }
+                if (lane == 0) hub[kMaxHubs + 1 + h] = r;
+            }
+        }
+        __syncthreads();
+        const double lognorm = hub[kMaxHubs];
+        ln_acc += lognorm;
+        if (st) {
+            const double gv = fexp<T>(ab - lognorm);       // NaN if -inf - -inf, as the reference
+            gam[t * S + j] = (T)gv;
+            if (t == 0 && gamma0_sum) atomicAdd(gamma0_sum + j, gv);
+            if (xi_sum && inner && lognorm > NINF) {
+                // arcs t -> t+1 leaving this state, and the hub flow entering it
+                const double ai = alpha[t * S + j] - lognorm;
+#pragma unroll
+                for (int k = 0; k < BEER_SEG; ++k) {
+                    if (ow[k] > NINF) {
+                        const double val = fexp<T>(ai + ow[k] + lb[odst[k]]);
+                        if (val == val) xi_r[k] += val;
+                    }
+                }
+                if (hd >= 0) {
+                    const double val = fexp<T>(hub[kMaxHubs + 1 + hd] + hd_w + lb[j] - lognorm);
+                    if (val == val) flow_r += val;
+                }
+            }
+        }
+        __syncthreads();                                  // lb readers done
+        if (st) lb[j] = (double)llh[t * S + j] + cur[j];  // for frame t-1
+        __syncthreads();
+    }
+    if (lognorm_mean && tid == 0) lognorm_mean[u] = (T)(ln_acc / (double)T_);
+    if (xi_sum && st) {
+#pragma unroll
+        for (int k = 0; k < BEER_SEG; ++k)
+            if (ow[k] > NINF && xi_r[k] != 0.0) atomicAdd(xi_sum + (size_t)j * S + odst[k], xi_r[k]);
+        if (hd >= 0 && hub_flow) atomicAdd(hub_flow + j, flow_r);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Viterbi
 // ---------------------------------------------------------------------------
 template <typename T>
@@ -432,15 +669,29 @@ int beer_hmm_scatter(int dtype, const beer_batch* batch_h, int S_total, const vo
 
 int beer_hmm_forward_backward(int dtype, const beer_batch* b, const void* pc_llhs,
                               double* alpha_ws, void* gamma, double* xi_sum, double* gamma0_sum,
-                              void* lognorm_mean, void* stream) {
+                              double* hub_flow, void* lognorm_mean, void* stream) {
     BEER_REQUIRE(b && b->nutt >= 0 && b->max_states >= 1 && b->max_states <= 32767);
     BEER_REQUIRE(dtype == BEER_F32 || dtype == BEER_F64);
     if (b->nutt == 0) return BEER_OK;
+    hipStream_t s = as_stream(stream);
+    if (b->all_lowdeg && b->max_states <= kLdThreads && (!xi_sum || hub_flow)) {
+        // factorised low-degree recursion: one thread per state
+        const size_t lds = ((size_t)2 * b->max_states + 4 * kMaxHubs + 8) * sizeof(double);
+        if (dtype == BEER_F32)
+            hipLaunchKernelGGL(fb_lowdeg_kernel<float>, dim3(b->nutt), dim3(kLdThreads), lds, s,
+                               *b, (const float*)pc_llhs, alpha_ws, (float*)gamma, xi_sum,
+                               gamma0_sum, hub_flow, (float*)lognorm_mean);
+        else
+            hipLaunchKernelGGL(fb_lowdeg_kernel<double>, dim3(b->nutt), dim3(kLdThreads), lds, s,
+                               *b, (const double*)pc_llhs, alpha_ws, (double*)gamma, xi_sum,
+                               gamma0_sum, hub_flow, (double*)lognorm_mean);
+        BEER_LAUNCH_CHECK();
+        return BEER_OK;
+    }
     const FbLayout L(b->max_states, b->max_arcs, b->max_segs, xi_sum != nullptr,
                      dtype == BEER_F32 ? 4 : 8);
     const size_t lds = L.total;
     BEER_REQUIRE(lds <= 160 * 1024);          // graph too large for one CU's LDS
-    hipStream_t s = as_stream(stream);
     if (dtype == BEER_F32) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fb_kernel<float>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

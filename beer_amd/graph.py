@@ -167,7 +167,7 @@ class Graph:
 class DeviceGraph:
     'CSR image of a CompiledGraph in device memory + its beer_graph struct.'
 
-    def __init__(self, init, final, trans, device, dtype):
+    def __init__(self, init, final, trans, device, dtype, hubs=()):
         trans_h = trans.detach().to('cpu', torch.float64)
         S = trans_h.shape[0]
         finite = trans_h > -float('inf')
@@ -198,12 +198,79 @@ class DeviceGraph:
             out_seg=out_seg.to(device), out_row_seg=out_row_seg.to(device))
         b = self.bufs
         p = lambda name: b[name].data_ptr()                     # noqa: E731
+        self.lowdeg = self._lowdeg(trans.detach().to('cpu'), finite, hubs, device, dtype)
+        lowdeg_ptr = 0
+        if self.lowdeg is not None:
+            b['lowdeg_struct'] = _hip.struct_to_device(self.lowdeg, device)
+            lowdeg_ptr = b['lowdeg_struct'].data_ptr()
         self.struct = _hip.Graph(S, self.n_arcs, self.n_in_seg, self.n_out_seg,
                                  p('init'), p('final'),
                                  p('in_ptr'), p('in_src'), p('in_dst'), p('in_w'),
                                  p('in_seg'), p('in_row_seg'),
                                  p('out_ptr'), p('out_dst'), p('out_src'), p('out_w'),
-                                 p('out_seg'), p('out_row_seg'))
+                                 p('out_seg'), p('out_row_seg'), lowdeg_ptr)
+
+    def _lowdeg(self, trans_h, finite, hubs, device, dtype):
+        '''Factorised image (beer_graph_lowdeg): the hub blocks -- verified to be
+        rank one in the log domain -- are removed from the CSR; kept only if
+        every remaining row has at most SEG arcs.'''
+        S = trans_h.shape[0]
+        if len(hubs) > _hip.MAX_HUBS:
+            return None
+        keep = finite.clone()
+        src_id = torch.full((S,), -1, dtype=torch.int32)
+        dst_id = torch.full((S,), -1, dtype=torch.int32)
+        src_w = torch.zeros(S, dtype=trans_h.dtype)
+        dst_w = torch.zeros(S, dtype=trans_h.dtype)
+        src_ptr, src_list, dst_ptr, dst_list = [0], [], [0], []
+        for h, (src, sw, dst, dw) in enumerate(hubs):
+            src, dst = torch.as_tensor(src).cpu().long(), torch.as_tensor(dst).cpu().long()
+            # The dense matrix is authoritative: factor the block itself
+            # (A[e,s] = A[e,0] + A[0,s] - A[0,0] for a rank-one log block) and
+            # use the caller's weights only as a hint that the block exists.
+            block = trans_h[src][:, dst].to(torch.float64)
+            if not bool(torch.isfinite(block).all()):
+                return None
+            sw = block[:, 0].clone()
+            dw = block[0, :] - block[0, 0]
+            model = sw[:, None] + dw[None, :]
+            ok = torch.allclose(block, model, rtol=0., atol=1e-6 * float(block.abs().max())) and \
+                bool((src_id[src] < 0).all()) and bool((dst_id[dst] < 0).all())
+            sw, dw = sw.to(trans_h.dtype), dw.to(trans_h.dtype)
+            if not ok:
+                return None
+            keep[src[:, None], dst[None, :]] = False
+            src_id[src], dst_id[dst] = h, h
+            src_w[src], dst_w[dst] = sw, dw
+            src_list += src.tolist()
+            src_ptr.append(len(src_list))
+            dst_list += dst.tolist()
+            dst_ptr.append(len(dst_list))
+        if keep.sum(0).max() > _hip.SEG or keep.sum(1).max() > _hip.SEG:
+            return None
+        dst_i, src_i = torch.nonzero(keep.t(), as_tuple=True)
+        in_ptr = torch.zeros(S + 1, dtype=torch.int32)
+        in_ptr[1:] = torch.cumsum(torch.bincount(dst_i, minlength=S), 0).to(torch.int32)
+        src_o, dst_o = torch.nonzero(keep, as_tuple=True)
+        out_ptr = torch.zeros(S + 1, dtype=torch.int32)
+        out_ptr[1:] = torch.cumsum(torch.bincount(src_o, minlength=S), 0).to(torch.int32)
+        i32 = lambda v: torch.as_tensor(v, dtype=torch.int32).to(device)       # noqa: E731
+        b = self.bufs
+        b.update(
+            ld_in_ptr=in_ptr.to(device), ld_in_src=i32(src_i),
+            ld_in_w=trans_h[src_i, dst_i].to(device, dtype).contiguous(),
+            ld_out_ptr=out_ptr.to(device), ld_out_dst=i32(dst_o),
+            ld_out_w=trans_h[src_o, dst_o].to(device, dtype).contiguous(),
+            ld_src_id=src_id.to(device), ld_src_w=src_w.to(device, dtype),
+            ld_dst_id=dst_id.to(device), ld_dst_w=dst_w.to(device, dtype),
+            ld_src_ptr=i32(src_ptr), ld_src_list=i32(src_list if src_list else [0]),
+            ld_dst_ptr=i32(dst_ptr), ld_dst_list=i32(dst_list if dst_list else [0]))
+        q = lambda name: b[name].data_ptr()                      # noqa: E731
+        return _hip.GraphLowDeg(
+            int(src_i.numel()), len(hubs), q('ld_in_ptr'), q('ld_in_src'), q('ld_in_w'),
+            q('ld_out_ptr'), q('ld_out_dst'), q('ld_out_w'), q('ld_src_id'), q('ld_src_w'),
+            q('ld_dst_id'), q('ld_dst_w'), q('ld_src_ptr'), q('ld_src_list'), q('ld_dst_ptr'),
+            q('ld_dst_list'))
 
     @staticmethod
     def _segments(ptr):
@@ -227,6 +294,16 @@ class CompiledGraph(torch.nn.Module):
         self.register_buffer('final_log_probs', final_log_probs)
         self.register_buffer('trans_log_probs', trans_log_probs)
         self.pdf_id_mapping = pdf_id_mapping
+        self.hubs = []
+
+    def set_hub(self, src_states, src_log_w, dst_states, dst_log_w):
+        '''Declare that trans_log_probs[src, dst] == src_log_w[:, None] +
+        dst_log_w[None, :] (the P x P block a phone loop's eliminated pivot
+        state leaves behind).  Purely an acceleration hint: the dense matrix
+        stays authoritative and the hint is verified before use.'''
+        self.hubs = [(list(src_states), src_log_w.detach().clone(), list(dst_states),
+                      dst_log_w.detach().clone())]
+        self.__dict__.pop('_device_memo', None)
 
     def __repr__(self):
         return '<CompiledGraph>'
@@ -250,7 +327,8 @@ class CompiledGraph(torch.nn.Module):
         if memo is not None and memo[0] == dtype and memo[2] == sig and \
                 all(a is b for a, b in zip(memo[1], tensors)):
             return memo[3]
-        dg = DeviceGraph(*tensors, device=_hip.require_device(), dtype=dtype)
+        dg = DeviceGraph(*tensors, device=_hip.require_device(), dtype=dtype,
+                         hubs=self.__dict__.get('hubs', ()))
         self.__dict__['_device_memo'] = (dtype, tensors, sig, dg)
         return dg
 
@@ -262,8 +340,8 @@ class CompiledGraph(torch.nn.Module):
         from .hmm_kernels import HmmBatch, forward_backward
         batch = HmmBatch([self], [0], [len(llhs)], llhs.dtype, with_pdf_ids=False)
         llhs_d = _hip.on_device(llhs)
-        gamma, xi_sum, _, lognorm = forward_backward(batch, llhs_d, want_xi=trans_posteriors,
-                                                     want_lognorm=True)
+        gamma, xi_sum, _, lognorm, _ = forward_backward(batch, llhs_d, want_xi=trans_posteriors,
+                                                        want_lognorm=True, dense_xi=True)
         gamma = gamma.view(len(llhs), -1)
         if trans_posteriors:
             return (gamma, xi_sum.to(llhs.dtype)), lognorm[0]

@@ -17,7 +17,7 @@ class HmmBatch:
     number of frames.  Packed per-state buffers hold utterance u at element
     offset `llh_off[u]` as a row-major [T_u, S_u] block.'''
 
-    def __init__(self, graphs, graph_ids, lengths, dtype, with_pdf_ids=True):
+    def __init__(self, graphs, graph_ids, lengths, dtype, with_pdf_ids=True, lowdeg=True):
         dev = _hip.require_device()
         self.dtype, self.device = dtype, dev
         self.nutt = len(lengths)
@@ -55,7 +55,10 @@ class HmmBatch:
         self.struct = _hip.Batch(
             self.nutt, max(n_states) if n_states else 1,
             max([dg.n_arcs for dg in self.dgraphs] + [1]),
-            max([max(dg.n_in_seg, dg.n_out_seg) for dg in self.dgraphs] + [1]), 0, len(graphs),
+            max([max(dg.n_in_seg, dg.n_out_seg) for dg in self.dgraphs] + [1]),
+            1 if (lowdeg and self.dgraphs and
+                  all(getattr(dg, 'lowdeg', None) is not None for dg in self.dgraphs)) else 0,
+            len(graphs),
             b['frame_off'].data_ptr(), b['llh_off'].data_ptr(), b['graph_id'].data_ptr(),
             b['graphs'].data_ptr(), b['pdf_off'].data_ptr(), b['pdf_ids'].data_ptr())
         self.shared_graph = len(graphs) == 1
@@ -73,25 +76,32 @@ def gather(batch, pc_all, scale=1.):
     return out
 
 
-def forward_backward(batch, pc_llhs, want_xi=False, want_lognorm=False):
+def forward_backward(batch, pc_llhs, want_xi=False, want_lognorm=False, dense_xi=False):
     '''(gamma packed, xi_sum [S,S] fp64 or None, gamma0_sum [S] fp64 or None,
-    lognorm_mean [nutt] or None).  xi / gamma0 need a batch sharing one graph.'''
+    lognorm_mean [nutt] or None, hub_flow [S] fp64 or None).  xi / gamma0 need
+    a batch sharing one graph.  When the graph carries a hub (phone loop) the
+    transition posteriors through it come back summed over its sources in
+    `hub_flow`; `dense_xi=True` forces the general kernel and a complete
+    [S, S] matrix.'''
     dt, dev = batch.dtype, batch.device
+    if dense_xi and want_xi and batch.struct.all_lowdeg:
+        batch.struct.all_lowdeg = 0
     gamma = torch.empty(batch.n_elems, dtype=dt, device=dev)
     alpha = torch.empty(batch.n_elems, dtype=torch.float64, device=dev)
-    xi = g0 = ln = None
+    xi = g0 = ln = flow = None
     if want_xi:
         if not batch.shared_graph:
             raise ValueError('transition posteriors need one graph for the whole batch')
         S = batch.n_states[0]
         xi = torch.zeros(S, S, dtype=torch.float64, device=dev)
         g0 = torch.zeros(S, dtype=torch.float64, device=dev)
+        flow = torch.zeros(S, dtype=torch.float64, device=dev)
     if want_lognorm:
         ln = torch.empty(batch.nutt, dtype=dt, device=dev)
     _hip.call('beer_hmm_forward_backward', _hip.dtype_code(dt), batch.ref(),
               _hip.ptr(pc_llhs), _hip.ptr(alpha), _hip.ptr(gamma), _hip.ptr(xi),
-              _hip.ptr(g0), _hip.ptr(ln))
-    return gamma, xi, g0, ln
+              _hip.ptr(g0), _hip.ptr(flow), _hip.ptr(ln))
+    return gamma, xi, g0, ln, flow
 
 
 def viterbi(batch, pc_llhs, map_pdf=False):
@@ -152,7 +162,8 @@ class _Columns:
             self._dg = type('DG', (), {})()
             self._dg.n_states, self._dg.n_arcs = self.n_states, 0
             self._dg.n_in_seg = self._dg.n_out_seg = 0
-            self._dg.struct = _hip.Graph(self.n_states, 0, 0, 0, *([None] * 14))
+            self._dg.lowdeg = None
+            self._dg.struct = _hip.Graph(self.n_states, 0, 0, 0, *([None] * 15))
         return self._dg
 
 

@@ -155,7 +155,7 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
     utt_llh = torch.zeros(nutt, dtype=torch.float64, device=dev)
     off = torch.zeros(nutt + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(torch.as_tensor(lengths, dtype=torch.int64), 0)
-    xi_tot = g0_tot = None
+    xi_tot = g0_tot = flow_tot = None
     max_S = model.graph.n_states if free_loop else max(g.n_states for g in graphs)
     bpf = (K_max + 2 * S_total) * X.element_size() + max_S * (3 * X.element_size() + 8)
     for run in _sub_batches(lengths, bpf, max_frames):
@@ -181,11 +181,14 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
             else:
                 path = torch.cat([torch.as_tensor(state_paths[u]).reshape(-1) for u in run])
             gamma, xi, g0 = hk.path_posteriors(batch, path, want_xi=free_loop)
+            flow = None
         else:
-            gamma, xi, g0, _ = hk.forward_backward(batch, pc_llhs, want_xi=free_loop)
+            gamma, xi, g0, _, flow = hk.forward_backward(batch, pc_llhs, want_xi=free_loop)
         if free_loop:
             xi_tot = xi if xi_tot is None else xi_tot + xi
             g0_tot = g0 if g0_tot is None else g0_tot + g0
+            if flow is not None:
+                flow_tot = flow if flow_tot is None else flow_tot + flow
         sr, _ = hk.scatter(batch, pc_llhs, gamma, S_total, scale, want_exp_llh=False,
                            utt_llh=utt_llh[run[0]:run[-1] + 1])
         first = 0
@@ -212,7 +215,8 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
         wparam = model.categorical.mean_field_factorization()[0][0]
         ref = wparam.stats
         if free_loop:
-            counts = model.phone_counts(xi_tot, g0_tot).to(dtype=ref.dtype, device=ref.device)
+            counts = model.phone_counts(xi_tot, g0_tot, flow_tot).to(dtype=ref.dtype,
+                                                                     device=ref.device)
             # per-utterance `sufficient_statistics` (last <- sum) then sum over
             # utterances == the same map applied to the summed counts.
             cstats = model.categorical.sufficient_statistics(counts.view(1, -1))

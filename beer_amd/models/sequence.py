@@ -48,7 +48,8 @@ class HMM(DiscreteLatentModel):
             path = hk.viterbi(batch, flat) if state_path is None else state_path
             gamma, xi, g0 = hk.path_posteriors(batch, path, want_xi=trans_posteriors)
         else:
-            gamma, xi, g0, _ = hk.forward_backward(batch, flat, want_xi=trans_posteriors)
+            gamma, xi, g0, _, _ = hk.forward_backward(batch, flat, want_xi=trans_posteriors,
+                                                      dense_xi=True)
         gamma = gamma.view(len(pc), -1)
         return ((gamma, xi) if trans_posteriors else gamma), None
 
@@ -71,15 +72,19 @@ class HMM(DiscreteLatentModel):
         T, S_total = pc_all.shape
         batch = self._batch_of_one(graph, T, pc_all.dtype)
         pc_llhs = hk.gather(batch, pc_all, scale)
+        flow = None
         if viterbi or state_path is not None:
             path = hk.viterbi(batch, pc_llhs) if state_path is None else state_path
             gamma, xi, g0 = hk.path_posteriors(batch, path, want_xi=trans_posts)
         else:
-            gamma, xi, g0, _ = hk.forward_backward(batch, pc_llhs, want_xi=trans_posts)
+            gamma, xi, g0, _, flow = hk.forward_backward(batch, pc_llhs, want_xi=trans_posts)
         state_resps, exp_llh = hk.scatter(batch, pc_llhs, gamma, S_total, scale)
         self.cache['resps'] = gamma.view(T, -1)
         if trans_posts:
-            self.cache['trans_resps'] = xi          # summed over time: [S, S]
+            # summed over time: [S, S]; transitions through a declared hub (phone
+            # loop) are summed over their sources in 'hub_flow' [S] instead
+            self.cache['trans_resps'] = xi
+            self.cache['hub_flow'] = flow
         self.cache['scaled_pdf_resps'] = state_resps
         self.cache['scale'] = scale
         return exp_llh
@@ -104,7 +109,7 @@ class HMM(DiscreteLatentModel):
         stats = self.modelset.sufficient_statistics(data) * scale
         pc_all = self._emissions().expected_log_likelihood(stats)
         batch = self._batch_of_one(graph, len(stats), pc_all.dtype)
-        gamma, _, _, _ = hk.forward_backward(batch, hk.gather(batch, pc_all, 1.))
+        gamma = hk.forward_backward(batch, hk.gather(batch, pc_all, 1.))[0]
         return gamma.view(len(stats), -1)
 
 
@@ -138,20 +143,29 @@ class PhoneLoop(HMM):
         log_weights = self.categorical.log_weights().to(dtype=trans.dtype,
                                                         device=trans.device)
         start_idxs = list(self.start_pdf.values())
+        residuals = []
         for end_idx in self.end_pdf.values():
             loop_prob = trans[end_idx, end_idx].exp()
-            trans[end_idx, start_idxs] = (1 - loop_prob).log() + log_weights
+            residuals.append((1 - loop_prob).log())
+            trans[end_idx, start_idxs] = residuals[-1] + log_weights
+        # the block just written is rank one: tell the graph, so that
+        # forward-backward can treat the eliminated pivot state as a hub
+        end_idxs = list(self.end_pdf.values())
+        if len(set(end_idxs)) == len(end_idxs) and len(set(start_idxs)) == len(start_idxs):
+            self.graph.set_hub(end_idxs, torch.stack(residuals), start_idxs, log_weights)
 
     def mean_field_factorization(self):
         from .mixtures import _merge_groups
         return _merge_groups(self.modelset.mean_field_factorization(),
                              self.categorical.mean_field_factorization())
 
-    def phone_counts(self, xi_sum, gamma0):
+    def phone_counts(self, xi_sum, gamma0, hub_flow=None):
         'sum_t xi_t[ends, starts] summed over ends + gamma_0[starts] (88-95).'
         start_idxs = list(self.start_pdf.values())
         end_idxs = list(self.end_pdf.values())
         counts = xi_sum[:, start_idxs][end_idxs, :].sum(dim=0)
+        if hub_flow is not None:
+            counts = counts + hub_flow[start_idxs]
         return counts + gamma0[start_idxs].to(counts.dtype)
 
     def accumulate(self, stats, parent_msg=None):
@@ -159,7 +173,8 @@ class PhoneLoop(HMM):
         wparam = self.categorical.mean_field_factorization()[0][0]
         ref = wparam.stats
         if 'trans_resps' in self.cache:
-            counts = self.phone_counts(self.cache['trans_resps'], self.cache['resps'][0])
+            counts = self.phone_counts(self.cache['trans_resps'], self.cache['resps'][0],
+                                       self.cache.get('hub_flow'))
             counts = counts.to(dtype=ref.dtype, device=ref.device)
             resps_stats = self.categorical.sufficient_statistics(counts.view(1, -1))
             retval.update(self.categorical.accumulate(resps_stats))

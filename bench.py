@@ -171,11 +171,18 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun')
+    # BEER_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with
+    # fewer GPUs than ranks (ranks then share devices); the default is RCCL.
+    backend = os.environ.get('BEER_BENCH_BACKEND', 'nccl')
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     X = synth_frames(args.frames, device, seed=1 + rank)
     lengths = [args.chunk] * (args.frames // args.chunk)
@@ -210,7 +217,8 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     if rank != 0:

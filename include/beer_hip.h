@@ -242,7 +242,35 @@ typedef struct {
     const void* out_w;         /* [nnz] */
     const int32_t* out_seg;    /* [n_out_seg+1] */
     const int32_t* out_row_seg;/* [S+1] */
+    const struct beer_graph_lowdeg* lowdeg;   /* optional factorised image, see below */
 } beer_graph;
+
+/* Optional low-degree image of the same graph, used by the fast
+ * forward-backward variant.  compile() of the reference eliminates
+ * non-emitting states, which turns a phone loop's pivot state into a dense
+ * P x P block of arcs (every phone end -> every phone start) whose
+ * log-weights are rank one: A[e, s] = src_w[e] + dst_w[s].  Such a block is
+ * kept here as a "hub" (one log-sum-exp over its sources per frame) and removed
+ * from the CSR, which leaves every state with a handful of arcs.  Present only
+ * when every remaining row has <= BEER_SEG arcs.  */
+typedef struct beer_graph_lowdeg {
+    int32_t n_arcs;            /* arcs left after removing the hub blocks */
+    int32_t n_hubs;
+    const int32_t* in_ptr;     /* [S+1] */
+    const int32_t* in_src;     /* [n_arcs] */
+    const void* in_w;          /* [n_arcs] */
+    const int32_t* out_ptr;    /* [S+1] */
+    const int32_t* out_dst;    /* [n_arcs] */
+    const void* out_w;         /* [n_arcs] */
+    const int32_t* hub_src_id; /* [S] hub fed by the state, -1: none */
+    const void* hub_src_w;     /* [S] */
+    const int32_t* hub_dst_id; /* [S] hub feeding the state, -1: none */
+    const void* hub_dst_w;     /* [S] */
+    const int32_t* src_ptr;    /* [n_hubs+1] source states of every hub ... */
+    const int32_t* src_list;
+    const int32_t* dst_ptr;    /* [n_hubs+1] ... and its destination states */
+    const int32_t* dst_list;
+} beer_graph_lowdeg;
 
 /* Ragged batch: utterance u owns frames [frame_off[u], frame_off[u+1]) of the
  * packed feature matrix and rows [llh_off[u], ...) (in elements) of the
@@ -253,7 +281,7 @@ typedef struct {
     int32_t max_states;        /* max n_states over the batch's graphs (LDS sizing) */
     int32_t max_arcs;          /* max n_arcs over the batch's graphs   (LDS sizing) */
     int32_t max_segs;          /* max(n_in_seg, n_out_seg) over the graphs          */
-    int32_t reserved;
+    int32_t all_lowdeg;        /* != 0: every graph has a `lowdeg` image            */
     int32_t n_graphs;
     const int64_t* frame_off;  /* [nutt+1] */
     const int64_t* llh_off;    /* [nutt]   element offsets */
@@ -279,10 +307,14 @@ int beer_hmm_gather(int dtype, const beer_batch* batch_h, int S_total,
  * fp64, +=) receives sum_u sum_t xi_t -- every utterance must then use
  * graph 0; `gamma0_sum` (nullable, [S] fp64, +=) receives sum_u gamma_0.
  * `lognorm_mean` (nullable, [nutt]) receives mean_t lognorm_t
- * (graph.py:326). */
+ * (graph.py:326).  When every graph of the batch carries a `lowdeg` image
+ * the factorised recursion runs; transition posteriors through a hub are
+ * then reported per destination state, summed over the hub's sources, in
+ * `hub_flow` ([S] fp64, +=; required whenever xi_sum is given) instead of as
+ * individual xi_sum entries. */
 int beer_hmm_forward_backward(int dtype, const beer_batch* batch_h,
                               const void* pc_llhs, double* alpha_ws, void* gamma,
-                              double* xi_sum, double* gamma0_sum,
+                              double* xi_sum, double* gamma0_sum, double* hub_flow,
                               void* lognorm_mean, void* stream);
 
 /* Viterbi + backtrack, CompiledGraph.best_path (beer/graph.py:329-344):

@@ -238,7 +238,14 @@ def test_g5_phoneloop(kind):
     stats = ploop.sufficient_statistics(X)
     assert_close(npy(ploop.expected_log_likelihood(stats)), g['exp_llh'], 1e-9, 'exp_llh')
     assert_close(npy(ploop.cache['resps']), g['gamma'], 1e-8, 'gamma')
-    assert_close(npy(ploop.cache['trans_resps']), g['xi_sum'], 1e-8, 'xi_sum')
+    # transitions through the phone-loop hub come back summed over the phone
+    # ends (hub_flow); every other entry of the summed xi matrix is explicit
+    xi, flow = npy(ploop.cache['trans_resps']), npy(ploop.cache['hub_flow'])
+    ends, starts = g['end_idxs'], g['start_idxs']
+    ref_xi = g['xi_sum'].copy()
+    assert_close(flow[starts], ref_xi[ends][:, starts].sum(0), 1e-8, 'hub flow')
+    ref_xi[np.ix_(ends, starts)] = 0.
+    assert_close(xi, ref_xi, 1e-8, 'xi_sum outside the hub')
     ploop.clear_cache()
     optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.)
     for it in range(2):

@@ -39,7 +39,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     # 4 int32 + 14 pointers; 6 int32 + 6 pointers (LP64)
-    assert ctypes.sizeof(_hip.Graph) == 16 + 14 * 8
+    assert ctypes.sizeof(_hip.Graph) == 16 + 15 * 8
+    assert ctypes.sizeof(_hip.GraphLowDeg) == 8 + 14 * 8
     assert ctypes.sizeof(_hip.Batch) == 24 + 6 * 8
 
 
