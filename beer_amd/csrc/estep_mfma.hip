@@ -410,6 +410,13 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
     const int xcount = kAccFT * D;
     T xreg[XPT];
     vec4_t rreg[RPT];
+    // with G % 4 == 0 the four components of a staged vec4 share their state:
+    // one state-responsibility load per vec4, its column fixed per thread
+    const bool sr_vec = SR && (G % 4 == 0);
+    int sr_col[RPT];
+#pragma unroll
+    for (int v = 0; v < RPT; ++v)
+        sr_col[v] = (kc0 + 4 * ((tid + v * kThreads) % (RC / 4))) / G;
     auto load_tile = [&](int64_t t0) {
         const T* xsrc = X + t0 * D;
         const int64_t xvalid = (te - t0) * D;
@@ -427,7 +434,11 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
             const int k = kc0 + 4 * c4;
             if (f < te && k + 3 < K) {
                 val = *reinterpret_cast<const vec4_t*>(R + f * K + k);
-                if (SR) {
+                if (sr_vec) {
+                    const T w = SR[f * S + sr_col[v]];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) val[c] *= w;
+                } else if (SR) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) val[c] *= SR[f * S + (k + c) / G];
                 }

@@ -84,6 +84,36 @@ __global__ void scatter_kernel(beer_batch b, int S_total, const T* __restrict__ 
     }
 }
 
+// Element-parallel scatter for the batched path (no per-frame exp_llh wanted):
+// coalesced reads of gamma / pc, per-utterance sum of gamma * pc reduced per
+// workgroup.  Repeated pdf ids (alignment graphs) need the atomic add.
+template <typename T>
+__global__ void scatter_flat_kernel(beer_batch b, int S_total, const T* __restrict__ pc,
+                                    const T* __restrict__ gamma, T scale, T* __restrict__ sr,
+                                    double* __restrict__ utt_llh) {
+    __shared__ double red[8];
+    const int u = blockIdx.x;
+    const int gid = b.graph_id[u];
+    const int S = b.graphs[gid].n_states;
+    const int32_t* ids = b.pdf_ids + b.pdf_off[gid];
+    const int64_t f0 = b.frame_off[u], nt = b.frame_off[u + 1] - f0;
+    const T* g = gamma + b.llh_off[u];
+    const T* p = pc + b.llh_off[u];
+    double mine = 0.0;
+    for (int64_t idx = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; idx < nt * S;
+         idx += (int64_t)gridDim.y * blockDim.x) {
+        const int64_t t = idx / S;
+        const int s = (int)(idx - t * S);
+        const T gv = g[idx];
+        if (sr) atomicAdd(sr + (f0 + t) * S_total + ids[s], scale * gv);
+        mine += (double)(p[idx] * gv);
+    }
+    if (utt_llh) {
+        const double tot = block_sum(mine, red);
+        if (threadIdx.x == 0) atomicAdd(utt_llh + u, tot);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // forward-backward
 // ---------------------------------------------------------------------------
@@ -644,6 +674,13 @@ int scatter_launch(const beer_batch* b, int S_total, const void* pc, const void*
                    double scale, void* sr, void* exp_llh, double* utt_llh, void* stream) {
     BEER_REQUIRE(b && b->nutt >= 0 && S_total >= 1);
     if (b->nutt == 0) return BEER_OK;
+    if (!exp_llh) {
+        hipLaunchKernelGGL(scatter_flat_kernel<T>, dim3(b->nutt, 8), dim3(256), 0,
+                           as_stream(stream), *b, S_total, (const T*)pc, (const T*)gamma,
+                           (T)scale, (T*)sr, utt_llh);
+        BEER_LAUNCH_CHECK();
+        return BEER_OK;
+    }
     hipLaunchKernelGGL(scatter_kernel<T>, dim3(b->nutt, 1), dim3(256), 0, as_stream(stream), *b,
                        S_total, (const T*)pc, (const T*)gamma, (T)scale, (T*)sr, (T*)exp_llh,
                        utt_llh);
