@@ -158,7 +158,10 @@ __global__ void pack_kernel(int cov, int D, int K, int NT, int nchunks,
         const int lane = (int)((rem_idx / NT) % 64);
         const int s = (int)(rem_idx / ((int64_t)NT * 64));
         const int i = lane & 15, g = lane >> 4;
-        const int k = chunk * NT * 16 + c * 16 + i;
+        // column (tile c, lane-column i) of the chunk holds component
+        // 64 (c / 4) + 4 i + c % 4: the four tiles of a "q-block" give every lane
+        // four CONSECUTIVE components -> 16-byte stores of the responsibilities
+        const int k = chunk * NT * 16 + 64 * (c >> 2) + 4 * i + (c & 3);
         const int t = slab_entry(cov, D, s);
         if (c == 0 && lane == 0 && chunk == 0) tab[s] = t;
         const int a = t & 0xff, b = ((t >> 8) & 0xff) + g, sq = t >> 16;
@@ -195,16 +198,19 @@ __global__ void tab_kernel(int cov, int D, int* __restrict__ tab) {
 
 // ---------------------------------------------------------------------------
 // K1: fused log-likelihood GEMM + softmax.  One wave owns 16*MT frames and a
-// chunk of 16*NT components (blockIdx.y); the softmax runs over groups of
-// G = 16*GT components (GT column tiles; for G < 16, `gl` = G lanes of one
-// tile): the whole mixture for a GMM (S = 1, one chunk, GT = NT), one state's
-// mixture for the GMM emissions of an HMM (S > 1, G a power of two).
+// chunk of 16*NT components (blockIdx.y).  Components are interleaved over the
+// column tiles in "q-blocks" of 4 tiles = 64 components so that a lane holds 4
+// consecutive components of a row (see pack_kernel).  The softmax runs over
+// groups of G components: the whole chunk for a GMM (S = 1, GQ = NT/4
+// q-blocks, gl = 16 lanes), or one state's mixture for the GMM emissions of an
+// HMM (S > 1, G a power of two): GQ = G/64 q-blocks for G >= 64, else `gl` =
+// G/4 lanes of one q-block (G >= 4) or `jw` = G of a lane's 4 values (G < 4).
 // ---------------------------------------------------------------------------
-template <typename T, int NT, int MT, int GT>
+template <typename T, int NT, int MT, int GQ>
 __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 && MT * NT <= 32) ? 2 : 1) void llh_kernel(
-    int64_t nframes, int D, int K, int S, int G, int gl, int nslab, const T* __restrict__ X,
-    const T* __restrict__ Pall, const int* __restrict__ tab, T* __restrict__ resps,
-    T* __restrict__ log_norm, double* __restrict__ llh_sum) {
+    int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nslab,
+    const T* __restrict__ X, const T* __restrict__ Pall, const int* __restrict__ tab,
+    T* __restrict__ resps, T* __restrict__ log_norm, double* __restrict__ llh_sum) {
     using M = Mma<T>;
     using acc_t = typename M::acc_t;
     using vec4_t = typename M::vec4_t;
@@ -285,44 +291,92 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 && MT * NT <= 32) ? 2 : 1
 
     // ---- epilogue: logsumexp over each group of G components ----
     double llh_local = 0.0;
+    const bool vec_ok = (K % 4) == 0;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            // one row at a time: without the barrier hipcc interleaves all
-            // 8 rows x NT/GT groups and spills the accumulators to scratch
+            // one row at a time: without the barrier hipcc interleaves all the
+            // rows and groups and spills the accumulators to scratch
             __builtin_amdgcn_sched_barrier(0);
             const int64_t f = fb + m * 16 + M::row(g, r);
 #pragma unroll
-            for (int tg = 0; tg < NT / GT; ++tg) {
-                T mx = acc[m][tg * GT][r];
+            for (int tq = 0; tq < NT / 4 / GQ; ++tq) {
+                T e[GQ][4];
+                const int kq = kbase + 64 * tq * GQ + 4 * i;       // lane's first component
+                if (jw == 4) {
+                    T mx = acc[m][4 * tq * GQ][r];
 #pragma unroll
-                for (int c = 1; c < GT; ++c)
-                    mx = acc[m][tg * GT + c][r] > mx ? acc[m][tg * GT + c][r] : mx;
-                mx = group_max(mx, gl);
-                T e[GT];
-                T sum = 0;
-#pragma unroll
-                for (int c = 0; c < GT; ++c) {
-                    e[c] = exp(acc[m][tg * GT + c][r] - mx);
-                    sum += e[c];
-                }
-                sum = group_sum(sum, gl);
-                const T lse = mx + log(sum);
-                const T inv = (T)1 / sum;
-                const int k0 = kbase + tg * GT * 16 + (i & ~(gl - 1));     // group's first comp
-                const int state = k0 / G;
-                if (f < nframes && state < S) {
-                    if (resps) {
-#pragma unroll
-                        for (int c = 0; c < GT; ++c) {
-                            const int k = kbase + (tg * GT + c) * 16 + i;
-                            if (k < K) resps[f * K + k] = e[c] * inv;
-                        }
+                    for (int c = 1; c < 4 * GQ; ++c) {
+                        const T w = acc[m][4 * tq * GQ + c][r];
+                        mx = w > mx ? w : mx;
                     }
-                    if ((i & (gl - 1)) == 0) {
+                    mx = group_max(mx, gl);
+                    T sum = 0;
+#pragma unroll
+                    for (int qq = 0; qq < GQ; ++qq)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            e[qq][j] = exp(acc[m][4 * (tq * GQ + qq) + j][r] - mx);
+                            sum += e[qq][j];
+                        }
+                    sum = group_sum(sum, gl);
+                    const T lse = mx + log(sum);
+                    const T inv = (T)1 / sum;
+#pragma unroll
+                    for (int qq = 0; qq < GQ; ++qq)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) e[qq][j] *= inv;
+                    const int state = (kbase + 64 * tq * GQ + 4 * (i & ~(gl - 1))) / G;
+                    if (f < nframes && state < S && (i & (gl - 1)) == 0) {
                         if (log_norm) log_norm[f * S + state] = lse;
                         llh_local += (double)lse;
+                    }
+                } else {
+                    // G = 1 or 2: groups inside a lane's 4 values (GQ == 1)
+#pragma unroll
+                    for (int j0 = 0; j0 < 4; j0 += 2) {
+                        const T a0 = acc[m][4 * tq * GQ + j0][r], a1 = acc[m][4 * tq * GQ + j0 + 1][r];
+                        if (jw == 2) {
+                            const T mx = a0 > a1 ? a0 : a1;
+                            const T e0 = exp(a0 - mx), e1 = exp(a1 - mx);
+                            const T lse = mx + log(e0 + e1);
+                            e[0][j0] = e0 / (e0 + e1);
+                            e[0][j0 + 1] = e1 / (e0 + e1);
+                            const int state = (kq + j0) / G;
+                            if (f < nframes && state < S) {
+                                if (log_norm) log_norm[f * S + state] = lse;
+                                llh_local += (double)lse;
+                            }
+                        } else {
+                            e[0][j0] = 1;
+                            e[0][j0 + 1] = 1;
+                            if (f < nframes) {
+                                if (kq + j0 < K) {
+                                    if (log_norm) log_norm[f * S + kq + j0] = a0;
+                                    llh_local += (double)a0;
+                                }
+                                if (kq + j0 + 1 < K) {
+                                    if (log_norm) log_norm[f * S + kq + j0 + 1] = a1;
+                                    llh_local += (double)a1;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (resps && f < nframes) {
+#pragma unroll
+                    for (int qq = 0; qq < GQ; ++qq) {
+                        const int k = kq + 64 * qq;
+                        T* dst = resps + f * K + k;
+                        if (vec_ok && k + 3 < K) {
+                            *reinterpret_cast<vec4_t*>(dst) =
+                                vec4_t{e[qq][0], e[qq][1], e[qq][2], e[qq][3]};
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (k + j < K) dst[j] = e[qq][j];
+                        }
                     }
                 }
             }
@@ -345,7 +399,7 @@ constexpr int kAccMC = 4;        // component tiles per wave (shared by the 4 wa
 constexpr int kAccFT = 64;       // frames per LDS tile
 constexpr int kFlush = 256;      // frames per MFMA accumulation chain
 
-template <typename T, int NQ>
+template <typename T, int NQ, bool HAS_SR>
 __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
     int64_t nframes, int D, int K, int G, int S, int nslab, const T* __restrict__ X,
     const T* __restrict__ R, const T* __restrict__ SR, const int* __restrict__ tab,
@@ -412,11 +466,13 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
     vec4_t rreg[RPT];
     // with G % 4 == 0 the four components of a staged vec4 share their state:
     // one state-responsibility load per vec4, its column fixed per thread
-    const bool sr_vec = SR && (G % 4 == 0);
-    int sr_col[RPT];
+    const bool sr_vec = HAS_SR && (G % 4 == 0);
+    int sr_col[HAS_SR ? RPT : 1];
+    if (HAS_SR) {
 #pragma unroll
-    for (int v = 0; v < RPT; ++v)
-        sr_col[v] = (kc0 + 4 * ((tid + v * kThreads) % (RC / 4))) / G;
+        for (int v = 0; v < RPT; ++v)
+            sr_col[v] = (kc0 + 4 * ((tid + v * kThreads) % (RC / 4))) / G;
+    }
     auto load_tile = [&](int64_t t0) {
         const T* xsrc = X + t0 * D;
         const int64_t xvalid = (te - t0) * D;
@@ -434,13 +490,15 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
             const int k = kc0 + 4 * c4;
             if (f < te && k + 3 < K) {
                 val = *reinterpret_cast<const vec4_t*>(R + f * K + k);
-                if (sr_vec) {
-                    const T w = SR[f * S + sr_col[v]];
+                if (HAS_SR) {
+                    if (sr_vec) {
+                        const T w = SR[f * S + sr_col[HAS_SR ? v : 0]];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) val[c] *= w;
-                } else if (SR) {
+                        for (int c = 0; c < 4; ++c) val[c] *= w;
+                    } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) val[c] *= SR[f * S + (k + c) / G];
+                        for (int c = 0; c < 4; ++c) val[c] *= SR[f * S + (k + c) / G];
+                    }
                 }
             }
             rreg[v] = val;
@@ -561,17 +619,17 @@ size_t align_up(size_t n) { return (n + 255) / 256 * 256; }
 inline int nt_for(int S, int K) { return S > 1 ? 16 : (K <= 64 ? 4 : (K <= 128 ? 8 : 16)); }
 inline int nchunks_for(int S, int K) { return S > 1 ? (K + 255) / 256 : 1; }
 
-template <typename T, int NT, int MT, int GT>
-int launch_llh(int64_t nframes, int D, int K, int S, int G, int gl, int nchunks, int nslab,
-               const T* X, const T* P, const int* tab, T* resps, T* log_norm, double* llh_sum,
-               hipStream_t s) {
+template <typename T, int NT, int MT, int GQ>
+int launch_llh(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nchunks,
+               int nslab, const T* X, const T* P, const int* tab, T* resps, T* log_norm,
+               double* llh_sum, hipStream_t s) {
     const int D4 = d4_of(D), LD = 4 * D4 + 5;
     constexpr int FB = 16 * MT * (kThreads / 64);
     const size_t lds = (size_t)FB * LD * sizeof(T);
     const int64_t blocks = (nframes + FB - 1) / FB;
-    hipLaunchKernelGGL((llh_kernel<T, NT, MT, GT>), dim3((unsigned)blocks, (unsigned)nchunks),
-                       dim3(kThreads), lds, s, nframes, D, K, S, G, gl, nslab, X, P, tab, resps,
-                       log_norm, llh_sum);
+    hipLaunchKernelGGL((llh_kernel<T, NT, MT, GQ>), dim3((unsigned)blocks, (unsigned)nchunks),
+                       dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nslab, X, P, tab,
+                       resps, log_norm, llh_sum);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }
@@ -596,24 +654,22 @@ int estep_impl(int cov, int64_t nframes, int D, int S, int G, const T* X, const 
                        nchunks, expT, logw, P, tab);
     BEER_LAUNCH_CHECK();
     constexpr int MT = sizeof(T) == 4 ? 2 : 1;
-#define BEER_LLH(NT_, GT_) \
-    return launch_llh<T, NT_, MT, GT_>(nframes, D, K, S, G, gl, nchunks, nslab, X, P, tab, resps, \
-                                       log_norm, llh_sum, s)
-    if (S == 1) {                                               // one group = the whole chunk
-        const int gl = 16;
-        if (NT == 4) BEER_LLH(4, 4);
-        if (NT == 8) BEER_LLH(8, 8);
-        // K (not a power of two in general) is the group: state = k0 / G must be 0
-        BEER_LLH(16, 16);
+#define BEER_LLH(NT_, GQ_) \
+    return launch_llh<T, NT_, MT, GQ_>(nframes, D, K, S, G, gl, jw, nchunks, nslab, X, P, tab, \
+                                       resps, log_norm, llh_sum, s)
+    if (S == 1) {                                   // one group = the whole (padded) chunk
+        const int gl = 16, jw = 4;
+        if (NT == 4) BEER_LLH(4, 1);
+        if (NT == 8) BEER_LLH(8, 2);
+        BEER_LLH(16, 4);
     }
-    const int gl = G < 16 ? G : 16;
-    const int gt = G < 16 ? 1 : G / 16;
-    switch (gt) {
+    const int jw = G < 4 ? G : 4;
+    const int gl = G < 4 ? 1 : (G < 64 ? G / 4 : 16);
+    const int gq = G <= 64 ? 1 : G / 64;
+    switch (gq) {
         case 1: BEER_LLH(16, 1);
         case 2: BEER_LLH(16, 2);
-        case 4: BEER_LLH(16, 4);
-        case 8: BEER_LLH(16, 8);
-        default: BEER_LLH(16, 16);
+        default: BEER_LLH(16, 4);
     }
 #undef BEER_LLH
 }
@@ -645,16 +701,22 @@ int acc_impl(int cov, int64_t nframes, int D, int S, int G, const T* X, const T*
     const size_t lds = 2 * ((size_t)(kAccFT * D + 2 + 3) / 4 * 4 + (size_t)kAccFT * 16 * kAccMC) *
                        sizeof(T);
     const dim3 grid(gx, gy, (unsigned)gz);
-#define BEER_ACC(NQ_)                                                                           \
+#define BEER_ACC(NQ_, SR_)                                                                      \
     do {                                                                                        \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc_kernel<T, NQ_>),            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc_kernel<T, NQ_, SR_>),       \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-        hipLaunchKernelGGL((acc_kernel<T, NQ_>), grid, dim3(kThreads), lds, s, nframes, D, K, G, \
-                           S, nslab, X, R, SR, tab, fpb, Sp);                                   \
+        hipLaunchKernelGGL((acc_kernel<T, NQ_, SR_>), grid, dim3(kThreads), lds, s, nframes, D, \
+                           K, G, S, nslab, X, R, SR, tab, fpb, Sp);                             \
     } while (0)
-    if (NQ == 4) BEER_ACC(4);
-    else if (NQ == 2) BEER_ACC(2);
-    else BEER_ACC(1);
+    if (SR) {
+        if (NQ == 4) BEER_ACC(4, true);
+        else if (NQ == 2) BEER_ACC(2, true);
+        else BEER_ACC(1, true);
+    } else {
+        if (NQ == 4) BEER_ACC(4, false);
+        else if (NQ == 2) BEER_ACC(2, false);
+        else BEER_ACC(1, false);
+    }
 #undef BEER_ACC
     BEER_LAUNCH_CHECK();
     const int64_t total = (int64_t)K * stats_dim(cov, D);
