@@ -141,6 +141,26 @@ def cpu_baseline(frames_target=1 << 20, chunk=8192, budget_s=15.):
                       f'reference op sequence, {dt:.1f} s'}
 
 
+def pmc_traffic(kernel_key):
+    '''HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r*_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    passes, full-size launches of this same command).  Counters cannot be read
+    from inside the timed run, so this is the last profiled value; None if absent.'''
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))['kernels'][kernel_key]
+        # FETCH_SIZE under-reports wide (16 B/lane) coalesced reads by 2x on gfx950
+        # (MI355X_MICROARCH.md): K2 streams R with 16-byte loads -> corrected; K1's
+        # reads are 4-byte -> raw.
+        read = k['hbm_read_bytes_raw'] * (2. if kernel_key == 'acc_kernel' else 1.)
+        return read + k['hbm_write_bytes']
+    except Exception:
+        return None
+
+
 def elbo_check(model, X, n=8192):
     'ELBO of the first n frames: HIP path vs fp64 oracle on identical inputs.'
     from oracle import beer_oracle as orc
@@ -251,8 +271,14 @@ def main():
         'elbo_per_frame': float(elbo) / (len(lengths) * world * datasize),
         'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'],
                      'peak': PEAK_TFLOPS['f32'], 'unit': 'TFLOP/s',
-                     'frac': kern[dom]['tflops'] / PEAK_TFLOPS['f32'], 'traffic': None,
-                     'avg_launch_ms': kern[dom]['ms']},
+                     'frac': kern[dom]['tflops'] / PEAK_TFLOPS['f32'],
+                     'traffic': pmc_traffic('acc_kernel' if 'accumulate' in dom
+                                            else 'llh_kernel'),
+                     'avg_launch_ms': kern[dom]['ms'],
+                     'note': 'achieved = algorithmic flops (2*K*Q per frame, no symmetry '
+                             'discount) / HIP-event time of the C-ABI call; the kernels '
+                             'contract only the D(D+1)/2 symmetric products (0.56x the '
+                             'multiply-adds), so frac can exceed 1'},
         'kernels': kern,
     }
     if not args.no_cpu_baseline:

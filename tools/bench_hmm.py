@@ -121,6 +121,15 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     out['free_loop'] = {'ms_per_iter': 1e3 * dt, 'frames_per_s': total / dt,
                         'elbo_per_frame': float(elbo) / (len(lengths) * total)}
+    # Viterbi decoding of the whole shard (HMM.decode, batched)
+    beer.decode_batch(ploop, (X, lengths))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        paths = beer.decode_batch(ploop, (X, lengths))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    out['viterbi_decode'] = {'ms': 1e3 * dt, 'frames_per_s': total / dt}
     if args.ali_utts:
         n = min(args.ali_utts, len(lengths))
         sub = lengths[:n]
