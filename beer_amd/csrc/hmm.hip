@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kFbThreads) void fb_kernel(
 // the other waves work on the sparse arcs.  Barriers per frame: 2 forward,
 // 4 backward (the general kernel above needs 5 + 9).
 // ---------------------------------------------------------------------------
-constexpr int kLdThreads = 256;
+constexpr int kLdThreads = 512;     // one state per thread: graphs up to 512 states
 constexpr int kMaxHubs = 4;
 
 template <typename T>
@@ -714,12 +714,14 @@ int beer_hmm_forward_backward(int dtype, const beer_batch* b, const void* pc_llh
     if (b->all_lowdeg && b->max_states <= kLdThreads && (!xi_sum || hub_flow)) {
         // factorised low-degree recursion: one thread per state
         const size_t lds = ((size_t)2 * b->max_states + 4 * kMaxHubs + 8) * sizeof(double);
+        // at least two waves (wave 1 recomputes the forward hub values)
+        const int threads = b->max_states <= 128 ? 128 : (b->max_states <= 256 ? 256 : 512);
         if (dtype == BEER_F32)
-            hipLaunchKernelGGL(fb_lowdeg_kernel<float>, dim3(b->nutt), dim3(kLdThreads), lds, s,
+            hipLaunchKernelGGL(fb_lowdeg_kernel<float>, dim3(b->nutt), dim3(threads), lds, s,
                                *b, (const float*)pc_llhs, alpha_ws, (float*)gamma, xi_sum,
                                gamma0_sum, hub_flow, (float*)lognorm_mean);
         else
-            hipLaunchKernelGGL(fb_lowdeg_kernel<double>, dim3(b->nutt), dim3(kLdThreads), lds, s,
+            hipLaunchKernelGGL(fb_lowdeg_kernel<double>, dim3(b->nutt), dim3(threads), lds, s,
                                *b, (const double*)pc_llhs, alpha_ws, (double*)gamma, xi_sum,
                                gamma0_sum, hub_flow, (double*)lognorm_mean);
         BEER_LAUNCH_CHECK();

@@ -566,3 +566,55 @@ def test_gmm_matrix_core_path_all_cov_types_vs_oracle(cov, dtype, tol, K, D):
     assert_close(float(elbo), truth['value'], tol, 'elbo')
     assert_close(npy(elbo._acc_stats[p0]), truth['acc_normal'], tol * 5, 'acc normal')
     assert_close(npy(elbo._acc_stats[p1]), truth['acc_weights'], tol * 5, 'acc weights')
+
+
+def _chain_graph(n_states, rng, dtype):
+    'Left-to-right alignment-like graph with skips: in/out degree <= 3.'
+    trans = np.full((n_states, n_states), -np.inf)
+    for i in range(n_states):
+        nxt = [j for j in (i, i + 1, i + 2) if j < n_states]
+        p = rng.dirichlet(np.ones(len(nxt)))
+        for j, pj in zip(nxt, p):
+            trans[i, j] = np.log(pj)
+    init = np.full(n_states, -np.inf)
+    init[:2] = np.log([.7, .3])
+    final = np.full(n_states, -np.inf)
+    final[-2:] = np.log([.4, .6])
+    return init.astype(dtype), final.astype(dtype), trans.astype(dtype)
+
+
+@pytest.mark.parametrize('n_states', [40, 300, 700])
+def test_forward_backward_kernels_agree_with_oracle_on_long_chains(n_states):
+    '''40 / 300 states run the low-degree kernel (128 / 512 threads), 700 states
+    the general segment kernel; both must match the oracle, and each other.'''
+    rng = np.random.RandomState(n_states)
+    init, final, trans = _chain_graph(n_states, rng, np.float64)
+    T = n_states + 60
+    llhs = rng.randn(T, n_states) * 3
+    graph = beer.graph.CompiledGraph(tt(init), tt(final), tt(trans), list(range(n_states)))
+    gam, xi, lnm = orc.posteriors(llhs, init, final, trans, True)
+    from beer_amd import hmm_kernels as hk
+    for dense in (False, True):
+        batch = hk.HmmBatch([graph], [0], [T], torch.float64)
+        g, x, g0, ln, flow = hk.forward_backward(batch, tt(llhs).reshape(-1), want_xi=True,
+                                                 want_lognorm=True, dense_xi=dense)
+        assert_close(npy(g).reshape(T, -1), gam, 1e-9, f'gamma dense={dense}')
+        assert_close(npy(x), xi.sum(0), 1e-9, f'xi dense={dense}')
+        assert_close(float(ln[0]), lnm, 1e-11)
+        assert_close(npy(g0), gam[0], 1e-9)
+    np.testing.assert_array_equal(npy(graph.best_path(tt(llhs))),
+                                  orc.best_path(llhs, init, final, trans))
+
+
+def test_hmm_batch_with_one_frame_utterances():
+    g = load_golden('g04_hmm_diagonal')
+    hmm = build_hmm(g)
+    X = tt(g['X'])
+    utts = [X[:1], X[1:40], X[40:41], X[41:]]
+    loop = beer.evidence_lower_bound(datasize=len(X))
+    for x in utts:
+        loop += beer.evidence_lower_bound(hmm, x, datasize=len(X))
+    batched = beer.accumulate_elbo(hmm, utts, datasize=len(X))
+    assert_close(float(batched), float(loop), 1e-11)
+    p0 = params_of(hmm)[0]
+    assert_close(npy(batched._acc_stats[p0]), npy(loop._acc_stats[p0]), 1e-10)
