@@ -1,0 +1,87 @@
+"""Load pickles written by the reference implementation (`beer.*` classes)
+into the `beer_amd` classes.  Works because the host layer keeps the
+reference's attribute names (buffers `mean`, `scale`, ...; `means_precisions`,
+`categorical`, `graph`, `start_pdf`, ...): an `nn.Module` pickle is its
+`__dict__`, so only the class lookup has to be redirected."""
+
+import importlib
+import pickle
+
+__all__ = ['load', 'loads', 'Unpickler', 'reference_aliases']
+
+_SEARCH = ('beer_amd.models', 'beer_amd.dists', 'beer_amd.graph', 'beer_amd.inference',
+           'beer_amd.inference.objectives', 'beer_amd.cli.dataset', 'beer_amd.dists.expfam',
+           'beer_amd.dists.families')
+
+
+class Unpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module == 'beer' or module.startswith('beer.'):
+            for target in _SEARCH:
+                mod = importlib.import_module(target)
+                if hasattr(mod, name):
+                    return getattr(mod, name)
+            raise pickle.UnpicklingError(
+                f'{module}.{name} has no counterpart in beer_amd (out of scope)')
+        return super().find_class(module, name)
+
+
+def load(fileobj):
+    'pickle.load that maps `beer.*` classes to `beer_amd.*`.'
+    return Unpickler(fileobj).load()
+
+
+def loads(data):
+    import io
+    return load(io.BytesIO(data))
+
+
+class _Alias:
+    'Stand-in for a `beer.*` module: attribute lookups resolve in beer_amd.'
+
+    def __init__(self, name):
+        self.__name__ = name
+
+    def __getattr__(self, name):
+        for target in _SEARCH:
+            mod = importlib.import_module(target)
+            if hasattr(mod, name):
+                return getattr(mod, name)
+        raise AttributeError(name)
+
+
+_REFERENCE_MODULES = (
+    'beer', 'beer.graph', 'beer.models', 'beer.dists', 'beer.inference',
+    'beer.inference.objectives', 'beer.cli', 'beer.cli.dataset',
+    'beer.models.hmm', 'beer.models.phoneloop', 'beer.models.mixture',
+    'beer.models.mixtureset', 'beer.models.normalset', 'beer.models.normal',
+    'beer.models.categorical', 'beer.models.categoricalset', 'beer.models.modelset',
+    'beer.models.parameters', 'beer.models.basemodel', 'beer.dists.normalwishart',
+    'beer.dists.normalgamma', 'beer.dists.isonormalgamma', 'beer.dists.dirichlet',
+    'beer.dists.gamma', 'beer.dists.basedist')
+
+
+class reference_aliases:
+    '''Context manager: while active, pickles that name `beer.*` classes (e.g.
+    the object arrays inside an `alis.npz` written by the reference) resolve to
+    beer_amd classes.  Does nothing if a real `beer` package is importable.'''
+
+    def __enter__(self):
+        import sys
+        self._added = []
+        try:
+            import beer                                   # noqa: F401
+            return self
+        except ImportError:
+            pass
+        for name in _REFERENCE_MODULES:
+            if name not in sys.modules:
+                sys.modules[name] = _Alias(name)
+                self._added.append(name)
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+        for name in self._added:
+            sys.modules.pop(name, None)
+        return False

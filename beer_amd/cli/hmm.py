@@ -1,0 +1,513 @@
+"""`beer hmm <cmd>`: the callers either side of the hot path
+(beer/cli/subcommands/hmm/*.py).  Same positional arguments, options, pickled
+artefacts and log lines; `accumulate` / `decode` process the whole list of
+utterances as ONE ragged batch on the GPU instead of a Python loop."""
+
+import os
+import pickle
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+import beer_amd as beer
+from . import compat
+
+# ---------------------------------------------------------------------------
+# helpers
+
+
+def _load(path):
+    with open(path, 'rb') as f:
+        return compat.load(f)
+
+
+def _dump(obj, path):
+    with open(path, 'wb') as f:
+        pickle.dump(obj, f)
+
+
+def _device():
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _utt_ids(args_utts, dataset):
+    if args_utts:
+        stream = sys.stdin if args_utts == '-' else open(args_utts)
+        return [line.strip().split()[0] for line in stream if line.strip()]
+    return [utt.id for utt in dataset.utterances(random_order=False)]
+
+
+def _cpu_elbo(elbo):
+    'ELBO object with every tensor on the host (portable pickle).'
+    acc = {p: s.cpu() for p, s in elbo._acc_stats.items()}
+    value = elbo.value.cpu() if isinstance(elbo.value, torch.Tensor) else elbo.value
+    return beer.EvidenceLowerBoundInstance(value, acc, elbo._model_parameters,
+                                           elbo._minibatchsize, elbo._datasize)
+
+
+def parse_topology(topology):
+    state_ids, arcs = set(), set()
+    for arc in topology:
+        start, end, weight = arc['start_id'], arc['end_id'], arc['trans_prob']
+        state_ids.update((start, end))
+        arcs.add((start, end, weight))
+    return sorted(state_ids), arcs
+
+
+def create_unit_graph(topology, start_pdf_id):
+    'Unit HMM whose first / last states are non-emitting (mkphones.py:27-43).'
+    state_ids, arcs = parse_topology(topology)
+    graph = beer.graph.Graph()
+    count = 0
+    for state_id in range(len(state_ids)):
+        if state_id in (state_ids[0], state_ids[-1]):
+            graph.add_state(pdf_id=None)
+        else:
+            graph.add_state(pdf_id=start_pdf_id + count)
+            count += 1
+    graph.start_state, graph.end_state = state_ids[0], state_ids[-1]
+    for arc in arcs:
+        graph.add_arc(*arc)
+    return graph, start_pdf_id + count
+
+
+def count_emitting_state(graph):
+    return sum(1 for s in graph.states() if graph.state_from_id(s).pdf_id is not None)
+
+
+def create_pdfs(mean, var, tot_emitting_states, conf):
+    modelset = beer.NormalSet.create(
+        mean=mean, cov=var, size=tot_emitting_states * conf['n_normal_per_state'],
+        prior_strength=conf['prior_strength'], noise_std=conf['noise_std'],
+        cov_type=conf['cov_type'], shared_cov=conf['shared_cov'])
+    return beer.MixtureSet.create(tot_emitting_states, modelset,
+                                  prior_strength=conf['prior_strength'])
+
+
+def create_graph_from_seq(seq, phone_graphs):
+    'Linear alignment graph of a phone sequence (mkaligraph.py:18-39).'
+    graph = beer.graph.Graph()
+    graph.start_state = graph.add_state()
+    last, phone_states = graph.start_state, []
+    for _ in seq:
+        state = graph.add_state()
+        phone_states.append(state)
+        graph.add_arc(last, state)
+        last = state
+    graph.end_state = graph.add_state()
+    graph.add_arc(last, graph.end_state)
+    for state, phone in zip(phone_states, seq):
+        graph.replace_state(state, phone_graphs[phone])
+    graph.normalize()
+    return graph.compile()
+
+
+def _single_pdf(graph, walk):
+    states = [s for s, _ in walk]
+    if len(states) != 1:
+        raise ValueError(f'expected only one emitting state, got: {len(states)}')
+    return graph.state_from_id(states[0]).pdf_id
+
+
+def state2phone(path, start_pdf, per_frame):
+    'Collapse a pdf-id path into phone symbols (decode.py:27-40).'
+    starts = list(start_pdf.values())
+    state2sym = {v: k for k, v in start_pdf.items()}
+    prev = path[0]
+    last = state2sym[prev]
+    phones = [last]
+    for state in path[1:]:
+        if state != prev and state in starts:
+            last = state2sym[state]
+            phones.append(last)
+        elif per_frame:
+            phones.append(last)
+        prev = state
+    return phones
+
+
+# ---------------------------------------------------------------------------
+# commands: each is (setup(parser), main(args, logger))
+
+class mkphones:
+    'create a set of left-to-right HMM representing "phones"'
+
+    @staticmethod
+    def setup(parser):
+        group = parser.add_mutually_exclusive_group(required=True)
+        group.add_argument('-d', '--dataset', help='dataset for initialization')
+        group.add_argument('-D', '--dimension', type=int, help='dimension of the features')
+        parser.add_argument('conf', help='configuration file')
+        parser.add_argument('units', help='list of units and their group')
+        parser.add_argument('out', help='output phone HMMs')
+
+    @staticmethod
+    def main(args, logger):
+        with open(args.conf) as f:
+            conf = yaml.safe_load(f)
+        groups = {g['group_name']: g for g in conf}
+        grouped = {name: [] for name in groups}
+        with open(args.units) as f:
+            for line in f:
+                name, group = line.strip().split()
+                grouped[group].append(name)
+        if args.dataset:
+            dataset = _load(args.dataset)
+            mean, var = dataset.mean, dataset.var
+        else:
+            mean, var = torch.zeros(args.dimension).float(), torch.ones(args.dimension).float()
+        start_pdf_id, pdfs, units = 0, [], {}
+        for group, names in grouped.items():
+            tot = 0
+            for name in names:
+                graph, start_pdf_id = create_unit_graph(groups[group]['topology'], start_pdf_id)
+                units[name] = graph
+                tot += count_emitting_state(graph)
+            pdfs.append(create_pdfs(mean, var, tot, groups[group]))
+        emissions = beer.JointModelSet(pdfs)
+        _dump((units, emissions), args.out)
+        logger.info(f'created {len(units)} HMMs for a total of {len(emissions)} emitting states')
+        logger.info(f'expected features dimension: {len(mean)}')
+
+
+class mkphoneloopgraph:
+    'create a phone-loop graph'
+
+    @staticmethod
+    def setup(parser):
+        parser.add_argument('-s', '--start-end-group', help='group starting/ending the loop')
+        parser.add_argument('units', help='list of units and their group')
+        parser.add_argument('out', help='output phone-loop graph')
+
+    @staticmethod
+    def main(args, logger):
+        with open(args.units) as f:
+            units = [tuple(line.strip().split()) for line in f if line.strip()]
+        graph = beer.graph.Graph()
+        graph.start_state, graph.end_state = graph.add_state(), graph.add_state()
+        pivot = graph.add_state()
+        unit2state = {'\\<s\\>': graph.start_state, '\\</s\\>': graph.end_state, '#1': pivot}
+        unit2state.update({name: graph.add_state() for name, _ in units})
+        state2unit = {s: u for u, s in unit2state.items()}
+        if args.start_end_group:
+            edge_units = [name for name, group in units if group == args.start_end_group]
+        else:
+            edge_units = [state2unit[pivot]]
+        for unit in edge_units:
+            graph.add_arc(graph.start_state, unit2state[unit])
+        for unit in edge_units:
+            graph.add_arc(unit2state[unit], graph.end_state)
+        for unit, _ in units:
+            graph.add_arc(pivot, unit2state[unit])
+            graph.add_arc(unit2state[unit], pivot)
+        graph.symbols = state2unit
+        graph.normalize()
+        _dump(graph, args.out)
+        logger.info(f'created phone-loop graph. # states: {len(list(graph.states()))} '
+                    f'# arcs: {len(list(graph.arcs()))} start/end group: {args.start_end_group}')
+
+
+class mkdecodegraph:
+    'combine a set of HMMs with a phone-loop graph'
+
+    @staticmethod
+    def setup(parser):
+        parser.add_argument('phoneloop', help='phone loop graph')
+        parser.add_argument('hmms', help="phones' hmms")
+        parser.add_argument('out', help='output decoding graph')
+
+    @staticmethod
+    def main(args, logger):
+        graph = _load(args.phoneloop)
+        units, _ = _load(args.hmms)
+        phone2state = {phone: state for state, phone in graph.symbols.items()}
+        for phone, hmm in units.items():
+            graph.replace_state(phone2state[phone], hmm)
+        graph.normalize()
+        start_pdf, end_pdf = {}, {}
+        for phone, hmm in units.items():
+            start_pdf[phone] = _single_pdf(hmm, hmm.find_next_pdf_ids(hmm.start_state))
+            end_pdf[phone] = _single_pdf(hmm, hmm.find_previous_pdf_ids(hmm.end_state))
+        _dump((graph, start_pdf, end_pdf), args.out)
+        logger.info(f'created decoding graph. # states: {len(list(graph.states()))} '
+                    f'# arcs: {len(list(graph.arcs()))} ')
+
+
+class mkphoneloop:
+    'create a phone-loop model'
+    PRIORS = ('dirichlet', 'dirichlet_process', 'gamma_dirichlet_process')
+
+    @staticmethod
+    def setup(parser):
+        parser.add_argument('-c', '--concentration', type=float,
+                            help='concentration of the Dirichlet Process')
+        parser.add_argument('--weights-prior', default='gamma_dirichlet_process',
+                            choices=mkphoneloop.PRIORS, help='prior over the phone weights')
+        parser.add_argument('decode_graph', help='decoding graph')
+        parser.add_argument('hmms', help="phones' hmm")
+        parser.add_argument('out', help='phone loop model')
+
+    @staticmethod
+    def main(args, logger):
+        graph, start_pdf, end_pdf = _load(args.decode_graph)
+        _, emissions = _load(args.hmms)
+        size = len(start_pdf)
+        conc = args.concentration if args.concentration else size / 2
+        if args.weights_prior == 'dirichlet':
+            cat = beer.Categorical.create(torch.ones(size) / size, prior_strength=conc)
+        elif args.weights_prior == 'dirichlet_process':
+            cat = beer.SBCategorical.create(truncation=size, prior_strength=conc)
+        else:
+            cat = beer.SBCategoricalHyperPrior.create(truncation=size, prior_strength=conc,
+                                                      hyper_prior_strength=1.)
+        ploop = beer.PhoneLoop.create(graph.compile(), start_pdf, end_pdf, emissions, cat)
+        _dump(ploop, args.out)
+        logger.info(f'successfully created a phone-loop model with {size} phones')
+
+
+class mkaligraph:
+    'create the alignment graphs from transcriptions (stdin)'
+
+    @staticmethod
+    def setup(parser):
+        parser.add_argument('hmms', help='hmm graph for each unit')
+        parser.add_argument('outdir', help='output directory')
+
+    @staticmethod
+    def main(args, logger):
+        hmm_graphs, _ = _load(args.hmms)
+        nutts = 0
+        for line in sys.stdin:
+            tokens = line.strip().split()
+            if not tokens:
+                continue
+            uttid, phones = tokens[0], tokens[1:]
+            if not phones:
+                logger.error(f'utterance {uttid} has no transcription')
+                continue
+            graph = create_graph_from_seq(phones, hmm_graphs)
+            arr = np.empty(1, dtype=object)
+            arr[0] = graph
+            np.save(os.path.join(args.outdir, uttid + '.npy'), arr)
+            nutts += 1
+        logger.info(f'created alignment graphs for {nutts} utterances')
+
+
+class phonelist:
+    "print the list of phones from a set of phones' HMM"
+
+    @staticmethod
+    def setup(parser):
+        parser.add_argument('hmms', help="phones' hmms")
+
+    @staticmethod
+    def main(args, logger):
+        units, _ = _load(args.hmms)
+        import re
+        natkey = lambda s: [int(t) if t.isdigit() else t for t in re.split(r'(\\d+)', s.lower())]
+        for key in sorted(units.keys(), key=natkey):
+            print(key)
+
+
+def _shard(model, dataset, uttids, alis, logger):
+    'Features and per-utterance graphs of the utterances that exist.'
+    feats, graphs, kept = [], [], []
+    for uttid in uttids:
+        try:
+            utt = dataset[uttid]
+        except KeyError:
+            logger.warning(f'no utterance {uttid} in the dataset')
+            continue
+        graph = None
+        if alis is not None:
+            try:
+                graph = alis[uttid][0]
+            except KeyError:
+                logger.warning(f'no alignment graph for utterance "{uttid}"')
+        feats.append(utt.features)
+        graphs.append(graph)
+        kept.append(uttid)
+    return feats, graphs, kept
+
+
+def _load_alis(path):
+    '''alis.npz: one `.npy` object array [CompiledGraph] per utterance
+    (mkaligraph.py:60-63, accumulate.py:35,50).  Loaded eagerly; archives
+    written by the reference are remapped to beer_amd classes.'''
+    if not path:
+        return None
+    with compat.reference_aliases():
+        raw = np.load(path, allow_pickle=True)
+        return {key: raw[key] for key in raw.files}
+
+
+class accumulate:
+    'Accumulate the ELBO from a list of utterances given from "stdin"'
+
+    @staticmethod
+    def setup(parser):
+        parser.add_argument('-a', '--alis', help='alignment graphs in a "npz" archive')
+        parser.add_argument('-s', '--acoustic-scale', default=1., type=float)
+        parser.add_argument('model', help='hmm based model')
+        parser.add_argument('dataset', help='training data set')
+        parser.add_argument('out', help='output accumulated ELBO')
+
+    @staticmethod
+    def main(args, logger):
+        model = _load(args.model).to(_device())
+        dataset = _load(args.dataset)
+        alis = _load_alis(args.alis)
+        uttids = [line.strip().split()[0] for line in sys.stdin if line.strip()]
+        feats, graphs, kept = _shard(model, dataset, uttids, alis, logger)
+        elbo = beer.evidence_lower_bound(datasize=dataset.size)
+        count = len(kept)
+        if count:
+            # utterances without an alignment graph fall back to the model's graph
+            use = None if alis is None else [g if g is not None else model.graph for g in graphs]
+            elbo = elbo + beer.accumulate_elbo(model, feats, datasize=dataset.size,
+                                               inference_graphs=use, scale=args.acoustic_scale)
+        _dump((_cpu_elbo(elbo), count), args.out)
+        norm = max(count, 1) * dataset.size
+        logger.info(f'accumulated ELBO over {count} utterances: {float(elbo) / norm :.3f}.')
+
+
+class update:
+    'Update the parameters of the model given the set of ELBO loaded from stdin'
+
+    @staticmethod
+    def setup(parser):
+        parser.add_argument('-l', '--learning-rate', default=1., type=float)
+        parser.add_argument('-o', '--optim-state', help='optimizer state')
+        parser.add_argument('model', help='model to update')
+        parser.add_argument('out_model', help='updated model')
+
+    @staticmethod
+    def main(args, logger):
+        model = _load(args.model)
+        optim = beer.VBConjugateOptimizer(model.conjugate_bayesian_parameters(keepgroups=True),
+                                          lrate=args.learning_rate)
+        if args.optim_state and os.path.isfile(args.optim_state):
+            optim.load_state_dict(torch.load(args.optim_state))
+        optim.init_step()
+        elbo, nutts = None, 0
+        for line in sys.stdin:
+            if not line.strip():
+                continue
+            elbo_batch, nutts_batch = _load(line.strip())
+            elbo = elbo_batch if elbo is None else elbo + elbo_batch
+            nutts += nutts_batch
+        elbo.sync(model)
+        elbo.backward()
+        optim.step()
+        _dump(model, args.out_model)
+        if args.optim_state:
+            torch.save(optim.state_dict(), args.optim_state)
+        logger.info(f'accumulated ELBO={float(elbo) / (nutts * elbo._datasize):.3f}')
+
+
+class train:
+    'train a HMM based model on a single machine'
+
+    @staticmethod
+    def setup(parser):
+        parser.add_argument('-b', '--batch-size', type=int, default=-1,
+                            help='utterances per update (-1: all)')
+        parser.add_argument('-e', '--epochs', type=int, default=1)
+        parser.add_argument('-l', '--lrate', type=float, default=1.)
+        parser.add_argument('model', help='hmm based model')
+        parser.add_argument('dataset', help='training data set')
+        parser.add_argument('out', help='output model')
+
+    @staticmethod
+    def main(args, logger):
+        # (the reference's `train` refers to an optimizer that no longer exists,
+        #  train.py:34; this is the working equivalent)
+        model = _load(args.model).to(_device())
+        dataset = _load(args.dataset)
+        optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=args.lrate)
+        for epoch in range(1, args.epochs + 1):
+            utts = list(dataset.utterances())
+            bsize = len(utts) if args.batch_size <= 0 else args.batch_size
+            for b in range(0, len(utts), bsize):
+                batch = utts[b:b + bsize]
+                optim.init_step()
+                elbo = beer.accumulate_elbo(model, [u.features for u in batch],
+                                            datasize=dataset.size)
+                elbo.backward()
+                optim.step()
+                logger.info(f'epoch={epoch} batch={b // bsize + 1} '
+                            f'ELBO={float(elbo) / (len(batch) * dataset.size):.3f}')
+        _dump(model.cpu(), args.out)
+        logger.info(f'finished training after {args.epochs} epochs. '
+                    f'KL(q || p) = {float(model.kl_div_posterior_prior()): .3f}')
+
+
+class decode:
+    'print the most likely path of all the utterances of a dataset'
+
+    @staticmethod
+    def setup(parser):
+        parser.add_argument('-a', '--alis', help='alignment graphs in a "npz" archive')
+        parser.add_argument('--per-frame', action='store_true')
+        parser.add_argument('-s', '--acoustic-scale', default=1., type=float)
+        parser.add_argument('-u', '--utts', help='utterances to decode ("-" for stdin)')
+        parser.add_argument('model', help='hmm based model')
+        parser.add_argument('dataset', help='data set')
+
+    @staticmethod
+    def main(args, logger):
+        model = _load(args.model).to(_device())
+        dataset = _load(args.dataset)
+        alis = _load_alis(args.alis)
+        feats, graphs, kept = _shard(model, dataset, _utt_ids(args.utts, dataset), alis, logger)
+        use = None if alis is None else [g if g is not None else model.graph for g in graphs]
+        paths = beer.decode_batch(model, feats, inference_graphs=use, scale=args.acoustic_scale) \
+            if kept else []
+        for uttid, path in zip(kept, paths):
+            phones = state2phone([int(p) for p in path.cpu()], model.start_pdf, args.per_frame)
+            print(uttid, ' '.join(phones))
+        logger.info(f'successfully decoded {len(kept)} utterances.')
+
+
+class posteriors:
+    'state / phone posteriors of all the utterances of a dataset'
+    EPS = 1e-5
+
+    @staticmethod
+    def setup(parser):
+        parser.add_argument('-S', '--state', action='store_true', help='state level')
+        parser.add_argument('-l', '--log', action='store_true', help='log domain')
+        parser.add_argument('-s', '--acoustic-scale', default=1., type=float)
+        parser.add_argument('-u', '--utts', help='utterances ("-" for stdin)')
+        parser.add_argument('model', help='hmm based model')
+        parser.add_argument('dataset', help='data set')
+        parser.add_argument('outdir', help='output directory')
+
+    @staticmethod
+    def main(args, logger):
+        model = _load(args.model).to(_device())
+        dataset = _load(args.dataset)
+        count = 0
+        for uttid in _utt_ids(args.utts, dataset):
+            try:
+                utt = dataset[uttid]
+            except KeyError:
+                logger.warning(f'no data for utterance {uttid}')
+                continue
+            posts = model.posteriors(utt.features, scale=args.acoustic_scale).cpu().numpy()
+            if not args.state:
+                out = np.zeros((len(posts), len(model.start_pdf)))
+                for i, unit in enumerate(model.start_pdf):
+                    out[:, i] = posts[:, model.start_pdf[unit]:model.end_pdf[unit]].sum(axis=-1)
+                posts = out
+            if args.log:
+                posts = np.log(posteriors.EPS + posts)
+            np.save(os.path.join(args.outdir, f'{uttid}.npy'), posts)
+            count += 1
+        logger.info(f'successfully computed the posteriors for {count} utterances.')
+
+
+COMMANDS = [accumulate, decode, mkaligraph, mkdecodegraph, mkphoneloop, mkphoneloopgraph,
+            mkphones, posteriors, phonelist, train, update]

@@ -17,7 +17,7 @@ __all__ = ['Graph', 'CompiledGraph']
 
 
 class State:
-    __slots__ = ('id', 'pdf_id')
+    'Node of a graph (plain attributes: pickles of the reference restore into it).'
 
     def __init__(self, id, pdf_id):
         self.id, self.pdf_id = id, pdf_id
@@ -28,7 +28,6 @@ class State:
 
 class Arc:
     'Weighted arc; identity (hash / equality) is the (start, end) pair.'
-    __slots__ = ('start', 'end', 'weight')
 
     def __init__(self, start, end, weight=1.0):
         self.start, self.end, self.weight = start, end, weight

@@ -552,3 +552,56 @@ if __name__ == '__main__':
     g9()
     g10()
     g_graph()
+    g_pickles()
+
+
+def g_pickles():
+    '''Pickles written by the REFERENCE classes (binary data: tensors + class
+    names, no source): a small phone loop, its unit HMMs and an alignment
+    archive, for the pickle-compatibility tests of beer_amd.cli.compat.'''
+    import pickle
+    import zipfile
+    ploop, units, start_pdf, end_pdf = build_phoneloop('dirichlet', 3, 'diagonal', 7, torch.float32)
+    with open(os.path.join(HERE, 'ref_phoneloop.pkl'), 'wb') as f:
+        pickle.dump(ploop, f)
+    emissions = ploop.modelset.original_modelset
+    with open(os.path.join(HERE, 'ref_units.pkl'), 'wb') as f:
+        pickle.dump((units, emissions), f)
+    rng = np.random.RandomState(3)
+    feats = {f'utt{i}': (rng.randn(T, 3) * 1.5).astype(np.float32)
+             for i, T in enumerate((35, 50, 41))}
+    np.savez(os.path.join(HERE, 'ref_feats.npz'), **feats)
+    seqs = {'utt0': ['sil', 'a', 'b', 'sil'], 'utt1': ['sil', 'c', 'a', 'd', 'sil'],
+            'utt2': ['sil', 'b', 'sil']}
+    tmp = os.path.join(HERE, '_tmp_ali')
+    os.makedirs(tmp, exist_ok=True)
+    with zipfile.ZipFile(os.path.join(HERE, 'ref_alis.npz'), 'w') as z:
+        for utt, seq in seqs.items():
+            path = os.path.join(tmp, utt + '.npy')
+            np.save(path, np.array([mkaligraph.create_graph_from_seq(seq, units)]))
+            z.write(path, utt + '.npy')
+            os.remove(path)
+    os.rmdir(tmp)
+    # what the reference computes with these files (accumulate.py loop + update.py)
+    out = {}
+    N = sum(len(v) for v in feats.values())
+    alis = np.load(os.path.join(HERE, 'ref_alis.npz'), allow_pickle=True)
+    optim = beer.VBConjugateOptimizer(ploop.conjugate_bayesian_parameters(keepgroups=True), 1.)
+    optim.init_step()
+    elbo = beer.evidence_lower_bound(datasize=N)
+    for utt in sorted(feats):
+        elbo += beer.evidence_lower_bound(ploop, torch.from_numpy(feats[utt]).float(),
+                                          inference_graph=alis[utt][0], datasize=N, scale=1.)
+    out['ali_elbo'] = np.asarray(float(elbo))
+    out['ali_logged'] = np.asarray(float(elbo) / (len(feats) * N))
+    dump_acc(out, 'ali_acc', ploop, elbo._acc_stats)
+    free = beer.evidence_lower_bound(datasize=N)
+    for utt in sorted(feats):
+        free += beer.evidence_lower_bound(ploop, torch.from_numpy(feats[utt]).float(), datasize=N)
+    out['free_elbo'] = np.asarray(float(free))
+    out['decode'] = np.concatenate([npy(ploop.decode(torch.from_numpy(feats[u]).float()))
+                                    for u in sorted(feats)])
+    free.backward()
+    optim.step()
+    dump_params(out, 'updated', ploop)
+    save('g13_cli_reference_run', out)
