@@ -5,6 +5,7 @@ from .models import *
 from .inference import *
 from . import dists
 from . import graph
+from . import nnet
 from . import utils
 from . import vbi
 from .stats import FrameStats

@@ -114,6 +114,13 @@ SIGNATURES = {
     'beer_hmm_path_posteriors': [c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     'beer_hmm_scatter': [c_i, c_p, c_i, c_p, c_p, c_d, c_p, c_p, c_p, c_p],
     'beer_segment_sum': [c_i, ctypes.c_int32, c_p, c_p, c_p, c_p],
+    'beer_dense_llh': [c_i, c_l, c_i, c_i, c_p, c_p, c_d, c_p, c_p],
+    'beer_dense_llh_backward': [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+    'beer_dense_accumulate': [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+    'beer_rowdot': [c_i, c_l, c_i, c_p, c_p, c_p, c_p],
+    'beer_softmax_groups': [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+    'beer_suffstats_mean': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p],
+    'beer_suffstats_backward': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
 }
 
 

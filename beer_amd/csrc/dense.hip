@@ -1,0 +1,341 @@
+// "Statistics-in" variants of the E-step: the caller hands dense sufficient
+// statistics [T, Q] instead of frames.  This is the path of the VAE models
+// (beer/models/vae.py:63-86): the prior model receives sample-averaged
+// statistics of the latent variable, its expected log-likelihood must be
+// differentiable w.r.t. those statistics (only sum_k r_k l_k carries gradient,
+// mixture.py:79,92), and it accumulates resps^T @ stats.
+//
+// With dense statistics these are plain GEMMs with a small inner or outer
+// dimension (Q = 2 D + 2 = 130 for a 64-d diagonal latent): HBM-bound on the
+// [T, Q] and [T, K] operands.  One generic LDS-tiled kernel serves the three
+// products; it is written for bandwidth (coalesced 64 x 16 tiles), not for MFMA.
+//
+// Reference restated: beer/dists/normalgamma.py:55-59 (llh = stats @ E[T]^T +
+// log base measure), beer/models/normalset.py:121-123 (resps^T @ stats).
+
+#include "common.h"
+
+using namespace beer;
+
+namespace {
+
+constexpr int TM = 64, TN = 64, TK = 16;
+
+// C[m,n] = alpha_m * sum_k A(m,k) B(k,n) + beta   (or atomically += into fp64)
+// A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn].  grid.z splits k.
+template <typename T, typename TC, bool ATOMIC>
+__global__ __launch_bounds__(256) void gemm_kernel(int64_t M, int N, int64_t Kd, const T* A,
+                                                   int64_t sam, int64_t sak, const T* B,
+                                                   int64_t sbk, int64_t sbn, TC* C,
+                                                   const T* row_scale, double beta,
+                                                   int64_t k_per_block, const T* a_scale,
+                                                   int a_group, int a_ld) {
+    __shared__ T As[TK][TM + 1];
+    __shared__ T Bs[TK][TN + 1];
+    const int tid = threadIdx.x;
+    const int64_t m0 = (int64_t)blockIdx.x * TM;
+    const int n0 = blockIdx.y * TN;
+    const int64_t kb = (int64_t)blockIdx.z * k_per_block;
+    const int64_t ke = min(Kd, kb + k_per_block);
+    const int tx = tid & 15, ty = tid >> 4;              // 16 x 16 threads, 4 x 4 outputs each
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int64_t k0 = kb; k0 < ke; k0 += TK) {
+        // the faster-varying global index goes on consecutive threads
+        for (int idx = tid; idx < TM * TK; idx += 256) {
+            int mm, kk;
+            if (sak == 1) { kk = idx % TK; mm = idx / TK; } else { mm = idx % TM; kk = idx / TM; }
+            const int64_t m = m0 + mm, k = k0 + kk;
+            T a = (m < M && k < ke) ? A[m * sam + k * sak] : (T)0;
+            // joint responsibilities: A(m, k) *= a_scale[k, m / a_group]
+            if (a_scale && m < M && k < ke) a *= a_scale[k * a_ld + m / a_group];
+            As[kk][mm] = a;
+        }
+        for (int idx = tid; idx < TN * TK; idx += 256) {
+            int nn, kk;
+            if (sbk == 1) { kk = idx % TK; nn = idx / TK; } else { nn = idx % TN; kk = idx / TN; }
+            const int n = n0 + nn;
+            const int64_t k = k0 + kk;
+            Bs[kk][nn] = (n < N && k < ke) ? B[k * sbk + n * sbn] : (T)0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TK; ++kk) {
+            T a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += (double)a[i] * (double)b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + ty * 4 + i;
+        if (m >= M) continue;
+        const double sc = row_scale ? (double)row_scale[m] : 1.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n >= N) continue;
+            if (ATOMIC) atomicAdd(reinterpret_cast<double*>(C) + m * N + n, acc[i][j]);
+            else C[m * N + n] = (TC)(sc * acc[i][j] + beta);
+        }
+    }
+}
+
+template <typename T>
+__global__ void rowdot_kernel(int64_t T_, int K, const T* __restrict__ a,
+                              const T* __restrict__ b, T* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (t >= T_) return;
+    const int lane = threadIdx.x & 63;
+    double s = 0.0;
+    for (int k = lane; k < K; k += 64) s += (double)a[t * K + k] * (double)b[t * K + k];
+    s = wave_sum(s);
+    if (lane == 0) out[t] = (T)s;
+}
+
+// w = pc + log_weights; per (t, s): log_norm = logsumexp_g w, resps = exp(w - log_norm)
+template <typename T>
+__global__ void softmax_groups_kernel(int64_t T_, int S, int G, const T* __restrict__ pc,
+                                      const T* __restrict__ logw, T* __restrict__ log_norm,
+                                      T* __restrict__ resps) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T_ * S) return;
+    const int s = (int)(idx % S);
+    const T* row = pc + idx * G;
+    const T* lw = logw ? logw + (size_t)s * G : nullptr;
+    double m = -__builtin_huge_val();
+    for (int g = 0; g < G; ++g) {
+        const double w = (double)row[g] + (lw ? (double)lw[g] : 0.0);
+        m = w > m ? w : m;
+    }
+    double ln = m;
+    if (m > -__builtin_huge_val() && m < __builtin_huge_val()) {
+        double sum = 0.0;
+        for (int g = 0; g < G; ++g) sum += exp((double)row[g] + (lw ? (double)lw[g] : 0.0) - m);
+        ln = m + log(sum);
+    }
+    if (log_norm) log_norm[idx] = (T)ln;
+    if (resps)
+        for (int g = 0; g < G; ++g)
+            resps[idx * G + g] = (T)exp((double)row[g] + (lw ? (double)lw[g] : 0.0) - ln);
+}
+
+// out[t,:] = mean over the ns samples of frame t of phi(x_ts)
+template <typename T>
+__global__ void suffstats_mean_kernel(int cov, int64_t T_, int ns, int D,
+                                      const T* __restrict__ X, T* __restrict__ out) {
+    const int Q = stats_dim(cov, D);
+    const int64_t total = T_ * Q;
+    const double inv = 1.0 / ns;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = idx / Q;
+        const int q = (int)(idx % Q);
+        const T* x = X + t * ns * D;
+        double v = 0.0;
+        if (q >= Q - 2) {
+            v = (q == Q - 2) ? -0.5 : (cov == BEER_ISO ? 0.5 * D : 0.5);
+        } else if (q < D) {
+            for (int s = 0; s < ns; ++s) v += (double)x[s * D + q];
+            v *= inv;
+        } else if (cov == BEER_FULL) {
+            const int i = (q - D) / D, j = (q - D) % D;
+            for (int s = 0; s < ns; ++s) v += (double)x[s * D + i] * (double)x[s * D + j];
+            v *= -0.5 * inv;
+        } else if (cov == BEER_DIAG) {
+            const int i = q - D;
+            for (int s = 0; s < ns; ++s) v += (double)x[s * D + i] * (double)x[s * D + i];
+            v *= -0.5 * inv;
+        } else {
+            for (int s = 0; s < ns; ++s)
+                for (int d = 0; d < D; ++d) v += (double)x[s * D + d] * (double)x[s * D + d];
+            v *= -0.5 * inv;
+        }
+        out[idx] = (T)v;
+    }
+}
+
+// d phi(x) / dx contracted with the upstream gradient of the statistics; with
+// ns > 1 the statistics of frame t are the mean over its ns samples (rows
+// t*ns .. t*ns+ns-1 of X).
+template <typename T>
+__global__ void suffstats_backward_kernel(int cov, int64_t T_, int ns, int D,
+                                          const T* __restrict__ X, const T* __restrict__ gs,
+                                          T* __restrict__ gx) {
+    const int Q = stats_dim(cov, D);
+    const double inv = 1.0 / ns;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < T_ * ns * D;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = idx / D;
+        const int d = (int)(idx % D);
+        const T* x = X + n * D;
+        const T* g = gs + (n / ns) * Q;
+        double v = (double)g[d];
+        if (cov == BEER_FULL) {
+            double s = 0.0;
+            for (int j = 0; j < D; ++j)
+                s += ((double)g[D + d * D + j] + (double)g[D + j * D + d]) * (double)x[j];
+            v -= 0.5 * s;
+        } else if (cov == BEER_DIAG) {
+            v -= (double)g[D + d] * (double)x[d];
+        } else {
+            v -= (double)g[D] * (double)x[d];
+        }
+        gx[idx] = (T)(v * inv);
+    }
+}
+
+template <typename T>
+int gemm_plain(int64_t M, int N, int64_t Kd, const T* A, int64_t sam, int64_t sak, const T* B,
+               int64_t sbk, int64_t sbn, T* C, const T* row_scale, double beta, hipStream_t s) {
+    const dim3 grid((unsigned)((M + TM - 1) / TM), (unsigned)((N + TN - 1) / TN), 1);
+    hipLaunchKernelGGL((gemm_kernel<T, T, false>), grid, dim3(256), 0, s, M, N, Kd, A, sam, sak, B,
+                       sbk, sbn, C, row_scale, beta, Kd, (const T*)nullptr, 1, 0);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+template <typename T>
+int dense_llh_launch(int64_t T_, int Q, int K, const void* stats, const void* expT, double base,
+                     void* out, void* stream) {
+    BEER_REQUIRE(T_ >= 0 && Q >= 1 && K >= 1 && stats && expT && out);
+    if (T_ == 0) return BEER_OK;
+    // out[t,k] = sum_q stats[t,q] expT[k,q] + base
+    return gemm_plain<T>(T_, K, Q, (const T*)stats, Q, 1, (const T*)expT, 1, Q, (T*)out, nullptr,
+                         base, as_stream(stream));
+}
+
+template <typename T>
+int dense_backward_launch(int64_t T_, int K, int Q, const void* w, const void* g,
+                          const void* expT, void* out, void* stream) {
+    BEER_REQUIRE(T_ >= 0 && Q >= 1 && K >= 1 && w && expT && out);
+    if (T_ == 0) return BEER_OK;
+    // out[t,q] = g_t * sum_k w[t,k] expT[k,q]
+    return gemm_plain<T>(T_, Q, K, (const T*)w, K, 1, (const T*)expT, Q, 1, (T*)out, (const T*)g,
+                         0.0, as_stream(stream));
+}
+
+template <typename T>
+int dense_accumulate_launch(int64_t T_, int K, int Q, int G, const void* w, const void* sr,
+                            const void* stats, double* acc, void* stream) {
+    BEER_REQUIRE(T_ >= 0 && Q >= 1 && K >= 1 && G >= 1 && K % G == 0 && w && stats && acc);
+    if (T_ == 0) return BEER_OK;
+    // acc[k,q] += sum_t w[t,k] stats[t,q]; frames split over grid.z, fp64 atomics
+    const int gx = (K + TM - 1) / TM, gy = (Q + TN - 1) / TN;
+    int64_t gz = (2048 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy);
+    const int64_t max_z = (T_ + 255) / 256;
+    if (gz > max_z) gz = max_z;
+    if (gz < 1) gz = 1;
+    int64_t kpb = (T_ + gz - 1) / gz;
+    kpb = (kpb + TK - 1) / TK * TK;
+    gz = (T_ + kpb - 1) / kpb;
+    hipLaunchKernelGGL((gemm_kernel<T, double, true>), dim3(gx, gy, (unsigned)gz), dim3(256), 0,
+                       as_stream(stream), (int64_t)K, Q, T_, (const T*)w, (int64_t)1, (int64_t)K,
+                       (const T*)stats, (int64_t)Q, (int64_t)1, acc, (const T*)nullptr, 0.0, kpb,
+                       (const T*)sr, G, K / G);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+template <typename T>
+int rowdot_launch(int64_t T_, int K, const void* a, const void* b, void* out, void* stream) {
+    BEER_REQUIRE(T_ >= 0 && K >= 1);
+    if (T_ == 0) return BEER_OK;
+    hipLaunchKernelGGL(rowdot_kernel<T>, dim3((unsigned)((T_ + 3) / 4)), dim3(256), 0,
+                       as_stream(stream), T_, K, (const T*)a, (const T*)b, (T*)out);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+template <typename T>
+int softmax_groups_launch(int64_t T_, int S, int G, const void* pc, const void* logw,
+                          void* log_norm, void* resps, void* stream) {
+    BEER_REQUIRE(T_ >= 0 && S >= 1 && G >= 1 && pc);
+    if (T_ == 0) return BEER_OK;
+    const int64_t n = T_ * S;
+    hipLaunchKernelGGL(softmax_groups_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), T_, S, G, (const T*)pc, (const T*)logw, (T*)log_norm,
+                       (T*)resps);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+template <typename T>
+int suffstats_mean_launch(int cov, int64_t T_, int ns, int D, const void* X, void* out,
+                          void* stream) {
+    BEER_REQUIRE(T_ >= 0 && ns >= 1 && D >= 1 && cov >= 0 && cov <= 2);
+    if (T_ == 0) return BEER_OK;
+    const int64_t total = T_ * stats_dim(cov, D);
+    const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    hipLaunchKernelGGL(suffstats_mean_kernel<T>, dim3(blocks), dim3(256), 0, as_stream(stream),
+                       cov, T_, ns, D, (const T*)X, (T*)out);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+template <typename T>
+int suffstats_backward_launch(int cov, int64_t T_, int ns, int D, const void* X, const void* gs,
+                              void* gx, void* stream) {
+    BEER_REQUIRE(T_ >= 0 && ns >= 1 && D >= 1 && cov >= 0 && cov <= 2);
+    if (T_ == 0) return BEER_OK;
+    const int64_t total = T_ * ns * D;
+    const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    hipLaunchKernelGGL(suffstats_backward_kernel<T>, dim3(blocks), dim3(256), 0, as_stream(stream),
+                       cov, T_, ns, D, (const T*)X, (const T*)gs, (T*)gx);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int beer_dense_llh(int dtype, int64_t T, int Q, int K, const void* stats, const void* exp_stats,
+                   double base, void* out, void* stream) {
+    BEER_DISPATCH(dtype, dense_llh_launch, T, Q, K, stats, exp_stats, base, out, stream);
+}
+
+int beer_dense_llh_backward(int dtype, int64_t T, int K, int Q, const void* weights,
+                            const void* grad, const void* exp_stats, void* out, void* stream) {
+    BEER_DISPATCH(dtype, dense_backward_launch, T, K, Q, weights, grad, exp_stats, out, stream);
+}
+
+int beer_dense_accumulate(int dtype, int64_t T, int K, int Q, int G, const void* weights,
+                          const void* state_resps, const void* stats, double* acc,
+                          void* stream) {
+    BEER_DISPATCH(dtype, dense_accumulate_launch, T, K, Q, G, weights, state_resps, stats, acc,
+                  stream);
+}
+
+int beer_rowdot(int dtype, int64_t T, int K, const void* a, const void* b, void* out,
+                void* stream) {
+    BEER_DISPATCH(dtype, rowdot_launch, T, K, a, b, out, stream);
+}
+
+int beer_softmax_groups(int dtype, int64_t T, int S, int G, const void* pc_llh,
+                        const void* log_weights, void* log_norm, void* resps, void* stream) {
+    BEER_DISPATCH(dtype, softmax_groups_launch, T, S, G, pc_llh, log_weights, log_norm, resps,
+                  stream);
+}
+
+int beer_suffstats_mean(int dtype, int cov, int64_t T, int ns, int D, const void* X, void* out,
+                        void* stream) {
+    BEER_DISPATCH(dtype, suffstats_mean_launch, cov, T, ns, D, X, out, stream);
+}
+
+int beer_suffstats_backward(int dtype, int cov, int64_t T, int ns, int D, const void* X,
+                            const void* grad_stats, void* grad_X, void* stream) {
+    BEER_DISPATCH(dtype, suffstats_backward_launch, cov, T, ns, D, X, grad_stats, grad_X, stream);
+}
+
+}  // extern "C"

@@ -51,8 +51,9 @@ __global__ void gather_kernel(beer_batch b, int S_total, const T* __restrict__ p
     }
 }
 
-// scatter (+ per-frame expected llh): one thread per frame, serial over the
-// utterance's states so that repeated pdf ids add without atomics.
+// scatter (+ per-frame expected llh): one wave per frame, lanes over the
+// utterance's states (coalesced rows of gamma / pc); repeated pdf ids
+// (alignment graphs) make the add atomic.
 template <typename T>
 __global__ void scatter_kernel(beer_batch b, int S_total, const T* __restrict__ pc,
                                const T* __restrict__ gamma, T scale, T* __restrict__ sr,
@@ -65,18 +66,22 @@ __global__ void scatter_kernel(beer_batch b, int S_total, const T* __restrict__ 
     const int64_t f0 = b.frame_off[u], nt = b.frame_off[u + 1] - f0;
     const T* g = gamma + b.llh_off[u];
     const T* p = pc + b.llh_off[u];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     double mine = 0.0;
-    for (int64_t t = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; t < nt;
-         t += (int64_t)gridDim.y * blockDim.x) {
+    for (int64_t t = (int64_t)blockIdx.y * nwave + wave; t < nt;
+         t += (int64_t)gridDim.y * nwave) {
         T e = 0;
         T* row = sr ? sr + (f0 + t) * S_total : nullptr;
-        for (int s = 0; s < S; ++s) {
+        for (int s = lane; s < S; s += 64) {
             const T gv = g[t * S + s];
-            if (row) row[ids[s]] += scale * gv;
+            if (row) atomicAdd(row + ids[s], scale * gv);
             e += p[t * S + s] * gv;
         }
-        if (exp_llh) exp_llh[f0 + t] = e;
-        mine += (double)e;
+        e = wave_sum(e);
+        if (lane == 0) {
+            if (exp_llh) exp_llh[f0 + t] = e;
+            mine += (double)e;
+        }
     }
     if (utt_llh) {
         const double tot = block_sum(mine, red);
@@ -681,7 +686,7 @@ int scatter_launch(const beer_batch* b, int S_total, const void* pc, const void*
         BEER_LAUNCH_CHECK();
         return BEER_OK;
     }
-    hipLaunchKernelGGL(scatter_kernel<T>, dim3(b->nutt, 1), dim3(256), 0, as_stream(stream), *b,
+    hipLaunchKernelGGL(scatter_kernel<T>, dim3(b->nutt, 8), dim3(256), 0, as_stream(stream), *b,
                        S_total, (const T*)pc, (const T*)gamma, (T)scale, (T*)sr, (T*)exp_llh,
                        utt_llh);
     BEER_LAUNCH_CHECK();

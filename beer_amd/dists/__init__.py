@@ -2,3 +2,4 @@
 
 from .expfam import *
 from .families import *
+from .normaldiag import *

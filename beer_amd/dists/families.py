@@ -130,14 +130,21 @@ class NormalLikelihood(ConjugateLikelihood):
     @classmethod
     def sufficient_statistics(cls, data):
         '''Lazy statistics: the [T, Q] tensor of the reference
-        (normalwishart.py:30-38) is only formed by `.dense()`.'''
+        (normalwishart.py:30-38) is only formed by `.dense()`.  Frames that
+        carry an autograd graph (samples of a VAE's latent variable,
+        vae.py:73) get the dense, differentiable tensor.'''
+        if torch.is_grad_enabled() and data.requires_grad:
+            from ..kernels import differentiable_stats
+            return differentiable_stats(data, cls.cov_type)
         return FrameStats(data, cls.cov_type)
 
     def __call__(self, pdfvecs, stats):
         'stats @ pdfvecs^T - D/2 ln 2pi -> [T, K] (normalwishart.py:88-92).'
-        from ..kernels import normal_llh
+        from ..kernels import dense_llh_autograd, is_dense, normal_llh
         if pdfvecs.dim() == 1:
             pdfvecs = pdfvecs.view(1, -1)
+        if is_dense(stats):
+            return dense_llh_autograd(stats, pdfvecs, self.dim)
         return normal_llh(stats, pdfvecs, self.cov_type)
 
 

@@ -24,6 +24,7 @@ from ..models.gaussians import NormalSet
 from ..models.mixtures import Mixture, MixtureSet
 from ..models.modelset import JointModelSet
 from ..models.sequence import HMM, PhoneLoop
+from ..models.vae import VAE
 from ..models.weights import SBCategorical
 from ..stats import FrameStats
 from .objectives import EvidenceLowerBoundInstance
@@ -227,8 +228,29 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
     return value_terms, out
 
 
+def _vae_batch(model, X, lengths, datasize, nsamples, llh_weight, kl_weight):
+    '''One minibatch of utterances through a VAE: the encoder / decoder see
+    the packed frames, an HMM prior sees them as a ragged batch.  The value
+    keeps its autograd graph (`elbo.backward()` reaches the networks).'''
+    kwargs = {'utt_lengths': lengths} if isinstance(model.prior, HMM) else {}
+    broadcast, model.reference_broadcast = model.reference_broadcast, False
+    try:
+        per_frame = model.expected_log_likelihood(X, nsamples=nsamples, llh_weight=llh_weight,
+                                                  kl_weight=kl_weight, **kwargs)
+    finally:
+        model.reference_broadcast = broadcast
+    # frame weights datasize / T_u (times T_u with the reference's [T, T] quirk)
+    w = [float(datasize) if broadcast else datasize / float(T) for T in lengths]
+    weights = torch.repeat_interleave(
+        torch.as_tensor(w, dtype=torch.float64, device=per_frame.device),
+        torch.as_tensor(lengths, device=per_frame.device))
+    value_terms = (weights * per_frame.to(torch.float64)).sum()
+    return value_terms, model.accumulate(None)
+
+
 def accumulate_elbo(model, utterances, datasize=-1, inference_graphs=None, scale=1.,
-                    viterbi=False, state_paths=None, labels=None, max_frames=1 << 20):
+                    viterbi=False, state_paths=None, labels=None, max_frames=1 << 20,
+                    nsamples=1, llh_weight=1., kl_weight=1.):
     '''ELBO + accumulated statistics of a shard of utterances, identical to the
     sum of per-utterance `evidence_lower_bound(model, utt, datasize=datasize,
     inference_graph=..., scale=..., viterbi=...)` calls.
@@ -242,6 +264,9 @@ def accumulate_elbo(model, utterances, datasize=-1, inference_graphs=None, scale
         scale: acoustic scale (HMM only).
         viterbi / state_paths: hard-alignment training branches (HMM only).
         labels: optional int64 [sum T_u] component labels (Mixture only).
+        nsamples, llh_weight, kl_weight: `VAE.expected_log_likelihood`
+            arguments (VAE only; the batch is one minibatch, its value keeps
+            the autograd graph of the networks).
     '''
     X, lengths = pack_utterances(utterances)
     if any(T <= 0 for T in lengths):
@@ -257,6 +282,9 @@ def accumulate_elbo(model, utterances, datasize=-1, inference_graphs=None, scale
     elif isinstance(model, HMM):
         value_terms, acc = _hmm_batch(model, X, lengths, datasize, inference_graphs, scale,
                                       viterbi, state_paths, max_frames)
+    elif isinstance(model, VAE):
+        value_terms, acc = _vae_batch(model, X, lengths, datasize, nsamples, llh_weight,
+                                      kl_weight)
     else:
         raise NotImplementedError(f'no batched E-step for {type(model).__name__}')
     model.clear_cache()

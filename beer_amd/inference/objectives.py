@@ -43,7 +43,8 @@ class EvidenceLowerBoundInstance:
         return f'EvidenceLowerBoundInstance(value={self.value})'
 
     def __float__(self):
-        return float(self.value)
+        value = self.value
+        return float(value.detach() if isinstance(value, torch.Tensor) else value)
 
     def __add__(self, other):
         if not isinstance(other, EvidenceLowerBoundInstance):
@@ -100,7 +101,12 @@ def evidence_lower_bound(model=None, minibatch_data=None, datasize=-1, **kwargs)
     stats = model.sufficient_statistics(minibatch_data)
     exp_llh = model.expected_log_likelihood(stats, **kwargs)
     kl_div = torch.as_tensor(model.kl_div_posterior_prior())
-    total = frame_sum(exp_llh)                                  # fp64 device scalar
+    if isinstance(exp_llh, torch.Tensor) and exp_llh.requires_grad:
+        # models with non-conjugate (torch.nn) parameters: VAE.  The sum stays
+        # in the autograd graph so that `elbo.backward()` reaches them.
+        total = _hip.on_device(exp_llh).to(torch.float64).sum()
+    else:
+        total = frame_sum(exp_llh)                              # fp64 device scalar
     elbo_value = float(scale) * total - kl_div.to(total.device, torch.float64)
     acc_stats = model.accumulate(stats)
     model.clear_cache()

@@ -9,15 +9,22 @@ import torch
 from . import _hip
 from .stats import FrameStats
 
-__all__ = ['normal_llh', 'mixtureset_estep', 'normal_accumulate', 'weights_from_acc']
+__all__ = ['normal_llh', 'mixtureset_estep', 'normal_accumulate', 'weights_from_acc',
+           'is_dense', 'dense_llh', 'dense_softmax', 'dense_accumulate', 'rowdot',
+           'attach_stats_grad', 'differentiable_stats']
+
+LOG_2PI = 1.8378770664093453
+
+
+def is_dense(stats):
+    'True for dense [T, Q] statistics (the VAE "stats-in" path).'
+    return isinstance(stats, torch.Tensor)
 
 
 def _frames(stats):
     if not isinstance(stats, FrameStats):
-        raise NotImplementedError(
-            'beer_amd E-step kernels take the lazy statistics returned by '
-            'model.sufficient_statistics(X); dense [T, Q] statistics (VAE '
-            '"stats-in" path) are a later row of the scope table')
+        raise TypeError('expected the lazy statistics returned by '
+                        'model.sufficient_statistics(X)')
     return stats
 
 
@@ -89,3 +96,159 @@ def weights_from_acc(acc, S, G):
     out = torch.zeros(S, G, dtype=torch.float64, device=acc.device)
     _hip.call('beer_weights_from_acc', S, G, acc.shape[1], _hip.ptr(acc), _hip.ptr(out))
     return out
+
+
+# ---- dense ("stats-in") statistics: the prior of a VAE ------------------------
+# beer/models/vae.py:63-89 hands the prior sample-averaged statistics [T, Q]
+# and differentiates its expected log-likelihood w.r.t. them.
+
+def _dense(stats, dtype=None):
+    return _hip.on_device(stats.detach(), dtype)
+
+
+def dense_llh(stats, exp_stats, dim):
+    'stats @ E[T]^T - dim/2 ln 2pi -> [T, K] (no autograd graph).'
+    st = _dense(stats)
+    E = _hip.on_device(exp_stats, st.dtype)
+    T, Q = st.shape
+    if E.shape[1] != Q:
+        raise ValueError(f'statistics of dimension {Q} for parameters of dimension {E.shape[1]}')
+    out = torch.empty(T, E.shape[0], dtype=st.dtype, device=st.device)
+    _hip.call('beer_dense_llh', _hip.dtype_code(st.dtype), T, Q, E.shape[0], _hip.ptr(st),
+              _hip.ptr(E), -.5 * dim * LOG_2PI, _hip.ptr(out))
+    return out
+
+
+def dense_softmax(pc_llh, log_weights, S, G, want_resps=True):
+    '(log_norm [T,S], resps [T,S*G]) of pc_llh [T,S*G] + log_weights [S,G].'
+    pc = _hip.on_device(pc_llh)
+    T = pc.shape[0]
+    lw = None if log_weights is None else _hip.on_device(log_weights, pc.dtype)
+    log_norm = torch.empty(T, S, dtype=pc.dtype, device=pc.device)
+    resps = torch.empty(T, S * G, dtype=pc.dtype, device=pc.device) if want_resps else None
+    _hip.call('beer_softmax_groups', _hip.dtype_code(pc.dtype), T, S, G, _hip.ptr(pc),
+              _hip.ptr(lw), _hip.ptr(log_norm), _hip.ptr(resps))
+    return log_norm, resps
+
+
+def rowdot(a, b):
+    'sum_k a[t,k] b[t,k] -> [T].'
+    a = _hip.on_device(a)
+    b = _hip.on_device(b, a.dtype)
+    out = torch.empty(a.shape[0], dtype=a.dtype, device=a.device)
+    _hip.call('beer_rowdot', _hip.dtype_code(a.dtype), a.shape[0], a.shape[1], _hip.ptr(a),
+              _hip.ptr(b), _hip.ptr(out))
+    return out
+
+
+def dense_accumulate(stats, comp_resps, state_resps, S, G, acc=None):
+    'acc[k,:] += sum_t comp_resps[t,k] state_resps[t,k//G] stats[t,:], fp64 [S*G, Q].'
+    st = _dense(stats)
+    T, Q = st.shape
+    K = S * G
+    if acc is None:
+        acc = torch.zeros(K, Q, dtype=torch.float64, device=st.device)
+    if comp_resps is None:
+        comp_resps, state_resps, G = state_resps, None, 1
+    if comp_resps is None:
+        comp_resps = torch.ones(T, K, dtype=st.dtype, device=st.device)
+    cr = _hip.on_device(comp_resps.detach(), st.dtype)
+    sr = None if state_resps is None else _hip.on_device(state_resps.detach(), st.dtype)
+    _hip.call('beer_dense_accumulate', _hip.dtype_code(st.dtype), T, K, Q, G, _hip.ptr(cr),
+              _hip.ptr(sr), _hip.ptr(st), _hip.ptr(acc))
+    return acc
+
+
+def _llh_backward(weights, grad, exp_stats):
+    w = _hip.on_device(weights)
+    E = _hip.on_device(exp_stats, w.dtype)
+    g = None if grad is None else _hip.on_device(grad, w.dtype)
+    out = torch.empty(w.shape[0], E.shape[1], dtype=w.dtype, device=w.device)
+    _hip.call('beer_dense_llh_backward', _hip.dtype_code(w.dtype), w.shape[0], w.shape[1],
+              E.shape[1], _hip.ptr(w), _hip.ptr(g), _hip.ptr(E), _hip.ptr(out))
+    return out
+
+
+class _StatsGrad(torch.autograd.Function):
+    """value[t] = sum_k weights[t,k] llh[t,k] (+ terms without gradient), with
+    d value[t] / d stats[t] = sum_k weights[t,k] E[T]_k: what the reference's
+    autograd derives for `(pc_llhs * resps).sum(-1)` with detached resps
+    (mixture.py:79,92; hmm.py:81-87)."""
+
+    @staticmethod
+    def forward(ctx, stats, value, weights, exp_stats):
+        ctx.save_for_backward(weights, exp_stats)
+        ctx.home = (stats.device, stats.dtype)
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, grad):
+        weights, exp_stats = ctx.saved_tensors
+        out = _llh_backward(weights, grad.contiguous(), exp_stats)
+        return out.to(device=ctx.home[0], dtype=ctx.home[1]), None, None, None
+
+
+def attach_stats_grad(stats, value, weights, exp_stats):
+    'Give `value` [T] its gradient w.r.t. dense `stats` (no-op without grad).'
+    if not (torch.is_grad_enabled() and stats.requires_grad):
+        return value
+    return _StatsGrad.apply(stats, value, weights.detach(), exp_stats.detach())
+
+
+class _DenseLlh(torch.autograd.Function):
+    'Differentiable stats @ E[T]^T + base -> [T, K].'
+
+    @staticmethod
+    def forward(ctx, stats, exp_stats, dim):
+        ctx.save_for_backward(exp_stats)
+        ctx.home = (stats.device, stats.dtype)
+        return dense_llh(stats, exp_stats, dim)
+
+    @staticmethod
+    def backward(ctx, grad):
+        exp_stats, = ctx.saved_tensors
+        out = _llh_backward(grad.contiguous(), None, exp_stats)
+        return out.to(device=ctx.home[0], dtype=ctx.home[1]), None, None
+
+
+def dense_llh_autograd(stats, exp_stats, dim):
+    if torch.is_grad_enabled() and stats.requires_grad:
+        return _DenseLlh.apply(stats, exp_stats.detach(), dim)
+    return dense_llh(stats, exp_stats, dim)
+
+
+class _SuffStats(torch.autograd.Function):
+    '''Mean over `ns` consecutive rows of phi(X) as a dense [T, Q] tensor,
+    differentiable w.r.t. the frames [T * ns, D].'''
+
+    @staticmethod
+    def forward(ctx, data, cov_type, ns):
+        X = _hip.on_device(data.detach())
+        ctx.save_for_backward(X)
+        ctx.cov_type, ctx.ns = cov_type, ns
+        ctx.home = (data.device, data.dtype)
+        T, D = X.shape[0] // ns, X.shape[1]
+        Q = FrameStats(X[:1], cov_type).shape[1]
+        out = torch.empty(T, Q, dtype=X.dtype, device=X.device)
+        _hip.call('beer_suffstats_mean', _hip.dtype_code(X.dtype), _hip.COV_CODE[cov_type],
+                  T, ns, D, _hip.ptr(X), _hip.ptr(out))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        X, = ctx.saved_tensors
+        g = _hip.on_device(grad, X.dtype)
+        out = torch.empty_like(X)
+        _hip.call('beer_suffstats_backward', _hip.dtype_code(X.dtype),
+                  _hip.COV_CODE[ctx.cov_type], X.shape[0] // ctx.ns, ctx.ns, X.shape[1],
+                  _hip.ptr(X), _hip.ptr(g), _hip.ptr(out))
+        return out.to(device=ctx.home[0], dtype=ctx.home[1]), None, None
+
+
+def differentiable_stats(data, cov_type, nsamples=1):
+    '''Dense statistics carrying the autograd graph of `data` [T * nsamples,
+    D]: phi(X) for nsamples = 1, else the mean of phi over each run of
+    `nsamples` rows -> [T, Q] (vae.py:73-74 without the [T*ns, Q] tensor).'''
+    if data.dim() != 2 or data.shape[0] % nsamples:
+        raise ValueError('expected [n_frames * nsamples, dim] samples')
+    return _SuffStats.apply(data, cov_type, int(nsamples))

@@ -5,3 +5,4 @@ from .weights import *
 from .gaussians import *
 from .mixtures import *
 from .sequence import *
+from .vae import *

@@ -114,7 +114,10 @@ class Normal(Model):
 
     def accumulate(self, stats, parent_msg=None):
         fn = self.mean_precision.likelihood_fn
-        acc = kernels.normal_accumulate(stats, None, None, 1, 1, fn.cov_type)
+        if kernels.is_dense(stats):
+            acc = kernels.dense_accumulate(stats, None, None, 1, 1)
+        else:
+            acc = kernels.normal_accumulate(stats, None, None, 1, 1, fn.cov_type)
         ref = self.mean_precision.stats
         return {self.mean_precision: acc.view(-1).to(dtype=ref.dtype, device=ref.device)}
 
@@ -157,7 +160,10 @@ class NormalSet(ModelSet):
     def accumulate(self, stats, resps):
         'resps^T @ phi(X) -> [K, Q], accumulated in fp64 on the GPU.'
         K = len(self)
-        acc = kernels.normal_accumulate(stats, resps, None, K, 1, self.cov_type)
+        if kernels.is_dense(stats):
+            acc = kernels.dense_accumulate(stats, resps, None, K, 1)
+        else:
+            acc = kernels.normal_accumulate(stats, resps, None, K, 1, self.cov_type)
         ref = self.means_precisions.stats
         return {self.means_precisions: acc.to(dtype=ref.dtype, device=ref.device)}
 

@@ -73,16 +73,40 @@ class Mixture(DiscreteLatentModel):
             raise NotImplementedError('Mixture components must be a NormalSet')
         ns = self.modelset
         K = len(ns)
+        if kernels.is_dense(stats):
+            return self._dense_expected_log_likelihood(stats, labels)
         log_norm, resps = kernels.mixtureset_estep(
             stats, ns.means_precisions.natural_form(), self._log_weights().view(1, K),
             1, K, ns.cov_type, labels=labels)
         self.cache['resps'] = resps
         return log_norm.view(-1)
 
+    def _dense_expected_log_likelihood(self, stats, labels):
+        '''Statistics-in variant (prior of a VAE): same value, and the gradient
+        w.r.t. the statistics flows through sum_k r_k l_k only (mixture.py:92).'''
+        ns = self.modelset
+        K = len(ns)
+        fn = ns.means_precisions.likelihood_fn
+        nparams = ns.means_precisions.natural_form()
+        pc = kernels.dense_llh(stats, nparams, fn.dim)
+        if labels is None:
+            log_norm, resps = kernels.dense_softmax(pc, self._log_weights().view(1, K), 1, K)
+            value = log_norm.view(-1)
+        else:
+            lab = torch.as_tensor(labels).to(device=pc.device, dtype=torch.int64).view(-1, 1)
+            resps = torch.zeros_like(pc).scatter_(1, lab, 1.)
+            value = kernels.rowdot(pc, resps)
+        self.cache['resps'] = resps
+        return kernels.attach_stats_grad(stats, value, resps, nparams)
+
     def accumulate(self, stats):
         ns = self.modelset
         K = len(ns)
-        acc = kernels.normal_accumulate(stats, self.cache['resps'], None, K, 1, ns.cov_type)
+        if kernels.is_dense(stats):
+            acc = kernels.dense_accumulate(stats, self.cache['resps'], None, K, 1)
+        else:
+            acc = kernels.normal_accumulate(stats, self.cache['resps'], None, K, 1,
+                                            ns.cov_type)
         wparam = self.categorical.mean_field_factorization()[0][0]
         if isinstance(self.categorical, SBCategorical):
             # stick-breaking weights take the raw counts N_k (categorical.py:149-151)
@@ -136,8 +160,16 @@ class MixtureSet(ModelSet):
             raise NotImplementedError('MixtureSet components must be a NormalSet')
         ns = self.modelset
         S, G = len(self), self.n_comp_per_mixture
-        log_norm, resps = kernels.mixtureset_estep(
-            stats, ns.means_precisions.natural_form(), self._log_weights(), S, G, ns.cov_type)
+        if kernels.is_dense(stats):
+            # statistics-in: no gradient, the log-normaliser is detached
+            # (mixtureset.py:93)
+            fn = ns.means_precisions.likelihood_fn
+            pc = kernels.dense_llh(stats, ns.means_precisions.natural_form(), fn.dim)
+            log_norm, resps = kernels.dense_softmax(pc, self._log_weights(), S, G)
+        else:
+            log_norm, resps = kernels.mixtureset_estep(
+                stats, ns.means_precisions.natural_form(), self._log_weights(), S, G,
+                ns.cov_type)
         self.cache['resps'] = resps.view(-1, S, G)
         return log_norm
 
@@ -146,7 +178,10 @@ class MixtureSet(ModelSet):
         ns = self.modelset
         S, G = len(self), self.n_comp_per_mixture
         comp = self.cache['resps'].reshape(-1, S * G)
-        acc = kernels.normal_accumulate(stats, comp, resps, S, G, ns.cov_type)
+        if kernels.is_dense(stats):
+            acc = kernels.dense_accumulate(stats, comp, resps, S, G)
+        else:
+            acc = kernels.normal_accumulate(stats, comp, resps, S, G, ns.cov_type)
         wacc = kernels.weights_from_acc(acc, S, G)
         wparam = self.categoricalset.weights
         return {wparam: _like(wparam, wacc),

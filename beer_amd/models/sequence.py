@@ -7,8 +7,9 @@ batched accumulator (beer_amd/inference/batch.py) with a batch of one.
 
 import torch
 
-from .. import _hip, hmm_kernels as hk
+from .. import _hip, hmm_kernels as hk, kernels
 from .basemodel import DiscreteLatentModel
+from .gaussians import NormalSet
 from .modelset import DynamicallyOrderedModelSet
 from .weights import Categorical, SBCategorical
 
@@ -61,16 +62,26 @@ class HMM(DiscreteLatentModel):
         return self.modelset.sufficient_statistics(data)
 
     def expected_log_likelihood(self, stats, inference_graph=None, viterbi=False,
-                                state_path=None, scale=1.):
+                                state_path=None, scale=1., utt_lengths=None):
         '''sum_s gamma_ts * scale * l_ts per frame (hmm.py:73-92).  Without an
         inference graph the model's own graph is used and the transition
-        posteriors are kept (PhoneLoop needs them).'''
+        posteriors are kept (PhoneLoop needs them).  `utt_lengths` (not in
+        the reference) treats the frames as that many consecutive utterances,
+        each decoded with the same graph, in one ragged batch.'''
         trans_posts = inference_graph is None
         graph = self.graph if inference_graph is None else inference_graph
-        pc_all = self._emissions().expected_log_likelihood(stats)      # [T, S_total]
+        dense = kernels.is_dense(stats)
+        emissions = self._emissions()
+        pc_all = emissions.expected_log_likelihood(stats.detach() if dense else stats)
         self.modelset.cache['order'] = graph.pdf_id_mapping
         T, S_total = pc_all.shape
-        batch = self._batch_of_one(graph, T, pc_all.dtype)
+        if utt_lengths is None:
+            batch = self._batch_of_one(graph, T, pc_all.dtype)
+        else:
+            lengths = [int(n) for n in utt_lengths]
+            if sum(lengths) != T:
+                raise ValueError('utt_lengths do not add up to the number of frames')
+            batch = hk.HmmBatch([graph], [0] * len(lengths), lengths, pc_all.dtype)
         pc_llhs = hk.gather(batch, pc_all, scale)
         flow = None
         if viterbi or state_path is not None:
@@ -87,6 +98,11 @@ class HMM(DiscreteLatentModel):
             self.cache['hub_flow'] = flow
         self.cache['scaled_pdf_resps'] = state_resps
         self.cache['scale'] = scale
+        if dense and isinstance(emissions, NormalSet):
+            # statistics-in (prior of a VAE): d exp_llh / d stats through
+            # sum_s gamma_ts * scale * l_ts with detached posteriors (hmm.py:81-87)
+            exp_llh = kernels.attach_stats_grad(
+                stats, exp_llh, state_resps, emissions.means_precisions.natural_form())
         return exp_llh
 
     def accumulate(self, stats, parent_msg=None):

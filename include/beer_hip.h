@@ -348,6 +348,60 @@ int beer_hmm_scatter(int dtype, const beer_batch* batch_h, int S_total,
 int beer_segment_sum(int dtype, int32_t nutt, const int64_t* frame_off,
                      const void* v, double* out, void* stream);
 
+/* ---- "statistics-in" E-step (VAE models, beer/models/vae.py:63-89) ---------
+ * The prior of a VAE receives dense sufficient statistics [T, Q] (averages of
+ * phi(z) over the samples of the latent variable) instead of frames, and its
+ * expected log-likelihood is differentiated w.r.t. them. */
+
+/* out[t,k] = sum_q stats[t,q] * exp_stats[k,q] + base   -> [T, K]
+ * (ConjugateLikelihood.__call__, beer/dists/normalgamma.py:55-59; base is the
+ * log base measure -D/2 ln 2pi). */
+int beer_dense_llh(int dtype, int64_t T, int Q, int K, const void* stats,
+                   const void* exp_stats, double base, void* out, void* stream);
+
+/* Gradient of sum_t grad[t] * sum_k weights[t,k] * llh[t,k] w.r.t. stats:
+ * out[t,q] = grad[t] * sum_k weights[t,k] * exp_stats[k,q]   -> [T, Q].
+ * This is what autograd gives the reference for `(pc_llh * resps).sum(-1)`
+ * with detached responsibilities (mixture.py:79,92; hmm.py:81-87).
+ * `grad` nullable (= 1). */
+int beer_dense_llh_backward(int dtype, int64_t T, int K, int Q,
+                            const void* weights, const void* grad,
+                            const void* exp_stats, void* out, void* stream);
+
+/* acc[k,q] += sum_t weights[t,k] * state_resps[t, k / G] * stats[t,q], fp64
+ * [K, Q] (NormalSet.accumulate, normalset.py:121-123, with the joint
+ * responsibilities of MixtureSet.accumulate, mixtureset.py:103-106).
+ * `state_resps` nullable [T, K / G]. */
+int beer_dense_accumulate(int dtype, int64_t T, int K, int Q, int G,
+                          const void* weights, const void* state_resps,
+                          const void* stats, double* acc, void* stream);
+
+/* out[t] = sum_k a[t,k] * b[t,k]  (exp_llh = (pc_llhs * resps).sum(-1)). */
+int beer_rowdot(int dtype, int64_t T, int K, const void* a, const void* b,
+                void* out, void* stream);
+
+/* Per (frame, mixture) softmax over G components of pc_llh[T, S*G] +
+ * log_weights[S, G] (nullable): log_norm [T, S] and resps [T, S*G], both
+ * nullable (mixture.py:78-82, mixtureset.py:92-95). */
+int beer_softmax_groups(int dtype, int64_t T, int S, int G, const void* pc_llh,
+                        const void* log_weights, void* log_norm, void* resps,
+                        void* stream);
+
+/* out[t,:] = (1/ns) sum_s phi(X[t*ns + s]) -> [T, Q]: the sample-averaged
+ * statistics a VAE hands to its prior (vae.py:73-74: sufficient_statistics of
+ * the [T*ns, D] samples, reshape, mean over the samples) without the
+ * [T*ns, Q] intermediate.  ns = 1 is beer_suffstats_expand. */
+int beer_suffstats_mean(int dtype, int cov, int64_t T, int ns, int D,
+                        const void* X, void* out, void* stream);
+
+/* Backward of beer_suffstats_mean: grad_X[t*ns + s, :] =
+ * (1/ns) J_phi(x_ts)^T grad_stats[t, :] -> [T*ns, D]
+ * (normalwishart.py:30-38 / normalgamma.py:22-31 / isotropicnormalgamma.py
+ * sufficient_statistics differentiated by autograd in the reference). */
+int beer_suffstats_backward(int dtype, int cov, int64_t T, int ns, int D,
+                            const void* X, const void* grad_stats,
+                            void* grad_X, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -542,19 +542,6 @@ def g_graph():
     save('g12_graph_compile', out)
 
 
-if __name__ == '__main__':
-    g1_g3_g11()
-    g4(torch.float64, '')
-    g4(torch.float32, '_f32')
-    g5()
-    g6_g8()
-    g7()
-    g9()
-    g10()
-    g_graph()
-    g_pickles()
-
-
 def g_pickles():
     '''Pickles written by the REFERENCE classes (binary data: tensors + class
     names, no source): a small phone loop, its unit HMMs and an alignment
@@ -605,3 +592,86 @@ def g_pickles():
     optim.step()
     dump_params(out, 'updated', ploop)
     save('g13_cli_reference_run', out)
+
+
+def g14_vae():
+    """Statistics-in path of the VAE models (vae.py:63-89): the prior gets
+    dense sample-averaged statistics and is differentiated w.r.t. them."""
+    rng = np.random.RandomState(14)
+    T, ns_, Dz = 60, 3, 3
+    z0 = torch.from_numpy(rng.randn(T, ns_, Dz) * 1.5)
+    cvec = torch.from_numpy(rng.rand(T) + .5)
+
+    def prior_case(name, prior, **kwargs):
+        prior = prior.double()
+        z = z0.clone().requires_grad_(True)
+        flat = prior.sufficient_statistics(z.view(-1, Dz))
+        stats = flat.reshape(T, ns_, -1).mean(dim=1)
+        stats.retain_grad()
+        exp_llh = prior.expected_log_likelihood(stats, **kwargs)
+        (cvec * exp_llh).sum().backward()
+        out = {'z': npy(z0), 'c': npy(cvec), 'stats': npy(stats), 'exp_llh': npy(exp_llh),
+               'grad_stats': npy(stats.grad), 'grad_z': npy(z.grad)}
+        dump_params(out, 'init', prior)
+        dump_acc(out, 'acc', prior, prior.accumulate(stats.detach()))
+        if hasattr(prior, 'graph'):
+            dump_graph(out, 'graph', prior.graph)
+        save(name, out)
+
+    for cov in ('full', 'diagonal', 'isotropic'):
+        torch.manual_seed(140)
+        nset = beer.NormalSet.create(torch.zeros(Dz), torch.ones(Dz) * 2., size=4,
+                                     prior_strength=1., noise_std=1., cov_type=cov)
+        prior_case(f'g14_statsin_gmm_{cov}', beer.Mixture.create(nset))
+        torch.manual_seed(141)
+        nset = beer.NormalSet.create(torch.zeros(Dz), torch.ones(Dz) * 2., size=3,
+                                     prior_strength=1., noise_std=1., cov_type=cov)
+        prior_case(f'g14_statsin_hmm_{cov}', beer.HMM.create(notebook_graph(), nset))
+    torch.manual_seed(142)
+    prior_case('g14_statsin_normal_full',
+               beer.Normal.create(torch.zeros(Dz), torch.ones(Dz), cov_type='full'))
+
+    # a whole VAE step with recorded noise
+    Dx, Dz2, T2, nsamp = 4, 2, 40, 5
+    torch.manual_seed(143)
+    X = torch.from_numpy(rng.randn(T2, Dx)).double()
+    enc = beer.nnet.ResidualFeedForwardNet(dim_in=Dx, nblocks=2, block_width=8)
+    dec = beer.nnet.ResidualFeedForwardNet(dim_in=Dz2, nblocks=2, block_width=8)
+    nset = beer.NormalSet.create(torch.zeros(Dz2), torch.ones(Dz2), size=3, cov_type='full')
+    vae = beer.VAE(beer.Mixture.create(nset), enc, dec).double()
+    noise = []
+    real_randn = torch.randn
+
+    def recording_randn(*a, **k):
+        t = real_randn(*a, **k)
+        noise.append(t)
+        return t
+    torch.randn = recording_randn
+    try:
+        elbo = beer.evidence_lower_bound(vae, X, nsamples=nsamp, datasize=10 * T2)
+    finally:
+        torch.randn = real_randn
+    assert len(noise) == 1
+    elbo.backward()
+    out = {'X': npy(X), 'noise': npy(noise[0]), 'nsamples': np.array(nsamp),
+           'datasize': np.array(10 * T2), 'elbo': np.asarray(float(elbo))}
+    for name, p in vae.named_parameters():
+        out['nn.' + name] = npy(p)
+        out['nngrad.' + name] = npy(p.grad)
+    dump_params(out, 'init', vae)
+    dump_acc(out, 'acc', vae, elbo._acc_stats)
+    save('g14_vae_gmm_step', out)
+
+
+if __name__ == '__main__':
+    g1_g3_g11()
+    g4(torch.float64, '')
+    g4(torch.float32, '_f32')
+    g5()
+    g6_g8()
+    g7()
+    g9()
+    g10()
+    g_graph()
+    g_pickles()
+    g14_vae()

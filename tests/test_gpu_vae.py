@@ -1,0 +1,191 @@
+"""GPU parity of the "statistics-in" path (VAE models, SURVEY.md section 8
+row f.2): dense [T, Q] statistics into the prior, gradient back to the
+statistics / frames, accumulation from dense statistics.  Goldens G14 were
+produced by the reference (tests/golden/make_golden.py:g14_vae)."""
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9          # fp64 kernels against the fp64 reference
+
+
+def _prior(g, kind):
+    import beer_amd as beer
+    from gpu_helpers import build_hmm, build_mixture, build_param
+    if kind == 'gmm':
+        return build_mixture(g)
+    if kind == 'hmm':
+        return build_hmm(g)
+    return beer.Normal(build_param(g, 'init.p0'))
+
+
+@pytest.mark.parametrize('name,kind', [
+    ('g14_statsin_gmm_full', 'gmm'), ('g14_statsin_gmm_diagonal', 'gmm'),
+    ('g14_statsin_gmm_isotropic', 'gmm'), ('g14_statsin_hmm_full', 'hmm'),
+    ('g14_statsin_hmm_diagonal', 'hmm'), ('g14_statsin_hmm_isotropic', 'hmm'),
+    ('g14_statsin_normal_full', 'normal')])
+def test_statsin_prior(name, kind):
+    from gpu_helpers import npy, params_of, tt
+    g = load_golden(name)
+    prior = _prior(g, kind)
+    z = tt(g['z']).requires_grad_(True)
+    T, ns, Dz = z.shape
+    c = tt(g['c'])
+    flat = prior.sufficient_statistics(z.view(-1, Dz))
+    assert isinstance(flat, torch.Tensor) and flat.requires_grad
+    stats = flat.reshape(T, ns, -1).mean(dim=1)
+    stats.retain_grad()
+    assert_close(npy(stats), g['stats'], 1e-12, 'stats')
+    exp_llh = prior.expected_log_likelihood(stats)
+    assert_close(npy(exp_llh).reshape(g['exp_llh'].shape), g['exp_llh'], TOL, 'exp_llh')
+    # same expression as the generator (for Normal the [T,1] value broadcasts)
+    (c * exp_llh.reshape(g['exp_llh'].shape)).sum().backward()
+    assert_close(npy(stats.grad), g['grad_stats'], TOL, 'd/dstats')
+    assert_close(npy(z.grad), g['grad_z'], TOL, 'd/dz')
+    acc = prior.accumulate(stats.detach())
+    for i, p in enumerate(params_of(prior)):
+        assert_close(npy(acc[p]).reshape(g[f'acc.p{i}'].shape), g[f'acc.p{i}'], TOL, f'acc p{i}')
+
+
+def test_statsin_matches_frames_path():
+    'Dense statistics of plain frames give the same E-step as the fused path.'
+    import beer_amd as beer
+    from gpu_helpers import npy
+    torch.manual_seed(0)
+    X = torch.randn(3000, 7, dtype=torch.float64, device='cuda')
+    for cov in ('full', 'diagonal', 'isotropic'):
+        ns = beer.NormalSet.create(torch.zeros(7, dtype=torch.float64),
+                                   torch.ones(7, dtype=torch.float64), size=12, cov_type=cov)
+        for model in (beer.Mixture.create(ns), beer.MixtureSet.create(3, ns)):
+            lazy = model.sufficient_statistics(X)
+            a = model.expected_log_likelihood(lazy)
+            if isinstance(model, beer.MixtureSet):
+                sr = torch.rand(len(X), 3, dtype=torch.float64, device='cuda')
+                acc_a = model.accumulate(lazy, sr)
+            else:
+                acc_a = model.accumulate(lazy)
+            model.clear_cache()
+            dense = lazy.dense()
+            b = model.expected_log_likelihood(dense)
+            acc_b = model.accumulate(dense, sr) if isinstance(model, beer.MixtureSet) \
+                else model.accumulate(dense)
+            model.clear_cache()
+            assert_close(npy(b), npy(a), 1e-10, f'{cov} llh')
+            for p in acc_a:
+                assert_close(npy(acc_b[p]), npy(acc_a[p]), 1e-9, f'{cov} acc')
+
+
+def test_vae_step_against_reference(monkeypatch):
+    'One ELBO + backward of a GMM-VAE with the reference\'s weights and noise.'
+    import beer_amd as beer
+    from beer_amd.dists import normaldiag
+    from gpu_helpers import build_mixture, npy, params_of, tt
+    g = load_golden('g14_vae_gmm_step')
+    X = tt(g['X'])
+    Dx, Dz = X.shape[1], g['noise'].shape[-1]
+    enc = beer.nnet.ResidualFeedForwardNet(dim_in=Dx, nblocks=2, block_width=8)
+    dec = beer.nnet.ResidualFeedForwardNet(dim_in=Dz, nblocks=2, block_width=8)
+    vae = beer.VAE(build_mixture(g), enc, dec, reference_broadcast=True).double().to('cuda')
+    with torch.no_grad():
+        for name, p in vae.named_parameters():
+            p.copy_(tt(g['nn.' + name]))
+    monkeypatch.setattr(normaldiag, '_randn', lambda *a, **k: tt(g['noise']))
+    elbo = beer.evidence_lower_bound(vae, X, nsamples=int(g['nsamples']),
+                                     datasize=int(g['datasize']))
+    assert abs(float(elbo) - float(g['elbo'])) <= 1e-9 * abs(float(g['elbo']))
+    elbo.backward()
+    for name, p in vae.named_parameters():
+        assert_close(npy(p.grad), g['nngrad.' + name], 1e-7, 'grad ' + name)
+    for i, p in enumerate(params_of(vae)):
+        assert_close(npy(elbo._acc_stats[p]).reshape(g[f'acc.p{i}'].shape), g[f'acc.p{i}'],
+                     1e-9, f'acc p{i}')
+
+
+def test_vae_trains():
+    'HMM-VAE (config 4 shape, reduced): the ELBO improves over a few epochs.'
+    import beer_amd as beer
+    torch.manual_seed(1)
+    T, Dx, Dz = 400, 6, 3
+    X = torch.randn(T, Dx, device='cuda') * 2. + 1.
+    graph = beer.graph.Graph()
+    s0, s4 = graph.add_state(), graph.add_state()
+    graph.start_state, graph.end_state = s0, s4
+    states = [graph.add_state(pdf_id=i) for i in range(3)]
+    graph.add_arc(s0, states[0])
+    for i, s in enumerate(states):
+        graph.add_arc(s, s)
+        graph.add_arc(s, states[(i + 1) % 3])
+    graph.add_arc(states[2], s4)
+    graph.normalize()
+    ns = beer.NormalSet.create(torch.zeros(Dz), torch.ones(Dz), size=3, cov_type='full')
+    vae = beer.VAE(beer.HMM.create(graph.compile(), ns),
+                   beer.nnet.ResidualFeedForwardNet(Dx, 2, 16),
+                   beer.nnet.ResidualFeedForwardNet(Dz, 2, 16)).to('cuda')
+    cjg = beer.VBConjugateOptimizer(vae.mean_field_factorization(), lrate=.1)
+    std = torch.optim.Adam(vae.parameters(), lr=1e-2)
+    optim = beer.VBOptimizer(cjg, std)
+    values = []
+    for _ in range(30):
+        optim.init_step()
+        elbo = beer.evidence_lower_bound(vae, X, nsamples=5)
+        elbo.backward()
+        optim.step()
+        values.append(float(elbo))
+    assert np.isfinite(values).all()
+    assert np.mean(values[-5:]) > np.mean(values[:5])
+
+
+def test_vae_batch_equals_per_utterance_loop(monkeypatch):
+    '''accumulate_elbo on a minibatch of utterances == the reference's loop of
+    per-utterance evidence_lower_bound calls (value, gradients, statistics).'''
+    import beer_amd as beer
+    from beer_amd.dists import normaldiag
+    from gpu_helpers import npy
+    torch.manual_seed(5)
+    Dx, Dz, nsamp = 5, 3, 2
+    lengths = [30, 17, 44]
+    X = torch.randn(sum(lengths), Dx, dtype=torch.float64, device='cuda')
+    master = torch.randn(sum(lengths), nsamp, Dz, dtype=torch.float64, device='cuda')
+    graph = beer.graph.Graph()
+    s0, s4 = graph.add_state(), graph.add_state()
+    graph.start_state, graph.end_state = s0, s4
+    st = [graph.add_state(pdf_id=i) for i in range(3)]
+    graph.add_arc(s0, st[0])
+    for i, s in enumerate(st):
+        graph.add_arc(s, s)
+        graph.add_arc(s, st[(i + 1) % 3])
+    graph.add_arc(st[2], s4)
+    graph.normalize()
+    ns = beer.NormalSet.create(torch.zeros(Dz, dtype=torch.float64),
+                               torch.ones(Dz, dtype=torch.float64), size=3,
+                               cov_type='diagonal')
+    vae = beer.VAE(beer.HMM.create(graph.compile(), ns),
+                   beer.nnet.ResidualFeedForwardNet(Dx, 1, 8),
+                   beer.nnet.ResidualFeedForwardNet(Dz, 1, 8)).double().to('cuda')
+    cursor = [0]
+
+    def fake_randn(n, *rest, **conf):
+        out = master[cursor[0]:cursor[0] + n]
+        cursor[0] += n
+        return out
+    monkeypatch.setattr(normaldiag, '_randn', fake_randn)
+    N = 1000
+    loop = beer.evidence_lower_bound(datasize=N)
+    for u in torch.split(X, lengths):
+        loop += beer.evidence_lower_bound(vae, u, datasize=N, nsamples=nsamp)
+    loop.backward()
+    grads = {n: p.grad.clone() for n, p in vae.named_parameters()}
+    vae.zero_grad()
+    cursor[0] = 0
+    batch = beer.accumulate_elbo(vae, (X, lengths), datasize=N, nsamples=nsamp)
+    assert abs(float(batch) - float(loop)) <= 1e-10 * abs(float(loop))
+    batch.backward()
+    for n, p in vae.named_parameters():
+        assert_close(npy(p.grad), npy(grads[n]), 1e-8, 'grad ' + n)
+    for p in vae.bayesian_parameters():
+        assert_close(npy(batch._acc_stats[p]), npy(loop._acc_stats[p]), 1e-9, 'acc')
