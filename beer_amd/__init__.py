@@ -4,6 +4,7 @@ beer's own model API (`import beer_amd as beer`).'''
 from .models import *
 from .inference import *
 from . import dists
+from . import features
 from . import graph
 from . import nnet
 from . import utils

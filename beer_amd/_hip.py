@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libbeer_hip.so')
 
-F32, F64 = 0, 1
+F32, F64, I16 = 0, 1, 2
 FULL, DIAG, ISO = 0, 1, 2
 SEG = 8                     # BEER_SEG of include/beer_hip.h
 MAX_HUBS = 4                # kMaxHubs of csrc/hmm.hip
@@ -80,6 +80,18 @@ class Batch(ctypes.Structure):
                 ('graphs', c_p), ('pdf_off', c_p), ('pdf_ids', c_p)]
 
 
+class FeaConf(ctypes.Structure):
+    'beer_feaconf of include/beer_hip.h.'
+    _fields_ = [('flen', ctypes.c_int32), ('fstep', ctypes.c_int32),
+                ('fft_len', ctypes.c_int32), ('mode', ctypes.c_int32),
+                ('nfilters', ctypes.c_int32), ('apply_log', ctypes.c_int32),
+                ('n_dct', ctypes.c_int32), ('add_energy', ctypes.c_int32),
+                ('preemph', ctypes.c_double), ('log_offset', ctypes.c_double),
+                ('norm', ctypes.c_double),
+                ('window', c_p), ('filters', c_p), ('filt_lo', c_p), ('filt_hi', c_p),
+                ('dct', c_p), ('lifter', c_p)]
+
+
 # name -> argument ctypes (return type is always int)
 _four = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]          # dtype,K,D,4 in,out,stream
 _from = [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]          # dtype,K,D,eta,4 out,stream
@@ -119,6 +131,12 @@ SIGNATURES = {
     'beer_dense_accumulate': [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     'beer_rowdot': [c_i, c_l, c_i, c_p, c_p, c_p, c_p],
     'beer_softmax_groups': [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
+    'beer_features_signal_mean': [c_i, ctypes.c_int32, c_p, c_p, c_p, c_p],
+    'beer_features_extract': [c_i, ctypes.c_int32, c_p, c_p, c_l, c_p, c_p, c_p, c_p,
+                              ctypes.c_int32, c_p],
+    'beer_features_deltas': [ctypes.c_int32, c_p, c_l, ctypes.c_int32, ctypes.c_int32,
+                             ctypes.c_int32, c_p, c_p, c_p],
+    'beer_features_cmn': [ctypes.c_int32, c_p, ctypes.c_int32, ctypes.c_int32, c_p, c_p],
     'beer_suffstats_mean': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p],
     'beer_suffstats_backward': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
 }

@@ -9,6 +9,7 @@ import random
 import numpy as np
 import torch
 
+from . import features as fea_cmds
 from . import hmm as hmm_cmds
 from .dataset import Dataset
 
@@ -34,6 +35,7 @@ class dataset_create:
 
 GROUPS = {
     'dataset': ('dataset management', {'create': dataset_create}),
+    'features': ('features related command', {c.__name__: c for c in fea_cmds.COMMANDS}),
     'hmm': ('Hidden Markov Model (HMM)',
             {c.__name__: c for c in hmm_cmds.COMMANDS}),
 }

@@ -38,6 +38,7 @@ extern "C" {
 
 #define BEER_F32 0
 #define BEER_F64 1
+#define BEER_I16 2   /* audio samples only (beer_features_*) */
 
 #define BEER_FULL 0
 #define BEER_DIAG 1
@@ -401,6 +402,65 @@ int beer_suffstats_mean(int dtype, int cov, int64_t T, int ns, int D,
 int beer_suffstats_backward(int dtype, int cov, int64_t T, int ns, int D,
                             const void* X, const void* grad_stats,
                             void* grad_X, void* stream);
+
+/* ---- feature front-end (beer/features.py, `beer features extract`) ----------
+ * Ragged batch of utterances: `signal` holds the samples of all utterances
+ * back to back, utterance u owns samples [sample_off[u], sample_off[u+1]) and
+ * output rows [frame_off[u], frame_off[u+1]), with
+ * frames_u = (samples_u - flen) / fstep + 1 (features.py:131,178).  Offsets
+ * are DEVICE arrays of nutt + 1 int64.  All arithmetic is float64 as in the
+ * reference (numpy), except the float32 pre-emphasis of `fbank()`. */
+
+typedef struct {
+    int32_t flen;        /* frame length in samples, int(srate * flen) */
+    int32_t fstep;       /* frame shift in samples, int(srate * frate) */
+    int32_t fft_len;     /* 2^(floor(log2(flen)) + 1), 64 .. 2048 */
+    int32_t mode;        /* 0: features.fbank() -- float32 pre-emphasis over the
+                            whole signal (features.py:182-184);
+                            1: features.short_term_mspec() -- DC removal and
+                            pre-emphasis inside each frame (features.py:124-139) */
+    int32_t nfilters;    /* rows of `filters`; 0 = keep the fft_len/2 magnitudes */
+    int32_t apply_log;   /* log(x + log_offset) after the filter bank */
+    int32_t n_dct;       /* columns of `dct`; 0 = no cosine transform */
+    int32_t add_energy;  /* prepend sum_f log-mel * norm (extract.py:148-151) */
+    double preemph;
+    double log_offset;   /* 1 in fbank() (features.py:204), 1e-6 in the CLI */
+    double norm;         /* sqrt(2 / nfilters) (extract.py:131) */
+    const double* window;   /* device [flen] */
+    const double* filters;  /* device [nfilters, fft_len/2] (create_fbank) */
+    const int32_t* filt_lo; /* device [nfilters] first non-zero bin, nullable */
+    const int32_t* filt_hi; /* device [nfilters] last non-zero bin, nullable */
+    const double* dct;      /* device [nfilters, n_dct] (extract.py:36-40) */
+    const double* lifter;   /* device [n_dct], nullable (extract.py:141-145) */
+} beer_feaconf;
+
+/* mean[u] = mean of the samples of utterance u (the DC offset removed by
+ * short_term_mspec, features.py:124).  in_dtype: BEER_I16 / BEER_F32 / BEER_F64. */
+int beer_features_signal_mean(int in_dtype, int32_t nutt, const int64_t* sample_off,
+                              const void* signal, double* mean, void* stream);
+
+/* Framing -> pre-emphasis -> window -> |FFT| -> filter bank -> log ->
+ * cosine transform * norm * lifter, with the optional energy column first.
+ * out [total_frames, out_ld] float64, the features occupy the first
+ * add_energy + (n_dct ? n_dct : nfilters ? nfilters : fft_len/2) columns of a
+ * row (room for the deltas after them).  `utt_mean` nullable (mode 1 only). */
+int beer_features_extract(int in_dtype, int32_t nutt, const int64_t* sample_off,
+                          const int64_t* frame_off, int64_t total_frames,
+                          const void* signal, const double* utt_mean,
+                          const beer_feaconf* conf, double* out, int32_t out_ld,
+                          void* stream);
+
+/* One order of derivatives (features.add_deltas, features.py:95-105):
+ * out[t,d] = sum_{j=-wlen..wlen} j / (2 sum j^2) * in[clamp(t+j), d], t clamped
+ * inside its utterance.  `in` / `out` point at the first of D columns of rows
+ * with stride ld (they may be column blocks of the same buffer). */
+int beer_features_deltas(int32_t nutt, const int64_t* frame_off, int64_t total_frames,
+                         int32_t D, int32_t ld, int32_t wlen, const double* in,
+                         double* out, void* stream);
+
+/* Per-utterance mean normalisation in place (extract.py:160-162). */
+int beer_features_cmn(int32_t nutt, const int64_t* frame_off, int32_t D, int32_t ld,
+                      double* x, void* stream);
 
 #ifdef __cplusplus
 }

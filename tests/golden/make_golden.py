@@ -663,6 +663,58 @@ def g14_vae():
     save('g14_vae_gmm_step', out)
 
 
+def g15_features():
+    """Feature front-end: outputs of beer/features.py functions and of the
+    `beer features extract` operation sequence (extract.py:107-161) on the
+    reference's test audio and on a longer synthetic signal."""
+    np.float = float            # removed from numpy >= 1.24; features.py:34 needs it
+    from beer import features as F
+    from beer.cli.subcommands.features import extract as X
+    audio = np.load('/root/reference/tests/audio.npy')
+    rng = np.random.RandomState(15)
+    t = np.arange(6000)
+    synth = (3000 * np.sin(2 * np.pi * 440 * t / 16000) + 800 * rng.randn(len(t)) + 150)
+    synth = synth.astype(np.int16)
+    out = {'synth': synth}
+
+    def pipeline(signal, conf):
+        c = dict(X.feaconf)
+        c.update(conf)
+        spec, fft_len = F.short_term_mspec(signal, flen=c['window_len'], frate=c['framerate'],
+                                           preemph=c['preemph'], srate=c['srate'])
+        if c['apply_fbank']:
+            fb = F.create_fbank(c['nfilters'], fft_len, lowfreq=c['cutoff_lfreq'],
+                                highfreq=c['cutoff_hfreq'])
+            spec = spec @ fb.T
+        lspec = np.log(1e-6 + spec)
+        norm = np.sqrt(2. / c['nfilters'])
+        if c['apply_dct']:
+            fea = lspec @ X.compute_dct_bases(c['nfilters'], c['n_dct_coeff'])
+            fea *= norm
+            lc = c['lifter_coeff']
+            fea *= 1 + (lc / 2) * np.sin(np.pi * (1 + np.arange(c['n_dct_coeff'])) / lc)
+        else:
+            fea = lspec
+        if c['add_energy']:
+            fea = np.c_[lspec.sum(axis=-1) * norm, fea]
+        if c['apply_deltas']:
+            fea = F.add_deltas(fea, tuple([c['delta_winlen']] * c['delta_order']))
+        if c['utt_mnorm']:
+            fea -= fea.mean(axis=0)[None, :]
+        return fea
+
+    for name, sig in (('audio', audio), ('synth', synth), ('synthf', synth / 32768.)):
+        out[f'{name}.fbank30'] = F.fbank(sig, nfilters=30, lowfreq=100)
+        out[f'{name}.fbank26'] = F.fbank(sig)
+        out[f'{name}.mspec'] = F.short_term_mspec(sig)[0]
+        out[f'{name}.mfcc'] = pipeline(sig, {})
+        out[f'{name}.fbank_cmn'] = pipeline(sig, {'apply_dct': False, 'utt_mnorm': True,
+                                                  'nfilters': 40, 'add_energy': False,
+                                                  'delta_order': 1, 'delta_winlen': 3})
+    out['filters30'] = F.create_fbank(30, 512, lowfreq=100, highfreq=8000)
+    save('g15_features', out)
+
+
 if __name__ == '__main__':
     g1_g3_g11()
     g4(torch.float64, '')
@@ -675,3 +727,4 @@ if __name__ == '__main__':
     g_graph()
     g_pickles()
     g14_vae()
+    g15_features()

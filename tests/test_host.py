@@ -42,6 +42,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_hip.Graph) == 16 + 15 * 8
     assert ctypes.sizeof(_hip.GraphLowDeg) == 8 + 14 * 8
     assert ctypes.sizeof(_hip.Batch) == 24 + 6 * 8
+    assert ctypes.sizeof(_hip.FeaConf) == 8 * 4 + 3 * 8 + 6 * 8
 
 
 @pytest.mark.skipif(HAS_GPU, reason='checks behaviour on a GPU-less host')
