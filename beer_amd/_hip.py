@@ -142,6 +142,20 @@ SIGNATURES = {
 }
 
 
+# host-side functions (graph compilation): host pointers, no stream
+c_pp = ctypes.POINTER(ctypes.c_void_p)
+HOST_SIGNATURES = {
+    'beer_graph_compile': [ctypes.c_int32, c_p, c_l, c_p, c_p, c_p, ctypes.c_int32,
+                           ctypes.c_int32, c_pp],
+    'beer_aligraphs_compile': [ctypes.c_int32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l,
+                               c_p, c_p, c_pp],
+    'beer_graphset_free': [c_p],
+    'beer_graphset_sizes': [c_p, c_p, c_p, c_p],
+    'beer_graphset_export': [c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'beer_graphset_image_bytes': [c_p, c_i, c_p],
+    'beer_graphset_image': [c_p, c_i, c_p, ctypes.c_uint64, c_p],
+}
+
 # size queries: return a byte count, take no stream
 SIZE_QUERIES = {
     'beer_estep_workspace_bytes': [c_i, c_i, c_i, c_i, c_i],
@@ -151,6 +165,10 @@ SIZE_QUERIES = {
 
 def _declare(l):
     for name, args in SIGNATURES.items():
+        fn = getattr(l, name)
+        fn.argtypes = args
+        fn.restype = c_i
+    for name, args in HOST_SIGNATURES.items():
         fn = getattr(l, name)
         fn.argtypes = args
         fn.restype = c_i
@@ -201,6 +219,13 @@ def call(name, *args):
     if rc != 0:
         what = 'invalid argument' if rc == EINVAL else f'hipError {-rc}'
         raise HipError(f'{name} failed: {what}')
+
+
+def call_host(name, *args):
+    'Call a host-side entry point (no stream, works without a GPU).'
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise HipError(f'{name} failed: invalid argument')
 
 
 _workspaces = {}

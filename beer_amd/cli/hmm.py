@@ -278,7 +278,7 @@ class mkaligraph:
     @staticmethod
     def main(args, logger):
         hmm_graphs, _ = _load(args.hmms)
-        nutts = 0
+        uttids, seqs = [], []
         for line in sys.stdin:
             tokens = line.strip().split()
             if not tokens:
@@ -287,12 +287,16 @@ class mkaligraph:
             if not phones:
                 logger.error(f'utterance {uttid} has no transcription')
                 continue
-            graph = create_graph_from_seq(phones, hmm_graphs)
+            uttids.append(uttid)
+            seqs.append(phones)
+        # every transcription in one native call (beer_aligraphs_compile); the
+        # files keep the reference's format: a pickled dense CompiledGraph
+        graphs = beer.graph.compile_alignments(seqs, hmm_graphs)
+        for uttid, graph in zip(uttids, graphs):
             arr = np.empty(1, dtype=object)
-            arr[0] = graph
+            arr[0] = graph.to_dense()
             np.save(os.path.join(args.outdir, uttid + '.npy'), arr)
-            nutts += 1
-        logger.info(f'created alignment graphs for {nutts} utterances')
+        logger.info(f'created alignment graphs for {len(uttids)} utterances')
 
 
 class phonelist:

@@ -9,11 +9,12 @@ CSR image of the transition matrix that `CompiledGraph` keeps on the device.
 import ctypes
 from collections import OrderedDict
 
+import numpy as np
 import torch
 
 from . import _hip
 
-__all__ = ['Graph', 'CompiledGraph']
+__all__ = ['Graph', 'CompiledGraph', 'GraphSet', 'SparseGraph', 'compile_alignments']
 
 
 class State:
@@ -126,41 +127,189 @@ class Graph:
     def find_previous_pdf_ids(self, start_state, init_weight=1.0):
         return self._walk(start_state, init_weight, incoming=True)
 
+    def _topology(self):
+        'Flat arrays of the graph for the native compiler.'
+        ids = list(self._states)
+        local = {sid: i for i, sid in enumerate(ids)}
+        pdf = np.asarray([-1 if self._states[s].pdf_id is None else int(self._states[s].pdf_id)
+                          for s in ids], dtype=np.int32)
+        arcs = list(self._arcs)
+        src = np.asarray([local[a.start] for a in arcs], dtype=np.int32)
+        dst = np.asarray([local[a.end] for a in arcs], dtype=np.int32)
+        w = np.asarray([a.weight for a in arcs], dtype=np.float64)
+        return pdf, src, dst, w, local[self.start_state], local[self.end_state]
+
     def compile(self):
         '''Remove the non-emitting states: initial / final / transition
         probabilities between emitting states (graph.py:185-240), rows
-        renormalised without changing the self-loop probability.'''
-        index, pdf_id_mapping = {}, []
-        for state_id, state in self._states.items():
-            if state.pdf_id is not None:
-                index[state_id] = len(pdf_id_mapping)
-                pdf_id_mapping.append(state.pdf_id)
-        n = len(pdf_id_mapping)
-        init_probs, final_probs = torch.zeros(n), torch.zeros(n)
-        trans_probs = torch.zeros(n, n)
-        for state_id, weight in self.find_next_pdf_ids(self.start_state, 1.0):
-            init_probs[index[state_id]] += weight
-        init_probs /= init_probs.sum()
-        for state_id, weight in self.find_previous_pdf_ids(self.end_state, 1.0):
-            final_probs[index[state_id]] += weight
-        final_probs /= final_probs.sum()
-        for arc in self.arcs():
-            if self._states[arc.start].pdf_id is None:
-                continue                           # handled by init_probs
-            src = index[arc.start]
-            if self._states[arc.end].pdf_id is None:
-                for state_id, weight in self.find_next_pdf_ids(arc.end, arc.weight):
-                    trans_probs[src, index[state_id]] += weight
-            else:
-                trans_probs[src, index[arc.end]] += arc.weight
-        for i in range(n):
-            diag = trans_probs[i, i].clone()
-            off_diag = trans_probs[i, :].sum() - diag
-            if diag > 0. and off_diag > 0:
-                trans_probs[i, :] /= off_diag / (1 - diag)
-                trans_probs[i, i] = diag
-        return CompiledGraph(init_probs.log(), final_probs.log(), trans_probs.log(),
-                             pdf_id_mapping)
+        renormalised without changing the self-loop probability.  Runs in the
+        native compiler (`beer_graph_compile`, O(states + arcs)).'''
+        pdf, src, dst, w, start, end = self._topology()
+        handle = ctypes.c_void_p()
+        _hip.call_host('beer_graph_compile', len(pdf), _np_ptr(pdf), len(src), _np_ptr(src),
+                       _np_ptr(dst), _np_ptr(w), start, end, ctypes.byref(handle))
+        return GraphSet(handle)[0].to_dense()
+
+
+def _np_ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a.size else None
+
+
+class GraphSet:
+    '''Compiled graphs held by the native library (`beer_graphset`): CSR
+    arcs with float32 probabilities, as the reference's tables before
+    `.log()`.  Indexing yields `SparseGraph` views; `device_image(dtype)` lays
+    ALL graphs out in one blob and copies it to the GPU once.'''
+
+    def __init__(self, handle):
+        self._handle = handle
+        n = ctypes.c_int64()
+        _hip.call_host('beer_graphset_sizes', handle, ctypes.byref(n), None, None)
+        self.n = n.value
+        self.state_off = np.zeros(self.n + 1, dtype=np.int64)
+        self.arc_off = np.zeros(self.n + 1, dtype=np.int64)
+        _hip.call_host('beer_graphset_sizes', handle, ctypes.byref(n), _np_ptr(self.state_off),
+                       _np_ptr(self.arc_off))
+        S, A = int(self.state_off[-1]), int(self.arc_off[-1])
+        self.init = np.zeros(S, dtype=np.float32)
+        self.final = np.zeros(S, dtype=np.float32)
+        self.pdf_ids = np.zeros(S, dtype=np.int32)
+        self.arc_src = np.zeros(A, dtype=np.int32)
+        self.arc_dst = np.zeros(A, dtype=np.int32)
+        self.arc_prob = np.zeros(A, dtype=np.float32)
+        _hip.call_host('beer_graphset_export', handle, _np_ptr(self.init), _np_ptr(self.final),
+                       _np_ptr(self.pdf_ids), _np_ptr(self.arc_src), _np_ptr(self.arc_dst),
+                       _np_ptr(self.arc_prob))
+        self._images = {}
+
+    def __del__(self):
+        handle, self._handle = getattr(self, '_handle', None), None
+        if handle:
+            try:
+                _hip.call_host('beer_graphset_free', handle)
+            except Exception:                               # interpreter shutdown
+                pass
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        return SparseGraph(self, i)
+
+    def __iter__(self):
+        return (SparseGraph(self, i) for i in range(self.n))
+
+    def device_image(self, dtype):
+        '(blob on the GPU, ctypes array of beer_graph descriptors), built once per dtype.'
+        memo = self._images.get(dtype)
+        if memo is None:
+            dev = _hip.require_device()
+            code = _hip.dtype_code(dtype)
+            nbytes = ctypes.c_size_t()
+            _hip.call_host('beer_graphset_image_bytes', self._handle, code, ctypes.byref(nbytes))
+            host = torch.empty(max(16, nbytes.value), dtype=torch.uint8)
+            blob = torch.empty(max(16, nbytes.value), dtype=torch.uint8, device=dev)
+            structs = (_hip.Graph * max(1, self.n))()
+            _hip.call_host('beer_graphset_image', self._handle, code,
+                           ctypes.c_void_p(host.data_ptr()), blob.data_ptr(), structs)
+            blob.copy_(host)
+            memo = self._images[dtype] = (blob, structs)
+        return memo
+
+
+class _ArenaDeviceGraph:
+    'Descriptor of one graph of a GraphSet image (what HmmBatch reads).'
+
+    def __init__(self, struct, keep):
+        self.struct, self._keep = struct, keep
+        self.n_states, self.n_arcs = struct.n_states, struct.n_arcs
+        self.n_in_seg, self.n_out_seg = struct.n_in_seg, struct.n_out_seg
+        self.lowdeg = True if struct.lowdeg else None
+
+
+class SparseGraph:
+    '''One compiled graph of a GraphSet.  Stands in for `CompiledGraph`
+    wherever an inference graph is expected (`inference_graph=`,
+    `accumulate_elbo(..., inference_graphs=)`); `to_dense()` gives the
+    reference's dense-matrix object (e.g. to pickle it).'''
+
+    def __init__(self, owner, i):
+        self._set, self._i = owner, i
+        s0, s1 = owner.state_off[i], owner.state_off[i + 1]
+        self.n_states = int(s1 - s0)
+        self.pdf_id_mapping = owner.pdf_ids[s0:s1]
+
+    def _arcs(self):
+        o = self._set
+        a0, a1 = o.arc_off[self._i], o.arc_off[self._i + 1]
+        return o.arc_src[a0:a1], o.arc_dst[a0:a1], o.arc_prob[a0:a1]
+
+    @property
+    def init_log_probs(self):
+        o = self._set
+        return torch.from_numpy(o.init[o.state_off[self._i]:o.state_off[self._i + 1]]).log()
+
+    @property
+    def final_log_probs(self):
+        o = self._set
+        return torch.from_numpy(o.final[o.state_off[self._i]:o.state_off[self._i + 1]]).log()
+
+    @property
+    def trans_log_probs(self):
+        src, dst, prob = self._arcs()
+        dense = torch.zeros(self.n_states, self.n_states)
+        dense[torch.from_numpy(src).long(), torch.from_numpy(dst).long()] = torch.from_numpy(prob)
+        return dense.log()
+
+    def to_dense(self):
+        return CompiledGraph(self.init_log_probs, self.final_log_probs, self.trans_log_probs,
+                             [int(i) for i in self.pdf_id_mapping])
+
+    def device_graph(self, dtype):
+        blob, structs = self._set.device_image(dtype)
+        return _ArenaDeviceGraph(structs[self._i], (self._set, blob))
+
+    def posteriors(self, llhs, trans_posteriors=False):
+        return CompiledGraph.posteriors(self, llhs, trans_posteriors)
+
+    def best_path(self, llhs):
+        return CompiledGraph.best_path(self, llhs)
+
+
+def compile_alignments(sequences, units):
+    '''Alignment graphs of many transcriptions in one native call
+    (`beer_aligraphs_compile`): `sequences` is a list of unit-name sequences,
+    `units` maps a unit name to its `Graph` (what `beer hmm mkphones` writes).
+    Returns a `GraphSet`; graph u equals
+    `create_graph_from_seq(sequences[u], units)` of the reference
+    (mkaligraph.py:18-39).'''
+    names = list(units)
+    uid = {name: i for i, name in enumerate(names)}
+    state_off, arc_off = [0], [0]
+    pdfs, starts, ends, srcs, dsts, ws = [], [], [], [], [], []
+    for name in names:
+        pdf, src, dst, w, start, end = units[name]._topology()
+        pdfs.append(pdf)
+        srcs.append(src)
+        dsts.append(dst)
+        ws.append(w)
+        starts.append(start)
+        ends.append(end)
+        state_off.append(state_off[-1] + len(pdf))
+        arc_off.append(arc_off[-1] + len(src))
+    i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)              # noqa: E731
+    cat = lambda parts, dt: np.ascontiguousarray(np.concatenate(parts), dtype=dt)  # noqa: E731
+    seq_off = np.zeros(len(sequences) + 1, dtype=np.int64)
+    seq_off[1:] = np.cumsum([len(s) for s in sequences])
+    flat = i32([uid[u] for seq in sequences for u in seq])
+    args = [i32(state_off), cat(pdfs, np.int32), i32(starts), i32(ends), i32(arc_off),
+            cat(srcs, np.int32), cat(dsts, np.int32), cat(ws, np.float64)]
+    handle = ctypes.c_void_p()
+    _hip.call_host('beer_aligraphs_compile', len(names), *[_np_ptr(a) for a in args],
+                   len(sequences), _np_ptr(seq_off), _np_ptr(flat), ctypes.byref(handle))
+    return GraphSet(handle)
 
 
 class DeviceGraph:

@@ -3,6 +3,7 @@ descriptors, pdf-id gather / scatter, forward-backward, Viterbi."""
 
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _hip
@@ -37,19 +38,17 @@ class HmmBatch:
         self.frame_off_h, self.llh_off_h = frame_off, llh_off
         self.n_states = n_states
         self.graph_ids = list(graph_ids)
-        pdf_off = [0]
-        pdf_ids = []
-        for g in graphs:
-            ids = list(g.pdf_id_mapping) if (with_pdf_ids and g.pdf_id_mapping is not None) \
-                else list(range(g.n_states))
-            pdf_ids += [int(i) for i in ids]
-            pdf_off.append(len(pdf_ids))
+        parts = [np.asarray(g.pdf_id_mapping, dtype=np.int32)
+                 if (with_pdf_ids and g.pdf_id_mapping is not None)
+                 else np.arange(g.n_states, dtype=np.int32) for g in graphs]
+        pdf_off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]) if parts else [0]
+        pdf_ids = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int32)
         arr = (_hip.Graph * len(graphs))(*[dg.struct for dg in self.dgraphs])
         self.bufs = dict(
             frame_off=frame_off.to(dev), llh_off=llh_off[:-1].contiguous().to(dev),
             graph_id=gid_t.to(torch.int32).to(dev),
             graphs=_hip.struct_to_device(arr, dev),
-            pdf_off=torch.as_tensor(pdf_off, dtype=torch.int32).to(dev),
+            pdf_off=torch.as_tensor(np.asarray(pdf_off), dtype=torch.int32).to(dev),
             pdf_ids=torch.as_tensor(pdf_ids, dtype=torch.int32).to(dev))
         b = self.bufs
         self.struct = _hip.Batch(

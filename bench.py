@@ -141,6 +141,29 @@ def cpu_baseline(frames_target=1 << 20, chunk=8192, budget_s=15.):
                       f'reference op sequence, {dt:.1f} s'}
 
 
+def cpu_baseline_features(signals, conf=None):
+    '''cpu_baseline leg of tools/bench_features.py: the numpy oracle of the
+    feature front-end on a bounded sample of utterances, one host core.
+    Returns (frames per second, list of feature matrices).'''
+    from oracle import features_oracle as fo
+    t0 = time.perf_counter()
+    feats = [fo.extract(sig, conf) for sig in signals]
+    dt = time.perf_counter() - t0
+    return sum(len(f) for f in feats) / dt, feats
+
+
+def cpu_baseline_graph_compile(sequences, units, graph_cls):
+    '''cpu_baseline leg of tools/bench_hmm.py: alignment graphs of a bounded
+    sample of transcriptions with the plain-Python restatement of the
+    reference's builder + Graph.compile (oracle/graph_oracle.py), one host
+    core.  Returns seconds per utterance.'''
+    from oracle import graph_oracle as go
+    t0 = time.perf_counter()
+    for seq in sequences:
+        go.compile_graph(go.alignment_graph(seq, units, graph_cls))
+    return (time.perf_counter() - t0) / max(1, len(sequences))
+
+
 def pmc_traffic(kernel_key):
     '''HBM bytes per launch of the dominant kernel from the committed PMC passes
     (profiles/r*_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate

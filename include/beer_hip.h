@@ -462,6 +462,61 @@ int beer_features_deltas(int32_t nutt, const int64_t* frame_off, int64_t total_f
 int beer_features_cmn(int32_t nutt, const int64_t* frame_off, int32_t D, int32_t ld,
                       double* x, void* stream);
 
+/* ---- graph compilation (HOST functions: host pointers, no stream) -----------
+ * Graph.compile (beer/graph.py:185-240) and create_graph_from_seq
+ * (beer/cli/subcommands/hmm/mkaligraph.py:18-39) in O(states + arcs), for one
+ * graph or for a whole corpus of transcriptions at once.  The result lives in
+ * an opaque host object; beer_graphset_image lays every graph out as the
+ * beer_graph CSR image above inside ONE blob, for a single host-to-device
+ * copy. */
+typedef struct beer_graphset beer_graphset;
+
+/* Compile one topology.  States 0..n_states-1 in insertion order, pdf_ids[s]
+ * < 0 for a non-emitting state; arcs in insertion order, weights are
+ * probabilities (already normalised by the caller, Graph.normalize). */
+int beer_graph_compile(int32_t n_states, const int32_t* pdf_ids, int64_t n_arcs,
+                       const int32_t* arc_src, const int32_t* arc_dst,
+                       const double* arc_w, int32_t start_state,
+                       int32_t end_state, beer_graphset** out);
+
+/* Alignment graphs of n_utts transcriptions: utterance u is the sequence of
+ * unit ids seq_units[seq_off[u] .. seq_off[u+1]), each unit a small HMM given
+ * by its states (unit_pdf_ids, < 0: non-emitting), start / end state and arcs
+ * (local state ids), all concatenated with *_off offsets.  Equals
+ * create_graph_from_seq(seq, units) for every utterance: chain of unit
+ * copies, Graph.normalize, Graph.compile. */
+int beer_aligraphs_compile(int32_t n_units, const int32_t* unit_state_off,
+                           const int32_t* unit_pdf_ids, const int32_t* unit_start,
+                           const int32_t* unit_end, const int32_t* unit_arc_off,
+                           const int32_t* unit_arc_src, const int32_t* unit_arc_dst,
+                           const double* unit_arc_w, int64_t n_utts,
+                           const int64_t* seq_off, const int32_t* seq_units,
+                           beer_graphset** out);
+
+int beer_graphset_free(beer_graphset* set);
+
+/* Number of graphs and (nullable) cumulative state / arc offsets [n+1]. */
+int beer_graphset_sizes(const beer_graphset* set, int64_t* n_graphs,
+                        int64_t* state_off, int64_t* arc_off);
+
+/* Concatenated contents (every pointer nullable): initial / final
+ * probabilities and pdf ids per state, arcs sorted by (source, destination)
+ * with local state ids and float32 probabilities, as the reference's tables
+ * before `.log()`. */
+int beer_graphset_export(const beer_graphset* set, float* init, float* fin,
+                         int32_t* pdf_ids, int32_t* arc_src, int32_t* arc_dst,
+                         float* arc_prob);
+
+/* Size of, and the blob holding, the device image of every graph in `dtype`
+ * (log-probabilities: float32 log of the float32 tables, as the reference).
+ * `graphs[i]` receives the beer_graph descriptor of graph i whose pointers
+ * are device_base + offset, i.e. valid once the blob has been copied to
+ * device_base.  Graphs whose states all have <= BEER_SEG arcs get the
+ * `lowdeg` image (no hubs). */
+int beer_graphset_image_bytes(const beer_graphset* set, int dtype, size_t* bytes);
+int beer_graphset_image(const beer_graphset* set, int dtype, void* host_blob,
+                        uint64_t device_base, beer_graph* graphs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -618,3 +618,38 @@ def test_hmm_batch_with_one_frame_utterances():
     assert_close(float(batched), float(loop), 1e-11)
     p0 = params_of(hmm)[0]
     assert_close(npy(batched._acc_stats[p0]), npy(loop._acc_stats[p0]), 1e-10)
+
+
+# --- native alignment-graph sets (row f.3) --------------------------------------------------------
+
+def test_sparse_alignment_graphs_equal_dense_graphs():
+    '''accumulate_elbo / decode_batch with the graphs of a natively compiled
+    GraphSet (one device blob) == the same utterances with dense CompiledGraph
+    objects built one by one.'''
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tools'))
+    from bench_hmm import build
+    torch.manual_seed(0)
+    ploop, units = build(6, 2, 5, 'diagonal', torch.device('cuda'), torch.float64)
+    rng = np.random.RandomState(1)
+    lengths = [60, 35, 90, 48]
+    seqs = [list(rng.randint(0, 6, n)) for n in (4, 2, 7, 3)]
+    X = torch.randn(sum(lengths), 5, dtype=torch.float64, device='cuda')
+    gset = beer.graph.compile_alignments(seqs, units)
+    sparse = list(gset)
+    dense = [g.to_dense() for g in sparse]
+    a = beer.accumulate_elbo(ploop, (X, lengths), datasize=1000, inference_graphs=dense)
+    b = beer.accumulate_elbo(ploop, (X, lengths), datasize=1000, inference_graphs=sparse)
+    assert float(a) == float(b)
+    for p in params_of(ploop):
+        np.testing.assert_array_equal(npy(a._acc_stats[p]), npy(b._acc_stats[p]))
+    pa = beer.decode_batch(ploop, (X, lengths), inference_graphs=dense)
+    pb = beer.decode_batch(ploop, (X, lengths), inference_graphs=sparse)
+    for x, y in zip(pa, pb):
+        np.testing.assert_array_equal(npy(x), npy(y))
+    # single-utterance model API with a sparse graph
+    u0 = X[:lengths[0]]
+    e1 = beer.evidence_lower_bound(ploop, u0, datasize=1000, inference_graph=dense[0])
+    e2 = beer.evidence_lower_bound(ploop, u0, datasize=1000, inference_graph=sparse[0])
+    assert float(e1) == float(e2)

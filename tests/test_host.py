@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 35
     for name in names:
         assert hasattr(lib, name), f'{name} is declared but not exported'
-    assert sorted(list(_hip.SIGNATURES) + list(_hip.SIZE_QUERIES)) == names, \
+    assert sorted(list(_hip.SIGNATURES) + list(_hip.SIZE_QUERIES) +
+                  list(_hip.HOST_SIGNATURES)) == names, \
         'ctypes table and header disagree'
     assert lib.beer_hip_version() >= 100
 
@@ -243,3 +244,51 @@ def test_default_priors_follow_the_reference_recipe():
     m = beer.Mixture.create(ns, prior_strength=3.)
     assert torch.allclose(m.categorical.weights.prior.params.concentrations,
                           torch.full((5,), 3. / 5))
+
+
+def test_native_compile_equals_python_oracle_and_batch_builder():
+    '''beer_graph_compile / beer_aligraphs_compile against the plain-Python
+    restatement (oracle/graph_oracle.py) on random transcriptions, and the
+    one-call corpus builder against per-utterance compilation.'''
+    sys_path_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, sys_path_root)
+    from oracle import graph_oracle as go
+    units = _units()
+    rng = np.random.RandomState(0)
+    names = list(units)
+    seqs = [[names[i] for i in rng.randint(0, len(names), n)] for n in (1, 2, 5, 17, 40)]
+    gset = beer.graph.compile_alignments(seqs, units)
+    assert len(gset) == len(seqs)
+    for seq, sparse in zip(seqs, gset):
+        graph = go.alignment_graph(seq, units, beer.graph.Graph)
+        init, final, trans, pdf = go.compile_graph(graph)
+        one = graph.compile()                                       # native, one graph
+        assert one.pdf_id_mapping == pdf == [int(i) for i in sparse.pdf_id_mapping]
+        for got in (one, sparse.to_dense()):
+            assert_close(got.init_log_probs.exp().numpy(), init, 1e-7)
+            assert_close(got.final_log_probs.exp().numpy(), final, 1e-7)
+            assert_close(got.trans_log_probs.exp().numpy(), trans, 1e-6)
+        assert sparse.n_states == len(pdf) == 3 * len(seq) - sum(u == 'sil' for u in seq)
+    # the phone loop: a non-emitting pivot reached from every unit
+    loop = beer.graph.Graph()
+    loop.start_state, loop.end_state = loop.add_state(), loop.add_state()
+    pivot = loop.add_state()
+    u2s = {name: loop.add_state() for name in units}
+    loop.add_arc(loop.start_state, pivot)
+    loop.add_arc(pivot, loop.end_state)
+    for name in units:
+        loop.add_arc(pivot, u2s[name])
+        loop.add_arc(u2s[name], pivot)
+    loop.normalize()
+    for name, hmm in units.items():
+        loop.replace_state(u2s[name], hmm)
+    loop.normalize()
+    init, final, trans, pdf = go.compile_graph(loop)
+    got = loop.compile()
+    assert got.pdf_id_mapping == pdf
+    assert_close(got.init_log_probs.exp().numpy(), init, 1e-7)
+    assert_close(got.final_log_probs.exp().numpy(), final, 1e-7)
+    assert_close(got.trans_log_probs.exp().numpy(), trans, 1e-6)
+    with pytest.raises(_hip.HipError):
+        beer.graph.compile_alignments([[]], units)                  # empty transcription

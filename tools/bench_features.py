@@ -47,14 +47,11 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     out['gpu'] = {'ms': 1e3 * dt, 'frames_per_s': nframes / dt,
                   'x_real_time': sum(lengths) / 16000 / dt}
-    from oracle import features_oracle as fo
+    import bench                                           # its cpu_baseline leg runs the oracle
     sample = [s.cpu().numpy() for s in sigs[:args.cpu_utts]]
-    t0 = time.perf_counter()
-    ref = [fo.extract(s) for s in sample]
-    dt = time.perf_counter() - t0
-    n = sum(len(r) for r in ref)
-    out['cpu_numpy_oracle'] = {'frames_per_s': n / dt, 'sample': f'{len(sample)} utterances',
-                               'cores': 1}
+    rate, ref = bench.cpu_baseline_features(sample)
+    out['cpu_baseline'] = {'value': rate, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+                           'sample': f'{len(sample)} utterances, numpy oracle'}
     err = max(float(np.abs(r - f.cpu().numpy()).max()) for r, f in zip(ref, feats))
     out['max_abs_err_vs_oracle'] = err
     print(json.dumps(out))

@@ -133,10 +133,22 @@ def main():
     if args.ali_utts:
         n = min(args.ali_utts, len(lengths))
         sub = lengths[:n]
+        seqs = [list(rng.randint(0, args.phones, max(2, T // 30))) for T in sub]
         t0 = time.perf_counter()
-        graphs = [ali_graph(list(rng.randint(0, args.phones, max(2, T // 30))), units)
-                  for T in sub]
-        out['ali_graph_build_s'] = time.perf_counter() - t0
+        gset = beer.graph.compile_alignments(seqs, units)
+        graphs = list(gset)
+        t1 = time.perf_counter()
+        gset.device_image(torch.float32)
+        torch.cuda.synchronize()
+        out['ali_graph_build'] = {'utts': n, 'native_compile_s': t1 - t0,
+                                  'device_image_s': time.perf_counter() - t1,
+                                  'states': int(gset.state_off[-1]), 'arcs': int(gset.arc_off[-1])}
+        # the reference's way: per-utterance pure-Python builder + compile, on a sample
+        import bench                                       # its cpu_baseline leg runs the oracle
+        m = min(n, 50)
+        out['ali_graph_build']['cpu_baseline'] = {
+            'value': bench.cpu_baseline_graph_compile(seqs[:m], units, beer.graph.Graph),
+            'unit': 's/utterance', 'cores': 1, 'kind': 'port', 'sample': f'{m} utterances'}
         Xs = X[:sum(sub)]
         run(graphs, Xs, sub)
         torch.cuda.synchronize()
