@@ -10,5 +10,6 @@ from . import nnet
 from . import utils
 from . import vbi
 from .stats import FrameStats
+from ._hip import get_f32_mode, set_f32_mode
 
 __version__ = '0.1.0'

@@ -145,6 +145,8 @@ SIGNATURES = {
 # host-side functions (graph compilation): host pointers, no stream
 c_pp = ctypes.POINTER(ctypes.c_void_p)
 HOST_SIGNATURES = {
+    'beer_hip_set_f32_mode': [c_i],
+    'beer_hip_get_f32_mode': [],
     'beer_graph_compile': [ctypes.c_int32, c_p, c_l, c_p, c_p, c_p, ctypes.c_int32,
                            ctypes.c_int32, c_pp],
     'beer_aligraphs_compile': [ctypes.c_int32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l,
@@ -219,6 +221,23 @@ def call(name, *args):
     if rc != 0:
         what = 'invalid argument' if rc == EINVAL else f'hipError {-rc}'
         raise HipError(f'{name} failed: {what}')
+
+
+F32_MODES = {'exact': 0, 'split_f16': 1}
+
+
+def set_f32_mode(mode):
+    '''How float32 models multiply on the matrix cores: 'exact' (fp32 MFMA,
+    bitwise an fmaf chain) or 'split_f16' (default: two fp16 halves per
+    operand, three fp16 MFMAs per product, fp32 accumulation; 5x the rate).'''
+    rc = lib().beer_hip_set_f32_mode(F32_MODES[mode])
+    if rc != 0:
+        raise HipError('beer_hip_set_f32_mode failed')
+
+
+def get_f32_mode():
+    code = lib().beer_hip_get_f32_mode()
+    return {v: k for k, v in F32_MODES.items()}[code]
 
 
 def call_host(name, *args):

@@ -10,12 +10,27 @@
 // mixtureset.py:85-112, dists/normalwishart.py:30-38,88-92 (and the
 // normalgamma / isonormalgamma equivalents).
 
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
 #include "estep_mfma.h"
 
 using namespace beer;
 
 namespace {
+
+// How fp32 models multiply on the matrix cores (beer_hip_set_f32_mode); the
+// initial value comes from the environment: BEER_F32_MODE=exact | split_f16.
+int& f32_mode_ref() {
+    static int mode = [] {
+        const char* e = getenv("BEER_F32_MODE");
+        if (e && (!strcmp(e, "exact") || !strcmp(e, "f32"))) return BEER_F32_EXACT;
+        return BEER_F32_SPLIT_F16;
+    }();
+    return mode;
+}
+int f32_mode() { return f32_mode_ref(); }
 
 constexpr int kFrameTile = 64;      // frames per workgroup tile (lane = frame)
 constexpr int kLlhThreads = 256;    // 4 waves, each walks a share of the comps
@@ -343,6 +358,12 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
         ws_bytes >= beer_mfma::estep_workspace_bytes(sizeof(T), cov, D, S, G) &&
         (log_norm || comp_resps || llh_sum)) {
         // gfx950 matrix-core path: GEMM + (grouped) softmax fused, one kernel
+        if (sizeof(T) == 4 && f32_mode() == BEER_F32_SPLIT_F16 &&
+            ws_bytes >= beer_mfma::estep16_workspace_bytes(cov, D, S, G))
+            return beer_mfma::estep_f16x3(cov, nframes, D, S, G, (const float*)X,
+                                          (const float*)expT, (const float*)logw,
+                                          (float*)comp_resps, (float*)log_norm, llh_sum, ws,
+                                          ws_bytes, s);
         return sizeof(T) == 4
                    ? beer_mfma::estep_f32(cov, nframes, D, S, G, (const float*)X,
                                           (const float*)expT, (const float*)logw,
@@ -462,8 +483,19 @@ int beer_mixtureset_estep(int dtype, int cov, int64_t T, int D, int S, int G, co
 
 size_t beer_estep_workspace_bytes(int dtype, int cov, int D, int S, int G) {
     if (cov < 0 || cov > 2) return 0;
-    return beer_mfma::estep_workspace_bytes(dtype == BEER_F64 ? 8 : 4, cov, D, S, G);
+    const size_t exact = beer_mfma::estep_workspace_bytes(dtype == BEER_F64 ? 8 : 4, cov, D, S, G);
+    if (dtype == BEER_F64) return exact;
+    const size_t split = beer_mfma::estep16_workspace_bytes(cov, D, S, G);
+    return exact > split ? exact : split;                 // either fp32 mode fits
 }
+
+int beer_hip_set_f32_mode(int mode) {
+    if (mode != BEER_F32_EXACT && mode != BEER_F32_SPLIT_F16) return BEER_EINVAL;
+    f32_mode_ref() = mode;
+    return BEER_OK;
+}
+
+int beer_hip_get_f32_mode(void) { return f32_mode(); }
 
 size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G) {
     (void)dtype;

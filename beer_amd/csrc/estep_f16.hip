@@ -1,0 +1,382 @@
+// fp32 E-step on the fp16 matrix pipes ("f16x3").
+//
+// gfx950 runs v_mfma_f32_16x16x4_f32 at 1/16 of the rate of
+// v_mfma_f32_16x16x32_f16 (MI355X_MICROARCH.md: 157 TF vs 2.5 PF dense).  Both
+// GEMMs of the E-step are therefore evaluated with every fp32 operand split
+// into two fp16 halves, v = hi + lo (hi = fp16(v), lo = fp16(v - hi): 22
+// mantissa bits), and three fp16 MFMAs per product, accumulated in fp32:
+//
+//     a * b  ~=  a_hi b_hi + a_hi b_lo + a_lo b_hi        (|err| <= 2^-21 |a b|)
+//
+// i.e. the accuracy of an fp32 multiply (2^-24) to within a factor of 8, at a
+// third of the fp16 rate = 5.3x the fp32 MFMA rate.  fp16's narrow exponent
+// range is handled with exact power-of-two scalings: the frames are scaled so
+// that |x| < 64 (products < 4096), every column of the packed parameter image
+// so that its largest entry is below 2^14; both are undone in the epilogue.
+// Entries more than 2^28 below the column maximum lose relative accuracy
+// (fp16 subnormals) but contribute < 2^-38 of the column's dominant term.
+//
+// Same slab enumeration, component interleave and softmax epilogue as
+// estep_mfma.hip; one k-step of the fp16 MFMA (32 deep) covers 8 slabs, lane
+// k-block g (8 values) = slabs 8s+2g and 8s+2g+1.
+//
+// Operand mapping of v_mfma_f32_16x16x32_f16 (lane l: i = l & 15, g = l >> 4):
+// A[i][k = 8g..8g+7], B[k = 8g..8g+7][n = i], C/D row 4g + r, column i.
+
+#include "estep_mfma.h"
+#include "estep_tiles.h"
+
+namespace beer_mfma {
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+constexpr int kScaleBits = 6;          // |x * sx| < 2^6
+constexpr int kColBits = 14;           // column maximum of P < 2^14
+
+// k-steps (8 slabs each), padded to an even count: the K1 loop is unrolled by two
+__host__ __device__ inline int nk16_of(int cov, int D) {
+    return ((nslab_of(cov, D) + 7) / 8 + 1) / 2 * 2;
+}
+constexpr int kPadBlocks = 4;          // look-ahead blocks behind the P image (a quarter k-step)
+
+// sc[0] = sx, sc[1] = 1 / sx, sc[2] = 1 / sx^2 from the bit pattern of max |x|
+__global__ void absmax_kernel(const float* __restrict__ X, int64_t n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const float v = fabsf(X[idx]);
+        m = v > m ? v : m;                                   // NaN never wins
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+__global__ void scale_kernel(const unsigned* __restrict__ absmax, float* __restrict__ sc) {
+    const float m = __uint_as_float(*absmax);
+    float sx = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+        int e;
+        frexpf(m, &e);                                       // m < 2^e
+        sx = ldexpf(1.f, kScaleBits - e);
+    }
+    sc[0] = sx;
+    sc[1] = 1.f / sx;
+    sc[2] = (1.f / sx) * (1.f / sx);
+}
+
+// Value of contraction entry (slab, e) for component k (the logic of
+// pack_kernel in estep_mfma.hip) times the inverse frame scaling.
+__device__ inline double entry_value(int cov, int D, int K, int k, int slab, int e,
+                                     const float* __restrict__ E, const float* __restrict__ logw,
+                                     double isx, double isx2, bool* is_const) {
+    const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(cov, D), Q = stats_dim(cov, D);
+    *is_const = false;
+    if (slab >= nslab) return 0.0;
+    const int t = slab_entry(cov, D, slab);
+    const int a = t & 0xff, b = ((t >> 8) & 0xff) + e, sq = t >> 16;
+    const bool constant = (a == Dp && b - e == Dp);
+    if (constant) *is_const = (e == 0);
+    if (k >= K) return 0.0;
+    const float* row = E + (size_t)k * Q;
+    if (sq) return b < D ? -0.5 * (double)row[cov == BEER_ISO ? D : D + b] * isx2 : 0.0;
+    if (a < D) {
+        if (b >= D || b < a) return 0.0;
+        return (b == a ? -0.5 * (double)row[D + a * D + a]
+                       : -0.5 * ((double)row[D + a * D + b] + (double)row[D + b * D + a])) * isx2;
+    }
+    if (!constant) return b < D ? (double)row[b] * isx : 0.0;
+    if (e != 0) return 0.0;
+    const double zero = cov == BEER_ISO ? 0.5 * (double)D : 0.5;
+    return -0.5 * (double)row[Q - 2] + zero * (double)row[Q - 1] - 0.5 * (double)D * kLog2Pi +
+           (logw ? (double)logw[k] : 0.0);
+}
+
+// One workgroup per (padded) component: column scale, then its fp16 hi / lo
+// images at P16[chunk][kstep][tile][hi 64 x 8 | lo 64 x 8] halves, and 1 / scale.
+__global__ void pack16_kernel(int cov, int D, int K, int NT, const float* __restrict__ E,
+                              const float* __restrict__ logw, const float* __restrict__ sc,
+                              _Float16* __restrict__ P, float* __restrict__ inv_scale,
+                              int* __restrict__ tab) {
+    __shared__ double red[8];
+    const int nk = nk16_of(cov, D), nent = nk * 32;
+    const int k = blockIdx.x;
+    const int chunk = k / (NT * 16), kk = k % (NT * 16);
+    const int c = 4 * (kk / 64) + (kk % 4), i = (kk % 64) / 4;
+    const double isx = (double)sc[1], isx2 = (double)sc[2];
+    if (k == 0)
+        for (int s = threadIdx.x; s < (nk + 1) * 8; s += blockDim.x) {
+            // padding slabs read the zero columns behind the "1" of a frame row
+            const int Dp = 4 * d4_of(D);
+            tab[s] = s < nslab_of(cov, D) ? slab_entry(cov, D, s) : ((Dp + 1) | ((Dp + 4) << 8));
+        }
+    double mx = 0.0;
+    bool dummy;
+    for (int q = threadIdx.x; q < nent; q += blockDim.x) {
+        const double v = fabs(entry_value(cov, D, K, k, q / 4, q % 4, E, logw, isx, isx2, &dummy));
+        mx = v > mx ? v : mx;
+    }
+    mx = block_max(mx, red);
+    double scale = 1.0;
+    if (mx > 0.0) {
+        int e;
+        frexp(mx, &e);                                       // mx < 2^e
+        scale = ldexp(1.0, kColBits - e);
+    }
+    if (threadIdx.x == 0) inv_scale[k] = k < K ? (float)(1.0 / scale) : 1.0e30f;
+    _Float16* base = P + ((size_t)chunk * nk * NT) * 1024;
+    for (int q = threadIdx.x; q < nent; q += blockDim.x) {
+        bool is_const;
+        double v = entry_value(cov, D, K, k, q / 4, q % 4, E, logw, isx, isx2, &is_const) * scale;
+        if (k >= K) v = is_const ? -1.0 : 0.0;            // padded component: logit -1e30
+        const float vf = (float)v;
+        const _Float16 hi = (_Float16)vf;
+        const _Float16 lo = (_Float16)(vf - (float)hi);
+        const int s = q / 32, g = (q % 32) / 8, j = q % 8;
+        _Float16* dst = base + ((size_t)s * NT + c) * 1024 + (g * 16 + i) * 8 + j;
+        dst[0] = hi;
+        dst[512] = lo;
+    }
+}
+
+__device__ __forceinline__ void split8(const f32x4& p0, const f32x4& p1, h8& hi, h8& lo) {
+    // hi = fp16(p) (towards zero), lo = fp16(p - hi): p - hi is exact in fp32
+    union { h8 v; hp2 p[4]; } H, L;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = q < 2 ? p0[2 * q] : p1[2 * q - 4];
+        const float b = q < 2 ? p0[2 * q + 1] : p1[2 * q - 3];
+        const hp2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+        H.p[q] = h;
+        L.p[q] = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+    }
+    hi = H.v;
+    lo = L.v;
+}
+
+// ---------------------------------------------------------------------------
+// K1 on the fp16 pipes: one wave owns 16 MT frames x 16 NT components.
+// ---------------------------------------------------------------------------
+template <int NT, int MT, int GQ>
+__global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
+    int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nk,
+    const float* __restrict__ X, const _Float16* __restrict__ Pall,
+    const float* __restrict__ inv_scale, const float* __restrict__ sc,
+    const int* __restrict__ tab, float* __restrict__ resps, float* __restrict__ log_norm,
+    double* __restrict__ llh_sum) {
+    using acc_t = f32x4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D4 = d4_of(D), Dp = 4 * D4, LD = Dp + 8;        // 16-byte aligned rows
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    constexpr int FW = 16 * MT;
+    float* xw = reinterpret_cast<float*>(smem) + wave * (FW * LD);
+    int* tabs = reinterpret_cast<int*>(reinterpret_cast<float*>(smem) + (kThreads / 64) * FW * LD);
+    const int64_t fb = ((int64_t)blockIdx.x * (kThreads / 64) + wave) * FW;
+    const float sx = sc[0];
+    for (int idx = tid; idx < (nk + 1) * 8; idx += kThreads) tabs[idx] = tab[idx];
+
+    for (int idx = lane; idx < FW * LD; idx += 64) {
+        const int r = idx / LD, c = idx - r * LD;
+        const int64_t f = fb + r;
+        float v = 0.f;
+        if (c < D) { if (f < nframes) v = X[f * D + c] * sx; }
+        else if (c == Dp) v = 1.f;
+        xw[idx] = v;
+    }
+    __syncthreads();
+
+    acc_t acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[m][c] = acc_t{0, 0, 0, 0};
+
+    const float* xrow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xrow[m] = xw + (m * 16 + i) * LD;
+
+    const int kbase = blockIdx.y * (16 * NT);
+    // the B stream of this chunk is one linear sequence of (k-step, tile) blocks
+    // of 2 KiB = 128 u4 (hi 64 lanes x 16 B, lo 64 lanes x 16 B)
+    const u4* Pl = reinterpret_cast<const u4*>(Pall + (size_t)blockIdx.y * nk * NT * 1024) + lane;
+    const int* tl = tabs + 2 * g;
+
+    // A fragments as 32-bit words (two fp16 each): word w of tile m holds the
+    // entries 2w, 2w+1 of the lane's 8-deep k-block (w < 2: first slab).
+    struct AFrag { unsigned hi[MT][4], lo[MT][4]; };
+    auto frag = [](const unsigned (&w)[4]) {
+        return __builtin_bit_cast(h8, u4{w[0], w[1], w[2], w[3]});
+    };
+    // one slab (half a k-block) of tile m of k-step s: LDS reads, 4 products,
+    // fp16 split -> words 2h, 2h+1
+    auto make_half = [&](int s, int m, int h, AFrag& f) {
+        const int t = tl[8 * s + h];
+        const int a = t & 0xff, j = (t >> 8) & 0xff;
+        const bool sq = (t >> 16) != 0;
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(xrow[m] + j);
+        const float xx = xrow[m][a];
+        f32x4 p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[e] = bb[e] * (sq ? bb[e] : xx);     // v_cndmask, no branch
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const hp2 hh = __builtin_amdgcn_cvt_pkrtz(p[2 * e], p[2 * e + 1]);
+            const hp2 ll = __builtin_amdgcn_cvt_pkrtz(p[2 * e] - (float)hh[0],
+                                                      p[2 * e + 1] - (float)hh[1]);
+            f.hi[m][2 * h + e] = __builtin_bit_cast(unsigned, hh);
+            f.lo[m][2 * h + e] = __builtin_bit_cast(unsigned, ll);
+        }
+    };
+    // Software pipeline in "quarters" of a k-step (QT = NT / 4 column tiles):
+    // the B fragments of the next quarter are loaded before the MFMA block of
+    // the current one (sched_group_barrier pins them there: hipcc otherwise
+    // sinks every load next to its first use), and a slice of the A fragments
+    // of the next k-step is prepared in between.
+    constexpr int QT = NT / 4;
+    struct BFrag { h8 hi[QT], lo[QT]; };
+    auto load_b = [&](int64_t blk, BFrag& b) {               // blocks blk .. blk + QT - 1
+#pragma unroll
+        for (int c = 0; c < QT; ++c) {
+            b.hi[c] = __builtin_bit_cast(h8, Pl[(size_t)(blk + c) * 128]);
+            b.lo[c] = __builtin_bit_cast(h8, Pl[(size_t)(blk + c) * 128 + 64]);
+        }
+    };
+    auto quarter = [&](int s, int q, const AFrag& cur, AFrag& nxt, const BFrag& b, BFrag& bn) {
+        load_b((int64_t)s * NT + (q + 1) * QT, bn);          // P is padded by one quarter
+        // slices of the next A: MT * 2 halves over 4 quarters
+#pragma unroll
+        for (int hh = q * MT * 2 / 4; hh < (q + 1) * MT * 2 / 4; ++hh)
+            make_half(s + 1, hh >> 1, hh & 1, nxt);          // the table is padded by one k-step
+#pragma unroll
+        for (int c = 0; c < QT; ++c) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                acc[m][q * QT + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                    frag(cur.hi[m]), b.hi[c], acc[m][q * QT + c], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                acc[m][q * QT + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                    frag(cur.hi[m]), b.lo[c], acc[m][q * QT + c], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                acc[m][q * QT + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                    frag(cur.lo[m]), b.hi[c], acc[m][q * QT + c], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 2 * QT, 0);          // VMEM reads
+        __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);              // DS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT * QT, 0);     // MFMA
+    };
+    auto kstep = [&](int s, const AFrag& cur, AFrag& nxt, BFrag& b0, BFrag& b1) {
+        quarter(s, 0, cur, nxt, b0, b1);
+        quarter(s, 1, cur, nxt, b1, b0);
+        quarter(s, 2, cur, nxt, b0, b1);
+        quarter(s, 3, cur, nxt, b1, b0);
+    };
+    AFrag f0, f1;
+    BFrag b0, b1;
+#pragma unroll
+    for (int hh = 0; hh < MT * 2; ++hh) make_half(0, hh >> 1, hh & 1, f0);
+    load_b(0, b0);
+    for (int s = 0; s < nk; s += 2) {                // nk is padded to an even count
+        kstep(s, f0, f1, b0, b1);
+        kstep(s + 1, f1, f0, b0, b1);
+    }
+
+    // undo the column scaling: column (tile c, lane-column i) is component
+    // kbase + 64 (c / 4) + 4 i + c % 4
+#pragma unroll
+    for (int q = 0; q < NT / 4; ++q) {
+        const f32x4 inv = *reinterpret_cast<const f32x4*>(inv_scale + kbase + 64 * q + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][4 * q + j] *= inv[j];
+    }
+    softmax_epilogue<float, NT, MT, GQ>(acc, fb, nframes, kbase, K, S, G, gl, jw, i, g, lane,
+                                        resps, log_norm, llh_sum);
+}
+
+template <int NT, int MT, int GQ>
+int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nchunks, int nk,
+                 const float* X, const _Float16* P, const float* inv_scale, const float* sc,
+                 const int* tab, float* resps, float* log_norm, double* llh_sum, hipStream_t s) {
+    const int LD = 4 * d4_of(D) + 8;
+    constexpr int FB = 16 * MT * (kThreads / 64);
+    const size_t lds = (size_t)FB * LD * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int);
+    const int64_t blocks = (nframes + FB - 1) / FB;
+    hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ>), dim3((unsigned)blocks, (unsigned)nchunks),
+                       dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nk, X, P, inv_scale,
+                       sc, tab, resps, log_norm, llh_sum);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+inline int nt16_for(int S, int K) { return S > 1 ? 16 : (K <= 64 ? 4 : (K <= 128 ? 8 : 16)); }
+inline int nchunks16_for(int S, int K) { return S > 1 ? (K + 255) / 256 : 1; }
+size_t up256(size_t n) { return (n + 255) / 256 * 256; }
+
+}  // namespace
+
+size_t estep16_workspace_bytes(int cov, int D, int S, int G) {
+    if (!supported_llh(D, S, G)) return 0;
+    const int K = S * G, NT = nt16_for(S, K), nchunks = nchunks16_for(S, K);
+    const size_t kpad = (size_t)nchunks * NT * 16;
+    return up256(((size_t)nchunks * nk16_of(cov, D) * NT + kPadBlocks) * 2048) +
+           up256(kpad * sizeof(float)) + up256((size_t)(nk16_of(cov, D) + 1) * 8 * sizeof(int)) +
+           256;
+}
+
+int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, const float* expT,
+                const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
+                size_t ws_bytes, hipStream_t s) {
+    const int K = S * G;
+    if (!supported_llh(D, S, G) || ws_bytes < estep16_workspace_bytes(cov, D, S, G))
+        return BEER_EINVAL;
+    const int NT = nt16_for(S, K), nchunks = nchunks16_for(S, K), nk = nk16_of(cov, D);
+    const int kpad = nchunks * NT * 16;
+    char* w = reinterpret_cast<char*>(ws);
+    _Float16* P = reinterpret_cast<_Float16*>(w);
+    w += up256(((size_t)nchunks * nk * NT + kPadBlocks) * 2048);
+    float* inv_scale = reinterpret_cast<float*>(w);
+    w += up256((size_t)kpad * sizeof(float));
+    int* tab = reinterpret_cast<int*>(w);
+    w += up256((size_t)(nk + 1) * 8 * sizeof(int));
+    unsigned* absmax = reinterpret_cast<unsigned*>(w);
+    float* sc = reinterpret_cast<float*>(w + 16);
+    hipError_t e = hipMemsetAsync(absmax, 0, sizeof(unsigned), s);
+    if (e != hipSuccess) return -(int)e;
+    const int64_t n = nframes * D;
+    int64_t ab = (n + 256 * 16 - 1) / (256 * 16);
+    if (ab > 2048) ab = 2048;
+    if (ab < 1) ab = 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)ab), dim3(256), 0, s, X, n, absmax);
+    hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, s, absmax, sc);
+    hipLaunchKernelGGL(pack16_kernel, dim3(kpad), dim3(256), 0, s, cov, D, K, NT, expT, logw, sc, P,
+                       inv_scale, tab);
+    BEER_LAUNCH_CHECK();
+#define BEER_LLH16(NT_, MT_, GQ_)                                                                \
+    return launch_llh16<NT_, MT_, GQ_>(nframes, D, K, S, G, gl, jw, nchunks, nk, X, P, inv_scale, \
+                                       sc, tab, resps, log_norm, llh_sum, s)
+    if (S == 1) {
+        const int gl = 16, jw = 4;
+        if (NT == 4) BEER_LLH16(4, 2, 1);
+        if (NT == 8) BEER_LLH16(8, 2, 2);
+        BEER_LLH16(16, 2, 4);
+    }
+    const int jw = G < 4 ? G : 4;
+    const int gl = G < 4 ? 1 : (G < 64 ? G / 4 : 16);
+    const int gq = G <= 64 ? 1 : G / 64;
+    switch (gq) {
+        case 1: BEER_LLH16(16, 2, 1);
+        case 2: BEER_LLH16(16, 2, 2);
+        default: BEER_LLH16(16, 2, 4);
+    }
+#undef BEER_LLH16
+}
+
+}  // namespace beer_mfma

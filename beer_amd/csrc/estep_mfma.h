@@ -14,6 +14,13 @@ bool supported_acc(int D, int K);
 size_t estep_workspace_bytes(size_t elem, int cov, int D, int S, int G);
 size_t acc_workspace_bytes(int cov, int D, int K);
 
+// fp32 models on the fp16 matrix pipes (estep_f16.hip): every fp32 operand is
+// split into two fp16 halves, three fp16 MFMAs per product, fp32 accumulation.
+size_t estep16_workspace_bytes(int cov, int D, int S, int G);
+int estep_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
+                const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
+                size_t ws_bytes, hipStream_t s);
+
 int estep_f32(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
               const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
               size_t ws_bytes, hipStream_t s);

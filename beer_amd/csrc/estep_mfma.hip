@@ -33,109 +33,13 @@
 #include <type_traits>
 
 #include "common.h"
+#include "estep_tiles.h"
 
 using namespace beer;
 
 namespace beer_mfma {
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-template <typename T> struct Mma;
-template <> struct Mma<float> {
-    using acc_t = f32x4;
-    using vec4_t = f32x4;
-    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
-        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ int row(int g, int r) { return 4 * g + r; }
-};
-template <> struct Mma<double> {
-    using acc_t = f64x4;
-    using vec4_t = f64x4;
-    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
-        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ int row(int g, int r) { return g + 4 * r; }
-};
-
-// All-reduce across the 16 lanes that hold one row of a 16x16 C tile, with
-// DPP (VALU, no LDS round trip): xor-1 / xor-2 inside a quad, then the two
-// mirrors (values are uniform inside a quad / half-row by then, so mirroring
-// equals the xor-4 / xor-8 exchange).  `gl` = lanes per group (1,2,4,8,16).
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-        0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double v) {
-    const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-template <typename T>
-__device__ __forceinline__ T group_max(T v, int gl) {
-    if (gl > 1) { const T w = dpp_move<0xB1>(v); v = w > v ? w : v; }      // quad_perm [1,0,3,2]
-    if (gl > 2) { const T w = dpp_move<0x4E>(v); v = w > v ? w : v; }      // quad_perm [2,3,0,1]
-    if (gl > 4) { const T w = dpp_move<0x141>(v); v = w > v ? w : v; }     // row_half_mirror
-    if (gl > 8) { const T w = dpp_move<0x140>(v); v = w > v ? w : v; }     // row_mirror
-    return v;
-}
-template <typename T>
-__device__ __forceinline__ T group_sum(T v, int gl) {
-    if (gl > 1) v += dpp_move<0xB1>(v);
-    if (gl > 2) v += dpp_move<0x4E>(v);
-    if (gl > 4) v += dpp_move<0x141>(v);
-    if (gl > 8) v += dpp_move<0x140>(v);
-    return v;
-}
-
-__host__ __device__ inline int d4_of(int D) { return (D + 3) / 4; }
-
-// Slab enumeration per covariance type (see the header comment).  Diagonal and
-// isotropic models only have D4 "square" slabs xe[4j+g]^2 (flag bit 16 in the
-// table), D4 linear slabs and the constant slab.
-__host__ __device__ inline int nslab_of(int cov, int D) {
-    const int D4 = d4_of(D);
-    int n = D4 + 1;                                   // linear + constant
-    if (cov != BEER_FULL) return n + D4;
-    for (int a = 0; a < D; ++a) n += D4 - a / 4;
-    return n;
-}
-// slab s -> table entry  a | (4j << 8) | (square << 16)
-__host__ __device__ inline int slab_entry(int cov, int D, int s) {
-    const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(cov, D);
-    const int nquad = nslab - (D4 + 1);
-    if (s >= nslab) return (Dp + 1) | (Dp << 8);          // padding: zero column
-    if (s >= nquad) return Dp | ((4 * (s - nquad)) << 8);  // linear / constant
-    if (cov != BEER_FULL) return Dp | ((4 * s) << 8) | (1 << 16);
-    int rem = s, a = 0;
-    for (;;) { const int len = D4 - a / 4; if (rem < len) break; rem -= len; ++a; }
-    return a | ((4 * (a / 4 + rem)) << 8);
-}
-// index of the quadratic slab holding x_a * x_b (a <= b), of linear slab j
-// (a == Dp) and of the constant slab (a == Dp, j == D4)
-__host__ __device__ inline int slab_index(int cov, int D, int a, int j) {
-    const int D4 = d4_of(D);
-    if (a >= D) return nslab_of(cov, D) - (D4 + 1) + j;
-    if (cov != BEER_FULL) return j;                       // square slab of x_{4j..4j+3}
-    const int q = a / 4, r = a % 4;
-    const int before = 4 * (q * D4 - q * (q - 1) / 2) + r * (D4 - q);
-    return before + (j - q);
-}
-
-// slabs in the packed parameter image: an even count (the K1 loop is unrolled
-// by two) plus one look-ahead slab, all zero beyond nslab_of().
-__host__ __device__ inline int nslab_padded(int cov, int D) {
-    return (nslab_of(cov, D) + 1) / 2 * 2 + 1;
-}
-
-constexpr int kThreads = 256;
-constexpr double kPadLogit = -1.0e30;
 
 // ---------------------------------------------------------------------------
 // Parameter packing: E[T] [K, Q] (+ log weights) ->
@@ -289,103 +193,8 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 && MT * NT <= 32) ? 2 : 1
         __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 1);
     }
 
-    // ---- epilogue: logsumexp over each group of G components ----
-    double llh_local = 0.0;
-    const bool vec_ok = (K % 4) == 0;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            // one row at a time: without the barrier hipcc interleaves all the
-            // rows and groups and spills the accumulators to scratch
-            __builtin_amdgcn_sched_barrier(0);
-            const int64_t f = fb + m * 16 + M::row(g, r);
-#pragma unroll
-            for (int tq = 0; tq < NT / 4 / GQ; ++tq) {
-                T e[GQ][4];
-                const int kq = kbase + 64 * tq * GQ + 4 * i;       // lane's first component
-                if (jw == 4) {
-                    T mx = acc[m][4 * tq * GQ][r];
-#pragma unroll
-                    for (int c = 1; c < 4 * GQ; ++c) {
-                        const T w = acc[m][4 * tq * GQ + c][r];
-                        mx = w > mx ? w : mx;
-                    }
-                    mx = group_max(mx, gl);
-                    T sum = 0;
-#pragma unroll
-                    for (int qq = 0; qq < GQ; ++qq)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            e[qq][j] = exp(acc[m][4 * (tq * GQ + qq) + j][r] - mx);
-                            sum += e[qq][j];
-                        }
-                    sum = group_sum(sum, gl);
-                    const T lse = mx + log(sum);
-                    const T inv = (T)1 / sum;
-#pragma unroll
-                    for (int qq = 0; qq < GQ; ++qq)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) e[qq][j] *= inv;
-                    const int state = (kbase + 64 * tq * GQ + 4 * (i & ~(gl - 1))) / G;
-                    if (f < nframes && state < S && (i & (gl - 1)) == 0) {
-                        if (log_norm) log_norm[f * S + state] = lse;
-                        llh_local += (double)lse;
-                    }
-                } else {
-                    // G = 1 or 2: groups inside a lane's 4 values (GQ == 1)
-#pragma unroll
-                    for (int j0 = 0; j0 < 4; j0 += 2) {
-                        const T a0 = acc[m][4 * tq * GQ + j0][r], a1 = acc[m][4 * tq * GQ + j0 + 1][r];
-                        if (jw == 2) {
-                            const T mx = a0 > a1 ? a0 : a1;
-                            const T e0 = exp(a0 - mx), e1 = exp(a1 - mx);
-                            const T lse = mx + log(e0 + e1);
-                            e[0][j0] = e0 / (e0 + e1);
-                            e[0][j0 + 1] = e1 / (e0 + e1);
-                            const int state = (kq + j0) / G;
-                            if (f < nframes && state < S) {
-                                if (log_norm) log_norm[f * S + state] = lse;
-                                llh_local += (double)lse;
-                            }
-                        } else {
-                            e[0][j0] = 1;
-                            e[0][j0 + 1] = 1;
-                            if (f < nframes) {
-                                if (kq + j0 < K) {
-                                    if (log_norm) log_norm[f * S + kq + j0] = a0;
-                                    llh_local += (double)a0;
-                                }
-                                if (kq + j0 + 1 < K) {
-                                    if (log_norm) log_norm[f * S + kq + j0 + 1] = a1;
-                                    llh_local += (double)a1;
-                                }
-                            }
-                        }
-                    }
-                }
-                if (resps && f < nframes) {
-#pragma unroll
-                    for (int qq = 0; qq < GQ; ++qq) {
-                        const int k = kq + 64 * qq;
-                        T* dst = resps + f * K + k;
-                        if (vec_ok && k + 3 < K) {
-                            *reinterpret_cast<vec4_t*>(dst) =
-                                vec4_t{e[qq][0], e[qq][1], e[qq][2], e[qq][3]};
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (k + j < K) dst[j] = e[qq][j];
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (llh_sum) {
-        llh_local = wave_sum(llh_local);
-        if (lane == 0) atomicAdd(llh_sum, llh_local);
-    }
+    softmax_epilogue<T, NT, MT, GQ>(acc, fb, nframes, kbase, K, S, G, gl, jw, i, g, lane, resps,
+                                    log_norm, llh_sum);
 }
 
 // ---------------------------------------------------------------------------

@@ -51,6 +51,18 @@ extern "C" {
 int beer_hip_version(void);
 int beer_hip_device_count(void);
 
+/* How float32 models multiply on the matrix cores (float64 models always use
+ * the exact fp64 MFMA).  BEER_F32_EXACT: v_mfma_f32_16x16x4_f32, bitwise an
+ * fmaf chain.  BEER_F32_SPLIT_F16 (default): every fp32 operand split into two
+ * fp16 halves, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulation
+ * -- product error <= 2^-21 relative (fp32: 2^-24) at 5.3x the MFMA rate.
+ * Process-wide; initial value from the environment variable BEER_F32_MODE
+ * (exact | split_f16). */
+#define BEER_F32_EXACT 0
+#define BEER_F32_SPLIT_F16 1
+int beer_hip_set_f32_mode(int mode);
+int beer_hip_get_f32_mode(void);
+
 /* ------------------------------------------------------------------------
  * Exponential-family parameter kernels (once per VB iteration, K = number of
  * distributions in the set, D = feature dimension).
