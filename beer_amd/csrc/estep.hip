@@ -444,6 +444,10 @@ int accumulate_launch(int cov, int64_t nframes, int D, int S, int G, const void*
     hipStream_t s = as_stream(stream);
     if (cr && ws && beer_mfma::supported_acc(D, S * G) &&
         ws_bytes >= beer_mfma::acc_workspace_bytes(cov, D, S * G)) {
+        if (sizeof(T) == 4 && f32_mode() == BEER_F32_SPLIT_F16 &&
+            ws_bytes >= beer_mfma::acc16_workspace_bytes(cov, D, S * G))
+            return beer_mfma::acc_f16x3(cov, nframes, D, S, G, (const float*)X, (const float*)cr,
+                                        (const float*)sr, acc, ws, ws_bytes, s);
         return sizeof(T) == 4
                    ? beer_mfma::acc_f32(cov, nframes, D, S, G, (const float*)X, (const float*)cr,
                                         (const float*)sr, acc, ws, ws_bytes, s)
@@ -498,9 +502,10 @@ int beer_hip_set_f32_mode(int mode) {
 int beer_hip_get_f32_mode(void) { return f32_mode(); }
 
 size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G) {
-    (void)dtype;
     if (cov < 0 || cov > 2) return 0;
-    return beer_mfma::acc_workspace_bytes(cov, D, S * G);
+    const size_t exact = beer_mfma::acc_workspace_bytes(cov, D, S * G);
+    const size_t split = dtype == BEER_F64 ? 0 : beer_mfma::acc16_workspace_bytes(cov, D, S * G);
+    return exact > split ? exact : split;
 }
 
 int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G, const void* X,

@@ -23,6 +23,8 @@
 // Operand mapping of v_mfma_f32_16x16x32_f16 (lane l: i = l & 15, g = l >> 4):
 // A[i][k = 8g..8g+7], B[k = 8g..8g+7][n = i], C/D row 4g + r, column i.
 
+#include <cstdlib>
+
 #include "estep_mfma.h"
 #include "estep_tiles.h"
 
@@ -31,10 +33,12 @@ namespace beer_mfma {
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
-constexpr int kScaleBits = 6;          // |x * sx| < 2^6
+constexpr int kScaleBits = 7;          // |x * sx| < 2^7: products < 2^14
+constexpr int kRespBits = 12;          // responsibilities are staged as r * 2^12 (fp16 range)
 constexpr int kColBits = 14;           // column maximum of P < 2^14
 
 // k-steps (8 slabs each), padded to an even count: the K1 loop is unrolled by two
@@ -142,16 +146,22 @@ __global__ void pack16_kernel(int cov, int D, int K, int NT, const float* __rest
     }
 }
 
+// v = hi + lo with hi = fp16(v), lo = fp16(v - hi), both round-to-nearest
+// (v_cvt_pk_f16_f32): v - hi is exact in fp32, so |v - hi - lo| <= 2^-22 |v|
+// unless lo falls into the fp16 subnormals (|v| < 2^-3: error <= 2^-25).
+__device__ __forceinline__ void split2(float a, float b, hp2& hi, hp2& lo) {
+    const f32x2 v = {a, b};
+    hi = __builtin_convertvector(v, hp2);
+    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), hp2);
+}
+
 __device__ __forceinline__ void split8(const f32x4& p0, const f32x4& p1, h8& hi, h8& lo) {
-    // hi = fp16(p) (towards zero), lo = fp16(p - hi): p - hi is exact in fp32
     union { h8 v; hp2 p[4]; } H, L;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float a = q < 2 ? p0[2 * q] : p1[2 * q - 4];
         const float b = q < 2 ? p0[2 * q + 1] : p1[2 * q - 3];
-        const hp2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-        H.p[q] = h;
-        L.p[q] = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+        split2(a, b, H.p[q], L.p[q]);
     }
     hi = H.v;
     lo = L.v;
@@ -225,9 +235,8 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
         for (int e = 0; e < 4; ++e) p[e] = bb[e] * (sq ? bb[e] : xx);     // v_cndmask, no branch
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const hp2 hh = __builtin_amdgcn_cvt_pkrtz(p[2 * e], p[2 * e + 1]);
-            const hp2 ll = __builtin_amdgcn_cvt_pkrtz(p[2 * e] - (float)hh[0],
-                                                      p[2 * e + 1] - (float)hh[1]);
+            hp2 hh, ll;
+            split2(p[2 * e], p[2 * e + 1], hh, ll);
             f.hi[m][2 * h + e] = __builtin_bit_cast(unsigned, hh);
             f.lo[m][2 * h + e] = __builtin_bit_cast(unsigned, ll);
         }
@@ -316,6 +325,232 @@ int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, in
     return BEER_OK;
 }
 
+// ---------------------------------------------------------------------------
+// K2 on the fp16 pipes: S[k, q] += sum_t r[t,k] * PHI_q(x_t) with frames as the
+// contraction index (32 per MFMA).  Workgroup = 4 waves (one per SIMD, so that a
+// wave can hold a 128 x 64 output tile twice) sharing one LDS tile of 64 frames:
+// R^T [128 components][64 frames] split into fp16 hi / lo when it is staged (each
+// element once, reused by every statistic tile), X^T [D + 2 rows][64 frames] in
+// fp32 (rows D, D+1 = the constants 1, 0).  A wave owns 128 components x NQ
+// statistic tiles: A fragments = one ds_read_b128 of R^T hi / lo per component
+// tile, B fragments = products of two X^T rows over the lane's 8 frames, split
+// on the fly and reused by the 8 component tiles (LDS traffic per MFMA is what
+// bounds this kernel: 32 ds_read_b128 per 96 MFMAs).  A workgroup sums at most
+// kA16MaxFrames frames in fp32 -- one rounding per 32-frame MFMA, 384 per sum,
+// against 4096 for the same frames on the 4-deep fp32 MFMA -- and adds its
+// partial sums to the fp64 image with atomics.
+// ---------------------------------------------------------------------------
+constexpr int kA16Threads = 256;     // 4 waves, one per SIMD: 512 registers per lane
+constexpr int kA16MC = 8;            // component tiles per workgroup (128 components)
+constexpr int kA16FT = 64;           // frames per LDS tile (2 k-steps)
+constexpr int kA16XS = kA16FT + 4;   // X^T row stride (floats), 16-byte aligned
+constexpr int kA16RS = kA16FT + 8;   // R^T row stride (halves), 16-byte aligned
+constexpr int kA16MaxFrames = 16384; // frames per workgroup: 384 fp32 roundings per sum
+
+template <int NQ, bool HAS_SR>
+__global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
+    int64_t nframes, int D, int K, int G, int S, int nslab, const float* __restrict__ X,
+    const float* __restrict__ R, const float* __restrict__ SR, const int* __restrict__ tab,
+    const float* __restrict__ sc, int64_t frames_per_block, double* __restrict__ Sp, int gx,
+    int gy, int gz, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int D4 = d4_of(D), Dp = 4 * D4, nq = nslab * 4;
+    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs, each
+    // with its own L2.  The gx statistic blocks that read the same R tile get ids
+    // congruent mod 8, i.e. the same XCD back to back: one of them misses in L2,
+    // the others hit.
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int bx = slot % gx;
+    const int yz = (slot / gx) * 8 + xcd;
+    if (yz >= gy * gz) return;
+    const int by = yz % gy, bz = yz / gy;
+    const int tile0 = (bx * (kA16Threads / 64) + wave) * NQ;    // first statistic tile
+    const int kc0 = by * (16 * kA16MC);
+    const int64_t tb = (int64_t)bz * frames_per_block;
+    const int64_t te = tb + frames_per_block < nframes ? tb + frames_per_block : nframes;
+    const float sx = sc[0];
+
+    const int xs_elems = (D + 2) * kA16XS;                     // floats
+    const int r_halves = 16 * kA16MC * kA16RS;                 // per hi / lo image
+    const size_t buf_bytes = (size_t)xs_elems * 4 + (size_t)r_halves * 2 * 2;
+    auto xs_of = [&](int buf) { return reinterpret_cast<float*>(smem + buf * buf_bytes); };
+    auto rh_of = [&](int buf) {
+        return reinterpret_cast<_Float16*>(smem + buf * buf_bytes + (size_t)xs_elems * 4);
+    };
+
+    // the two X^T rows of this lane's statistic column in each of its tiles
+    int ra[NQ], rb[NQ];
+    auto factors = [&](int uu, int& a, int& b) {
+        const int col = 16 * (tile0 + uu) + i, slab = col >> 2;
+        a = b = Dp + 1;
+        if (slab < nslab) {
+            const int t = tab[slab];
+            b = ((t >> 8) & 0xff) + (col & 3);
+            a = (t >> 16) ? b : (t & 0xff);
+        }
+    };
+#pragma unroll
+    for (int uu = 0; uu < NQ; ++uu) {
+        int a, b;
+        factors(uu, a, b);
+        // row D = ones, row D + 1 = zeros
+        ra[uu] = (a < D ? a : (a == Dp ? D : D + 1)) * kA16XS;
+        rb[uu] = (b < D ? b : (b == Dp ? D : D + 1)) * kA16XS;
+    }
+    f32x4 acc[kA16MC][NQ];
+#pragma unroll
+    for (int c = 0; c < kA16MC; ++c)
+#pragma unroll
+        for (int uu = 0; uu < NQ; ++uu) acc[c][uu] = f32x4{0, 0, 0, 0};
+
+    // staging registers (global -> registers during the MFMAs -> other LDS buffer)
+    constexpr int RPT = 16 * kA16MC * (kA16FT / 2) / kA16Threads;    // (component, frame pair)
+    constexpr int XPT = (kA16FT * 64 + kA16Threads - 1) / kA16Threads;   // D <= 64
+    const int xcount = kA16FT * D;
+    struct Stage { float x[XPT]; float r[RPT][2]; float w[HAS_SR ? RPT : 1][2]; };
+    // Loads are unconditional on clamped addresses and nothing is computed on the
+    // loaded values here: a branch or an early use per load makes hipcc put an
+    // s_waitcnt behind every one of them (one memory round trip each).  Scaling
+    // and zeroing of the out-of-range elements happen when the tile is stored.
+    auto load_tile = [&](int64_t t0, Stage& st) {
+        const float* xsrc = X + t0 * D;
+        const int64_t xvalid = (te - t0) * D;
+        const int xlast = (int)(xvalid < xcount ? xvalid : xcount) - 1;      // >= 0
+#pragma unroll
+        for (int v = 0; v < XPT; ++v) {
+            const int idx = tid + v * kA16Threads;
+            st.x[v] = xsrc[idx <= xlast ? idx : xlast];
+        }
+#pragma unroll
+        for (int v = 0; v < RPT; ++v) {
+            const int e = tid + v * kA16Threads;
+            const int kk = e % (16 * kA16MC), fp = e / (16 * kA16MC);
+            const int k = kc0 + kk, kc = k < K ? k : K - 1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t f = t0 + 2 * fp + h, fc = f < te ? f : te - 1;
+                st.r[v][h] = R[fc * K + kc];
+                if (HAS_SR) st.w[v][h] = SR[fc * S + kc / G];
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, XPT + (HAS_SR ? 4 : 2) * RPT, 0);
+    };
+    auto store_tile = [&](int buf, int64_t t0, const Stage& st) {
+        float* xs = xs_of(buf);
+        _Float16* rh = rh_of(buf);
+        _Float16* rl = rh + r_halves;
+        const int64_t xvalid = (te - t0) * D;
+#pragma unroll
+        for (int v = 0; v < XPT; ++v) {
+            const int idx = tid + v * kA16Threads;
+            if (idx < xcount) {
+                const int f = idx / D, d = idx - f * D;
+                xs[d * kA16XS + f] = idx < xvalid ? st.x[v] * sx : 0.f;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < RPT; ++v) {
+            const int e = tid + v * kA16Threads;
+            const int kk = e % (16 * kA16MC), fp = e / (16 * kA16MC);
+            float r2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float val = st.r[v][h] * (float)(1 << kRespBits);
+                if (HAS_SR) val *= st.w[v][h];
+                r2[h] = (t0 + 2 * fp + h < te && kc0 + kk < K) ? val : 0.f;
+            }
+            hp2 hi, lo;
+            split2(r2[0], r2[1], hi, lo);
+            *reinterpret_cast<hp2*>(rh + kk * kA16RS + 2 * fp) = hi;
+            *reinterpret_cast<hp2*>(rl + kk * kA16RS + 2 * fp) = lo;
+        }
+    };
+
+    for (int buf = 0; buf < 2; ++buf) {                       // constant rows, both buffers
+        float* xs = xs_of(buf);
+        for (int f = tid; f < kA16XS; f += kA16Threads) {
+            xs[D * kA16XS + f] = 1.f;
+            xs[(D + 1) * kA16XS + f] = 0.f;
+        }
+    }
+    // Registers run two tiles ahead of the MFMAs, LDS one: while tile t is being
+    // multiplied, tile t+1 sits in registers (stored to the other LDS buffer after
+    // the MFMAs) and the loads of tile t+2 are in flight.
+    const int64_t ntiles = (te - tb + kA16FT - 1) / kA16FT;
+    Stage sa, sb;
+    if (ntiles > 0) { load_tile(tb, sa); store_tile(0, tb, sa); }
+    if (ntiles > 1) load_tile(tb + kA16FT, sa);
+    __syncthreads();
+    const bool active = tile0 * 16 < nq && !(dbg & 1);         // waves past the last tile idle
+    auto iteration = [&](int64_t tile, const Stage& held, Stage& far) {
+        const int buf = (int)(tile & 1);
+        const float* xs = xs_of(buf);
+        const _Float16* rh = rh_of(buf);
+        const _Float16* rl = rh + r_halves;
+        if (tile + 2 < ntiles && !(dbg & 2)) load_tile(tb + (tile + 2) * kA16FT, far);
+        if (active) {
+#pragma unroll 1
+            for (int ks = 0; ks < kA16FT / 32; ++ks) {
+                const int f0 = 32 * ks + 8 * g;                 // the lane's 8 frames
+                h8 ah[kA16MC], al[kA16MC];
+#pragma unroll
+                for (int c = 0; c < kA16MC; ++c) {
+                    ah[c] = *reinterpret_cast<const h8*>(rh + (16 * c + i) * kA16RS + f0);
+                    al[c] = *reinterpret_cast<const h8*>(rl + (16 * c + i) * kA16RS + f0);
+                }
+#pragma unroll
+                for (int uu = 0; uu < NQ; ++uu) {
+                    const f32x4 xa0 = *reinterpret_cast<const f32x4*>(xs + ra[uu] + f0);
+                    const f32x4 xa1 = *reinterpret_cast<const f32x4*>(xs + ra[uu] + f0 + 4);
+                    const f32x4 xb0 = *reinterpret_cast<const f32x4*>(xs + rb[uu] + f0);
+                    const f32x4 xb1 = *reinterpret_cast<const f32x4*>(xs + rb[uu] + f0 + 4);
+                    h8 bh, bl;
+                    split8(xa0 * xb0, xa1 * xb1, bh, bl);
+#pragma unroll
+                    for (int c = 0; c < kA16MC; ++c)
+                        acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], bh, acc[c][uu], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < kA16MC; ++c)
+                        acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], bl, acc[c][uu], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < kA16MC; ++c)
+                        acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c], bh, acc[c][uu], 0, 0, 0);
+                }
+            }
+        }
+        if (tile + 1 < ntiles && !(dbg & 4)) store_tile(buf ^ 1, tb + (tile + 1) * kA16FT, held);
+        __syncthreads();
+    };
+    for (int64_t tile = 0; tile < ntiles; tile += 2) {
+        iteration(tile, sa, sb);
+        if (tile + 1 < ntiles) iteration(tile + 1, sb, sa);
+    }
+    if (dbg & 8) return;
+    // C rows = components kc0 + 16 c + 4 g + r, columns = statistic 16 tile + i;
+    // undo the frame scaling (one factor sx per real column) and the 2^12 of R
+    const double isx = (double)sc[1];
+#pragma unroll
+    for (int uu = 0; uu < NQ; ++uu) {
+        const int q = (tile0 + uu) * 16 + i;
+        if (q >= nq) continue;
+        int a, b;
+        factors(uu, a, b);
+        const double unscale = (a < D ? isx : 1.0) * (b < D ? isx : 1.0) / (double)(1 << kRespBits);
+#pragma unroll
+        for (int c = 0; c < kA16MC; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = kc0 + 16 * c + 4 * g + r;
+                if (k < K)
+                    atomicAdd(Sp + (size_t)k * nq + q,
+                              (double)acc[c][uu][r] * unscale);
+            }
+    }
+}
+
 inline int nt16_for(int S, int K) { return S > 1 ? 16 : (K <= 64 ? 4 : (K <= 128 ? 8 : 16)); }
 inline int nchunks16_for(int S, int K) { return S > 1 ? (K + 255) / 256 : 1; }
 size_t up256(size_t n) { return (n + 255) / 256 * 256; }
@@ -377,6 +612,78 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
         default: BEER_LLH16(16, 2, 4);
     }
 #undef BEER_LLH16
+}
+
+size_t acc16_workspace_bytes(int cov, int D, int K) {
+    if (!supported_acc(D, K)) return 0;
+    const int nslab = nslab_of(cov, D);
+    return up256((size_t)K * nslab * 4 * sizeof(double)) + up256((size_t)nslab * sizeof(int)) + 256;
+}
+
+int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, const float* R,
+              const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
+    const int K = S * G;
+    if (!supported_acc(D, K) || ws_bytes < acc16_workspace_bytes(cov, D, K)) return BEER_EINVAL;
+    const int nslab = nslab_of(cov, D), nq = nslab * 4;
+    char* w = reinterpret_cast<char*>(ws);
+    double* Sp = reinterpret_cast<double*>(w);
+    w += up256((size_t)K * nq * sizeof(double));
+    int* tab = reinterpret_cast<int*>(w);
+    w += up256((size_t)nslab * sizeof(int));
+    unsigned* absmax = reinterpret_cast<unsigned*>(w);
+    float* sc = reinterpret_cast<float*>(w + 16);
+    hipError_t e = hipMemsetAsync(absmax, 0, sizeof(unsigned), s);
+    if (e != hipSuccess) return -(int)e;
+    e = hipMemsetAsync(Sp, 0, (size_t)K * nq * sizeof(double), s);
+    if (e != hipSuccess) return -(int)e;
+    const int64_t n = nframes * D;
+    int64_t ab = (n + 256 * 16 - 1) / (256 * 16);
+    if (ab > 2048) ab = 2048;
+    if (ab < 1) ab = 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)ab), dim3(256), 0, s, X, n, absmax);
+    hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, s, absmax, sc);
+    hipLaunchKernelGGL(tab_kernel, dim3(1), dim3(256), 0, s, cov, D, tab);
+    BEER_LAUNCH_CHECK();
+    const int ntiles = (nq + 15) / 16;
+    const int waves = kA16Threads / 64;
+    const int NQ = ntiles > 2 * waves ? 4 : (ntiles > waves ? 2 : 1);
+    const int gx = (ntiles + NQ * waves - 1) / (NQ * waves);
+    const int gy = (K + 16 * kA16MC - 1) / (16 * kA16MC);
+    int64_t gz = (1024 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy);
+    const int64_t max_z = (nframes + 1023) / 1024, min_z = (nframes + kA16MaxFrames - 1) / kA16MaxFrames;
+    if (gz > max_z) gz = max_z;
+    if (gz < min_z) gz = min_z;
+    if (gz < 1) gz = 1;
+    int64_t fpb = (nframes + gz - 1) / gz;
+    fpb = (fpb + kA16FT - 1) / kA16FT * kA16FT;
+    gz = (nframes + fpb - 1) / fpb;
+    const size_t lds = 2 * ((size_t)(D + 2) * kA16XS * 4 + (size_t)16 * kA16MC * kA16RS * 2 * 2);
+    const int dbg = getenv("BEER_DBG") ? atoi(getenv("BEER_DBG")) : 0;
+    const int64_t nyz = ((int64_t)gy * gz + 7) / 8 * 8;
+    const dim3 grid((unsigned)(nyz * gx));
+#define BEER_ACC16(NQ_, SR_)                                                                     \
+    do {                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc16_kernel<NQ_, SR_>),         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        hipLaunchKernelGGL((acc16_kernel<NQ_, SR_>), grid, dim3(kA16Threads), lds, s, nframes, D, \
+                           K, G, S, nslab, X, R, SR, tab, sc, fpb, Sp, gx, gy, (int)gz, dbg);    \
+    } while (0)
+    if (SR) {
+        if (NQ == 4) BEER_ACC16(4, true);
+        else if (NQ == 2) BEER_ACC16(2, true);
+        else BEER_ACC16(1, true);
+    } else {
+        if (NQ == 4) BEER_ACC16(4, false);
+        else if (NQ == 2) BEER_ACC16(2, false);
+        else BEER_ACC16(1, false);
+    }
+#undef BEER_ACC16
+    BEER_LAUNCH_CHECK();
+    const int64_t total = (int64_t)K * stats_dim(cov, D);
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cov,
+                       D, K, Sp, acc);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
 }
 
 }  // namespace beer_mfma

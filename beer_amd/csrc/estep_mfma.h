@@ -21,6 +21,10 @@ int estep_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const f
                 const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
                 size_t ws_bytes, hipStream_t s);
 
+size_t acc16_workspace_bytes(int cov, int D, int K);
+int acc_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* R,
+              const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s);
+
 int estep_f32(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
               const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
               size_t ws_bytes, hipStream_t s);

@@ -109,6 +109,51 @@ __host__ __device__ inline int nslab_padded(int cov, int D) {
 constexpr int kThreads = 256;
 constexpr double kPadLogit = -1.0e30;
 
+namespace {
+
+__global__ void tab_kernel(int cov, int D, int* __restrict__ tab) {
+    const int nslab = nslab_of(cov, D);
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nslab; s += gridDim.x * blockDim.x)
+        tab[s] = slab_entry(cov, D, s);
+}
+
+// Sp [K][nslab*4] (packed sums) -> acc [K][Q] += in the reference's layout:
+// full [sum r x, -.5 sum r x x^T (dense D x D), -.5 N, +.5 N], diagonal
+// [sum r x, -.5 sum r x^2, -.5 N, +.5 N], isotropic [sum r x, -.5 sum r |x|^2,
+// -.5 N, +.5 D N].
+__global__ void unpack_kernel(int cov, int D, int K, const double* __restrict__ Sp,
+                              double* __restrict__ acc) {
+    const int D4 = d4_of(D), Dp = 4 * D4, nq = nslab_of(cov, D) * 4;
+    const int Q = stats_dim(cov, D);
+    const int64_t total = (int64_t)K * Q;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx / Q), q = (int)(idx % Q);
+        const double* s = Sp + (size_t)k * nq;
+        double v;
+        if (q < D) {
+            v = s[slab_index(cov, D, Dp, q / 4) * 4 + q % 4];
+        } else if (q >= Q - 2) {
+            const double n = s[slab_index(cov, D, Dp, D4) * 4];
+            v = (q == Q - 2) ? -0.5 * n : (cov == BEER_ISO ? 0.5 * (double)D * n : 0.5 * n);
+        } else if (cov == BEER_FULL) {
+            int a = (q - D) / D, b = (q - D) % D;
+            if (a > b) { const int t = a; a = b; b = t; }
+            v = -0.5 * s[slab_index(cov, D, a, b / 4) * 4 + b % 4];
+        } else if (cov == BEER_DIAG) {
+            const int d = q - D;
+            v = -0.5 * s[slab_index(cov, D, d, d / 4) * 4 + d % 4];
+        } else {
+            double tot = 0.0;
+            for (int d = 0; d < D; ++d) tot += s[slab_index(cov, D, d, d / 4) * 4 + d % 4];
+            v = -0.5 * tot;
+        }
+        acc[idx] += v;
+    }
+}
+
+}  // namespace
+
 // ---------------------------------------------------------------------------
 // Epilogue of K1: logsumexp + responsibilities over each group of G components
 // of a wave's acc[MT][NT] tiles (frames fb .. fb + 16 MT, components kbase ..).
