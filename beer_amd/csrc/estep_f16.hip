@@ -23,8 +23,6 @@
 // Operand mapping of v_mfma_f32_16x16x32_f16 (lane l: i = l & 15, g = l >> 4):
 // A[i][k = 8g..8g+7], B[k = 8g..8g+7][n = i], C/D row 4g + r, column i.
 
-#include <cstdlib>
-
 #include "estep_mfma.h"
 #include "estep_tiles.h"
 
@@ -344,7 +342,9 @@ constexpr int kA16Threads = 256;     // 4 waves, one per SIMD: 512 registers per
 constexpr int kA16MC = 8;            // component tiles per workgroup (128 components)
 constexpr int kA16FT = 64;           // frames per LDS tile (2 k-steps)
 constexpr int kA16XS = kA16FT + 4;   // X^T row stride (floats), 16-byte aligned
-constexpr int kA16RS = kA16FT + 8;   // R^T row stride (halves), 16-byte aligned
+constexpr int kA16RS = kA16FT;       // R^T row = 8 chunks of 8 frames (16 B), chunk c of row
+                                     // r stored at position c ^ (r & 7): conflict-free
+                                     // ds_read_b128 for the MFMA lane groups, 2-way ds_write_b32
 constexpr int kA16MaxFrames = 16384; // frames per workgroup: 384 fp32 roundings per sum
 
 template <int NQ, bool HAS_SR>
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     int64_t nframes, int D, int K, int G, int S, int nslab, const float* __restrict__ X,
     const float* __restrict__ R, const float* __restrict__ SR, const int* __restrict__ tab,
     const float* __restrict__ sc, int64_t frames_per_block, double* __restrict__ Sp, int gx,
-    int gy, int gz, int dbg) {
+    int gy, int gz) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     const int64_t te = tb + frames_per_block < nframes ? tb + frames_per_block : nframes;
     const float sx = sc[0];
 
-    const int xs_elems = (D + 2) * kA16XS;                     // floats
+    const int xs_elems = (D + 3) * kA16XS;                     // floats (+ a spare row)
     const int r_halves = 16 * kA16MC * kA16RS;                 // per hi / lo image
     const size_t buf_bytes = (size_t)xs_elems * 4 + (size_t)r_halves * 2 * 2;
     auto xs_of = [&](int buf) { return reinterpret_cast<float*>(smem + buf * buf_bytes); };
@@ -411,6 +411,15 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     constexpr int XPT = (kA16FT * 64 + kA16Threads - 1) / kA16Threads;   // D <= 64
     const int xcount = kA16FT * D;
     struct Stage { float x[XPT]; float r[RPT][2]; float w[HAS_SR ? RPT : 1][2]; };
+    // staged item v of this thread: component kk (of 128) and frame pair fp (of
+    // 32).  One wave instruction covers 32 components x 2 frame pairs: 128-byte
+    // row segments from global memory, and ds_write_b32 with at most 2 lanes per
+    // bank in the swizzled R^T image.
+    auto stage_item = [&](int v, int& kk, int& fp) {
+        const int slot = wave * RPT + v;
+        kk = 32 * (slot & 3) + (lane & 15) + 16 * (lane >> 5);
+        fp = 2 * (slot >> 2) + ((lane >> 4) & 1);
+    };
     // Loads are unconditional on clamped addresses and nothing is computed on the
     // loaded values here: a branch or an early use per load makes hipcc put an
     // s_waitcnt behind every one of them (one memory round trip each).  Scaling
@@ -426,8 +435,8 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
         }
 #pragma unroll
         for (int v = 0; v < RPT; ++v) {
-            const int e = tid + v * kA16Threads;
-            const int kk = e % (16 * kA16MC), fp = e / (16 * kA16MC);
+            int kk, fp;
+            stage_item(v, kk, fp);
             const int k = kc0 + kk, kc = k < K ? k : K - 1;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -438,23 +447,21 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
         }
         __builtin_amdgcn_sched_group_barrier(0x020, XPT + (HAS_SR ? 4 : 2) * RPT, 0);
     };
-    auto store_tile = [&](int buf, int64_t t0, const Stage& st) {
+    auto store_x = [&](int buf, int64_t t0, const Stage& st, int v) {
         float* xs = xs_of(buf);
+        const int64_t xvalid = (te - t0) * D;
+        const int idx = tid + v * kA16Threads;
+        const int f = idx / D, d = idx - f * D;
+        // threads past the tile write to the spare row behind the constants
+        const int at = idx < xcount ? d * kA16XS + f : (D + 2) * kA16XS + (tid & 63);
+        xs[at] = idx < xvalid ? st.x[v] * sx : 0.f;
+    };
+    auto store_r = [&](int buf, int64_t t0, const Stage& st, int v) {
         _Float16* rh = rh_of(buf);
         _Float16* rl = rh + r_halves;
-        const int64_t xvalid = (te - t0) * D;
-#pragma unroll
-        for (int v = 0; v < XPT; ++v) {
-            const int idx = tid + v * kA16Threads;
-            if (idx < xcount) {
-                const int f = idx / D, d = idx - f * D;
-                xs[d * kA16XS + f] = idx < xvalid ? st.x[v] * sx : 0.f;
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < RPT; ++v) {
-            const int e = tid + v * kA16Threads;
-            const int kk = e % (16 * kA16MC), fp = e / (16 * kA16MC);
+        {
+            int kk, fp;
+            stage_item(v, kk, fp);
             float r2[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -464,9 +471,16 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
             }
             hp2 hi, lo;
             split2(r2[0], r2[1], hi, lo);
-            *reinterpret_cast<hp2*>(rh + kk * kA16RS + 2 * fp) = hi;
-            *reinterpret_cast<hp2*>(rl + kk * kA16RS + 2 * fp) = lo;
+            const int at = kk * kA16RS + (((fp >> 2) ^ (kk & 7)) << 3) + 2 * (fp & 3);
+            *reinterpret_cast<hp2*>(rh + at) = hi;
+            *reinterpret_cast<hp2*>(rl + at) = lo;
         }
+    };
+    auto store_tile = [&](int buf, int64_t t0, const Stage& st) {
+#pragma unroll
+        for (int v = 0; v < XPT; ++v) store_x(buf, t0, st, v);
+#pragma unroll
+        for (int v = 0; v < RPT; ++v) store_r(buf, t0, st, v);
     };
 
     for (int buf = 0; buf < 2; ++buf) {                       // constant rows, both buffers
@@ -484,51 +498,93 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     if (ntiles > 0) { load_tile(tb, sa); store_tile(0, tb, sa); }
     if (ntiles > 1) load_tile(tb + kA16FT, sa);
     __syncthreads();
-    const bool active = tile0 * 16 < nq && !(dbg & 1);         // waves past the last tile idle
+    const bool active = tile0 * 16 < nq;         // waves past the last tile idle
     auto iteration = [&](int64_t tile, const Stage& held, Stage& far) {
         const int buf = (int)(tile & 1);
         const float* xs = xs_of(buf);
         const _Float16* rh = rh_of(buf);
         const _Float16* rl = rh + r_halves;
-        if (tile + 2 < ntiles && !(dbg & 2)) load_tile(tb + (tile + 2) * kA16FT, far);
+        if (tile + 2 < ntiles) load_tile(tb + (tile + 2) * kA16FT, far);
         if (active) {
-#pragma unroll 1
-            for (int ks = 0; ks < kA16FT / 32; ++ks) {
+            // B fragments are produced one (k-step, statistic tile) ahead of the
+            // MFMAs that consume them; sched_group_barrier spreads their LDS reads
+            // and the ~28 VALU of the split into the issue gaps of the 24 MFMAs.
+            auto gen_b = [&](int ks, int uu, h8& bh, h8& bl) {
                 const int f0 = 32 * ks + 8 * g;                 // the lane's 8 frames
+                const f32x4 xa0 = *reinterpret_cast<const f32x4*>(xs + ra[uu] + f0);
+                const f32x4 xa1 = *reinterpret_cast<const f32x4*>(xs + ra[uu] + f0 + 4);
+                const f32x4 xb0 = *reinterpret_cast<const f32x4*>(xs + rb[uu] + f0);
+                const f32x4 xb1 = *reinterpret_cast<const f32x4*>(xs + rb[uu] + f0 + 4);
+                split8(xa0 * xb0, xa1 * xb1, bh, bl);
+            };
+            h8 bh[2], bl[2];
+            gen_b(0, 0, bh[0], bl[0]);
+            static_assert(NQ == 1 || NQ % 2 == 0, "the B double buffer alternates per tile");
+#pragma unroll
+            for (int ks = 0; ks < kA16FT / 32; ++ks) {
                 h8 ah[kA16MC], al[kA16MC];
 #pragma unroll
                 for (int c = 0; c < kA16MC; ++c) {
-                    ah[c] = *reinterpret_cast<const h8*>(rh + (16 * c + i) * kA16RS + f0);
-                    al[c] = *reinterpret_cast<const h8*>(rl + (16 * c + i) * kA16RS + f0);
+                    const int at = (16 * c + i) * kA16RS + (((4 * ks + g) ^ (i & 7)) << 3);
+                    ah[c] = *reinterpret_cast<const h8*>(rh + at);
+                    al[c] = *reinterpret_cast<const h8*>(rl + at);
                 }
 #pragma unroll
                 for (int uu = 0; uu < NQ; ++uu) {
-                    const f32x4 xa0 = *reinterpret_cast<const f32x4*>(xs + ra[uu] + f0);
-                    const f32x4 xa1 = *reinterpret_cast<const f32x4*>(xs + ra[uu] + f0 + 4);
-                    const f32x4 xb0 = *reinterpret_cast<const f32x4*>(xs + rb[uu] + f0);
-                    const f32x4 xb1 = *reinterpret_cast<const f32x4*>(xs + rb[uu] + f0 + 4);
-                    h8 bh, bl;
-                    split8(xa0 * xb0, xa1 * xb1, bh, bl);
+                    // (the generation after the last tile of the last k-step reads
+                    // the next 32 frames of the padded rows and is never used)
+                    const int cur = NQ == 1 ? 0 : (uu & 1);
+                    const bool last = false;
+                    if (NQ == 1) {
+                        // no double buffer: generated in place after the MFMAs below
+                    } else {
+                        gen_b(uu + 1 < NQ ? ks : ks + 1, uu + 1 < NQ ? uu + 1 : 0, bh[cur ^ 1],
+                              bl[cur ^ 1]);
+                    }
 #pragma unroll
                     for (int c = 0; c < kA16MC; ++c)
-                        acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], bh, acc[c][uu], 0, 0, 0);
+                        acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], bh[cur], acc[c][uu], 0, 0, 0);
 #pragma unroll
                     for (int c = 0; c < kA16MC; ++c)
-                        acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], bl, acc[c][uu], 0, 0, 0);
+                        acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], bl[cur], acc[c][uu], 0, 0, 0);
 #pragma unroll
                     for (int c = 0; c < kA16MC; ++c)
-                        acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c], bh, acc[c][uu], 0, 0, 0);
+                        acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c], bh[cur], acc[c][uu], 0, 0, 0);
+                    if (NQ == 1) gen_b(ks + 1, 0, bh[0], bl[0]);
+                    // the slice of the next tile's staging that belongs to this step
+                    // (past the last tile this stores stale registers into the idle
+                    // buffer: harmless, and it keeps the loop free of branches)
+                    {
+                        constexpr int NSTEP = (kA16FT / 32) * NQ;
+                        const int step = ks * NQ + uu;
+#pragma unroll
+                        for (int v = step * RPT / NSTEP; v < (step + 1) * RPT / NSTEP; ++v)
+                            store_r(buf ^ 1, tb + (tile + 1) * kA16FT, held, v);
+#pragma unroll
+                        for (int v = step * XPT / NSTEP; v < (step + 1) * XPT / NSTEP; ++v)
+                            store_x(buf ^ 1, tb + (tile + 1) * kA16FT, held, v);
+                    }
+                    if (!last && NQ > 1) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);          // DS reads
+                        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);          // MFMA
+#pragma unroll
+                        for (int z = 0; z < 16; ++z) {
+                            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // VALU
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                        }
+                    }
                 }
+                // keep the A fragments of the next k-step from being hoisted up here
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (tile + 1 < ntiles && !(dbg & 4)) store_tile(buf ^ 1, tb + (tile + 1) * kA16FT, held);
+        if (!active) store_tile(buf ^ 1, tb + (tile + 1) * kA16FT, held);
         __syncthreads();
     };
     for (int64_t tile = 0; tile < ntiles; tile += 2) {
         iteration(tile, sa, sb);
         if (tile + 1 < ntiles) iteration(tile + 1, sb, sa);
     }
-    if (dbg & 8) return;
     // C rows = components kc0 + 16 c + 4 g + r, columns = statistic 16 tile + i;
     // undo the frame scaling (one factor sx per real column) and the 2^12 of R
     const double isx = (double)sc[1];
@@ -657,8 +713,7 @@ int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, con
     int64_t fpb = (nframes + gz - 1) / gz;
     fpb = (fpb + kA16FT - 1) / kA16FT * kA16FT;
     gz = (nframes + fpb - 1) / fpb;
-    const size_t lds = 2 * ((size_t)(D + 2) * kA16XS * 4 + (size_t)16 * kA16MC * kA16RS * 2 * 2);
-    const int dbg = getenv("BEER_DBG") ? atoi(getenv("BEER_DBG")) : 0;
+    const size_t lds = 2 * ((size_t)(D + 3) * kA16XS * 4 + (size_t)16 * kA16MC * kA16RS * 2 * 2);
     const int64_t nyz = ((int64_t)gy * gz + 7) / 8 * 8;
     const dim3 grid((unsigned)(nyz * gx));
 #define BEER_ACC16(NQ_, SR_)                                                                     \
@@ -666,7 +721,7 @@ int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, con
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc16_kernel<NQ_, SR_>),         \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
         hipLaunchKernelGGL((acc16_kernel<NQ_, SR_>), grid, dim3(kA16Threads), lds, s, nframes, D, \
-                           K, G, S, nslab, X, R, SR, tab, sc, fpb, Sp, gx, gy, (int)gz, dbg);    \
+                           K, G, S, nslab, X, R, SR, tab, sc, fpb, Sp, gx, gy, (int)gz);         \
     } while (0)
     if (SR) {
         if (NQ == 4) BEER_ACC16(4, true);
