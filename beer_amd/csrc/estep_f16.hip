@@ -48,13 +48,28 @@ constexpr int kPadBlocks = 4;          // look-ahead blocks behind the P image (
 // sc[0] = sx, sc[1] = 1 / sx, sc[2] = 1 / sx^2 from the bit pattern of max |x|
 __global__ void absmax_kernel(const float* __restrict__ X, int64_t n, unsigned* __restrict__ out) {
     float m = 0.f;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const float v = fabsf(X[idx]);
-        m = v > m ? v : m;                                   // NaN never wins
+    const int64_t n4 = n / 4;
+    const f32x4* X4 = reinterpret_cast<const f32x4*>(X);       // torch allocations are 16-B aligned
+    const bool aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (aligned) {
+        for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += stride) {
+            const f32x4 v = X4[idx];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = fabsf(v[e]);
+                m = a > m ? a : m;                               // NaN never wins
+            }
+        }
     }
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+    for (int64_t idx = (aligned ? n4 * 4 : 0) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+         idx < n; idx += stride) {
+        const float a = fabsf(X[idx]);
+        m = a > m ? a : m;
+    }
+    __shared__ float red[8];
+    m = block_max(m, red);                                     // one atomic per workgroup
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(m));
 }
 
 __global__ void scale_kernel(const unsigned* __restrict__ absmax, float* __restrict__ sc) {
@@ -424,32 +439,40 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     // loaded values here: a branch or an early use per load makes hipcc put an
     // s_waitcnt behind every one of them (one memory round trip each).  Scaling
     // and zeroing of the out-of-range elements happen when the tile is stored.
+    // Loads are unconditional on clamped addresses and nothing is computed on the
+    // loaded values here: a branch or an early use per load makes hipcc put an
+    // s_waitcnt behind every one of them (one memory round trip each).  Scaling
+    // and zeroing of the out-of-range elements happen when the tile is stored.
+    // Addresses are a uniform tile base + a 32-bit per-lane index.
+    const int kvalid = K - kc0 < 16 * kA16MC ? K - kc0 : 16 * kA16MC;      // >= 1
     auto load_tile = [&](int64_t t0, Stage& st) {
         const float* xsrc = X + t0 * D;
-        const int64_t xvalid = (te - t0) * D;
-        const int xlast = (int)(xvalid < xcount ? xvalid : xcount) - 1;      // >= 0
+        const int rows = (int)(te - t0 < kA16FT ? te - t0 : kA16FT);       // >= 1
+        const int xlast = rows * D - 1;
 #pragma unroll
         for (int v = 0; v < XPT; ++v) {
             const int idx = tid + v * kA16Threads;
             st.x[v] = xsrc[idx <= xlast ? idx : xlast];
         }
+        const float* Rt = R + t0 * K + kc0;
+        const float* Wt = HAS_SR ? SR + t0 * S : nullptr;
 #pragma unroll
         for (int v = 0; v < RPT; ++v) {
             int kk, fp;
             stage_item(v, kk, fp);
-            const int k = kc0 + kk, kc = k < K ? k : K - 1;
+            const int kcl = kk < kvalid ? kk : kvalid - 1;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int64_t f = t0 + 2 * fp + h, fc = f < te ? f : te - 1;
-                st.r[v][h] = R[fc * K + kc];
-                if (HAS_SR) st.w[v][h] = SR[fc * S + kc / G];
+                const int row = 2 * fp + h < rows ? 2 * fp + h : rows - 1;
+                st.r[v][h] = Rt[row * K + kcl];
+                if (HAS_SR) st.w[v][h] = Wt[row * S + (kc0 + kcl) / G];
             }
         }
         __builtin_amdgcn_sched_group_barrier(0x020, XPT + (HAS_SR ? 4 : 2) * RPT, 0);
     };
     auto store_x = [&](int buf, int64_t t0, const Stage& st, int v) {
         float* xs = xs_of(buf);
-        const int64_t xvalid = (te - t0) * D;
+        const int xvalid = (int)(te - t0 < kA16FT ? te - t0 : kA16FT) * D;
         const int idx = tid + v * kA16Threads;
         const int f = idx / D, d = idx - f * D;
         // threads past the tile write to the spare row behind the constants
@@ -459,22 +482,21 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     auto store_r = [&](int buf, int64_t t0, const Stage& st, int v) {
         _Float16* rh = rh_of(buf);
         _Float16* rl = rh + r_halves;
-        {
-            int kk, fp;
-            stage_item(v, kk, fp);
-            float r2[2];
+        const int rows = (int)(te - t0 < kA16FT ? te - t0 : kA16FT);
+        int kk, fp;
+        stage_item(v, kk, fp);
+        float r2[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float val = st.r[v][h] * (float)(1 << kRespBits);
-                if (HAS_SR) val *= st.w[v][h];
-                r2[h] = (t0 + 2 * fp + h < te && kc0 + kk < K) ? val : 0.f;
-            }
-            hp2 hi, lo;
-            split2(r2[0], r2[1], hi, lo);
-            const int at = kk * kA16RS + (((fp >> 2) ^ (kk & 7)) << 3) + 2 * (fp & 3);
-            *reinterpret_cast<hp2*>(rh + at) = hi;
-            *reinterpret_cast<hp2*>(rl + at) = lo;
+        for (int h = 0; h < 2; ++h) {
+            float val = st.r[v][h] * (float)(1 << kRespBits);
+            if (HAS_SR) val *= st.w[v][h];
+            r2[h] = (2 * fp + h < rows && kk < kvalid) ? val : 0.f;
         }
+        hp2 hi, lo;
+        split2(r2[0], r2[1], hi, lo);
+        const int at = kk * kA16RS + (((fp >> 2) ^ (kk & 7)) << 3) + 2 * (fp & 3);
+        *reinterpret_cast<hp2*>(rh + at) = hi;
+        *reinterpret_cast<hp2*>(rl + at) = lo;
     };
     auto store_tile = [&](int buf, int64_t t0, const Stage& st) {
 #pragma unroll
@@ -643,7 +665,7 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
     if (e != hipSuccess) return -(int)e;
     const int64_t n = nframes * D;
     int64_t ab = (n + 256 * 16 - 1) / (256 * 16);
-    if (ab > 2048) ab = 2048;
+    if (ab > 1024) ab = 1024;
     if (ab < 1) ab = 1;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)ab), dim3(256), 0, s, X, n, absmax);
     hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, s, absmax, sc);
@@ -694,7 +716,7 @@ int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, con
     if (e != hipSuccess) return -(int)e;
     const int64_t n = nframes * D;
     int64_t ab = (n + 256 * 16 - 1) / (256 * 16);
-    if (ab > 2048) ab = 2048;
+    if (ab > 1024) ab = 1024;
     if (ab < 1) ab = 1;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)ab), dim3(256), 0, s, X, n, absmax);
     hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, s, absmax, sc);

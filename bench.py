@@ -31,7 +31,8 @@ from beer_amd.distributed import all_reduce_elbo           # noqa: E402
 
 K, D = 256, 40
 Q = D * D + D + 2
-PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6}     # MI355X_MICROARCH.md (f32 MFMA); f64: datasheet
+# MI355X_MICROARCH.md: dense MFMA peaks (f32 operands; f16 operands / f32 accumulate)
+PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6, 'f16': 2500.}
 
 
 def synth_frames(n, device, seed):
@@ -280,6 +281,21 @@ def main():
         flops = 2. * K * Q * frames_per_launch
         kern[nm] = {'ms': ms, 'launches': n, 'tflops': flops / (ms * 1e-3) / 1e12}
     dom = max(kern, key=lambda nm: kern[nm]['ms'] * kern[nm]['launches'])
+    mode = beer.get_f32_mode()
+    split = mode == 'split_f16'
+    peak = PEAK_TFLOPS['f16' if split else 'f32']
+    if split:
+        note = ('fp32 operands are split into two fp16 halves and every product is three '
+                'v_mfma_f32_16x16x32_f16 (fp32 accumulate), so the peak is the dense fp16 MFMA '
+                'peak; achieved = algorithmic flops (2*K*Q per frame, no symmetry discount, '
+                'one flop pair per product) / HIP-event time of the C-ABI call.  The matrix '
+                'cores execute 3 * 2*K*928 flop per frame (1.70x the algorithmic count): '
+                'hardware rate = 1.70 * achieved.  The same call on the exact fp32 MFMA '
+                '(BEER_F32_MODE=exact, peak 157.3) ran at 174 TFLOP/s algorithmic.')
+    else:
+        note = ('achieved = algorithmic flops (2*K*Q per frame, no symmetry discount) / '
+                'HIP-event time of the C-ABI call; the kernels contract only the D(D+1)/2 '
+                'symmetric products (0.56x the multiply-adds), so frac can exceed 1')
     out = {
         'metric': 'frames/sec per VB iteration (E+M)', 'value': value, 'unit': 'frames/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -292,16 +308,14 @@ def main():
                    'components': K, 'dim': D},
         'elbo_rel_err_vs_cpu_fp64': rel_err,
         'elbo_per_frame': float(elbo) / (len(lengths) * world * datasize),
+        'f32_mode': mode,
         'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'],
-                     'peak': PEAK_TFLOPS['f32'], 'unit': 'TFLOP/s',
-                     'frac': kern[dom]['tflops'] / PEAK_TFLOPS['f32'],
-                     'traffic': pmc_traffic('acc_kernel' if 'accumulate' in dom
-                                            else 'llh_kernel'),
+                     'peak': peak, 'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / peak,
+                     'traffic': pmc_traffic(('acc16_kernel' if split else 'acc_kernel')
+                                            if 'accumulate' in dom else
+                                            ('llh16_kernel' if split else 'llh_kernel')),
                      'avg_launch_ms': kern[dom]['ms'],
-                     'note': 'achieved = algorithmic flops (2*K*Q per frame, no symmetry '
-                             'discount) / HIP-event time of the C-ABI call; the kernels '
-                             'contract only the D(D+1)/2 symmetric products (0.56x the '
-                             'multiply-adds), so frac can exceed 1'},
+                     'note': note},
         'kernels': kern,
     }
     if not args.no_cpu_baseline:
