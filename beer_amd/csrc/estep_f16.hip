@@ -45,51 +45,76 @@ __host__ __device__ inline int nk16_of(int cov, int D) {
 }
 constexpr int kPadBlocks = 4;          // look-ahead blocks behind the P image (a quarter k-step)
 
-// sc[0] = sx, sc[1] = 1 / sx, sc[2] = 1 / sx^2 from the bit pattern of max |x|
-__global__ void absmax_kernel(const float* __restrict__ X, int64_t n, unsigned* __restrict__ out) {
+// Per-dimension frame scaling: sc[d] = s_d, a power of two with |x_d s_d| < 2^7,
+// sc[64 + d] = 1 / s_d (D <= 64).  One scale per dimension rather than one for
+// the whole matrix: features of very different magnitude (an energy next to
+// cepstra, unnormalised filter-bank outputs) keep their own fp16 range.
+// absmax[d] = bit pattern of max_t |x_td|: one wave reads one frame per step
+// (lane = dimension), no atomics until the end.
+__global__ __launch_bounds__(512) void absmax_kernel(const float* __restrict__ X, int64_t nframes,
+                                                     int D, unsigned* __restrict__ out) {
+    __shared__ float red[8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     float m = 0.f;
-    const int64_t n4 = n / 4;
-    const f32x4* X4 = reinterpret_cast<const f32x4*>(X);       // torch allocations are 16-B aligned
-    const bool aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    if (aligned) {
-        for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += stride) {
-            const f32x4 v = X4[idx];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a = fabsf(v[e]);
-                m = a > m ? a : m;                               // NaN never wins
-            }
+    if (lane < D) {
+        int64_t f = (int64_t)blockIdx.x * nwave + wave;
+        const int64_t stride = (int64_t)gridDim.x * nwave;
+        // four frames in flight per wave
+        for (; f + 3 * stride < nframes; f += 4 * stride) {
+            const float a = fabsf(X[f * D + lane]), b = fabsf(X[(f + stride) * D + lane]);
+            const float c = fabsf(X[(f + 2 * stride) * D + lane]);
+            const float d = fabsf(X[(f + 3 * stride) * D + lane]);
+            const float ab = a > b ? a : b, cd = c > d ? c : d, q = ab > cd ? ab : cd;
+            m = q > m ? q : m;                                   // NaN never wins
+        }
+        for (; f < nframes; f += stride) {
+            const float a = fabsf(X[f * D + lane]);
+            m = a > m ? a : m;
         }
     }
-    for (int64_t idx = (aligned ? n4 * 4 : 0) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-         idx < n; idx += stride) {
-        const float a = fabsf(X[idx]);
-        m = a > m ? a : m;
+    red[wave][lane] = m;
+    __syncthreads();
+    if (wave == 0 && lane < D) {
+        for (int w = 1; w < nwave; ++w) m = red[w][lane] > m ? red[w][lane] : m;
+        atomicMax(out + lane, __float_as_uint(m));
     }
-    __shared__ float red[8];
-    m = block_max(m, red);                                     // one atomic per workgroup
-    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(m));
 }
 
-__global__ void scale_kernel(const unsigned* __restrict__ absmax, float* __restrict__ sc) {
-    const float m = __uint_as_float(*absmax);
+__global__ void scale_kernel(const unsigned* __restrict__ absmax, int D, float* __restrict__ sc) {
+    const int d = threadIdx.x;
+    if (d >= 64) return;
     float sx = 1.f;
-    if (m > 0.f && m < 3.0e38f) {
-        int e;
-        frexpf(m, &e);                                       // m < 2^e
-        sx = ldexpf(1.f, kScaleBits - e);
+    if (d < D) {
+        const float m = __uint_as_float(absmax[d]);
+        if (m > 0.f && m < 3.0e38f) {
+            int e;
+            frexpf(m, &e);                                       // m < 2^e
+            sx = ldexpf(1.f, kScaleBits - e);
+        }
     }
-    sc[0] = sx;
-    sc[1] = 1.f / sx;
-    sc[2] = (1.f / sx) * (1.f / sx);
+    sc[d] = sx;
+    sc[64 + d] = 1.f / sx;
+}
+
+int launch_scales(const float* X, int64_t nframes, int D, unsigned* absmax, float* sc,
+                  hipStream_t s) {
+    hipError_t e = hipMemsetAsync(absmax, 0, 64 * sizeof(unsigned), s);
+    if (e != hipSuccess) return -(int)e;
+    int64_t blocks = (nframes + 8 * 16 - 1) / (8 * 16);
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(512), 0, s, X, nframes, D,
+                       absmax);
+    hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(64), 0, s, absmax, D, sc);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
 }
 
 // Value of contraction entry (slab, e) for component k (the logic of
 // pack_kernel in estep_mfma.hip) times the inverse frame scaling.
 __device__ inline double entry_value(int cov, int D, int K, int k, int slab, int e,
                                      const float* __restrict__ E, const float* __restrict__ logw,
-                                     double isx, double isx2, bool* is_const) {
+                                     const float* __restrict__ isx, bool* is_const) {
     const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(cov, D), Q = stats_dim(cov, D);
     *is_const = false;
     if (slab >= nslab) return 0.0;
@@ -99,13 +124,16 @@ __device__ inline double entry_value(int cov, int D, int K, int k, int slab, int
     if (constant) *is_const = (e == 0);
     if (k >= K) return 0.0;
     const float* row = E + (size_t)k * Q;
-    if (sq) return b < D ? -0.5 * (double)row[cov == BEER_ISO ? D : D + b] * isx2 : 0.0;
+    if (sq)
+        return b < D ? -0.5 * (double)row[cov == BEER_ISO ? D : D + b] * (double)isx[b] * (double)isx[b]
+                     : 0.0;
     if (a < D) {
         if (b >= D || b < a) return 0.0;
         return (b == a ? -0.5 * (double)row[D + a * D + a]
-                       : -0.5 * ((double)row[D + a * D + b] + (double)row[D + b * D + a])) * isx2;
+                       : -0.5 * ((double)row[D + a * D + b] + (double)row[D + b * D + a])) *
+               (double)isx[a] * (double)isx[b];
     }
-    if (!constant) return b < D ? (double)row[b] * isx : 0.0;
+    if (!constant) return b < D ? (double)row[b] * (double)isx[b] : 0.0;
     if (e != 0) return 0.0;
     const double zero = cov == BEER_ISO ? 0.5 * (double)D : 0.5;
     return -0.5 * (double)row[Q - 2] + zero * (double)row[Q - 1] - 0.5 * (double)D * kLog2Pi +
@@ -123,7 +151,7 @@ __global__ void pack16_kernel(int cov, int D, int K, int NT, const float* __rest
     const int k = blockIdx.x;
     const int chunk = k / (NT * 16), kk = k % (NT * 16);
     const int c = 4 * (kk / 64) + (kk % 4), i = (kk % 64) / 4;
-    const double isx = (double)sc[1], isx2 = (double)sc[2];
+    const float* isx = sc + 64;
     if (k == 0)
         for (int s = threadIdx.x; s < (nk + 1) * 8; s += blockDim.x) {
             // padding slabs read the zero columns behind the "1" of a frame row
@@ -133,7 +161,7 @@ __global__ void pack16_kernel(int cov, int D, int K, int NT, const float* __rest
     double mx = 0.0;
     bool dummy;
     for (int q = threadIdx.x; q < nent; q += blockDim.x) {
-        const double v = fabs(entry_value(cov, D, K, k, q / 4, q % 4, E, logw, isx, isx2, &dummy));
+        const double v = fabs(entry_value(cov, D, K, k, q / 4, q % 4, E, logw, isx, &dummy));
         mx = v > mx ? v : mx;
     }
     mx = block_max(mx, red);
@@ -147,7 +175,7 @@ __global__ void pack16_kernel(int cov, int D, int K, int NT, const float* __rest
     _Float16* base = P + ((size_t)chunk * nk * NT) * 1024;
     for (int q = threadIdx.x; q < nent; q += blockDim.x) {
         bool is_const;
-        double v = entry_value(cov, D, K, k, q / 4, q % 4, E, logw, isx, isx2, &is_const) * scale;
+        double v = entry_value(cov, D, K, k, q / 4, q % 4, E, logw, isx, &is_const) * scale;
         if (k >= K) v = is_const ? -1.0 : 0.0;            // padded component: logit -1e30
         const float vf = (float)v;
         const _Float16 hi = (_Float16)vf;
@@ -200,14 +228,13 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     float* xw = reinterpret_cast<float*>(smem) + wave * (FW * LD);
     int* tabs = reinterpret_cast<int*>(reinterpret_cast<float*>(smem) + (kThreads / 64) * FW * LD);
     const int64_t fb = ((int64_t)blockIdx.x * (kThreads / 64) + wave) * FW;
-    const float sx = sc[0];
     for (int idx = tid; idx < (nk + 1) * 8; idx += kThreads) tabs[idx] = tab[idx];
 
     for (int idx = lane; idx < FW * LD; idx += 64) {
         const int r = idx / LD, c = idx - r * LD;
         const int64_t f = fb + r;
         float v = 0.f;
-        if (c < D) { if (f < nframes) v = X[f * D + c] * sx; }
+        if (c < D) { if (f < nframes) v = X[f * D + c] * sc[c]; }
         else if (c == Dp) v = 1.f;
         xw[idx] = v;
     }
@@ -386,11 +413,12 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     const int kc0 = by * (16 * kA16MC);
     const int64_t tb = (int64_t)bz * frames_per_block;
     const int64_t te = tb + frames_per_block < nframes ? tb + frames_per_block : nframes;
-    const float sx = sc[0];
 
     const int xs_elems = (D + 3) * kA16XS;                     // floats (+ a spare row)
     const int r_halves = 16 * kA16MC * kA16RS;                 // per hi / lo image
     const size_t buf_bytes = (size_t)xs_elems * 4 + (size_t)r_halves * 2 * 2;
+    float* sxs = reinterpret_cast<float*>(smem + 2 * buf_bytes);          // the 64 frame scales
+    if (tid < 64) sxs[tid] = sc[tid];
     auto xs_of = [&](int buf) { return reinterpret_cast<float*>(smem + buf * buf_bytes); };
     auto rh_of = [&](int buf) {
         return reinterpret_cast<_Float16*>(smem + buf * buf_bytes + (size_t)xs_elems * 4);
@@ -477,7 +505,7 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
         const int f = idx / D, d = idx - f * D;
         // threads past the tile write to the spare row behind the constants
         const int at = idx < xcount ? d * kA16XS + f : (D + 2) * kA16XS + (tid & 63);
-        xs[at] = idx < xvalid ? st.x[v] * sx : 0.f;
+        xs[at] = idx < xvalid ? st.x[v] * sxs[d] : 0.f;
     };
     auto store_r = [&](int buf, int64_t t0, const Stage& st, int v) {
         _Float16* rh = rh_of(buf);
@@ -609,14 +637,15 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     }
     // C rows = components kc0 + 16 c + 4 g + r, columns = statistic 16 tile + i;
     // undo the frame scaling (one factor sx per real column) and the 2^12 of R
-    const double isx = (double)sc[1];
+    const float* isx = sc + 64;
 #pragma unroll
     for (int uu = 0; uu < NQ; ++uu) {
         const int q = (tile0 + uu) * 16 + i;
         if (q >= nq) continue;
         int a, b;
         factors(uu, a, b);
-        const double unscale = (a < D ? isx : 1.0) * (b < D ? isx : 1.0) / (double)(1 << kRespBits);
+        const double unscale = (a < D ? (double)isx[a] : 1.0) * (b < D ? (double)isx[b] : 1.0) /
+                               (double)(1 << kRespBits);
 #pragma unroll
         for (int c = 0; c < kA16MC; ++c)
 #pragma unroll
@@ -641,7 +670,7 @@ size_t estep16_workspace_bytes(int cov, int D, int S, int G) {
     const size_t kpad = (size_t)nchunks * NT * 16;
     return up256(((size_t)nchunks * nk16_of(cov, D) * NT + kPadBlocks) * 2048) +
            up256(kpad * sizeof(float)) + up256((size_t)(nk16_of(cov, D) + 1) * 8 * sizeof(int)) +
-           256;
+           1024;
 }
 
 int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, const float* expT,
@@ -660,15 +689,9 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
     int* tab = reinterpret_cast<int*>(w);
     w += up256((size_t)(nk + 1) * 8 * sizeof(int));
     unsigned* absmax = reinterpret_cast<unsigned*>(w);
-    float* sc = reinterpret_cast<float*>(w + 16);
-    hipError_t e = hipMemsetAsync(absmax, 0, sizeof(unsigned), s);
-    if (e != hipSuccess) return -(int)e;
-    const int64_t n = nframes * D;
-    int64_t ab = (n + 256 * 16 - 1) / (256 * 16);
-    if (ab > 1024) ab = 1024;
-    if (ab < 1) ab = 1;
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)ab), dim3(256), 0, s, X, n, absmax);
-    hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, s, absmax, sc);
+    float* sc = reinterpret_cast<float*>(w + 256);
+    const int rc = launch_scales(X, nframes, D, absmax, sc, s);
+    if (rc != BEER_OK) return rc;
     hipLaunchKernelGGL(pack16_kernel, dim3(kpad), dim3(256), 0, s, cov, D, K, NT, expT, logw, sc, P,
                        inv_scale, tab);
     BEER_LAUNCH_CHECK();
@@ -695,7 +718,7 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
 size_t acc16_workspace_bytes(int cov, int D, int K) {
     if (!supported_acc(D, K)) return 0;
     const int nslab = nslab_of(cov, D);
-    return up256((size_t)K * nslab * 4 * sizeof(double)) + up256((size_t)nslab * sizeof(int)) + 256;
+    return up256((size_t)K * nslab * 4 * sizeof(double)) + up256((size_t)nslab * sizeof(int)) + 1024;
 }
 
 int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, const float* R,
@@ -709,17 +732,11 @@ int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, con
     int* tab = reinterpret_cast<int*>(w);
     w += up256((size_t)nslab * sizeof(int));
     unsigned* absmax = reinterpret_cast<unsigned*>(w);
-    float* sc = reinterpret_cast<float*>(w + 16);
-    hipError_t e = hipMemsetAsync(absmax, 0, sizeof(unsigned), s);
+    float* sc = reinterpret_cast<float*>(w + 256);
+    hipError_t e = hipMemsetAsync(Sp, 0, (size_t)K * nq * sizeof(double), s);
     if (e != hipSuccess) return -(int)e;
-    e = hipMemsetAsync(Sp, 0, (size_t)K * nq * sizeof(double), s);
-    if (e != hipSuccess) return -(int)e;
-    const int64_t n = nframes * D;
-    int64_t ab = (n + 256 * 16 - 1) / (256 * 16);
-    if (ab > 1024) ab = 1024;
-    if (ab < 1) ab = 1;
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)ab), dim3(256), 0, s, X, n, absmax);
-    hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(1), 0, s, absmax, sc);
+    const int rc = launch_scales(X, nframes, D, absmax, sc, s);
+    if (rc != BEER_OK) return rc;
     hipLaunchKernelGGL(tab_kernel, dim3(1), dim3(256), 0, s, cov, D, tab);
     BEER_LAUNCH_CHECK();
     const int ntiles = (nq + 15) / 16;
@@ -735,7 +752,7 @@ int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, con
     int64_t fpb = (nframes + gz - 1) / gz;
     fpb = (fpb + kA16FT - 1) / kA16FT * kA16FT;
     gz = (nframes + fpb - 1) / fpb;
-    const size_t lds = 2 * ((size_t)(D + 3) * kA16XS * 4 + (size_t)16 * kA16MC * kA16RS * 2 * 2);
+    const size_t lds = 2 * ((size_t)(D + 3) * kA16XS * 4 + (size_t)16 * kA16MC * kA16RS * 2 * 2) + 256;
     const int64_t nyz = ((int64_t)gy * gz + 7) / 8 * 8;
     const dim3 grid((unsigned)(nyz * gx));
 #define BEER_ACC16(NQ_, SR_)                                                                     \

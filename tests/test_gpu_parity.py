@@ -653,3 +653,48 @@ def test_sparse_alignment_graphs_equal_dense_graphs():
     e1 = beer.evidence_lower_bound(ploop, u0, datasize=1000, inference_graph=dense[0])
     e2 = beer.evidence_lower_bound(ploop, u0, datasize=1000, inference_graph=sparse[0])
     assert float(e1) == float(e2)
+
+
+# --- float32 models: exact fp32 MFMA vs the fp16-split matrix path ------------------------------------
+
+@pytest.mark.parametrize('cov,K,D', [('full', 256, 40), ('diagonal', 64, 24), ('full', 48, 13)])
+def test_f32_modes_agree_with_fp64(cov, K, D):
+    '''Both ways of multiplying float32 on the matrix cores (exact fp32 MFMA;
+    two fp16 halves per operand, three fp16 MFMAs per product) against the fp64
+    kernels on the same inputs: per-frame log-normaliser, responsibilities and
+    accumulated statistics.  Badly scaled features (one dimension 1000x the
+    others, an offset of 50) exercise the power-of-two range scaling.'''
+    from beer_amd import kernels
+    torch.manual_seed(3)
+    T = 20000
+    X = torch.randn(T, D, dtype=torch.float64, device=DEV) * 2 + 50.
+    X[:, 0] *= 1000.
+    X[:, 1] *= 1e-3
+    ns = beer.NormalSet.create(X.mean(0).cpu(), torch.diag(X.var(0).cpu()), size=K,
+                               prior_strength=1., noise_std=.5, cov_type=cov)
+    model = beer.Mixture.create(ns).double().to(DEV)
+    E64 = ns.means_precisions.natural_form()
+    lw64 = model._log_weights().view(1, K)
+    st64 = beer.FrameStats(X, cov)
+    ln64, r64 = kernels.mixtureset_estep(st64, E64, lw64, 1, K, cov)
+    acc64 = kernels.normal_accumulate(st64, r64, None, K, 1, cov)
+    st32 = beer.FrameStats(X.float(), cov)
+    old = beer.get_f32_mode()
+    err = {}
+    try:
+        for mode in ('exact', 'split_f16'):
+            beer.set_f32_mode(mode)
+            assert beer.get_f32_mode() == mode
+            ln, r = kernels.mixtureset_estep(st32, E64.float(), lw64.float(), 1, K, cov)
+            acc = kernels.normal_accumulate(st32, r64.float(), None, K, 1, cov)
+            rel = ((acc - acc64).abs() / (acc64.abs() + 1e-4 * acc64.abs().amax(0, keepdim=True)))
+            err[mode] = (float((ln.double() - ln64).abs().max()),
+                         float((acc - acc64).abs().max() / acc64.abs().max()), float(rel.max()),
+                         abs(float(-2 * acc[:, -2].sum()) - T) / T)
+    finally:
+        beer.set_f32_mode(old)
+    # the split path may lose a small factor against the exact fp32 products
+    # (2^-21 vs 2^-24 per product, same fp32 accumulation), never more
+    for e_exact, e_split in zip(err['exact'], err['split_f16']):
+        assert e_split <= 4. * e_exact + 1e-7, (err['exact'], err['split_f16'])
+    assert err['split_f16'][1] <= 2e-6 and err['split_f16'][3] <= 2e-6, err['split_f16']

@@ -292,3 +292,13 @@ def test_native_compile_equals_python_oracle_and_batch_builder():
     assert_close(got.trans_log_probs.exp().numpy(), trans, 1e-6)
     with pytest.raises(_hip.HipError):
         beer.graph.compile_alignments([[]], units)                  # empty transcription
+
+
+def test_f32_mode_switch():
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    assert lib.beer_hip_set_f32_mode(7) == _hip.EINVAL
+    old = _hip.get_f32_mode()
+    for mode in ('exact', 'split_f16'):
+        _hip.set_f32_mode(mode)
+        assert _hip.get_f32_mode() == mode
+    _hip.set_f32_mode(old)

@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 PMC passes of `bench.py` into profiles/<round>_pmc.json.
+
+    python tools/pmc_summary.py r01 gpurun_out/pmc_a gpurun_out/pmc_b gpurun_out/pmc_c
+
+Each directory holds one `rocprofv3 --kernel-trace --pmc ...` pass.  Only the
+full-size launches (1 M frames) of the four E-step kernels are kept; the
+filtered rows are written next to the summary as <round>_pmc_pass<i>.csv.
+GRBM_GUI_ACTIVE is summed over the 8 XCDs; FETCH_SIZE / WRITE_SIZE are KiB as
+reported (MI355X_MICROARCH.md: FETCH_SIZE under-reports 16 B/lane coalesced
+reads by 2x; corrected where bench.py uses it, raw here).
+"""
+
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+KERNELS = {'llh16_kernel': 'llh16_kernel', 'acc16_kernel': 'acc16_kernel',
+           'llh_kernel<': 'llh_kernel', 'acc_kernel<': 'acc_kernel'}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    rnd, dirs = sys.argv[1], sys.argv[2:]
+    out = collections.defaultdict(dict)
+    for i, d in enumerate(dirs, start=1):
+        f = glob.glob(os.path.join(d, '*', '*counter_collection.csv'))[0]
+        rows = list(csv.DictReader(open(f)))
+        keep = []
+        per = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in rows:
+            key = next((v for k, v in KERNELS.items() if k in r['Kernel_Name']), None)
+            if key is None:
+                continue
+            keep.append(r)
+            dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
+            per[key][r['Counter_Name']].append((float(r['Counter_Value']), dur))
+        for key, counters in per.items():
+            for name, vals in counters.items():
+                big = max(v for v, _ in vals)
+                full = [(v, t) for v, t in vals if v > .5 * big] or vals     # full-size launches
+                out[key][name] = sum(v for v, _ in full) / len(full)
+                out[key][name + '_ms'] = sum(t for _, t in full) / len(full)
+        with open(os.path.join(ROOT, 'profiles', f'{rnd}_pmc_pass{i}.csv'), 'w', newline='') as g:
+            w = csv.DictWriter(g, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(keep)
+    for key, k in out.items():
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in k and 'GRBM_GUI_ACTIVE' in k:
+            cycles = k['GRBM_GUI_ACTIVE'] / 8.                   # per XCD
+            k['mfma_util'] = k['SQ_VALU_MFMA_BUSY_CYCLES'] / (cycles * 1024)
+            k['clock_ghz'] = cycles / (k['GRBM_GUI_ACTIVE_ms'] * 1e6)
+        if 'FETCH_SIZE' in k:
+            k['hbm_read_bytes_raw'] = k['FETCH_SIZE'] * 1024
+        if 'WRITE_SIZE' in k:
+            k['hbm_write_bytes'] = k['WRITE_SIZE'] * 1024
+    path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc.json')
+    old = json.load(open(path))['kernels'] if os.path.exists(path) else {}
+    old.update(out)
+    json.dump({'source': 'rocprofv3 --kernel-trace --pmc (separate passes) -- python bench.py '
+                         '--steps 3 --warmup 1 --no-cpu-baseline; full-size (1 M frame) launches '
+                         'only; see tools/pmc_summary.py', 'kernels': old},
+              open(path, 'w'), indent=1)
+    for key, k in out.items():
+        print(key, {n: round(v, 4) for n, v in k.items() if n in ('mfma_util', 'clock_ghz')},
+              k.get('hbm_read_bytes_raw'), k.get('hbm_write_bytes'))
+
+
+if __name__ == '__main__':
+    main()
