@@ -137,6 +137,7 @@ SIGNATURES = {
     'beer_features_deltas': [ctypes.c_int32, c_p, c_l, ctypes.c_int32, ctypes.c_int32,
                              ctypes.c_int32, c_p, c_p, c_p],
     'beer_features_cmn': [ctypes.c_int32, c_p, ctypes.c_int32, ctypes.c_int32, c_p, c_p],
+    'beer_copy_pinned': [c_p, c_p, c_z, c_p],
     'beer_suffstats_mean': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p],
     'beer_suffstats_backward': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
 }
@@ -263,6 +264,54 @@ def workspace(query, dtype, cov, D, S, G, device):
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf, nbytes
+
+
+_staging_ring = []          # [(pinned buffer, event)], reused round-robin
+_staging_next = [0]
+
+
+def _staging(nbytes):
+    '''A pinned staging buffer of at least `nbytes` from a small ring that is
+    allocated once and grown rarely: `hipHostMalloc` takes tens of ms and
+    synchronises the device, so it must not happen per batch.'''
+    if not _staging_ring:
+        for _ in range(4):
+            _staging_ring.append([torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True),
+                                  torch.cuda.Event()])
+    slot = _staging_ring[_staging_next[0] % len(_staging_ring)]
+    _staging_next[0] += 1
+    slot[1].synchronize()                      # the copy that last used it has run
+    if slot[0].numel() < nbytes:
+        slot[0] = torch.empty(max(nbytes, 2 * slot[0].numel()), dtype=torch.uint8,
+                              pin_memory=True)
+    return slot[0], slot[1]
+
+
+def upload(tensors, device):
+    '''Copy a dict of small host tensors to the GPU as ONE asynchronous
+    transfer from pinned memory; returns {name: device view}.  Dozens of
+    pageable `tensor.to(device)` copies each make the host wait for the stream
+    (and were seen to stall it for tens of ms inside an iteration).'''
+    names, metas, total = [], [], 0
+    for name, t in tensors.items():
+        t = t.detach().contiguous()
+        nbytes = t.numel() * t.element_size()
+        names.append(name)
+        metas.append((t, total, nbytes))
+        total = (total + nbytes + 15) // 16 * 16
+    host, done = _staging(max(total, 16))
+    for t, off, nbytes in metas:
+        if nbytes:
+            host[off:off + nbytes] = t.reshape(-1).view(torch.uint8)
+    nbytes = (max(total, 16) + 15) // 16 * 16
+    blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    call('beer_copy_pinned', ptr(blob), ctypes.c_void_p(host.data_ptr()), nbytes)
+    done.record()
+    out = {}
+    for name, (t, off, nbytes) in zip(names, metas):
+        out[name] = blob[off:off + nbytes].view(t.dtype).view(t.shape)
+    out['_blob'] = blob
+    return out
 
 
 def struct_to_device(obj, device):

@@ -382,6 +382,7 @@ int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, in
 // ---------------------------------------------------------------------------
 constexpr int kA16Threads = 256;     // 4 waves, one per SIMD: 512 registers per lane
 constexpr int kA16MC = 8;            // component tiles per workgroup (128 components)
+constexpr int kA16MCsr = 4;          // ... when state responsibilities are multiplied in
 constexpr int kA16FT = 64;           // frames per LDS tile (2 k-steps)
 constexpr int kA16XS = kA16FT + 4;   // X^T row stride (floats), 16-byte aligned
 constexpr int kA16RS = kA16FT;       // R^T row = 8 chunks of 8 frames (16 B), chunk c of row
@@ -395,6 +396,9 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     const float* __restrict__ R, const float* __restrict__ SR, const int* __restrict__ tab,
     const float* __restrict__ sc, int64_t frames_per_block, double* __restrict__ Sp, int gx,
     int gy, int gz) {
+    // with state responsibilities the staging registers double: half the component
+    // tile keeps the kernel free of spills
+    constexpr int MC = HAS_SR ? kA16MCsr : kA16MC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -410,12 +414,12 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     if (yz >= gy * gz) return;
     const int by = yz % gy, bz = yz / gy;
     const int tile0 = (bx * (kA16Threads / 64) + wave) * NQ;    // first statistic tile
-    const int kc0 = by * (16 * kA16MC);
+    const int kc0 = by * (16 * MC);
     const int64_t tb = (int64_t)bz * frames_per_block;
     const int64_t te = tb + frames_per_block < nframes ? tb + frames_per_block : nframes;
 
     const int xs_elems = (D + 3) * kA16XS;                     // floats (+ a spare row)
-    const int r_halves = 16 * kA16MC * kA16RS;                 // per hi / lo image
+    const int r_halves = 16 * MC * kA16RS;                 // per hi / lo image
     const size_t buf_bytes = (size_t)xs_elems * 4 + (size_t)r_halves * 2 * 2;
     float* sxs = reinterpret_cast<float*>(smem + 2 * buf_bytes);          // the 64 frame scales
     if (tid < 64) sxs[tid] = sc[tid];
@@ -443,14 +447,14 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
         ra[uu] = (a < D ? a : (a == Dp ? D : D + 1)) * kA16XS;
         rb[uu] = (b < D ? b : (b == Dp ? D : D + 1)) * kA16XS;
     }
-    f32x4 acc[kA16MC][NQ];
+    f32x4 acc[MC][NQ];
 #pragma unroll
-    for (int c = 0; c < kA16MC; ++c)
+    for (int c = 0; c < MC; ++c)
 #pragma unroll
         for (int uu = 0; uu < NQ; ++uu) acc[c][uu] = f32x4{0, 0, 0, 0};
 
     // staging registers (global -> registers during the MFMAs -> other LDS buffer)
-    constexpr int RPT = 16 * kA16MC * (kA16FT / 2) / kA16Threads;    // (component, frame pair)
+    constexpr int RPT = 16 * MC * (kA16FT / 2) / kA16Threads;    // (component, frame pair)
     constexpr int XPT = (kA16FT * 64 + kA16Threads - 1) / kA16Threads;   // D <= 64
     const int xcount = kA16FT * D;
     struct Stage { float x[XPT]; float r[RPT][2]; float w[HAS_SR ? RPT : 1][2]; };
@@ -460,8 +464,9 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     // bank in the swizzled R^T image.
     auto stage_item = [&](int v, int& kk, int& fp) {
         const int slot = wave * RPT + v;
-        kk = 32 * (slot & 3) + (lane & 15) + 16 * (lane >> 5);
-        fp = 2 * (slot >> 2) + ((lane >> 4) & 1);
+        constexpr int NB = MC / 2;                              // blocks of 32 components
+        kk = 32 * (slot % NB) + (lane & 15) + 16 * (lane >> 5);
+        fp = 2 * (slot / NB) + ((lane >> 4) & 1);
     };
     // Loads are unconditional on clamped addresses and nothing is computed on the
     // loaded values here: a branch or an early use per load makes hipcc put an
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     // s_waitcnt behind every one of them (one memory round trip each).  Scaling
     // and zeroing of the out-of-range elements happen when the tile is stored.
     // Addresses are a uniform tile base + a 32-bit per-lane index.
-    const int kvalid = K - kc0 < 16 * kA16MC ? K - kc0 : 16 * kA16MC;      // >= 1
+    const int kvalid = K - kc0 < 16 * MC ? K - kc0 : 16 * MC;      // >= 1
     auto load_tile = [&](int64_t t0, Stage& st) {
         const float* xsrc = X + t0 * D;
         const int rows = (int)(te - t0 < kA16FT ? te - t0 : kA16FT);       // >= 1
@@ -572,9 +577,9 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
             static_assert(NQ == 1 || NQ % 2 == 0, "the B double buffer alternates per tile");
 #pragma unroll
             for (int ks = 0; ks < kA16FT / 32; ++ks) {
-                h8 ah[kA16MC], al[kA16MC];
+                h8 ah[MC], al[MC];
 #pragma unroll
-                for (int c = 0; c < kA16MC; ++c) {
+                for (int c = 0; c < MC; ++c) {
                     const int at = (16 * c + i) * kA16RS + (((4 * ks + g) ^ (i & 7)) << 3);
                     ah[c] = *reinterpret_cast<const h8*>(rh + at);
                     al[c] = *reinterpret_cast<const h8*>(rl + at);
@@ -592,13 +597,13 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
                               bl[cur ^ 1]);
                     }
 #pragma unroll
-                    for (int c = 0; c < kA16MC; ++c)
+                    for (int c = 0; c < MC; ++c)
                         acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], bh[cur], acc[c][uu], 0, 0, 0);
 #pragma unroll
-                    for (int c = 0; c < kA16MC; ++c)
+                    for (int c = 0; c < MC; ++c)
                         acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], bl[cur], acc[c][uu], 0, 0, 0);
 #pragma unroll
-                    for (int c = 0; c < kA16MC; ++c)
+                    for (int c = 0; c < MC; ++c)
                         acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c], bh[cur], acc[c][uu], 0, 0, 0);
                     if (NQ == 1) gen_b(ks + 1, 0, bh[0], bl[0]);
                     // the slice of the next tile's staging that belongs to this step
@@ -647,7 +652,7 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
         const double unscale = (a < D ? (double)isx[a] : 1.0) * (b < D ? (double)isx[b] : 1.0) /
                                (double)(1 << kRespBits);
 #pragma unroll
-        for (int c = 0; c < kA16MC; ++c)
+        for (int c = 0; c < MC; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = kc0 + 16 * c + 4 * g + r;
@@ -743,7 +748,8 @@ int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, con
     const int waves = kA16Threads / 64;
     const int NQ = ntiles > 2 * waves ? 4 : (ntiles > waves ? 2 : 1);
     const int gx = (ntiles + NQ * waves - 1) / (NQ * waves);
-    const int gy = (K + 16 * kA16MC - 1) / (16 * kA16MC);
+    const int mc = SR ? kA16MCsr : kA16MC;
+    const int gy = (K + 16 * mc - 1) / (16 * mc);
     int64_t gz = (1024 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy);
     const int64_t max_z = (nframes + 1023) / 1024, min_z = (nframes + kA16MaxFrames - 1) / kA16MaxFrames;
     if (gz > max_z) gz = max_z;
@@ -752,7 +758,7 @@ int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, con
     int64_t fpb = (nframes + gz - 1) / gz;
     fpb = (fpb + kA16FT - 1) / kA16FT * kA16FT;
     gz = (nframes + fpb - 1) / fpb;
-    const size_t lds = 2 * ((size_t)(D + 3) * kA16XS * 4 + (size_t)16 * kA16MC * kA16RS * 2 * 2) + 256;
+    const size_t lds = 2 * ((size_t)(D + 3) * kA16XS * 4 + (size_t)16 * mc * kA16RS * 2 * 2) + 256;
     const int64_t nyz = ((int64_t)gy * gz + 7) / 8 * 8;
     const dim3 grid((unsigned)(nyz * gx));
 #define BEER_ACC16(NQ_, SR_)                                                                     \

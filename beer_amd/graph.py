@@ -209,12 +209,13 @@ class GraphSet:
             code = _hip.dtype_code(dtype)
             nbytes = ctypes.c_size_t()
             _hip.call_host('beer_graphset_image_bytes', self._handle, code, ctypes.byref(nbytes))
-            host = torch.empty(max(16, nbytes.value), dtype=torch.uint8)
+            host = torch.empty(max(16, nbytes.value), dtype=torch.uint8, pin_memory=True)
             blob = torch.empty(max(16, nbytes.value), dtype=torch.uint8, device=dev)
             structs = (_hip.Graph * max(1, self.n))()
             _hip.call_host('beer_graphset_image', self._handle, code,
                            ctypes.c_void_p(host.data_ptr()), blob.data_ptr(), structs)
-            blob.copy_(host)
+            blob.copy_(host, non_blocking=True)
+            self._host_image = host                  # keep the pinned source until the copy ran
             memo = self._images[dtype] = (blob, structs)
         return memo
 
@@ -333,23 +334,21 @@ class DeviceGraph:
         in_seg, in_row_seg = self._segments(in_ptr)
         out_seg, out_row_seg = self._segments(out_ptr)
         self.n_in_seg, self.n_out_seg = len(in_seg) - 1, len(out_seg) - 1
-        self.bufs = dict(
-            init=init.detach().to(device, dtype).contiguous(),
-            final=final.detach().to(device, dtype).contiguous(),
-            in_ptr=in_ptr.to(device), in_src=src.to(torch.int32).to(device),
-            in_dst=dst.to(torch.int32).to(device),
-            in_w=in_w.to(device, dtype).contiguous(),
-            in_seg=in_seg.to(device), in_row_seg=in_row_seg.to(device),
-            out_ptr=out_ptr.to(device), out_dst=dst2.to(torch.int32).to(device),
-            out_src=src2.to(torch.int32).to(device),
-            out_w=out_w.to(device, dtype).contiguous(),
-            out_seg=out_seg.to(device), out_row_seg=out_row_seg.to(device))
+        i32 = lambda t: t.to(torch.int32)                       # noqa: E731
+        self.bufs = _hip.upload(dict(
+            init=init.detach().to('cpu', dtype), final=final.detach().to('cpu', dtype),
+            in_ptr=in_ptr, in_src=i32(src), in_dst=i32(dst), in_w=in_w.to(dtype),
+            in_seg=in_seg, in_row_seg=in_row_seg,
+            out_ptr=out_ptr, out_dst=i32(dst2), out_src=i32(src2), out_w=out_w.to(dtype),
+            out_seg=out_seg, out_row_seg=out_row_seg), device)
         b = self.bufs
         p = lambda name: b[name].data_ptr()                     # noqa: E731
         self.lowdeg = self._lowdeg(trans.detach().to('cpu'), finite, hubs, device, dtype)
         lowdeg_ptr = 0
         if self.lowdeg is not None:
-            b['lowdeg_struct'] = _hip.struct_to_device(self.lowdeg, device)
+            b['lowdeg_struct'] = _hip.upload(
+                {'s': torch.frombuffer(bytearray(bytes(self.lowdeg)), dtype=torch.uint8)},
+                device)['s']
             lowdeg_ptr = b['lowdeg_struct'].data_ptr()
         self.struct = _hip.Graph(S, self.n_arcs, self.n_in_seg, self.n_out_seg,
                                  p('init'), p('final'),
@@ -402,23 +401,46 @@ class DeviceGraph:
         src_o, dst_o = torch.nonzero(keep, as_tuple=True)
         out_ptr = torch.zeros(S + 1, dtype=torch.int32)
         out_ptr[1:] = torch.cumsum(torch.bincount(src_o, minlength=S), 0).to(torch.int32)
-        i32 = lambda v: torch.as_tensor(v, dtype=torch.int32).to(device)       # noqa: E731
+        i32 = lambda v: torch.as_tensor(v, dtype=torch.int32)                  # noqa: E731
         b = self.bufs
-        b.update(
-            ld_in_ptr=in_ptr.to(device), ld_in_src=i32(src_i),
-            ld_in_w=trans_h[src_i, dst_i].to(device, dtype).contiguous(),
-            ld_out_ptr=out_ptr.to(device), ld_out_dst=i32(dst_o),
-            ld_out_w=trans_h[src_o, dst_o].to(device, dtype).contiguous(),
-            ld_src_id=src_id.to(device), ld_src_w=src_w.to(device, dtype),
-            ld_dst_id=dst_id.to(device), ld_dst_w=dst_w.to(device, dtype),
+        ld = _hip.upload(dict(
+            ld_in_ptr=in_ptr, ld_in_src=i32(src_i), ld_in_w=trans_h[src_i, dst_i].to(dtype),
+            ld_in_dst=i32(dst_i), ld_out_src=i32(src_o),
+            ld_out_ptr=out_ptr, ld_out_dst=i32(dst_o), ld_out_w=trans_h[src_o, dst_o].to(dtype),
+            ld_src_id=src_id, ld_src_w=src_w.to(dtype), ld_dst_id=dst_id, ld_dst_w=dst_w.to(dtype),
             ld_src_ptr=i32(src_ptr), ld_src_list=i32(src_list if src_list else [0]),
-            ld_dst_ptr=i32(dst_ptr), ld_dst_list=i32(dst_list if dst_list else [0]))
+            ld_dst_ptr=i32(dst_ptr), ld_dst_list=i32(dst_list if dst_list else [0])), device)
+        ld['_ld_blob'] = ld.pop('_blob')
+        b.update(ld)
+        self._hub_ptr = (list(src_ptr), list(dst_ptr))
         q = lambda name: b[name].data_ptr()                      # noqa: E731
         return _hip.GraphLowDeg(
             int(src_i.numel()), len(hubs), q('ld_in_ptr'), q('ld_in_src'), q('ld_in_w'),
             q('ld_out_ptr'), q('ld_out_dst'), q('ld_out_w'), q('ld_src_id'), q('ld_src_w'),
             q('ld_dst_id'), q('ld_dst_w'), q('ld_src_ptr'), q('ld_src_list'), q('ld_dst_ptr'),
             q('ld_dst_list'))
+
+    def refresh(self, trans):
+        '''New transition log-probabilities on the SAME sparsity pattern (the
+        phone-loop weights were rewritten): every weight array of the image
+        is re-gathered from the dense matrix by device index tensors -- no
+        host round trip, the descriptors keep their addresses.'''
+        b = self.bufs
+        dtype = b['in_w'].dtype
+        t = trans.detach()
+        idx = lambda name: b[name].long()                        # noqa: E731
+        b['in_w'].copy_(t[idx('in_src'), idx('in_dst')].to(dtype))
+        b['out_w'].copy_(t[idx('out_src'), idx('out_dst')].to(dtype))
+        if self.lowdeg is not None:
+            if b['ld_in_w'].numel():
+                b['ld_in_w'].copy_(t[idx('ld_in_src'), idx('ld_in_dst')].to(dtype))
+                b['ld_out_w'].copy_(t[idx('ld_out_src'), idx('ld_out_dst')].to(dtype))
+            for h in range(self.lowdeg.n_hubs):
+                src = b['ld_src_list'][self._hub_ptr[0][h]:self._hub_ptr[0][h + 1]].long()
+                dst = b['ld_dst_list'][self._hub_ptr[1][h]:self._hub_ptr[1][h + 1]].long()
+                # A[e, s] = A[e, 0] + (A[0, s] - A[0, 0]), as when the image was built
+                b['ld_src_w'][src] = t[src, dst[0]].to(dtype)
+                b['ld_dst_w'][dst] = (t[src[0], dst].double() - t[src[0], dst[0]].double()).to(dtype)
 
     @staticmethod
     def _segments(ptr):
@@ -449,9 +471,18 @@ class CompiledGraph(torch.nn.Module):
         dst_log_w[None, :] (the P x P block a phone loop's eliminated pivot
         state leaves behind).  Purely an acceleration hint: the dense matrix
         stays authoritative and the hint is verified before use.'''
+        old = self.__dict__.get('hubs') or []       # (absent on graphs unpickled from the reference)
+        same = len(old) == 1 and old[0][0] == list(src_states) and old[0][2] == list(dst_states)
         self.hubs = [(list(src_states), src_log_w.detach().clone(), list(dst_states),
                       dst_log_w.detach().clone())]
-        self.__dict__.pop('_device_memo', None)
+        if not same:
+            self.__dict__.pop('_device_memo', None)
+
+    def weights_rewritten(self):
+        '''Tell the graph that `trans_log_probs` was rewritten in place on the
+        same sparsity pattern (finite entries stay finite): its device image
+        is then refreshed on the device instead of being rebuilt.'''
+        self.__dict__['_weights_rewritten'] = True
 
     def __repr__(self):
         return '<CompiledGraph>'
@@ -463,6 +494,8 @@ class CompiledGraph(torch.nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state.pop('_device_memo', None)
+        state.pop('_weights_rewritten', None)
+        state.pop('_batch_cache', None)
         return state
 
     def device_graph(self, dtype):
@@ -472,9 +505,15 @@ class CompiledGraph(torch.nn.Module):
         tensors = (self.init_log_probs, self.final_log_probs, self.trans_log_probs)
         sig = tuple(t._version for t in tensors)
         memo = self.__dict__.get('_device_memo')
-        if memo is not None and memo[0] == dtype and memo[2] == sig and \
-                all(a is b for a, b in zip(memo[1], tensors)):
-            return memo[3]
+        if memo is not None and memo[0] == dtype and all(a is b for a, b in zip(memo[1], tensors)):
+            if memo[2] == sig:
+                return memo[3]
+            if self.__dict__.pop('_weights_rewritten', False) and memo[2][:2] == sig[:2] and \
+                    self.trans_log_probs.device.type == 'cuda':
+                memo[3].refresh(self.trans_log_probs)
+                self.__dict__['_device_memo'] = (dtype, tensors, sig, memo[3])
+                return memo[3]
+        self.__dict__.pop('_weights_rewritten', None)
         dg = DeviceGraph(*tensors, device=_hip.require_device(), dtype=dtype,
                          hubs=self.__dict__.get('hubs', ()))
         self.__dict__['_device_memo'] = (dtype, tensors, sig, dg)

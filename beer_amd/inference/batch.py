@@ -70,11 +70,18 @@ def _normalset(group):
 
 
 def _sub_batches(lengths, bytes_per_frame, max_frames):
-    'Split utterance indices into runs whose scratch fits the budget.'
+    '''Split utterance indices into runs whose scratch fits the budget.  The
+    runs are balanced (same number of frames, within an utterance) rather than
+    filled greedily: equal-sized scratch tensors are recycled by the caching
+    allocator, unequal ones make it hipMalloc / hipFree gigabytes every
+    iteration (25 ms stalls at config 3).'''
     budget = max(1, min(max_frames, _SCRATCH_BYTES // max(1, bytes_per_frame)))
+    total = sum(lengths)
+    n_runs = max(1, -(-total // budget))
+    target = -(-total // n_runs)
     runs, cur, n = [], [], 0
     for u, T in enumerate(lengths):
-        if cur and n + T > budget:
+        if cur and (n + T > budget or (n >= target and len(runs) < n_runs - 1)):
             runs.append(cur)
             cur, n = [], 0
         cur.append(u)
@@ -82,6 +89,43 @@ def _sub_batches(lengths, bytes_per_frame, max_frames):
     if cur:
         runs.append(cur)
     return runs
+
+
+_in_flight = []
+
+
+def _throttle(depth=2):
+    '''Keep the host at most `depth` sub-batches ahead of the GPU.  Every
+    sub-batch allocates gigabytes of scratch (responsibilities, per-state
+    likelihoods); a host that queues many of them before the first has run
+    makes the caching allocator hipMalloc new blocks instead of recycling --
+    tens of ms each, and the stream waits for them.'''
+    while len(_in_flight) >= depth:
+        _in_flight.pop(0).synchronize()
+    ev = torch.cuda.Event()
+    _in_flight.append(ev)
+    return ev
+
+
+def _cached_batch(graph, run_lengths, dtype):
+    '''Batch descriptor of utterances that all use `graph` (the free phone
+    loop).  Training iterates over the same shard again and again: the
+    descriptor is kept on the graph and reused as long as the graph's device
+    image is the same object (its weights are refreshed in place), so the
+    steady-state iteration has no host -> device copy at all.'''
+    cache = graph.__dict__.setdefault('_batch_cache', {})
+    key = (dtype, tuple(run_lengths))
+    dg = graph.device_graph(dtype)
+    hit = cache.get(key)
+    if hit is not None and hit.dgraphs[0] is dg:
+        hit.struct.all_lowdeg = hit.lowdeg_default       # forward_backward may have cleared it
+        return hit
+    if len(cache) >= 8:
+        cache.clear()
+    batch = hk.HmmBatch([graph], [0] * len(run_lengths), run_lengths, dtype)
+    batch.lowdeg_default = batch.struct.all_lowdeg
+    cache[key] = batch
+    return batch
 
 
 def _finish(model, value_terms, kl, nutt, acc, datasize, total_frames):
@@ -105,16 +149,25 @@ def _mixture_batch(model, X, lengths, datasize, labels, max_frames):
     utt_llh = torch.zeros(len(lengths), dtype=torch.float64, device=dev)
     off = torch.zeros(len(lengths) + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(torch.as_tensor(lengths, dtype=torch.int64), 0)
-    for run in _sub_batches(lengths, K * X.element_size(), max_frames):
-        f0, f1 = int(off[run[0]]), int(off[run[-1] + 1])
-        stats = FrameStats(X[f0:f1], cov)
-        lab = None if labels is None else labels[f0:f1]
-        log_norm, resps = kernels.mixtureset_estep(stats, exp_T, lw, 1, K, cov, labels=lab)
-        seg = (off[run[0]:run[-1] + 2] - f0).to(dev)
-        hk.segment_sum(log_norm.view(-1), seg, len(run), out=utt_llh[run[0]:run[-1] + 1])
-        kernels.normal_accumulate(stats, resps, None, K, 1, cov, acc=acc)
+    # every host -> device copy happens here, BEFORE the first big kernel: a copy
+    # from pageable memory makes the host wait for the stream, and one issued
+    # after the E-step kernels would keep the host from queueing the M-step
+    # launches while those kernels run
+    off_dev = off.to(dev)
     scales = torch.as_tensor([datasize / float(T) for T in lengths], dtype=torch.float64,
                              device=dev)
+    lab_dev = None if labels is None else \
+        _hip.on_device(torch.as_tensor(labels)).to(torch.int64).contiguous()
+    for run in _sub_batches(lengths, K * X.element_size(), max_frames):
+        done = _throttle()
+        f0, f1 = int(off[run[0]]), int(off[run[-1] + 1])
+        stats = FrameStats(X[f0:f1], cov)
+        lab = None if lab_dev is None else lab_dev[f0:f1]
+        log_norm, resps = kernels.mixtureset_estep(stats, exp_T, lw, 1, K, cov, labels=lab)
+        seg = off_dev[run[0]:run[-1] + 2] - f0
+        hk.segment_sum(log_norm.view(-1), seg, len(run), out=utt_llh[run[0]:run[-1] + 1])
+        kernels.normal_accumulate(stats, resps, None, K, 1, cov, acc=acc)
+        done.record()
     value_terms = (scales * utt_llh).sum()
     wparam = model.categorical.mean_field_factorization()[0][0]
     if isinstance(model.categorical, SBCategorical):
@@ -156,16 +209,21 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
     utt_llh = torch.zeros(nutt, dtype=torch.float64, device=dev)
     off = torch.zeros(nutt + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(torch.as_tensor(lengths, dtype=torch.int64), 0)
+    scales = torch.as_tensor([datasize / float(T) for T in lengths], dtype=torch.float64,
+                             device=dev)
     xi_tot = g0_tot = flow_tot = None
     max_S = model.graph.n_states if free_loop else max(g.n_states for g in graphs)
     bpf = (K_max + 2 * S_total) * X.element_size() + max_S * (3 * X.element_size() + 8)
     for run in _sub_batches(lengths, bpf, max_frames):
+        done = _throttle()
         f0, f1 = int(off[run[0]]), int(off[run[-1] + 1])
         run_lengths = [lengths[u] for u in run]
+        # the emission E-step is queued first: building the batch descriptor (host
+        # work + one asynchronous copy from pinned memory) overlaps with it
         stats = FrameStats(X[f0:f1], _normalset(groups[0][0]).cov_type)
         pc_all, comps = _emission_estep(groups, stats, dtype)
         if free_loop:
-            batch = hk.HmmBatch([model.graph], [0] * len(run), run_lengths, dtype)
+            batch = _cached_batch(model.graph, run_lengths, dtype)
         else:
             uniq, ids, seen = [], [], {}
             for u in run:
@@ -202,8 +260,7 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
                 kernels.normal_accumulate(gstats, sr_g, None, S, 1, ns.cov_type, acc=acc)
             else:
                 kernels.normal_accumulate(gstats, comp, sr_g, S, G, ns.cov_type, acc=acc)
-    scales = torch.as_tensor([datasize / float(T) for T in lengths], dtype=torch.float64,
-                             device=dev)
+        done.record()
     value_terms = (scales * utt_llh).sum()
     out = {}
     for (grp, S, G), acc in zip(groups, accs):

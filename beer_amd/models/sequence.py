@@ -159,16 +159,21 @@ class PhoneLoop(HMM):
         log_weights = self.categorical.log_weights().to(dtype=trans.dtype,
                                                         device=trans.device)
         start_idxs = list(self.start_pdf.values())
-        residuals = []
-        for end_idx in self.end_pdf.values():
-            loop_prob = trans[end_idx, end_idx].exp()
-            residuals.append((1 - loop_prob).log())
-            trans[end_idx, start_idxs] = residuals[-1] + log_weights
+        end_idxs = list(self.end_pdf.values())
+        # all phones at once (the reference loops over them; same elementwise ops)
+        ends = torch.as_tensor(end_idxs, device=trans.device)
+        starts = torch.as_tensor(start_idxs, device=trans.device)
+        residuals = (1 - trans[ends, ends].exp()).log()
+        if len(set(end_idxs)) == len(end_idxs):
+            trans[ends[:, None], starts[None, :]] = residuals[:, None] + log_weights[None, :]
+        else:                                    # repeated end states: last write wins
+            for i, end_idx in enumerate(end_idxs):
+                trans[end_idx, start_idxs] = residuals[i] + log_weights
+        self.graph.weights_rewritten()
         # the block just written is rank one: tell the graph, so that
         # forward-backward can treat the eliminated pivot state as a hub
-        end_idxs = list(self.end_pdf.values())
         if len(set(end_idxs)) == len(end_idxs) and len(set(start_idxs)) == len(start_idxs):
-            self.graph.set_hub(end_idxs, torch.stack(residuals), start_idxs, log_weights)
+            self.graph.set_hub(end_idxs, residuals, start_idxs, log_weights)
 
     def mean_field_factorization(self):
         from .mixtures import _merge_groups

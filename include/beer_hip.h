@@ -474,6 +474,14 @@ int beer_features_deltas(int32_t nutt, const int64_t* frame_off, int64_t total_f
 int beer_features_cmn(int32_t nutt, const int64_t* frame_off, int32_t D, int32_t ld,
                       double* x, void* stream);
 
+/* Copy `nbytes` (a multiple of 16, both pointers 16-byte aligned) from PINNED
+ * host memory to device memory with a kernel on `stream`.  Used for the small
+ * batch / graph descriptors: a copy-engine transfer queued behind running
+ * kernels was measured to stall the stream for tens of ms on this platform; a
+ * kernel that reads the pinned pages directly does not. */
+int beer_copy_pinned(void* dst_device, const void* src_pinned_host, size_t nbytes,
+                     void* stream);
+
 /* ---- graph compilation (HOST functions: host pointers, no stream) -----------
  * Graph.compile (beer/graph.py:185-240) and create_graph_from_seq
  * (beer/cli/subcommands/hmm/mkaligraph.py:18-39) in O(states + arcs), for one

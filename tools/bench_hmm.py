@@ -90,6 +90,10 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--ali-utts', type=int, default=0, help='also time N utterances with '
                     'alignment graphs')
+    ap.add_argument('--gc', default='freeze', choices=['freeze', 'default', 'off'],
+                    help='Python garbage collector during the timed loops: freeze the set-up '
+                         'objects (default; a generation-2 collection over them costs 25-40 ms '
+                         'every few iterations), leave it alone, or switch it off')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     rng = np.random.RandomState(2)
@@ -112,7 +116,14 @@ def main():
         optim.step()
         return elbo
 
-    run(None, X, lengths)
+    for _ in range(2):                                  # allocator + workspaces settle
+        run(None, X, lengths)
+    import gc
+    if args.gc == 'freeze':
+        gc.collect()
+        gc.freeze()
+    elif args.gc == 'off':
+        gc.disable()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -150,7 +161,11 @@ def main():
             'value': bench.cpu_baseline_graph_compile(seqs[:m], units, beer.graph.Graph),
             'unit': 's/utterance', 'cores': 1, 'kind': 'port', 'sample': f'{m} utterances'}
         Xs = X[:sum(sub)]
-        run(graphs, Xs, sub)
+        for _ in range(2):
+            run(graphs, Xs, sub)
+        if args.gc == 'freeze':
+            gc.collect()
+            gc.freeze()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
