@@ -138,6 +138,7 @@ SIGNATURES = {
                              ctypes.c_int32, c_p, c_p, c_p],
     'beer_features_cmn': [ctypes.c_int32, c_p, ctypes.c_int32, ctypes.c_int32, c_p, c_p],
     'beer_copy_pinned': [c_p, c_p, c_z, c_p],
+    'beer_f32_split_hazard': [c_l, c_i, c_p, c_p, c_p, c_p],
     'beer_suffstats_mean': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p],
     'beer_suffstats_backward': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
 }
@@ -239,6 +240,45 @@ def set_f32_mode(mode):
 def get_f32_mode():
     code = lib().beer_hip_get_f32_mode()
     return {v: k for k, v in F32_MODES.items()}[code]
+
+
+# frames smaller than this always take the exact fp32 path (it costs microseconds
+# there, and the range check below would cost a synchronisation per utterance)
+SPLIT_MIN_FRAMES = 16384
+_range_memo = {}
+
+
+def f32_split_ok(X):
+    '''True when float32 frames `X` [T, D] may take the fp16-split matrix path:
+    the mode is on, there are enough frames, and no dimension has outliers more
+    than 2^9 times its mean magnitude (checked once per tensor version on the
+    GPU; one small synchronisation the first time a tensor is seen).'''
+    if X.dtype != torch.float32 or get_f32_mode() != 'split_f16':
+        return False
+    if X.shape[0] < SPLIT_MIN_FRAMES or X.shape[1] > 64:
+        return False
+    key = (X.data_ptr(), tuple(X.shape), X._version)
+    hit = _range_memo.get(key)
+    if hit is None:
+        scratch = torch.empty(1024, dtype=torch.uint8, device=X.device)
+        flag = torch.empty(1, dtype=torch.int32, device=X.device)
+        call('beer_f32_split_hazard', X.shape[0], X.shape[1], ptr(X), ptr(scratch), ptr(flag))
+        hit = int(flag.item()) == 0
+        if len(_range_memo) > 64:
+            _range_memo.clear()
+        _range_memo[key] = hit
+    return hit
+
+
+class exact_f32:
+    'Context manager: float32 matrix products on the exact fp32 MFMA inside.'
+
+    def __enter__(self):
+        self.old = get_f32_mode()
+        set_f32_mode('exact')
+
+    def __exit__(self, *exc):
+        set_f32_mode(self.old)
 
 
 def call_host(name, *args):

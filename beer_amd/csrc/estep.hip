@@ -501,6 +501,15 @@ int beer_hip_set_f32_mode(int mode) {
 
 int beer_hip_get_f32_mode(void) { return f32_mode(); }
 
+int beer_f32_split_hazard(int64_t T, int D, const void* X, void* scratch, int* hazard,
+                          void* stream) {
+    BEER_REQUIRE(T >= 0 && D >= 1 && D <= 64 && scratch && hazard);
+    if (T == 0) return hipMemsetAsync(hazard, 0, sizeof(int), as_stream(stream)) == hipSuccess
+                           ? BEER_OK : BEER_EINVAL;
+    BEER_REQUIRE(X);
+    return beer_mfma::f16_range_hazard(T, D, (const float*)X, scratch, hazard, as_stream(stream));
+}
+
 size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G) {
     if (cov < 0 || cov > 2) return 0;
     const size_t exact = beer_mfma::acc_workspace_bytes(cov, D, S * G);

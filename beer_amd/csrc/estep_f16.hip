@@ -96,6 +96,42 @@ __global__ void scale_kernel(const unsigned* __restrict__ absmax, int D, float* 
     sc[64 + d] = 1.f / sx;
 }
 
+// sum_t |x_td| per dimension (same access pattern as absmax_kernel)
+__global__ __launch_bounds__(512) void abssum_kernel(const float* __restrict__ X, int64_t nframes,
+                                                     int D, double* __restrict__ out) {
+    __shared__ double red[8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    double m = 0.0;
+    if (lane < D)
+        for (int64_t f = (int64_t)blockIdx.x * nwave + wave; f < nframes;
+             f += (int64_t)gridDim.x * nwave) {
+            const float a = fabsf(X[f * D + lane]);
+            if (a == a && a < 3.0e38f) m += (double)a;
+        }
+    red[wave][lane] = m;
+    __syncthreads();
+    if (wave == 0 && lane < D) {
+        for (int w = 1; w < nwave; ++w) m += red[w][lane];
+        atomicAdd(out + lane, m);
+    }
+}
+
+// hazard = 1 when some dimension's largest magnitude is more than 2^kRangeBits
+// times its mean magnitude: after scaling the maximum to 2^7, the products of
+// typical values would fall into fp16's subnormals (< 2^-14) and lose bits.
+constexpr int kRangeBits = 9;
+__global__ void hazard_kernel(const unsigned* __restrict__ absmax, const double* __restrict__ abssum,
+                              int64_t nframes, int D, int* __restrict__ hazard) {
+    int bad = 0;
+    for (int d = 0; d < D; ++d) {
+        const double mx = (double)__uint_as_float(absmax[d]);
+        const double mean = abssum[d] / (double)(nframes > 0 ? nframes : 1);
+        if (!(mx < 3.0e38)) bad = 1;                               // inf / huge values
+        if (mean > 0.0 && mx > ldexp(mean, kRangeBits)) bad = 1;
+    }
+    *hazard = bad;
+}
+
 int launch_scales(const float* X, int64_t nframes, int D, unsigned* absmax, float* sc,
                   hipStream_t s) {
     hipError_t e = hipMemsetAsync(absmax, 0, 64 * sizeof(unsigned), s);
@@ -668,6 +704,23 @@ inline int nchunks16_for(int S, int K) { return S > 1 ? (K + 255) / 256 : 1; }
 size_t up256(size_t n) { return (n + 255) / 256 * 256; }
 
 }  // namespace
+
+int f16_range_hazard(int64_t nframes, int D, const float* X, void* scratch, int* hazard,
+                     hipStream_t s) {
+    // scratch: 64 unsigned + 64 double
+    unsigned* absmax = reinterpret_cast<unsigned*>(scratch);
+    double* abssum = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + 256);
+    hipError_t e = hipMemsetAsync(scratch, 0, 256 + 512, s);
+    if (e != hipSuccess) return -(int)e;
+    int64_t blocks = (nframes + 8 * 16 - 1) / (8 * 16);
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(512), 0, s, X, nframes, D, absmax);
+    hipLaunchKernelGGL(abssum_kernel, dim3((unsigned)blocks), dim3(512), 0, s, X, nframes, D, abssum);
+    hipLaunchKernelGGL(hazard_kernel, dim3(1), dim3(1), 0, s, absmax, abssum, nframes, D, hazard);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
 
 size_t estep16_workspace_bytes(int cov, int D, int S, int G) {
     if (!supported_llh(D, S, G)) return 0;

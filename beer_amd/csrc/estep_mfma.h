@@ -21,6 +21,10 @@ int estep_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const f
                 const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
                 size_t ws_bytes, hipStream_t s);
 
+// 1 in *hazard (device) when the split path would lose accuracy on these frames
+// (a dimension whose maximum is > 2^9 times its mean magnitude); scratch >= 768 B.
+int f16_range_hazard(int64_t T, int D, const float* X, void* scratch, int* hazard,
+                     hipStream_t s);
 size_t acc16_workspace_bytes(int cov, int D, int K);
 int acc_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* R,
               const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s);

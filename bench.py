@@ -185,7 +185,7 @@ def pmc_traffic(kernel_key):
         return None
 
 
-def elbo_check(model, X, n=8192):
+def elbo_check(model, X, n=16384):
     'ELBO of the first n frames: HIP path vs fp64 oracle on identical inputs.'
     from oracle import beer_oracle as orc
     p0, p1 = list(model.bayesian_parameters())

@@ -62,6 +62,15 @@ int beer_hip_device_count(void);
 #define BEER_F32_SPLIT_F16 1
 int beer_hip_set_f32_mode(int mode);
 int beer_hip_get_f32_mode(void);
+/* Range check for BEER_F32_SPLIT_F16 on float32 frames X [T, D] (D <= 64):
+ * *hazard (device int) = 1 when some dimension's largest magnitude exceeds 2^9
+ * times its mean magnitude (or is not finite).  The split path scales every
+ * dimension so that its maximum is 2^7; values that far below the maximum
+ * would have their products rounded in fp16's subnormal range.  The host
+ * layer runs this once per data tensor and uses the exact path for such data.
+ * scratch: >= 768 bytes of device memory. */
+int beer_f32_split_hazard(int64_t T, int D, const void* X, void* scratch,
+                          int* hazard, void* stream);
 
 /* ------------------------------------------------------------------------
  * Exponential-family parameter kernels (once per VB iteration, K = number of

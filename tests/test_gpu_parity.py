@@ -698,3 +698,32 @@ def test_f32_modes_agree_with_fp64(cov, K, D):
     for e_exact, e_split in zip(err['exact'], err['split_f16']):
         assert e_split <= 4. * e_exact + 1e-7, (err['exact'], err['split_f16'])
     assert err['split_f16'][1] <= 2e-6 and err['split_f16'][3] <= 2e-6, err['split_f16']
+
+
+def test_f32_split_path_is_skipped_for_outliers_and_small_inputs():
+    '''Frames with an outlier 10^5 times the typical magnitude (or too few
+    frames) take the exact fp32 path even in split mode: identical results.'''
+    from beer_amd import _hip, kernels
+    torch.manual_seed(5)
+    T, D, K = 20000, 16, 32
+    X = torch.randn(T, D, device=DEV)
+    ns = beer.NormalSet.create(torch.zeros(D), torch.ones(D), size=K, cov_type='full')
+    model = beer.Mixture.create(ns).to(DEV)
+    E, lw = ns.means_precisions.natural_form(), model._log_weights().view(1, K)
+    assert _hip.get_f32_mode() == 'split_f16'
+    assert _hip.f32_split_ok(X)
+    assert not _hip.f32_split_ok(X[:1000])                       # small: exact
+    Xo = X.clone()
+    Xo[123, 3] = 1.0e5
+    assert not _hip.f32_split_ok(Xo)
+    ln_auto, r_auto = kernels.mixtureset_estep(beer.FrameStats(Xo, 'full'), E, lw, 1, K, 'full')
+    with _hip.exact_f32():
+        ln_exact, r_exact = kernels.mixtureset_estep(beer.FrameStats(Xo, 'full'), E, lw, 1, K,
+                                                     'full')
+    assert torch.equal(ln_auto, ln_exact) and torch.equal(r_auto, r_exact)
+    assert _hip.get_f32_mode() == 'split_f16'
+    # in-place modification of the data is noticed (tensor version)
+    Y = X.clone()
+    assert _hip.f32_split_ok(Y)
+    Y[5, 2] = float('inf')
+    assert not _hip.f32_split_ok(Y)
