@@ -1,3 +1,9 @@
+#!/usr/bin/env python
+"""Time `beer_normal_accumulate` alone at the config-3 shape (K = 1920 = 120 states x
+16 components, state responsibilities multiplied in), diagonal and full covariance.
+
+    python tools/time_accumulate.py
+"""
 import sys, torch, time
 sys.path.insert(0, '/root/repo')
 import beer_amd as beer
