@@ -344,8 +344,14 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
     // (pc_llh only, or G == 1 log_norm only) pass 1 alone is enough.
     const bool need_norm = (log_norm || comp_resps || llh_sum) && !labels;
     void* w_buf = comp_resps;
-    if (need_norm && !w_buf) {
-        // G == 1: log_norm == w; let pass 1 write into log_norm directly.
+    const bool mfma_ok = !labels && !pc_llh && stat_scale == 1.0 && ws &&
+                         beer_mfma::supported_llh(D, S, G) &&
+                         ws_bytes >= beer_mfma::estep_workspace_bytes(sizeof(T), cov, D, S, G) &&
+                         (log_norm || comp_resps || llh_sum);
+    if (need_norm && !w_buf && !mfma_ok) {
+        // G == 1: log_norm == w; let pass 1 write into log_norm directly (the
+        // matrix-core path keeps the responsibilities in registers and needs no
+        // buffer for any G).
         BEER_REQUIRE(G == 1 && log_norm);
         w_buf = log_norm;
     }
@@ -354,9 +360,7 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
     BEER_REQUIRE(!labels || pc_arg);
     void* w_arg = labels ? nullptr : (need_norm ? w_buf : nullptr);
 
-    if (!labels && !pc_llh && stat_scale == 1.0 && ws && beer_mfma::supported_llh(D, S, G) &&
-        ws_bytes >= beer_mfma::estep_workspace_bytes(sizeof(T), cov, D, S, G) &&
-        (log_norm || comp_resps || llh_sum)) {
+    if (mfma_ok) {
         // gfx950 matrix-core path: GEMM + (grouped) softmax fused, one kernel
         if (sizeof(T) == 4 && f32_mode() == BEER_F32_SPLIT_F16 &&
             ws_bytes >= beer_mfma::estep16_workspace_bytes(cov, D, S, G))
