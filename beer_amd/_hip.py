@@ -354,6 +354,12 @@ def upload(tensors, device):
     return out
 
 
+def to_device(host_tensor, device=None):
+    'One small host tensor to the GPU through the pinned staging ring (see `upload`).'
+    device = device or require_device()
+    return upload({'t': host_tensor}, device)['t']
+
+
 def struct_to_device(obj, device):
     'Copy a ctypes structure (or array of them) to device memory as bytes.'
     buf = torch.frombuffer(bytearray(bytes(obj)), dtype=torch.uint8)

@@ -153,9 +153,9 @@ def _mixture_batch(model, X, lengths, datasize, labels, max_frames):
     # from pageable memory makes the host wait for the stream, and one issued
     # after the E-step kernels would keep the host from queueing the M-step
     # launches while those kernels run
-    off_dev = off.to(dev)
-    scales = torch.as_tensor([datasize / float(T) for T in lengths], dtype=torch.float64,
-                             device=dev)
+    up = _hip.upload({'off': off, 'scales': torch.as_tensor(
+        [datasize / float(T) for T in lengths], dtype=torch.float64)}, dev)
+    off_dev, scales = up['off'], up['scales']
     lab_dev = None if labels is None else \
         _hip.on_device(torch.as_tensor(labels)).to(torch.int64).contiguous()
     for run in _sub_batches(lengths, K * X.element_size(), max_frames):
@@ -209,8 +209,8 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
     utt_llh = torch.zeros(nutt, dtype=torch.float64, device=dev)
     off = torch.zeros(nutt + 1, dtype=torch.int64)
     off[1:] = torch.cumsum(torch.as_tensor(lengths, dtype=torch.int64), 0)
-    scales = torch.as_tensor([datasize / float(T) for T in lengths], dtype=torch.float64,
-                             device=dev)
+    scales = _hip.to_device(torch.as_tensor([datasize / float(T) for T in lengths],
+                                            dtype=torch.float64), dev)
     xi_tot = g0_tot = flow_tot = None
     max_S = model.graph.n_states if free_loop else max(g.n_states for g in graphs)
     bpf = (K_max + 2 * S_total) * X.element_size() + max_S * (3 * X.element_size() + 8)

@@ -74,6 +74,7 @@ class Model(torch.nn.Module, metaclass=abc.ABCMeta):
     def __getstate__(self):
         state = self.__dict__.copy()
         state['_cache'] = {}
+        state.pop('_idx_memo', None)             # device-side index tensors (PhoneLoop)
         return state
 
     # -- to be implemented by concrete models ---------------------------------

@@ -151,6 +151,19 @@ class PhoneLoop(HMM):
         param.register_callback(self._on_weights_update)
         self._on_weights_update()
 
+    def _index_tensors(self, device):
+        '''(end states, start states) of the phones as device index tensors,
+        built once per device: a host -> device copy from pageable memory
+        behind queued kernels blocks the host for tens of ms (it showed up as
+        a 50 ms stall every time the phone weights were updated).'''
+        end_idxs, start_idxs = list(self.end_pdf.values()), list(self.start_pdf.values())
+        memo = self.__dict__.get('_idx_memo')
+        if memo is None or memo[0] != device or memo[1] != (end_idxs, start_idxs):
+            memo = (device, (end_idxs, start_idxs), torch.as_tensor(end_idxs, device=device),
+                    torch.as_tensor(start_idxs, device=device))
+            self.__dict__['_idx_memo'] = memo
+        return memo[2], memo[3]
+
     def _on_weights_update(self):
         '''Rewrite the phone-exit transitions with E[ln w] (phoneloop.py:53-65).
         Host-side callback over P x P entries; the CSR copy on the device is
@@ -161,8 +174,7 @@ class PhoneLoop(HMM):
         start_idxs = list(self.start_pdf.values())
         end_idxs = list(self.end_pdf.values())
         # all phones at once (the reference loops over them; same elementwise ops)
-        ends = torch.as_tensor(end_idxs, device=trans.device)
-        starts = torch.as_tensor(start_idxs, device=trans.device)
+        ends, starts = self._index_tensors(trans.device)
         residuals = (1 - trans[ends, ends].exp()).log()
         if len(set(end_idxs)) == len(end_idxs):
             trans[ends[:, None], starts[None, :]] = residuals[:, None] + log_weights[None, :]
@@ -182,12 +194,11 @@ class PhoneLoop(HMM):
 
     def phone_counts(self, xi_sum, gamma0, hub_flow=None):
         'sum_t xi_t[ends, starts] summed over ends + gamma_0[starts] (88-95).'
-        start_idxs = list(self.start_pdf.values())
-        end_idxs = list(self.end_pdf.values())
-        counts = xi_sum[:, start_idxs][end_idxs, :].sum(dim=0)
+        ends, starts = self._index_tensors(xi_sum.device)
+        counts = xi_sum[:, starts][ends, :].sum(dim=0)
         if hub_flow is not None:
-            counts = counts + hub_flow[start_idxs]
-        return counts + gamma0[start_idxs].to(counts.dtype)
+            counts = counts + hub_flow[starts]
+        return counts + gamma0[starts].to(counts.dtype)
 
     def accumulate(self, stats, parent_msg=None):
         retval = super().accumulate(stats, parent_msg)
