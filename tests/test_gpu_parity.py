@@ -727,3 +727,41 @@ def test_f32_split_path_is_skipped_for_outliers_and_small_inputs():
     assert _hip.f32_split_ok(Y)
     Y[5, 2] = float('inf')
     assert not _hip.f32_split_ok(Y)
+
+
+@pytest.mark.parametrize('cov,S,G,D', [('diagonal', 30, 16, 40), ('full', 12, 16, 20),
+                                         ('diagonal', 40, 4, 13), ('full', 5, 64, 16)])
+def test_f32_split_path_mixture_sets(cov, S, G, D):
+    '''The fp16-split kernels on the shapes of HMM emissions (S mixtures of G
+    components: grouped softmax, component chunks of 256, state responsibilities
+    multiplied into the accumulation) against the fp64 kernels.'''
+    from beer_amd import _hip, kernels
+    torch.manual_seed(11)
+    T, K = 20000, S * G
+    X = torch.randn(T, D, dtype=torch.float64, device=DEV) * 1.5 + 3.
+    ns = beer.NormalSet.create(X.mean(0).cpu(), torch.diag(X.var(0).cpu()), size=K,
+                               prior_strength=1., noise_std=.7, cov_type=cov)
+    mset = beer.MixtureSet.create(S, ns).double().to(DEV)
+    E64 = ns.means_precisions.natural_form()
+    lw64 = mset._log_weights()
+    sr64 = torch.rand(T, S, dtype=torch.float64, device=DEV)
+    st64 = beer.FrameStats(X, cov)
+    ln64, r64 = kernels.mixtureset_estep(st64, E64, lw64, S, G, cov)
+    acc64 = kernels.normal_accumulate(st64, r64, sr64, S, G, cov)
+    st32 = beer.FrameStats(X.float(), cov)
+    assert _hip.f32_split_ok(st32.data)
+    err = {}
+    for mode in ('exact', 'split_f16'):
+        old = beer.get_f32_mode()
+        beer.set_f32_mode(mode)
+        try:
+            ln, r = kernels.mixtureset_estep(st32, E64.float(), lw64.float(), S, G, cov)
+            acc = kernels.normal_accumulate(st32, r64.float(), sr64.float(), S, G, cov)
+        finally:
+            beer.set_f32_mode(old)
+        err[mode] = (float((ln.double() - ln64).abs().max()),
+                     float((r.double() - r64).abs().max()),
+                     float((acc - acc64).abs().max() / acc64.abs().max()))
+    for e_exact, e_split in zip(err['exact'], err['split_f16']):
+        assert e_split <= 4. * e_exact + 1e-7, err
+    assert err['split_f16'][2] <= 2e-6, err
