@@ -193,7 +193,9 @@ int beer_suffstats_expand(int dtype, int cov, int64_t T, int D, const void* X,
  * log_norm[t] = l[t, label] (mixture.py:85-87).  `log_weights` nullable
  * (= 0).  `stat_scale` reproduces HMM.posteriors' scaling of the statistics
  * (beer/models/hmm.py:119); pass 1.  `llh_sum` (nullable) += sum_t,s log_norm
- * in fp64. */
+ * in fp64.  With G > 1 the generic kernels need `comp_resps` as their work
+ * buffer; the matrix-core path (workspace given, shape supported) keeps the
+ * responsibilities in registers and accepts log_norm / llh_sum alone. */
 int beer_mixtureset_estep(int dtype, int cov, int64_t T, int D, int S, int G,
                           const void* X, const void* exp_stats,
                           const void* log_weights, const int64_t* labels,
@@ -205,7 +207,8 @@ int beer_mixtureset_estep(int dtype, int cov, int64_t T, int D, int S, int G,
  * this comment need (packed parameter / partial-sum images).  0 = the shape
  * has no MFMA implementation.  With `workspace` NULL or too small the calls
  * run the generic kernels -- same results, slower.  The workspace holds no
- * state between calls. */
+ * state between calls.  For float32 the size covers both arithmetic variants
+ * (beer_hip_set_f32_mode). */
 size_t beer_estep_workspace_bytes(int dtype, int cov, int D, int S, int G);
 size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G);
 
