@@ -528,6 +528,37 @@ int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G, c
                   workspace, workspace_bytes, stream);
 }
 
+int beer_mixture_estep_packed(int cov, int64_t T, int D, int K, const float* X,
+                              const float* exp_stats, const float* log_weights, float* log_norm,
+                              void* packed_resps, double* llh_sum, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    BEER_REQUIRE(T >= 0 && D >= 1 && K >= 1 && cov >= 0 && cov <= 2);
+    BEER_REQUIRE(X && exp_stats && log_weights && packed_resps && workspace);
+    BEER_REQUIRE(beer_mfma::supported_llh(D, 1, K));
+    BEER_REQUIRE(workspace_bytes >= beer_mfma::estep16_workspace_bytes(cov, D, 1, K));
+    if (T == 0) return BEER_OK;
+    return beer_mfma::estep_f16x3(cov, T, D, 1, K, X, exp_stats, log_weights,
+                                  reinterpret_cast<float*>(packed_resps), log_norm, llh_sum,
+                                  workspace, workspace_bytes, as_stream(stream), true);
+}
+
+int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float* X,
+                                  const void* packed_resps, double* acc, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    BEER_REQUIRE(T >= 0 && D >= 1 && K >= 1 && cov >= 0 && cov <= 2);
+    BEER_REQUIRE(X && packed_resps && acc && workspace);
+    BEER_REQUIRE(beer_mfma::supported_acc(D, K));
+    BEER_REQUIRE(workspace_bytes >= beer_mfma::acc16_workspace_bytes(cov, D, K));
+    if (T == 0) return BEER_OK;
+    return beer_mfma::acc_f16x3(cov, T, D, 1, K, X, reinterpret_cast<const float*>(packed_resps),
+                                nullptr, acc, workspace, workspace_bytes, as_stream(stream), true);
+}
+
+int beer_unpack_resps(int64_t T, int K, const void* packed_resps, float* resps, void* stream) {
+    BEER_REQUIRE(T >= 0 && K >= 1 && (T == 0 || (packed_resps && resps)));
+    return beer_mfma::unpack_resps(T, K, packed_resps, resps, as_stream(stream));
+}
+
 int beer_weights_from_acc(int S, int G, int Q, const double* acc, double* out, void* stream) {
     BEER_REQUIRE(S >= 0 && G >= 1 && Q >= 3 && acc && out);
     if (S == 0) return BEER_OK;

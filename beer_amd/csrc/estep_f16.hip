@@ -23,6 +23,8 @@
 // Operand mapping of v_mfma_f32_16x16x32_f16 (lane l: i = l & 15, g = l >> 4):
 // A[i][k = 8g..8g+7], B[k = 8g..8g+7][n = i], C/D row 4g + r, column i.
 
+#include <type_traits>
+
 #include "estep_mfma.h"
 #include "estep_tiles.h"
 
@@ -247,7 +249,7 @@ __device__ __forceinline__ void split8(const f32x4& p0, const f32x4& p1, h8& hi,
 // ---------------------------------------------------------------------------
 // K1 on the fp16 pipes: one wave owns 16 MT frames x 16 NT components.
 // ---------------------------------------------------------------------------
-template <int NT, int MT, int GQ>
+template <int NT, int MT, int GQ, bool PACKED>
 __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nk,
     const float* __restrict__ X, const _Float16* __restrict__ Pall,
@@ -382,11 +384,11 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m][4 * q + j] *= inv[j];
     }
-    softmax_epilogue<float, NT, MT, GQ>(acc, fb, nframes, kbase, K, S, G, gl, jw, i, g, lane,
+    softmax_epilogue<float, NT, MT, GQ, PACKED>(acc, fb, nframes, kbase, K, S, G, gl, jw, i, g, lane,
                                         resps, log_norm, llh_sum);
 }
 
-template <int NT, int MT, int GQ>
+template <int NT, int MT, int GQ, bool PACKED = false>
 int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nchunks, int nk,
                  const float* X, const _Float16* P, const float* inv_scale, const float* sc,
                  const int* tab, float* resps, float* log_norm, double* llh_sum, hipStream_t s) {
@@ -394,7 +396,7 @@ int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, in
     constexpr int FB = 16 * MT * (kThreads / 64);
     const size_t lds = (size_t)FB * LD * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int);
     const int64_t blocks = (nframes + FB - 1) / FB;
-    hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ>), dim3((unsigned)blocks, (unsigned)nchunks),
+    hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ, PACKED>), dim3((unsigned)blocks, (unsigned)nchunks),
                        dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nk, X, P, inv_scale,
                        sc, tab, resps, log_norm, llh_sum);
     BEER_LAUNCH_CHECK();
@@ -426,7 +428,7 @@ constexpr int kA16RS = kA16FT;       // R^T row = 8 chunks of 8 frames (16 B), c
                                      // ds_read_b128 for the MFMA lane groups, 2-way ds_write_b32
 constexpr int kA16MaxFrames = 16384; // frames per workgroup: 384 fp32 roundings per sum
 
-template <int NQ, bool HAS_SR>
+template <int NQ, bool HAS_SR, bool PACKED>
 __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     int64_t nframes, int D, int K, int G, int S, int nslab, const float* __restrict__ X,
     const float* __restrict__ R, const float* __restrict__ SR, const int* __restrict__ tab,
@@ -457,15 +459,17 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     const int xs_elems = (D + 3) * kA16XS;                     // floats (+ a spare row)
     const int r_halves = 16 * MC * kA16RS;                 // per hi / lo image
     const size_t buf_bytes = (size_t)xs_elems * 4 + (size_t)r_halves * 2 * 2;
-    float* sxs = reinterpret_cast<float*>(smem + 2 * buf_bytes);          // the 64 frame scales
-    if (tid < 64) sxs[tid] = sc[tid];
     auto xs_of = [&](int buf) { return reinterpret_cast<float*>(smem + buf * buf_bytes); };
     auto rh_of = [&](int buf) {
         return reinterpret_cast<_Float16*>(smem + buf * buf_bytes + (size_t)xs_elems * 4);
     };
 
     // the two X^T rows of this lane's statistic column in each of its tiles
+    // and the power-of-two range scale of the product, sx[a] * sx[b]: applied when
+    // the B fragment is generated (a scale looked up per staged element would be
+    // an LDS read + wait in the middle of the MFMA stream)
     int ra[NQ], rb[NQ];
+    float sab[NQ];
     auto factors = [&](int uu, int& a, int& b) {
         const int col = 16 * (tile0 + uu) + i, slab = col >> 2;
         a = b = Dp + 1;
@@ -482,6 +486,7 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
         // row D = ones, row D + 1 = zeros
         ra[uu] = (a < D ? a : (a == Dp ? D : D + 1)) * kA16XS;
         rb[uu] = (b < D ? b : (b == Dp ? D : D + 1)) * kA16XS;
+        sab[uu] = (a < D ? sc[a] : 1.f) * (b < D ? sc[b] : 1.f);
     }
     f32x4 acc[MC][NQ];
 #pragma unroll
@@ -493,7 +498,11 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     constexpr int RPT = 16 * MC * (kA16FT / 2) / kA16Threads;    // (component, frame pair)
     constexpr int XPT = (kA16FT * 64 + kA16Threads - 1) / kA16Threads;   // D <= 64
     const int xcount = kA16FT * D;
-    struct Stage { float x[XPT]; float r[RPT][2]; float w[HAS_SR ? RPT : 1][2]; };
+    static_assert(!(PACKED && HAS_SR), "packed responsibilities carry no state factor");
+    static_assert(kPackedRespBits == kRespBits, "K1 packs with the scale K2 removes");
+    // PACKED: r[v] = the (hi, lo) words K1 wrote for the frame pair, stored as they are
+    using rword_t = typename std::conditional<PACKED, unsigned, float>::type;
+    struct Stage { float x[XPT]; rword_t r[RPT][2]; float w[HAS_SR ? RPT : 1][2]; };
     // staged item v of this thread: component kk (of 128) and frame pair fp (of
     // 32).  One wave instruction covers 32 components x 2 frame pairs: 128-byte
     // row segments from global memory, and ds_write_b32 with at most 2 lanes per
@@ -530,14 +539,25 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
             int kk, fp;
             stage_item(v, kk, fp);
             const int kcl = kk < kvalid ? kk : kvalid - 1;
+            if constexpr (PACKED) {
+                typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+                const int pairs = (rows + 1) >> 1;
+                const int prow = fp < pairs ? fp : pairs - 1;
+                const uint2_t w2 = *reinterpret_cast<const uint2_t*>(
+                    reinterpret_cast<const unsigned*>(R) + 2 * ((t0 >> 1) * K + kc0) +
+                    2 * (prow * K + kcl));
+                st.r[v][0] = w2.x;
+                st.r[v][1] = w2.y;
+            } else {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = 2 * fp + h < rows ? 2 * fp + h : rows - 1;
-                st.r[v][h] = Rt[row * K + kcl];
-                if (HAS_SR) st.w[v][h] = Wt[row * S + (kc0 + kcl) / G];
+                for (int h = 0; h < 2; ++h) {
+                    const int row = 2 * fp + h < rows ? 2 * fp + h : rows - 1;
+                    st.r[v][h] = Rt[row * K + kcl];
+                    if (HAS_SR) st.w[v][h] = Wt[row * S + (kc0 + kcl) / G];
+                }
             }
         }
-        __builtin_amdgcn_sched_group_barrier(0x020, XPT + (HAS_SR ? 4 : 2) * RPT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, XPT + (PACKED ? 1 : (HAS_SR ? 4 : 2)) * RPT, 0);
     };
     auto store_x = [&](int buf, int64_t t0, const Stage& st, int v) {
         float* xs = xs_of(buf);
@@ -546,7 +566,7 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
         const int f = idx / D, d = idx - f * D;
         // threads past the tile write to the spare row behind the constants
         const int at = idx < xcount ? d * kA16XS + f : (D + 2) * kA16XS + (tid & 63);
-        xs[at] = idx < xvalid ? st.x[v] * sxs[d] : 0.f;
+        xs[at] = idx < xvalid ? st.x[v] : 0.f;
     };
     auto store_r = [&](int buf, int64_t t0, const Stage& st, int v) {
         _Float16* rh = rh_of(buf);
@@ -554,6 +574,14 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
         const int rows = (int)(te - t0 < kA16FT ? te - t0 : kA16FT);
         int kk, fp;
         stage_item(v, kk, fp);
+        const int at = kk * kA16RS + (((fp >> 2) ^ (kk & 7)) << 3) + 2 * (fp & 3);
+        if constexpr (PACKED) {
+            // the odd frame of a last, half-filled pair was zeroed by K1
+            const bool ok = 2 * fp < rows && kk < kvalid;
+            *reinterpret_cast<unsigned*>(rh + at) = ok ? st.r[v][0] : 0u;
+            *reinterpret_cast<unsigned*>(rl + at) = ok ? st.r[v][1] : 0u;
+            return;
+        }
         float r2[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -563,7 +591,6 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
         }
         hp2 hi, lo;
         split2(r2[0], r2[1], hi, lo);
-        const int at = kk * kA16RS + (((fp >> 2) ^ (kk & 7)) << 3) + 2 * (fp & 3);
         *reinterpret_cast<hp2*>(rh + at) = hi;
         *reinterpret_cast<hp2*>(rl + at) = lo;
     };
@@ -606,7 +633,7 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
                 const f32x4 xa1 = *reinterpret_cast<const f32x4*>(xs + ra[uu] + f0 + 4);
                 const f32x4 xb0 = *reinterpret_cast<const f32x4*>(xs + rb[uu] + f0);
                 const f32x4 xb1 = *reinterpret_cast<const f32x4*>(xs + rb[uu] + f0 + 4);
-                split8(xa0 * xb0, xa1 * xb1, bh, bl);
+                split8((xa0 * sab[uu]) * xb0, (xa1 * sab[uu]) * xb1, bh, bl);
             };
             h8 bh[2], bl[2];
             gen_b(0, 0, bh[0], bl[0]);
@@ -699,6 +726,21 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     }
 }
 
+// packed responsibilities -> float32 (tests, callers that want to look at them)
+__global__ void unpack_resps_kernel(int64_t nframes, int K, const unsigned* __restrict__ Rp,
+                                    float* __restrict__ R) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // (pair, k)
+    const int64_t pairs = (nframes + 1) >> 1;
+    if (idx >= pairs * K) return;
+    const int64_t p = idx / K;
+    const int k = (int)(idx - p * K);
+    const hp2 hi = __builtin_bit_cast(hp2, Rp[2 * idx]);
+    const hp2 lo = __builtin_bit_cast(hp2, Rp[2 * idx + 1]);
+    const float down = 1.f / (float)(1 << kRespBits);
+    R[(2 * p) * K + k] = ((float)hi[0] + (float)lo[0]) * down;
+    if (2 * p + 1 < nframes) R[(2 * p + 1) * K + k] = ((float)hi[1] + (float)lo[1]) * down;
+}
+
 inline int nt16_for(int S, int K) { return S > 1 ? 16 : (K <= 64 ? 4 : (K <= 128 ? 8 : 16)); }
 inline int nchunks16_for(int S, int K) { return S > 1 ? (K + 255) / 256 : 1; }
 size_t up256(size_t n) { return (n + 255) / 256 * 256; }
@@ -722,6 +764,15 @@ int f16_range_hazard(int64_t nframes, int D, const float* X, void* scratch, int*
     return BEER_OK;
 }
 
+int unpack_resps(int64_t nframes, int K, const void* packed, float* resps, hipStream_t s) {
+    const int64_t n = ((nframes + 1) >> 1) * K;
+    if (n == 0) return BEER_OK;
+    hipLaunchKernelGGL(unpack_resps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       nframes, K, reinterpret_cast<const unsigned*>(packed), resps);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
 size_t estep16_workspace_bytes(int cov, int D, int S, int G) {
     if (!supported_llh(D, S, G)) return 0;
     const int K = S * G, NT = nt16_for(S, K), nchunks = nchunks16_for(S, K);
@@ -733,8 +784,9 @@ size_t estep16_workspace_bytes(int cov, int D, int S, int G) {
 
 int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, const float* expT,
                 const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
-                size_t ws_bytes, hipStream_t s) {
+                size_t ws_bytes, hipStream_t s, bool packed) {
     const int K = S * G;
+    if (packed && S != 1) return BEER_EINVAL;
     if (!supported_llh(D, S, G) || ws_bytes < estep16_workspace_bytes(cov, D, S, G))
         return BEER_EINVAL;
     const int NT = nt16_for(S, K), nchunks = nchunks16_for(S, K), nk = nk16_of(cov, D);
@@ -756,6 +808,16 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
 #define BEER_LLH16(NT_, MT_, GQ_)                                                                \
     return launch_llh16<NT_, MT_, GQ_>(nframes, D, K, S, G, gl, jw, nchunks, nk, X, P, inv_scale, \
                                        sc, tab, resps, log_norm, llh_sum, s)
+    if (S == 1 && packed) {
+        const int gl = 16, jw = 4;
+#define BEER_LLH16P(NT_, GQ_)                                                                    \
+    return launch_llh16<NT_, 2, GQ_, true>(nframes, D, K, S, G, gl, jw, nchunks, nk, X, P,       \
+                                           inv_scale, sc, tab, resps, log_norm, llh_sum, s)
+        if (NT == 4) BEER_LLH16P(4, 1);
+        if (NT == 8) BEER_LLH16P(8, 2);
+        BEER_LLH16P(16, 4);
+#undef BEER_LLH16P
+    }
     if (S == 1) {
         const int gl = 16, jw = 4;
         if (NT == 4) BEER_LLH16(4, 2, 1);
@@ -780,8 +842,9 @@ size_t acc16_workspace_bytes(int cov, int D, int K) {
 }
 
 int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, const float* R,
-              const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
+              const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s, bool packed) {
     const int K = S * G;
+    if (packed && SR) return BEER_EINVAL;
     if (!supported_acc(D, K) || ws_bytes < acc16_workspace_bytes(cov, D, K)) return BEER_EINVAL;
     const int nslab = nslab_of(cov, D), nq = nslab * 4;
     char* w = reinterpret_cast<char*>(ws);
@@ -814,14 +877,20 @@ int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, con
     const size_t lds = 2 * ((size_t)(D + 3) * kA16XS * 4 + (size_t)16 * mc * kA16RS * 2 * 2) + 256;
     const int64_t nyz = ((int64_t)gy * gz + 7) / 8 * 8;
     const dim3 grid((unsigned)(nyz * gx));
-#define BEER_ACC16(NQ_, SR_)                                                                     \
+#define BEER_ACC16_(NQ_, SR_, P_)                                                                \
     do {                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc16_kernel<NQ_, SR_>),         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc16_kernel<NQ_, SR_, P_>),     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-        hipLaunchKernelGGL((acc16_kernel<NQ_, SR_>), grid, dim3(kA16Threads), lds, s, nframes, D, \
-                           K, G, S, nslab, X, R, SR, tab, sc, fpb, Sp, gx, gy, (int)gz);         \
+        hipLaunchKernelGGL((acc16_kernel<NQ_, SR_, P_>), grid, dim3(kA16Threads), lds, s,        \
+                           nframes, D, K, G, S, nslab, X, R, SR, tab, sc, fpb, Sp, gx, gy,       \
+                           (int)gz);                                                             \
     } while (0)
-    if (SR) {
+#define BEER_ACC16(NQ_, SR_) BEER_ACC16_(NQ_, SR_, false)
+    if (packed) {
+        if (NQ == 4) BEER_ACC16_(4, false, true);
+        else if (NQ == 2) BEER_ACC16_(2, false, true);
+        else BEER_ACC16_(1, false, true);
+    } else if (SR) {
         if (NQ == 4) BEER_ACC16(4, true);
         else if (NQ == 2) BEER_ACC16(2, true);
         else BEER_ACC16(1, true);
@@ -831,6 +900,7 @@ int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, con
         else BEER_ACC16(1, false);
     }
 #undef BEER_ACC16
+#undef BEER_ACC16_
     BEER_LAUNCH_CHECK();
     const int64_t total = (int64_t)K * stats_dim(cov, D);
     hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cov,

@@ -17,17 +17,22 @@ size_t acc_workspace_bytes(int cov, int D, int K);
 // fp32 models on the fp16 matrix pipes (estep_f16.hip): every fp32 operand is
 // split into two fp16 halves, three fp16 MFMAs per product, fp32 accumulation.
 size_t estep16_workspace_bytes(int cov, int D, int S, int G);
+// `packed`: S = 1 only; `resps` then receives the fp16 hi / lo pairs the
+// accumulation kernel consumes (estep_tiles.h: softmax_epilogue<PACKED>).
 int estep_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
                 const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
-                size_t ws_bytes, hipStream_t s);
+                size_t ws_bytes, hipStream_t s, bool packed = false);
 
 // 1 in *hazard (device) when the split path would lose accuracy on these frames
 // (a dimension whose maximum is > 2^9 times its mean magnitude); scratch >= 768 B.
+int unpack_resps(int64_t T, int K, const void* packed, float* resps, hipStream_t s);
 int f16_range_hazard(int64_t T, int D, const float* X, void* scratch, int* hazard,
                      hipStream_t s);
 size_t acc16_workspace_bytes(int cov, int D, int K);
+// `packed`: R holds the packed pairs written by estep_f16x3(..., packed = true); SR must be null.
 int acc_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* R,
-              const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s);
+              const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s,
+              bool packed = false);
 
 int estep_f32(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
               const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,

@@ -158,7 +158,14 @@ __global__ void unpack_kernel(int cov, int D, int K, const double* __restrict__ 
 // Epilogue of K1: logsumexp + responsibilities over each group of G components
 // of a wave's acc[MT][NT] tiles (frames fb .. fb + 16 MT, components kbase ..).
 // ---------------------------------------------------------------------------
-template <typename T, int NT, int MT, int GQ>
+// PACKED (float only): instead of float32 responsibilities, `resps` receives
+// them already split for the fp16 accumulation kernel -- per (frame pair, k) two
+// 32-bit words, (hi(f), hi(f+1)) and (lo(f), lo(f+1)) of r * 2^12 as fp16 pairs,
+// at word index 2 * ((f / 2) * K + k): the same bytes per element, and
+// acc16_kernel stores them into its LDS image without any arithmetic.
+constexpr int kPackedRespBits = 12;
+
+template <typename T, int NT, int MT, int GQ, bool PACKED = false>
 __device__ __forceinline__ void softmax_epilogue(
     typename Mma<T>::acc_t (&acc)[MT][NT], int64_t fb, int64_t nframes, int kbase, int K, int S,
     int G, int gl, int jw, int i, int g, int lane, T* __restrict__ resps,
@@ -239,7 +246,13 @@ __device__ __forceinline__ void softmax_epilogue(
                         }
                     }
                 }
-                if (resps && f < nframes) {
+                if (PACKED) {
+                    // keep the responsibilities where the logits were; packed below
+#pragma unroll
+                    for (int qq = 0; qq < GQ; ++qq)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[m][4 * (tq * GQ + qq) + j][r] = e[qq][j];
+                } else if (resps && f < nframes) {
 #pragma unroll
                     for (int qq = 0; qq < GQ; ++qq) {
                         const int k = kq + 64 * qq;
@@ -251,6 +264,45 @@ __device__ __forceinline__ void softmax_epilogue(
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
                                 if (k + j < K) dst[j] = e[qq][j];
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (PACKED) {
+            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+            typedef float float2_t __attribute__((ext_vector_type(2)));
+            typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+            unsigned int* out = reinterpret_cast<unsigned int*>(resps);
+            const float up = (float)(1 << kPackedRespBits);
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int64_t f = fb + m * 16 + M::row(g, 2 * p2);       // even
+                if (out && f < nframes) {
+                    const bool second = f + 1 < nframes;
+#pragma unroll
+                    for (int tq = 0; tq < NT / 4; ++tq) {
+                        const int k = kbase + 64 * tq + 4 * i;
+                        unsigned int w[8];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float2_t v = {(float)acc[m][4 * tq + j][2 * p2] * up,
+                                                second ? (float)acc[m][4 * tq + j][2 * p2 + 1] * up : 0.f};
+                            const half2_t hi = __builtin_convertvector(v, half2_t);
+                            const half2_t lo = __builtin_convertvector(
+                                v - __builtin_convertvector(hi, float2_t), half2_t);
+                            w[2 * j] = __builtin_bit_cast(unsigned int, hi);
+                            w[2 * j + 1] = __builtin_bit_cast(unsigned int, lo);
+                        }
+                        unsigned int* dst = out + 2 * ((size_t)(f >> 1) * K + k);
+                        if (vec_ok && k + 3 < K) {
+                            *reinterpret_cast<uint4_t*>(dst) = uint4_t{w[0], w[1], w[2], w[3]};
+                            *reinterpret_cast<uint4_t*>(dst + 4) = uint4_t{w[4], w[5], w[6], w[7]};
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (k + j < K) { dst[2 * j] = w[2 * j]; dst[2 * j + 1] = w[2 * j + 1]; }
                         }
                     }
                 }

@@ -86,9 +86,64 @@ def mixtureset_estep(stats, exp_stats, log_weights, S, G, cov_type, labels=None,
     return log_norm, resps
 
 
+class PackedResps:
+    '''Responsibilities [T, K] of one mixture in the form the fp16 accumulation
+    kernel multiplies with (include/beer_hip.h: beer_mixture_estep_packed):
+    `words` int32 [ceil(T/2), K, 2].  `unpack()` gives the float32 matrix.'''
+
+    def __init__(self, words, nframes):
+        self.words, self.nframes = words, nframes
+
+    @property
+    def shape(self):
+        return (self.nframes, self.words.shape[1])
+
+    def unpack(self):
+        T, K = self.shape
+        out = torch.empty(T, K, dtype=torch.float32, device=self.words.device)
+        _hip.call('beer_unpack_resps', T, K, _hip.ptr(self.words), _hip.ptr(out))
+        return out
+
+
+def packed_path_ok(stats, K, cov_type):
+    '''True when the E-step of a K-component mixture over `stats` can hand its
+    responsibilities to the accumulation in packed form: float32 frames on the
+    fp16-split path, unscaled, shapes with a matrix-core kernel on both sides.'''
+    st = _frames(stats)
+    X = st.data
+    if st.scale != 1.0 or not _hip.f32_split_ok(X):
+        return False
+    code, D = _hip.COV_CODE[cov_type], X.shape[1]
+    lib, dt = _hip.lib(), _hip.dtype_code(X.dtype)
+    return lib.beer_estep_workspace_bytes(dt, code, D, 1, K) > 0 and \
+        lib.beer_accumulate_workspace_bytes(dt, code, D, 1, K) > 0
+
+
+def mixture_estep_packed(stats, exp_stats, log_weights, K, cov_type, llh_sum=None):
+    '''(log_norm [T,1], PackedResps) of one mixture: `mixtureset_estep` with
+    S = 1 whose responsibilities go straight to `normal_accumulate`.  Only where
+    `packed_path_ok`.'''
+    st = _frames(stats)
+    X = st.data
+    T, D = X.shape
+    E = _hip.on_device(exp_stats, X.dtype)
+    lw = _hip.on_device(log_weights, X.dtype)
+    if E.shape[0] != K or lw.numel() != K:
+        raise ValueError(f'{E.shape[0]} Gaussians, {lw.numel()} weights for {K} components')
+    log_norm = torch.empty(T, 1, dtype=X.dtype, device=X.device)
+    words = torch.empty((T + 1) // 2, K, 2, dtype=torch.int32, device=X.device)
+    ws, ws_bytes = _hip.workspace('beer_estep_workspace_bytes', X.dtype,
+                                  _hip.COV_CODE[cov_type], D, 1, K, X.device)
+    _hip.call('beer_mixture_estep_packed', _hip.COV_CODE[cov_type], T, D, K, _hip.ptr(X),
+              _hip.ptr(E), _hip.ptr(lw), _hip.ptr(log_norm), _hip.ptr(words), _hip.ptr(llh_sum),
+              _hip.ptr(ws), ws_bytes)
+    return log_norm, PackedResps(words, T)
+
+
 def normal_accumulate(stats, comp_resps, state_resps, S, G, cov_type, acc=None):
     '''acc[k,:] += sum_t comp_resps[t,k] * state_resps[t, k // G] * phi(x_t),
-    fp64 [S*G, Q].'''
+    fp64 [S*G, Q].  `comp_resps` may be the `PackedResps` of
+    `mixture_estep_packed` (no state responsibilities then).'''
     st = _frames(stats)
     if st.scale != 1.0:
         raise ValueError('scaled statistics cannot be accumulated')
@@ -98,6 +153,15 @@ def normal_accumulate(stats, comp_resps, state_resps, S, G, cov_type, acc=None):
     Q = st.shape[1]
     if acc is None:
         acc = torch.zeros(K, Q, dtype=torch.float64, device=X.device)
+    if isinstance(comp_resps, PackedResps):
+        if state_resps is not None or tuple(comp_resps.shape) != (T, K):
+            raise ValueError('packed responsibilities: same frames and components, no state '
+                             'responsibilities')
+        ws, ws_bytes = _hip.workspace('beer_accumulate_workspace_bytes', X.dtype,
+                                      _hip.COV_CODE[cov_type], D, 1, K, X.device)
+        _hip.call('beer_normal_accumulate_packed', _hip.COV_CODE[cov_type], T, D, K,
+                  _hip.ptr(X), _hip.ptr(comp_resps.words), _hip.ptr(acc), _hip.ptr(ws), ws_bytes)
+        return acc
     cr = None if comp_resps is None else _hip.on_device(comp_resps, X.dtype)
     sr = None if state_resps is None else _hip.on_device(state_resps, X.dtype)
     ws, ws_bytes = _hip.workspace('beer_accumulate_workspace_bytes', X.dtype,

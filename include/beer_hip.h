@@ -223,6 +223,32 @@ int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G,
                            const void* state_resps, double* acc, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* The E-step -> accumulate hand-over of a single mixture (S = 1, float32, split
+ * arithmetic: beer_hip_set_f32_mode) without the float32 responsibilities in
+ * between.  `packed_resps` (T rounded up to even, times K, times 4 bytes: the
+ * size of the [T,K] float32 matrix) receives each responsibility already split
+ * into the fp16 pair the accumulation kernel multiplies with -- per (frame
+ * pair p, component k) two 32-bit words at word index 2 * (p * K + k): the high
+ * halves of r * 2^12 for frames 2p, 2p+1, then the low halves.  The values are
+ * the ones beer_mixtureset_estep / beer_normal_accumulate compute in the split
+ * mode (same roundings), so the statistics are bit-identical to the two-call
+ * path; the accumulation kernel just stops spending vector ALU on the split.
+ * Same reference functions as the two calls above (mixture.py:86-101 for the
+ * responsibilities, normalset.py:121-123 for the statistics).
+ * beer_unpack_resps restores the [T,K] float32 matrix (hi + lo) / 2^12.
+ * EINVAL: shape without a matrix-core path, workspace NULL / too small (sizes
+ * from beer_estep_workspace_bytes / beer_accumulate_workspace_bytes, BEER_F32). */
+int beer_mixture_estep_packed(int cov, int64_t T, int D, int K, const float* X,
+                              const float* exp_stats, const float* log_weights,
+                              float* log_norm, void* packed_resps, double* llh_sum,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float* X,
+                                  const void* packed_resps, double* acc,
+                                  void* workspace, size_t workspace_bytes,
+                                  void* stream);
+int beer_unpack_resps(int64_t T, int K, const void* packed_resps, float* resps,
+                      void* stream);
+
 /* Mixture-weight statistics from the accumulated Gaussian statistics: the
  * zero-order count is N_k = -2 * acc[k, Q-2]; out[s,g] = N_{s,g} for
  * g < G-1 and out[s,G-1] = sum_g N_{s,g} -- the "last column <- row sum"

@@ -765,3 +765,97 @@ def test_f32_split_path_mixture_sets(cov, S, G, D):
     for e_exact, e_split in zip(err['exact'], err['split_f16']):
         assert e_split <= 4. * e_exact + 1e-7, err
     assert err['split_f16'][2] <= 2e-6, err
+
+
+@pytest.mark.parametrize('cov,K,D,T', [('full', 256, 40, 40001), ('diagonal', 256, 40, 33000),
+                                       ('full', 64, 13, 20000), ('diagonal', 100, 24, 16385),
+                                       ('isotropic', 128, 16, 17000)])
+def test_packed_responsibilities_match_the_two_call_path(cov, K, D, T):
+    '''E-step -> accumulate with the responsibilities handed over as fp16
+    hi / lo pairs (beer_mixture_estep_packed, beer_normal_accumulate_packed):
+    same log-normalisers and, up to the order of the fp64 atomics, the same
+    statistics as the float32 hand-over of the split path; and within the
+    float32 tolerance of the fp64 kernels.  T odd: the last frame pair is half
+    empty; K = 100: component tiles past K.'''
+    from beer_amd import _hip, kernels
+    torch.manual_seed(5)
+    X = torch.randn(T, D, dtype=torch.float64, device=DEV) * 2. - 1.
+    ns = beer.NormalSet.create(X.mean(0).cpu(), torch.diag(X.var(0).cpu()), size=K,
+                               prior_strength=1., noise_std=.7, cov_type=cov)
+    mix = beer.Mixture.create(ns).double().to(DEV)
+    E64 = ns.means_precisions.natural_form()
+    lw64 = mix._log_weights().view(1, K)
+    st64 = beer.FrameStats(X, cov)
+    ln64, r64 = kernels.mixtureset_estep(st64, E64, lw64, 1, K, cov)
+    acc64 = kernels.normal_accumulate(st64, r64, None, 1, K, cov)
+    st32 = beer.FrameStats(X.float(), cov)
+    assert kernels.packed_path_ok(st32, K, cov)
+    ln, r = kernels.mixtureset_estep(st32, E64.float(), lw64.float(), 1, K, cov)
+    acc = kernels.normal_accumulate(st32, r, None, 1, K, cov)
+    total = torch.zeros((), dtype=torch.float64, device=DEV)
+    ln_p, packed = kernels.mixture_estep_packed(st32, E64.float(), lw64.float(), K, cov,
+                                                llh_sum=total)
+    assert packed.shape == (T, K)
+    acc_p = kernels.normal_accumulate(st32, packed, None, 1, K, cov)
+    assert torch.equal(ln_p, ln)
+    torch.testing.assert_close(total, ln.double().sum(), rtol=1e-12, atol=0)
+    # hi + lo holds 22 bits of r * 2^12
+    torch.testing.assert_close(packed.unpack(), r, rtol=1e-6, atol=1e-9)
+    torch.testing.assert_close(acc_p, acc, rtol=1e-11, atol=1e-11 * float(acc.abs().max()))
+    # float32 logits of magnitude ~1e2 carry ~1e-5 of absolute error, the
+    # responsibilities the same relative error: the yardstick is the exact fp32 path
+    with _hip.exact_f32():
+        ln_e, r_e = kernels.mixtureset_estep(st32, E64.float(), lw64.float(), 1, K, cov)
+        acc_e = kernels.normal_accumulate(st32, r_e, None, 1, K, cov)
+    scale = float(acc64.abs().max())
+    e_exact = float((acc_e - acc64).abs().max()) / scale
+    e_packed = float((acc_p - acc64).abs().max()) / scale
+    assert e_packed <= 4. * e_exact + 2e-6, (e_packed, e_exact)
+    ln_scale = float(ln64.abs().max())
+    assert float((ln_p.double() - ln64).abs().max()) <= \
+        4. * float((ln_e.double() - ln64).abs().max()) + 1e-6 * ln_scale
+
+
+class _no_packed:
+    'Inside: mixture batches hand float32 responsibilities over, as before.'
+
+    def __enter__(self):
+        from beer_amd import kernels
+        self.orig = kernels.packed_path_ok
+        kernels.packed_path_ok = lambda *a, **kw: False
+
+    def __exit__(self, *exc):
+        from beer_amd import kernels
+        kernels.packed_path_ok = self.orig
+
+
+def test_packed_path_is_what_a_mixture_batch_takes():
+    'accumulate_elbo on a float32 mixture over enough frames uses the packed hand-over.'
+    from beer_amd import kernels
+    from beer_amd.inference import batch as B
+    torch.manual_seed(2)
+    T, D, K = 40000, 20, 64
+    X = torch.randn(T, D, dtype=torch.float32, device=DEV)
+    ns = beer.NormalSet.create(torch.zeros(D), torch.eye(D), size=K, prior_strength=1.,
+                               noise_std=1., cov_type='full')
+    model = beer.Mixture.create(ns).to(DEV)
+    utts = list(torch.split(X, 1000))
+    calls = []
+    orig = kernels.mixture_estep_packed
+
+    def spy(*a, **kw):
+        calls.append(1)
+        return orig(*a, **kw)
+    kernels.mixture_estep_packed = spy
+    try:
+        elbo_p = B.accumulate_elbo(model, utts)
+    finally:
+        kernels.mixture_estep_packed = orig
+    assert calls
+    with _no_packed():
+        elbo_u = B.accumulate_elbo(model, utts)
+    assert abs(float(elbo_p) - float(elbo_u)) <= 1e-9 * abs(float(elbo_u))
+    for (pa, a), (pb, b) in zip(sorted(elbo_p._acc_stats.items(), key=lambda kv: id(kv[0])),
+                                sorted(elbo_u._acc_stats.items(), key=lambda kv: id(kv[0]))):
+        assert pa is pb
+        torch.testing.assert_close(a, b, rtol=1e-9, atol=1e-9 * float(b.abs().max()))
