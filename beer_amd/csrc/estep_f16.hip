@@ -622,7 +622,11 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
         const float* xs = xs_of(buf);
         const _Float16* rh = rh_of(buf);
         const _Float16* rl = rh + r_halves;
-        if (tile + 2 < ntiles) load_tile(tb + (tile + 2) * kA16FT, far);
+        // Unconditional (past the end the last tile is loaded again and never used):
+        // behind a branch, hipcc merges the wait counters of the two paths and makes
+        // every use of `held` wait for the loads just issued into `far` as well --
+        // one full memory latency per tile.
+        load_tile(tb + (tile + 2 < ntiles ? tile + 2 : ntiles - 1) * kA16FT, far);
         if (active) {
             // B fragments are produced one (k-step, statistic tile) ahead of the
             // MFMAs that consume them; sched_group_barrier spreads their LDS reads
