@@ -168,6 +168,8 @@ HOST_SIGNATURES = {
 SIZE_QUERIES = {
     'beer_estep_workspace_bytes': [c_i, c_i, c_i, c_i, c_i],
     'beer_accumulate_workspace_bytes': [c_i, c_i, c_i, c_i, c_i],
+    'beer_packed_resps_bytes': [c_l, c_i],
+    'beer_accumulate_packed_workspace_bytes': [c_i, c_l, c_i, c_i],
 }
 
 
@@ -303,6 +305,20 @@ def workspace(query, dtype, cov, D, S, G, device):
     if nbytes == 0:
         return None, 0
     key = (query, dtype, cov, D, S, G, device, torch.cuda.current_stream().cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf, nbytes
+
+
+def packed_workspace(cov, T, D, K, device):
+    '''(tensor, nbytes) scratch of `beer_normal_accumulate_packed` (grows with T:
+    it holds the transposed frames); one buffer per (shape, stream), grown on demand.'''
+    nbytes = lib().beer_accumulate_packed_workspace_bytes(cov, T, D, K)
+    if nbytes == 0:
+        return None, 0
+    key = ('packed', cov, D, K, device, torch.cuda.current_stream().cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)

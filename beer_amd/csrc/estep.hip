@@ -548,10 +548,19 @@ int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float*
     BEER_REQUIRE(T >= 0 && D >= 1 && K >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(X && packed_resps && acc && workspace);
     BEER_REQUIRE(beer_mfma::supported_acc(D, K));
-    BEER_REQUIRE(workspace_bytes >= beer_mfma::acc16_workspace_bytes(cov, D, K));
+    BEER_REQUIRE(workspace_bytes >= beer_mfma::acc16p_workspace_bytes(cov, T, D, K));
     if (T == 0) return BEER_OK;
-    return beer_mfma::acc_f16x3(cov, T, D, 1, K, X, reinterpret_cast<const float*>(packed_resps),
-                                nullptr, acc, workspace, workspace_bytes, as_stream(stream), true);
+    return beer_mfma::acc_f16x3_packed(cov, T, D, K, X, packed_resps, acc, workspace,
+                                       workspace_bytes, as_stream(stream));
+}
+
+size_t beer_packed_resps_bytes(int64_t T, int K) {
+    return T < 0 || K < 1 ? 0 : beer_mfma::packed_resps_bytes(T, K);
+}
+
+size_t beer_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int K) {
+    if (cov < 0 || cov > 2 || T < 0 || D < 1 || K < 1) return 0;
+    return beer_mfma::acc16p_workspace_bytes(cov, T, D, K);
 }
 
 int beer_unpack_resps(int64_t T, int K, const void* packed_resps, float* resps, void* stream) {

@@ -428,7 +428,7 @@ constexpr int kA16RS = kA16FT;       // R^T row = 8 chunks of 8 frames (16 B), c
                                      // ds_read_b128 for the MFMA lane groups, 2-way ds_write_b32
 constexpr int kA16MaxFrames = 16384; // frames per workgroup: 384 fp32 roundings per sum
 
-template <int NQ, bool HAS_SR, bool PACKED>
+template <int NQ, bool HAS_SR>
 __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     int64_t nframes, int D, int K, int G, int S, int nslab, const float* __restrict__ X,
     const float* __restrict__ R, const float* __restrict__ SR, const int* __restrict__ tab,
@@ -498,11 +498,7 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     constexpr int RPT = 16 * MC * (kA16FT / 2) / kA16Threads;    // (component, frame pair)
     constexpr int XPT = (kA16FT * 64 + kA16Threads - 1) / kA16Threads;   // D <= 64
     const int xcount = kA16FT * D;
-    static_assert(!(PACKED && HAS_SR), "packed responsibilities carry no state factor");
-    static_assert(kPackedRespBits == kRespBits, "K1 packs with the scale K2 removes");
-    // PACKED: r[v] = the (hi, lo) words K1 wrote for the frame pair, stored as they are
-    using rword_t = typename std::conditional<PACKED, unsigned, float>::type;
-    struct Stage { float x[XPT]; rword_t r[RPT][2]; float w[HAS_SR ? RPT : 1][2]; };
+    struct Stage { float x[XPT]; float r[RPT][2]; float w[HAS_SR ? RPT : 1][2]; };
     // staged item v of this thread: component kk (of 128) and frame pair fp (of
     // 32).  One wave instruction covers 32 components x 2 frame pairs: 128-byte
     // row segments from global memory, and ds_write_b32 with at most 2 lanes per
@@ -539,25 +535,14 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
             int kk, fp;
             stage_item(v, kk, fp);
             const int kcl = kk < kvalid ? kk : kvalid - 1;
-            if constexpr (PACKED) {
-                typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
-                const int pairs = (rows + 1) >> 1;
-                const int prow = fp < pairs ? fp : pairs - 1;
-                const uint2_t w2 = *reinterpret_cast<const uint2_t*>(
-                    reinterpret_cast<const unsigned*>(R) + 2 * ((t0 >> 1) * K + kc0) +
-                    2 * (prow * K + kcl));
-                st.r[v][0] = w2.x;
-                st.r[v][1] = w2.y;
-            } else {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int row = 2 * fp + h < rows ? 2 * fp + h : rows - 1;
                     st.r[v][h] = Rt[row * K + kcl];
                     if (HAS_SR) st.w[v][h] = Wt[row * S + (kc0 + kcl) / G];
                 }
-            }
         }
-        __builtin_amdgcn_sched_group_barrier(0x020, XPT + (PACKED ? 1 : (HAS_SR ? 4 : 2)) * RPT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, XPT + (HAS_SR ? 4 : 2) * RPT, 0);
     };
     auto store_x = [&](int buf, int64_t t0, const Stage& st, int v) {
         float* xs = xs_of(buf);
@@ -575,13 +560,6 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
         int kk, fp;
         stage_item(v, kk, fp);
         const int at = kk * kA16RS + (((fp >> 2) ^ (kk & 7)) << 3) + 2 * (fp & 3);
-        if constexpr (PACKED) {
-            // the odd frame of a last, half-filled pair was zeroed by K1
-            const bool ok = 2 * fp < rows && kk < kvalid;
-            *reinterpret_cast<unsigned*>(rh + at) = ok ? st.r[v][0] : 0u;
-            *reinterpret_cast<unsigned*>(rl + at) = ok ? st.r[v][1] : 0u;
-            return;
-        }
         float r2[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -730,19 +708,285 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// K2 for packed responsibilities (one mixture, no state factor).  Same tiles and
+// products as acc16_kernel; what changes is the data movement, which bounds that
+// kernel (a CU streams ~10 B/clk when every CU does: the 42 KB of a 64-frame
+// tile take longer than the 768 MFMAs of 4 statistic tiles per wave):
+//  * both operands arrive as ready-made LDS images -- R as K1 packed it
+//    (estep_tiles.h: packed_word), X as xt_image_kernel transposed it -- so a
+//    tile is a linear copy of 16-byte pieces, global_load_dwordx4 ->
+//    ds_write_b128, without any address or select arithmetic;
+//  * staging is a rolling window: every step of the MFMA loop stores the pieces
+//    loaded half a tile earlier and issues the loads of the pieces half a tile
+//    ahead (~half the registers of one tile instead of two whole tiles);
+//  * the registers this frees allow two waves per SIMD (8 waves of 2 statistic
+//    tiles): one wave's B-fragment arithmetic and LDS waits overlap the other's
+//    MFMAs;
+//  * A and B fragments are loaded one k-step / one step ahead, in place, and the
+//    single barrier per tile sits in front of its last step (see `iteration`).
+// ---------------------------------------------------------------------------
+constexpr int kPiece = kA16Threads * 16;          // bytes one load of the workgroup moves
+
+inline int xt_rows(int D) { return D + 2; }                              // + ones, zeros
+inline int xt_pieces(int D) { return (xt_rows(D) * kA16XS * 4 + kPiece - 1) / kPiece; }
+
+// X [T, D] -> per 64-frame tile the image [D + 2][kA16XS] (rows D, D + 1 = the
+// constants 1, 0; frames past T = 0), padded to whole pieces
+__global__ __launch_bounds__(256) void xt_image_kernel(int64_t nframes, int D, int NX,
+                                                       const float* __restrict__ X,
+                                                       float* __restrict__ Xt) {
+    __shared__ float tile[kA16FT * 65];
+    const int64_t tau = blockIdx.x, t0 = tau * kA16FT;
+    const int rows = (int)(nframes - t0 < kA16FT ? nframes - t0 : kA16FT);
+    for (int e = threadIdx.x; e < rows * D; e += 256) {
+        const int f = e / D, d = e - f * D;
+        tile[f * 65 + d] = X[t0 * D + e];
+    }
+    __syncthreads();
+    float* out = Xt + tau * ((size_t)NX * (kPiece / 4));
+    for (int e = threadIdx.x; e < NX * (kPiece / 4); e += 256) {
+        const int row = e / kA16XS, col = e - row * kA16XS;
+        float v = 0.f;
+        if (row < D) v = col < rows ? tile[col * 65 + row] : 0.f;
+        else if (row == D) v = 1.f;
+        out[e] = v;
+    }
+}
+
+template <int NQ, int NX, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void acc16p_kernel(
+    int64_t nframes, int D, int K, int nslab, const float* __restrict__ Xt,
+    const unsigned* __restrict__ Rimg, const int* __restrict__ tab,
+    const float* __restrict__ sc, int64_t frames_per_block, double* __restrict__ Sp, int gx,
+    int gy, int gz) {
+    constexpr int MC = kA16MC;
+    static_assert(16 * MC == kPackedComps && kA16FT == kPackedFrames && kA16RS == kPackedFrames,
+                  "the packed image is this kernel's LDS tile");
+    static_assert(kPackedRespBits == kRespBits, "K1 packs with the scale K2 removes");
+    constexpr int NSTEP = (kA16FT / 32) * NQ;            // MFMA steps per tile
+    constexpr int LAG = NSTEP / 2;                        // steps between load and store
+    constexpr int NR = 16 * MC * kA16RS * 2 * 2 / kPiece;    // R pieces (hi + lo images)
+    constexpr int NI = NX + NR;
+    // 256 threads move one piece; with 8 waves the two halves of the workgroup take
+    // alternate pieces (an odd last piece is moved twice: same bytes, same place)
+    constexpr int HALVES = WAVES / 4, NIT = (NI + HALVES - 1) / HALVES;
+    static_assert(WAVES == 4 || WAVES == 8, "one or two waves per SIMD");
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int D4 = d4_of(D), Dp = 4 * D4, nq = nslab * 4;
+    // XCD-aware mapping as in acc16_kernel
+    const int id = blockIdx.x, xcd = id & 7, slot0 = id >> 3;
+    const int bx = slot0 % gx;
+    const int yz = (slot0 / gx) * 8 + xcd;
+    if (yz >= gy * gz) return;
+    const int by = yz % gy, bz = yz / gy;
+    const int tile0 = (bx * WAVES + wave) * NQ;
+    const int kc0 = by * (16 * MC);
+    const int64_t tb = (int64_t)bz * frames_per_block;
+    const int64_t te = tb + frames_per_block < nframes ? tb + frames_per_block : nframes;
+    const int ntiles = (int)((te - tb + kA16FT - 1) / kA16FT);
+    const int64_t tau0 = tb / kA16FT, tau_last = (nframes + kA16FT - 1) / kA16FT - 1;
+
+    // LDS: two buffers of [X image: NX pieces][R hi image][R lo image].  Every LDS
+    // address below is one per-lane byte offset (kept in a register for the whole
+    // kernel) plus a compile-time constant -- buffer, k-step, component tile, hi / lo
+    // all go into the offset field of the DS instruction.
+    constexpr int buf_bytes = NI * kPiece;
+    constexpr int r_off = NX * kPiece, lo_off = 16 * MC * kA16RS * 2;
+
+    auto factors = [&](int uu, int& a, int& b) {
+        const int col = 16 * (tile0 + uu) + i, slab = col >> 2;
+        a = b = Dp + 1;
+        if (slab < nslab) {
+            const int t = tab[slab];
+            b = ((t >> 8) & 0xff) + (col & 3);
+            a = (t >> 16) ? b : (t & 0xff);
+        }
+    };
+    // byte offsets of the lane's 8 frames (k-step 0) in the two X^T rows of its
+    // statistic column, per tile of the wave; and the range scale of the product
+    int xa_off[NQ], xb_off[NQ];
+    float sab[NQ];
+#pragma unroll
+    for (int uu = 0; uu < NQ; ++uu) {
+        int a, b;
+        factors(uu, a, b);
+        xa_off[uu] = ((a < D ? a : (a == Dp ? D : D + 1)) * kA16XS + 8 * g) * 4;
+        xb_off[uu] = ((b < D ? b : (b == Dp ? D : D + 1)) * kA16XS + 8 * g) * 4;
+        sab[uu] = (a < D ? sc[a] : 1.f) * (b < D ? sc[b] : 1.f);
+    }
+    // A fragments: row i of component tile c, chunk (4 ks + g) ^ (i & 7)
+    int a_off[kA16FT / 32];
+#pragma unroll
+    for (int ks = 0; ks < kA16FT / 32; ++ks)
+        a_off[ks] = r_off + (i * kA16RS + (((4 * ks + g) ^ (i & 7)) << 3)) * 2;
+    const int t_off = 16 * (tid & (kA16Threads - 1));
+    const int half = __builtin_amdgcn_readfirstlane(tid / kA16Threads);
+
+    f32x4 acc[MC][NQ];
+#pragma unroll
+    for (int c = 0; c < MC; ++c)
+#pragma unroll
+        for (int uu = 0; uu < NQ; ++uu) acc[c][uu] = f32x4{0, 0, 0, 0};
+
+    // piece v of a tile: v < NX from the X image, the others from the R image of
+    // component block `by`; thread tid moves bytes [16 tid, 16 tid + 16) of it.
+    // Tiles past the end of the data read the last tile again (never used).
+    const int nblk = (K + 16 * MC - 1) / (16 * MC);
+    // item j of a thread = piece HALVES * j + half
+    u32x4 w[NIT];
+    const char* xsrc = reinterpret_cast<const char*>(Xt) + t_off;
+    const char* rsrc = reinterpret_cast<const char*>(Rimg) + t_off;
+    auto piece_of = [&](int j) {
+        const int v = HALVES * j + half;
+        return v < NI ? v : NI - 1;
+    };
+    auto issue = [&](int tile, int j) {
+        int64_t tau = tau0 + tile;
+        tau = tau < tau_last ? tau : tau_last;
+        const int v = piece_of(j);
+        const char* src = v < NX ? xsrc + (tau * NX + v) * (size_t)kPiece
+                                 : rsrc + ((tau * nblk + by) * NR + (v - NX)) * (size_t)kPiece;
+        w[j] = *reinterpret_cast<const u32x4*>(src);
+    };
+    auto store = [&](int j, int buf) {
+        *reinterpret_cast<u32x4*>(smem + t_off + (buf * buf_bytes + piece_of(j) * kPiece)) = w[j];
+    };
+    // step that stores item j: all but the last step of a tile, see the barrier below
+    auto store_step = [](int j) { return NSTEP == 1 ? 0 : j * (NSTEP - 1) / NIT; };
+
+    if (ntiles > 0) {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) issue(0, j);
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) store(j, 0);
+#pragma unroll
+        for (int j = 0; j < NIT; ++j)
+            if (store_step(j) < LAG) issue(1, j);
+    }
+    __syncthreads();
+    const bool active = tile0 * 16 < nq;
+    // operand fragments, loaded one step (B) / one k-step (A) before the MFMAs
+    // that use them: loop-carried, the last step of a tile loads from the next one
+    h8 ah[MC], al[MC], bh[2], bl[2];
+    auto gen_b = [&](int buf, int ks, int uu, h8& h, h8& l) {
+        const char* pa = smem + xa_off[uu] + (buf * buf_bytes + 128 * ks);
+        const char* pb = smem + xb_off[uu] + (buf * buf_bytes + 128 * ks);
+        const f32x4 xa0 = *reinterpret_cast<const f32x4*>(pa);
+        const f32x4 xa1 = *reinterpret_cast<const f32x4*>(pa + 16);
+        const f32x4 xb0 = *reinterpret_cast<const f32x4*>(pb);
+        const f32x4 xb1 = *reinterpret_cast<const f32x4*>(pb + 16);
+        split8((xa0 * sab[uu]) * xb0, (xa1 * sab[uu]) * xb1, h, l);
+    };
+    auto a_ptr = [&](int buf, int ks, int c) {
+        return smem + a_off[ks] + (buf * buf_bytes + c * 16 * kA16RS * 2);
+    };
+    if (active && ntiles > 0) {
+#pragma unroll
+        for (int c = 0; c < MC; ++c) {
+            ah[c] = *reinterpret_cast<const h8*>(a_ptr(0, 0, c));
+            al[c] = *reinterpret_cast<const h8*>(a_ptr(0, 0, c) + lo_off);
+        }
+        gen_b(0, 0, 0, bh[0], bl[0]);
+    }
+    // One tile out of buffer `buf` (a constant once inlined).  ONE barrier per
+    // tile, in front of its last step: by then every wave has stored its pieces of
+    // tile + 1 (all stores are in the steps before) and has read everything it
+    // needs from this buffer (the fragments of the last step were loaded during
+    // the step before), so the last step may load the first fragments of tile + 1
+    // from the other buffer, and the next tile may overwrite this one.
+    auto iteration = [&](int tile, int buf) __attribute__((always_inline)) {
+        // step s: store the pieces of tile + 1 that are due, issue those due LAG
+        // steps from now (of tile + 1, or of tile + 2 past the end of this tile)
+        auto stage_step = [&](int s) {
+#pragma unroll
+            for (int j = 0; j < NIT; ++j)
+                if (store_step(j) == s) store(j, buf ^ 1);
+#pragma unroll
+            for (int j = 0; j < NIT; ++j)
+                if (store_step(j) == (s + LAG) % NSTEP) issue(tile + 1 + (s + LAG) / NSTEP, j);
+        };
+        if (active) {
+#pragma unroll
+            for (int ks = 0; ks < kA16FT / 32; ++ks) {
+#pragma unroll
+                for (int uu = 0; uu < NQ; ++uu) {
+                    const int step = ks * NQ + uu;
+                    const bool last_step = step == NSTEP - 1, last_uu = uu == NQ - 1;
+                    if (last_step) __syncthreads();
+                    // where the fragments of the next step / k-step come from
+                    const int nbuf = last_step ? buf ^ 1 : buf;
+                    const int nks = last_uu ? (ks + 1) % (kA16FT / 32) : ks;
+                    const int cur = step & 1;
+                    gen_b(nbuf, nks, last_uu ? 0 : uu + 1, bh[cur ^ 1], bl[cur ^ 1]);
+#pragma unroll
+                    for (int c = 0; c < MC; ++c)
+                        acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], bh[cur], acc[c][uu], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < MC; ++c) {
+                        acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], bl[cur], acc[c][uu], 0, 0, 0);
+                        if (last_uu) ah[c] = *reinterpret_cast<const h8*>(a_ptr(nbuf, nks, c));
+                    }
+#pragma unroll
+                    for (int c = 0; c < MC; ++c) {
+                        acc[c][uu] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c], bh[cur], acc[c][uu], 0, 0, 0);
+                        if (last_uu)
+                            al[c] = *reinterpret_cast<const h8*>(a_ptr(nbuf, nks, c) + lo_off);
+                    }
+                    stage_step(step);
+                    // one step at a time: keeps the staging and the fragment loads
+                    // of later steps from being hoisted (and their registers live)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                if (s == NSTEP - 1) __syncthreads();
+                stage_step(s);
+            }
+        }
+    };
+    for (int tile = 0; tile < ntiles; tile += 2) {
+        iteration(tile, 0);
+        if (tile + 1 < ntiles) iteration(tile + 1, 1);
+    }
+    const float* isx = sc + 64;
+#pragma unroll
+    for (int uu = 0; uu < NQ; ++uu) {
+        const int q = (tile0 + uu) * 16 + i;
+        if (q >= nq) continue;
+        int a, b;
+        factors(uu, a, b);
+        const double unscale = (a < D ? (double)isx[a] : 1.0) * (b < D ? (double)isx[b] : 1.0) /
+                               (double)(1 << kRespBits);
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = kc0 + 16 * c + 4 * g + r;
+                if (k < K) atomicAdd(Sp + (size_t)k * nq + q, (double)acc[c][uu][r] * unscale);
+            }
+    }
+}
+
 // packed responsibilities -> float32 (tests, callers that want to look at them)
-__global__ void unpack_resps_kernel(int64_t nframes, int K, const unsigned* __restrict__ Rp,
+__global__ void unpack_resps_kernel(int64_t nframes, int K, const unsigned* __restrict__ Rimg,
                                     float* __restrict__ R) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // (pair, k)
-    const int64_t pairs = (nframes + 1) >> 1;
-    if (idx >= pairs * K) return;
-    const int64_t p = idx / K;
-    const int k = (int)(idx - p * K);
-    const hp2 hi = __builtin_bit_cast(hp2, Rp[2 * idx]);
-    const hp2 lo = __builtin_bit_cast(hp2, Rp[2 * idx + 1]);
-    const float down = 1.f / (float)(1 << kRespBits);
-    R[(2 * p) * K + k] = ((float)hi[0] + (float)lo[0]) * down;
-    if (2 * p + 1 < nframes) R[(2 * p + 1) * K + k] = ((float)hi[1] + (float)lo[1]) * down;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // (frame, k)
+    if (idx >= nframes * K) return;
+    const int64_t f = idx / K;
+    const int k = (int)(idx - f * K);
+    const int nblk = (K + kPackedComps - 1) / kPackedComps;
+    const int f6 = (int)(f % kPackedFrames);
+    const _Float16* hi = reinterpret_cast<const _Float16*>(
+        Rimg + packed_word(f / kPackedFrames, nblk, k / kPackedComps, k % kPackedComps, f6 & ~1));
+    const _Float16* lo = hi + kPackedComps * kPackedFrames;
+    R[idx] = ((float)hi[f6 & 1] + (float)lo[f6 & 1]) * (1.f / (float)(1 << kRespBits));
 }
 
 inline int nt16_for(int S, int K) { return S > 1 ? 16 : (K <= 64 ? 4 : (K <= 128 ? 8 : 16)); }
@@ -768,8 +1012,14 @@ int f16_range_hazard(int64_t nframes, int D, const float* X, void* scratch, int*
     return BEER_OK;
 }
 
+size_t packed_resps_bytes(int64_t nframes, int K) {
+    const int64_t tiles = (nframes + kPackedFrames - 1) / kPackedFrames;
+    const int nblk = (K + kPackedComps - 1) / kPackedComps;
+    return (size_t)tiles * nblk * kPackedComps * kPackedFrames * 4;
+}
+
 int unpack_resps(int64_t nframes, int K, const void* packed, float* resps, hipStream_t s) {
-    const int64_t n = ((nframes + 1) >> 1) * K;
+    const int64_t n = nframes * K;
     if (n == 0) return BEER_OK;
     hipLaunchKernelGGL(unpack_resps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                        nframes, K, reinterpret_cast<const unsigned*>(packed), resps);
@@ -845,10 +1095,85 @@ size_t acc16_workspace_bytes(int cov, int D, int K) {
     return up256((size_t)K * nslab * 4 * sizeof(double)) + up256((size_t)nslab * sizeof(int)) + 1024;
 }
 
+size_t acc16p_workspace_bytes(int cov, int64_t nframes, int D, int K) {
+    const size_t base = acc16_workspace_bytes(cov, D, K);
+    if (base == 0) return 0;
+    const int64_t tiles = (nframes + kA16FT - 1) / kA16FT;
+    return base + (size_t)tiles * xt_pieces(D) * kPiece;
+}
+
+int acc_f16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, const void* Rimg,
+                     double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!supported_acc(D, K) || ws_bytes < acc16p_workspace_bytes(cov, nframes, D, K))
+        return BEER_EINVAL;
+    const int nslab = nslab_of(cov, D), nq = nslab * 4;
+    char* w = reinterpret_cast<char*>(ws);
+    double* Sp = reinterpret_cast<double*>(w);
+    w += up256((size_t)K * nq * sizeof(double));
+    int* tab = reinterpret_cast<int*>(w);
+    w += up256((size_t)nslab * sizeof(int));
+    unsigned* absmax = reinterpret_cast<unsigned*>(w);
+    float* sc = reinterpret_cast<float*>(w + 256);
+    float* Xt = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + acc16_workspace_bytes(cov, D, K));
+    hipError_t e = hipMemsetAsync(Sp, 0, (size_t)K * nq * sizeof(double), s);
+    if (e != hipSuccess) return -(int)e;
+    const int rc = launch_scales(X, nframes, D, absmax, sc, s);
+    if (rc != BEER_OK) return rc;
+    hipLaunchKernelGGL(tab_kernel, dim3(1), dim3(256), 0, s, cov, D, tab);
+    BEER_LAUNCH_CHECK();
+    const int64_t tiles = (nframes + kA16FT - 1) / kA16FT;
+    const int NX = xt_pieces(D);
+    hipLaunchKernelGGL(xt_image_kernel, dim3((unsigned)tiles), dim3(256), 0, s, nframes, D, NX, X, Xt);
+    BEER_LAUNCH_CHECK();
+    const int ntiles = (nq + 15) / 16;
+    // 8 waves, two per SIMD (256 registers each): measured faster than 4 waves with
+    // twice the statistic tiles each (1.26 against 1.31 ms at K = 256, D = 40, full)
+    const int waves = 8;
+    const int NQ = ntiles > waves ? 2 : 1;
+    const int gx = (ntiles + NQ * waves - 1) / (NQ * waves);
+    const int gy = (K + 16 * kA16MC - 1) / (16 * kA16MC);
+    int64_t gz = (1024 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy);
+    const int64_t max_z = (nframes + 1023) / 1024, min_z = (nframes + kA16MaxFrames - 1) / kA16MaxFrames;
+    if (gz > max_z) gz = max_z;
+    if (gz < min_z) gz = min_z;
+    if (gz < 1) gz = 1;
+    int64_t fpb = (nframes + gz - 1) / gz;
+    fpb = (fpb + kA16FT - 1) / kA16FT * kA16FT;
+    gz = (nframes + fpb - 1) / fpb;
+    const size_t lds = 2 * (size_t)(NX + 8) * kPiece;
+    const int64_t nyz = ((int64_t)gy * gz + 7) / 8 * 8;
+    const dim3 grid((unsigned)(nyz * gx));
+#define BEER_ACC16P(NQ_, NX_, W_)                                                                \
+    do {                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc16p_kernel<NQ_, NX_, W_>),    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        hipLaunchKernelGGL((acc16p_kernel<NQ_, NX_, W_>), grid, dim3(64 * W_), lds, s, nframes,  \
+                           D, K, nslab, Xt, reinterpret_cast<const unsigned*>(Rimg), tab, sc,    \
+                           fpb, Sp, gx, gy, (int)gz);                                            \
+    } while (0)
+#define BEER_ACC16P_NX(NQ_, W_)                                                                  \
+    do {                                                                                         \
+        if (NX == 1) BEER_ACC16P(NQ_, 1, W_);                                                    \
+        else if (NX == 2) BEER_ACC16P(NQ_, 2, W_);                                               \
+        else if (NX == 3) BEER_ACC16P(NQ_, 3, W_);                                               \
+        else if (NX == 4) BEER_ACC16P(NQ_, 4, W_);                                               \
+        else BEER_ACC16P(NQ_, 5, W_);                                                            \
+    } while (0)
+    if (NQ == 2) BEER_ACC16P_NX(2, 8);
+    else BEER_ACC16P_NX(1, 8);
+#undef BEER_ACC16P_NX
+#undef BEER_ACC16P
+    BEER_LAUNCH_CHECK();
+    const int64_t total = (int64_t)K * stats_dim(cov, D);
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cov,
+                       D, K, Sp, acc);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
 int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, const float* R,
-              const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s, bool packed) {
+              const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
     const int K = S * G;
-    if (packed && SR) return BEER_EINVAL;
     if (!supported_acc(D, K) || ws_bytes < acc16_workspace_bytes(cov, D, K)) return BEER_EINVAL;
     const int nslab = nslab_of(cov, D), nq = nslab * 4;
     char* w = reinterpret_cast<char*>(ws);
@@ -881,20 +1206,14 @@ int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, con
     const size_t lds = 2 * ((size_t)(D + 3) * kA16XS * 4 + (size_t)16 * mc * kA16RS * 2 * 2) + 256;
     const int64_t nyz = ((int64_t)gy * gz + 7) / 8 * 8;
     const dim3 grid((unsigned)(nyz * gx));
-#define BEER_ACC16_(NQ_, SR_, P_)                                                                \
+#define BEER_ACC16(NQ_, SR_)                                                                     \
     do {                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc16_kernel<NQ_, SR_, P_>),     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc16_kernel<NQ_, SR_>),         \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-        hipLaunchKernelGGL((acc16_kernel<NQ_, SR_, P_>), grid, dim3(kA16Threads), lds, s,        \
-                           nframes, D, K, G, S, nslab, X, R, SR, tab, sc, fpb, Sp, gx, gy,       \
-                           (int)gz);                                                             \
+        hipLaunchKernelGGL((acc16_kernel<NQ_, SR_>), grid, dim3(kA16Threads), lds, s, nframes,   \
+                           D, K, G, S, nslab, X, R, SR, tab, sc, fpb, Sp, gx, gy, (int)gz);      \
     } while (0)
-#define BEER_ACC16(NQ_, SR_) BEER_ACC16_(NQ_, SR_, false)
-    if (packed) {
-        if (NQ == 4) BEER_ACC16_(4, false, true);
-        else if (NQ == 2) BEER_ACC16_(2, false, true);
-        else BEER_ACC16_(1, false, true);
-    } else if (SR) {
+    if (SR) {
         if (NQ == 4) BEER_ACC16(4, true);
         else if (NQ == 2) BEER_ACC16(2, true);
         else BEER_ACC16(1, true);
@@ -904,7 +1223,6 @@ int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, con
         else BEER_ACC16(1, false);
     }
 #undef BEER_ACC16
-#undef BEER_ACC16_
     BEER_LAUNCH_CHECK();
     const int64_t total = (int64_t)K * stats_dim(cov, D);
     hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cov,

@@ -17,8 +17,8 @@ size_t acc_workspace_bytes(int cov, int D, int K);
 // fp32 models on the fp16 matrix pipes (estep_f16.hip): every fp32 operand is
 // split into two fp16 halves, three fp16 MFMAs per product, fp32 accumulation.
 size_t estep16_workspace_bytes(int cov, int D, int S, int G);
-// `packed`: S = 1 only; `resps` then receives the fp16 hi / lo pairs the
-// accumulation kernel consumes (estep_tiles.h: softmax_epilogue<PACKED>).
+// `packed`: S = 1 only; `resps` (packed_resps_bytes) then receives the fp16 hi / lo
+// image the accumulation kernel consumes (estep_tiles.h: softmax_epilogue<PACKED>).
 int estep_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
                 const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
                 size_t ws_bytes, hipStream_t s, bool packed = false);
@@ -29,10 +29,14 @@ int unpack_resps(int64_t T, int K, const void* packed, float* resps, hipStream_t
 int f16_range_hazard(int64_t T, int D, const float* X, void* scratch, int* hazard,
                      hipStream_t s);
 size_t acc16_workspace_bytes(int cov, int D, int K);
-// `packed`: R holds the packed pairs written by estep_f16x3(..., packed = true); SR must be null.
 int acc_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* R,
-              const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s,
-              bool packed = false);
+              const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s);
+// One mixture with the responsibilities as estep_f16x3(..., packed = true) wrote them
+// (packed_resps_bytes); the workspace also holds the transposed frames, hence T.
+size_t packed_resps_bytes(int64_t T, int K);
+size_t acc16p_workspace_bytes(int cov, int64_t T, int D, int K);
+int acc_f16x3_packed(int cov, int64_t T, int D, int K, const float* X, const void* Rimg,
+                     double* acc, void* ws, size_t ws_bytes, hipStream_t s);
 
 int estep_f32(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
               const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,

@@ -159,11 +159,22 @@ __global__ void unpack_kernel(int cov, int D, int K, const double* __restrict__ 
 // of a wave's acc[MT][NT] tiles (frames fb .. fb + 16 MT, components kbase ..).
 // ---------------------------------------------------------------------------
 // PACKED (float only): instead of float32 responsibilities, `resps` receives
-// them already split for the fp16 accumulation kernel -- per (frame pair, k) two
-// 32-bit words, (hi(f), hi(f+1)) and (lo(f), lo(f+1)) of r * 2^12 as fp16 pairs,
-// at word index 2 * ((f / 2) * K + k): the same bytes per element, and
-// acc16_kernel stores them into its LDS image without any arithmetic.
+// them as the accumulation kernel's LDS image, so that it copies them there
+// without arithmetic.  The image is cut into tiles of 64 frames x 128
+// components (tile index tau * nblk + beta, 32 KB each): first the fp16 high
+// halves of r * 2^12 as rows [component][64 frames] of 128 bytes whose 16-byte
+// chunks (8 frames) are stored at position chunk ^ (component & 7) -- the
+// swizzle that makes the MFMA fragment reads conflict-free -- then the low
+// halves in the same arrangement.  Frames past T and components past K are 0.
 constexpr int kPackedRespBits = 12;
+constexpr int kPackedFrames = 64, kPackedComps = 128;
+
+// 32-bit word index of the hi half of (component kk of block beta, frame f6 of
+// tile tau); the lo half is kPackedComps * kPackedFrames / 2 words further
+__host__ __device__ inline size_t packed_word(int64_t tau, int nblk, int beta, int kk, int f6) {
+    const int half = kk * kPackedFrames + (((f6 >> 3) ^ (kk & 7)) << 3) + (f6 & 7);
+    return ((size_t)tau * nblk + beta) * (kPackedComps * kPackedFrames) + (half >> 1);
+}
 
 template <typename T, int NT, int MT, int GQ, bool PACKED = false>
 __device__ __forceinline__ void softmax_epilogue(
@@ -269,43 +280,59 @@ __device__ __forceinline__ void softmax_epilogue(
                 }
             }
         }
-        if constexpr (PACKED) {
-            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-            typedef float float2_t __attribute__((ext_vector_type(2)));
-            typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
-            unsigned int* out = reinterpret_cast<unsigned int*>(resps);
-            const float up = (float)(1 << kPackedRespBits);
+    }
+    if constexpr (PACKED) {
+        // acc[m][4 tt + j] = component kbase + 64 tt + 4 i + j, its 4 values = frames
+        // fb + 16 m + 4 g + (0..3): half of a 16-byte chunk (8 frames) of the image
+        // row.  Lanes g and g ^ 1 (16 lanes apart) hold the two halves, for m = 0
+        // and for m = 1: one v_permlane16_swap per word leaves the even-g lane with
+        // the whole chunk of m = 0 and the odd-g lane with that of m = 1, so that
+        // every lane stores 16 bytes and 4 lanes fill a 64-byte segment of the row.
+        static_assert(!PACKED || MT == 2, "the lane pairs exchange the two frame tiles");
+        typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+        typedef float float4_t __attribute__((ext_vector_type(4)));
+        typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
+        typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+        unsigned int* out = reinterpret_cast<unsigned int*>(resps);
+        const float up = (float)(1 << kPackedRespBits);
+        const int nblk = (K + kPackedComps - 1) / kPackedComps;
+        const int64_t tiles = (nframes + kPackedFrames - 1) / kPackedFrames;
+        // the chunk this lane stores after the exchange
+        const int64_t fc = fb + 16 * (g & 1) + 8 * (g >> 1);
+        const int64_t tau = fc / kPackedFrames;
+        const int f6 = (int)(fc - tau * kPackedFrames);
+        const bool chunk_ok = out && fc < tiles * kPackedFrames;
 #pragma unroll
-            for (int p2 = 0; p2 < 2; ++p2) {
-                __builtin_amdgcn_sched_barrier(0);
-                const int64_t f = fb + m * 16 + M::row(g, 2 * p2);       // even
-                if (out && f < nframes) {
-                    const bool second = f + 1 < nframes;
+        for (int nt = 0; nt < NT; ++nt) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int k = kbase + 64 * (nt >> 2) + 4 * i + (nt & 3);
+            uint2_t hi[2], lo[2];
 #pragma unroll
-                    for (int tq = 0; tq < NT / 4; ++tq) {
-                        const int k = kbase + 64 * tq + 4 * i;
-                        unsigned int w[8];
+            for (int m = 0; m < 2; ++m) {
+                const int64_t f0 = fb + m * 16 + M::row(g, 0);
+                float4_t v;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float2_t v = {(float)acc[m][4 * tq + j][2 * p2] * up,
-                                                second ? (float)acc[m][4 * tq + j][2 * p2 + 1] * up : 0.f};
-                            const half2_t hi = __builtin_convertvector(v, half2_t);
-                            const half2_t lo = __builtin_convertvector(
-                                v - __builtin_convertvector(hi, float2_t), half2_t);
-                            w[2 * j] = __builtin_bit_cast(unsigned int, hi);
-                            w[2 * j + 1] = __builtin_bit_cast(unsigned int, lo);
-                        }
-                        unsigned int* dst = out + 2 * ((size_t)(f >> 1) * K + k);
-                        if (vec_ok && k + 3 < K) {
-                            *reinterpret_cast<uint4_t*>(dst) = uint4_t{w[0], w[1], w[2], w[3]};
-                            *reinterpret_cast<uint4_t*>(dst + 4) = uint4_t{w[4], w[5], w[6], w[7]};
-                        } else {
+                for (int r = 0; r < 4; ++r)
+                    v[r] = f0 + r < nframes && k < K ? (float)acc[m][nt][r] * up : 0.f;
+                const half4_t h = __builtin_convertvector(v, half4_t);
+                const half4_t l = __builtin_convertvector(
+                    v - __builtin_convertvector(h, float4_t), half4_t);
+                hi[m] = __builtin_bit_cast(uint2_t, h);
+                lo[m] = __builtin_bit_cast(uint2_t, l);
+            }
+            uint4_t ch, cl;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (k + j < K) { dst[2 * j] = w[2 * j]; dst[2 * j + 1] = w[2 * j + 1]; }
-                        }
-                    }
-                }
+            for (int wd = 0; wd < 2; ++wd) {
+                const auto sh = __builtin_amdgcn_permlane16_swap(hi[0][wd], hi[1][wd], false, false);
+                const auto sl = __builtin_amdgcn_permlane16_swap(lo[0][wd], lo[1][wd], false, false);
+                ch[wd] = sh[0]; ch[2 + wd] = sh[1];
+                cl[wd] = sl[0]; cl[2 + wd] = sl[1];
+            }
+            if (chunk_ok && k < nblk * kPackedComps) {
+                unsigned int* dst = out + packed_word(tau, nblk, k / kPackedComps,
+                                                      k & (kPackedComps - 1), f6);
+                *reinterpret_cast<uint4_t*>(dst) = ch;
+                *reinterpret_cast<uint4_t*>(dst + kPackedComps * kPackedFrames / 2) = cl;
             }
         }
     }

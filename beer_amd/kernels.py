@@ -89,14 +89,11 @@ def mixtureset_estep(stats, exp_stats, log_weights, S, G, cov_type, labels=None,
 class PackedResps:
     '''Responsibilities [T, K] of one mixture in the form the fp16 accumulation
     kernel multiplies with (include/beer_hip.h: beer_mixture_estep_packed):
-    `words` int32 [ceil(T/2), K, 2].  `unpack()` gives the float32 matrix.'''
+    `words` int32, the tiles of 64 frames x 128 components that kernel copies
+    to LDS.  `unpack()` gives the float32 matrix.'''
 
-    def __init__(self, words, nframes):
-        self.words, self.nframes = words, nframes
-
-    @property
-    def shape(self):
-        return (self.nframes, self.words.shape[1])
+    def __init__(self, words, nframes, ncomp):
+        self.words, self.shape = words, (nframes, ncomp)
 
     def unpack(self):
         T, K = self.shape
@@ -131,13 +128,14 @@ def mixture_estep_packed(stats, exp_stats, log_weights, K, cov_type, llh_sum=Non
     if E.shape[0] != K or lw.numel() != K:
         raise ValueError(f'{E.shape[0]} Gaussians, {lw.numel()} weights for {K} components')
     log_norm = torch.empty(T, 1, dtype=X.dtype, device=X.device)
-    words = torch.empty((T + 1) // 2, K, 2, dtype=torch.int32, device=X.device)
+    words = torch.empty(_hip.lib().beer_packed_resps_bytes(T, K) // 4, dtype=torch.int32,
+                        device=X.device)
     ws, ws_bytes = _hip.workspace('beer_estep_workspace_bytes', X.dtype,
                                   _hip.COV_CODE[cov_type], D, 1, K, X.device)
     _hip.call('beer_mixture_estep_packed', _hip.COV_CODE[cov_type], T, D, K, _hip.ptr(X),
               _hip.ptr(E), _hip.ptr(lw), _hip.ptr(log_norm), _hip.ptr(words), _hip.ptr(llh_sum),
               _hip.ptr(ws), ws_bytes)
-    return log_norm, PackedResps(words, T)
+    return log_norm, PackedResps(words, T, K)
 
 
 def normal_accumulate(stats, comp_resps, state_resps, S, G, cov_type, acc=None):
@@ -157,8 +155,7 @@ def normal_accumulate(stats, comp_resps, state_resps, S, G, cov_type, acc=None):
         if state_resps is not None or tuple(comp_resps.shape) != (T, K):
             raise ValueError('packed responsibilities: same frames and components, no state '
                              'responsibilities')
-        ws, ws_bytes = _hip.workspace('beer_accumulate_workspace_bytes', X.dtype,
-                                      _hip.COV_CODE[cov_type], D, 1, K, X.device)
+        ws, ws_bytes = _hip.packed_workspace(_hip.COV_CODE[cov_type], T, D, K, X.device)
         _hip.call('beer_normal_accumulate_packed', _hip.COV_CODE[cov_type], T, D, K,
                   _hip.ptr(X), _hip.ptr(comp_resps.words), _hip.ptr(acc), _hip.ptr(ws), ws_bytes)
         return acc

@@ -225,19 +225,26 @@ int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G,
 
 /* The E-step -> accumulate hand-over of a single mixture (S = 1, float32, split
  * arithmetic: beer_hip_set_f32_mode) without the float32 responsibilities in
- * between.  `packed_resps` (T rounded up to even, times K, times 4 bytes: the
- * size of the [T,K] float32 matrix) receives each responsibility already split
- * into the fp16 pair the accumulation kernel multiplies with -- per (frame
- * pair p, component k) two 32-bit words at word index 2 * (p * K + k): the high
- * halves of r * 2^12 for frames 2p, 2p+1, then the low halves.  The values are
- * the ones beer_mixtureset_estep / beer_normal_accumulate compute in the split
- * mode (same roundings), so the statistics are bit-identical to the two-call
- * path; the accumulation kernel just stops spending vector ALU on the split.
- * Same reference functions as the two calls above (mixture.py:86-101 for the
- * responsibilities, normalset.py:121-123 for the statistics).
- * beer_unpack_resps restores the [T,K] float32 matrix (hi + lo) / 2^12.
+ * between.  `packed_resps` (beer_packed_resps_bytes(T, K) bytes: 4 bytes per
+ * element with T rounded up to 64 and K to 128) receives each responsibility
+ * already split into the fp16 pair the accumulation kernel multiplies with,
+ * laid out as that kernel's LDS tiles: per (64 frames, 128 components) 32 KB =
+ * the high halves of r * 2^12 as rows [component][64 frames] whose 16-byte
+ * chunks sit at position chunk ^ (component & 7), then the low halves in the
+ * same arrangement; frames >= T and components >= K are 0.  The accumulation
+ * kernel copies the tiles to LDS as they are.  The values are the ones
+ * beer_mixtureset_estep / beer_normal_accumulate compute in the split mode
+ * (same roundings), so the statistics equal the two-call path up to the order
+ * of the fp64 sums.  Same reference functions as the two calls above
+ * (mixture.py:86-101 for the responsibilities, normalset.py:121-123 for the
+ * statistics).  beer_unpack_resps restores the [T,K] float32 matrix
+ * (hi + lo) / 2^12.  The accumulation workspace also holds the frames
+ * transposed into 64-frame tiles, hence its own size query with T.
  * EINVAL: shape without a matrix-core path, workspace NULL / too small (sizes
- * from beer_estep_workspace_bytes / beer_accumulate_workspace_bytes, BEER_F32). */
+ * from beer_estep_workspace_bytes(BEER_F32, ...) and
+ * beer_accumulate_packed_workspace_bytes). */
+size_t beer_packed_resps_bytes(int64_t T, int K);
+size_t beer_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int K);
 int beer_mixture_estep_packed(int cov, int64_t T, int D, int K, const float* X,
                               const float* exp_stats, const float* log_weights,
                               float* log_norm, void* packed_resps, double* llh_sum,
