@@ -23,6 +23,13 @@ template <> struct Mma<float> {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ int row(int g, int r) { return 4 * g + r; }
+    // exp of a non-positive softmax argument: v_exp_f32 (1 ulp) on x * log2(e).  The
+    // product's rounding adds |x| * 6e-8 of relative error to a term of weight
+    // e^x -- at most 2e-8 of the sum -- against the 12 instructions of expf.
+    static __device__ __forceinline__ float exp_neg(float x) {
+        return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+    }
+    static __device__ __forceinline__ float recip(float x) { return __builtin_amdgcn_rcpf(x); }
 };
 template <> struct Mma<double> {
     using acc_t = f64x4;
@@ -31,6 +38,8 @@ template <> struct Mma<double> {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ int row(int g, int r) { return g + 4 * r; }
+    static __device__ __forceinline__ double exp_neg(double x) { return exp(x); }
+    static __device__ __forceinline__ double recip(double x) { return 1.0 / x; }
 };
 
 // All-reduce across the 16 lanes that hold one row of a 16x16 C tile, with
@@ -210,12 +219,12 @@ __device__ __forceinline__ void softmax_epilogue(
                     for (int qq = 0; qq < GQ; ++qq)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            e[qq][j] = exp(acc[m][4 * (tq * GQ + qq) + j][r] - mx);
+                            e[qq][j] = M::exp_neg(acc[m][4 * (tq * GQ + qq) + j][r] - mx);
                             sum += e[qq][j];
                         }
                     sum = group_sum(sum, gl);
                     const T lse = mx + log(sum);
-                    const T inv = (T)1 / sum;
+                    const T inv = M::recip(sum);
 #pragma unroll
                     for (int qq = 0; qq < GQ; ++qq)
 #pragma unroll
@@ -232,7 +241,7 @@ __device__ __forceinline__ void softmax_epilogue(
                         const T a0 = acc[m][4 * tq * GQ + j0][r], a1 = acc[m][4 * tq * GQ + j0 + 1][r];
                         if (jw == 2) {
                             const T mx = a0 > a1 ? a0 : a1;
-                            const T e0 = exp(a0 - mx), e1 = exp(a1 - mx);
+                            const T e0 = M::exp_neg(a0 - mx), e1 = M::exp_neg(a1 - mx);
                             const T lse = mx + log(e0 + e1);
                             e[0][j0] = e0 / (e0 + e1);
                             e[0][j0 + 1] = e1 / (e0 + e1);
