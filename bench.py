@@ -179,7 +179,7 @@ def pmc_traffic(kernel_key):
         # FETCH_SIZE under-reports wide (16 B/lane) coalesced reads by 2x on gfx950
         # (MI355X_MICROARCH.md): K2 streams R with 16-byte loads -> corrected; K1's
         # reads are 4-byte -> raw.
-        read = k['hbm_read_bytes_raw'] * (2. if kernel_key == 'acc_kernel' else 1.)
+        read = k['hbm_read_bytes_raw'] * (2. if kernel_key.startswith('acc') else 1.)
         return read + k['hbm_write_bytes']
     except Exception:
         return None
@@ -315,7 +315,8 @@ def main():
         'f32_mode': mode,
         'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'],
                      'peak': peak, 'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / peak,
-                     'traffic': pmc_traffic(('acc16_kernel' if split else 'acc_kernel')
+                     'traffic': pmc_traffic((('acc16p_kernel' if 'packed' in dom else 'acc16_kernel')
+                                             if split else 'acc_kernel')
                                             if 'accumulate' in dom else
                                             ('llh16_kernel' if split else 'llh_kernel')),
                      'avg_launch_ms': kern[dom]['ms'],

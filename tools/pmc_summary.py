@@ -18,7 +18,8 @@ import json
 import os
 import sys
 
-KERNELS = {'llh16_kernel': 'llh16_kernel', 'acc16_kernel': 'acc16_kernel',
+KERNELS = {'llh16_kernel': 'llh16_kernel', 'acc16p_kernel': 'acc16p_kernel',
+           'acc16_kernel': 'acc16_kernel',
            'llh_kernel<': 'llh_kernel', 'acc_kernel<': 'acc_kernel'}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -27,7 +28,8 @@ def main():
     rnd, dirs = sys.argv[1], sys.argv[2:]
     out = collections.defaultdict(dict)
     for i, d in enumerate(dirs, start=1):
-        f = glob.glob(os.path.join(d, '*', '*counter_collection.csv'))[0]
+        f = (glob.glob(os.path.join(d, '*', '*counter_collection.csv')) +
+             glob.glob(os.path.join(d, '*counter_collection.csv')))[0]
         rows = list(csv.DictReader(open(f)))
         keep = []
         per = collections.defaultdict(lambda: collections.defaultdict(list))
