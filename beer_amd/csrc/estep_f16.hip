@@ -727,16 +727,23 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
 //    single barrier per tile sits in front of its last step (see `iteration`).
 // ---------------------------------------------------------------------------
 constexpr int kPiece = kA16Threads * 16;          // bytes one load of the workgroup moves
+// The packed responsibilities start with the frame scales K1 computed (64 scales,
+// 64 inverses): K2 reuses them instead of a second pass over the frames.
+constexpr int kPackedHeader = 128 * sizeof(float);
 
 inline int xt_rows(int D) { return D + 2; }                              // + ones, zeros
 inline int xt_pieces(int D) { return (xt_rows(D) * kA16XS * 4 + kPiece - 1) / kPiece; }
 
-// X [T, D] -> per 64-frame tile the image [D + 2][kA16XS] (rows D, D + 1 = the
-// constants 1, 0; frames past T = 0), padded to whole pieces
+// X [T, D] -> per 64-frame tile the image [D + 2][kA16XS] of the range-scaled
+// frames x_d * s_d (rows D, D + 1 = the constants 1, 0; frames past T = 0),
+// padded to whole pieces
 __global__ __launch_bounds__(256) void xt_image_kernel(int64_t nframes, int D, int NX,
                                                        const float* __restrict__ X,
+                                                       const float* __restrict__ sc,
                                                        float* __restrict__ Xt) {
     __shared__ float tile[kA16FT * 65];
+    __shared__ float scale[64];
+    if (threadIdx.x < 64) scale[threadIdx.x] = sc[threadIdx.x];
     const int64_t tau = blockIdx.x, t0 = tau * kA16FT;
     const int rows = (int)(nframes - t0 < kA16FT ? nframes - t0 : kA16FT);
     for (int e = threadIdx.x; e < rows * D; e += 256) {
@@ -748,7 +755,7 @@ __global__ __launch_bounds__(256) void xt_image_kernel(int64_t nframes, int D, i
     for (int e = threadIdx.x; e < NX * (kPiece / 4); e += 256) {
         const int row = e / kA16XS, col = e - row * kA16XS;
         float v = 0.f;
-        if (row < D) v = col < rows ? tile[col * 65 + row] : 0.f;
+        if (row < D) v = col < rows ? tile[col * 65 + row] * scale[row] : 0.f;
         else if (row == D) v = 1.f;
         out[e] = v;
     }
@@ -808,16 +815,14 @@ __global__ __launch_bounds__(64 * WAVES, 1) void acc16p_kernel(
         }
     };
     // byte offsets of the lane's 8 frames (k-step 0) in the two X^T rows of its
-    // statistic column, per tile of the wave; and the range scale of the product
+    // statistic column, per tile of the wave
     int xa_off[NQ], xb_off[NQ];
-    float sab[NQ];
 #pragma unroll
     for (int uu = 0; uu < NQ; ++uu) {
         int a, b;
         factors(uu, a, b);
         xa_off[uu] = ((a < D ? a : (a == Dp ? D : D + 1)) * kA16XS + 8 * g) * 4;
         xb_off[uu] = ((b < D ? b : (b == Dp ? D : D + 1)) * kA16XS + 8 * g) * 4;
-        sab[uu] = (a < D ? sc[a] : 1.f) * (b < D ? sc[b] : 1.f);
     }
     // A fragments: row i of component tile c, chunk (4 ks + g) ^ (i & 7)
     int a_off[kA16FT / 32];
@@ -880,7 +885,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void acc16p_kernel(
         const f32x4 xa1 = *reinterpret_cast<const f32x4*>(pa + 16);
         const f32x4 xb0 = *reinterpret_cast<const f32x4*>(pb);
         const f32x4 xb1 = *reinterpret_cast<const f32x4*>(pb + 16);
-        split8((xa0 * sab[uu]) * xb0, (xa1 * sab[uu]) * xb1, h, l);
+        split8(xa0 * xb0, xa1 * xb1, h, l);
     };
     auto a_ptr = [&](int buf, int ks, int c) {
         return smem + a_off[ks] + (buf * buf_bytes + c * 16 * kA16RS * 2);
@@ -984,7 +989,7 @@ __global__ void unpack_resps_kernel(int64_t nframes, int K, const unsigned* __re
     const int nblk = (K + kPackedComps - 1) / kPackedComps;
     const int f6 = (int)(f % kPackedFrames);
     const _Float16* hi = reinterpret_cast<const _Float16*>(
-        Rimg + packed_word(f / kPackedFrames, nblk, k / kPackedComps, k % kPackedComps, f6 & ~1));
+        Rimg + kPackedHeader / 4 + packed_word(f / kPackedFrames, nblk, k / kPackedComps, k % kPackedComps, f6 & ~1));
     const _Float16* lo = hi + kPackedComps * kPackedFrames;
     R[idx] = ((float)hi[f6 & 1] + (float)lo[f6 & 1]) * (1.f / (float)(1 << kRespBits));
 }
@@ -1015,7 +1020,7 @@ int f16_range_hazard(int64_t nframes, int D, const float* X, void* scratch, int*
 size_t packed_resps_bytes(int64_t nframes, int K) {
     const int64_t tiles = (nframes + kPackedFrames - 1) / kPackedFrames;
     const int nblk = (K + kPackedComps - 1) / kPackedComps;
-    return (size_t)tiles * nblk * kPackedComps * kPackedFrames * 4;
+    return kPackedHeader + (size_t)tiles * nblk * kPackedComps * kPackedFrames * 4;
 }
 
 int unpack_resps(int64_t nframes, int K, const void* packed, float* resps, hipStream_t s) {
@@ -1064,6 +1069,9 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
                                        sc, tab, resps, log_norm, llh_sum, s)
     if (S == 1 && packed) {
         const int gl = 16, jw = 4;
+        if (hipMemcpyAsync(resps, sc, kPackedHeader, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return BEER_EINVAL;
+        resps += kPackedHeader / sizeof(float);
 #define BEER_LLH16P(NT_, GQ_)                                                                    \
     return launch_llh16<NT_, 2, GQ_, true>(nframes, D, K, S, G, gl, jw, nchunks, nk, X, P,       \
                                            inv_scale, sc, tab, resps, log_norm, llh_sum, s)
@@ -1111,19 +1119,18 @@ int acc_f16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, con
     double* Sp = reinterpret_cast<double*>(w);
     w += up256((size_t)K * nq * sizeof(double));
     int* tab = reinterpret_cast<int*>(w);
-    w += up256((size_t)nslab * sizeof(int));
-    unsigned* absmax = reinterpret_cast<unsigned*>(w);
-    float* sc = reinterpret_cast<float*>(w + 256);
+    // frame scales: the header K1 left in front of the tiles
+    const float* sc = reinterpret_cast<const float*>(Rimg);
+    Rimg = reinterpret_cast<const char*>(Rimg) + kPackedHeader;
     float* Xt = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + acc16_workspace_bytes(cov, D, K));
     hipError_t e = hipMemsetAsync(Sp, 0, (size_t)K * nq * sizeof(double), s);
     if (e != hipSuccess) return -(int)e;
-    const int rc = launch_scales(X, nframes, D, absmax, sc, s);
-    if (rc != BEER_OK) return rc;
     hipLaunchKernelGGL(tab_kernel, dim3(1), dim3(256), 0, s, cov, D, tab);
     BEER_LAUNCH_CHECK();
     const int64_t tiles = (nframes + kA16FT - 1) / kA16FT;
     const int NX = xt_pieces(D);
-    hipLaunchKernelGGL(xt_image_kernel, dim3((unsigned)tiles), dim3(256), 0, s, nframes, D, NX, X, Xt);
+    hipLaunchKernelGGL(xt_image_kernel, dim3((unsigned)tiles), dim3(256), 0, s, nframes, D, NX, X,
+                       sc, Xt);
     BEER_LAUNCH_CHECK();
     const int ntiles = (nq + 15) / 16;
     // 8 waves, two per SIMD (256 registers each): measured faster than 4 waves with

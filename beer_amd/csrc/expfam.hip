@@ -22,55 +22,52 @@ constexpr int kMaxFullDim = 128;   // D*D fp64 must fit one CU's 160 KiB LDS
 // row-major fp64 in LDS).
 // ---------------------------------------------------------------------------
 
-// In-place lower Cholesky; returns log|A| (all threads).  The strict upper
-// triangle is left untouched.  `red` is LDS scratch of >= 8 doubles.
-__device__ double chol_inplace(double* A, int D, double* red) {
+// In-place inverse of the SPD matrix A by Gauss-Jordan elimination without
+// pivoting (backward stable for SPD matrices); returns log|A| = sum of the log
+// pivots (all threads).  Two barriers per column and D*D / nt entry updates per
+// thread and column -- against a Cholesky factorisation plus a triangular
+// inverse whose substitution runs D*D / 2 dependent LDS reads deep in ONE thread
+// per column (76 -> ~20 us per launch at D = 40: these kernels are pure latency,
+// one workgroup per matrix).  `cr` = LDS scratch of 2 D doubles.  With
+// `want_inverse` false only the trailing (Schur) updates are made: log|A| alone.
+__device__ double spd_inverse(double* A, int D, double* cr, bool want_inverse) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    double logdet = 0.0;
+    double* col = cr;
+    double* row = cr + D;
+    const int i0 = tid / D, k0 = tid - i0 * D, di = nt / D, dk = nt - di * D;
+    double mant = 1.0;                      // log|A| = log(mant) + expo * log 2
+    int expo = 0;
     for (int j = 0; j < D; ++j) {
         __syncthreads();
-        const double d = sqrt(A[j * D + j]);
-        logdet += 2.0 * log(d);
+        const double p = A[j * D + j], ip = 1.0 / p;
+        int e;
+        mant *= frexp(p, &e);
+        expo += e;
+        if ((j & 31) == 31) { mant = frexp(mant, &e); expo += e; }
+        // log|A| alone: the lower triangle is enough (column j serves as row j)
+        for (int i = tid; i < D; i += nt) {
+            col[i] = A[i * D + j];
+            row[i] = (want_inverse ? A[j * D + i] : A[i * D + j]) * ip;
+        }
         __syncthreads();
-        if (tid == 0) A[j * D + j] = d;
-        for (int i = j + 1 + tid; i < D; i += nt) A[i * D + j] /= d;
-        __syncthreads();
-        const int n = D - j - 1;
-        for (int idx = tid; idx < n * n; idx += nt) {
-            const int i = j + 1 + idx / n, k = j + 1 + idx % n;
-            if (k <= i) A[i * D + k] -= A[i * D + j] * A[k * D + j];
+        int i = i0, k = k0;
+        for (int idx = tid; idx < D * D; idx += nt) {
+            if (want_inverse) {
+                double v;
+                if (i == j) v = (k == j) ? ip : row[k];
+                else if (k == j) v = -col[i] * ip;
+                else v = A[idx] - col[i] * row[k];
+                A[idx] = v;
+            } else if (k > j && k <= i) {
+                A[idx] -= col[i] * row[k];
+            }
+            i += di;
+            k += dk;
+            if (k >= D) { k -= D; ++i; }
         }
     }
     __syncthreads();
-    (void)red;
-    return logdet;
-}
-
-// Given the Cholesky factor L in the lower triangle of A, store L^{-T}
-// (strictly upper part) in the strict upper triangle: A[c][i] = Linv[i][c],
-// i > c.  Linv[c][c] = 1 / L[c][c] is implicit.
-__device__ void tri_inverse_upper(double* A, int D) {
-    for (int c = threadIdx.x; c < D; c += blockDim.x) {
-        const double dcc = 1.0 / A[c * D + c];
-        for (int i = c + 1; i < D; ++i) {
-            double s = A[i * D + c] * dcc;
-            for (int k = c + 1; k < i; ++k) s += A[i * D + k] * A[c * D + k];
-            A[c * D + i] = -s / A[i * D + i];
-        }
-    }
-    __syncthreads();
-}
-
-// (A^{-1})[a][b] from the packed L / L^{-T} image produced above.
-__device__ __forceinline__ double inv_entry(const double* A, int D, int a, int b) {
-    if (a > b) { const int t = a; a = b; b = t; }          // a <= b
-    // Linv[i][a] for i >= a: i == a -> 1/L[a][a], else A[a][i].
-    double s = 0.0;
-    const double lb = 1.0 / A[b * D + b];
-    const double la = (a == b) ? lb : A[a * D + b];
-    s = la * lb;                                               // i = b term
-    for (int i = b + 1; i < D; ++i) s += A[a * D + i] * A[b * D + i];
-    return s;
+    return log(mant) + (double)expo * 0.69314718055994530942;
 }
 
 // ---------------------------------------------------------------------------
@@ -111,7 +108,7 @@ __global__ __launch_bounds__(kNwThreads) void nw_expected_stats_kernel(
     double dg = 0.0;
     for (int i = tid; i < D; i += nt) dg += digamma(0.5 * (nu + 1.0 - (double)(i + 1)));
     const double dgs = block_sum(dg, red);
-    const double logdet = chol_inplace(A, D, red);
+    const double logdet = spd_inverse(A, D, red + 8, false);
     if (tid == 0) {
         o[D + D * D] = (T)((double)D / kappa + tr);
         o[D + D * D + 1] = (T)(dgs + (double)D * kLog2 + logdet);
@@ -132,7 +129,7 @@ __global__ __launch_bounds__(kNwThreads) void nw_log_norm_kernel(
     double lg = 0.0;
     for (int i = tid; i < D; i += nt) lg += lgamma(0.5 * (nu + 1.0 - (double)(i + 1)));
     const double lgs = block_sum(lg, red);
-    const double logdet = chol_inplace(A, D, red);
+    const double logdet = spd_inverse(A, D, red + 8, false);
     if (tid == 0) {
         const double d = (double)D;
         out[k] = (T)(0.5 * nu * logdet + 0.5 * nu * d * kLog2 +
@@ -163,11 +160,11 @@ __global__ __launch_bounds__(kNwThreads) void nw_natural_kernel(
         m[i] = (double)mean[(size_t)k * D + i];
         o[i] = (T)(kappa * m[i]);
     }
-    chol_inplace(A, D, red);
-    tri_inverse_upper(A, D);
+    spd_inverse(A, D, red + 8, true);
     for (int idx = tid; idx < D * D; idx += nt) {
         const int i = idx / D, j = idx % D;
-        o[D + idx] = (T)(-0.5 * (inv_entry(A, D, i, j) + kappa * m[i] * m[j]));
+        // (the elimination leaves A^-1 symmetric up to rounding: average)
+        o[D + idx] = (T)(-0.5 * (0.5 * (A[i * D + j] + A[j * D + i]) + kappa * m[i] * m[j]));
     }
     if (tid == 0) {
         o[D + D * D] = (T)(-0.5 * kappa);
@@ -197,11 +194,12 @@ __global__ __launch_bounds__(kNwThreads) void nw_from_natural_kernel(
         const double b = 0.5 * ((double)e[D + i * D + j] + (double)e[D + j * D + i]);
         A[idx] = -2.0 * b - kappa * m[i] * m[j];
     }
-    chol_inplace(A, D, red);
-    tri_inverse_upper(A, D);
+    spd_inverse(A, D, red + 8, true);
     T* Wk = W + (size_t)k * D * D;
-    for (int idx = tid; idx < D * D; idx += nt)
-        Wk[idx] = (T)inv_entry(A, D, idx / D, idx % D);
+    for (int idx = tid; idx < D * D; idx += nt) {
+        const int i = idx / D, j = idx - i * D;
+        Wk[idx] = (T)(0.5 * (A[i * D + j] + A[j * D + i]));
+    }
     if (tid == 0) {
         scale[k] = (T)kappa;
         dof[k] = (T)(2.0 * (double)e[D + D * D + 1] + (double)D);
@@ -458,7 +456,7 @@ int nw_launch(int which, int K, int D, const void* mean, const void* scale,
               const void* W, const void* dof, void* out, void* stream) {
     BEER_REQUIRE(K >= 0 && D >= 1 && D <= kMaxFullDim);
     if (K == 0) return BEER_OK;
-    const size_t lds = ((size_t)D * D + 2 * D + 16) * sizeof(double);
+    const size_t lds = ((size_t)D * D + 4 * D + 16) * sizeof(double);
     hipStream_t s = as_stream(stream);
     if (which == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nw_expected_stats_kernel<T>),
@@ -485,7 +483,7 @@ int nw_from_natural_launch(int K, int D, const void* eta, void* mean, void* scal
                            void* W, void* dof, void* stream) {
     BEER_REQUIRE(K >= 0 && D >= 1 && D <= kMaxFullDim);
     if (K == 0) return BEER_OK;
-    const size_t lds = ((size_t)D * D + 2 * D + 16) * sizeof(double);
+    const size_t lds = ((size_t)D * D + 4 * D + 16) * sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nw_from_natural_kernel<T>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(nw_from_natural_kernel<T>, dim3(K), dim3(kNwThreads), lds,

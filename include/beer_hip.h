@@ -225,8 +225,10 @@ int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G,
 
 /* The E-step -> accumulate hand-over of a single mixture (S = 1, float32, split
  * arithmetic: beer_hip_set_f32_mode) without the float32 responsibilities in
- * between.  `packed_resps` (beer_packed_resps_bytes(T, K) bytes: 4 bytes per
- * element with T rounded up to 64 and K to 128) receives each responsibility
+ * between.  `packed_resps` (beer_packed_resps_bytes(T, K) bytes: a 512-byte
+ * header -- the per-dimension frame scales the E-step computed, reused by the
+ * accumulation -- then 4 bytes per element with T rounded up to 64 and K to
+ * 128) receives each responsibility
  * already split into the fp16 pair the accumulation kernel multiplies with,
  * laid out as that kernel's LDS tiles: per (64 frames, 128 components) 32 KB =
  * the high halves of r * 2^12 as rows [component][64 frames] whose 16-byte
