@@ -45,7 +45,8 @@ constexpr int kColBits = 14;           // column maximum of P < 2^14
 __host__ __device__ inline int nk16_of(int cov, int D) {
     return ((nslab_of(cov, D) + 7) / 8 + 1) / 2 * 2;
 }
-constexpr int kPadBlocks = 4;          // look-ahead blocks behind the P image (a quarter k-step)
+constexpr int kPadBlocks = 16;         // look-ahead blocks behind the P image (a quarter k-step
+                                       // of the second component half, see KS)
 
 // Per-dimension frame scaling: sc[d] = s_d, a power of two with |x_d s_d| < 2^7,
 // sc[64 + d] = 1 / s_d (D <= 64).  One scale per dimension rather than one for
@@ -248,8 +249,14 @@ __device__ __forceinline__ void split8(const f32x4& p0, const f32x4& p1, h8& hi,
 
 // ---------------------------------------------------------------------------
 // K1 on the fp16 pipes: one wave owns 16 MT frames x 16 NT components.
+// KS = 2 (one mixture, packed output): waves 2p, 2p + 1 share the 16 MT frames of
+// pair p and own 16 NT components each of the chunk's 32 NT -- every wave
+// streams half of the packed parameters for twice the frames (the B stream
+// through the vector L1, 29 GB per launch at K = 256 with one wave per frame
+// tile, is what bounds the main loop), and the softmax spans the two waves
+// (softmax_epilogue_pair).
 // ---------------------------------------------------------------------------
-template <int NT, int MT, int GQ, bool PACKED>
+template <int NT, int MT, int GQ, bool PACKED, int KS = 1>
 __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nk,
     const float* __restrict__ X, const _Float16* __restrict__ Pall,
@@ -262,13 +269,15 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    constexpr int FW = 16 * MT;
-    float* xw = reinterpret_cast<float*>(smem) + wave * (FW * LD);
-    int* tabs = reinterpret_cast<int*>(reinterpret_cast<float*>(smem) + (kThreads / 64) * FW * LD);
-    const int64_t fb = ((int64_t)blockIdx.x * (kThreads / 64) + wave) * FW;
+    constexpr int FW = 16 * MT, NGRP = kThreads / 64 / KS;      // frame groups per workgroup
+    static_assert(KS == 1 || (KS == 2 && PACKED), "the component split writes packed tiles");
+    const int grp = wave / KS, part = wave % KS;
+    float* xw = reinterpret_cast<float*>(smem) + grp * (FW * LD);
+    int* tabs = reinterpret_cast<int*>(reinterpret_cast<float*>(smem) + NGRP * FW * LD);
+    const int64_t fb = ((int64_t)blockIdx.x * NGRP + grp) * FW;
     for (int idx = tid; idx < (nk + 1) * 8; idx += kThreads) tabs[idx] = tab[idx];
 
-    for (int idx = lane; idx < FW * LD; idx += 64) {
+    for (int idx = part * 64 + lane; idx < FW * LD; idx += 64 * KS) {
         const int r = idx / LD, c = idx - r * LD;
         const int64_t f = fb + r;
         float v = 0.f;
@@ -288,10 +297,12 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
 #pragma unroll
     for (int m = 0; m < MT; ++m) xrow[m] = xw + (m * 16 + i) * LD;
 
-    const int kbase = blockIdx.y * (16 * NT);
+    const int kbase = blockIdx.y * (16 * NT * KS) + part * (16 * NT);
     // the B stream of this chunk is one linear sequence of (k-step, tile) blocks
-    // of 2 KiB = 128 u4 (hi 64 lanes x 16 B, lo 64 lanes x 16 B)
-    const u4* Pl = reinterpret_cast<const u4*>(Pall + (size_t)blockIdx.y * nk * NT * 1024) + lane;
+    // of 2 KiB = 128 u4 (hi 64 lanes x 16 B, lo 64 lanes x 16 B); with KS = 2 a
+    // k-step has 2 NT tiles and this wave reads tiles part * NT ..
+    const u4* Pl = reinterpret_cast<const u4*>(Pall + (size_t)blockIdx.y * nk * (NT * KS) * 1024) +
+                   lane + (size_t)part * NT * 128;
     const int* tl = tabs + 2 * g;
 
     // A fragments as 32-bit words (two fp16 each): word w of tile m holds the
@@ -334,7 +345,9 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
         }
     };
     auto quarter = [&](int s, int q, const AFrag& cur, AFrag& nxt, const BFrag& b, BFrag& bn) {
-        load_b((int64_t)s * NT + (q + 1) * QT, bn);          // P is padded by one quarter
+        // P is padded by one quarter (q + 1 = 4: first quarter of the next k-step)
+        if constexpr (KS == 1) load_b((int64_t)s * NT + (q + 1) * QT, bn);
+        else load_b((int64_t)(s + (q + 1) / 4) * (NT * KS) + ((q + 1) % 4) * QT, bn);
         // slices of the next A: MT * 2 halves over 4 quarters
 #pragma unroll
         for (int hh = q * MT * 2 / 4; hh < (q + 1) * MT * 2 / 4; ++hh)
@@ -384,19 +397,26 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m][4 * q + j] *= inv[j];
     }
-    softmax_epilogue<float, NT, MT, GQ, PACKED>(acc, fb, nframes, kbase, K, S, G, gl, jw, i, g, lane,
-                                        resps, log_norm, llh_sum);
+    if constexpr (KS == 2) {
+        float* xch = reinterpret_cast<float*>(tabs + (nk + 1) * 8);
+        softmax_epilogue_pair<NT, MT>(acc, fb, nframes, kbase, K, i, g, lane, wave, xch, resps,
+                                      log_norm, llh_sum);
+    } else {
+        softmax_epilogue<float, NT, MT, GQ, PACKED>(acc, fb, nframes, kbase, K, S, G, gl, jw, i, g,
+                                                    lane, resps, log_norm, llh_sum);
+    }
 }
 
-template <int NT, int MT, int GQ, bool PACKED = false>
+template <int NT, int MT, int GQ, bool PACKED = false, int KS = 1>
 int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nchunks, int nk,
                  const float* X, const _Float16* P, const float* inv_scale, const float* sc,
                  const int* tab, float* resps, float* log_norm, double* llh_sum, hipStream_t s) {
     const int LD = 4 * d4_of(D) + 8;
-    constexpr int FB = 16 * MT * (kThreads / 64);
-    const size_t lds = (size_t)FB * LD * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int);
+    constexpr int FB = 16 * MT * (kThreads / 64) / KS;
+    const size_t lds = (size_t)FB * LD * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int) +
+                       (KS == 2 ? 8 * 16 * MT * sizeof(float) : 0);
     const int64_t blocks = (nframes + FB - 1) / FB;
-    hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ, PACKED>), dim3((unsigned)blocks, (unsigned)nchunks),
+    hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ, PACKED, KS>), dim3((unsigned)blocks, (unsigned)nchunks),
                        dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nk, X, P, inv_scale,
                        sc, tab, resps, log_norm, llh_sum);
     BEER_LAUNCH_CHECK();
@@ -1077,7 +1097,9 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
                                            inv_scale, sc, tab, resps, log_norm, llh_sum, s)
         if (NT == 4) BEER_LLH16P(4, 1);
         if (NT == 8) BEER_LLH16P(8, 2);
-        BEER_LLH16P(16, 4);
+        // 129 .. 256 components: two waves per frame group, 128 components each
+        return launch_llh16<8, 4, 2, true, 2>(nframes, D, K, S, G, gl, jw, nchunks, nk, X, P,
+                                              inv_scale, sc, tab, resps, log_norm, llh_sum, s);
 #undef BEER_LLH16P
     }
     if (S == 1) {

@@ -351,4 +351,135 @@ __device__ __forceinline__ void softmax_epilogue(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Epilogue of K1 when TWO waves share the frames of a tile and own one half of
+// the components each (one mixture, float, packed output): the logsumexp over
+// all components needs the partner's partial maximum and partial sum, exchanged
+// through LDS (`xch`: 2 x 4 waves x 16 MT floats; two workgroup barriers).
+// acc[m][nt] of a wave = component kbase + 64 (nt / 4) + 4 i + nt % 4 (kbase
+// includes the wave's half), frames fb + 16 m + 4 g + (0..3).  Writes the packed
+// tiles (see PACKED above), log_norm and llh_sum (from the even wave).
+// ---------------------------------------------------------------------------
+template <int NT, int MT>
+__device__ __forceinline__ void softmax_epilogue_pair(
+    f32x4 (&acc)[MT][NT], int64_t fb, int64_t nframes, int kbase, int K, int i, int g, int lane,
+    int wave, float* __restrict__ xch, float* __restrict__ resps, float* __restrict__ log_norm,
+    double* __restrict__ llh_sum) {
+    using M = Mma<float>;
+    static_assert(MT % 2 == 0, "lane pairs exchange two frame tiles");
+    constexpr int ROWS = 16 * MT;
+    float* mine = xch + wave * ROWS;
+    const float* theirs = xch + (wave ^ 1) * ROWS;
+    float mx[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[m][0][r];
+#pragma unroll
+            for (int nt = 1; nt < NT; ++nt) v = acc[m][nt][r] > v ? acc[m][nt][r] : v;
+            v = group_max(v, 16);
+            mx[m][r] = v;
+            if (i == 0) mine[m * 16 + M::row(g, r)] = v;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float o = theirs[m * 16 + M::row(g, r)];
+            mx[m][r] = o > mx[m][r] ? o : mx[m][r];
+        }
+    float* mine_s = mine + 4 * ROWS;
+    const float* theirs_s = theirs + 4 * ROWS;
+    float sum[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            __builtin_amdgcn_sched_barrier(0);
+            float sacc = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float e = M::exp_neg(acc[m][nt][r] - mx[m][r]);
+                acc[m][nt][r] = e;
+                sacc += e;
+            }
+            sacc = group_sum(sacc, 16);
+            sum[m][r] = sacc;
+            if (i == 0) mine_s[m * 16 + M::row(g, r)] = sacc;
+        }
+    __syncthreads();
+    double llh_local = 0.0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float total = sum[m][r] + theirs_s[m * 16 + M::row(g, r)];
+            const float inv = M::recip(total);
+            const int64_t f = fb + m * 16 + M::row(g, r);
+            if ((wave & 1) == 0 && i == 0 && f < nframes) {
+                const float lse = mx[m][r] + log(total);
+                if (log_norm) log_norm[f] = lse;
+                llh_local += (double)lse;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt][r] *= inv;
+        }
+    // packing: as in softmax_epilogue<PACKED>, per pair of frame tiles
+    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+    typedef float float4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+    unsigned int* out = reinterpret_cast<unsigned int*>(resps);
+    const float up = (float)(1 << kPackedRespBits);
+    const int nblk = (K + kPackedComps - 1) / kPackedComps;
+    const int64_t tiles = (nframes + kPackedFrames - 1) / kPackedFrames;
+#pragma unroll
+    for (int mp = 0; mp < MT / 2; ++mp) {
+        const int64_t fc = fb + 32 * mp + 16 * (g & 1) + 8 * (g >> 1);
+        const int64_t tau = fc / kPackedFrames;
+        const int f6 = (int)(fc - tau * kPackedFrames);
+        const bool chunk_ok = out && fc < tiles * kPackedFrames;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int k = kbase + 64 * (nt >> 2) + 4 * i + (nt & 3);
+            uint2_t hi[2], lo[2];
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const int m = 2 * mp + mm;
+                const int64_t f0 = fb + m * 16 + M::row(g, 0);
+                float4_t v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = f0 + r < nframes && k < K ? acc[m][nt][r] * up : 0.f;
+                const half4_t h = __builtin_convertvector(v, half4_t);
+                const half4_t l = __builtin_convertvector(
+                    v - __builtin_convertvector(h, float4_t), half4_t);
+                hi[mm] = __builtin_bit_cast(uint2_t, h);
+                lo[mm] = __builtin_bit_cast(uint2_t, l);
+            }
+            uint4_t ch, cl;
+#pragma unroll
+            for (int wd = 0; wd < 2; ++wd) {
+                const auto sh = __builtin_amdgcn_permlane16_swap(hi[0][wd], hi[1][wd], false, false);
+                const auto sl = __builtin_amdgcn_permlane16_swap(lo[0][wd], lo[1][wd], false, false);
+                ch[wd] = sh[0]; ch[2 + wd] = sh[1];
+                cl[wd] = sl[0]; cl[2 + wd] = sl[1];
+            }
+            if (chunk_ok && k < nblk * kPackedComps) {
+                unsigned int* dst = out + packed_word(tau, nblk, k / kPackedComps,
+                                                      k & (kPackedComps - 1), f6);
+                *reinterpret_cast<uint4_t*>(dst) = ch;
+                *reinterpret_cast<uint4_t*>(dst + kPackedComps * kPackedFrames / 2) = cl;
+            }
+        }
+    }
+    if (llh_sum) {
+        llh_local = wave_sum(llh_local);
+        if (lane == 0 && (wave & 1) == 0) atomicAdd(llh_sum, llh_local);
+    }
+}
+
 }  // namespace beer_mfma
