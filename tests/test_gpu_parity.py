@@ -769,14 +769,18 @@ def test_f32_split_path_mixture_sets(cov, S, G, D):
 
 @pytest.mark.parametrize('cov,K,D,T', [('full', 256, 40, 40001), ('diagonal', 256, 40, 33000),
                                        ('full', 64, 13, 20000), ('diagonal', 100, 24, 16385),
-                                       ('isotropic', 128, 16, 17000)])
+                                       ('isotropic', 128, 16, 17000), ('full', 200, 64, 17001),
+                                       ('diagonal', 132, 64, 16500), ('full', 32, 5, 16447),
+                                       ('diagonal', 252, 3, 20063)])
 def test_packed_responsibilities_match_the_two_call_path(cov, K, D, T):
     '''E-step -> accumulate with the responsibilities handed over as fp16
     hi / lo pairs (beer_mixture_estep_packed, beer_normal_accumulate_packed):
     same log-normalisers (to the last bits) and, up to the order of the sums, the
     same statistics as the float32 hand-over of the split path; and within the
-    float32 tolerance of the fp64 kernels.  T odd: the last frame pair is half
-    empty; K = 100: component tiles past K.'''
+    float32 tolerance of the fp64 kernels.  T not a multiple of 64: the last tile
+    is partly empty; K = 100, 132, 200, 252: component tiles / blocks past K (and,
+    above 128, the two-wave softmax); D = 3 .. 64: 1 .. 5 pieces of transposed
+    frames per tile.'''
     from beer_amd import _hip, kernels
     torch.manual_seed(5)
     X = torch.randn(T, D, dtype=torch.float64, device=DEV) * 2. - 1.
