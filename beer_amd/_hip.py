@@ -102,6 +102,7 @@ SIGNATURES = {
     'beer_hip_device_count': [],
     'beer_nw_expected_stats': _four, 'beer_nw_log_norm': _four, 'beer_nw_natural': _four,
     'beer_nw_from_natural': _from,
+    'beer_nw_expected_stats_log_norm': [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     'beer_ng_expected_stats': _four, 'beer_ng_log_norm': _four, 'beer_ng_natural': _four,
     'beer_ng_from_natural': _from,
     'beer_ing_expected_stats': _four, 'beer_ing_log_norm': _four, 'beer_ing_natural': _four,

@@ -77,7 +77,8 @@ __device__ double spd_inverse(double* A, int D, double* cr, bool want_inverse) {
 template <typename T>
 __global__ __launch_bounds__(kNwThreads) void nw_expected_stats_kernel(
     int D, const T* __restrict__ mean, const T* __restrict__ scale,
-    const T* __restrict__ W, const T* __restrict__ dof, T* __restrict__ out) {
+    const T* __restrict__ W, const T* __restrict__ dof, T* __restrict__ out,
+    T* __restrict__ lnorm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* A = reinterpret_cast<double*>(smem);       // D*D
     double* m = A + D * D;                              // D
@@ -108,10 +109,22 @@ __global__ __launch_bounds__(kNwThreads) void nw_expected_stats_kernel(
     double dg = 0.0;
     for (int i = tid; i < D; i += nt) dg += digamma(0.5 * (nu + 1.0 - (double)(i + 1)));
     const double dgs = block_sum(dg, red);
+    double lgs = 0.0;
+    if (lnorm) {                   // the log-normaliser shares the factorisation
+        double lg = 0.0;
+        for (int i = tid; i < D; i += nt) lg += lgamma(0.5 * (nu + 1.0 - (double)(i + 1)));
+        lgs = block_sum(lg, red);
+    }
     const double logdet = spd_inverse(A, D, red + 8, false);
     if (tid == 0) {
         o[D + D * D] = (T)((double)D / kappa + tr);
         o[D + D * D + 1] = (T)(dgs + (double)D * kLog2 + logdet);
+        if (lnorm) {
+            const double d = (double)D;
+            lnorm[k] = (T)(0.5 * nu * logdet + 0.5 * nu * d * kLog2 +
+                           0.25 * d * (d - 1.0) * kLogPi + lgs - 0.5 * d * log(kappa) +
+                           0.5 * d * kLog2Pi);
+        }
     }
 }
 
@@ -453,7 +466,7 @@ inline int blocks_for(int64_t n, int bs) { return (int)((n + bs - 1) / bs); }
 
 template <typename T>
 int nw_launch(int which, int K, int D, const void* mean, const void* scale,
-              const void* W, const void* dof, void* out, void* stream) {
+              const void* W, const void* dof, void* out, void* stream, void* lnorm = nullptr) {
     BEER_REQUIRE(K >= 0 && D >= 1 && D <= kMaxFullDim);
     if (K == 0) return BEER_OK;
     const size_t lds = ((size_t)D * D + 4 * D + 16) * sizeof(double);
@@ -462,7 +475,8 @@ int nw_launch(int which, int K, int D, const void* mean, const void* scale,
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nw_expected_stats_kernel<T>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(nw_expected_stats_kernel<T>, dim3(K), dim3(kNwThreads), lds, s, D,
-                           (const T*)mean, (const T*)scale, (const T*)W, (const T*)dof, (T*)out);
+                           (const T*)mean, (const T*)scale, (const T*)W, (const T*)dof, (T*)out,
+                           (T*)lnorm);
     } else if (which == 1) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nw_log_norm_kernel<T>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -610,6 +624,12 @@ int beer_hip_device_count(void) {
 int beer_nw_expected_stats(int dtype, int K, int D, const void* mean, const void* scale,
                            const void* W, const void* dof, void* out, void* stream) {
     BEER_DISPATCH(dtype, nw_launch, 0, K, D, mean, scale, W, dof, out, stream);
+}
+int beer_nw_expected_stats_log_norm(int dtype, int K, int D, const void* mean, const void* scale,
+                                    const void* W, const void* dof, void* out, void* log_norm,
+                                    void* stream) {
+    BEER_REQUIRE(log_norm != nullptr || K == 0);
+    BEER_DISPATCH(dtype, nw_launch, 0, K, D, mean, scale, W, dof, out, stream, log_norm);
 }
 int beer_nw_log_norm(int dtype, int K, int D, const void* mean, const void* scale,
                      const void* W, const void* dof, void* out, void* stream) {

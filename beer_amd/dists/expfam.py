@@ -181,6 +181,11 @@ class ExponentialFamily(torch.nn.Module, metaclass=abc.ABCMeta):
     def update_from_natural_parameters(self, natural_params):
         self.params = self.params.from_natural_parameters(natural_params)
         self.__dict__['_memo'] = {}
+        # eta <-> standard parameters is a bijection: what was just set IS the
+        # natural form of the new parameters (the next natural-gradient step
+        # would otherwise invert every scale matrix again to recover it)
+        eta = natural_params.detach()
+        self._memoised('nat', lambda: eta)
 
 
 class ConjugateLikelihood(metaclass=abc.ABCMeta):

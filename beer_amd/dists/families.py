@@ -197,6 +197,32 @@ class NormalWishart(_NormalFamily):
     def conjugate(self):
         return NormalLikelihood(self.params.mean.shape[-1])
 
+    def _stats_and_log_norm(self):
+        '''E[T] and the log-normaliser from ONE factorisation of the scale matrices
+        (a VB iteration asks for both); each lands in the memo of the other.'''
+        mean = self.params.mean
+        single, K, D = self._geometry()
+        dtype = mean.dtype
+        out = _empty((K, self._qdim(D)), mean, dtype)
+        lnorm = _empty((K,), mean, dtype)
+        _run('beer_nw_expected_stats_log_norm', dtype, (K, D), self._tensors(), (out, lnorm))
+        out, lnorm = out.to(mean.device), lnorm.to(mean.device)
+        return (out.view(-1) if single else out), lnorm
+
+    def expected_sufficient_statistics(self):
+        def both():
+            exp, lnorm = self._stats_and_log_norm()
+            self._memoised('lnorm', lambda: lnorm)
+            return exp
+        return self._memoised('exp', both)
+
+    def log_norm(self):
+        def both():
+            exp, lnorm = self._stats_and_log_norm()
+            self._memoised('exp', lambda: exp)
+            return lnorm
+        return self._memoised('lnorm', both)
+
     def expected_value(self):
         'Expected mean and expected precision matrix (normalwishart.py:212-217).'
         if self.params.mean.dim() == 1:

@@ -85,6 +85,14 @@ int beer_f32_split_hazard(int64_t T, int D, const void* X, void* scratch,
 int beer_nw_expected_stats(int dtype, int K, int D, const void* mean,
                            const void* scale, const void* scale_matrix,
                            const void* dof, void* out, void* stream);
+/* The two calls around this comment in one launch (they share the
+ * factorisation of the scale matrix, and a VB iteration needs both: E[T] for
+ * the E-step, the log-normaliser for the KL term): out [K, D*D+D+2],
+ * log_norm [K]. */
+int beer_nw_expected_stats_log_norm(int dtype, int K, int D, const void* mean,
+                                    const void* scale, const void* scale_matrix,
+                                    const void* dof, void* out, void* log_norm,
+                                    void* stream);
 /* NormalWishart.log_norm (normalwishart.py:219-236) -> out [K]. */
 int beer_nw_log_norm(int dtype, int K, int D, const void* mean,
                      const void* scale, const void* scale_matrix,
