@@ -285,13 +285,33 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     const int64_t fb = ((int64_t)blockIdx.x * NGRP + grp) * FW;
     for (int idx = tid; idx < (nk + 1) * 8; idx += kThreads) tabs[idx] = tab[idx];
 
-    for (int idx = part * 64 + lane; idx < FW * LD; idx += 64 * KS) {
-        const int r = idx / LD, c = idx - r * LD;
-        const int64_t f = fb + r;
-        float v = 0.f;
-        if (c < D) { if (f < nframes) v = X[f * D + c] * sc[c]; }
-        else if (c == Dp) v = 1.f;
-        xw[idx] = v;
+    if ((D & 3) == 0) {
+        // rows of whole float4: 16-byte loads and LDS stores, one division per 4 values
+        const int C4 = D >> 2;
+        const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
+        const f32x4* sc4 = reinterpret_cast<const f32x4*>(sc);
+        for (int idx = part * 64 + lane; idx < FW * C4; idx += 64 * KS) {
+            const int r = idx / C4, c4 = idx - r * C4;
+            const int64_t f = fb + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (f < nframes) v = X4[f * C4 + c4] * sc4[c4];
+            *reinterpret_cast<f32x4*>(xw + r * LD + 4 * c4) = v;
+        }
+        // columns D .. LD - 1: the constant 1 at Dp (= D), zeros behind it
+        for (int idx = part * 64 + lane; idx < FW * 2; idx += 64 * KS) {
+            const int r = idx >> 1, h = idx & 1;
+            *reinterpret_cast<f32x4*>(xw + r * LD + D + 4 * h) =
+                f32x4{h == 0 ? 1.f : 0.f, 0.f, 0.f, 0.f};
+        }
+    } else {
+        for (int idx = part * 64 + lane; idx < FW * LD; idx += 64 * KS) {
+            const int r = idx / LD, c = idx - r * LD;
+            const int64_t f = fb + r;
+            float v = 0.f;
+            if (c < D) { if (f < nframes) v = X[f * D + c] * sc[c]; }
+            else if (c == Dp) v = 1.f;
+            xw[idx] = v;
+        }
     }
     __syncthreads();
 
