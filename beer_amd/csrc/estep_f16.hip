@@ -264,7 +264,9 @@ __device__ __forceinline__ void split8(const f32x4& p0, const f32x4& p1, h8& hi,
 // tile, is what bounds the main loop), and the softmax spans the two waves
 // (softmax_epilogue_pair).
 // ---------------------------------------------------------------------------
-template <int NT, int MT, int GQ, bool PACKED, int KS = 1>
+// SQ = false: no "square" slabs in the table (full covariance), the per-product
+// select between x_j^2 and x_a x_j drops out of the A-fragment arithmetic.
+template <int NT, int MT, int GQ, bool PACKED, int KS = 1, bool SQ = true>
 __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nk,
     const float* __restrict__ X, const _Float16* __restrict__ Pall,
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     auto make_half = [&](int s, int m, int h, AFrag& f) {
         const int t = tl[8 * s + h];
         const int a = t & 0xff, j = (t >> 8) & 0xff;
-        const bool sq = (t >> 16) != 0;
+        const bool sq = SQ && (t >> 16) != 0;
         const f32x4 bb = *reinterpret_cast<const f32x4*>(xrow[m] + j);
         const float xx = xrow[m][a];
         f32x4 p;
@@ -377,9 +379,10 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
         if constexpr (KS == 1) load_b((int64_t)s * NT + (q + 1) * QT, bn);
         else load_b((int64_t)(s + (q + 1) / 4) * (NT * KS) + ((q + 1) % 4) * QT, bn);
         // slices of the next A: MT * 2 halves over 4 quarters
+        // (half-major: the halves of one quarter share the table entry)
 #pragma unroll
         for (int hh = q * MT * 2 / 4; hh < (q + 1) * MT * 2 / 4; ++hh)
-            make_half(s + 1, hh >> 1, hh & 1, nxt);          // the table is padded by one k-step
+            make_half(s + 1, hh % MT, hh / MT, nxt);         // the table is padded by one k-step
 #pragma unroll
         for (int c = 0; c < QT; ++c) {
 #pragma unroll
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     AFrag f0, f1;
     BFrag b0, b1;
 #pragma unroll
-    for (int hh = 0; hh < MT * 2; ++hh) make_half(0, hh >> 1, hh & 1, f0);
+    for (int hh = 0; hh < MT * 2; ++hh) make_half(0, hh % MT, hh / MT, f0);
     load_b(0, b0);
     for (int s = 0; s < nk; s += 2) {                // nk is padded to an even count
         kstep(s, f0, f1, b0, b1);
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     }
 }
 
-template <int NT, int MT, int GQ, bool PACKED = false, int KS = 1>
+template <int NT, int MT, int GQ, bool PACKED = false, int KS = 1, bool SQ = true>
 int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nchunks, int nk,
                  const float* X, const _Float16* P, const float* inv_scale, const float* sc,
                  const int* tab, float* resps, float* log_norm, double* llh_sum, hipStream_t s) {
@@ -444,7 +447,7 @@ int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, in
     const size_t lds = (size_t)FB * LD * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int) +
                        (KS == 2 ? 8 * 16 * MT * sizeof(float) : 0);
     const int64_t blocks = (nframes + FB - 1) / FB;
-    hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ, PACKED, KS>), dim3((unsigned)blocks, (unsigned)nchunks),
+    hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ, PACKED, KS, SQ>), dim3((unsigned)blocks, (unsigned)nchunks),
                        dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nk, X, P, inv_scale,
                        sc, tab, resps, log_norm, llh_sum);
     BEER_LAUNCH_CHECK();
@@ -1126,6 +1129,10 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
         if (NT == 4) BEER_LLH16P(4, 1);
         if (NT == 8) BEER_LLH16P(8, 2);
         // 129 .. 256 components: two waves per frame group, 128 components each
+        if (cov == BEER_FULL)
+            return launch_llh16<8, 4, 2, true, 2, false>(nframes, D, K, S, G, gl, jw, nchunks, nk, X,
+                                                         P, inv_scale, sc, tab, resps, log_norm,
+                                                         llh_sum, s);
         return launch_llh16<8, 4, 2, true, 2>(nframes, D, K, S, G, gl, jw, nchunks, nk, X, P,
                                               inv_scale, sc, tab, resps, log_norm, llh_sum, s);
 #undef BEER_LLH16P
