@@ -169,7 +169,7 @@ HOST_SIGNATURES = {
 SIZE_QUERIES = {
     'beer_estep_workspace_bytes': [c_i, c_i, c_i, c_i, c_i],
     'beer_accumulate_workspace_bytes': [c_i, c_i, c_i, c_i, c_i],
-    'beer_packed_resps_bytes': [c_l, c_i],
+    'beer_packed_resps_bytes': [c_l, c_i, c_i],
     'beer_accumulate_packed_workspace_bytes': [c_i, c_l, c_i, c_i],
 }
 

@@ -554,8 +554,8 @@ int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float*
                                        workspace_bytes, as_stream(stream));
 }
 
-size_t beer_packed_resps_bytes(int64_t T, int K) {
-    return T < 0 || K < 1 ? 0 : beer_mfma::packed_resps_bytes(T, K);
+size_t beer_packed_resps_bytes(int64_t T, int D, int K) {
+    return T < 0 || D < 1 || D > 64 || K < 1 ? 0 : beer_mfma::packed_resps_bytes(T, D, K);
 }
 
 size_t beer_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int K) {

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     const float* __restrict__ X, const _Float16* __restrict__ Pall,
     const float* __restrict__ inv_scale, const float* __restrict__ sc,
     const int* __restrict__ tab, float* __restrict__ resps, float* __restrict__ log_norm,
-    double* __restrict__ llh_sum) {
+    double* __restrict__ llh_sum, float* __restrict__ xt_out, int xt_floats) {
     using acc_t = f32x4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D4 = d4_of(D), Dp = 4 * D4, LD = Dp + 8;        // 16-byte aligned rows
@@ -316,6 +316,27 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
         }
     }
     __syncthreads();
+    if constexpr (KS == 2) {
+        // The group's 64 scaled frames are one tile of the accumulation kernel:
+        // leave them behind transposed, [D + 2][kA16XS] (rows D, D + 1 = 1, 0; see
+        // xt_image_kernel, which this replaces -- one pass over the frames less).
+        static_assert(KS != 2 || FW == 64, "a frame group is one 64-frame tile");
+        if (xt_out && fb < (nframes + 63) / 64 * 64) {
+            float* img = xt_out + (fb / 64) * (size_t)xt_floats;
+            constexpr int XS = 68, C4 = XS / 4;
+            for (int e4 = part * 64 + lane; e4 < xt_floats / 4; e4 += 64 * KS) {
+                const int row = e4 / C4, c = 4 * (e4 - row * C4);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row < D) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = c + j < 64 ? xw[(c + j) * LD + row] : 0.f;
+                } else if (row == D) {
+                    v = f32x4{1.f, 1.f, 1.f, 1.f};
+                }
+                *reinterpret_cast<f32x4*>(img + 4 * e4) = v;
+            }
+        }
+    }
 
     acc_t acc[MT][NT];
 #pragma unroll
@@ -441,7 +462,8 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
 template <int NT, int MT, int GQ, bool PACKED = false, int KS = 1, bool SQ = true>
 int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nchunks, int nk,
                  const float* X, const _Float16* P, const float* inv_scale, const float* sc,
-                 const int* tab, float* resps, float* log_norm, double* llh_sum, hipStream_t s) {
+                 const int* tab, float* resps, float* log_norm, double* llh_sum, hipStream_t s,
+                 float* xt_out = nullptr, int xt_floats = 0) {
     const int LD = 4 * d4_of(D) + 8;
     constexpr int FB = 16 * MT * (kThreads / 64) / KS;
     const size_t lds = (size_t)FB * LD * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int) +
@@ -449,7 +471,7 @@ int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, in
     const int64_t blocks = (nframes + FB - 1) / FB;
     hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ, PACKED, KS, SQ>), dim3((unsigned)blocks, (unsigned)nchunks),
                        dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nk, X, P, inv_scale,
-                       sc, tab, resps, log_norm, llh_sum);
+                       sc, tab, resps, log_norm, llh_sum, xt_out, xt_floats);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }
@@ -478,6 +500,15 @@ constexpr int kA16RS = kA16FT;       // R^T row = 8 chunks of 8 frames (16 B), c
                                      // r stored at position c ^ (r & 7): conflict-free
                                      // ds_read_b128 for the MFMA lane groups, 2-way ds_write_b32
 constexpr int kA16MaxFrames = 16384; // frames per workgroup: 384 fp32 roundings per sum
+
+constexpr int kPiece = kA16Threads * 16;          // bytes one load of the workgroup moves
+// The packed responsibilities start with the frame scales K1 computed (64 scales,
+// 64 inverses): K2 reuses them instead of a second pass over the frames.
+constexpr int kPackedHeader = 128 * sizeof(float);
+
+inline int xt_rows(int D) { return D + 2; }                              // + ones, zeros
+inline int xt_pieces(int D) { return (xt_rows(D) * kA16XS * 4 + kPiece - 1) / kPiece; }
+
 
 template <int NQ, bool HAS_SR>
 __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
@@ -777,14 +808,6 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
 //  * A and B fragments are loaded one k-step / one step ahead, in place, and the
 //    single barrier per tile sits in front of its last step (see `iteration`).
 // ---------------------------------------------------------------------------
-constexpr int kPiece = kA16Threads * 16;          // bytes one load of the workgroup moves
-// The packed responsibilities start with the frame scales K1 computed (64 scales,
-// 64 inverses): K2 reuses them instead of a second pass over the frames.
-constexpr int kPackedHeader = 128 * sizeof(float);
-
-inline int xt_rows(int D) { return D + 2; }                              // + ones, zeros
-inline int xt_pieces(int D) { return (xt_rows(D) * kA16XS * 4 + kPiece - 1) / kPiece; }
-
 // X [T, D] -> per 64-frame tile the image [D + 2][kA16XS] of the range-scaled
 // frames x_d * s_d (rows D, D + 1 = the constants 1, 0; frames past T = 0),
 // padded to whole pieces
@@ -1068,10 +1091,18 @@ int f16_range_hazard(int64_t nframes, int D, const float* X, void* scratch, int*
     return BEER_OK;
 }
 
-size_t packed_resps_bytes(int64_t nframes, int K) {
+// 129 .. 256 components: the E-step kernel (KS = 2) also leaves the transposed,
+// range-scaled frames behind its tiles -- [header][R tiles][X^T tiles]
+inline bool packed_has_xt(int K) { return K > kPackedComps && K <= 2 * kPackedComps; }
+inline size_t packed_tiles_bytes(int64_t nframes, int K) {
     const int64_t tiles = (nframes + kPackedFrames - 1) / kPackedFrames;
     const int nblk = (K + kPackedComps - 1) / kPackedComps;
-    return kPackedHeader + (size_t)tiles * nblk * kPackedComps * kPackedFrames * 4;
+    return (size_t)tiles * nblk * kPackedComps * kPackedFrames * 4;
+}
+size_t packed_resps_bytes(int64_t nframes, int D, int K) {
+    const int64_t tiles = (nframes + kPackedFrames - 1) / kPackedFrames;
+    return kPackedHeader + packed_tiles_bytes(nframes, K) +
+           (packed_has_xt(K) ? (size_t)tiles * xt_pieces(D) * kPiece : 0);
 }
 
 int unpack_resps(int64_t nframes, int K, const void* packed, float* resps, hipStream_t s) {
@@ -1129,12 +1160,16 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
         if (NT == 4) BEER_LLH16P(4, 1);
         if (NT == 8) BEER_LLH16P(8, 2);
         // 129 .. 256 components: two waves per frame group, 128 components each
+        float* xt = reinterpret_cast<float*>(reinterpret_cast<char*>(resps) +
+                                             packed_tiles_bytes(nframes, K));
+        const int xtf = xt_pieces(D) * (kPiece / 4);
         if (cov == BEER_FULL)
             return launch_llh16<8, 4, 2, true, 2, false>(nframes, D, K, S, G, gl, jw, nchunks, nk, X,
                                                          P, inv_scale, sc, tab, resps, log_norm,
-                                                         llh_sum, s);
+                                                         llh_sum, s, xt, xtf);
         return launch_llh16<8, 4, 2, true, 2>(nframes, D, K, S, G, gl, jw, nchunks, nk, X, P,
-                                              inv_scale, sc, tab, resps, log_norm, llh_sum, s);
+                                              inv_scale, sc, tab, resps, log_norm, llh_sum, s, xt,
+                                              xtf);
 #undef BEER_LLH16P
     }
     if (S == 1) {
@@ -1186,9 +1221,14 @@ int acc_f16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, con
     BEER_LAUNCH_CHECK();
     const int64_t tiles = (nframes + kA16FT - 1) / kA16FT;
     const int NX = xt_pieces(D);
-    hipLaunchKernelGGL(xt_image_kernel, dim3((unsigned)tiles), dim3(256), 0, s, nframes, D, NX, X,
-                       sc, Xt);
-    BEER_LAUNCH_CHECK();
+    if (packed_has_xt(K)) {                  // the E-step kernel left the image behind the tiles
+        Xt = reinterpret_cast<float*>(const_cast<char*>(reinterpret_cast<const char*>(Rimg)) +
+                                      packed_tiles_bytes(nframes, K));
+    } else {
+        hipLaunchKernelGGL(xt_image_kernel, dim3((unsigned)tiles), dim3(256), 0, s, nframes, D, NX,
+                           X, sc, Xt);
+        BEER_LAUNCH_CHECK();
+    }
     const int ntiles = (nq + 15) / 16;
     // 8 waves, two per SIMD (256 registers each): measured faster than 4 waves with
     // twice the statistic tiles each (1.26 against 1.31 ms at K = 256, D = 40, full)

@@ -33,7 +33,7 @@ int acc_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const flo
               const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s);
 // One mixture with the responsibilities as estep_f16x3(..., packed = true) wrote them
 // (packed_resps_bytes); the workspace also holds the transposed frames, hence T.
-size_t packed_resps_bytes(int64_t T, int K);
+size_t packed_resps_bytes(int64_t T, int D, int K);
 size_t acc16p_workspace_bytes(int cov, int64_t T, int D, int K);
 int acc_f16x3_packed(int cov, int64_t T, int D, int K, const float* X, const void* Rimg,
                      double* acc, void* ws, size_t ws_bytes, hipStream_t s);

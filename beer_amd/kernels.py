@@ -128,7 +128,7 @@ def mixture_estep_packed(stats, exp_stats, log_weights, K, cov_type, llh_sum=Non
     if E.shape[0] != K or lw.numel() != K:
         raise ValueError(f'{E.shape[0]} Gaussians, {lw.numel()} weights for {K} components')
     log_norm = torch.empty(T, 1, dtype=X.dtype, device=X.device)
-    words = torch.empty(_hip.lib().beer_packed_resps_bytes(T, K) // 4, dtype=torch.int32,
+    words = torch.empty(_hip.lib().beer_packed_resps_bytes(T, D, K) // 4, dtype=torch.int32,
                         device=X.device)
     ws, ws_bytes = _hip.workspace('beer_estep_workspace_bytes', X.dtype,
                                   _hip.COV_CODE[cov_type], D, 1, K, X.device)

@@ -233,10 +233,11 @@ int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G,
 
 /* The E-step -> accumulate hand-over of a single mixture (S = 1, float32, split
  * arithmetic: beer_hip_set_f32_mode) without the float32 responsibilities in
- * between.  `packed_resps` (beer_packed_resps_bytes(T, K) bytes: a 512-byte
+ * between.  `packed_resps` (beer_packed_resps_bytes(T, D, K) bytes: a 512-byte
  * header -- the per-dimension frame scales the E-step computed, reused by the
  * accumulation -- then 4 bytes per element with T rounded up to 64 and K to
- * 128) receives each responsibility
+ * 128, then, for 129..256 components, the transposed range-scaled frames the
+ * E-step kernel leaves behind for the accumulation) receives each responsibility
  * already split into the fp16 pair the accumulation kernel multiplies with,
  * laid out as that kernel's LDS tiles: per (64 frames, 128 components) 32 KB =
  * the high halves of r * 2^12 as rows [component][64 frames] whose 16-byte
@@ -253,7 +254,7 @@ int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G,
  * EINVAL: shape without a matrix-core path, workspace NULL / too small (sizes
  * from beer_estep_workspace_bytes(BEER_F32, ...) and
  * beer_accumulate_packed_workspace_bytes). */
-size_t beer_packed_resps_bytes(int64_t T, int K);
+size_t beer_packed_resps_bytes(int64_t T, int D, int K);
 size_t beer_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int K);
 int beer_mixture_estep_packed(int cov, int64_t T, int D, int K, const float* X,
                               const float* exp_stats, const float* log_weights,
