@@ -864,3 +864,46 @@ def test_packed_path_is_what_a_mixture_batch_takes():
                                 sorted(elbo_u._acc_stats.items(), key=lambda kv: id(kv[0]))):
         assert pa is pb
         torch.testing.assert_close(a, b, rtol=1e-9, atol=1e-9 * float(b.abs().max()))
+
+
+def test_packed_hand_over_random_shapes():
+    '''The packed E-step -> accumulate path over random shapes: every covariance
+    type, D from 1 to 64 (1 .. 5 frame pieces, rows that are / are not whole
+    float4), K from 16 to 256 (one / two waves per frame group, blocks past K),
+    T around the tile boundaries.  Yardstick: the exact fp32 kernels against the
+    fp64 kernels on the same inputs.'''
+    import random
+    from beer_amd import _hip, kernels
+    rnd = random.Random(7)
+    for case in range(14):
+        cov = rnd.choice(['full', 'diagonal', 'isotropic'])
+        D = rnd.choice([1, 2, 3, 4, 5, 7, 8, 12, 13, 16, 20, 24, 31, 32, 39, 40, 48, 63, 64])
+        K = 4 * rnd.randint(4, 64)
+        T = rnd.choice([16384, 16385, 16447, 16448, 20000, 25001, 32768, 40001])
+        torch.manual_seed(case)
+        X = torch.randn(T, D, dtype=torch.float64, device=DEV) * rnd.choice([.5, 1., 3.]) + \
+            rnd.choice([0., 2.])
+        ns = beer.NormalSet.create(X.mean(0).cpu(), torch.diag(X.var(0).cpu().reshape(D)), size=K,
+                                   prior_strength=1., noise_std=.7, cov_type=cov)
+        mix = beer.Mixture.create(ns).double().to(DEV)
+        E64, lw64 = ns.means_precisions.natural_form(), mix._log_weights().view(1, K)
+        st64 = beer.FrameStats(X, cov)
+        ln64, r64 = kernels.mixtureset_estep(st64, E64, lw64, 1, K, cov)
+        acc64 = kernels.normal_accumulate(st64, r64, None, 1, K, cov)
+        st32 = beer.FrameStats(X.float(), cov)
+        assert kernels.packed_path_ok(st32, K, cov), (cov, D, K, T)
+        with _hip.exact_f32():
+            ln_e, r_e = kernels.mixtureset_estep(st32, E64.float(), lw64.float(), 1, K, cov)
+            acc_e = kernels.normal_accumulate(st32, r_e, None, 1, K, cov)
+        ln_p, packed = kernels.mixture_estep_packed(st32, E64.float(), lw64.float(), K, cov)
+        acc_p = kernels.normal_accumulate(st32, packed, None, 1, K, cov)
+        scale = float(acc64.abs().max())
+        e_e = float((acc_e - acc64).abs().max()) / scale
+        e_p = float((acc_p - acc64).abs().max()) / scale
+        l_e = float((ln_e.double() - ln64).abs().max())
+        l_p = float((ln_p.double() - ln64).abs().max())
+        what = (cov, D, K, T, e_p, e_e, l_p, l_e)
+        assert bool(torch.isfinite(acc_p).all()), what
+        assert e_p <= 4. * e_e + 2e-6, what
+        assert l_p <= 4. * l_e + 1e-6 * float(ln64.abs().max()), what
+        assert float((packed.unpack().double() - r64).abs().max()) < 1e-4, what
