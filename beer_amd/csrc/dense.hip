@@ -13,6 +13,9 @@
 // Reference restated: beer/dists/normalgamma.py:55-59 (llh = stats @ E[T]^T +
 // log base measure), beer/models/normalset.py:121-123 (resps^T @ stats).
 
+#include <dlfcn.h>
+#include <rocblas/rocblas.h>             // types and prototypes only: the library is dlopen'ed
+
 #include "common.h"
 
 using namespace beer;
@@ -195,6 +198,145 @@ __global__ void suffstats_backward_kernel(int cov, int64_t T_, int ns, int D,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Large float32 products (full-covariance latent: Q = D*D + D + 2 in the
+// thousands) go to rocBLAS: plain GEMMs with a long inner or outer dimension,
+// where the LDS-tiled VALU kernel above runs at 25 TFLOP/s and the library's
+// fp32 MFMA kernels at several times that.  The library is looked up at run time
+// by its soname (inside a PyTorch process that is the copy PyTorch already
+// loaded); without it, or for small / fp64 problems, the kernel above runs.
+// Products are exact fp32 with fp32 accumulation; sums over frames are cut into
+// kChunk-frame partial sums that are added in fp64.
+// ---------------------------------------------------------------------------
+constexpr int kBlasMinQ = 512;
+constexpr int64_t kBlasMinT = 8192;
+constexpr int kChunk = 4096;
+
+struct RocBlas {
+    decltype(&rocblas_create_handle) create = nullptr;
+    decltype(&rocblas_set_stream) set_stream = nullptr;
+    decltype(&rocblas_sgemm) sgemm = nullptr;
+    decltype(&rocblas_sgemm_strided_batched) sgemm_sb = nullptr;
+    rocblas_handle handle = nullptr;
+    bool ok = false;
+    RocBlas() {
+        if (const char* e = getenv("BEER_NO_ROCBLAS")) { if (e[0] == '1') return; }
+        void* lib = dlopen("librocblas.so.5", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return;
+        create = reinterpret_cast<decltype(create)>(dlsym(lib, "rocblas_create_handle"));
+        set_stream = reinterpret_cast<decltype(set_stream)>(dlsym(lib, "rocblas_set_stream"));
+        sgemm = reinterpret_cast<decltype(sgemm)>(dlsym(lib, "rocblas_sgemm"));
+        sgemm_sb = reinterpret_cast<decltype(sgemm_sb)>(
+            dlsym(lib, "rocblas_sgemm_strided_batched"));
+        ok = create && set_stream && sgemm && sgemm_sb &&
+             create(&handle) == rocblas_status_success;
+    }
+};
+RocBlas* blas_for(hipStream_t s) {
+    static RocBlas rb;                         // one handle: calls are serialised by the caller
+    if (!rb.ok || rb.set_stream(rb.handle, s) != rocblas_status_success) return nullptr;
+    return &rb;
+}
+inline bool blas_shape(int64_t T_, int Q, int K) {
+    return Q >= kBlasMinQ && T_ >= kBlasMinT && T_ < (int64_t)1 << 31 && K >= 1;
+}
+
+__global__ void fill_kernel(int64_t n, float v, float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) out[idx] = v;
+}
+// out[t,k] = w[t,k] * (g ? g[t] : 1) * (sr ? sr[t, k / G] : 1)
+__global__ void scale_rows_kernel(int64_t T_, int K, int G, const float* __restrict__ w,
+                                  const float* __restrict__ g, const float* __restrict__ sr,
+                                  float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T_ * K) return;
+    const int64_t t = idx / K;
+    const int k = (int)(idx - t * K);
+    float v = w[idx];
+    if (g) v *= g[t];
+    if (sr) v *= sr[t * (K / G) + k / G];
+    out[idx] = v;
+}
+// acc[i] += sum_b part[b][i]  (fp64)
+__global__ void add_partials_kernel(int64_t n, int nb, const float* __restrict__ part,
+                                    double* __restrict__ acc) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    double sacc = 0.0;
+    for (int b = 0; b < nb; ++b) sacc += (double)part[(size_t)b * n + idx];
+    acc[idx] += sacc;
+}
+
+// rocBLAS is column-major: a row-major [r, c] array is its [c, r] matrix with ld = c.
+// out[T,K] = stats[T,Q] @ E[K,Q]^T + base
+int blas_llh(RocBlas* rb, int64_t T_, int Q, int K, const float* stats, const float* E,
+             double base, float* out, hipStream_t s) {
+    const int64_t n = T_ * K;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n,
+                       (float)base, out);
+    BEER_LAUNCH_CHECK();
+    const float one = 1.f;
+    return rb->sgemm(rb->handle, rocblas_operation_transpose, rocblas_operation_none, K, (int)T_,
+                     Q, &one, E, Q, stats, Q, &one, out, K) == rocblas_status_success
+               ? BEER_OK : BEER_EINVAL;
+}
+// out[T,Q] = g_t * sum_k w[t,k] E[k,q]
+int blas_backward(RocBlas* rb, int64_t T_, int K, int Q, const float* w, const float* g,
+                  const float* E, float* out, hipStream_t s) {
+    float* wg = nullptr;
+    const int64_t n = T_ * K;
+    if (g) {
+        if (hipMallocAsync(reinterpret_cast<void**>(&wg), (size_t)n * sizeof(float), s) !=
+            hipSuccess)
+            return BEER_EINVAL;
+        hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                           T_, K, 1, w, g, (const float*)nullptr, wg);
+    }
+    const float one = 1.f, zero = 0.f;
+    const rocblas_status st =
+        rb->sgemm(rb->handle, rocblas_operation_none, rocblas_operation_none, Q, (int)T_, K, &one,
+                  E, Q, g ? wg : w, K, &zero, out, Q);
+    if (wg) (void)hipFreeAsync(wg, s);
+    return st == rocblas_status_success ? BEER_OK : BEER_EINVAL;
+}
+// acc[K,Q] += sum_t w[t,k] sr[t, k / G] stats[t,q]
+int blas_accumulate(RocBlas* rb, int64_t T_, int K, int Q, int G, const float* w,
+                    const float* sr, const float* stats, double* acc, hipStream_t s) {
+    const int nfull = (int)(T_ / kChunk), rest = (int)(T_ - (int64_t)nfull * kChunk);
+    const int nb = nfull + (rest ? 1 : 0);
+    const int64_t n = T_ * K, kq = (int64_t)K * Q;
+    float* buf = nullptr;                       // [joint weights T*K (if sr)] [partials nb*K*Q]
+    const size_t wj_floats = sr ? (size_t)n : 0;
+    if (hipMallocAsync(reinterpret_cast<void**>(&buf),
+                       (wj_floats + (size_t)nb * kq) * sizeof(float), s) != hipSuccess)
+        return BEER_EINVAL;
+    const float* wj = w;
+    if (sr) {
+        hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                           T_, K, G, w, (const float*)nullptr, sr, buf);
+        wj = buf;
+    }
+    float* part = buf + wj_floats;
+    const float one = 1.f, zero = 0.f;
+    rocblas_status st = rocblas_status_success;
+    // P_b [K,Q] (row-major) = wj_b^T stats_b  ==  col-major [Q,K] = stats_b^T[Q,Tb] * wj_b[Tb,K]
+    if (nfull)
+        st = rb->sgemm_sb(rb->handle, rocblas_operation_none, rocblas_operation_transpose, Q, K,
+                          kChunk, &one, stats, Q, (rocblas_stride)kChunk * Q, wj, K,
+                          (rocblas_stride)kChunk * K, &zero, part, Q, (rocblas_stride)kq, nfull);
+    if (st == rocblas_status_success && rest)
+        st = rb->sgemm(rb->handle, rocblas_operation_none, rocblas_operation_transpose, Q, K, rest,
+                       &one, stats + (size_t)nfull * kChunk * Q, Q, wj + (size_t)nfull * kChunk * K,
+                       K, &zero, part + (size_t)nfull * kq, Q);
+    if (st == rocblas_status_success)
+        hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)((kq + 255) / 256)), dim3(256), 0, s,
+                           kq, nb, part, acc);
+    (void)hipFreeAsync(buf, s);
+    return st == rocblas_status_success ? BEER_OK : BEER_EINVAL;
+}
+
 template <typename T>
 int gemm_plain(int64_t M, int N, int64_t Kd, const T* A, int64_t sam, int64_t sak, const T* B,
                int64_t sbk, int64_t sbn, T* C, const T* row_scale, double beta, hipStream_t s) {
@@ -211,6 +353,10 @@ int dense_llh_launch(int64_t T_, int Q, int K, const void* stats, const void* ex
     BEER_REQUIRE(T_ >= 0 && Q >= 1 && K >= 1 && stats && expT && out);
     if (T_ == 0) return BEER_OK;
     // out[t,k] = sum_q stats[t,q] expT[k,q] + base
+    if (sizeof(T) == 4 && blas_shape(T_, Q, K))
+        if (RocBlas* rb = blas_for(as_stream(stream)))
+            return blas_llh(rb, T_, Q, K, (const float*)stats, (const float*)expT, base,
+                            (float*)out, as_stream(stream));
     return gemm_plain<T>(T_, K, Q, (const T*)stats, Q, 1, (const T*)expT, 1, Q, (T*)out, nullptr,
                          base, as_stream(stream));
 }
@@ -221,6 +367,10 @@ int dense_backward_launch(int64_t T_, int K, int Q, const void* w, const void* g
     BEER_REQUIRE(T_ >= 0 && Q >= 1 && K >= 1 && w && expT && out);
     if (T_ == 0) return BEER_OK;
     // out[t,q] = g_t * sum_k w[t,k] expT[k,q]
+    if (sizeof(T) == 4 && blas_shape(T_, Q, K))
+        if (RocBlas* rb = blas_for(as_stream(stream)))
+            return blas_backward(rb, T_, K, Q, (const float*)w, (const float*)g,
+                                 (const float*)expT, (float*)out, as_stream(stream));
     return gemm_plain<T>(T_, Q, K, (const T*)w, K, 1, (const T*)expT, Q, 1, (T*)out, (const T*)g,
                          0.0, as_stream(stream));
 }
@@ -231,6 +381,10 @@ int dense_accumulate_launch(int64_t T_, int K, int Q, int G, const void* w, cons
     BEER_REQUIRE(T_ >= 0 && Q >= 1 && K >= 1 && G >= 1 && K % G == 0 && w && stats && acc);
     if (T_ == 0) return BEER_OK;
     // acc[k,q] += sum_t w[t,k] stats[t,q]; frames split over grid.z, fp64 atomics
+    if (sizeof(T) == 4 && blas_shape(T_, Q, K))
+        if (RocBlas* rb = blas_for(as_stream(stream)))
+            return blas_accumulate(rb, T_, K, Q, G, (const float*)w, (const float*)sr,
+                                   (const float*)stats, acc, as_stream(stream));
     const int gx = (K + TM - 1) / TM, gy = (Q + TN - 1) / TN;
     int64_t gz = (2048 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy);
     const int64_t max_z = (T_ + 255) / 256;
@@ -299,6 +453,8 @@ int suffstats_backward_launch(int cov, int64_t T_, int ns, int D, const void* X,
 }  // namespace
 
 extern "C" {
+
+int beer_hip_has_rocblas(void) { return blas_for(nullptr) ? 1 : 0; }
 
 int beer_dense_llh(int dtype, int64_t T, int Q, int K, const void* stats, const void* exp_stats,
                    double base, void* out, void* stream) {

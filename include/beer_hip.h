@@ -422,6 +422,13 @@ int beer_segment_sum(int dtype, int32_t nutt, const int64_t* frame_off,
  * phi(z) over the samples of the latent variable) instead of frames, and its
  * expected log-likelihood is differentiated w.r.t. them. */
 
+/* 1 when rocBLAS was found at run time (dlopen by soname): the float32
+ * statistics-in products below with Q >= 512 and T >= 8192 then run on its fp32
+ * MFMA GEMMs (exact fp32 products, fp32 accumulation, sums over frames in
+ * 4096-frame partials added in fp64; temporaries from the stream-ordered
+ * allocator), everything else on the library's own kernels. */
+int beer_hip_has_rocblas(void);
+
 /* out[t,k] = sum_q stats[t,q] * exp_stats[k,q] + base   -> [T, K]
  * (ConjugateLikelihood.__call__, beer/dists/normalgamma.py:55-59; base is the
  * log base measure -D/2 ln 2pi). */

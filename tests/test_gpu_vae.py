@@ -189,3 +189,36 @@ def test_vae_batch_equals_per_utterance_loop(monkeypatch):
         assert_close(npy(p.grad), npy(grads[n]), 1e-8, 'grad ' + n)
     for p in vae.bayesian_parameters():
         assert_close(npy(batch._acc_stats[p]), npy(loop._acc_stats[p]), 1e-9, 'acc')
+
+
+@pytest.mark.parametrize('T,Q,S,G', [(20001, 932, 24, 4), (8192, 600, 64, 1), (12000, 2162, 7, 16)])
+def test_large_dense_products_on_the_library_gemm(T, Q, S, G):
+    '''float32 statistics-in products with a long statistics dimension (full-
+    covariance latent) run on rocBLAS (dense.hip: blas_llh / blas_backward /
+    blas_accumulate); same results, to float32 accuracy, as the fp64 kernels.'''
+    from beer_amd import _hip, kernels
+    from gpu_helpers import DEV
+    assert _hip.lib().beer_hip_has_rocblas() == 1      # else this test compares a kernel with itself
+    torch.manual_seed(4)
+    K = S * G
+    st = torch.randn(T, Q, dtype=torch.float64, device=DEV)
+    E = torch.randn(K, Q, dtype=torch.float64, device=DEV) / Q ** .5
+    w = torch.rand(T, K, dtype=torch.float64, device=DEV)
+    sr = torch.rand(T, S, dtype=torch.float64, device=DEV)
+    g = torch.rand(T, dtype=torch.float64, device=DEV) + .5
+    llh64 = kernels.dense_llh(st, E, 30)
+    llh32 = kernels.dense_llh(st.float(), E.float(), 30)
+    torch.testing.assert_close(llh32.double(), llh64, rtol=0, atol=2e-6 * float(llh64.abs().max()))
+    for grad in (g, None):
+        b64 = kernels._llh_backward(w, grad, E)
+        b32 = kernels._llh_backward(w.float(), None if grad is None else grad.float(), E.float())
+        torch.testing.assert_close(b32.double(), b64, rtol=0, atol=2e-6 * float(b64.abs().max()))
+    for state in (sr, None):
+        a64 = kernels.dense_accumulate(st, w, state, S, G)
+        a32 = kernels.dense_accumulate(st.float(), w.float(), None if state is None else state.float(),
+                                       S, G)
+        torch.testing.assert_close(a32, a64, rtol=0, atol=2e-6 * float(a64.abs().max()))
+        # accumulation adds to what is there
+        again = kernels.dense_accumulate(st.float(), w.float(),
+                                         None if state is None else state.float(), S, G, acc=a32.clone())
+        torch.testing.assert_close(again, 2. * a32, rtol=1e-12, atol=0)
