@@ -337,6 +337,45 @@ int blas_accumulate(RocBlas* rb, int64_t T_, int K, int Q, int G, const float* w
     return st == rocblas_status_success ? BEER_OK : BEER_EINVAL;
 }
 
+// Full covariance: the upstream gradient of a frame holds a D x D block G, and
+// every output needs row d AND column d of it -- read straight from memory by a
+// thread per output (the kernel above) the rows are 4-byte gathers D * 4 bytes
+// apart: 33 ms per 1 M frames at D = 64.  Here a wave owns a frame: it copies G
+// (coalesced) into LDS rows of D + 1 words (conflict-free by row and by column),
+// then lane d forms sum_j (G[d][j] + G[j][d]) x[j] for each of the frame's samples.
+template <typename T>
+__global__ __launch_bounds__(256) void suffstats_backward_full_kernel(
+    int64_t T_, int ns, int D, const T* __restrict__ X, const T* __restrict__ gs,
+    T* __restrict__ gx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int LD = D + 1, Q = D * D + D + 2;
+    T* G = reinterpret_cast<T*>(smem) + wave * (D * LD + 2 * D);
+    T* lin = G + D * LD;
+    T* xs = lin + D;
+    const double inv = 1.0 / ns;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < T_; t += (int64_t)gridDim.x * 4) {
+        const T* g = gs + t * Q;
+        for (int e = lane; e < D * D; e += 64) {
+            const int r = e / D, c = e - r * D;
+            G[r * LD + c] = g[D + e];
+        }
+        if (lane < D) lin[lane] = g[lane];
+        for (int sidx = 0; sidx < ns; ++sidx) {
+            const int64_t n = t * ns + sidx;
+            if (lane < D) xs[lane] = X[n * D + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < D) {
+                double acc = 0.0;
+                for (int j = 0; j < D; ++j)
+                    acc += ((double)G[lane * LD + j] + (double)G[j * LD + lane]) * (double)xs[j];
+                gx[n * D + lane] = (T)(((double)lin[lane] - 0.5 * acc) * inv);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 template <typename T>
 int gemm_plain(int64_t M, int N, int64_t Kd, const T* A, int64_t sam, int64_t sak, const T* B,
                int64_t sbk, int64_t sbn, T* C, const T* row_scale, double beta, hipStream_t s) {
@@ -442,6 +481,17 @@ int suffstats_backward_launch(int cov, int64_t T_, int ns, int D, const void* X,
                               void* gx, void* stream) {
     BEER_REQUIRE(T_ >= 0 && ns >= 1 && D >= 1 && cov >= 0 && cov <= 2);
     if (T_ == 0) return BEER_OK;
+    if (cov == BEER_FULL && D <= 64 && D >= 8) {
+        const size_t lds = 4 * ((size_t)D * (D + 1) + 2 * D) * sizeof(T);
+        const int64_t wgs = (T_ + 3) / 4;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(suffstats_backward_full_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(suffstats_backward_full_kernel<T>,
+                           dim3((unsigned)(wgs > 65536 ? 65536 : wgs)), dim3(256), lds,
+                           as_stream(stream), T_, ns, D, (const T*)X, (const T*)gs, (T*)gx);
+        BEER_LAUNCH_CHECK();
+        return BEER_OK;
+    }
     const int64_t total = T_ * ns * D;
     const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
     hipLaunchKernelGGL(suffstats_backward_kernel<T>, dim3(blocks), dim3(256), 0, as_stream(stream),

@@ -222,3 +222,36 @@ def test_large_dense_products_on_the_library_gemm(T, Q, S, G):
         again = kernels.dense_accumulate(st.float(), w.float(),
                                          None if state is None else state.float(), S, G, acc=a32.clone())
         torch.testing.assert_close(again, 2. * a32, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize('cov,D,ns,dtype,tol', [
+    ('full', 64, 1, torch.float32, 2e-6), ('full', 40, 3, torch.float32, 2e-6),
+    ('full', 8, 2, torch.float64, 1e-13), ('full', 33, 1, torch.float64, 1e-13),
+    ('full', 5, 2, torch.float64, 1e-13), ('diagonal', 40, 2, torch.float64, 1e-13)])
+def test_statistics_gradient_against_autograd(cov, D, ns, dtype, tol):
+    '''d (mean over ns samples of phi(x)) / dx contracted with an upstream gradient:
+    the kernels (wave-per-frame for full covariance with D >= 8) against torch
+    autograd on the dense construction of the same statistics (fp64).'''
+    from beer_amd import kernels
+    from gpu_helpers import DEV
+    torch.manual_seed(9)
+    T = 301
+    x64 = torch.randn(T * ns, D, dtype=torch.float64, device=DEV)
+    ones = torch.ones(T * ns, 1, dtype=torch.float64, device=DEV)
+    xr = x64.clone().requires_grad_(True)
+    if cov == 'full':
+        dense = torch.cat([xr, -.5 * (xr[:, :, None] * xr[:, None, :]).reshape(T * ns, D * D),
+                           -.5 * ones, .5 * ones], dim=1)
+    else:
+        dense = torch.cat([xr, -.5 * xr ** 2, -.5 * ones, .5 * ones], dim=1)
+    mean = dense.view(T, ns, -1).mean(1)
+    up = torch.randn(T, mean.shape[1], dtype=torch.float64, device=DEV)
+    (mean * up).sum().backward()
+    mean = mean.detach()
+    data = x64.to(dtype).clone().requires_grad_(True)
+    stats = kernels.differentiable_stats(data, cov, ns)
+    torch.testing.assert_close(stats.detach().double(), mean, rtol=0,
+                               atol=tol * float(mean.abs().max()) + 1e-30)
+    (stats * up.to(dtype)).sum().backward()
+    torch.testing.assert_close(data.grad.double(), xr.grad, rtol=0,
+                               atol=tol * float(xr.grad.abs().max()))
