@@ -390,7 +390,8 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
     // hub[0..kMaxHubs): hub value of the running recursion; hub[kMaxHubs]:
     // lognorm_t; hub[kMaxHubs+1 ..): forward hub values H_h(t), recomputed in the
     // backward pass from alpha_t by wave 1 (needed for the hub flows)
-    double* hub = lb + b.max_states;
+    double* al = lb + b.max_states;                      // [S] alpha_t of the backward frame
+    double* hub = al + b.max_states;
 
     // One state per thread (S <= blockDim is required by the launcher).
     const int j = tid;
@@ -449,7 +450,14 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
         alpha[j] = a;
     }
     __syncthreads();
+    // The recursion is a chain of T dependent steps: everything a step reads from
+    // global memory (its emission log-likelihood, in the backward pass also its
+    // alpha) is loaded one step ahead, so that no memory round trip sits in the
+    // chain (2 us per step before, most of it two exposed loads).
+    double ll_next = st && T_ > 1 ? (double)llh[S + j] : 0.0;
     for (int64_t t = 1; t < T_; ++t) {
+        const double ll = ll_next;
+        if (st && t + 1 < T_) ll_next = (double)llh[(t + 1) * S + j];
         if (wave == 0 && H > 0) hub_lse(cur, L.src_ptr, L.src_list, hsw);
         double m = NINF, sm = 0.0;
         if (st) {
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
         if (st) {
             double lse = (m > NINF && m < PINF) ? m + flog<T>(sm) : m;
             if (hd >= 0) lse = logaddexp2<T>(lse, hub[hd] + hd_w);
-            const double a = (double)llh[t * S + j] + lse;
+            const double a = ll + lse;
             cur[j] = a;
             alpha[t * S + j] = a;
         }
@@ -477,10 +485,23 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
 
     // ---- backward + posteriors ----
     if (st) cur[j] = (double)((const T*)g.final)[j];     // beta_{T-1}
+    // alpha_t and llh_t of the frame in hand, loaded one iteration ahead; alpha_t
+    // goes to LDS for the waves that reduce over all states
+    double a_next = st ? alpha[(T_ - 1) * S + j] : NINF;
+    double lt_next = st ? (double)llh[(T_ - 1) * S + j] : 0.0;
     __syncthreads();
     double ln_acc = 0.0;
     for (int64_t t = T_ - 1; t >= 0; --t) {
         const bool inner = t < T_ - 1;
+        const double a_cur = a_next, lt_cur = lt_next;
+        if (st) {
+            al[j] = a_cur;
+            if (t > 0) {
+                a_next = alpha[(t - 1) * S + j];
+                lt_next = (double)llh[(t - 1) * S + j];
+            }
+        }
+        if (!inner) __syncthreads();                      // al visible (else: the barriers below)
         if (inner) {
             // beta_t(i) = lse(sparse: A_ij + lb_j ; hub: r_i + lse_s(w_s + lb_s))
             if (wave == 0 && H > 0) hub_lse(lb, L.dst_ptr, L.dst_list, hdw);
@@ -507,18 +528,18 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
         }
         // lognorm_t = lse_i(alpha_t(i) + beta_t(i)) by wave 0; forward hub values
         // H_h(t) = lse_e(alpha_t(e) + r_e) (for the hub flows) by wave 1
-        const double ab = st ? alpha[t * S + j] + cur[j] : NINF;
+        const double ab = st ? a_cur + cur[j] : NINF;
         if (wave == 0) {
             double m = NINF;
             for (int p = lane; p < S; p += 64) {
-                const double val = alpha[t * S + p] + cur[p];
+                const double val = al[p] + cur[p];
                 m = val > m ? val : m;
             }
             m = wave_max(m);
             double r = m;
             if (m > NINF && m < PINF) {
                 double sm = 0.0;
-                for (int p = lane; p < S; p += 64) sm += fexp<T>(alpha[t * S + p] + cur[p] - m);
+                for (int p = lane; p < S; p += 64) sm += fexp<T>(al[p] + cur[p] - m);
                 sm = wave_sum(sm);
                 r = m + flog<T>(sm);
             }
@@ -529,7 +550,7 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
                 double m = NINF;
                 for (int p = beg + lane; p < end; p += 64) {
                     const int e = L.src_list[p];
-                    const double val = alpha[t * S + e] + (double)hsw[e];
+                    const double val = al[e] + (double)hsw[e];
                     m = val > m ? val : m;
                 }
                 m = wave_max(m);
@@ -538,7 +559,7 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
                     double sm = 0.0;
                     for (int p = beg + lane; p < end; p += 64) {
                         const int e = L.src_list[p];
-                        sm += fexp<T>(alpha[t * S + e] + (double)hsw[e] - m);
+                        sm += fexp<T>(al[e] + (double)hsw[e] - m);
                     }
                     sm = wave_sum(sm);
                     r = m + flog<T>(sm);
@@ -555,7 +576,7 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
             if (t == 0 && gamma0_sum) atomicAdd(gamma0_sum + j, gv);
             if (xi_sum && inner && lognorm > NINF) {
                 // arcs t -> t+1 leaving this state, and the hub flow entering it
-                const double ai = alpha[t * S + j] - lognorm;
+                const double ai = a_cur - lognorm;
 #pragma unroll
                 for (int k = 0; k < BEER_SEG; ++k) {
                     if (ow[k] > NINF) {
@@ -570,7 +591,7 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
             }
         }
         __syncthreads();                                  // lb readers done
-        if (st) lb[j] = (double)llh[t * S + j] + cur[j];  // for frame t-1
+        if (st) lb[j] = lt_cur + cur[j];                  // for frame t-1
         __syncthreads();
     }
     if (lognorm_mean && tid == 0) lognorm_mean[u] = (T)(ln_acc / (double)T_);
@@ -718,7 +739,7 @@ int beer_hmm_forward_backward(int dtype, const beer_batch* b, const void* pc_llh
     hipStream_t s = as_stream(stream);
     if (b->all_lowdeg && b->max_states <= kLdThreads && (!xi_sum || hub_flow)) {
         // factorised low-degree recursion: one thread per state
-        const size_t lds = ((size_t)2 * b->max_states + 4 * kMaxHubs + 8) * sizeof(double);
+        const size_t lds = ((size_t)3 * b->max_states + 4 * kMaxHubs + 8) * sizeof(double);
         // at least two waves (wave 1 recomputes the forward hub values)
         const int threads = b->max_states <= 128 ? 128 : (b->max_states <= 256 ? 256 : 512);
         if (dtype == BEER_F32)
