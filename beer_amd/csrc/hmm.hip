@@ -30,6 +30,17 @@ __device__ __forceinline__ T ninf() { return (T)-INFINITY; }
 // transcendental-bound); maxima, sums and the trellis itself stay fp64.
 template <typename T> __device__ __forceinline__ double fexp(double x) { return (double)exp((T)x); }
 template <typename T> __device__ __forceinline__ double flog(double x) { return (double)log((T)x); }
+// float: the hardware's 2^x and log2 (1 ulp) around an fp64 change of base -- the
+// argument is rounded to float once, as in expf((float)x), at a quarter of the
+// instructions.  Arguments are <= 0 after the max subtraction (results below
+// 2^-126 flush to 0: they are added to a term equal to 1), logs are taken of
+// sums >= 1.
+template <> __device__ __forceinline__ double fexp<float>(double x) {
+    return (double)__builtin_amdgcn_exp2f((float)(x * 1.4426950408889634074));
+}
+template <> __device__ __forceinline__ double flog<float>(double x) {
+    return (double)__builtin_amdgcn_logf((float)x) * 0.69314718055994530942;
+}
 
 // ---------------------------------------------------------------------------
 // gather: pc_llhs[u][t,s] = scale * pc_all[frame_off[u]+t, pdf_ids[...]]
