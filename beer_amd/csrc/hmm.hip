@@ -617,15 +617,22 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
 // ---------------------------------------------------------------------------
 // Viterbi
 // ---------------------------------------------------------------------------
+// The recursion is a chain of T dependent steps per utterance, so nothing a step
+// needs may come from global memory inside the chain: the graph's arc lists live
+// in LDS, the emission log-likelihoods of step t + 1 are loaded during step t, and
+// the back-trace walks the back-pointers through LDS, kViterbiChunk frames at a
+// time (one coalesced load per chunk instead of one dependent load per frame).
+constexpr int kViterbiChunk = 32;
+
 template <typename T>
 __global__ __launch_bounds__(kHmmThreads) void viterbi_kernel(
     beer_batch b, const T* __restrict__ pc_llhs, int32_t* __restrict__ bt_ws,
-    int64_t* __restrict__ path, int map_pdf) {
+    int64_t* __restrict__ path, int map_pdf, int arcs_in_lds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int u = blockIdx.x, tid = threadIdx.x, nt_ = blockDim.x;
     const int gid = b.graph_id[u];
     const beer_graph g = b.graphs[gid];
-    const int S = g.n_states;
+    const int S = g.n_states, A = g.n_arcs;
     const int64_t T_ = b.frame_off[u + 1] - b.frame_off[u];
     if (T_ <= 0) return;
     const T* llh = pc_llhs + b.llh_off[u];
@@ -633,30 +640,48 @@ __global__ __launch_bounds__(kHmmThreads) void viterbi_kernel(
     int64_t* out = path + b.frame_off[u];
     const T* init = (const T*)g.init;
     const T* fin = (const T*)g.final;
-    const T* in_w = (const T*)g.in_w;
     T* cur = reinterpret_cast<T*>(smem);
-    T* nxt = cur + S;
-
+    T* nxt = cur + b.max_states;
+    int32_t* btc = reinterpret_cast<int32_t*>(nxt + b.max_states);     // [chunk][S]
+    int32_t* l_ptr = btc + (size_t)kViterbiChunk * b.max_states;       // [S + 1]
+    int32_t* l_src = l_ptr + b.max_states + 1;                         // [A]
+    T* l_w = reinterpret_cast<T*>(l_src + b.max_arcs + ((b.max_states + 1 + b.max_arcs) & 1));
+    const int32_t* in_ptr = g.in_ptr;
+    const int32_t* in_src = g.in_src;
+    const T* in_w = (const T*)g.in_w;
+    if (arcs_in_lds) {
+        for (int j = tid; j <= S; j += nt_) l_ptr[j] = g.in_ptr[j];
+        for (int e = tid; e < A; e += nt_) { l_src[e] = g.in_src[e]; l_w[e] = in_w[e]; }
+        in_ptr = l_ptr; in_src = l_src; in_w = l_w;
+    }
     for (int j = tid; j < S; j += nt_) cur[j] = llh[j] + init[j];
     __syncthreads();
+    // (one state per thread in the common case: the prefetch register is per thread)
+    const bool one = S <= nt_;
+    T ll_next = one && tid < S && T_ > 1 ? llh[S + tid] : (T)0;
     for (int64_t t = 1; t < T_; ++t) {
+        const T ll_cur = ll_next;
+        if (one && tid < S && t + 1 < T_) ll_next = llh[(t + 1) * S + tid];
         for (int j = tid; j < S; j += nt_) {
             // argmax_i(omega_i + A_ij): first index wins; all -inf -> 0
             // (torch.argmax over the dense column, graph.py:337-338).
             T best = ninf<T>();
             int arg = 0;
-            for (int e = g.in_ptr[j]; e < g.in_ptr[j + 1]; ++e) {
-                const T v = cur[g.in_src[e]] + in_w[e];
-                if (v > best) { best = v; arg = g.in_src[e]; }
+            for (int e = in_ptr[j]; e < in_ptr[j + 1]; ++e) {
+                const int src = in_src[e];
+                const T v = cur[src] + in_w[e];
+                if (v > best) { best = v; arg = src; }
             }
             bt[t * S + j] = arg;
             // hypothesis[j, arg]: when no arc is finite the dense entry is
             // omega_0 + A_0j = -inf (or NaN-free -inf + finite)
-            nxt[j] = llh[t * S + j] + best;
+            nxt[j] = (one ? ll_cur : llh[t * S + j]) + best;
         }
         __syncthreads();
         T* tmp = cur; cur = nxt; nxt = tmp;
     }
+    // final state (thread 0), then the back-trace chunk by chunk
+    int* s_state = reinterpret_cast<int*>(nxt);             // nxt is free now
     if (tid == 0) {
         T best = ninf<T>();
         int arg = 0;
@@ -664,11 +689,23 @@ __global__ __launch_bounds__(kHmmThreads) void viterbi_kernel(
             const T v = cur[j] + fin[j];
             if (v > best) { best = v; arg = j; }
         }
-        const int32_t* ids = b.pdf_ids + b.pdf_off[gid];
-        int s = arg;
-        for (int64_t t = T_ - 1; t >= 0; --t) {
-            out[t] = map_pdf ? (int64_t)ids[s] : (int64_t)s;
-            if (t > 0) s = bt[t * S + s];
+        s_state[0] = arg;
+    }
+    const int32_t* ids = b.pdf_ids + b.pdf_off[gid];
+    for (int64_t hi = T_ - 1; hi >= 0; hi -= kViterbiChunk) {
+        const int64_t lo = hi - kViterbiChunk + 1 > 0 ? hi - kViterbiChunk + 1 : 0;   // frames lo .. hi
+        __syncthreads();                                    // bt stores / previous chunk done
+        // back-pointers of frames max(lo, 1) .. hi (frame 0 has none)
+        const int64_t first = lo > 0 ? lo : 1;
+        for (int64_t e = tid; e < (hi - first + 1) * S; e += nt_) btc[e] = bt[first * S + e];
+        __syncthreads();
+        if (tid == 0) {
+            int st = s_state[0];
+            for (int64_t t = hi; t >= lo; --t) {
+                out[t] = map_pdf ? (int64_t)ids[st] : (int64_t)st;
+                if (t > 0) st = btc[(t - first) * S + st];
+            }
+            s_state[0] = st;
         }
     }
 }
@@ -790,20 +827,25 @@ int beer_hmm_viterbi(int dtype, const beer_batch* b, const void* pc_llhs, int32_
     BEER_REQUIRE(b && b->nutt >= 0 && b->max_states >= 1);
     if (b->nutt == 0) return BEER_OK;
     hipStream_t s = as_stream(stream);
+    // LDS: two trellis columns, a chunk of back-pointers and, when they fit, the arcs
+    const size_t elem = dtype == BEER_F32 ? sizeof(float) : sizeof(double);
+    const size_t base = (size_t)2 * b->max_states * elem +
+                        (size_t)kViterbiChunk * b->max_states * sizeof(int32_t);
+    const size_t arcs = ((size_t)b->max_states + 2 + b->max_arcs) * sizeof(int32_t) +
+                        (size_t)b->max_arcs * elem;
+    BEER_REQUIRE(base <= 160 * 1024);
+    const int arcs_in_lds = base + arcs <= 64 * 1024;
+    const size_t lds = base + (arcs_in_lds ? arcs : 0);
     if (dtype == BEER_F32) {
-        const size_t lds = (size_t)2 * b->max_states * sizeof(float);
-        BEER_REQUIRE(lds <= 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(viterbi_kernel<float>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(viterbi_kernel<float>, dim3(b->nutt), dim3(kHmmThreads), lds, s, *b,
-                           (const float*)pc_llhs, bt_ws, path, map_pdf);
+                           (const float*)pc_llhs, bt_ws, path, map_pdf, arcs_in_lds);
     } else if (dtype == BEER_F64) {
-        const size_t lds = (size_t)2 * b->max_states * sizeof(double);
-        BEER_REQUIRE(lds <= 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(viterbi_kernel<double>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(viterbi_kernel<double>, dim3(b->nutt), dim3(kHmmThreads), lds, s, *b,
-                           (const double*)pc_llhs, bt_ws, path, map_pdf);
+                           (const double*)pc_llhs, bt_ws, path, map_pdf, arcs_in_lds);
     } else {
         return BEER_EINVAL;
     }
