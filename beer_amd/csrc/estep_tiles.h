@@ -30,6 +30,10 @@ template <> struct Mma<float> {
         return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
     }
     static __device__ __forceinline__ float recip(float x) { return __builtin_amdgcn_rcpf(x); }
+    // log of a softmax denominator (a sum in [1, group size]): v_log_f32 (log2, 1 ulp)
+    static __device__ __forceinline__ float log_sum(float x) {
+        return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
+    }
 };
 template <> struct Mma<double> {
     using acc_t = f64x4;
@@ -40,6 +44,7 @@ template <> struct Mma<double> {
     static __device__ __forceinline__ int row(int g, int r) { return g + 4 * r; }
     static __device__ __forceinline__ double exp_neg(double x) { return exp(x); }
     static __device__ __forceinline__ double recip(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double log_sum(double x) { return log(x); }
 };
 
 // All-reduce across the 16 lanes that hold one row of a 16x16 C tile, with
@@ -223,7 +228,7 @@ __device__ __forceinline__ void softmax_epilogue(
                             sum += e[qq][j];
                         }
                     sum = group_sum(sum, gl);
-                    const T lse = mx + log(sum);
+                    const T lse = mx + M::log_sum(sum);
                     const T inv = M::recip(sum);
 #pragma unroll
                     for (int qq = 0; qq < GQ; ++qq)
@@ -242,7 +247,7 @@ __device__ __forceinline__ void softmax_epilogue(
                         if (jw == 2) {
                             const T mx = a0 > a1 ? a0 : a1;
                             const T e0 = M::exp_neg(a0 - mx), e1 = M::exp_neg(a1 - mx);
-                            const T lse = mx + log(e0 + e1);
+                            const T lse = mx + M::log_sum(e0 + e1);
                             e[0][j0] = e0 / (e0 + e1);
                             e[0][j0 + 1] = e1 / (e0 + e1);
                             const int state = (kq + j0) / G;
@@ -419,7 +424,7 @@ __device__ __forceinline__ void softmax_epilogue_pair(
             const float inv = M::recip(total);
             const int64_t f = fb + m * 16 + M::row(g, r);
             if ((wave & 1) == 0 && i == 0 && f < nframes) {
-                const float lse = mx[m][r] + log(total);
+                const float lse = mx[m][r] + M::log_sum(total);
                 if (log_norm) log_norm[f] = lse;
                 llh_local += (double)lse;
             }
