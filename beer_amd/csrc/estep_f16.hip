@@ -493,7 +493,7 @@ int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, in
 // ---------------------------------------------------------------------------
 constexpr int kA16Threads = 256;     // 4 waves, one per SIMD: 512 registers per lane
 constexpr int kA16MC = 8;            // component tiles per workgroup (128 components)
-constexpr int kA16MCsr = 4;          // ... when state responsibilities are multiplied in
+constexpr int kA16MCsr = 4;          // ... with state responsibilities AND 4 statistic tiles
 constexpr int kA16FT = 64;           // frames per LDS tile (2 k-steps)
 constexpr int kA16XS = kA16FT + 4;   // X^T row stride (floats), 16-byte aligned
 constexpr int kA16RS = kA16FT;       // R^T row = 8 chunks of 8 frames (16 B), chunk c of row
@@ -516,9 +516,9 @@ __global__ __launch_bounds__(kA16Threads, 1) void acc16_kernel(
     const float* __restrict__ R, const float* __restrict__ SR, const int* __restrict__ tab,
     const float* __restrict__ sc, int64_t frames_per_block, double* __restrict__ Sp, int gx,
     int gy, int gz) {
-    // with state responsibilities the staging registers double: half the component
-    // tile keeps the kernel free of spills
-    constexpr int MC = HAS_SR ? kA16MCsr : kA16MC;
+    // with state responsibilities the staging registers double: with 4 statistic
+    // tiles per wave only half the component tile keeps the kernel free of spills
+    constexpr int MC = HAS_SR && NQ > 2 ? kA16MCsr : kA16MC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1299,7 +1299,7 @@ int acc_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, con
     const int waves = kA16Threads / 64;
     const int NQ = ntiles > 2 * waves ? 4 : (ntiles > waves ? 2 : 1);
     const int gx = (ntiles + NQ * waves - 1) / (NQ * waves);
-    const int mc = SR ? kA16MCsr : kA16MC;
+    const int mc = SR && NQ > 2 ? kA16MCsr : kA16MC;
     const int gy = (K + 16 * mc - 1) / (16 * mc);
     int64_t gz = (1024 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy);
     const int64_t max_z = (nframes + 1023) / 1024, min_z = (nframes + kA16MaxFrames - 1) / kA16MaxFrames;
