@@ -280,7 +280,8 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     constexpr int FW = 16 * MT, NGRP = kThreads / 64 / KS;      // frame groups per workgroup
-    static_assert(KS == 1 || (KS == 2 && PACKED), "the component split writes packed tiles");
+    // KS = 2 without PACKED: mixture sets whose groups (G <= 128 components) lie
+    // inside one wave's half of the chunk -- no cross-wave softmax needed
     const int grp = wave / KS, part = wave % KS;
     float* xw = reinterpret_cast<float*>(smem) + grp * (FW * LD);
     int* tabs = reinterpret_cast<int*>(reinterpret_cast<float*>(smem) + NGRP * FW * LD);
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m][4 * q + j] *= inv[j];
     }
-    if constexpr (KS == 2) {
+    if constexpr (KS == 2 && PACKED) {
         float* xch = reinterpret_cast<float*>(tabs + (nk + 1) * 8);
         softmax_epilogue_pair<NT, MT>(acc, fb, nframes, kbase, K, i, g, lane, wave, xch, resps,
                                       log_norm, llh_sum);
@@ -1181,6 +1182,18 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
     const int jw = G < 4 ? G : 4;
     const int gl = G < 4 ? 1 : (G < 64 ? G / 4 : 16);
     const int gq = G <= 64 ? 1 : G / 64;
+    // Full covariance (a long parameter stream per frame tile): groups of at most
+    // 128 components fit one wave's half of a 256-component chunk, so the waves can
+    // split the components as in the packed kernel (half the stream per MFMA).
+    if (cov == BEER_FULL && G <= 128) {
+        if (gq == 1)
+            return launch_llh16<8, 4, 1, false, 2, false>(nframes, D, K, S, G, gl, jw, nchunks, nk,
+                                                          X, P, inv_scale, sc, tab, resps,
+                                                          log_norm, llh_sum, s);
+        return launch_llh16<8, 4, 2, false, 2, false>(nframes, D, K, S, G, gl, jw, nchunks, nk, X,
+                                                      P, inv_scale, sc, tab, resps, log_norm,
+                                                      llh_sum, s);
+    }
     switch (gq) {
         case 1: BEER_LLH16(16, 2, 1);
         case 2: BEER_LLH16(16, 2, 2);
