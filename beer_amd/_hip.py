@@ -125,6 +125,7 @@ SIGNATURES = {
                                   c_p],
     'beer_normal_accumulate_packed': [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_z, c_p],
     'beer_unpack_resps': [c_l, c_i, c_p, c_p, c_p],
+    'beer_pack_resps': [c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     'beer_weights_from_acc': [c_i, c_i, c_i, c_p, c_p, c_p],
     'beer_hmm_gather': [c_i, c_p, c_i, c_p, c_d, c_p, c_p],
     'beer_hmm_forward_backward': [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],

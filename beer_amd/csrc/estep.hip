@@ -563,6 +563,14 @@ size_t beer_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int K) 
     return beer_mfma::acc16p_workspace_bytes(cov, T, D, K);
 }
 
+int beer_pack_resps(int64_t T, int D, int S, int G, const float* X, const float* comp_resps,
+                    const float* state_resps, void* packed_resps, void* stream) {
+    BEER_REQUIRE(T >= 0 && D >= 1 && D <= 64 && S >= 1 && G >= 1 && (S * G) % 4 == 0);
+    BEER_REQUIRE(T == 0 || (X && comp_resps && packed_resps));
+    return beer_mfma::pack_resps(T, D, S, G, X, comp_resps, state_resps, packed_resps,
+                                 as_stream(stream));
+}
+
 int beer_unpack_resps(int64_t T, int K, const void* packed_resps, float* resps, void* stream) {
     BEER_REQUIRE(T >= 0 && K >= 1 && (T == 0 || (packed_resps && resps)));
     return beer_mfma::unpack_resps(T, K, packed_resps, resps, as_stream(stream));

@@ -1069,6 +1069,58 @@ __global__ void unpack_resps_kernel(int64_t nframes, int K, const unsigned* __re
     R[idx] = ((float)hi[f6 & 1] + (float)lo[f6 & 1]) * (1.f / (float)(1 << kRespBits));
 }
 
+// float32 responsibilities [T, K] (times state responsibilities [T, S]) -> packed
+// tiles: one workgroup per tile of 64 frames x 128 components, transposed through
+// LDS (rows of 129 words: conflict-free both ways), split, stored as whole
+// 16-byte chunks.  For accumulations that are far from the memory roofline with
+// float32 operands (full covariance: 4 statistic blocks re-read R) the 2 x 4 B
+// per element of this pass buy the packed kernel.
+__global__ __launch_bounds__(256) void pack_resps_kernel(int64_t nframes, int K, int S, int G,
+                                                         const float* __restrict__ R,
+                                                         const float* __restrict__ SR,
+                                                         unsigned* __restrict__ out) {
+    __shared__ float tile[kPackedFrames * 129];
+    const int64_t tau = blockIdx.x, t0 = tau * kPackedFrames;
+    const int beta = blockIdx.y, nblk = gridDim.y, kc0 = beta * kPackedComps;
+    const int rows = (int)(nframes - t0 < kPackedFrames ? nframes - t0 : kPackedFrames);
+    const float up = (float)(1 << kRespBits);
+    for (int e = threadIdx.x; e < kPackedFrames * (kPackedComps / 4); e += 256) {
+        const int f = e / (kPackedComps / 4), c4 = 4 * (e - f * (kPackedComps / 4)), k = kc0 + c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (f < rows && k < K) {                               // K % 4 == 0
+            v = *reinterpret_cast<const f32x4*>(R + (t0 + f) * K + k) * up;
+            if (SR) {
+                const float* sr = SR + (t0 + f) * S;
+                if ((G & 3) == 0) {
+                    v *= sr[k / G];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= sr[(k + j) / G];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[f * 129 + c4 + j] = v[j];
+    }
+    __syncthreads();
+    typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+    for (int e = threadIdx.x; e < kPackedComps * 8; e += 256) {
+        const int kk = e >> 3, c8 = e & 7;
+        f32x4 p0, p1;
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+            p0[i2] = tile[(8 * c8 + i2) * 129 + kk];
+            p1[i2] = tile[(8 * c8 + 4 + i2) * 129 + kk];
+        }
+        h8 hi, lo;
+        split8(p0, p1, hi, lo);
+        unsigned* dst = out + packed_word(tau, nblk, beta, kk, 8 * c8);
+        *reinterpret_cast<uint4_t*>(dst) = __builtin_bit_cast(uint4_t, hi);
+        *reinterpret_cast<uint4_t*>(dst + kPackedComps * kPackedFrames / 2) =
+            __builtin_bit_cast(uint4_t, lo);
+    }
+}
+
 inline int nt16_for(int S, int K) { return S > 1 ? 16 : (K <= 64 ? 4 : (K <= 128 ? 8 : 16)); }
 inline int nchunks16_for(int S, int K) { return S > 1 ? (K + 255) / 256 : 1; }
 size_t up256(size_t n) { return (n + 255) / 256 * 256; }
@@ -1104,6 +1156,30 @@ size_t packed_resps_bytes(int64_t nframes, int D, int K) {
     const int64_t tiles = (nframes + kPackedFrames - 1) / kPackedFrames;
     return kPackedHeader + packed_tiles_bytes(nframes, K) +
            (packed_has_xt(K) ? (size_t)tiles * xt_pieces(D) * kPiece : 0);
+}
+
+int pack_resps(int64_t nframes, int D, int S, int G, const float* X, const float* R,
+               const float* SR, void* packed, hipStream_t s) {
+    const int K = S * G;
+    if ((K & 3) || D < 1 || D > 64) return BEER_EINVAL;
+    if (nframes == 0) return BEER_OK;
+    // header: the frame scales (the absmax scratch borrows the first tile, which the
+    // pack kernel overwrites afterwards)
+    float* sc = reinterpret_cast<float*>(packed);
+    unsigned* tiles = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(packed) + kPackedHeader);
+    const int rc = launch_scales(X, nframes, D, tiles, sc, s);
+    if (rc != BEER_OK) return rc;
+    const int64_t ntile = (nframes + kPackedFrames - 1) / kPackedFrames;
+    const int nblk = (K + kPackedComps - 1) / kPackedComps;
+    hipLaunchKernelGGL(pack_resps_kernel, dim3((unsigned)ntile, (unsigned)nblk), dim3(256), 0, s,
+                       nframes, K, S, G, R, SR, tiles);
+    if (packed_has_xt(K))               // what the E-step kernel would have left behind
+        hipLaunchKernelGGL(xt_image_kernel, dim3((unsigned)ntile), dim3(256), 0, s, nframes, D,
+                           xt_pieces(D), X, sc,
+                           reinterpret_cast<float*>(reinterpret_cast<char*>(tiles) +
+                                                    packed_tiles_bytes(nframes, K)));
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
 }
 
 int unpack_resps(int64_t nframes, int K, const void* packed, float* resps, hipStream_t s) {

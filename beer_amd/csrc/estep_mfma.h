@@ -26,6 +26,9 @@ int estep_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const f
 // 1 in *hazard (device) when the split path would lose accuracy on these frames
 // (a dimension whose maximum is > 2^9 times its mean magnitude); scratch >= 768 B.
 int unpack_resps(int64_t T, int K, const void* packed, float* resps, hipStream_t s);
+// comp_resps [T, S*G] (x state_resps [T, S], nullable) -> packed tiles + scale header
+int pack_resps(int64_t T, int D, int S, int G, const float* X, const float* R, const float* SR,
+               void* packed, hipStream_t s);
 int f16_range_hazard(int64_t T, int D, const float* X, void* scratch, int* hazard,
                      hipStream_t s);
 size_t acc16_workspace_bytes(int cov, int D, int K);

@@ -264,6 +264,15 @@ int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float*
                                   const void* packed_resps, double* acc,
                                   void* workspace, size_t workspace_bytes,
                                   void* stream);
+/* The packed buffer from float32 responsibilities: comp_resps [T, S*G], times
+ * state_resps[t, k / G] when given (the joint responsibilities of
+ * MixtureSet.accumulate, mixtureset.py:100-112), split and tiled as above, with
+ * the frame scales of X in the header; (S*G) % 4 == 0.  Lets accumulations that
+ * re-read the responsibilities several times (full covariance) run on the packed
+ * kernel. */
+int beer_pack_resps(int64_t T, int D, int S, int G, const float* X,
+                    const float* comp_resps, const float* state_resps,
+                    void* packed_resps, void* stream);
 int beer_unpack_resps(int64_t T, int K, const void* packed_resps, float* resps,
                       void* stream);
 

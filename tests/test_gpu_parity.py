@@ -907,3 +907,34 @@ def test_packed_hand_over_random_shapes():
         assert e_p <= 4. * e_e + 2e-6, what
         assert l_p <= 4. * l_e + 1e-6 * float(ln64.abs().max()), what
         assert float((packed.unpack().double() - r64).abs().max()) < 1e-4, what
+
+
+@pytest.mark.parametrize('cov,S,G,D', [('full', 12, 16, 24), ('full', 5, 64, 30), ('full', 9, 12, 40),
+                                         ('diagonal', 30, 16, 40), ('full', 1, 200, 24)])
+def test_pack_resps_and_repacked_accumulation(cov, S, G, D):
+    '''beer_pack_resps: float32 component x state responsibilities into packed
+    tiles (unpacked they equal the product), and `normal_accumulate` on top of them
+    -- the route full-covariance accumulations of float32 responsibilities take --
+    against the fp64 kernels.'''
+    from beer_amd import kernels
+    torch.manual_seed(21)
+    T, K = 20011, S * G
+    X = torch.randn(T, D, dtype=torch.float64, device=DEV) * 1.5 + 1.
+    r = torch.rand(T, K, dtype=torch.float64, device=DEV)
+    r = r / r.sum(1, keepdim=True) * S
+    sr = torch.rand(T, S, dtype=torch.float64, device=DEV)
+    st64, st32 = beer.FrameStats(X, cov), beer.FrameStats(X.float(), cov)
+    acc64 = kernels.normal_accumulate(st64, r, sr, S, G, cov)
+    for state in (sr, None):
+        packed = kernels.pack_resps(st32, r.float(), None if state is None else state.float(), S, G)
+        want = r.float() * (1. if state is None else state.float().repeat_interleave(G, dim=1))
+        torch.testing.assert_close(packed.unpack(), want, rtol=2e-6, atol=1e-9)
+    packed = kernels.pack_resps(st32, r.float(), sr.float(), S, G)
+    acc_p = kernels.normal_accumulate(st32, packed, None, S, G, cov)
+    assert float((acc_p - acc64).abs().max() / acc64.abs().max()) <= 2e-6
+    # what normal_accumulate itself does with float32 operands (repacks when it pays)
+    acc32 = kernels.normal_accumulate(st32, r.float(), sr.float(), S, G, cov)
+    assert float((acc32 - acc64).abs().max() / acc64.abs().max()) <= 2e-6
+    if cov == 'full' and D * D + D + 2 > 512:
+        assert kernels._repack_pays(st32, K, cov)
+        torch.testing.assert_close(acc32, acc_p, rtol=0, atol=1e-9 * float(acc_p.abs().max()))
