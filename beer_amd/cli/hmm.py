@@ -43,8 +43,11 @@ def _cpu_elbo(elbo):
     'ELBO object with every tensor on the host (portable pickle).'
     acc = {p: s.cpu() for p, s in elbo._acc_stats.items()}
     value = elbo.value.cpu() if isinstance(elbo.value, torch.Tensor) else elbo.value
-    return beer.EvidenceLowerBoundInstance(value, acc, elbo._model_parameters,
-                                           elbo._minibatchsize, elbo._datasize)
+    mbsize = elbo._minibatchsize
+    if isinstance(mbsize, torch.Tensor):                  # after an RCCL all-reduce
+        mbsize = int(round(float(mbsize)))
+    return beer.EvidenceLowerBoundInstance(value, acc, elbo._model_parameters, mbsize,
+                                           elbo._datasize)
 
 
 def parse_topology(topology):

@@ -39,9 +39,14 @@ def shard_utterances(lengths, world_size, rank):
 def flatten_elbo(elbo, params, n_utts, device):
     '''[value, minibatchsize, n_utts, stats of params[0], stats of params[1], ...]
     as one fp64 vector.  Missing statistics count as zeros.'''
+    # (counts go in by fill kernels: a tensor built from Python numbers would be a
+    # copy from pageable memory, which makes the host wait for the stream)
+    def count(v):
+        if isinstance(v, torch.Tensor):
+            return v.to(device=device, dtype=torch.float64).reshape(1)
+        return torch.full((1,), float(v), dtype=torch.float64, device=device)
     parts = [torch.as_tensor(elbo.value, dtype=torch.float64, device=device).reshape(1),
-             torch.tensor([float(elbo._minibatchsize), float(n_utts)], dtype=torch.float64,
-                          device=device)]
+             count(elbo._minibatchsize), count(n_utts)]
     for p in params:
         s = elbo._acc_stats.get(p)
         if s is None:
@@ -52,7 +57,12 @@ def flatten_elbo(elbo, params, n_utts, device):
 
 def unflatten_elbo(flat, params, datasize):
     value = flat[0].clone()
-    mbsize, n_utts = int(round(float(flat[1]))), int(round(float(flat[2])))
+    if flat.is_cuda:
+        # stay on the device: reading the counts back would stall the host until
+        # the collective is over, and with it the queueing of the M-step
+        mbsize, n_utts = flat[1], flat[2]
+    else:
+        mbsize, n_utts = int(round(float(flat[1]))), int(round(float(flat[2])))
     acc, first = {}, 3
     for p in params:
         n = p.stats.numel()
@@ -65,7 +75,9 @@ def unflatten_elbo(flat, params, datasize):
 def all_reduce_elbo(elbo, model, n_utts=0, group=None):
     '''Sum the ELBO objects of every rank.  Returns (global elbo, global
     utterance count).  With no initialised process group this is the
-    identity (single GPU).'''
+    identity (single GPU).  Over RCCL the counts (minibatch size of the returned
+    ELBO, utterance count) are 0-dim device tensors -- no host synchronisation
+    between the E-step and the M-step; `int(...)` them where a number is needed.'''
     params = list(model.bayesian_parameters())
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return elbo, n_utts

@@ -938,3 +938,36 @@ def test_pack_resps_and_repacked_accumulation(cov, S, G, D):
     if cov == 'full' and D * D + D + 2 > 512:
         assert kernels._repack_pays(st32, K, cov)
         torch.testing.assert_close(acc32, acc_p, rtol=0, atol=1e-9 * float(acc_p.abs().max()))
+
+
+def test_elbo_round_trip_through_the_flat_device_buffer():
+    '''What an RCCL all-reduce does to an ELBO object, minus the collective:
+    flatten on the device, unflatten (the counts stay 0-dim device tensors: no
+    host synchronisation), M-step -- same posterior as without the round trip.'''
+    from beer_amd.distributed import flatten_elbo, unflatten_elbo
+    g = load_golden('g02_gmm_full')
+    X = tt(g['X'])
+    posts = []
+    for roundtrip in (False, True):
+        model = build_mixture(g)
+        optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.)
+        optim.init_step()
+        elbo = beer.evidence_lower_bound(model, X)
+        if roundtrip:
+            params = list(model.bayesian_parameters())
+            flat = flatten_elbo(elbo, params, 3, X.device)
+            elbo2, n = unflatten_elbo(flat, params, elbo._datasize)
+            assert isinstance(n, torch.Tensor) and int(n) == 3
+            assert isinstance(elbo2._minibatchsize, torch.Tensor)
+            assert abs(float(elbo2) - float(elbo)) <= 1e-12 * abs(float(elbo))
+            # a second trip carries the tensor counts
+            flat2 = flatten_elbo(elbo2, params, n, X.device)
+            torch.testing.assert_close(flat2, flat, rtol=0, atol=0)
+            elbo = elbo2
+        elbo.backward()
+        optim.step()
+        p0, p1 = params_of(model)
+        posts.append([npy(getattr(p0.posterior.params, n_)) for n_ in p0.posterior._std_params_def] +
+                     [npy(p1.posterior.params.concentrations)])
+    for a, b in zip(*posts):
+        assert_close(a, b, 1e-12)
