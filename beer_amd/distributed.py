@@ -8,7 +8,7 @@ update.py:41-62).  Here the `+` is a single `all_reduce(SUM)` (RCCL over xGMI
 on a GPU node, gloo on CPU for the tests) over one flat fp64 buffer holding
 every parameter's accumulated statistics, the ELBO value and the frame /
 utterance counts; every rank then applies the identical M-step to identical
-inputs (no broadcast needed).  The message is small (1.7 MB fp64 at K = 256,
+inputs (no broadcast needed).  The message is small (3.4 MB fp64 at K = 256,
 D = 40 full covariance), so the exchange is latency-bound: what matters is
 doing exactly one collective, not one per parameter.
 """
