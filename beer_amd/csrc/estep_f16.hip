@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
                 } else if (row == D) {
                     v = f32x4{1.f, 1.f, 1.f, 1.f};
                 }
-                *reinterpret_cast<f32x4*>(img + 4 * e4) = v;
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(img + 4 * e4));
             }
         }
     }

@@ -283,8 +283,10 @@ __device__ __forceinline__ void softmax_epilogue(
                         const int k = kq + 64 * qq;
                         T* dst = resps + f * K + k;
                         if (vec_ok && k + 3 < K) {
-                            *reinterpret_cast<vec4_t*>(dst) =
-                                vec4_t{e[qq][0], e[qq][1], e[qq][2], e[qq][3]};
+                            // (streamed: written once, read once by the accumulation)
+                            __builtin_nontemporal_store(
+                                vec4_t{e[qq][0], e[qq][1], e[qq][2], e[qq][3]},
+                                reinterpret_cast<vec4_t*>(dst));
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
@@ -345,8 +347,10 @@ __device__ __forceinline__ void softmax_epilogue(
             if (chunk_ok && k < nblk * kPackedComps) {
                 unsigned int* dst = out + packed_word(tau, nblk, k / kPackedComps,
                                                       k & (kPackedComps - 1), f6);
-                *reinterpret_cast<uint4_t*>(dst) = ch;
-                *reinterpret_cast<uint4_t*>(dst + kPackedComps * kPackedFrames / 2) = cl;
+                // non-temporal: 1 GB streamed once; keeps the packed parameters in L2
+                __builtin_nontemporal_store(ch, reinterpret_cast<uint4_t*>(dst));
+                __builtin_nontemporal_store(
+                    cl, reinterpret_cast<uint4_t*>(dst + kPackedComps * kPackedFrames / 2));
             }
         }
     }
@@ -476,8 +480,9 @@ __device__ __forceinline__ void softmax_epilogue_pair(
             if (chunk_ok && k < nblk * kPackedComps) {
                 unsigned int* dst = out + packed_word(tau, nblk, k / kPackedComps,
                                                       k & (kPackedComps - 1), f6);
-                *reinterpret_cast<uint4_t*>(dst) = ch;
-                *reinterpret_cast<uint4_t*>(dst + kPackedComps * kPackedFrames / 2) = cl;
+                __builtin_nontemporal_store(ch, reinterpret_cast<uint4_t*>(dst));
+                __builtin_nontemporal_store(
+                    cl, reinterpret_cast<uint4_t*>(dst + kPackedComps * kPackedFrames / 2));
             }
         }
     }
