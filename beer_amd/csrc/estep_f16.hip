@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(256) void pack_resps_kernel(int64_t nframes, int K,
         const int f = e / (kPackedComps / 4), c4 = 4 * (e - f * (kPackedComps / 4)), k = kc0 + c4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (f < rows && k < K) {                               // K % 4 == 0
-            v = *reinterpret_cast<const f32x4*>(R + (t0 + f) * K + k) * up;
+            v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(R + (t0 + f) * K + k)) * up;
             if (SR) {
                 const float* sr = SR + (t0 + f) * S;
                 if ((G & 3) == 0) {
@@ -1115,9 +1115,10 @@ __global__ __launch_bounds__(256) void pack_resps_kernel(int64_t nframes, int K,
         h8 hi, lo;
         split8(p0, p1, hi, lo);
         unsigned* dst = out + packed_word(tau, nblk, beta, kk, 8 * c8);
-        *reinterpret_cast<uint4_t*>(dst) = __builtin_bit_cast(uint4_t, hi);
-        *reinterpret_cast<uint4_t*>(dst + kPackedComps * kPackedFrames / 2) =
-            __builtin_bit_cast(uint4_t, lo);
+        __builtin_nontemporal_store(__builtin_bit_cast(uint4_t, hi), reinterpret_cast<uint4_t*>(dst));
+        __builtin_nontemporal_store(
+            __builtin_bit_cast(uint4_t, lo),
+            reinterpret_cast<uint4_t*>(dst + kPackedComps * kPackedFrames / 2));
     }
 }
 
