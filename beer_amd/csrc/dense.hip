@@ -164,7 +164,7 @@ __global__ void suffstats_mean_kernel(int cov, int64_t T_, int ns, int D,
                 for (int d = 0; d < D; ++d) v += (double)x[s * D + d] * (double)x[s * D + d];
             v *= -0.5 * inv;
         }
-        out[idx] = (T)v;
+        __builtin_nontemporal_store((T)v, out + idx);
     }
 }
 

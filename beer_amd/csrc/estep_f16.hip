@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256) void xt_image_kernel(int64_t nframes, int D, i
         float v = 0.f;
         if (row < D) v = col < rows ? tile[col * 65 + row] * scale[row] : 0.f;
         else if (row == D) v = 1.f;
-        out[e] = v;
+        __builtin_nontemporal_store(v, out + e);
     }
 }
 
