@@ -54,21 +54,86 @@ __device__ inline double digamma(double x) {
     return r + log(x) - 0.5 / x + t;
 }
 
-// Wave (64 lanes) reductions.
+// Wave (64 lanes) all-reductions without the LDS crossbar (__shfl_xor is a
+// ds_bpermute per 32-bit word and step: 12 dependent LDS round trips for one fp64
+// reduction, which sat on the critical path of every forward-backward step):
+// inside a row of 16 lanes by DPP (xor 1, xor 2, half-row mirror, row mirror),
+// between the 4 rows by gfx950's v_permlane16_swap / v_permlane32_swap.
+namespace wave_detail {
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_word(unsigned w) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, CTRL, 0xf, 0xf, true);
+}
+template <typename T> struct Words;
+template <> struct Words<float> {
+    static constexpr int N = 1;
+    static __device__ __forceinline__ void split(float v, unsigned (&w)[2]) {
+        w[0] = __builtin_bit_cast(unsigned, v);
+    }
+    static __device__ __forceinline__ float join(const unsigned (&w)[2]) {
+        return __builtin_bit_cast(float, w[0]);
+    }
+};
+template <> struct Words<double> {
+    static constexpr int N = 2;
+    static __device__ __forceinline__ void split(double v, unsigned (&w)[2]) {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+        w[0] = (unsigned)b;
+        w[1] = (unsigned)(b >> 32);
+    }
+    static __device__ __forceinline__ double join(const unsigned (&w)[2]) {
+        return __builtin_bit_cast(double, ((unsigned long long)w[1] << 32) | w[0]);
+    }
+};
+template <typename T, int CTRL>
+__device__ __forceinline__ T dpp(T v) {
+    unsigned w[2];
+    Words<T>::split(v, w);
+#pragma unroll
+    for (int i = 0; i < Words<T>::N; ++i) w[i] = dpp_word<CTRL>(w[i]);
+    return Words<T>::join(w);
+}
+// the two operands of the next combining step across rows: with both inputs equal
+// to v, the swap leaves a = (rows 0,0,2,2), b = (rows 1,1,3,3) [16] resp.
+// a = lower half everywhere, b = upper half everywhere [32]
+template <typename T, bool HALVES>
+__device__ __forceinline__ void cross(T v, T& a, T& b) {
+    unsigned w[2], wa[2], wb[2];
+    Words<T>::split(v, w);
+#pragma unroll
+    for (int i = 0; i < Words<T>::N; ++i) {
+        if (HALVES) {
+            const auto r = __builtin_amdgcn_permlane32_swap(w[i], w[i], false, false);
+            wa[i] = r[0]; wb[i] = r[1];
+        } else {
+            const auto r = __builtin_amdgcn_permlane16_swap(w[i], w[i], false, false);
+            wa[i] = r[0]; wb[i] = r[1];
+        }
+    }
+    a = Words<T>::join(wa);
+    b = Words<T>::join(wb);
+}
+template <typename T, typename Op>
+__device__ __forceinline__ T allreduce(T v, Op op) {
+    v = op(v, dpp<T, 0xB1>(v));          // quad_perm [1,0,3,2]
+    v = op(v, dpp<T, 0x4E>(v));          // quad_perm [2,3,0,1]
+    v = op(v, dpp<T, 0x141>(v));         // row_half_mirror
+    v = op(v, dpp<T, 0x140>(v));         // row_mirror
+    T a, b;
+    cross<T, false>(v, a, b);
+    v = op(a, b);
+    cross<T, true>(v, a, b);
+    return op(a, b);
+}
+}  // namespace wave_detail
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return wave_detail::allreduce(v, [](T x, T y) { return x + y; });
 }
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        T w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
-    }
-    return v;
+    return wave_detail::allreduce(v, [](T x, T y) { return y > x ? y : x; });
 }
 
 // Block reductions through LDS scratch of >= blockDim/64 elements.  All

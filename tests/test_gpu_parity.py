@@ -641,9 +641,11 @@ def test_sparse_alignment_graphs_equal_dense_graphs():
     dense = [g.to_dense() for g in sparse]
     a = beer.accumulate_elbo(ploop, (X, lengths), datasize=1000, inference_graphs=dense)
     b = beer.accumulate_elbo(ploop, (X, lengths), datasize=1000, inference_graphs=sparse)
-    assert float(a) == float(b)
+    # (fp64 atomics of per-block partial sums: equal up to their order)
+    assert abs(float(a) - float(b)) <= 1e-13 * abs(float(a))
     for p in params_of(ploop):
-        np.testing.assert_array_equal(npy(a._acc_stats[p]), npy(b._acc_stats[p]))
+        np.testing.assert_allclose(npy(a._acc_stats[p]), npy(b._acc_stats[p]), rtol=1e-12,
+                                   atol=1e-12 * float(np.abs(npy(b._acc_stats[p])).max()))
     pa = beer.decode_batch(ploop, (X, lengths), inference_graphs=dense)
     pb = beer.decode_batch(ploop, (X, lengths), inference_graphs=sparse)
     for x, y in zip(pa, pb):
@@ -652,7 +654,7 @@ def test_sparse_alignment_graphs_equal_dense_graphs():
     u0 = X[:lengths[0]]
     e1 = beer.evidence_lower_bound(ploop, u0, datasize=1000, inference_graph=dense[0])
     e2 = beer.evidence_lower_bound(ploop, u0, datasize=1000, inference_graph=sparse[0])
-    assert float(e1) == float(e2)
+    assert abs(float(e1) - float(e2)) <= 1e-13 * abs(float(e1))
 
 
 # --- float32 models: exact fp32 MFMA vs the fp16-split matrix path ------------------------------------
