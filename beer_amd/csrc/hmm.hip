@@ -429,6 +429,10 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
         xi_r[k] = 0.0;
     }
     double flow_r = 0.0;                                  // hub -> this state
+    // largest in / out degree of the graph: the arc loops below stop there (a
+    // workgroup-uniform bound: phone-loop states have 2-3 of the BEER_SEG slots in use)
+    const int kin = (int)block_max((double)(in_end - in_beg), hub);
+    const int kout = (int)block_max((double)(out_end - out_beg), hub);
 
     // wave 0: log-sum-exp over the members of every hub
     // (vals[] are read from LDS `cur` or `lb` + per-member weight)
@@ -472,15 +476,18 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
         if (wave == 0 && H > 0) hub_lse(cur, L.src_ptr, L.src_list, hsw);
         double m = NINF, sm = 0.0;
         if (st) {
+            // (absent arcs have weight -inf: their term is exp(-inf) = 0, no branch)
+            double val[BEER_SEG];
 #pragma unroll
-            for (int k = 0; k < BEER_SEG; ++k) {
-                const double val = cur[isrc[k]] + iw[k];
-                m = val > m ? val : m;
-            }
+            for (int k = 0; k < BEER_SEG; ++k)
+                if (k < kin) {
+                    val[k] = cur[isrc[k]] + iw[k];
+                    m = val[k] > m ? val[k] : m;
+                }
             if (m > NINF && m < PINF) {
 #pragma unroll
                 for (int k = 0; k < BEER_SEG; ++k)
-                    if (iw[k] > NINF) sm += fexp<T>(cur[isrc[k]] + iw[k] - m);
+                    if (k < kin) sm += fexp<T>(val[k] - m);
             }
         }
         __syncthreads();                                  // hub values visible; cur fully read
@@ -518,15 +525,17 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
             if (wave == 0 && H > 0) hub_lse(lb, L.dst_ptr, L.dst_list, hdw);
             double m = NINF, sm = 0.0;
             if (st) {
+                double val[BEER_SEG];
 #pragma unroll
-                for (int k = 0; k < BEER_SEG; ++k) {
-                    const double val = ow[k] + lb[odst[k]];
-                    m = val > m ? val : m;
-                }
+                for (int k = 0; k < BEER_SEG; ++k)
+                    if (k < kout) {
+                        val[k] = ow[k] + lb[odst[k]];
+                        m = val[k] > m ? val[k] : m;
+                    }
                 if (m > NINF && m < PINF) {
 #pragma unroll
                     for (int k = 0; k < BEER_SEG; ++k)
-                        if (ow[k] > NINF) sm += fexp<T>(ow[k] + lb[odst[k]] - m);
+                        if (k < kout) sm += fexp<T>(val[k] - m);
                 }
             }
             __syncthreads();
@@ -590,7 +599,7 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
                 const double ai = a_cur - lognorm;
 #pragma unroll
                 for (int k = 0; k < BEER_SEG; ++k) {
-                    if (ow[k] > NINF) {
+                    if (k < kout && ow[k] > NINF) {
                         const double val = fexp<T>(ai + ow[k] + lb[odst[k]]);
                         if (val == val) xi_r[k] += val;
                     }
