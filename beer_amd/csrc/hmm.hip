@@ -366,6 +366,7 @@ __global__ __launch_bounds__(kFbThreads) void fb_kernel(
 // ---------------------------------------------------------------------------
 constexpr int kLdThreads = 512;     // one state per thread: graphs up to 512 states
 constexpr int kMaxHubs = 4;
+constexpr int kRegHubs = 1;         // hubs whose member lists are cached in registers
 
 template <typename T>
 __device__ __forceinline__ double logaddexp2(double a, double b) {
@@ -434,10 +435,54 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
     const int kin = (int)block_max((double)(in_end - in_beg), hub);
     const int kout = (int)block_max((double)(out_end - out_beg), hub);
 
+    // Members of the hub (phone-loop pivot: a few dozen sources / destinations) in
+    // registers, one per lane: the lists and weights do not change over the frames,
+    // and re-reading them from global memory put three dependent loads into every
+    // step of the chain.  (`fits` false: more than kRegHubs hubs or more than 64
+    // members -- the loops over the lists below.)
+    int hm_src[kRegHubs], hm_dst[kRegHubs];
+    T hw_src[kRegHubs], hw_dst[kRegHubs];          // (converted at use, as the loops do)
+    bool fits = H <= kRegHubs;
+#pragma unroll
+    for (int h = 0; h < kRegHubs; ++h) {
+        hm_src[h] = hm_dst[h] = -1;
+        hw_src[h] = hw_dst[h] = ninf<T>();
+        if (h < H) {
+            const int sb = L.src_ptr[h], se = L.src_ptr[h + 1];
+            const int db = L.dst_ptr[h], de = L.dst_ptr[h + 1];
+            fits = fits && se - sb <= 64 && de - db <= 64;
+            if (sb + lane < se) {
+                hm_src[h] = L.src_list[sb + lane];
+                hw_src[h] = hsw[hm_src[h]];
+            }
+            if (db + lane < de) {
+                hm_dst[h] = L.dst_list[db + lane];
+                hw_dst[h] = hdw[hm_dst[h]];
+            }
+        }
+    }
+    // log-sum-exp over the members of a hub held in registers: col[member] + weight
+    auto hub_lse_reg = [&](const double* col, int member, T weight) {
+        const double val = member >= 0 ? col[member] + (double)weight : NINF;
+        const double m = wave_max(val);
+        double r = m;
+        if (m > NINF && m < PINF) r = m + flog<T>(wave_sum(fexp<T>(val - m)));
+        return r;
+    };
+
     // wave 0: log-sum-exp over the members of every hub
     // (vals[] are read from LDS `cur` or `lb` + per-member weight)
     auto hub_lse = [&](const double* col, const int32_t* ptr, const int32_t* list,
-                       const T* w) {
+                       const T* w, const int (&hm)[kRegHubs], const T (&hw)[kRegHubs]) {
+        if (fits) {
+#pragma unroll
+            for (int h = 0; h < kRegHubs; ++h)
+                if (h < H) {
+                    const double r = hub_lse_reg(col, hm[h], hw[h]);
+                    if (lane == 0) hub[h] = r;
+                }
+            return;
+        }
         for (int h = 0; h < H; ++h) {
             const int beg = ptr[h], end = ptr[h + 1];
             double m = NINF;
@@ -473,7 +518,7 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
     for (int64_t t = 1; t < T_; ++t) {
         const double ll = ll_next;
         if (st && t + 1 < T_) ll_next = (double)llh[(t + 1) * S + j];
-        if (wave == 0 && H > 0) hub_lse(cur, L.src_ptr, L.src_list, hsw);
+        if (wave == 0 && H > 0) hub_lse(cur, L.src_ptr, L.src_list, hsw, hm_src, hw_src);
         double m = NINF, sm = 0.0;
         if (st) {
             // (absent arcs have weight -inf: their term is exp(-inf) = 0, no branch)
@@ -522,7 +567,7 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
         if (!inner) __syncthreads();                      // al visible (else: the barriers below)
         if (inner) {
             // beta_t(i) = lse(sparse: A_ij + lb_j ; hub: r_i + lse_s(w_s + lb_s))
-            if (wave == 0 && H > 0) hub_lse(lb, L.dst_ptr, L.dst_list, hdw);
+            if (wave == 0 && H > 0) hub_lse(lb, L.dst_ptr, L.dst_list, hdw, hm_dst, hw_dst);
             double m = NINF, sm = 0.0;
             if (st) {
                 double val[BEER_SEG];
@@ -564,6 +609,13 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
                 r = m + flog<T>(sm);
             }
             if (lane == 0) hub[kMaxHubs] = r;
+        } else if (wave == 1 && inner && xi_sum && H > 0 && fits) {
+#pragma unroll
+            for (int h = 0; h < kRegHubs; ++h)
+                if (h < H) {
+                    const double r = hub_lse_reg(al, hm_src[h], hw_src[h]);
+                    if (lane == 0) hub[kMaxHubs + 1 + h] = r;
+                }
         } else if (wave == 1 && inner && xi_sum && H > 0) {
             for (int h = 0; h < H; ++h) {
                 const int beg = L.src_ptr[h], end = L.src_ptr[h + 1];
