@@ -685,8 +685,10 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
 // time (one coalesced load per chunk instead of one dependent load per frame).
 constexpr int kViterbiChunk = 32;
 
+constexpr int kViterbiThreads = 512;
+
 template <typename T>
-__global__ __launch_bounds__(kHmmThreads) void viterbi_kernel(
+__global__ __launch_bounds__(kViterbiThreads) void viterbi_kernel(
     beer_batch b, const T* __restrict__ pc_llhs, int32_t* __restrict__ bt_ws,
     int64_t* __restrict__ path, int map_pdf, int arcs_in_lds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -719,9 +721,48 @@ __global__ __launch_bounds__(kHmmThreads) void viterbi_kernel(
     __syncthreads();
     // (one state per thread in the common case: the prefetch register is per thread)
     const bool one = S <= nt_;
-    T ll_next = one && tid < S && T_ > 1 ? llh[S + tid] : (T)0;
+    // Four lanes per state when the workgroup has them: the in-arcs of a state are
+    // dealt to the lanes of a quad and the four (best, source) pairs combined by DPP
+    // -- larger value, on ties the smaller source index: the first maximum in source
+    // order, as one lane scanning the whole list finds it.  A phone-loop state that
+    // follows the pivot has an arc from every phone (40 here) while most have 2: the
+    // longest list sets the time of the step.
+    const bool quad = 4 * S <= nt_;
+    const int qj = tid >> 2, qp = tid & 3;
+    T ll_next = (T)0;
+    if (quad) { if (qj < S && T_ > 1) ll_next = llh[S + qj]; }
+    else if (one && tid < S && T_ > 1) ll_next = llh[S + tid];
     for (int64_t t = 1; t < T_; ++t) {
         const T ll_cur = ll_next;
+        if (quad) {
+            if (qj < S && t + 1 < T_) ll_next = llh[(t + 1) * S + qj];
+            T best = ninf<T>();
+            int arg = 0;
+            if (qj < S) {
+                for (int e = in_ptr[qj] + qp; e < in_ptr[qj + 1]; e += 4) {
+                    const int src = in_src[e];
+                    const T v = cur[src] + in_w[e];
+                    if (v > best) { best = v; arg = src; }
+                }
+            }
+            {
+                const T ob = wave_detail::dpp<T, 0xB1>(best);
+                const int oa = (int)wave_detail::dpp_word<0xB1>((unsigned)arg);
+                if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+            }
+            {
+                const T ob = wave_detail::dpp<T, 0x4E>(best);
+                const int oa = (int)wave_detail::dpp_word<0x4E>((unsigned)arg);
+                if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+            }
+            if (qj < S && qp == 0) {
+                bt[t * S + qj] = arg;
+                nxt[qj] = ll_cur + best;
+            }
+            __syncthreads();
+            T* tmp = cur; cur = nxt; nxt = tmp;
+            continue;
+        }
         if (one && tid < S && t + 1 < T_) ll_next = llh[(t + 1) * S + tid];
         for (int j = tid; j < S; j += nt_) {
             // argmax_i(omega_i + A_ij): first index wins; all -inf -> 0
@@ -897,15 +938,17 @@ int beer_hmm_viterbi(int dtype, const beer_batch* b, const void* pc_llhs, int32_
     BEER_REQUIRE(base <= 160 * 1024);
     const int arcs_in_lds = base + arcs <= 64 * 1024;
     const size_t lds = base + (arcs_in_lds ? arcs : 0);
+    // four lanes per state when 512 threads suffice for that, else 256 threads
+    const int vthreads = 4 * b->max_states <= kViterbiThreads ? kViterbiThreads : kHmmThreads;
     if (dtype == BEER_F32) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(viterbi_kernel<float>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(viterbi_kernel<float>, dim3(b->nutt), dim3(kHmmThreads), lds, s, *b,
+        hipLaunchKernelGGL(viterbi_kernel<float>, dim3(b->nutt), dim3(vthreads), lds, s, *b,
                            (const float*)pc_llhs, bt_ws, path, map_pdf, arcs_in_lds);
     } else if (dtype == BEER_F64) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(viterbi_kernel<double>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(viterbi_kernel<double>, dim3(b->nutt), dim3(kHmmThreads), lds, s, *b,
+        hipLaunchKernelGGL(viterbi_kernel<double>, dim3(b->nutt), dim3(vthreads), lds, s, *b,
                            (const double*)pc_llhs, bt_ws, path, map_pdf, arcs_in_lds);
     } else {
         return BEER_EINVAL;
