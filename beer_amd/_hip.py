@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libbeer_hip.so')
+# BEER_HIP_LIB: another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get('BEER_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libbeer_hip.so')
 
 F32, F64, I16 = 0, 1, 2
 FULL, DIAG, ISO = 0, 1, 2
@@ -77,7 +78,9 @@ class Batch(ctypes.Structure):
                 ('max_arcs', ctypes.c_int32), ('max_segs', ctypes.c_int32),
                 ('all_lowdeg', ctypes.c_int32), ('n_graphs', ctypes.c_int32),
                 ('frame_off', c_p), ('llh_off', c_p), ('graph_id', c_p),
-                ('graphs', c_p), ('pdf_off', c_p), ('pdf_ids', c_p)]
+                ('graphs', c_p), ('pdf_off', c_p), ('pdf_ids', c_p),
+                ('max_degree', ctypes.c_int32), ('max_hubs', ctypes.c_int32),
+                ('max_hub_members', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 class FeaConf(ctypes.Structure):
@@ -128,7 +131,9 @@ SIGNATURES = {
     'beer_pack_resps': [c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     'beer_weights_from_acc': [c_i, c_i, c_i, c_p, c_p, c_p],
     'beer_hmm_gather': [c_i, c_p, c_i, c_p, c_d, c_p, c_p],
-    'beer_hmm_forward_backward': [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'beer_hmm_forward_backward': [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'beer_hmm_posteriors_fused': [c_i, c_p, c_i, c_p, c_d, c_p, c_p, c_p, c_i, c_p, c_p, c_p,
+                                  c_p],
     'beer_hmm_viterbi': [c_i, c_p, c_p, c_p, c_p, c_i, c_p],
     'beer_hmm_path_posteriors': [c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     'beer_hmm_scatter': [c_i, c_p, c_i, c_p, c_p, c_d, c_p, c_p, c_p, c_p],
@@ -154,8 +159,6 @@ SIGNATURES = {
 # host-side functions (graph compilation): host pointers, no stream
 c_pp = ctypes.POINTER(ctypes.c_void_p)
 HOST_SIGNATURES = {
-    'beer_hip_set_f32_mode': [c_i],
-    'beer_hip_get_f32_mode': [],
     'beer_graph_compile': [ctypes.c_int32, c_p, c_l, c_p, c_p, c_p, ctypes.c_int32,
                            ctypes.c_int32, c_pp],
     'beer_aligraphs_compile': [ctypes.c_int32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l,
@@ -191,9 +194,11 @@ def _declare(l):
         fn.restype = c_z
 
 
-def dtype_code(dtype):
+def dtype_code(dtype, exact=False):
+    '''BEER_F32 / BEER_F64 of a torch dtype; `exact` adds BEER_EXACT (float32
+    products on the exact fp32 MFMA instead of the split-fp16 arithmetic).'''
     if dtype == torch.float32:
-        return F32
+        return F32 | EXACT if exact else F32
     if dtype == torch.float64:
         return F64
     raise TypeError(f'beer_amd kernels take float32 or float64 tensors, got {dtype}')
@@ -234,48 +239,66 @@ def call(name, *args):
         raise HipError(f'{name} failed: {what}')
 
 
-F32_MODES = {'exact': 0, 'split_f16': 1}
+EXACT = 0x10                # BEER_EXACT of include/beer_hip.h: `dtype | EXACT`
+F32_MODES = ('exact', 'split_f16')
+# Host-side policy (the library itself keeps no mode: the arithmetic is an
+# argument of every call): initial value from BEER_F32_MODE=exact | split_f16.
+_f32_mode = ['exact' if os.environ.get('BEER_F32_MODE') in ('exact', 'f32') else 'split_f16']
 
 
 def set_f32_mode(mode):
     '''How float32 models multiply on the matrix cores: 'exact' (fp32 MFMA,
     bitwise an fmaf chain) or 'split_f16' (default: two fp16 halves per
     operand, three fp16 MFMAs per product, fp32 accumulation; 5x the rate).'''
-    rc = lib().beer_hip_set_f32_mode(F32_MODES[mode])
-    if rc != 0:
-        raise HipError('beer_hip_set_f32_mode failed')
+    if mode not in F32_MODES:
+        raise ValueError(f'f32 mode {mode!r}: expected one of {F32_MODES}')
+    _f32_mode[0] = mode
 
 
 def get_f32_mode():
-    code = lib().beer_hip_get_f32_mode()
-    return {v: k for k, v in F32_MODES.items()}[code]
+    return _f32_mode[0]
 
 
 # frames smaller than this always take the exact fp32 path (it costs microseconds
 # there, and the range check below would cost a synchronisation per utterance)
 SPLIT_MIN_FRAMES = 16384
-_range_memo = {}
+
+
+def _range_owner(X):
+    '''The tensor object the range verdicts of `X` live on: its base when `X` is
+    a view (a slice of a resident shard), so that every sub-batch of one shard
+    shares one memo, and the memo dies with the data.'''
+    base = X._base
+    return X if base is None else base
 
 
 def f32_split_ok(X):
     '''True when float32 frames `X` [T, D] may take the fp16-split matrix path:
     the mode is on, there are enough frames, and no dimension has outliers more
-    than 2^9 times its mean magnitude (checked once per tensor version on the
-    GPU; one small synchronisation the first time a tensor is seen).'''
+    than 2^9 times its mean magnitude (checked on the GPU, one small
+    synchronisation the first time a tensor is seen).  The verdict is remembered
+    ON the tensor (its base for views) together with the version counter -- never
+    by address: a new minibatch that the allocator places where an old one lived
+    is a new object and is checked again.'''
     if X.dtype != torch.float32 or get_f32_mode() != 'split_f16':
         return False
     if X.shape[0] < SPLIT_MIN_FRAMES or X.shape[1] > 64:
         return False
-    key = (X.data_ptr(), tuple(X.shape), X._version)
-    hit = _range_memo.get(key)
+    owner = _range_owner(X)
+    memo = owner.__dict__.get('_beer_range_memo')
+    if memo is None or memo[0] != owner._version:
+        memo = (owner._version, {})
+        owner.__dict__['_beer_range_memo'] = memo
+    key = (X.storage_offset(), tuple(X.shape), tuple(X.stride()))
+    hit = memo[1].get(key)
     if hit is None:
         scratch = torch.empty(1024, dtype=torch.uint8, device=X.device)
         flag = torch.empty(1, dtype=torch.int32, device=X.device)
         call('beer_f32_split_hazard', X.shape[0], X.shape[1], ptr(X), ptr(scratch), ptr(flag))
         hit = int(flag.item()) == 0
-        if len(_range_memo) > 64:
-            _range_memo.clear()
-        _range_memo[key] = hit
+        if len(memo[1]) > 256:
+            memo[1].clear()
+        memo[1][key] = hit
     return hit
 
 

@@ -10,27 +10,12 @@
 // mixtureset.py:85-112, dists/normalwishart.py:30-38,88-92 (and the
 // normalgamma / isonormalgamma equivalents).
 
-#include <cstdlib>
-#include <cstring>
-
 #include "common.h"
 #include "estep_mfma.h"
 
 using namespace beer;
 
 namespace {
-
-// How fp32 models multiply on the matrix cores (beer_hip_set_f32_mode); the
-// initial value comes from the environment: BEER_F32_MODE=exact | split_f16.
-int& f32_mode_ref() {
-    static int mode = [] {
-        const char* e = getenv("BEER_F32_MODE");
-        if (e && (!strcmp(e, "exact") || !strcmp(e, "f32"))) return BEER_F32_EXACT;
-        return BEER_F32_SPLIT_F16;
-    }();
-    return mode;
-}
-int f32_mode() { return f32_mode_ref(); }
 
 constexpr int kFrameTile = 64;      // frames per workgroup tile (lane = frame)
 constexpr int kLlhThreads = 256;    // 4 waves, each walks a share of the comps
@@ -333,7 +318,7 @@ template <typename T>
 int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, const void* expT,
                  const void* logw, const int64_t* labels, double stat_scale, void* pc_llh,
                  void* log_norm, void* comp_resps, double* llh_sum, void* ws, size_t ws_bytes,
-                 void* stream) {
+                 void* stream, bool exact) {
     BEER_REQUIRE(nframes >= 0 && D >= 1 && S >= 1 && G >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(X && expT);
     BEER_REQUIRE(!labels || S == 1);
@@ -362,7 +347,7 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
 
     if (mfma_ok) {
         // gfx950 matrix-core path: GEMM + (grouped) softmax fused, one kernel
-        if (sizeof(T) == 4 && f32_mode() == BEER_F32_SPLIT_F16 &&
+        if (sizeof(T) == 4 && !exact &&
             ws_bytes >= beer_mfma::estep16_workspace_bytes(cov, D, S, G))
             return beer_mfma::estep_f16x3(cov, nframes, D, S, G, (const float*)X,
                                           (const float*)expT, (const float*)logw,
@@ -441,14 +426,14 @@ int acc_launch(int64_t nframes, int D, int S, int G, const void* X, const void* 
 template <typename T>
 int accumulate_launch(int cov, int64_t nframes, int D, int S, int G, const void* X,
                       const void* cr, const void* sr, double* acc, void* ws, size_t ws_bytes,
-                      void* stream) {
+                      void* stream, bool exact) {
     BEER_REQUIRE(nframes >= 0 && D >= 1 && S >= 1 && G >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(X && acc);
     if (nframes == 0) return BEER_OK;
     hipStream_t s = as_stream(stream);
     if (cr && ws && beer_mfma::supported_acc(D, S * G) &&
         ws_bytes >= beer_mfma::acc_workspace_bytes(cov, D, S * G)) {
-        if (sizeof(T) == 4 && f32_mode() == BEER_F32_SPLIT_F16 &&
+        if (sizeof(T) == 4 && !exact &&
             ws_bytes >= beer_mfma::acc16_workspace_bytes(cov, D, S * G))
             return beer_mfma::acc_f16x3(cov, nframes, D, S, G, (const float*)X, (const float*)cr,
                                         (const float*)sr, acc, ws, ws_bytes, s);
@@ -484,26 +469,20 @@ int beer_mixtureset_estep(int dtype, int cov, int64_t T, int D, int S, int G, co
                           const int64_t* labels, double stat_scale, void* pc_llh,
                           void* log_norm, void* comp_resps, double* llh_sum, void* workspace,
                           size_t workspace_bytes, void* stream) {
-    BEER_DISPATCH(dtype, estep_launch, cov, T, D, S, G, X, exp_stats, log_weights, labels,
-                  stat_scale, pc_llh, log_norm, comp_resps, llh_sum, workspace, workspace_bytes,
-                  stream);
+    const bool exact = (dtype & BEER_EXACT) != 0;
+    BEER_DISPATCH(dtype & ~BEER_EXACT, estep_launch, cov, T, D, S, G, X, exp_stats, log_weights,
+                  labels, stat_scale, pc_llh, log_norm, comp_resps, llh_sum, workspace,
+                  workspace_bytes, stream, exact);
 }
 
 size_t beer_estep_workspace_bytes(int dtype, int cov, int D, int S, int G) {
     if (cov < 0 || cov > 2) return 0;
+    dtype &= ~BEER_EXACT;
     const size_t exact = beer_mfma::estep_workspace_bytes(dtype == BEER_F64 ? 8 : 4, cov, D, S, G);
     if (dtype == BEER_F64) return exact;
     const size_t split = beer_mfma::estep16_workspace_bytes(cov, D, S, G);
     return exact > split ? exact : split;                 // either fp32 mode fits
 }
-
-int beer_hip_set_f32_mode(int mode) {
-    if (mode != BEER_F32_EXACT && mode != BEER_F32_SPLIT_F16) return BEER_EINVAL;
-    f32_mode_ref() = mode;
-    return BEER_OK;
-}
-
-int beer_hip_get_f32_mode(void) { return f32_mode(); }
 
 int beer_f32_split_hazard(int64_t T, int D, const void* X, void* scratch, int* hazard,
                           void* stream) {
@@ -516,6 +495,7 @@ int beer_f32_split_hazard(int64_t T, int D, const void* X, void* scratch, int* h
 
 size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G) {
     if (cov < 0 || cov > 2) return 0;
+    dtype &= ~BEER_EXACT;
     const size_t exact = beer_mfma::acc_workspace_bytes(cov, D, S * G);
     const size_t split = dtype == BEER_F64 ? 0 : beer_mfma::acc16_workspace_bytes(cov, D, S * G);
     return exact > split ? exact : split;
@@ -524,8 +504,9 @@ size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G) 
 int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G, const void* X,
                            const void* comp_resps, const void* state_resps, double* acc,
                            void* workspace, size_t workspace_bytes, void* stream) {
-    BEER_DISPATCH(dtype, accumulate_launch, cov, T, D, S, G, X, comp_resps, state_resps, acc,
-                  workspace, workspace_bytes, stream);
+    const bool exact = (dtype & BEER_EXACT) != 0;
+    BEER_DISPATCH(dtype & ~BEER_EXACT, accumulate_launch, cov, T, D, S, G, X, comp_resps,
+                  state_resps, acc, workspace, workspace_bytes, stream, exact);
 }
 
 int beer_mixture_estep_packed(int cov, int64_t T, int D, int K, const float* X,

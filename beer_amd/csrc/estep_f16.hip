@@ -45,6 +45,15 @@ constexpr int kColBits = 14;           // column maximum of P < 2^14
 __host__ __device__ inline int nk16_of(int cov, int D) {
     return ((nslab_of(cov, D) + 7) / 8 + 1) / 2 * 2;
 }
+// Row stride (floats) of K1's LDS frame tile: the D values, the constant 1 and at
+// least 7 zeros (the padding slabs read them), with stride / 4 odd -- the 16 rows
+// of an A-fragment ds_read_b128 then start in 16 different 16-byte slots of the
+// 256-byte bank row (with stride 48 at D = 40 they fell on 4 slots: 74 % of the
+// LDS cycles of the kernel were bank conflicts, profiles/r01_pmc.json).
+__host__ __device__ inline int ld16_of(int D) {
+    const int ld = 4 * d4_of(D) + 8;
+    return (ld / 4) % 2 ? ld : ld + 4;
+}
 constexpr int kPadBlocks = 16;         // look-ahead blocks behind the P image (a quarter k-step
                                        // of the second component half, see KS)
 
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     double* __restrict__ llh_sum, float* __restrict__ xt_out, int xt_floats) {
     using acc_t = f32x4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int D4 = d4_of(D), Dp = 4 * D4, LD = Dp + 8;        // 16-byte aligned rows
+    const int D4 = d4_of(D), Dp = 4 * D4, LD = ld16_of(D);    // 16-byte aligned rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
@@ -465,7 +474,7 @@ int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, in
                  const float* X, const _Float16* P, const float* inv_scale, const float* sc,
                  const int* tab, float* resps, float* log_norm, double* llh_sum, hipStream_t s,
                  float* xt_out = nullptr, int xt_floats = 0) {
-    const int LD = 4 * d4_of(D) + 8;
+    const int LD = ld16_of(D);
     constexpr int FB = 16 * MT * (kThreads / 64) / KS;
     const size_t lds = (size_t)FB * LD * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int) +
                        (KS == 2 ? 8 * 16 * MT * sizeof(float) : 0);

@@ -676,6 +676,343 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// forward-backward, ONE WAVE per utterance (low-degree graphs with at most one
+// hub, <= 256 states)
+// ---------------------------------------------------------------------------
+// The workgroup version above is bound by instruction issue, not by the latency
+// of its dependent steps: a CU holds 16 utterances of two waves each and every
+// frame costs each wave hundreds of instructions around 7 workgroup barriers,
+// fp64 cross-lane reductions done by one wave while the other waits, and values
+// recomputed in the backward pass (rocprof: 6000 cycles per frame and utterance at
+// S = 120).  Here a wave owns an utterance alone -- lane l holds states l, l + 64,
+// ... (SPL per lane) -- and the step is one straight line of code:
+//  * the trellis column lives in LDS without any barrier (the LDS operations of
+//    one wave execute in order);
+//  * every log-sum-exp is "relative to an approximate maximum": the terms stay
+//    fp64, their maximum is taken in float (any m near the maximum gives the same
+//    sum; DPP reductions of 32-bit values are one instruction per stage, of 64-bit
+//    values five), differences to it are formed in fp64 and exponentiated, summed
+//    and log'ed in the model's precision (float models: v_exp_f32 / v_log_f32 and
+//    float sums of <= 65 terms <= 1, the precision class of the kernel above);
+//  * absent arcs, absent hub links and lanes without a state carry the weight
+//    -inf: exp(-inf) = 0, so the unrolled arc slots (DEG, the graph's largest
+//    in / out degree) need no branch;
+//  * the hub's forward values are kept from the forward pass (hub_ws) for the
+//    hub flows instead of being recomputed, the lane's own lb value stays in a
+//    register.
+// FUSED: the pdf-id gather (modelset.py:140-146) with the acoustic scale
+// (hmm.py:79) happens when the emission log-likelihoods are read, the scatter
+// back to pdf ids (modelset.py:148-154, hmm.py:95) and the utterance's
+// sum_t sum_s gamma * pc (hmm.py:87) when gamma is written: three launches and
+// two round trips of the [frames, states] arrays less.
+constexpr int kWvWaves = 4;            // utterances (waves) per workgroup
+
+// arithmetic of a log-sum-exp relative to an approximate maximum
+template <typename T> struct Rel;
+template <> struct Rel<float> {
+    typedef float r_t;
+    static __device__ __forceinline__ float down(double v) { return (float)v; }
+    static __device__ __forceinline__ float mx(float a, float b) { return __builtin_fmaxf(a, b); }
+    static __device__ __forceinline__ float wmax(float v) {
+        return wave_detail::allreduce(v, [](float x, float y) { return __builtin_fmaxf(x, y); });
+    }
+    static __device__ __forceinline__ float ex(double d) {       // exp(d), d <~ 0
+        return __builtin_amdgcn_exp2f((float)d * 1.44269504088896340736f);
+    }
+    static __device__ __forceinline__ double lg(float s) {        // log(s)
+        return (double)(__builtin_amdgcn_logf(s) * 0.69314718055994530942f);
+    }
+};
+template <> struct Rel<double> {
+    typedef double r_t;
+    static __device__ __forceinline__ double down(double v) { return v; }
+    static __device__ __forceinline__ double mx(double a, double b) { return b > a ? b : a; }
+    static __device__ __forceinline__ double wmax(double v) { return wave_max(v); }
+    static __device__ __forceinline__ double ex(double d) { return exp(d); }
+    static __device__ __forceinline__ double lg(double s) { return log(s); }
+};
+// the maximum as an fp64 offset: 0 when every term is -inf (the sum is then 0 and
+// its log -inf, as it must be)
+template <typename R>
+__device__ __forceinline__ double rel_base(R m) {
+    return m > (R)-INFINITY ? (double)m : 0.0;
+}
+
+template <typename T, int SPL, int DEG, bool FUSED, bool XI>
+__global__ __launch_bounds__(64 * kWvWaves) void fb_wave_kernel(
+    beer_batch b, const T* __restrict__ pc, int S_total, T scale, double* __restrict__ alpha_ws,
+    double* __restrict__ hubf_ws, T* __restrict__ out, T resp_scale, int atomic_out,
+    double* __restrict__ xi_sum, double* __restrict__ gamma0_sum, double* __restrict__ hub_flow,
+    double* __restrict__ utt_llh, T* __restrict__ lognorm_mean) {
+    typedef Rel<T> R;
+    typedef typename R::r_t r_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u = blockIdx.x * kWvWaves + wave;
+    if (u >= b.nutt) return;                              // (no workgroup barrier below)
+    const int gid = b.graph_id[u];
+    const beer_graph g = b.graphs[gid];
+    const beer_graph_lowdeg L = *g.lowdeg;
+    const int S = g.n_states;
+    const bool has_hub = L.n_hubs > 0;
+    const int64_t f0 = b.frame_off[u], T_ = b.frame_off[u + 1] - f0;
+    if (T_ <= 0) return;
+    const double NINF = neg_inf();
+    constexpr int NS = 64 * SPL;                          // LDS slots per column
+    // byte addresses in LDS: cur[NS] (alpha_{t-1}), lb[NS] (llh_{t+1} + beta_{t+1})
+    const int cur0 = wave * (2 * NS * 8), lb0 = cur0 + NS * 8;
+    auto lds = [&](int addr) -> double& { return *reinterpret_cast<double*>(smem + addr); };
+    const T* in_w = (const T*)L.in_w;
+    const T* out_w = (const T*)L.out_w;
+    const T* hsw = (const T*)L.hub_src_w;
+    const T* hdw = (const T*)L.hub_dst_w;
+    const T* init = (const T*)g.init;
+    const T* fin = (const T*)g.final;
+
+    // ---- the lane's states (lanes without one: weights -inf, their own slots) ----
+    int own[SPL], isrc[SPL][DEG], odst[SPL][DEG];          // LDS byte addresses
+    T iw[SPL][DEG], ow[SPL][DEG], hs_w[SPL], hd_w[SPL], fin_w[SPL];
+    bool st[SPL];
+    int64_t ll_off[SPL], a_off[SPL];                       // element offsets per frame 0
+    double xi_r[XI ? SPL : 1][DEG], flow_r[SPL];
+    const int32_t* ids = FUSED ? b.pdf_ids + b.pdf_off[gid] : nullptr;
+#pragma unroll
+    for (int p = 0; p < SPL; ++p) {
+        const int j = lane + 64 * p;
+        st[p] = j < S;
+        own[p] = cur0 + 8 * j;
+        hs_w[p] = hd_w[p] = fin_w[p] = ninf<T>();
+        flow_r[p] = 0.0;
+        int ib = 0, ie = 0, ob = 0, oe = 0, id = 0;
+        if (st[p]) {
+            ib = L.in_ptr[j]; ie = L.in_ptr[j + 1];
+            ob = L.out_ptr[j]; oe = L.out_ptr[j + 1];
+            if (has_hub && L.hub_src_id[j] >= 0) hs_w[p] = hsw[j];
+            if (has_hub && L.hub_dst_id[j] >= 0) hd_w[p] = hdw[j];
+            fin_w[p] = fin[j];
+            if (FUSED) id = ids[j];
+        }
+        ll_off[p] = st[p] ? (FUSED ? (int64_t)id : (int64_t)j) : 0;    // (always a valid element)
+        a_off[p] = j;
+#pragma unroll
+        for (int k = 0; k < DEG; ++k) {
+            const bool a = ib + k < ie, o = ob + k < oe;
+            isrc[p][k] = a ? cur0 + 8 * L.in_src[ib + k] : own[p];
+            iw[p][k] = a ? in_w[ib + k] : ninf<T>();
+            odst[p][k] = o ? lb0 + 8 * L.out_dst[ob + k] : own[p] + NS * 8;
+            ow[p][k] = o ? out_w[ob + k] : ninf<T>();
+            if (XI) xi_r[p][k] = 0.0;
+        }
+    }
+    // the hub's members, one per lane
+    int hm_src = own[0], hm_dst = own[0] + NS * 8;
+    T hw_src = ninf<T>(), hw_dst = ninf<T>();
+    if (has_hub) {
+        const int sb = L.src_ptr[0], se = L.src_ptr[1], db = L.dst_ptr[0], de = L.dst_ptr[1];
+        if (sb + lane < se) {
+            const int e = L.src_list[sb + lane];
+            hm_src = cur0 + 8 * e;
+            hw_src = hsw[e];
+        }
+        if (db + lane < de) {
+            const int e = L.dst_list[db + lane];
+            hm_dst = lb0 + 8 * e;
+            hw_dst = hdw[e];
+        }
+    }
+    // log-sum-exp over the wave of one value per lane
+    auto wave_lse = [&](double val) {
+        const double m = rel_base(R::wmax(R::down(val)));
+        return m + R::lg(wave_sum(R::ex(val - m)));
+    };
+    // log-sum-exp of the lane's DEG arc terms and its hub term
+    auto lane_lse = [&](const double (&v)[DEG], double vh) {
+        r_t m = R::down(vh);
+#pragma unroll
+        for (int k = 0; k < DEG; ++k) m = R::mx(m, R::down(v[k]));
+        const double mb = rel_base(m);
+        r_t sm = R::ex(vh - mb);
+#pragma unroll
+        for (int k = 0; k < DEG; ++k) sm += R::ex(v[k] - mb);
+        return mb + R::lg(sm);
+    };
+    // The wave's LDS writes are visible to its later reads in program order; the
+    // compiler must keep that order (no instruction is emitted for this).
+#define BEER_WAVE_ORDER() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+    const T* llh = FUSED ? pc + f0 * (int64_t)S_total : pc + b.llh_off[u];
+    const int64_t ll_stride = FUSED ? S_total : S;
+    double* alpha = alpha_ws + b.llh_off[u];
+    double* hubf = hubf_ws + f0;                          // forward hub value per frame
+    auto load_ll = [&](int64_t t, int p) -> T {
+        const T v = llh[t * ll_stride + ll_off[p]];       // (lanes without a state: element 0)
+        return FUSED ? scale * v : v;
+    };
+
+    // ---- forward ----
+    T ll_next[SPL];
+#pragma unroll
+    for (int p = 0; p < SPL; ++p) {
+        const double a = st[p] ? (double)load_ll(0, p) + (double)init[lane + 64 * p] : NINF;
+        lds(own[p]) = a;
+        if (st[p]) alpha[a_off[p]] = a;
+        ll_next[p] = load_ll(T_ > 1 ? 1 : 0, p);
+    }
+    BEER_WAVE_ORDER();
+    for (int64_t t = 1; t < T_; ++t) {
+        T ll[SPL];
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            ll[p] = ll_next[p];
+            ll_next[p] = load_ll(t + 1 < T_ ? t + 1 : t, p);
+        }
+        double hub = NINF;
+        if (has_hub) {
+            hub = wave_lse(lds(hm_src) + (double)hw_src);
+            if (lane == 0) hubf[t - 1] = hub;             // H(t-1): flows of the arcs t-1 -> t
+        }
+        double a[SPL];
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            double v[DEG];
+#pragma unroll
+            for (int k = 0; k < DEG; ++k) v[k] = lds(isrc[p][k]) + (double)iw[p][k];
+            a[p] = (double)ll[p] + lane_lse(v, hub + (double)hd_w[p]);
+        }
+        BEER_WAVE_ORDER();                                // every read of the column is done
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            lds(own[p]) = st[p] ? a[p] : NINF;
+            if (st[p]) alpha[t * S + a_off[p]] = a[p];
+        }
+        BEER_WAVE_ORDER();
+    }
+
+    // ---- backward + posteriors ----
+    // frame T-1 first (beta = final, nothing to recurse), then the loop
+    double ln_acc = 0.0, llh_acc = 0.0;
+    double lb_own[SPL], a_next[SPL];
+    T lt_next[SPL];
+    double hf_next = NINF;
+    auto finish_frame = [&](int64_t t, const double (&a_cur)[SPL], const T (&lt_cur)[SPL],
+                            const double (&beta)[SPL], const double (&vout)[SPL][DEG],
+                            double hf_cur, bool inner) {
+        double ab[SPL];
+        r_t m = (r_t)-INFINITY;
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            ab[p] = a_cur[p] + beta[p];                    // (lanes without a state: -inf)
+            m = R::mx(m, R::down(ab[p]));
+        }
+        const double mb = rel_base(R::wmax(m));
+        r_t sm = 0;
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) sm += R::ex(ab[p] - mb);
+        const double lognorm = mb + R::lg(wave_sum(sm));   // per frame (graph.py:304-307)
+        ln_acc += lognorm;
+        const bool ok = lognorm > NINF;
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            // NaN when alpha + beta and lognorm are both -inf, as in the reference
+            const double gv = st[p] ? (double)R::ex(ab[p] - lognorm) : 0.0;
+            if (st[p]) {
+                if (FUSED) {
+                    const T gT = (T)gv;
+                    T* dst = out + (f0 + t) * (int64_t)S_total + ll_off[p];
+                    if (atomic_out) atomicAdd(dst, resp_scale * gT);
+                    else *dst = resp_scale * gT;
+                    llh_acc += (double)(lt_cur[p] * gT);
+                } else {
+                    out[b.llh_off[u] + t * S + a_off[p]] = (T)gv;
+                }
+                if (t == 0 && gamma0_sum) atomicAdd(gamma0_sum + a_off[p], gv);
+            }
+            if (inner) {
+                if (XI) {
+                    const double ai = a_cur[p] - lognorm;
+#pragma unroll
+                    for (int k = 0; k < DEG; ++k) {
+                        const double val = (double)R::ex(ai + vout[p][k]);
+                        xi_r[p][k] += (ok && val == val) ? val : 0.0;
+                    }
+                }
+                if (has_hub && hub_flow) {
+                    const double val = (double)R::ex(hf_cur + (double)hd_w[p] + lb_own[p] - lognorm);
+                    flow_r[p] += (ok && val == val) ? val : 0.0;
+                }
+            }
+        }
+        BEER_WAVE_ORDER();                                 // lb fully read
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            lb_own[p] = st[p] ? (double)lt_cur[p] + beta[p] : NINF;     // for frame t - 1
+            lds(own[p] + NS * 8) = lb_own[p];
+        }
+        BEER_WAVE_ORDER();
+    };
+    {
+        const int64_t t = T_ - 1;
+        double a_cur[SPL], beta[SPL], vout[SPL][DEG];
+        T lt_cur[SPL];
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            a_cur[p] = st[p] ? alpha[t * S + a_off[p]] : NINF;
+            lt_cur[p] = load_ll(t, p);
+            beta[p] = (double)fin_w[p];
+            lb_own[p] = NINF;
+#pragma unroll
+            for (int k = 0; k < DEG; ++k) vout[p][k] = NINF;
+            a_next[p] = (st[p] && t > 0) ? alpha[(t - 1) * S + a_off[p]] : NINF;
+            lt_next[p] = load_ll(t > 0 ? t - 1 : 0, p);
+        }
+        if (has_hub && t > 0) hf_next = hubf[t - 1];
+        finish_frame(t, a_cur, lt_cur, beta, vout, NINF, false);
+    }
+    for (int64_t t = T_ - 2; t >= 0; --t) {
+        double a_cur[SPL], beta[SPL], vout[SPL][DEG];
+        T lt_cur[SPL];
+        const double hf_cur = hf_next;                    // H(t)
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            a_cur[p] = a_next[p];
+            lt_cur[p] = lt_next[p];
+            const int64_t tp = t > 0 ? t - 1 : 0;
+            a_next[p] = st[p] ? alpha[tp * S + a_off[p]] : NINF;
+            lt_next[p] = load_ll(tp, p);
+        }
+        if (has_hub) hf_next = hubf[t > 0 ? t - 1 : 0];
+        double hub = NINF;
+        if (has_hub) hub = wave_lse(lds(hm_dst) + (double)hw_dst);
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+#pragma unroll
+            for (int k = 0; k < DEG; ++k) vout[p][k] = (double)ow[p][k] + lds(odst[p][k]);
+            beta[p] = lane_lse(vout[p], (double)hs_w[p] + hub);
+        }
+        finish_frame(t, a_cur, lt_cur, beta, vout, hf_cur, true);
+    }
+#undef BEER_WAVE_ORDER
+    if (lognorm_mean && lane == 0) lognorm_mean[u] = (T)(ln_acc / (double)T_);
+    if (FUSED && utt_llh) {
+        llh_acc = wave_sum(llh_acc);
+        if (lane == 0) atomicAdd(utt_llh + u, llh_acc);
+    }
+#pragma unroll
+    for (int p = 0; p < SPL; ++p) {
+        if (!st[p]) continue;
+        const int j = lane + 64 * p;
+        if (XI && xi_sum) {
+#pragma unroll
+            for (int k = 0; k < DEG; ++k)
+                if (ow[p][k] > ninf<T>() && xi_r[p][k] != 0.0)
+                    atomicAdd(xi_sum + (size_t)j * S + (odst[p][k] - lb0) / 8, xi_r[p][k]);
+        }
+        if (hub_flow && hd_w[p] > ninf<T>()) atomicAdd(hub_flow + j, flow_r[p]);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Viterbi
 // ---------------------------------------------------------------------------
 // The recursion is a chain of T dependent steps per utterance, so nothing a step
@@ -864,9 +1201,77 @@ int scatter_launch(const beer_batch* b, int S_total, const void* pc, const void*
     return BEER_OK;
 }
 
+// graphs the one-wave-per-utterance kernel takes: low-degree images with at most one
+// hub of at most 64 members a side, <= 4 states per lane (the host layer fills the
+// batch's max_degree / max_hubs / max_hub_members; 0 = unknown: not taken)
+constexpr int kWvMaxStates = 256;
+inline bool wave_fb_ok(const beer_batch* b) {
+    return b->all_lowdeg && b->max_states <= kWvMaxStates && b->max_degree >= 1 &&
+           b->max_degree <= BEER_SEG && b->max_hubs <= 1 && b->max_hub_members <= 64;
+}
+
+template <typename T, bool FUSED>
+int wave_fb_launch(const beer_batch* b, const T* pc, int S_total, T scale, double* alpha_ws,
+                   double* hub_ws, T* out, T resp_scale, int atomic_out, double* xi_sum,
+                   double* gamma0_sum, double* hub_flow, double* utt_llh, T* lognorm_mean,
+                   hipStream_t s) {
+    const dim3 grid((unsigned)((b->nutt + kWvWaves - 1) / kWvWaves)), block(64 * kWvWaves);
+    const bool xi = !FUSED && xi_sum != nullptr;
+    const int spl = b->max_states <= 64 ? 1 : (b->max_states <= 128 ? 2 : 4);
+    const int deg = b->max_degree <= 2 ? 2 : (b->max_degree <= 4 ? 4 : 8);
+    const size_t lds = (size_t)kWvWaves * 2 * 64 * spl * sizeof(double);
+#define BEER_WV(SPL_, DEG_, XI_)                                                                \
+    hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_>), grid, block, lds, s, *b,   \
+                       pc, S_total, scale, alpha_ws, hub_ws, out, resp_scale, atomic_out,      \
+                       xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean)
+#define BEER_WV_DEG(SPL_, XI_)                                                                  \
+    do {                                                                                        \
+        if (deg == 2) BEER_WV(SPL_, 2, XI_);                                                    \
+        else if (deg == 4) BEER_WV(SPL_, 4, XI_);                                               \
+        else BEER_WV(SPL_, 8, XI_);                                                             \
+    } while (0)
+#define BEER_WV_SPL(XI_)                                                                        \
+    do {                                                                                        \
+        if (spl == 1) BEER_WV_DEG(1, XI_);                                                      \
+        else if (spl == 2) BEER_WV_DEG(2, XI_);                                                 \
+        else BEER_WV_DEG(4, XI_);                                                               \
+    } while (0)
+    if constexpr (FUSED) {
+        BEER_WV_SPL(false);
+    } else {
+        if (xi) BEER_WV_SPL(true);
+        else BEER_WV_SPL(false);
+    }
+#undef BEER_WV_SPL
+#undef BEER_WV_DEG
+#undef BEER_WV
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int beer_hmm_posteriors_fused(int dtype, const beer_batch* b, int S_total, const void* pc_all,
+                              double scale, double* alpha_ws, double* hub_ws, void* state_resps,
+                              int atomic_out, double* gamma0_sum, double* hub_flow,
+                              double* utt_llh, void* stream) {
+    BEER_REQUIRE(b && b->nutt >= 0 && b->max_states >= 1 && S_total >= 1);
+    BEER_REQUIRE(dtype == BEER_F32 || dtype == BEER_F64);
+    BEER_REQUIRE(wave_fb_ok(b));
+    if (b->nutt == 0) return BEER_OK;
+    BEER_REQUIRE(pc_all && alpha_ws && hub_ws && state_resps);
+    hipStream_t s = as_stream(stream);
+    if (dtype == BEER_F32)
+        return wave_fb_launch<float, true>(b, (const float*)pc_all, S_total, (float)scale,
+                                           alpha_ws, hub_ws, (float*)state_resps, (float)scale,
+                                           atomic_out, nullptr, gamma0_sum, hub_flow, utt_llh,
+                                           nullptr, s);
+    return wave_fb_launch<double, true>(b, (const double*)pc_all, S_total, scale, alpha_ws,
+                                        hub_ws, (double*)state_resps, scale, atomic_out, nullptr,
+                                        gamma0_sum, hub_flow, utt_llh, nullptr, s);
+}
 
 int beer_hmm_gather(int dtype, const beer_batch* batch_h, int S_total, const void* pc_all,
                     double scale, void* pc_llhs, void* stream) {
@@ -881,12 +1286,25 @@ int beer_hmm_scatter(int dtype, const beer_batch* batch_h, int S_total, const vo
 }
 
 int beer_hmm_forward_backward(int dtype, const beer_batch* b, const void* pc_llhs,
-                              double* alpha_ws, void* gamma, double* xi_sum, double* gamma0_sum,
-                              double* hub_flow, void* lognorm_mean, void* stream) {
+                              double* alpha_ws, double* hub_ws, void* gamma, double* xi_sum,
+                              double* gamma0_sum, double* hub_flow, void* lognorm_mean,
+                              void* stream) {
     BEER_REQUIRE(b && b->nutt >= 0 && b->max_states >= 1 && b->max_states <= 32767);
     BEER_REQUIRE(dtype == BEER_F32 || dtype == BEER_F64);
     if (b->nutt == 0) return BEER_OK;
     hipStream_t s = as_stream(stream);
+    if (wave_fb_ok(b) && hub_ws && (!xi_sum || hub_flow)) {
+        // one wave per utterance, no barriers
+        if (dtype == BEER_F32)
+            return wave_fb_launch<float, false>(b, (const float*)pc_llhs, b->max_states, 1.f,
+                                                alpha_ws, hub_ws, (float*)gamma, 1.f, 0, xi_sum,
+                                                gamma0_sum, hub_flow, nullptr,
+                                                (float*)lognorm_mean, s);
+        return wave_fb_launch<double, false>(b, (const double*)pc_llhs, b->max_states, 1.0,
+                                             alpha_ws, hub_ws, (double*)gamma, 1.0, 0, xi_sum,
+                                             gamma0_sum, hub_flow, nullptr,
+                                             (double*)lognorm_mean, s);
+    }
     if (b->all_lowdeg && b->max_states <= kLdThreads && (!xi_sum || hub_flow)) {
         // factorised low-degree recursion: one thread per state
         const size_t lds = ((size_t)3 * b->max_states + 4 * kMaxHubs + 8) * sizeof(double);

@@ -181,6 +181,14 @@ class GraphSet:
                        _np_ptr(self.pdf_ids), _np_ptr(self.arc_src), _np_ptr(self.arc_dst),
                        _np_ptr(self.arc_prob))
         self._images = {}
+        # largest in / out degree over all graphs (beer_batch.max_degree)
+        gidx = np.repeat(np.arange(self.n), np.diff(self.arc_off))
+        deg = 1
+        if A:
+            base = self.state_off[gidx]
+            deg = max(int(np.bincount(base + self.arc_src, minlength=S).max()),
+                      int(np.bincount(base + self.arc_dst, minlength=S).max()), 1)
+        self.max_degree = deg
 
     def __del__(self):
         handle, self._handle = getattr(self, '_handle', None), None
@@ -228,6 +236,8 @@ class _ArenaDeviceGraph:
         self.n_states, self.n_arcs = struct.n_states, struct.n_arcs
         self.n_in_seg, self.n_out_seg = struct.n_in_seg, struct.n_out_seg
         self.lowdeg = True if struct.lowdeg else None
+        if self.lowdeg:
+            self.lowdeg_info = (keep[0].max_degree, 0, 0)        # alignment chains: no hub
 
 
 class SparseGraph:
@@ -413,6 +423,12 @@ class DeviceGraph:
         ld['_ld_blob'] = ld.pop('_blob')
         b.update(ld)
         self._hub_ptr = (list(src_ptr), list(dst_ptr))
+        # (largest degree of the image's CSR, hubs, largest hub side): what the batch
+        # descriptor tells the kernels (beer_batch.max_degree ...)
+        members = [src_ptr[h + 1] - src_ptr[h] for h in range(len(hubs))] + \
+            [dst_ptr[h + 1] - dst_ptr[h] for h in range(len(hubs))] + [0]
+        self.lowdeg_info = (max(1, int(keep.sum(0).max()), int(keep.sum(1).max())), len(hubs),
+                            max(members))
         q = lambda name: b[name].data_ptr()                      # noqa: E731
         return _hip.GraphLowDeg(
             int(src_i.numel()), len(hubs), q('ld_in_ptr'), q('ld_in_src'), q('ld_in_w'),

@@ -9,7 +9,8 @@ import torch
 from . import _hip
 
 __all__ = ['HmmBatch', 'gather', 'forward_backward', 'viterbi', 'path_posteriors',
-           'scatter', 'gather_columns', 'scatter_columns', 'segment_sum']
+           'scatter', 'gather_columns', 'scatter_columns', 'segment_sum', 'fused_ok',
+           'posteriors_fused']
 
 
 class HmmBatch:
@@ -50,6 +51,7 @@ class HmmBatch:
             else:
                 pdf_ids = (np.arange(pdf_off[-1]) - np.repeat(pdf_off[:-1], counts)).astype(np.int32)
             self.dgraphs = [gset]                               # keeps the image alive
+            ld_info = (gset.max_degree, 0, 0)                   # alignment chains: no hub
         else:
             self.dgraphs = [g.device_graph(dtype) for g in graphs]
             n_states = [dg.n_states for dg in self.dgraphs]
@@ -64,6 +66,9 @@ class HmmBatch:
             max_segs = max([max(dg.n_in_seg, dg.n_out_seg) for dg in self.dgraphs] + [1])
             all_lowdeg = bool(self.dgraphs) and \
                 all(getattr(dg, 'lowdeg', None) is not None for dg in self.dgraphs)
+            infos = [getattr(dg, 'lowdeg_info', (0, 0, 0)) for dg in self.dgraphs] or [(0, 0, 0)]
+            known = all(i[0] > 0 for i in infos)
+            ld_info = tuple(max(i[k] for i in infos) if known else 0 for k in range(3))
         states_t = torch.as_tensor(n_states, dtype=torch.int64)[gid_t] \
             if self.nutt else torch.zeros(0, dtype=torch.int64)
         frame_off = torch.zeros(self.nutt + 1, dtype=torch.int64)
@@ -86,8 +91,28 @@ class HmmBatch:
             self.nutt, max(n_states) if n_states else 1, max(max_arcs, 1), max(max_segs, 1),
             1 if (lowdeg and all_lowdeg) else 0, len(graphs),
             b['frame_off'].data_ptr(), b['llh_off'].data_ptr(), b['graph_id'].data_ptr(),
-            b['graphs'].data_ptr(), b['pdf_off'].data_ptr(), b['pdf_ids'].data_ptr())
+            b['graphs'].data_ptr(), b['pdf_off'].data_ptr(), b['pdf_ids'].data_ptr(),
+            *(ld_info if all_lowdeg else (0, 0, 0)), 0)
         self.shared_graph = len(graphs) == 1
+        self._pdf_ids_h, self._pdf_off_h = np.asarray(pdf_ids), np.asarray(pdf_off)
+        self._profile = {}
+
+    def pdf_ids_profile(self, S_total):
+        '''(some graph repeats a pdf id, every graph's ids are exactly 0 .. S_total-1):
+        what decides between atomic adds, plain stores into a zero-filled array and
+        plain stores into an uninitialised one when posteriors go back to pdf ids.'''
+        hit = self._profile.get(S_total)
+        if hit is None:
+            ids, off = self._pdf_ids_h, self._pdf_off_h
+            n = len(off) - 1
+            counts = np.diff(off)
+            gidx = np.repeat(np.arange(n), counts)
+            key = gidx.astype(np.int64) * (int(ids.max()) + 1 if len(ids) else 1) + ids
+            distinct = len(np.unique(key)) == len(key)
+            covers = distinct and bool((counts == S_total).all()) and \
+                (len(ids) == 0 or int(ids.max()) < S_total)
+            hit = self._profile[S_total] = (not distinct, covers)
+        return hit
 
     def ref(self):
         return ctypes.byref(self.struct)
@@ -114,6 +139,7 @@ def forward_backward(batch, pc_llhs, want_xi=False, want_lognorm=False, dense_xi
         batch.struct.all_lowdeg = 0
     gamma = torch.empty(batch.n_elems, dtype=dt, device=dev)
     alpha = torch.empty(batch.n_elems, dtype=torch.float64, device=dev)
+    hub_ws = torch.empty(_hip.MAX_HUBS * batch.n_frames, dtype=torch.float64, device=dev)
     xi = g0 = ln = flow = None
     if want_xi:
         if not batch.shared_graph:
@@ -125,9 +151,48 @@ def forward_backward(batch, pc_llhs, want_xi=False, want_lognorm=False, dense_xi
     if want_lognorm:
         ln = torch.empty(batch.nutt, dtype=dt, device=dev)
     _hip.call('beer_hmm_forward_backward', _hip.dtype_code(dt), batch.ref(),
-              _hip.ptr(pc_llhs), _hip.ptr(alpha), _hip.ptr(gamma), _hip.ptr(xi),
+              _hip.ptr(pc_llhs), _hip.ptr(alpha), _hip.ptr(hub_ws), _hip.ptr(gamma), _hip.ptr(xi),
               _hip.ptr(g0), _hip.ptr(flow), _hip.ptr(ln))
     return gamma, xi, g0, ln, flow
+
+
+FUSED_MAX_STATES = 256      # kWvMaxStates of csrc/hmm.hip
+
+
+def fused_ok(batch):
+    '''True when `posteriors_fused` takes the batch: low-degree graphs of <= 256
+    states with at most one hub of <= 64 members a side (wave_fb_ok of csrc/hmm.hip).'''
+    st = batch.struct
+    return bool(st.all_lowdeg) and st.max_states <= FUSED_MAX_STATES and \
+        1 <= st.max_degree <= _hip.SEG and st.max_hubs <= 1 and st.max_hub_members <= 64
+
+
+def posteriors_fused(batch, pc_all, scale=1., want_counts=False, utt_llh=None):
+    '''Gather + forward-backward + scatter of a shard in one launch
+    (`beer_hmm_posteriors_fused`): (state_resps [n_frames, S_total] = scale *
+    gamma at the pdf ids, gamma0_sum [S] or None, hub_flow [S] or None);
+    `utt_llh` [nutt] fp64 += sum_t sum_s gamma * scale * pc.  `want_counts`
+    (one graph for the whole batch): the posteriors of the first frame and the
+    flows through the graph's hub -- what PhoneLoop counts (phoneloop.py:88-95).'''
+    dt, dev = batch.dtype, batch.device
+    pc_all = _hip.on_device(pc_all, dt)
+    S_total = pc_all.shape[1]
+    repeats, covers = batch.pdf_ids_profile(S_total)
+    make = torch.zeros if (repeats or not covers) else torch.empty
+    sr = make(batch.n_frames, S_total, dtype=dt, device=dev)
+    alpha = torch.empty(batch.n_elems, dtype=torch.float64, device=dev)
+    hub_ws = torch.empty(_hip.MAX_HUBS * batch.n_frames, dtype=torch.float64, device=dev)
+    g0 = flow = None
+    if want_counts:
+        if not batch.shared_graph:
+            raise ValueError('first-frame posteriors / hub flows need one graph for the batch')
+        S = batch.n_states[0]
+        g0 = torch.zeros(S, dtype=torch.float64, device=dev)
+        flow = torch.zeros(S, dtype=torch.float64, device=dev)
+    _hip.call('beer_hmm_posteriors_fused', _hip.dtype_code(dt), batch.ref(), S_total,
+              _hip.ptr(pc_all), float(scale), _hip.ptr(alpha), _hip.ptr(hub_ws), _hip.ptr(sr),
+              1 if repeats else 0, _hip.ptr(g0), _hip.ptr(flow), _hip.ptr(utt_llh))
+    return sr, g0, flow
 
 
 def viterbi(batch, pc_llhs, map_pdf=False):

@@ -237,23 +237,36 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
                     uniq.append(g)
                 ids.append(seen[id(g)])
             batch = hk.HmmBatch(uniq, ids, run_lengths, dtype)
-        pc_llhs = hk.gather(batch, pc_all, scale)
-        if viterbi or state_paths is not None:
-            if state_paths is None:
-                path = hk.viterbi(batch, pc_llhs)
-            else:
-                path = torch.cat([torch.as_tensor(state_paths[u]).reshape(-1) for u in run])
-            gamma, xi, g0 = hk.path_posteriors(batch, path, want_xi=free_loop)
-            flow = None
+        hard = viterbi or state_paths is not None
+        # phone counts come from the flows through the loop's hub (the eliminated
+        # pivot); a loop whose end -> start arcs stayed ordinary arcs needs xi
+        need_counts = free_loop and isinstance(model, PhoneLoop)
+        hubbed = need_counts and getattr(getattr(batch.dgraphs[0], 'lowdeg', None), 'n_hubs', 0) >= 1
+        if not hard and hk.fused_ok(batch) and (hubbed or not need_counts):
+            # gather + forward-backward + scatter in one launch, one wave per utterance
+            sr, g0, flow = hk.posteriors_fused(batch, pc_all, scale, want_counts=need_counts,
+                                               utt_llh=utt_llh[run[0]:run[-1] + 1])
+            xi = None
         else:
-            gamma, xi, g0, _, flow = hk.forward_backward(batch, pc_llhs, want_xi=free_loop)
+            pc_llhs = hk.gather(batch, pc_all, scale)
+            if hard:
+                if state_paths is None:
+                    path = hk.viterbi(batch, pc_llhs)
+                else:
+                    path = torch.cat([torch.as_tensor(state_paths[u]).reshape(-1) for u in run])
+                gamma, xi, g0 = hk.path_posteriors(batch, path, want_xi=free_loop)
+                flow = None
+            else:
+                gamma, xi, g0, _, flow = hk.forward_backward(batch, pc_llhs, want_xi=free_loop)
+            sr, _ = hk.scatter(batch, pc_llhs, gamma, S_total, scale, want_exp_llh=False,
+                               utt_llh=utt_llh[run[0]:run[-1] + 1])
         if free_loop:
-            xi_tot = xi if xi_tot is None else xi_tot + xi
-            g0_tot = g0 if g0_tot is None else g0_tot + g0
+            if xi is not None:
+                xi_tot = xi if xi_tot is None else xi_tot + xi
+            if g0 is not None:
+                g0_tot = g0 if g0_tot is None else g0_tot + g0
             if flow is not None:
                 flow_tot = flow if flow_tot is None else flow_tot + flow
-        sr, _ = hk.scatter(batch, pc_llhs, gamma, S_total, scale, want_exp_llh=False,
-                           utt_llh=utt_llh[run[0]:run[-1] + 1])
         first = 0
         for (grp, S, G), comp, acc in zip(groups, comps, accs):
             ns = _normalset(grp)

@@ -21,20 +21,10 @@ def is_dense(stats):
     return isinstance(stats, torch.Tensor)
 
 
-class _Keep:
-    def __enter__(self):
-        pass
-
-    def __exit__(self, *exc):
-        pass
-
-
-def _f32_path(X):
-    '''The fp16-split matrix path only for float32 frames that are numerous
-    and well ranged (`_hip.f32_split_ok`); everything else multiplies exactly.'''
-    if X.dtype != torch.float32 or _hip.get_f32_mode() != 'split_f16' or _hip.f32_split_ok(X):
-        return _Keep()
-    return _hip.exact_f32()
+def _exact(X):
+    '''Whether this call multiplies float32 frames exactly: the fp16-split matrix
+    path is only for frames that are numerous and well ranged (`_hip.f32_split_ok`).'''
+    return X.dtype == torch.float32 and not _hip.f32_split_ok(X)
 
 
 def _frames(stats):
@@ -78,11 +68,10 @@ def mixtureset_estep(stats, exp_stats, log_weights, S, G, cov_type, labels=None,
         lab = _hip.on_device(torch.as_tensor(labels)).to(torch.int64).contiguous()
     ws, ws_bytes = _hip.workspace('beer_estep_workspace_bytes', X.dtype,
                                   _hip.COV_CODE[cov_type], D, S, G, X.device)
-    with _f32_path(X):
-        _hip.call('beer_mixtureset_estep', _hip.dtype_code(X.dtype), _hip.COV_CODE[cov_type],
-                  T, D, S, G, _hip.ptr(X), _hip.ptr(E), _hip.ptr(lw), _hip.ptr(lab), st.scale,
-                  None, _hip.ptr(log_norm), _hip.ptr(resps), _hip.ptr(llh_sum), _hip.ptr(ws),
-                  ws_bytes)
+    _hip.call('beer_mixtureset_estep', _hip.dtype_code(X.dtype, _exact(X)),
+              _hip.COV_CODE[cov_type], T, D, S, G, _hip.ptr(X), _hip.ptr(E), _hip.ptr(lw),
+              _hip.ptr(lab), st.scale, None, _hip.ptr(log_norm), _hip.ptr(resps),
+              _hip.ptr(llh_sum), _hip.ptr(ws), ws_bytes)
     return log_norm, resps
 
 
@@ -195,10 +184,9 @@ def normal_accumulate(stats, comp_resps, state_resps, S, G, cov_type, acc=None):
     sr = None if state_resps is None else _hip.on_device(state_resps, X.dtype)
     ws, ws_bytes = _hip.workspace('beer_accumulate_workspace_bytes', X.dtype,
                                   _hip.COV_CODE[cov_type], D, S, G, X.device)
-    with _f32_path(X):
-        _hip.call('beer_normal_accumulate', _hip.dtype_code(X.dtype), _hip.COV_CODE[cov_type],
-                  T, D, S, G, _hip.ptr(X), _hip.ptr(cr), _hip.ptr(sr), _hip.ptr(acc),
-                  _hip.ptr(ws), ws_bytes)
+    _hip.call('beer_normal_accumulate', _hip.dtype_code(X.dtype, _exact(X)),
+              _hip.COV_CODE[cov_type], T, D, S, G, _hip.ptr(X), _hip.ptr(cr), _hip.ptr(sr),
+              _hip.ptr(acc), _hip.ptr(ws), ws_bytes)
     return acc
 
 

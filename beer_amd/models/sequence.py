@@ -193,12 +193,16 @@ class PhoneLoop(HMM):
                              self.categorical.mean_field_factorization())
 
     def phone_counts(self, xi_sum, gamma0, hub_flow=None):
-        'sum_t xi_t[ends, starts] summed over ends + gamma_0[starts] (88-95).'
-        ends, starts = self._index_tensors(xi_sum.device)
-        counts = xi_sum[:, starts][ends, :].sum(dim=0)
+        '''sum_t xi_t[ends, starts] summed over ends + gamma_0[starts] (88-95).
+        `xi_sum` may be None when the graph routes every end -> start arc through
+        its hub: `hub_flow` then holds the whole sum.'''
+        ends, starts = self._index_tensors(gamma0.device)
+        counts = gamma0[starts].to(torch.float64)
+        if xi_sum is not None:
+            counts = counts + xi_sum[:, starts][ends, :].sum(dim=0)
         if hub_flow is not None:
             counts = counts + hub_flow[starts]
-        return counts + gamma0[starts].to(counts.dtype)
+        return counts
 
     def accumulate(self, stats, parent_msg=None):
         retval = super().accumulate(stats, parent_msg)

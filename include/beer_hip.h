@@ -17,8 +17,8 @@
  *     (cross-frame accumulators are fp64 whatever the model dtype is);
  *   - matrices are row-major and dense, no padding;
  *   - `stream` is a hipStream_t (0 = default stream); calls are asynchronous,
- *     never synchronise, never allocate, keep no global state and are
- *     re-entrant per stream;
+ *     never synchronise, never allocate device memory, keep no state between
+ *     calls and are re-entrant per stream;
  *   - return value: 0 on success, BEER_EINVAL for a bad argument, or
  *     -(hipError_t) if a launch failed.  Nothing throws.
  *   - `cov`: BEER_FULL / BEER_DIAG / BEER_ISO selects the layout of the
@@ -51,18 +51,15 @@ extern "C" {
 int beer_hip_version(void);
 int beer_hip_device_count(void);
 
-/* How float32 models multiply on the matrix cores (float64 models always use
- * the exact fp64 MFMA).  BEER_F32_EXACT: v_mfma_f32_16x16x4_f32, bitwise an
- * fmaf chain.  BEER_F32_SPLIT_F16 (default): every fp32 operand split into two
- * fp16 halves, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulation
- * -- product error <= 2^-21 relative (fp32: 2^-24) at 5.3x the MFMA rate.
- * Process-wide; initial value from the environment variable BEER_F32_MODE
- * (exact | split_f16). */
-#define BEER_F32_EXACT 0
-#define BEER_F32_SPLIT_F16 1
-int beer_hip_set_f32_mode(int mode);
-int beer_hip_get_f32_mode(void);
-/* Range check for BEER_F32_SPLIT_F16 on float32 frames X [T, D] (D <= 64):
+/* How float32 models multiply on the matrix cores is chosen PER CALL (float64
+ * models always use the exact fp64 MFMA): the `dtype` argument of
+ * beer_mixtureset_estep and beer_normal_accumulate is BEER_F32 for the default,
+ * split arithmetic -- every fp32 operand split into two fp16 halves, three
+ * v_mfma_f32_16x16x32_f16 per product, fp32 accumulation: product error <= 2^-21
+ * relative (fp32: 2^-24) at 5.3x the MFMA rate -- or BEER_F32 | BEER_EXACT for
+ * v_mfma_f32_16x16x4_f32, bitwise an fmaf chain.  The library keeps no mode. */
+#define BEER_EXACT 0x10
+/* Range check for the split arithmetic on float32 frames X [T, D] (D <= 64):
  * *hazard (device int) = 1 when some dimension's largest magnitude exceeds 2^9
  * times its mean magnitude (or is not finite).  The split path scales every
  * dimension so that its maximum is 2^7; values that far below the maximum
@@ -216,7 +213,7 @@ int beer_mixtureset_estep(int dtype, int cov, int64_t T, int D, int S, int G,
  * has no MFMA implementation.  With `workspace` NULL or too small the calls
  * run the generic kernels -- same results, slower.  The workspace holds no
  * state between calls.  For float32 the size covers both arithmetic variants
- * (beer_hip_set_f32_mode). */
+ * (BEER_EXACT). */
 size_t beer_estep_workspace_bytes(int dtype, int cov, int D, int S, int G);
 size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G);
 
@@ -232,7 +229,7 @@ int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G,
                            size_t workspace_bytes, void* stream);
 
 /* The E-step -> accumulate hand-over of a single mixture (S = 1, float32, split
- * arithmetic: beer_hip_set_f32_mode) without the float32 responsibilities in
+ * arithmetic) without the float32 responsibilities in
  * between.  `packed_resps` (beer_packed_resps_bytes(T, D, K) bytes: a 512-byte
  * header -- the per-dimension frame scales the E-step computed, reused by the
  * accumulation -- then 4 bytes per element with T rounded up to 64 and K to
@@ -367,6 +364,12 @@ typedef struct {
     const beer_graph* graphs;  /* device array of graph descriptors */
     const int32_t* pdf_off;    /* [n_graphs+1] offsets into pdf_ids */
     const int32_t* pdf_ids;    /* concatenated pdf_id_mapping of every graph */
+    /* what the host knows about the `lowdeg` images (0 = unknown: the
+     * one-wave-per-utterance recursion is then not used) */
+    int32_t max_degree;        /* largest in / out degree of their CSRs (>= 1) */
+    int32_t max_hubs;          /* largest n_hubs */
+    int32_t max_hub_members;   /* largest number of sources / destinations of a hub */
+    int32_t reserved;
 } beer_batch;
 
 /* pc_llhs[u][t,s] = scale * pc_all[frame_off[u]+t, pdf_id[s]]: the gather of
@@ -389,11 +392,37 @@ int beer_hmm_gather(int dtype, const beer_batch* batch_h, int S_total,
  * the factorised recursion runs; transition posteriors through a hub are
  * then reported per destination state, summed over the hub's sources, in
  * `hub_flow` ([S] fp64, +=; required whenever xi_sum is given) instead of as
- * individual xi_sum entries. */
+ * individual xi_sum entries.  `hub_ws` (nullable; fp64 scratch, 4 per frame of
+ * the batch) lets low-degree graphs of at most 256 states run one WAVE per
+ * utterance (no workgroup barrier in the recursion: about 4x faster). */
 int beer_hmm_forward_backward(int dtype, const beer_batch* batch_h,
-                              const void* pc_llhs, double* alpha_ws, void* gamma,
-                              double* xi_sum, double* gamma0_sum, double* hub_flow,
-                              void* lognorm_mean, void* stream);
+                              const void* pc_llhs, double* alpha_ws, double* hub_ws,
+                              void* gamma, double* xi_sum, double* gamma0_sum,
+                              double* hub_flow, void* lognorm_mean, void* stream);
+
+/* The HMM inference step of a whole shard in ONE launch, for batches whose
+ * graphs all carry a `lowdeg` image with at most one hub of at most 64 sources /
+ * destinations and have at most 256 states (phone loops with their pivot declared
+ * as a hub, alignment chains): the gather of
+ * beer_hmm_gather, the recursions of beer_hmm_forward_backward (one wave per
+ * utterance) and the scatter of beer_hmm_scatter without the packed pc_llhs /
+ * gamma arrays in between.
+ *   pc_all       [n_frames, S_total] per-pdf log-likelihoods (read through the
+ *                pdf ids, times `scale`: modelset.py:140-146, hmm.py:79)
+ *   state_resps  [n_frames, S_total]: scale * gamma at the pdf ids
+ *                (modelset.py:148-154, hmm.py:95).  atomic_out = 0: plain stores --
+ *                every graph's pdf ids are distinct; the caller zero-fills the
+ *                array unless they also cover 0 .. S_total-1.  atomic_out != 0:
+ *                added atomically into the zero-filled array (repeated ids).
+ *   utt_llh      (nullable, [nutt] fp64, +=) sum_t sum_s gamma * scale * pc
+ *                (hmm.py:87);  gamma0_sum, hub_flow: as above (graph 0 for all).
+ *   alpha_ws     fp64 scratch, sum_u T_u * S_u;  hub_ws: fp64 scratch, n_frames.
+ * EINVAL when the batch is not of that kind (use the three calls instead). */
+int beer_hmm_posteriors_fused(int dtype, const beer_batch* batch_h, int S_total,
+                              const void* pc_all, double scale, double* alpha_ws,
+                              double* hub_ws, void* state_resps, int atomic_out,
+                              double* gamma0_sum, double* hub_flow, double* utt_llh,
+                              void* stream);
 
 /* Viterbi + backtrack, CompiledGraph.best_path (beer/graph.py:329-344):
  * first-index tie-break, -inf safe, int64 state path per frame (packed like

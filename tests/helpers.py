@@ -61,3 +61,15 @@ def assert_close(a, b, tol, what=''):
     assert a.shape == b.shape, f'{what}: shape {a.shape} != {b.shape}'
     err = rel_err(a, b)
     assert err <= tol, f'{what}: rel err {err:.3e} > {tol:.1e}'
+
+
+def assert_within_f32_band(got, truth, ref32, what='', tol=1e-5):
+    '''float32 results against the fp64 truth of the same float32 inputs: within
+    north_star's 1e-5, or -- where float32 arithmetic itself cannot do that --
+    within the error of the reference's own float32 op sequence (`ref32`: the
+    oracle run in float32, or the reference's float32 golden).'''
+    band = max(tol, rel_err(ref32, truth))
+    err = rel_err(got, truth)
+    assert err <= band, f'{what}: rel err {err:.3e} > band {band:.3e} (reference fp32: ' \
+                        f'{rel_err(ref32, truth):.3e})'
+    return err, band

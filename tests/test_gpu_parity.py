@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import COV_OF, assert_close, dist_cls, load_golden, orc, std_params
+from helpers import (COV_OF, assert_close, assert_within_f32_band, dist_cls, load_golden, orc,
+                     std_params)
 
 pytestmark = pytest.mark.gpu
 
@@ -407,6 +408,86 @@ def test_c2_shape_one_step_vs_oracle(dtype, tol):
         assert_close(got.reshape(ref.shape), ref, tol * 10, 'posterior ' + n)
 
 
+def _oracle_gmm_chunked(Xn, cov, post, prior, w_post, w_prior, chunk=8192):
+    'orc.gmm_elbo_step over one utterance of any length, a chunk of frames at a time.'
+    per_frame, acc_n, acc_w, kl = 0., 0., 0., None
+    for lo in range(0, len(Xn), chunk):
+        r = orc.gmm_elbo_step(Xn[lo:lo + chunk], cov, post, prior, w_post, w_prior)
+        per_frame += r['per_frame'].sum()
+        acc_n, acc_w, kl = acc_n + r['acc_normal'], acc_w + r['acc_weights'], r['kl']
+    return dict(value=per_frame - kl, acc_normal=acc_n, acc_weights=acc_w, kl=kl)
+
+
+@pytest.mark.parametrize('cov,K', [('full', 256), ('diagonal', 256), ('full', 160)])
+def test_bench_kernel_variant_vs_oracle(cov, K):
+    '''The kernels `bench.py` times -- float32, K = 256 full covariance, D = 40, the
+    fp16-split E-step with the components split over two waves writing packed
+    responsibilities (`beer_mixture_estep_packed`) + `beer_normal_accumulate_packed`
+    -- against the numpy oracle on the same 65,536 frames: ELBO, accumulated
+    statistics and the posterior after one step, at north_star's 1e-5.
+    Reference: beer/models/mixture.py:70-102.'''
+    from beer_amd import kernels
+    D, T = 40, 65536
+    rng = np.random.RandomState(3)
+    means = rng.randn(K, D) * 2
+    A = rng.randn(D, D) * .2 + np.eye(D)
+    Xn = (means[rng.randint(0, K, T)] + rng.randn(T, D) @ A).astype(np.float32)
+    X = torch.from_numpy(Xn)
+    torch.manual_seed(7)
+    c0 = torch.from_numpy(np.cov(Xn.T)).float()
+    ns = beer.NormalSet.create(X.mean(0), c0 if cov == 'full' else c0.diag(), size=K,
+                               prior_strength=1., noise_std=1., cov_type=cov)
+    model = beer.Mixture.create(ns, prior_strength=1.).to(DEV)
+    p0, p1 = params_of(model)
+    as64 = lambda d: [npy(getattr(d.params, n)).astype(np.float64) for n in d._std_params_def]
+    post, prior = as64(p0.posterior), as64(p0.prior)
+    (w_post,), (w_prior,) = as64(p1.posterior), as64(p1.prior)
+    truth = _oracle_gmm_chunked(Xn.astype(np.float64), cov, post, prior, w_post, w_prior)
+    # the reference's own float32 op sequence on the same inputs: where float32
+    # arithmetic cannot reach 1e-5, its error is the band (assert_within_f32_band)
+    f32 = lambda arrs: [a.astype(np.float32) for a in arrs]
+    ref32 = _oracle_gmm_chunked(Xn, cov, f32(post), f32(prior), w_post.astype(np.float32),
+                                w_prior.astype(np.float32))
+    calls = {'estep': 0, 'acc': 0}
+    orig_e, orig_call = kernels.mixture_estep_packed, kernels._hip.call
+
+    def spy_e(*a, **kw):
+        calls['estep'] += 1
+        return orig_e(*a, **kw)
+
+    def spy_call(name, *a):
+        calls['acc'] += name == 'beer_normal_accumulate_packed'
+        return orig_call(name, *a)
+    kernels.mixture_estep_packed, kernels._hip.call = spy_e, spy_call
+    try:
+        optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), 1.)
+        optim.init_step()
+        elbo = beer.accumulate_elbo(model, (X.to(DEV), [T]), datasize=T)
+    finally:
+        kernels.mixture_estep_packed, kernels._hip.call = orig_e, orig_call
+    assert calls['estep'] == 1 and calls['acc'] == 1, calls      # the packed kernels ran
+    assert beer.get_f32_mode() == 'split_f16'
+    assert_close(float(elbo), truth['value'], 1e-5, 'elbo')
+    acc = npy(elbo._acc_stats[p0]).astype(np.float64)
+    assert_within_f32_band(acc, truth['acc_normal'], ref32['acc_normal'], 'acc normal')
+    assert_within_f32_band(npy(elbo._acc_stats[p1]).astype(np.float64), truth['acc_weights'],
+                           ref32['acc_weights'], 'acc weights')
+    elbo.backward()
+    optim.step()
+    new_post, new_w = orc.gmm_mstep(cov, post, prior, w_post, w_prior, truth['acc_normal'],
+                                    truth['acc_weights'])
+    ref_post, ref_w = orc.gmm_mstep(cov, f32(post), f32(prior), w_post.astype(np.float32),
+                                    w_prior.astype(np.float32),
+                                    ref32['acc_normal'].astype(np.float32),
+                                    ref32['acc_weights'].astype(np.float32))
+    for n, ref, r32 in zip(p0.posterior._std_params_def, new_post, ref_post):
+        got = npy(getattr(p0.posterior.params, n)).astype(np.float64)
+        assert_within_f32_band(got.reshape(ref.shape), ref, r32.reshape(ref.shape), 'posterior ' + n)
+    assert_within_f32_band(
+        npy(p1.posterior.params.concentrations).astype(np.float64).reshape(new_w.shape), new_w,
+        ref_w.reshape(new_w.shape), 'posterior weights')
+
+
 def test_full_size_properties_linearity_and_monotone_elbo():
     '''BASELINE config-2 size per GPU-second budget: 262,144 frames, K=256,
     D=40 fp32.  (i) accumulating two halves == accumulating the whole,
@@ -540,6 +621,76 @@ def test_c3_shape_batched_phone_loop_vs_oracle(cov, dtype, tol):
     assert_close(npy(elbo._acc_stats[ms.modelset.means_precisions]), acc_n, tol * 10, 'acc normal')
     assert_close(npy(elbo._acc_stats[ms.categoricalset.weights]), acc_w, tol * 10, 'acc weights')
     assert_close(npy(elbo._acc_stats[cat]), counts, tol * 10, 'phone counts')
+
+
+def _oracle_phone_loop_shard(ploop, utts, N, with_counts=True):
+    '''Sum of orc.hmm_elbo_step over utterances (free phone loop): value and
+    statistics (phone counts need the [T-1, S, S] transition posteriors: most of
+    the oracle's time at S = 120).'''
+    groups = _oracle_groups(ploop)
+    gr = ploop.graph
+    graph = dict(init=npy(gr.init_log_probs).astype(np.float64),
+                 final=npy(gr.final_log_probs).astype(np.float64),
+                 trans=npy(gr.trans_log_probs).astype(np.float64),
+                 order=np.asarray(gr.pdf_id_mapping))
+    cat = ploop.categorical.weights
+    extra_kl = orc.dir_kl(npy(cat.posterior.params.concentrations).astype(np.float64),
+                          npy(cat.prior.params.concentrations).astype(np.float64)).sum()
+    value, acc_n, acc_w, counts = 0., 0., 0., 0.
+    starts, ends = list(ploop.start_pdf.values()), list(ploop.end_pdf.values())
+    for x in utts:
+        r = orc.hmm_elbo_step(x.astype(np.float64), groups, graph, datasize=N,
+                              trans_posteriors=with_counts, extra_kl=extra_kl)
+        value += r['value']
+        acc_n, acc_w = acc_n + r['acc'][0][0], acc_w + r['acc'][0][1]
+        if with_counts:
+            counts = counts + orc.cat_suffstats(orc.phone_counts(
+                r['trans_resps'], r['resps'], starts, ends).reshape(1, -1)).sum(0)
+    return value, acc_n, acc_w, counts
+
+
+@pytest.mark.parametrize('cov,dtype,nutt,tol', [('diagonal', torch.float64, 3, 1e-8),
+                                                ('full', torch.float64, 3, 1e-8),
+                                                ('diagonal', torch.float32, 4, 1e-5),
+                                                ('full', torch.float32, 4, 1e-5),
+                                                ('diagonal', torch.float32, 56, 1e-5),
+                                                ('full', torch.float32, 56, 1e-5)])
+def test_c3_real_dimensions_phone_loop_vs_oracle(cov, dtype, nutt, tol):
+    '''BASELINE config 3 at its real dimensions -- 40 phones x 3 states (S = 120,
+    a 40-phone hub), G = 16 Gaussians per state (K = 1920: 8 component chunks),
+    D = 40 -- utterances of ~300 frames through the batched E-step vs the oracle's
+    per-utterance loop (beer/models/hmm.py:73-100, mixtureset.py:85-112).  The
+    56-utterance float32 cases (> 16384 frames) take the fp16-split matrix kernels
+    (phone counts not re-checked there: they do not depend on the emission
+    kernels' arithmetic), the 4-utterance ones the exact float32 kernels.'''
+    P, G, D = 40, 16, 40
+    ploop = _phone_loop(P, G, D, cov, dtype, seed=33)
+    rng = np.random.RandomState(12)
+    lens = [int(n) for n in rng.randint(250, 350, nutt)]
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    # frames drawn around the model's own component means: responsibilities and
+    # state posteriors are neither flat nor one-hot
+    ns = ploop.modelset.original_modelset.modelsets[0].modelset
+    mu = npy(ns.means_precisions.posterior.params.mean).astype(np.float64)
+    utts = []
+    for T in lens:
+        seq = np.repeat(rng.randint(0, P, T // 30 + 1), 30)[:T]
+        comp = 16 * (3 * seq + rng.randint(0, 3, T)) + rng.randint(0, G, T)
+        utts.append((mu[comp] + rng.randn(T, D) * 1.5).astype(npdt))
+    N = 10_000_000
+    value, acc_n, acc_w, counts = _oracle_phone_loop_shard(ploop, utts, N, with_counts=nutt < 10)
+    if dtype == torch.float32:
+        from beer_amd import _hip
+        X = torch.cat([tt(x) for x in utts])
+        assert _hip.f32_split_ok(X) == (sum(lens) >= _hip.SPLIT_MIN_FRAMES)
+    elbo = beer.accumulate_elbo(ploop, [tt(x) for x in utts], datasize=N)
+    assert_close(float(elbo), value, tol, 'elbo')
+    ms = ploop.modelset.original_modelset.modelsets[0]
+    cat = ploop.categorical.weights
+    assert_close(npy(elbo._acc_stats[ms.modelset.means_precisions]), acc_n, tol * 10, 'acc normal')
+    assert_close(npy(elbo._acc_stats[ms.categoricalset.weights]), acc_w, tol * 10, 'acc weights')
+    if nutt < 10:
+        assert_close(npy(elbo._acc_stats[cat]), counts, tol * 10, 'phone counts')
 
 
 @pytest.mark.parametrize('cov', ['diagonal', 'isotropic', 'full'])

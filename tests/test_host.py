@@ -42,7 +42,7 @@ def test_struct_layouts_match_header():
     # 4 int32 + 14 pointers; 6 int32 + 6 pointers (LP64)
     assert ctypes.sizeof(_hip.Graph) == 16 + 15 * 8
     assert ctypes.sizeof(_hip.GraphLowDeg) == 8 + 14 * 8
-    assert ctypes.sizeof(_hip.Batch) == 24 + 6 * 8
+    assert ctypes.sizeof(_hip.Batch) == 24 + 6 * 8 + 16
     assert ctypes.sizeof(_hip.FeaConf) == 8 * 4 + 3 * 8 + 6 * 8
 
 
@@ -294,11 +294,57 @@ def test_native_compile_equals_python_oracle_and_batch_builder():
         beer.graph.compile_alignments([[]], units)                  # empty transcription
 
 
-def test_f32_mode_switch():
+def test_f32_mode_is_a_per_call_flag_not_library_state():
+    '''The library exports no mode setter: the arithmetic of float32 products is
+    the BEER_EXACT bit of each call's `dtype`; the host-side preference lives in
+    beer_amd._hip (initial value from BEER_F32_MODE).'''
     lib = ctypes.CDLL(_hip.LIB_PATH)
-    assert lib.beer_hip_set_f32_mode(7) == _hip.EINVAL
+    assert not hasattr(lib, 'beer_hip_set_f32_mode')
+    assert _hip.dtype_code(torch.float32) == _hip.F32
+    assert _hip.dtype_code(torch.float32, exact=True) == _hip.F32 | _hip.EXACT
+    assert _hip.dtype_code(torch.float64, exact=True) == _hip.F64
     old = _hip.get_f32_mode()
     for mode in ('exact', 'split_f16'):
         _hip.set_f32_mode(mode)
         assert _hip.get_f32_mode() == mode
+    with pytest.raises(ValueError):
+        _hip.set_f32_mode('bf16')
     _hip.set_f32_mode(old)
+    with _hip.exact_f32():
+        assert _hip.get_f32_mode() == 'exact'
+    assert _hip.get_f32_mode() == old
+
+
+def test_range_memo_is_keyed_on_the_tensor_not_its_address():
+    '''a verdict remembered by (address, shape, version) would be
+    handed to a different minibatch that the allocator placed at the same
+    address.  The memo lives on the tensor object (its base for views).'''
+    calls = []
+    orig = _hip.call
+
+    def fake(name, *args):
+        assert name == 'beer_f32_split_hazard'
+        calls.append(name)
+    a = torch.zeros(_hip.SPLIT_MIN_FRAMES + 8, 4)
+    flag_value = [0]
+
+    class _Flag:
+        def item(self):
+            return flag_value[0]
+    real_empty = torch.empty
+    _hip.call = fake
+    torch.empty = lambda *s, **kw: _Flag() if kw.get('dtype') == torch.int32 else \
+        real_empty(*s, **{k: v for k, v in kw.items() if k != 'device'})
+    _hip.ptr, real_ptr = (lambda t: None), _hip.ptr
+    try:
+        assert _hip.f32_split_ok(a) and len(calls) == 1
+        assert _hip.f32_split_ok(a) and len(calls) == 1                 # remembered
+        assert _hip.f32_split_ok(a[8:]) and len(calls) == 2             # another view: checked
+        assert _hip.f32_split_ok(a[8:]) and len(calls) == 2             # ... once
+        a.add_(1.)                                                      # new version
+        assert _hip.f32_split_ok(a) and len(calls) == 3
+        b = torch.zeros_like(a)                     # same shape, version 0: a new object
+        flag_value[0] = 1
+        assert not _hip.f32_split_ok(b) and len(calls) == 4
+    finally:
+        _hip.call, torch.empty, _hip.ptr = orig, real_empty, real_ptr
