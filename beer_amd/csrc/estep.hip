@@ -535,6 +535,26 @@ int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float*
                                        workspace_bytes, as_stream(stream));
 }
 
+size_t beer_accumulate_fused_workspace_bytes(int cov, int D, int S, int G) {
+    if (cov < 0 || cov > 2 || D < 1 || S < 1 || G < 1) return 0;
+    return beer_mfma::accf_workspace_bytes(cov, D, S, G);
+}
+
+int beer_mixtureset_accumulate_fused(int cov, int64_t T, int D, int S, int G, const float* X,
+                                     const float* exp_stats, const float* log_weights,
+                                     const float* log_norm, const float* state_resps,
+                                     double* acc, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    BEER_REQUIRE(T >= 0 && D >= 1 && S >= 1 && G >= 1 && cov >= 0 && cov <= 2);
+    BEER_REQUIRE(beer_mfma::supported_accf(cov, D, S, G));
+    BEER_REQUIRE(workspace && workspace_bytes >= beer_mfma::accf_workspace_bytes(cov, D, S, G));
+    if (T == 0) return BEER_OK;
+    BEER_REQUIRE(X && exp_stats && log_norm && acc);
+    return beer_mfma::acc_fused_f16x3(cov, T, D, S, G, X, exp_stats, log_weights, log_norm,
+                                      state_resps, acc, workspace, workspace_bytes,
+                                      as_stream(stream));
+}
+
 size_t beer_packed_resps_bytes(int64_t T, int D, int K) {
     return T < 0 || D < 1 || D > 64 || K < 1 ? 0 : beer_mfma::packed_resps_bytes(T, D, K);
 }

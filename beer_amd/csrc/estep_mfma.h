@@ -41,6 +41,16 @@ size_t acc16p_workspace_bytes(int cov, int64_t T, int D, int K);
 int acc_f16x3_packed(int cov, int64_t T, int D, int K, const float* X, const void* Rimg,
                      double* acc, void* ws, size_t ws_bytes, hipStream_t s);
 
+// Mixture sets with diagonal / isotropic Gaussians: accumulation that recomputes the
+// component responsibilities from the frames and the per-state log-normalisers
+// [T, S] of the E-step (times the state responsibilities sr [T, S], nullable)
+// instead of reading them from memory (estep_f16.hip: accf_kernel).
+bool supported_accf(int cov, int D, int S, int G);
+size_t accf_workspace_bytes(int cov, int D, int S, int G);
+int acc_fused_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
+                    const float* logw, const float* log_norm, const float* sr, double* acc,
+                    void* ws, size_t ws_bytes, hipStream_t s);
+
 int estep_f32(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
               const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
               size_t ws_bytes, hipStream_t s);

@@ -182,17 +182,21 @@ def _mixture_batch(model, X, lengths, datasize, labels, max_frames):
     return value_terms, out
 
 
-def _emission_estep(groups, stats, dtype):
-    'pc_all [T, S_total] + per-group component responsibilities.'
+def _emission_estep(groups, stats, dtype, for_accumulate=False):
+    '''pc_all [T, S_total] + per group what its accumulation needs: the component
+    responsibilities [T, S*G], or -- where the accumulation recomputes them from
+    the frames (`kernels.fused_accumulate_ok`) -- the group's log-normalisers.'''
     cols, comps = [], []
     for grp, S, G in groups:
         ns = _normalset(grp)
         lw = grp._log_weights() if isinstance(grp, MixtureSet) else None
+        fused = for_accumulate and G > 1 and \
+            kernels.fused_accumulate_ok(FrameStats(stats.data, ns.cov_type), S, G, ns.cov_type)
         log_norm, resps = kernels.mixtureset_estep(
             stats, ns.means_precisions.natural_form(), lw, S, G, ns.cov_type,
-            want_resps=False)
+            want_resps=for_accumulate and G > 1 and not fused)
         cols.append(log_norm)
-        comps.append(resps)
+        comps.append(('fused', log_norm, lw) if fused else resps)
     pc_all = cols[0] if len(cols) == 1 else torch.cat(cols, dim=-1)
     return pc_all, comps
 
@@ -217,7 +221,11 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
                                             dtype=torch.float64), dev)
     xi_tot = g0_tot = flow_tot = None
     max_S = model.graph.n_states if free_loop else max(g.n_states for g in graphs)
-    bpf = (K_max + 2 * S_total) * X.element_size() + max_S * (3 * X.element_size() + 8)
+    # scratch per frame: the responsibilities of the groups whose accumulation does
+    # not recompute them, per-state likelihoods / posteriors, the trellis
+    K_scratch = sum(S * G for grp, S, G in groups if G > 1 and not kernels.fused_accumulate_ok(
+        FrameStats(X, _normalset(grp).cov_type), S, G, _normalset(grp).cov_type))
+    bpf = (K_scratch + 2 * S_total) * X.element_size() + max_S * (3 * X.element_size() + 8)
     for run in _sub_batches(lengths, bpf, max_frames):
         done = _throttle()
         f0, f1 = int(off[run[0]]), int(off[run[-1] + 1])
@@ -225,7 +233,7 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
         # the emission E-step is queued first: building the batch descriptor (host
         # work + one asynchronous copy from pinned memory) overlaps with it
         stats = FrameStats(X[f0:f1], _normalset(groups[0][0]).cov_type)
-        pc_all, comps = _emission_estep(groups, stats, dtype)
+        pc_all, comps = _emission_estep(groups, stats, dtype, for_accumulate=True)
         if free_loop:
             batch = _cached_batch(model.graph, run_lengths, dtype)
         else:
@@ -275,6 +283,11 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
             gstats = FrameStats(X[f0:f1], ns.cov_type)
             if G == 1:
                 kernels.normal_accumulate(gstats, sr_g, None, S, 1, ns.cov_type, acc=acc)
+            elif isinstance(comp, tuple):
+                # responsibilities recomputed inside the accumulation: no [T, K] matrix
+                kernels.mixtureset_accumulate_fused(
+                    gstats, ns.means_precisions.natural_form(), comp[2], comp[1], sr_g, S, G,
+                    ns.cov_type, acc=acc)
             else:
                 kernels.normal_accumulate(gstats, comp, sr_g, S, G, ns.cov_type, acc=acc)
         done.record()

@@ -61,13 +61,15 @@ def mixtureset_estep(stats, exp_stats, log_weights, S, G, cov_type, labels=None,
     if E.shape[0] != K:
         raise ValueError(f'{E.shape[0]} Gaussians for {S} x {G} mixture components')
     log_norm = torch.empty(T, S, dtype=X.dtype, device=X.device)
-    need_resps = want_resps or G > 1
+    ws, ws_bytes = _hip.workspace('beer_estep_workspace_bytes', X.dtype,
+                                  _hip.COV_CODE[cov_type], D, S, G, X.device)
+    # the generic kernels normalise in place in the responsibilities buffer; the
+    # matrix-core kernels (workspace given) keep them in registers
+    need_resps = want_resps or (G > 1 and (ws is None or labels is not None or st.scale != 1.0))
     resps = torch.empty(T, K, dtype=X.dtype, device=X.device) if need_resps else None
     lab = None
     if labels is not None:
         lab = _hip.on_device(torch.as_tensor(labels)).to(torch.int64).contiguous()
-    ws, ws_bytes = _hip.workspace('beer_estep_workspace_bytes', X.dtype,
-                                  _hip.COV_CODE[cov_type], D, S, G, X.device)
     _hip.call('beer_mixtureset_estep', _hip.dtype_code(X.dtype, _exact(X)),
               _hip.COV_CODE[cov_type], T, D, S, G, _hip.ptr(X), _hip.ptr(E), _hip.ptr(lw),
               _hip.ptr(lab), st.scale, None, _hip.ptr(log_norm), _hip.ptr(resps),
@@ -187,6 +189,49 @@ def normal_accumulate(stats, comp_resps, state_resps, S, G, cov_type, acc=None):
     _hip.call('beer_normal_accumulate', _hip.dtype_code(X.dtype, _exact(X)),
               _hip.COV_CODE[cov_type], T, D, S, G, _hip.ptr(X), _hip.ptr(cr), _hip.ptr(sr),
               _hip.ptr(acc), _hip.ptr(ws), ws_bytes)
+    return acc
+
+
+def fused_accumulate_ok(stats, S, G, cov_type):
+    '''True when `mixtureset_accumulate_fused` takes the call: float32 frames on the
+    fp16-split path, unscaled, diagonal / isotropic Gaussians (few statistics per
+    Gaussian) -- the E-step then needs to leave no responsibilities behind.'''
+    st = _frames(stats)
+    X = st.data
+    if st.scale != 1.0 or not _hip.f32_split_ok(X):
+        return False
+    # the E-step that leaves the log-normalisers must be the matrix-core one: the
+    # recomputed logits then carry the same roundings as the normalisers (against the
+    # generic kernels' logits a 1e-5 mismatch does not cancel)
+    code = _hip.COV_CODE[cov_type]
+    return _hip.lib().beer_accumulate_fused_workspace_bytes(code, X.shape[1], S, G) > 0 and \
+        _hip.lib().beer_estep_workspace_bytes(_hip.F32, code, X.shape[1], S, G) > 0
+
+
+def mixtureset_accumulate_fused(stats, exp_stats, log_weights, log_norm, state_resps, S, G,
+                                cov_type, acc=None):
+    '''acc[k,:] += sum_t exp(l[t,k] - log_norm[t, k // G]) * state_resps[t, k // G] *
+    phi(x_t), the component logits l recomputed from the frames (no [T, K] matrix).'''
+    st = _frames(stats)
+    X = st.data
+    T, D = X.shape
+    K = S * G
+    E = _hip.on_device(exp_stats, X.dtype)
+    lw = None if log_weights is None else _hip.on_device(log_weights, X.dtype)
+    ln = _hip.on_device(log_norm, X.dtype)
+    sr = None if state_resps is None else _hip.on_device(state_resps, X.dtype)
+    if tuple(ln.shape) != (T, S) or (sr is not None and tuple(sr.shape) != (T, S)):
+        raise ValueError(f'log_norm / state_resps must be [{T}, {S}]')
+    if acc is None:
+        acc = torch.zeros(K, st.shape[1], dtype=torch.float64, device=X.device)
+    code = _hip.COV_CODE[cov_type]
+    nbytes = _hip.lib().beer_accumulate_fused_workspace_bytes(code, D, S, G)
+    key = ('accf', code, D, S, G, X.device, torch.cuda.current_stream().cuda_stream)
+    ws = _hip._workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _hip._workspaces[key] = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+    _hip.call('beer_mixtureset_accumulate_fused', code, T, D, S, G, _hip.ptr(X), _hip.ptr(E),
+              _hip.ptr(lw), _hip.ptr(ln), _hip.ptr(sr), _hip.ptr(acc), _hip.ptr(ws), nbytes)
     return acc
 
 

@@ -273,6 +273,30 @@ int beer_pack_resps(int64_t T, int D, int S, int G, const float* X,
 int beer_unpack_resps(int64_t T, int K, const void* packed_resps, float* resps,
                       void* stream);
 
+/* The accumulation of a mixture set WITHOUT its responsibilities in memory
+ * (float32, split arithmetic; diagonal / isotropic covariances, D <= 64: few
+ * statistics per Gaussian).  beer_mixtureset_estep is then called with
+ * comp_resps = NULL and leaves only the per-state log-normalisers `log_norm`
+ * [T, S]; after the forward-backward pass this call recomputes the component
+ * logits on the matrix cores, forms
+ *     r[t,k] * state_resps[t, k / G] = exp(l[t,k] - log_norm[t, k / G]) * state_resps[t, k / G]
+ * in registers and multiplies them with the statistics of the frames at once:
+ *     acc[k,:] += sum_t r[t,k] state_resps[t, k / G] phi(x_t)            (fp64, +=)
+ * -- MixtureSet.accumulate (beer/models/mixtureset.py:100-112) over
+ * NormalSet.accumulate (normalset.py:121-123) with the responsibilities of
+ * mixtureset.py:85-98 recomputed instead of cached.  `exp_stats`, `log_weights`
+ * ([S,G], nullable) as given to beer_mixtureset_estep; `state_resps` [T,S]
+ * nullable (= 1).  At K = 1920 Gaussians this removes 15.4 GB of traffic per
+ * million frames (the [T, K] matrix written and read back).
+ * EINVAL: full covariance, D > 64, workspace NULL / too small. */
+size_t beer_accumulate_fused_workspace_bytes(int cov, int D, int S, int G);
+int beer_mixtureset_accumulate_fused(int cov, int64_t T, int D, int S, int G,
+                                     const float* X, const float* exp_stats,
+                                     const float* log_weights, const float* log_norm,
+                                     const float* state_resps, double* acc,
+                                     void* workspace, size_t workspace_bytes,
+                                     void* stream);
+
 /* Mixture-weight statistics from the accumulated Gaussian statistics: the
  * zero-order count is N_k = -2 * acc[k, Q-2]; out[s,g] = N_{s,g} for
  * g < G-1 and out[s,G-1] = sum_g N_{s,g} -- the "last column <- row sum"

@@ -1062,6 +1062,51 @@ def test_packed_hand_over_random_shapes():
         assert float((packed.unpack().double() - r64).abs().max()) < 1e-4, what
 
 
+@pytest.mark.parametrize('cov,S,G,D,T', [('diagonal', 120, 16, 40, 20011), ('diagonal', 7, 4, 13, 17000),
+                                           ('isotropic', 30, 8, 40, 16500), ('diagonal', 3, 32, 64, 16385),
+                                           ('diagonal', 1, 200, 24, 18000), ('diagonal', 50, 2, 7, 16400),
+                                           ('diagonal', 9, 128, 39, 16511)])
+def test_fused_accumulation_recomputes_the_responsibilities(cov, S, G, D, T):
+    '''beer_mixtureset_accumulate_fused (no [T, K] matrix: the logits are recomputed
+    from the frames and normalised with the E-step's log-normalisers) against the
+    fp64 kernels -- E-step with responsibilities + accumulation -- on the same
+    inputs: MixtureSet.accumulate, beer/models/mixtureset.py:100-112.'''
+    from beer_amd import kernels
+    torch.manual_seed(S + G + D)
+    K = S * G
+    mu = torch.randn(K, D, dtype=torch.float64) * 1.5
+    X = (mu[torch.randint(0, K, (T,))] + torch.randn(T, D, dtype=torch.float64)).to(DEV)
+    ns = beer.NormalSet.create(torch.zeros(D), torch.ones(D), size=K, prior_strength=1.,
+                               noise_std=1.5, cov_type=cov)
+    ms = beer.MixtureSet.create(S, ns, prior_strength=1.).double().to(DEV)
+    E64, lw64 = ns.means_precisions.natural_form(), ms._log_weights()
+    sr64 = torch.rand(T, S, dtype=torch.float64, device=DEV)
+    sr64 = sr64 * (torch.rand(T, S, dtype=torch.float64, device=DEV) < .3)     # sparse posteriors
+    st64 = beer.FrameStats(X, cov)
+    _, r64 = kernels.mixtureset_estep(st64, E64, lw64, S, G, cov)
+    acc64 = kernels.normal_accumulate(st64, r64, sr64, S, G, cov)
+    st32 = beer.FrameStats(X.float(), cov)
+    assert kernels.fused_accumulate_ok(st32, S, G, cov)
+    ln32, none = kernels.mixtureset_estep(st32, E64.float(), lw64.float(), S, G, cov,
+                                          want_resps=False)
+    assert none is None
+    for state in (sr64.float(), None):
+        got = kernels.mixtureset_accumulate_fused(st32, E64.float(), lw64.float(), ln32, state, S,
+                                                  G, cov)
+        ref = acc64 if state is not None else kernels.normal_accumulate(st64, r64, None, S, G, cov)
+        err = float((got - ref).abs().max() / ref.abs().max())
+        # yardstick: the two-call float32 path (responsibilities through memory)
+        _, r32 = kernels.mixtureset_estep(st32, E64.float(), lw64.float(), S, G, cov)
+        two = kernels.normal_accumulate(st32, r32, state, S, G, cov)
+        err2 = float((two - ref).abs().max() / ref.abs().max())
+        assert bool(torch.isfinite(got).all())
+        assert err <= max(2e-6, 3. * err2), (cov, S, G, D, err, err2)
+    # += semantics
+    again = kernels.mixtureset_accumulate_fused(st32, E64.float(), lw64.float(), ln32, None, S, G,
+                                                cov, acc=got.clone())
+    torch.testing.assert_close(again, 2 * got, rtol=1e-9, atol=1e-9 * float(got.abs().max()))
+
+
 @pytest.mark.parametrize('cov,S,G,D', [('full', 12, 16, 24), ('full', 5, 64, 30), ('full', 9, 12, 40),
                                          ('diagonal', 30, 16, 40), ('full', 1, 200, 24)])
 def test_pack_resps_and_repacked_accumulation(cov, S, G, D):
