@@ -276,7 +276,7 @@ __device__ __forceinline__ void split8(const f32x4& p0, const f32x4& p1, h8& hi,
 // ---------------------------------------------------------------------------
 // SQ = false: no "square" slabs in the table (full covariance), the per-product
 // select between x_j^2 and x_a x_j drops out of the A-fragment arithmetic.
-template <int NT, int MT, int GQ, bool PACKED, int KS = 1, bool SQ = true>
+template <int NT, int MT, int GQ, bool PACKED, int KS = 1, bool SQ = true, bool LNO = false>
 __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nk,
     const float* __restrict__ X, const _Float16* __restrict__ Pall,
@@ -465,12 +465,12 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
         softmax_epilogue_pair<NT, MT>(acc, fb, nframes, kbase, K, i, g, lane, wave, xch, resps,
                                       log_norm, llh_sum);
     } else {
-        softmax_epilogue<float, NT, MT, GQ, PACKED>(acc, fb, nframes, kbase, K, S, G, gl, jw, i, g,
-                                                    lane, resps, log_norm, llh_sum);
+        softmax_epilogue<float, NT, MT, GQ, PACKED, LNO>(acc, fb, nframes, kbase, K, S, G, gl, jw, i,
+                                                         g, lane, resps, log_norm, llh_sum);
     }
 }
 
-template <int NT, int MT, int GQ, bool PACKED = false, int KS = 1, bool SQ = true>
+template <int NT, int MT, int GQ, bool PACKED = false, int KS = 1, bool SQ = true, bool LNO = false>
 int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nchunks, int nk,
                  const float* X, const _Float16* P, const float* inv_scale, const float* sc,
                  const int* tab, float* resps, float* log_norm, double* llh_sum, hipStream_t s,
@@ -480,7 +480,7 @@ int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, in
     const size_t lds = (size_t)FB * LD * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int) +
                        (KS == 2 ? 8 * 16 * MT * sizeof(float) : 0);
     const int64_t blocks = (nframes + FB - 1) / FB;
-    hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ, PACKED, KS, SQ>), dim3((unsigned)blocks, (unsigned)nchunks),
+    hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ, PACKED, KS, SQ, LNO>), dim3((unsigned)blocks, (unsigned)nchunks),
                        dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nk, X, P, inv_scale,
                        sc, tab, resps, log_norm, llh_sum, xt_out, xt_floats);
     BEER_LAUNCH_CHECK();
@@ -1667,6 +1667,19 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
         return launch_llh16<8, 4, 2, false, 2, false>(nframes, D, K, S, G, gl, jw, nchunks, nk, X,
                                                       P, inv_scale, sc, tab, resps, log_norm,
                                                       llh_sum, s);
+    }
+    if (!resps && jw == 4) {
+        // log-normalisers only (the accumulation recomputes the responsibilities)
+#define BEER_LLH16N(GQ_)                                                                          \
+    return launch_llh16<16, 2, GQ_, false, 1, true, true>(nframes, D, K, S, G, gl, jw, nchunks,   \
+                                                          nk, X, P, inv_scale, sc, tab, resps,    \
+                                                          log_norm, llh_sum, s)
+        switch (gq) {
+            case 1: BEER_LLH16N(1);
+            case 2: BEER_LLH16N(2);
+            default: BEER_LLH16N(4);
+        }
+#undef BEER_LLH16N
     }
     switch (gq) {
         case 1: BEER_LLH16(16, 2, 1);

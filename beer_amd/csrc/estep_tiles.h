@@ -30,6 +30,8 @@ template <> struct Mma<float> {
         return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
     }
     static __device__ __forceinline__ float recip(float x) { return __builtin_amdgcn_rcpf(x); }
+    // v_max_f32 (one instruction, also as a DPP operand) instead of compare + select
+    static __device__ __forceinline__ float mx(float a, float b) { return __builtin_fmaxf(a, b); }
     // log of a softmax denominator (a sum in [1, group size]): v_log_f32 (log2, 1 ulp)
     static __device__ __forceinline__ float log_sum(float x) {
         return __builtin_amdgcn_logf(x) * 0.69314718055994530942f;
@@ -44,6 +46,7 @@ template <> struct Mma<double> {
     static __device__ __forceinline__ int row(int g, int r) { return g + 4 * r; }
     static __device__ __forceinline__ double exp_neg(double x) { return exp(x); }
     static __device__ __forceinline__ double recip(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double mx(double a, double b) { return b > a ? b : a; }
     static __device__ __forceinline__ double log_sum(double x) { return log(x); }
 };
 
@@ -65,10 +68,10 @@ __device__ __forceinline__ double dpp_move(double v) {
 }
 template <typename T>
 __device__ __forceinline__ T group_max(T v, int gl) {
-    if (gl > 1) { const T w = dpp_move<0xB1>(v); v = w > v ? w : v; }      // quad_perm [1,0,3,2]
-    if (gl > 2) { const T w = dpp_move<0x4E>(v); v = w > v ? w : v; }      // quad_perm [2,3,0,1]
-    if (gl > 4) { const T w = dpp_move<0x141>(v); v = w > v ? w : v; }     // row_half_mirror
-    if (gl > 8) { const T w = dpp_move<0x140>(v); v = w > v ? w : v; }     // row_mirror
+    if (gl > 1) v = Mma<T>::mx(v, dpp_move<0xB1>(v));      // quad_perm [1,0,3,2]
+    if (gl > 2) v = Mma<T>::mx(v, dpp_move<0x4E>(v));      // quad_perm [2,3,0,1]
+    if (gl > 4) v = Mma<T>::mx(v, dpp_move<0x141>(v));     // row_half_mirror
+    if (gl > 8) v = Mma<T>::mx(v, dpp_move<0x140>(v));     // row_mirror
     return v;
 }
 template <typename T>
@@ -190,7 +193,9 @@ __host__ __device__ inline size_t packed_word(int64_t tau, int nblk, int beta, i
     return ((size_t)tau * nblk + beta) * (kPackedComps * kPackedFrames) + (half >> 1);
 }
 
-template <typename T, int NT, int MT, int GQ, bool PACKED = false>
+// LNO: only the log-normalisers are wanted (the accumulation recomputes the
+// responsibilities): no reciprocal, no normalisation, no store of them.
+template <typename T, int NT, int MT, int GQ, bool PACKED = false, bool LNO = false>
 __device__ __forceinline__ void softmax_epilogue(
     typename Mma<T>::acc_t (&acc)[MT][NT], int64_t fb, int64_t nframes, int kbase, int K, int S,
     int G, int gl, int jw, int i, int g, int lane, T* __restrict__ resps,
@@ -214,10 +219,7 @@ __device__ __forceinline__ void softmax_epilogue(
                 if (jw == 4) {
                     T mx = acc[m][4 * tq * GQ][r];
 #pragma unroll
-                    for (int c = 1; c < 4 * GQ; ++c) {
-                        const T w = acc[m][4 * tq * GQ + c][r];
-                        mx = w > mx ? w : mx;
-                    }
+                    for (int c = 1; c < 4 * GQ; ++c) mx = M::mx(mx, acc[m][4 * tq * GQ + c][r]);
                     mx = group_max(mx, gl);
                     T sum = 0;
 #pragma unroll
@@ -229,11 +231,13 @@ __device__ __forceinline__ void softmax_epilogue(
                         }
                     sum = group_sum(sum, gl);
                     const T lse = mx + M::log_sum(sum);
-                    const T inv = M::recip(sum);
+                    if (!LNO) {
+                        const T inv = M::recip(sum);
 #pragma unroll
-                    for (int qq = 0; qq < GQ; ++qq)
+                        for (int qq = 0; qq < GQ; ++qq)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) e[qq][j] *= inv;
+                            for (int j = 0; j < 4; ++j) e[qq][j] *= inv;
+                    }
                     const int state = (kbase + 64 * tq * GQ + 4 * (i & ~(gl - 1))) / G;
                     if (f < nframes && state < S && (i & (gl - 1)) == 0) {
                         if (log_norm) log_norm[f * S + state] = lse;
@@ -277,7 +281,7 @@ __device__ __forceinline__ void softmax_epilogue(
                     for (int qq = 0; qq < GQ; ++qq)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[m][4 * (tq * GQ + qq) + j][r] = e[qq][j];
-                } else if (resps && f < nframes) {
+                } else if (!LNO && resps && f < nframes) {
 #pragma unroll
                     for (int qq = 0; qq < GQ; ++qq) {
                         const int k = kq + 64 * qq;

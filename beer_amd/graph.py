@@ -452,11 +452,18 @@ class DeviceGraph:
                 b['ld_in_w'].copy_(t[idx('ld_in_src'), idx('ld_in_dst')].to(dtype))
                 b['ld_out_w'].copy_(t[idx('ld_out_src'), idx('ld_out_dst')].to(dtype))
             for h in range(self.lowdeg.n_hubs):
-                src = b['ld_src_list'][self._hub_ptr[0][h]:self._hub_ptr[0][h + 1]].long()
-                dst = b['ld_dst_list'][self._hub_ptr[1][h]:self._hub_ptr[1][h + 1]].long()
+                memo = self.__dict__.setdefault('_hub_index', {})
+                if h not in memo:
+                    src = b['ld_src_list'][self._hub_ptr[0][h]:self._hub_ptr[0][h + 1]].long()
+                    dst = b['ld_dst_list'][self._hub_ptr[1][h]:self._hub_ptr[1][h + 1]].long()
+                    # one-element index tensors, not 0-dim ones: torch turns a 0-dim
+                    # index into a Python int with .item() -- a device synchronisation
+                    # per VB iteration that kept the host from queueing ahead
+                    memo[h] = (src, dst, src[:1], dst[:1])
+                src, dst, src0, dst0 = memo[h]
                 # A[e, s] = A[e, 0] + (A[0, s] - A[0, 0]), as when the image was built
-                b['ld_src_w'][src] = t[src, dst[0]].to(dtype)
-                b['ld_dst_w'][dst] = (t[src[0], dst].double() - t[src[0], dst[0]].double()).to(dtype)
+                b['ld_src_w'][src] = t[src, dst0].to(dtype)
+                b['ld_dst_w'][dst] = (t[src0, dst].double() - t[src0, dst0].double()).to(dtype)
 
     @staticmethod
     def _segments(ptr):
