@@ -114,6 +114,8 @@ SIGNATURES = {
     'beer_dirichlet_expected_stats': _dir, 'beer_dirichlet_log_norm': _dir,
     'beer_dirichlet_natural': _dir, 'beer_dirichlet_from_natural': _dir,
     'beer_dirichlet_log_weights': _dir,
+    'beer_sb_transform_stats': [c_i, c_i, c_p, c_p, c_p, c_p],
+    'beer_sb_log_weights': [c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     'beer_gamma_expected_stats': _gam, 'beer_gamma_log_norm': _gam,
     'beer_gamma_natural': _gam,
     'beer_gamma_from_natural': [c_i, c_i, c_p, c_p, c_p, c_p],

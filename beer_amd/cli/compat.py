@@ -64,24 +64,23 @@ _REFERENCE_MODULES = (
 class reference_aliases:
     '''Context manager: while active, pickles that name `beer.*` classes (e.g.
     the object arrays inside an `alis.npz` written by the reference) resolve to
-    beer_amd classes.  Does nothing if a real `beer` package is importable.'''
+    beer_amd classes -- always, whether or not a `beer` package is installed next
+    to beer_amd: the product path never hands its objects to the reference.  The
+    module table is restored on exit (an installed `beer` is untouched outside).'''
 
     def __enter__(self):
         import sys
-        self._added = []
-        try:
-            import beer                                   # noqa: F401
-            return self
-        except ImportError:
-            pass
+        self._saved = {}
         for name in _REFERENCE_MODULES:
-            if name not in sys.modules:
-                sys.modules[name] = _Alias(name)
-                self._added.append(name)
+            self._saved[name] = sys.modules.get(name)
+            sys.modules[name] = _Alias(name)
         return self
 
     def __exit__(self, *exc):
         import sys
-        for name in self._added:
-            sys.modules.pop(name, None)
+        for name, old in self._saved.items():
+            if old is None:
+                sys.modules.pop(name, None)
+            else:
+                sys.modules[name] = old
         return False

@@ -41,13 +41,16 @@ def _utt_ids(args_utts, dataset):
 
 def _cpu_elbo(elbo):
     'ELBO object with every tensor on the host (portable pickle).'
-    acc = {p: s.cpu() for p, s in elbo._acc_stats.items()}
+    # parameters are named by their uuid (models.parameters.ParameterRef): the file
+    # holds neither device tensors nor model objects, `update` reads it without a GPU
+    from ..models.parameters import ParameterRef
+    acc = {ParameterRef(p.uuid): s.cpu() for p, s in elbo._acc_stats.items()}
     value = elbo.value.cpu() if isinstance(elbo.value, torch.Tensor) else elbo.value
     mbsize = elbo._minibatchsize
     if isinstance(mbsize, torch.Tensor):                  # after an RCCL all-reduce
         mbsize = int(round(float(mbsize)))
-    return beer.EvidenceLowerBoundInstance(value, acc, elbo._model_parameters, mbsize,
-                                           elbo._datasize)
+    refs = [ParameterRef(p.uuid) for p in elbo._model_parameters]
+    return beer.EvidenceLowerBoundInstance(value, acc, refs, mbsize, elbo._datasize)
 
 
 def parse_topology(topology):
@@ -313,7 +316,7 @@ class phonelist:
     def main(args, logger):
         units, _ = _load(args.hmms)
         import re
-        natkey = lambda s: [int(t) if t.isdigit() else t for t in re.split(r'(\\d+)', s.lower())]
+        natkey = lambda s: [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', s.lower())]
         for key in sorted(units.keys(), key=natkey):
             print(key)
 
@@ -370,11 +373,19 @@ class accumulate:
         feats, graphs, kept = _shard(model, dataset, uttids, alis, logger)
         elbo = beer.evidence_lower_bound(datasize=dataset.size)
         count = len(kept)
-        if count:
-            # utterances without an alignment graph fall back to the model's graph
-            use = None if alis is None else [g if g is not None else model.graph for g in graphs]
-            elbo = elbo + beer.accumulate_elbo(model, feats, datasize=dataset.size,
-                                               inference_graphs=use, scale=args.acoustic_scale)
+        # Utterances with an alignment graph train the emissions only (the phone
+        # weights get no counts: phoneloop.py:98-100); those without one go through
+        # the free phone loop and DO count phones, as the reference's per-utterance
+        # `inference_graph=None` does (accumulate.py:45-54): two batches, one sum.
+        aligned = [i for i, g in enumerate(graphs) if g is not None]
+        free = [i for i, g in enumerate(graphs) if g is None]
+        if aligned:
+            elbo = elbo + beer.accumulate_elbo(
+                model, [feats[i] for i in aligned], datasize=dataset.size,
+                inference_graphs=[graphs[i] for i in aligned], scale=args.acoustic_scale)
+        if free:
+            elbo = elbo + beer.accumulate_elbo(model, [feats[i] for i in free],
+                                               datasize=dataset.size, scale=args.acoustic_scale)
         _dump((_cpu_elbo(elbo), count), args.out)
         norm = max(count, 1) * dataset.size
         logger.info(f'accumulated ELBO over {count} utterances: {float(elbo) / norm :.3f}.')

@@ -617,6 +617,98 @@ int suffstats_launch(int cov, int64_t T_, int D, const void* X, void* out, void*
 // C ABI
 // ---------------------------------------------------------------------------
 
+// ---------------------------------------------------------------------------
+// Truncated stick-breaking categorical (beer/models/categorical.py:106-131): the
+// bookkeeping between the phone counts and the Dirichlet pairs of the sticks.
+// P <= 1024 sticks: one workgroup, every thread ranks its own stick against all
+// others (stable: equal counts keep their index order, as the oracle's
+// argsort(-counts, kind='stable')).
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int kSbMax = 1024;
+
+template <typename T>
+__device__ inline int sb_rank(const T* v, int P, int i) {          // position in descending order
+    int r = 0;
+    const T mine = v[i];
+    for (int j = 0; j < P; ++j) r += (v[j] > mine) || (v[j] == mine && j < i);
+    return r;
+}
+
+// counts [P] -> ordering [P] (stick -> category), stats [P,2] = (count_i, count_i +
+// sum of the counts ranked after i) in the categories' own order
+template <typename T>
+__global__ void sb_transform_kernel(int P, const T* __restrict__ counts,
+                                    int64_t* __restrict__ ordering, T* __restrict__ stats) {
+    __shared__ T v[kSbMax];
+    __shared__ int rank[kSbMax], ord[kSbMax];
+    for (int i = threadIdx.x; i < P; i += blockDim.x) v[i] = counts[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        rank[i] = sb_rank(v, P, i);
+        ord[rank[i]] = i;
+        ordering[rank[i]] = i;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        // sum of the later sticks, added from the last one up (the reference's flipped
+        // cumulative sum)
+        double tail = 0.0;
+        for (int r = P - 1; r > rank[i]; --r) tail += (double)v[ord[r]];
+        stats[2 * i] = v[i];
+        stats[2 * i + 1] = (T)(tail + (double)v[i]);
+    }
+}
+
+// concentrations [P,2], ordering [P] -> E[ln pi_i] [P] (categories' order) and
+// sum_i E[ln(1 - v_i)]
+template <typename T>
+__global__ void sb_log_weights_kernel(int P, const T* __restrict__ conc,
+                                      const int64_t* __restrict__ ordering,
+                                      T* __restrict__ log_w, T* __restrict__ log_1_v_sum) {
+    __shared__ double l1v[kSbMax];          // E[ln(1 - v)] by stick
+    __shared__ double lv[kSbMax];
+    for (int r = threadIdx.x; r < P; r += blockDim.x) {
+        const int i = (int)ordering[r];
+        const double a = (double)conc[2 * i], b = (double)conc[2 * i + 1], sd = digamma(a + b);
+        lv[r] = digamma(a) - sd;
+        l1v[r] = digamma(b) - sd;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < P; r += blockDim.x) {
+        double acc = lv[r];
+        for (int q = 0; q < r; ++q) acc += l1v[q];
+        log_w[ordering[r]] = (T)acc;
+    }
+    if (threadIdx.x == 0 && log_1_v_sum) {
+        double tot = 0.0;
+        for (int r = 0; r < P; ++r) tot += l1v[r];
+        *log_1_v_sum = (T)tot;
+    }
+}
+
+template <typename T>
+int sb_transform_launch(int P, const void* counts, int64_t* ordering, void* stats, void* stream) {
+    BEER_REQUIRE(P >= 1 && P <= kSbMax && counts && ordering && stats);
+    hipLaunchKernelGGL(sb_transform_kernel<T>, dim3(1), dim3(256), 0, as_stream(stream), P,
+                       (const T*)counts, ordering, (T*)stats);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+template <typename T>
+int sb_log_weights_launch(int P, const void* conc, const int64_t* ordering, void* log_w,
+                          void* log_1_v_sum, void* stream) {
+    BEER_REQUIRE(P >= 1 && P <= kSbMax && conc && ordering && log_w);
+    hipLaunchKernelGGL(sb_log_weights_kernel<T>, dim3(1), dim3(256), 0, as_stream(stream), P,
+                       (const T*)conc, ordering, (T*)log_w, (T*)log_1_v_sum);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int beer_hip_version(void) { return 100; }
@@ -694,6 +786,15 @@ int beer_dirichlet_log_weights(int dtype, int S, int G, const void* conc, void* 
 }
 int beer_dirichlet_log_norm(int dtype, int S, int G, const void* conc, void* out, void* stream) {
     BEER_DISPATCH(dtype, dirichlet_launch, 4, S, G, conc, out, stream);
+}
+
+int beer_sb_transform_stats(int dtype, int P, const void* counts, int64_t* ordering, void* stats,
+                            void* stream) {
+    BEER_DISPATCH(dtype, sb_transform_launch, P, counts, ordering, stats, stream);
+}
+int beer_sb_log_weights(int dtype, int P, const void* conc, const int64_t* ordering, void* log_w,
+                        void* log_1_v_sum, void* stream) {
+    BEER_DISPATCH(dtype, sb_log_weights_launch, P, conc, ordering, log_w, log_1_v_sum, stream);
 }
 
 int beer_gamma_expected_stats(int dtype, int n, const void* shape, const void* rate, void* out, void* stream) {

@@ -391,7 +391,11 @@ class DeviceGraph:
             sw = block[:, 0].clone()
             dw = block[0, :] - block[0, 0]
             model = sw[:, None] + dw[None, :]
-            ok = torch.allclose(block, model, rtol=0., atol=1e-6 * float(block.abs().max())) and \
+            # as exact as the image's arithmetic: a float32-rounded table is rank one
+            # only to 1e-7, which a float64 image must not silently inherit (it then
+            # keeps the dense block: the general kernel)
+            tol = 1e-12 if dtype == torch.float64 else 1e-6
+            ok = torch.allclose(block, model, rtol=0., atol=tol * float(block.abs().max())) and \
                 bool((src_id[src] < 0).all()) and bool((dst_id[dst] < 0).all())
             sw, dw = sw.to(trans_h.dtype), dw.to(trans_h.dtype)
             if not ok:

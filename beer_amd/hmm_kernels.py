@@ -150,9 +150,20 @@ def forward_backward(batch, pc_llhs, want_xi=False, want_lognorm=False, dense_xi
         flow = torch.zeros(S, dtype=torch.float64, device=dev)
     if want_lognorm:
         ln = torch.empty(batch.nutt, dtype=dt, device=dev)
-    _hip.call('beer_hmm_forward_backward', _hip.dtype_code(dt), batch.ref(),
-              _hip.ptr(pc_llhs), _hip.ptr(alpha), _hip.ptr(hub_ws), _hip.ptr(gamma), _hip.ptr(xi),
-              _hip.ptr(g0), _hip.ptr(flow), _hip.ptr(ln))
+    try:
+        _hip.call('beer_hmm_forward_backward', _hip.dtype_code(dt), batch.ref(),
+                  _hip.ptr(pc_llhs), _hip.ptr(alpha), _hip.ptr(hub_ws), _hip.ptr(gamma),
+                  _hip.ptr(xi), _hip.ptr(g0), _hip.ptr(flow), _hip.ptr(ln))
+    except _hip.HipError as err:
+        st = batch.struct
+        if 'invalid argument' in str(err) and not st.all_lowdeg:
+            raise _hip.HipError(
+                f'forward-backward: a graph of the batch ({st.max_states} states, {st.max_arcs} '
+                'arcs) does not fit the general kernel, which keeps the whole arc list in the '
+                "CU's 160 KB of LDS (about 4000 arcs with transition posteriors, 6500 without); "
+                'sparser graphs, or graphs with at most 8 arcs per state besides a declared '
+                'hub (CompiledGraph.set_hub), run at any size') from err
+        raise
     return gamma, xi, g0, ln, flow
 
 

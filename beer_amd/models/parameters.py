@@ -11,7 +11,33 @@ import torch
 from .. import _hip
 from ..dists import kl_div
 
-__all__ = ['BayesianParameter', 'ConjugateBayesianParameter']
+__all__ = ['ParameterRef', 'BayesianParameter', 'ConjugateBayesianParameter']
+
+
+class ParameterRef:
+    '''The identity of a parameter without its tensors: hashes and compares like
+    the parameter with the same uuid.  What a pickled ELBO object keys its
+    accumulated statistics with (`beer hmm accumulate` -> `beer hmm update`): the
+    file then holds no device tensors and no model objects.'''
+    __slots__ = ('uuid',)
+
+    def __init__(self, uuid):
+        self.uuid = uuid
+
+    def __hash__(self):
+        return hash(self.uuid)
+
+    def __eq__(self, other):
+        return getattr(other, 'uuid', None) == self.uuid
+
+    def __getstate__(self):
+        return {'uuid': self.uuid}
+
+    def __setstate__(self, state):
+        self.uuid = state['uuid']
+
+    def __repr__(self):
+        return f'ParameterRef({self.uuid})'
 
 
 class BayesianParameter(torch.nn.Module):
@@ -42,7 +68,7 @@ class BayesianParameter(torch.nn.Module):
         return hash(self.uuid)
 
     def __eq__(self, other):
-        return isinstance(other, BayesianParameter) and self.uuid == other.uuid
+        return isinstance(other, (BayesianParameter, ParameterRef)) and self.uuid == other.uuid
 
     def dispatch(self, before_update=False):
         'Run the registered callbacks of the given phase.'

@@ -1,40 +1,44 @@
-"""Residual feed-forward network (API of beer/nnet/residual.py:5-51)."""
+"""Residual feed-forward encoder / decoder trunk of the VAE examples.
+
+torch.nn modules (they run on PyTorch-ROCm as they are: SURVEY.md marks beer/nnet
+as context of the hot path, not part of it).  Interface of
+beer/nnet/residual.py:5-51: `ResidualFeedForwardNet(dim_in, nblocks, block_width)`
+with `dim_in` / `dim_out`; the block class keeps the reference's spelling
+(`ResidualFeedFowardBlock`) and sub-module names (`layer1`, `layer2`,
+`activation_fn`, `blocks`) because pickled models and state dicts name them.
+"""
 
 import torch
+from torch import nn
 
 __all__ = ['ResidualFeedForwardNet']
 
 
-class ResidualFeedFowardBlock(torch.nn.Module):
-    'y = x + f(W2 f(W1 x + b1) + b2).'
+class ResidualFeedFowardBlock(nn.Module):
+    'x -> x + act(W2 act(W1 x + b1) + b2): a bottleneck of `width` units around the identity.'
 
-    def __init__(self, dim_in, width, activation_fn=torch.nn.Tanh):
+    def __init__(self, dim_in, width, activation_fn=nn.Tanh):
         super().__init__()
-        self.layer1 = torch.nn.Linear(dim_in, width)
-        self.layer2 = torch.nn.Linear(width, dim_in)
+        self.layer1, self.layer2 = nn.Linear(dim_in, width), nn.Linear(width, dim_in)
         self.activation_fn = activation_fn()
 
     def forward(self, x):
-        hidden = self.activation_fn(self.layer1(x))
-        return x + self.activation_fn(self.layer2(hidden))
+        act = self.activation_fn
+        return x + act(self.layer2(act(self.layer1(x))))
 
 
-class ResidualFeedForwardNet(torch.nn.Module):
-    'Stack of residual blocks; input and output have the same dimension.'
+class ResidualFeedForwardNet(nn.Module):
+    '`nblocks` residual blocks in sequence; the dimension does not change.'
 
     def __init__(self, dim_in, nblocks=1, block_width=10):
         super().__init__()
         self._dim_in = dim_in
-        self.blocks = torch.nn.Sequential(*[ResidualFeedFowardBlock(dim_in, block_width)
-                                            for _ in range(nblocks)])
+        self.blocks = nn.Sequential()
+        for n in range(nblocks):
+            self.blocks.add_module(str(n), ResidualFeedFowardBlock(dim_in, block_width))
 
-    @property
-    def dim_in(self):
-        return self._dim_in
-
-    @property
-    def dim_out(self):
-        return self._dim_in
+    dim_in = property(lambda self: self._dim_in)
+    dim_out = property(lambda self: self._dim_in)
 
     def forward(self, X):
         return self.blocks(X)

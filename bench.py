@@ -1,20 +1,28 @@
 #!/usr/bin/env python
-"""Headline benchmark: frames/sec per VB iteration (E-step + all-reduce +
-M-step) on BASELINE.json config 2 -- GMM, K = 256 full-covariance Gaussians,
-D = 40, 1,000,000 fp32 frames per GPU, processed as 8192-frame "utterances".
+"""Headline benchmark: frames/sec per VB iteration (E-step + all-reduce + M-step).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W            # BASELINE config 2 (default)
+    python bench.py --gpus N --config 3 [--frames 10000000]   # BASELINE config 3
 
-One process per GPU; utterances are sharded (each rank owns its own 1 M
-synthetic frames: weak scaling), one RCCL all-reduce of the accumulated
-statistics per iteration, replicated M-step.  Rank 0 prints ONE JSON line.
+* config 2 (`configs[1]`, the configuration the metric is quoted on): GMM, K = 256
+  full-covariance Gaussians, D = 40, 1,000,000 fp32 frames PER GPU in 8192-frame
+  "utterances" (weak scaling).
+* config 3 (`configs[2]`): monophone phone-loop HMM, 40 phones x 3 states x 16
+  diagonal Gaussians, D = 40, a FIXED corpus of 10 M frames in ~33 k utterances
+  sharded over the ranks by frame count (strong scaling), forward-backward + VB
+  update.
+
+One process per GPU, ONE RCCL all-reduce of the accumulated statistics per
+iteration, replicated M-step.  With --gpus N > 1 and no launcher in the
+environment (no WORLD_SIZE) the script spawns its own N ranks; under
+`python -m torch.distributed.run` it takes RANK / LOCAL_RANK / WORLD_SIZE from
+the environment.  Rank 0 prints ONE JSON line.
 """
 
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -27,13 +35,110 @@ sys.path.insert(0, ROOT)
 
 import beer_amd as beer                                   # noqa: E402
 from beer_amd import _hip                                  # noqa: E402
-from beer_amd.distributed import all_reduce_elbo           # noqa: E402
+from beer_amd.distributed import all_reduce_elbo, shard_utterances   # noqa: E402
 
 K, D = 256, 40
 Q = D * D + D + 2
-# MI355X_MICROARCH.md: dense MFMA peaks (f32 operands; f16 operands / f32 accumulate)
+# MI355X_MICROARCH.md: dense MFMA peaks (f32 operands; f16 operands / f32 accumulate), HBM3E
 PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6, 'f16': 2500.}
+PEAK_HBM_GBS = 8000.
 
+
+# --------------------------------------------------------------------------------------------
+# shared pieces
+# --------------------------------------------------------------------------------------------
+
+class KernelTimer:
+    'HIP-event timing of chosen C-ABI calls on the launching (current) stream.'
+
+    def __init__(self, names):
+        self.names, self.events = set(names), {n: [] for n in names}
+        self._orig = _hip.call
+
+    def __enter__(self):
+        def timed(name, *args):
+            if name not in self.names:
+                return self._orig(name, *args)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self._orig(name, *args)
+            b.record()
+            self.events[name].append((a, b))
+        _hip.call = timed
+        return self
+
+    def __exit__(self, *exc):
+        _hip.call = self._orig
+
+    def mean_ms(self, name):
+        ev = self.events[name]
+        return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev)), len(ev)
+
+
+class PhaseTimer:
+    'HIP-event timing of named phases of a step (all-reduce, M-step) on the current stream.'
+
+    def __init__(self):
+        self.spans = {}
+
+    def span(self, name):
+        timer = self
+
+        class _Span:
+            def __enter__(self):
+                self.a = torch.cuda.Event(enable_timing=True)
+                self.b = torch.cuda.Event(enable_timing=True)
+                self.a.record()
+
+            def __exit__(self, *exc):
+                self.b.record()
+                timer.spans.setdefault(name, []).append((self.a, self.b))
+        return _Span()
+
+    def mean_ms(self, name):
+        ev = self.spans.get(name, [])
+        return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
+
+    def clear(self):
+        self.spans = {}
+
+
+def pmc_traffic(kernel_key):
+    '''HBM bytes per launch of a kernel from the committed PMC passes
+    (profiles/r*_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    passes, full-size launches of this same command).  Counters cannot be read
+    from inside the timed run, so this is the last profiled value; None if absent.'''
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')), reverse=True):
+        try:
+            k = json.load(open(path))['kernels'][kernel_key]
+            # FETCH_SIZE under-reports wide (16 B / lane) coalesced reads by 2x on gfx950
+            # (MI355X_MICROARCH.md): kernels that stream with 16-byte loads are corrected
+            read = k['hbm_read_bytes_raw'] * (2. if k.get('wide_loads', kernel_key.startswith('acc'))
+                                              else 1.)
+            return read + k['hbm_write_bytes']
+        except Exception:
+            continue
+    return None
+
+
+def fence(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(elapsed, world, device, backend):
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    return elapsed
+
+
+# --------------------------------------------------------------------------------------------
+# config 2: GMM K = 256 full covariance
+# --------------------------------------------------------------------------------------------
 
 def synth_frames(n, device, seed):
     'Seeded draw from a 256-component ground-truth mixture in 40 dimensions.'
@@ -57,7 +162,7 @@ def synth_frames(n, device, seed):
     return X[perm].contiguous()
 
 
-def make_model(device):
+def make_gmm(device):
     '''Mixture of K full-covariance Gaussians initialised from a common seeded
     sample (identical on every rank); init noise drawn once on the CPU.'''
     torch.manual_seed(7)
@@ -69,36 +174,7 @@ def make_model(device):
     return beer.Mixture.create(ns, prior_strength=1.).to(device)
 
 
-class KernelTimer:
-    'HIP-event timing of chosen C-ABI calls on the launching (current) stream.'
-
-    def __init__(self, names):
-        self.names, self.events = set(names), {n: [] for n in names}
-        self._orig = _hip.call
-
-    def __enter__(self):
-        def timed(name, *args):
-            if name not in self.names:
-                return self._orig(name, *args)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            self._orig(name, *args)
-            b.record()
-            self.events[name].append((a, b))
-        _hip.call = timed
-        for mod in (beer.kernels, beer.hmm_kernels):
-            mod._hip.call = timed
-        return self
-
-    def __exit__(self, *exc):
-        _hip.call = self._orig
-
-    def mean_ms(self, name):
-        ev = self.events[name]
-        return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev)), len(ev)
-
-
-def cpu_baseline(frames_target=1 << 20, chunk=8192, budget_s=15.):
+def cpu_baseline_gmm(frames_target=1 << 20, chunk=8192, budget_s=15.):
     '''beer's CPU path on the host cores: the reference's own op sequence replayed
     with torch CPU ops (oracle/torch_port.py; numerically identical to the
     reference) on a bounded sample of config 2.'''
@@ -165,56 +241,357 @@ def cpu_baseline_graph_compile(sequences, units, graph_cls):
     return (time.perf_counter() - t0) / max(1, len(sequences))
 
 
-def pmc_traffic(kernel_key):
-    '''HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r*_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    passes, full-size launches of this same command).  Counters cannot be read
-    from inside the timed run, so this is the last profiled value; None if absent.'''
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')))
-    if not files:
-        return None
-    try:
-        k = json.load(open(files[-1]))['kernels'][kernel_key]
-        # FETCH_SIZE under-reports wide (16 B/lane) coalesced reads by 2x on gfx950
-        # (MI355X_MICROARCH.md): K2 streams R with 16-byte loads -> corrected; K1's
-        # reads are 4-byte -> raw.
-        read = k['hbm_read_bytes_raw'] * (2. if kernel_key.startswith('acc') else 1.)
-        return read + k['hbm_write_bytes']
-    except Exception:
-        return None
-
-
-def elbo_check(model, X, n=16384):
-    'ELBO of the first n frames: HIP path vs fp64 oracle on identical inputs.'
+def gmm_parity_check(model, X, n=65536, chunk=8192):
+    '''The kernels the timed loop runs (packed hand-over: n >= 16384 frames) against
+    the fp64 numpy oracle on the same frames: relative error of the ELBO and of the
+    accumulated statistics.'''
     from oracle import beer_oracle as orc
     p0, p1 = list(model.bayesian_parameters())
 
     def as64(d):
         return [getattr(d.params, nm).cpu().numpy().astype(np.float64)
                 for nm in d._std_params_def]
-    truth = orc.gmm_elbo_step(X[:n].cpu().numpy().astype(np.float64), 'full',
-                              as64(p0.posterior), as64(p0.prior),
-                              as64(p1.posterior)[0], as64(p1.prior)[0])
-    got = float(beer.evidence_lower_bound(model, X[:n]))
-    return abs(got - truth['value']) / abs(truth['value'])
+    post, prior, w_post, w_prior = as64(p0.posterior), as64(p0.prior), as64(p1.posterior)[0], \
+        as64(p1.prior)[0]
+    Xh = X[:n].cpu().numpy().astype(np.float64)
+    per_frame, acc_n, kl = 0., 0., None
+    for lo in range(0, n, chunk):
+        r = orc.gmm_elbo_step(Xh[lo:lo + chunk], 'full', post, prior, w_post, w_prior)
+        per_frame += r['per_frame'].sum()
+        acc_n, kl = acc_n + r['acc_normal'], r['kl']
+    truth = per_frame - kl
+    elbo = beer.accumulate_elbo(model, (X[:n], [n]), datasize=n)
+    got_acc = elbo._acc_stats[p0].cpu().numpy().astype(np.float64)
+    return (abs(float(elbo) - truth) / abs(truth),
+            float(np.abs(got_acc - acc_n).max() / np.abs(acc_n).max()))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--frames', type=int, default=1_000_000, help='frames per GPU')
-    ap.add_argument('--chunk', type=int, default=8192, help='frames per "utterance"')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
+def run_gmm(args, rank, world, device, backend):
+    X = synth_frames(args.frames, device, seed=1 + rank)
+    lengths = [args.chunk] * (args.frames // args.chunk)
+    if args.frames % args.chunk:
+        lengths.append(args.frames % args.chunk)
+    datasize = args.frames * world
+    model = make_gmm(device)             # identical on every rank
+    optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.)
+    elbo_err = stats_err = None
+    if rank == 0 and not args.no_check:
+        elbo_err, stats_err = gmm_parity_check(model, X, n=min(65536, args.frames))
+    phases = PhaseTimer()
 
+    def step():
+        optim.init_step()
+        elbo = beer.accumulate_elbo(model, (X, lengths), datasize=datasize)
+        with phases.span('all_reduce'):
+            elbo, _ = all_reduce_elbo(elbo, model, len(lengths))
+        with phases.span('m_step'):
+            elbo.backward()
+            optim.step()
+        return elbo
+
+    # the float32 split path hands the responsibilities over packed (two entry points)
+    names = ('beer_mixtureset_estep', 'beer_normal_accumulate',
+             'beer_mixture_estep_packed', 'beer_normal_accumulate_packed')
+
+    def timed_loop(steps, warmup):
+        for _ in range(warmup):
+            step()
+        phases.clear()
+        fence(world)
+        with KernelTimer(names) as kt:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                elbo = step()
+            fence(world)
+            elapsed = time.perf_counter() - t0
+        return max_over_ranks(elapsed, world, device, backend), kt, elbo
+
+    def kernel_table(kt, steps):
+        kern = {}
+        for nm in names:
+            ms, n = kt.mean_ms(nm)
+            if n == 0:
+                continue
+            # algorithmic work of one launch (SURVEY 8d: 2*K*Q flop per frame per GEMM,
+            # no symmetry discount), for the frames one launch processes
+            flops = 2. * K * Q * args.frames * steps / max(1, n)
+            kern[nm] = {'ms': ms, 'launches': n, 'tflops': flops / (ms * 1e-3) / 1e12}
+        return kern
+
+    elapsed, kt, elbo = timed_loop(args.steps, args.warmup)
+    kern = kernel_table(kt, args.steps)
+    allreduce_ms, mstep_ms = phases.mean_ms('all_reduce'), phases.mean_ms('m_step')
+    mode = beer.get_f32_mode()
+    # secondary: the same iteration on the exact fp32 MFMA (every product an fmaf)
+    exact = None
+    if mode == 'split_f16' and not args.no_exact:
+        with _hip.exact_f32():
+            e_steps = max(2, min(5, args.steps))
+            e_elapsed, e_kt, _ = timed_loop(e_steps, 1)
+            e_kern = kernel_table(e_kt, e_steps)
+        e_dom = max(e_kern, key=lambda nm: e_kern[nm]['ms'] * e_kern[nm]['launches'])
+        exact = {'ms_per_step': 1e3 * e_elapsed / e_steps,
+                 'value': datasize * e_steps / e_elapsed, 'kernel': e_dom,
+                 'achieved': e_kern[e_dom]['tflops'], 'peak': PEAK_TFLOPS['f32'],
+                 'frac': e_kern[e_dom]['tflops'] / PEAK_TFLOPS['f32'],
+                 'avg_launch_ms': e_kern[e_dom]['ms'],
+                 'note': 'v_mfma_f32_16x16x4_f32, bitwise an fmaf chain; the kernels contract only '
+                         'the D(D+1)/2 symmetric products, so frac can exceed 1'}
+    if rank != 0:
+        return None
+    ms_per_step = 1e3 * elapsed / args.steps
+    dom = max(kern, key=lambda nm: kern[nm]['ms'] * kern[nm]['launches'])
+    split = mode == 'split_f16'
+    peak = PEAK_TFLOPS['f16' if split else 'f32']
+    if split:
+        note = ('fp32 operands are split into two fp16 halves and every product is three '
+                'v_mfma_f32_16x16x32_f16 (fp32 accumulate), so the peak is the dense fp16 MFMA '
+                'peak; achieved = algorithmic flops (2*K*Q per frame, no symmetry discount, '
+                'one flop pair per product) / HIP-event time of the C-ABI call.  The matrix '
+                'cores execute 3 * 2*K*928 flop per frame (1.70x the algorithmic count): '
+                'hardware rate = 1.70 * achieved.  f32_exact: the same iteration on the exact '
+                'fp32 MFMA (peak 157.3).')
+    else:
+        note = ('achieved = algorithmic flops (2*K*Q per frame, no symmetry discount) / '
+                'HIP-event time of the C-ABI call; the kernels contract only the D(D+1)/2 '
+                'symmetric products (0.56x the multiply-adds), so frac can exceed 1')
+    pmc_key = (('acc16p_kernel' if 'packed' in dom else 'acc16_kernel') if split else 'acc_kernel') \
+        if 'accumulate' in dom else ('llh16_kernel' if split else 'llh_kernel')
+    out = {
+        'metric': 'frames/sec per VB iteration (E+M)', 'value': datasize * args.steps / elapsed,
+        'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: GMM K=256 full-covariance, D=40, '
+                               f'{args.frames} fp32 frames per GPU in {args.chunk}-frame '
+                               'utterances, 1 VB iteration = E-step + all-reduce + M-step',
+                   'parallelism': f'dp{world}', 'frames_per_gpu': args.frames,
+                   'components': K, 'dim': D},
+        'elbo_rel_err_vs_cpu_fp64': elbo_err, 'stats_rel_err_vs_cpu_fp64': stats_err,
+        'parity_check': 'first 65536 frames through the timed kernels (packed hand-over) vs the '
+                        'fp64 numpy oracle',
+        'elbo_per_frame': float(elbo) / (len(lengths) * world * datasize),
+        'f32_mode': mode, 'all_reduce_ms': allreduce_ms, 'm_step_ms': mstep_ms,
+        'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'],
+                     'peak': peak, 'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / peak,
+                     'traffic': pmc_traffic(pmc_key), 'avg_launch_ms': kern[dom]['ms'],
+                     'note': note},
+        'kernels': kern,
+    }
+    if exact:
+        out['f32_exact'] = exact
+    if not args.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline_gmm()
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# config 3: monophone phone-loop HMM
+# --------------------------------------------------------------------------------------------
+
+N_PHONES, N_COMP = 40, 16
+TOPO = [(0, 1, 1.), (1, 1, .75), (1, 2, .25), (2, 2, .75), (2, 3, .25), (3, 3, .75), (3, 4, .25)]
+
+
+def make_phone_loop(cov, device):
+    'beer hmm mkphones / mkphoneloopgraph / mkphoneloop in memory (recipes/aud/conf/hmm.yml topology).'
+    units, pdf = {}, 0
+    for p in range(N_PHONES):
+        g = beer.graph.Graph()
+        for sid in range(5):
+            g.add_state(pdf_id=None if sid in (0, 4) else pdf + sid - 1)
+        g.start_state, g.end_state = 0, 4
+        for arc in TOPO:
+            g.add_arc(*arc)
+        units[p] = g
+        pdf += 3
+    graph = beer.graph.Graph()
+    graph.start_state, graph.end_state = graph.add_state(), graph.add_state()
+    pivot = graph.add_state()
+    u2s = {p: graph.add_state() for p in units}
+    graph.add_arc(graph.start_state, pivot)
+    graph.add_arc(pivot, graph.end_state)
+    for p in units:
+        graph.add_arc(pivot, u2s[p])
+        graph.add_arc(u2s[p], pivot)
+    graph.normalize()
+    for p, hmm in units.items():
+        graph.replace_state(u2s[p], hmm)
+    graph.normalize()
+    torch.manual_seed(3)
+    S = 3 * N_PHONES
+    ns = beer.NormalSet.create(torch.zeros(D), torch.ones(D), size=S * N_COMP, prior_strength=1.,
+                               noise_std=1., cov_type=cov)
+    emissions = beer.JointModelSet([beer.MixtureSet.create(S, ns, prior_strength=1.)])
+    ploop = beer.PhoneLoop.create(graph.compile(), {p: 3 * p for p in units},
+                                  {p: 3 * p + 2 for p in units}, emissions)
+    return ploop.float().to(device)
+
+
+def hmm_corpus(total_frames):
+    'Utterance lengths U[200, 400] until `total_frames` (seed 2): the same corpus for every N.'
+    rng = np.random.RandomState(2)
+    lengths = []
+    while sum(lengths) < total_frames:
+        lengths.append(int(rng.randint(200, 401)))
+    return lengths
+
+
+def cpu_baseline_hmm(budget_s=20.):
+    '''beer's CPU path for config 3 on the host cores: the reference's op sequence for one
+    `evidence_lower_bound(PhoneLoop, utterance)` per utterance -- phi(X), stats @ E[T]^T,
+    per-state logsumexp, a Python loop of dense [S, S] logsumexp per frame for forward
+    and backward, [T-1, S, S] transition posteriors, joint responsibilities^T @ stats,
+    KL of every parameter per utterance -- replayed with torch CPU ops
+    (oracle/torch_port.py: hmm_elbo) on a bounded sample of utterances.'''
+    from oracle import torch_port as tp
+    g = torch.Generator().manual_seed(5)
+    S, G = 3 * N_PHONES, N_COMP
+    KK = S * G
+    prior = (torch.zeros(KK, D), torch.ones(KK, 1), torch.ones(KK, 1), torch.ones(KK, D))
+    post = (torch.randn(KK, D, generator=g),) + prior[1:]
+    w = torch.ones(S, G)
+    trans = torch.full((S, S), -float('inf'))
+    for s in range(S):
+        trans[s, s] = np.log(.75)
+        if s % 3 < 2:
+            trans[s, s + 1] = np.log(.25)
+        else:
+            trans[s, ::3] = np.log(.25 / N_PHONES)
+    init = torch.where(torch.arange(S) % 3 == 0, torch.tensor(np.log(1. / N_PHONES)),
+                       torch.tensor(-float('inf'))).float()
+    fin = torch.where(torch.arange(S) % 3 == 2, torch.tensor(np.log(.25)),
+                      torch.tensor(-float('inf'))).float()
+    rng = np.random.RandomState(2)
+    ncpu = os.cpu_count() or 1
+    best = (0., torch.get_num_threads())
+    probe = torch.randn(300, D, generator=g)
+    for nt in sorted({min(ncpu, c) for c in (4, 8, 16)}):
+        torch.set_num_threads(nt)
+        t = time.perf_counter()
+        tp.hmm_elbo(probe, post, prior, w, w, init, fin, trans, 10_000_000)
+        rate = 300 / (time.perf_counter() - t)
+        if rate > best[0]:
+            best = (rate, nt)
+    torch.set_num_threads(best[1])
+    t0 = time.perf_counter()
+    frames = utts = 0
+    acc = 0.
+    while time.perf_counter() - t0 < budget_s:
+        T = int(rng.randint(200, 401))
+        X = torch.randn(T, D, generator=g)
+        _, a, _, _ = tp.hmm_elbo(X, post, prior, w, w, init, fin, trans, 10_000_000)
+        acc = acc + a
+        frames += T
+        utts += 1
+    dt = time.perf_counter() - t0
+    return {'value': frames / dt, 'unit': 'frames/s', 'cores': int(torch.get_num_threads()),
+            'kind': 'port',
+            'sample': f'{utts} utterances ({frames} frames) of the config-3 workload (phone loop '
+                      f'40x3 states, 16 diagonal Gaussians per state, D=40, fp32), E-step only, '
+                      f'torch-CPU replay of the reference op sequence, {dt:.1f} s'}
+
+
+def run_hmm(args, rank, world, device, backend):
+    total_frames = args.frames
+    lengths_all = hmm_corpus(total_frames)
+    datasize = sum(lengths_all)
+    mine = shard_utterances(lengths_all, world, rank)        # balanced by frame count
+    lengths = [lengths_all[u] for u in mine]
+    n_local = sum(lengths)
+    g = torch.Generator(device=device).manual_seed(2 + rank)
+    X = torch.randn(n_local, D, generator=g, device=device)
+    ploop = make_phone_loop(args.cov, device)                # identical on every rank
+    optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.)
+    phases = PhaseTimer()
+
+    def step():
+        optim.init_step()
+        elbo = beer.accumulate_elbo(ploop, (X, lengths), datasize=datasize,
+                                    max_frames=args.max_frames)
+        with phases.span('all_reduce'):
+            elbo, _ = all_reduce_elbo(elbo, ploop, len(lengths))
+        with phases.span('m_step'):
+            elbo.backward()
+            optim.step()
+        return elbo
+
+    names = ('beer_mixtureset_estep', 'beer_hmm_posteriors_fused', 'beer_hmm_forward_backward',
+             'beer_mixtureset_accumulate_fused', 'beer_normal_accumulate',
+             'beer_normal_accumulate_packed', 'beer_pack_resps')
+    for _ in range(args.warmup):
+        step()
+    import gc
+    gc.collect()
+    gc.freeze()                  # the set-up's objects: a gen-2 collection over them costs 30 ms
+    phases.clear()
+    fence(world)
+    with KernelTimer(names) as kt:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            elbo = step()
+        fence(world)
+        elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed, world, device, backend)
+    if rank != 0:
+        return None
+    kern = {}
+    for nm in names:
+        ms, n = kt.mean_ms(nm)
+        if n:
+            kern[nm] = {'ms': ms, 'launches': n, 'frames_per_launch': n_local * args.steps / n}
+    dom = max(kern, key=lambda nm: kern[nm]['ms'] * kern[nm]['launches'])
+    # HBM roofline of the dominant call: its algorithmic traffic is the frames it reads,
+    # 4 D bytes each (SURVEY 8d: B(D) = 160 B / frame), once
+    alg_bytes = 4. * D * kern[dom]['frames_per_launch']
+    achieved = alg_bytes / (kern[dom]['ms'] * 1e-3) / 1e9
+    pmc_key = {'beer_mixtureset_accumulate_fused': 'accf_kernel',
+               'beer_mixtureset_estep': 'llh16_kernel',
+               'beer_hmm_posteriors_fused': 'fb_wave_kernel'}.get(dom, dom)
+    Qd = {'diagonal': 2 * D + 2, 'full': D * D + D + 2, 'isotropic': D + 3}[args.cov]
+    out = {
+        'metric': 'frames/sec per VB iteration (E+M)', 'value': datasize * args.steps / elapsed,
+        'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'configs[2]: monophone phone-loop HMM, {N_PHONES} phones x 3 states, '
+                               f'{N_COMP} {args.cov} Gaussians per state (K={3 * N_PHONES * N_COMP}), '
+                               f'D={D}, {datasize} fp32 frames in {len(lengths_all)} utterances '
+                               f'sharded over the ranks by frame count (free phone loop), 1 VB '
+                               'iteration = emission E-step + forward-backward + statistics + '
+                               'all-reduce + M-step',
+                   'parallelism': f'dp{world}', 'frames_total': datasize,
+                   'frames_rank0': n_local, 'utterances': len(lengths_all)},
+        'elbo_per_frame': float(elbo) / (len(lengths_all) * datasize),
+        'f32_mode': beer.get_f32_mode(),
+        'all_reduce_ms': phases.mean_ms('all_reduce'), 'm_step_ms': phases.mean_ms('m_step'),
+        'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': PEAK_HBM_GBS,
+                     'unit': 'GB/s', 'frac': achieved / PEAK_HBM_GBS,
+                     'traffic': pmc_traffic(pmc_key), 'avg_launch_ms': kern[dom]['ms'],
+                     'note': 'achieved = algorithmic bytes (the frames the call reads: 4*D = 160 B '
+                             'per frame) / HIP-event time of the C-ABI call.  The call is bound by '
+                             'matrix-core and VALU work, not by HBM: with the responsibilities '
+                             'recomputed in registers its counter traffic is the frames (re-read '
+                             'per 64-component chunk, mostly from L2), the per-state normalisers '
+                             'and posteriors; algorithmic flops of the iteration are '
+                             f'4*K*Q = {4 * 3 * N_PHONES * N_COMP * Qd} per frame.'},
+        'kernels': kern,
+    }
+    if not args.no_cpu_baseline and world == 1 and args.cov == 'diagonal':
+        out['cpu_baseline'] = cpu_baseline_hmm()
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# launch
+# --------------------------------------------------------------------------------------------
+
+def worker(args):
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', rank))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     # BEER_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with
     # fewer GPUs than ranks (ranks then share devices); the default is RCCL.
     backend = os.environ.get('BEER_BENCH_BACKEND', 'nccl')
@@ -227,107 +604,50 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-
-    X = synth_frames(args.frames, device, seed=1 + rank)
-    lengths = [args.chunk] * (args.frames // args.chunk)
-    if args.frames % args.chunk:
-        lengths.append(args.frames % args.chunk)
-    datasize = args.frames * world
-    model = make_model(device)             # identical on every rank
-    optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.)
-    rel_err = elbo_check(model, X) if rank == 0 else None
-
-    def step():
-        optim.init_step()
-        elbo = beer.accumulate_elbo(model, (X, lengths), datasize=datasize)
-        elbo, _ = all_reduce_elbo(elbo, model, len(lengths))
-        elbo.backward()
-        optim.step()
-        return elbo
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    # the float32 split path hands the responsibilities over packed (two entry points)
-    names = ('beer_mixtureset_estep', 'beer_normal_accumulate',
-             'beer_mixture_estep_packed', 'beer_normal_accumulate_packed')
-    fence()
-    with KernelTimer(names) as kt:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            elbo = step()
-        fence()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device=device if backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = datasize * args.steps / elapsed
-    # algorithmic work of one launch (2*K*Q flop per frame per GEMM,
-    # no symmetry discount), for the frames one launch processes
-    kern = {}
-    for nm in names:
-        ms, n = kt.mean_ms(nm)
-        if n == 0:
-            continue
-        frames_per_launch = args.frames * args.steps / max(1, n)
-        flops = 2. * K * Q * frames_per_launch
-        kern[nm] = {'ms': ms, 'launches': n, 'tflops': flops / (ms * 1e-3) / 1e12}
-    dom = max(kern, key=lambda nm: kern[nm]['ms'] * kern[nm]['launches'])
-    mode = beer.get_f32_mode()
-    split = mode == 'split_f16'
-    peak = PEAK_TFLOPS['f16' if split else 'f32']
-    if split:
-        note = ('fp32 operands are split into two fp16 halves and every product is three '
-                'v_mfma_f32_16x16x32_f16 (fp32 accumulate), so the peak is the dense fp16 MFMA '
-                'peak; achieved = algorithmic flops (2*K*Q per frame, no symmetry discount, '
-                'one flop pair per product) / HIP-event time of the C-ABI call.  The matrix '
-                'cores execute 3 * 2*K*928 flop per frame (1.70x the algorithmic count): '
-                'hardware rate = 1.70 * achieved.  The same call on the exact fp32 MFMA '
-                '(BEER_F32_MODE=exact, peak 157.3) ran at 174 TFLOP/s algorithmic.')
-    else:
-        note = ('achieved = algorithmic flops (2*K*Q per frame, no symmetry discount) / '
-                'HIP-event time of the C-ABI call; the kernels contract only the D(D+1)/2 '
-                'symmetric products (0.56x the multiply-adds), so frac can exceed 1')
-    out = {
-        'metric': 'frames/sec per VB iteration (E+M)', 'value': value, 'unit': 'frames/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'configs[1]: GMM K=256 full-covariance, D=40, '
-                               f'{args.frames} fp32 frames per GPU in {args.chunk}-frame '
-                               'utterances, 1 VB iteration = E-step + all-reduce + M-step',
-                   'parallelism': f'dp{world}', 'frames_per_gpu': args.frames,
-                   'components': K, 'dim': D},
-        'elbo_rel_err_vs_cpu_fp64': rel_err,
-        'elbo_per_frame': float(elbo) / (len(lengths) * world * datasize),
-        'f32_mode': mode,
-        'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'],
-                     'peak': peak, 'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / peak,
-                     'traffic': pmc_traffic((('acc16p_kernel' if 'packed' in dom else 'acc16_kernel')
-                                             if split else 'acc_kernel')
-                                            if 'accumulate' in dom else
-                                            ('llh16_kernel' if split else 'llh_kernel')),
-                     'avg_launch_ms': kern[dom]['ms'],
-                     'note': note},
-        'kernels': kern,
-    }
-    if not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline()
-    print(json.dumps(out), flush=True)
+    run = run_gmm if args.config == 2 else run_hmm
+    out = run(args, rank, world, device, backend)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _spawned(rank, args, port):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    worker(args)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', type=int, default=2, choices=(2, 3),
+                    help='BASELINE.json config: 2 = GMM K=256 full (headline), 3 = phone-loop HMM')
+    ap.add_argument('--frames', type=int, default=None,
+                    help='config 2: frames per GPU (1,000,000); config 3: frames of the whole '
+                         'corpus (10,000,000)')
+    ap.add_argument('--chunk', type=int, default=8192, help='config 2: frames per "utterance"')
+    ap.add_argument('--cov', default='diagonal', help='config 3: covariance type of the emissions')
+    ap.add_argument('--max-frames', type=int, default=1 << 21,
+                    help='config 3: frames per launch of the batched E-step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-exact', action='store_true', help='config 2: skip the f32_exact leg')
+    ap.add_argument('--no-check', action='store_true', help='config 2: skip the oracle check')
+    args = ap.parse_args()
+    if args.frames is None:
+        args.frames = 1_000_000 if args.config == 2 else 10_000_000
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher: spawn the ranks ourselves (one process per GPU, loopback rendezvous)
+        import torch.multiprocessing as mp
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        mp.spawn(_spawned, args=(args, port), nprocs=args.gpus, join=True)
+        return
+    worker(args)
 
 
 if __name__ == '__main__':

@@ -141,6 +141,21 @@ int beer_dirichlet_natural(int dtype, int S, int G, const void* conc,
                            void* out, void* stream);
 int beer_dirichlet_from_natural(int dtype, int S, int G, const void* eta,
                                 void* conc, void* stream);
+/* Truncated stick-breaking categorical (P <= 1024 sticks; device, one workgroup).
+ * beer_sb_transform_stats: SBCategorical._transform_stats
+ * (beer/models/categorical.py:106-118) -- the sticks are ordered by decreasing
+ * count (stable), `ordering[r]` = category of stick r, and the counts [P] become
+ * the Dirichlet statistics of the sticks [P,2] = (count_i, count_i + sum of the
+ * counts ordered after i), stored in the categories' own order.
+ * beer_sb_log_weights: SBCategorical._log_prob + the re-ordering of
+ * expected_log_likelihood (categorical.py:120-131, 157-159) -- E[ln pi_i] =
+ * E[ln v_i] + sum over the sticks before i of E[ln(1 - v)], [P] in the categories'
+ * order; `log_1_v_sum` (nullable) = sum_i E[ln(1 - v_i)], the statistic of the
+ * Gamma hyper-prior (categorical.py:203-209). */
+int beer_sb_transform_stats(int dtype, int P, const void* counts, int64_t* ordering,
+                            void* stats, void* stream);
+int beer_sb_log_weights(int dtype, int P, const void* conc, const int64_t* ordering,
+                        void* log_w, void* log_1_v_sum, void* stream);
 /* E[ln pi] of S categoricals: the `eye -> sufficient_statistics -> stats @
  * E[T]` sequence of Mixture._log_weights (beer/models/mixture.py:45-48) and
  * MixtureSet._log_weights (mixtureset.py:64-67) -> out [S,G]. */

@@ -137,3 +137,113 @@ def gmm_iteration(X, post, prior, w_post, w_prior, chunk):
         total, acc_n, acc_w = total + v, acc_n + an, acc_w + aw
     new_post, new_w = gmm_update(post, prior, w_post, w_prior, acc_n, acc_w, D)
     return float(total), new_post, new_w
+
+
+# ---------------------------------------------------------------------------
+# Phone-loop HMM with diagonal-covariance mixture emissions (BASELINE config 3):
+# one `evidence_lower_bound(PhoneLoop, utterance)` call in the reference's op
+# sequence --
+#     phi(X) with mul + cat                                normalgamma.py:20-27
+#     E[T] with digamma / log                              normalgamma.py:118-146
+#     stats @ E[T]^T, per-state logsumexp, resps           mixtureset.py:85-98
+#     gather by pdf id, scale                              modelset.py:140-146, hmm.py:79
+#     forward / backward: a Python loop over frames of
+#       torch.logsumexp over the dense [S, S] matrix       graph.py:270-287
+#     posteriors + [T-1, S, S] transition posteriors       graph.py:289-326
+#     joint responsibilities, resps^T @ stats              mixtureset.py:100-112
+#     KL(q || p) of every parameter, once per utterance    objectives.py:183
+# Numerically pinned against the numpy oracle
+# (tests/test_oracle_golden.py::test_torch_port_hmm_matches_oracle).
+# ---------------------------------------------------------------------------
+
+def ng_exp_stats(mean, scale, shape, rates):
+    D = mean.shape[-1]
+    prec = shape / rates
+    pqm = (prec * mean ** 2).sum(-1, keepdim=True) + D / scale
+    logdet = (torch.digamma(shape) - torch.log(rates)).sum(-1, keepdim=True)
+    return torch.cat([prec * mean, prec, pqm, logdet], dim=-1)
+
+
+def ng_log_norm(mean, scale, shape, rates):
+    D = rates.shape[-1]
+    return (D * torch.lgamma(shape) - shape * torch.log(rates).sum(-1, keepdim=True)
+            - .5 * D * torch.log(scale)).sum(-1)
+
+
+def ng_natural(mean, scale, shape, rates):
+    return torch.cat([scale * mean, -.5 * scale * mean ** 2 - rates, -.5 * scale, shape - .5],
+                     dim=-1)
+
+
+def dirset_exp_stats(c):
+    'Rows of Dirichlet concentrations [S, G] -> E[T] [S, G] (dirichlet.py:106-128).'
+    out = torch.zeros_like(c)
+    psi = torch.digamma(c[:, -1])
+    out[:, :-1] = torch.digamma(c[:, :-1]) - psi[:, None]
+    out[:, -1] = psi - torch.digamma(c.sum(-1))
+    return out
+
+
+def dirset_natural(c):
+    out = c - 1
+    out[:, -1] = (c - 1).sum(-1)
+    return out
+
+
+def dirset_log_norm(c):
+    return torch.lgamma(c).sum(-1) - torch.lgamma(c.sum(-1))
+
+
+def hmm_forward_backward(llhs, init_lp, final_lp, trans_lp):
+    'graph.py:270-326: (gamma [T,S], xi [T-1,S,S]).'
+    T, S = llhs.shape
+    la = torch.full_like(llhs, -float('inf'))
+    la[0] = llhs[0] + init_lp
+    At = trans_lp.t()
+    for i in range(1, T):
+        la[i] = llhs[i] + torch.logsumexp(la[i - 1] + At, dim=1)
+    lb = torch.full_like(llhs, -float('inf'))
+    lb[-1] = final_lp
+    for i in reversed(range(T - 1)):
+        lb[i] = torch.logsumexp(trans_lp + llhs[i + 1] + lb[i + 1], dim=1)
+    lognorm = torch.logsumexp(la + lb, dim=1)
+    gamma = torch.exp(la + lb - lognorm[:, None])
+    log_xi = la[:-1, :, None] + trans_lp[None] + (llhs + lb)[1:, None, :]
+    log_xi = log_xi.reshape(-1, S * S)
+    xi = torch.exp(log_xi - torch.logsumexp(log_xi, dim=1)[:, None])
+    xi[xi != xi] = 0.
+    return gamma, xi.reshape(-1, S, S)
+
+
+def hmm_elbo(X, post, prior, w_post, w_prior, init_lp, final_lp, trans_lp, datasize,
+             trans_posteriors=True):
+    '''One utterance through a phone-loop HMM whose S states each have a G-component
+    diagonal mixture (pdf ids = states).  post / prior: Normal-Gamma std params of
+    the S*G Gaussians; w_post / w_prior [S, G].  Returns (value, Gaussian stats
+    [S*G, 2D+2], weight stats [S, G], summed transition posteriors [S, S]).'''
+    T, D = X.shape
+    S, G = w_post.shape
+    one = torch.ones(T, 1, dtype=X.dtype)
+    stats = torch.cat([X, -.5 * X ** 2, -.5 * one, .5 * one], dim=-1)
+    exp_T = ng_exp_stats(*post)
+    pc = (stats @ exp_T.t() - .5 * D * LOG2PI).reshape(T, S, G)
+    eye = torch.eye(G, dtype=X.dtype)
+    eye[:, -1] = eye.sum(-1)
+    lw = (eye @ dirset_exp_stats(w_post).t()).t()
+    w = pc + lw[None]
+    log_norm = torch.logsumexp(w, dim=-1)
+    comp = torch.exp(w - log_norm[:, :, None])
+    gamma, xi = hmm_forward_backward(log_norm, init_lp, final_lp, trans_lp)
+    exp_llh = (log_norm * gamma).sum(-1)
+    kl = (ng_log_norm(*prior) - ng_log_norm(*post)
+          - torch.sum(exp_T * (ng_natural(*prior) - ng_natural(*post)), dim=-1)).sum()
+    kl = kl + (dirset_log_norm(w_prior) - dirset_log_norm(w_post)
+               - torch.sum(dirset_exp_stats(w_post) * (dirset_natural(w_prior)
+                                                       - dirset_natural(w_post)), dim=-1)).sum()
+    value = (datasize / float(T)) * exp_llh.sum() - kl
+    joint = comp * gamma[:, :, None]
+    wstats = joint.reshape(-1, G).clone()
+    wstats[:, -1] = wstats.sum(-1)
+    wstats = wstats.reshape(T, S, G).sum(0)
+    acc = joint.reshape(T, S * G).t() @ stats
+    return value, acc, wstats, (xi.sum(0) if trans_posteriors else None)

@@ -348,3 +348,37 @@ def test_torch_port_matches_oracle():
     for arr, ref in zip(new_post, std_params(g, 'it0.p0.posterior')):
         assert_close(arr.numpy().reshape(ref.shape), ref, 1e-8)
     assert_close(new_w.numpy(), g['it0.p1.posterior.concentrations'], 1e-10)
+
+
+def test_torch_port_hmm_matches_oracle():
+    '''bench.py's config-3 cpu_baseline (oracle/torch_port.py: hmm_elbo, the
+    reference's op sequence on torch CPU tensors) against the numpy oracle, which
+    is pinned on the reference's goldens G4-G6.'''
+    import torch
+    from oracle import torch_port as tp
+    rng = np.random.RandomState(0)
+    P, G, D, T = 5, 4, 6, 40
+    S, K = 3 * P, 3 * P * G
+    post = (rng.randn(K, D), 1 + rng.rand(K, 1), 2 + rng.rand(K, 1), 1 + rng.rand(K, D))
+    prior = (rng.randn(K, D), np.ones((K, 1)), np.ones((K, 1)), np.ones((K, D)))
+    wp, w0 = 1 + rng.rand(S, G), np.ones((S, G))
+    trans = np.full((S, S), -np.inf)
+    for s in range(S):
+        trans[s, s] = np.log(.75)
+        if s % 3 < 2:
+            trans[s, s + 1] = np.log(.25)
+        else:
+            trans[s, ::3] = np.log(.25 / P)
+    init = np.where(np.arange(S) % 3 == 0, np.log(1. / P), -np.inf)
+    fin = np.where(np.arange(S) % 3 == 2, np.log(.25), -np.inf)
+    X = rng.randn(T, D)
+    groups = [dict(cov_type='diagonal', S=S, G=G, post=post, prior=prior, w_post=wp, w_prior=w0)]
+    ref = orc.hmm_elbo_step(X, groups, dict(init=init, final=fin, trans=trans, order=np.arange(S)),
+                            datasize=1000, trans_posteriors=True)
+    t = lambda a: torch.from_numpy(np.asarray(a))        # noqa: E731
+    value, acc, wstats, xi = tp.hmm_elbo(t(X), tuple(map(t, post)), tuple(map(t, prior)), t(wp),
+                                         t(w0), t(init), t(fin), t(trans), 1000)
+    assert_close(float(value), ref['value'], 1e-12, 'value')
+    assert_close(acc.numpy(), ref['acc'][0][0], 1e-12, 'Gaussian statistics')
+    assert_close(wstats.numpy(), ref['acc'][0][1], 1e-12, 'weight statistics')
+    assert_close(xi.numpy(), ref['trans_resps'].sum(0), 1e-12, 'transition posteriors')
