@@ -139,6 +139,7 @@ SIGNATURES = {
     'beer_hmm_posteriors_fused': [c_i, c_p, c_i, c_p, c_d, c_p, c_p, c_p, c_i, c_p, c_p, c_p,
                                   c_p],
     'beer_hmm_viterbi': [c_i, c_p, c_p, c_p, c_p, c_i, c_p],
+    'beer_hmm_trans_posteriors': [c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     'beer_hmm_path_posteriors': [c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     'beer_hmm_scatter': [c_i, c_p, c_i, c_p, c_p, c_d, c_p, c_p, c_p, c_p],
     'beer_segment_sum': [c_i, ctypes.c_int32, c_p, c_p, c_p, c_p],

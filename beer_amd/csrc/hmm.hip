@@ -1169,6 +1169,53 @@ __global__ void path_post_kernel(beer_batch b, const int64_t* __restrict__ path,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Per-frame transition posteriors in the reference's layout, [T-1, S, S]
+// (graph.py:308-323), for callers that ask for that tensor (small inputs: it is
+// 8 S^2 bytes per frame).  From what a forward-backward call leaves behind --
+// alpha (fp64 workspace), gamma -- and the dense transition matrix:
+//   xi_t(i,j)  ~  alpha_t(i) + A_ij + llh_{t+1}(j) + beta_{t+1}(j),
+//   beta_{t+1}(j) = ln gamma_{t+1}(j) - alpha_{t+1}(j) + const,
+// normalised per frame; a frame whose terms are all -inf gives 0 (the
+// reference's NaN -> 0).  One workgroup per frame.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void xi_dense_kernel(int64_t nframes, int S,
+                                                       const double* __restrict__ alpha,
+                                                       const T* __restrict__ llh,
+                                                       const T* __restrict__ gamma,
+                                                       const T* __restrict__ trans,
+                                                       T* __restrict__ out) {
+    __shared__ double red[8];
+    const int64_t t = blockIdx.x;
+    if (t + 1 >= nframes) return;
+    const double NINF = neg_inf();
+    const double* a0 = alpha + t * S;
+    const double* a1 = alpha + (t + 1) * S;
+    const T* l1 = llh + (t + 1) * S;
+    const T* g1 = gamma + (t + 1) * S;
+    T* o = out + t * (int64_t)S * S;
+    auto term = [&](int e) {
+        const int i = e / S, j = e - i * S;
+        const double gj = (double)g1[j];
+        if (!(gj > 0.0)) return NINF;
+        return a0[i] + (double)trans[e] + (double)l1[j] + log(gj) - a1[j];
+    };
+    double m = NINF;
+    for (int e = threadIdx.x; e < S * S; e += blockDim.x) {
+        const double v = term(e);
+        m = v > m ? v : m;
+    }
+    m = block_max(m, red);
+    const bool finite = m > NINF && m < __builtin_huge_val();
+    double sm = 0.0;
+    if (finite)
+        for (int e = threadIdx.x; e < S * S; e += blockDim.x) sm += exp(term(e) - m);
+    sm = block_sum(sm, red);
+    for (int e = threadIdx.x; e < S * S; e += blockDim.x)
+        o[e] = finite && sm > 0.0 ? (T)(exp(term(e) - m) / sm) : (T)0;
+}
+
 // ---- launchers -------------------------------------------------------------
 
 template <typename T>
@@ -1338,6 +1385,23 @@ int beer_hmm_forward_backward(int dtype, const beer_batch* b, const void* pc_llh
                            (const double*)pc_llhs, alpha_ws, (double*)gamma, xi_sum,
                            gamma0_sum, (double*)lognorm_mean);
     }
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+int beer_hmm_trans_posteriors(int dtype, int64_t T, int S, const double* alpha, const void* llhs,
+                              const void* gamma, const void* trans, void* xi, void* stream) {
+    BEER_REQUIRE(T >= 0 && S >= 1 && (dtype == BEER_F32 || dtype == BEER_F64));
+    if (T <= 1) return BEER_OK;
+    BEER_REQUIRE(alpha && llhs && gamma && trans && xi);
+    if (dtype == BEER_F32)
+        hipLaunchKernelGGL(xi_dense_kernel<float>, dim3((unsigned)(T - 1)), dim3(256), 0,
+                           as_stream(stream), T, S, alpha, (const float*)llhs, (const float*)gamma,
+                           (const float*)trans, (float*)xi);
+    else
+        hipLaunchKernelGGL(xi_dense_kernel<double>, dim3((unsigned)(T - 1)), dim3(256), 0,
+                           as_stream(stream), T, S, alpha, (const double*)llhs,
+                           (const double*)gamma, (const double*)trans, (double*)xi);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }

@@ -11,7 +11,7 @@ import math
 import torch
 
 from .. import _hip
-from ..stats import FrameStats
+from ..stats import FrameStats, reference_layout_enabled
 from .expfam import ConjugateLikelihood, ExponentialFamily, make_std_params
 
 __all__ = [
@@ -136,7 +136,8 @@ class NormalLikelihood(ConjugateLikelihood):
         if torch.is_grad_enabled() and data.requires_grad:
             from ..kernels import differentiable_stats
             return differentiable_stats(data, cls.cov_type)
-        return FrameStats(data, cls.cov_type)
+        stats = FrameStats(data, cls.cov_type)
+        return stats.dense() if reference_layout_enabled() else stats
 
     def __call__(self, pdfvecs, stats):
         'stats @ pdfvecs^T - D/2 ln 2pi -> [T, K] (normalwishart.py:88-92).'

@@ -551,11 +551,18 @@ class CompiledGraph(torch.nn.Module):
         reference's [N-1, K, K] tensor, transition posteriors [K, K]) from
         per-frame, per-state log-likelihoods.  Returns (posteriors,
         mean per-frame log-normaliser) like graph.py:289-326.'''
-        from .hmm_kernels import HmmBatch, forward_backward
+        from .hmm_kernels import HmmBatch, forward_backward, trans_posteriors_dense
+        from .stats import reference_layout_enabled
         batch = HmmBatch([self], [0], [len(llhs)], llhs.dtype, with_pdf_ids=False)
         llhs_d = _hip.on_device(llhs)
-        gamma, xi_sum, _, lognorm, _ = forward_backward(batch, llhs_d, want_xi=trans_posteriors,
-                                                        want_lognorm=True, dense_xi=True)
+        per_frame = trans_posteriors and reference_layout_enabled()
+        gamma, xi_sum, _, lognorm, _ = forward_backward(
+            batch, llhs_d, want_xi=trans_posteriors and not per_frame, want_lognorm=True,
+            dense_xi=True)
+        if per_frame:
+            # the reference's [N-1, K, K] tensor (beer_amd.reference_layout)
+            xi = trans_posteriors_dense(batch, llhs_d, gamma, self.trans_log_probs)
+            return (gamma.view(len(llhs), -1), xi), lognorm[0]
         gamma = gamma.view(len(llhs), -1)
         if trans_posteriors:
             return (gamma, xi_sum.to(llhs.dtype)), lognorm[0]

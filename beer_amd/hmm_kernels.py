@@ -10,7 +10,7 @@ from . import _hip
 
 __all__ = ['HmmBatch', 'gather', 'forward_backward', 'viterbi', 'path_posteriors',
            'scatter', 'gather_columns', 'scatter_columns', 'segment_sum', 'fused_ok',
-           'posteriors_fused']
+           'posteriors_fused', 'trans_posteriors_dense']
 
 
 class HmmBatch:
@@ -164,7 +164,23 @@ def forward_backward(batch, pc_llhs, want_xi=False, want_lognorm=False, dense_xi
                 'sparser graphs, or graphs with at most 8 arcs per state besides a declared '
                 'hub (CompiledGraph.set_hub), run at any size') from err
         raise
+    batch.last_alpha = alpha              # (for `trans_posteriors_dense`)
     return gamma, xi, g0, ln, flow
+
+
+def trans_posteriors_dense(batch, pc_llhs, gamma, trans_log_probs):
+    '''Per-frame transition posteriors [T-1, S, S] of a ONE-utterance batch whose
+    forward-backward call has just run (`beer_hmm_trans_posteriors`): the
+    reference's layout, graph.py:308-323.'''
+    if batch.nutt != 1:
+        raise ValueError('per-frame transition posteriors: one utterance at a time')
+    S, T = batch.n_states[0], batch.n_frames
+    trans = _hip.on_device(trans_log_probs, batch.dtype)
+    xi = torch.zeros(max(T - 1, 0), S, S, dtype=batch.dtype, device=batch.device)
+    _hip.call('beer_hmm_trans_posteriors', _hip.dtype_code(batch.dtype), T, S,
+              _hip.ptr(batch.last_alpha), _hip.ptr(pc_llhs), _hip.ptr(gamma), _hip.ptr(trans),
+              _hip.ptr(xi))
+    return xi
 
 
 FUSED_MAX_STATES = 256      # kWvMaxStates of csrc/hmm.hip

@@ -8,6 +8,7 @@ batched accumulator (beer_amd/inference/batch.py) with a batch of one.
 import torch
 
 from .. import _hip, hmm_kernels as hk, kernels
+from ..stats import reference_layout_enabled
 from .basemodel import DiscreteLatentModel
 from .gaussians import NormalSet
 from .modelset import DynamicallyOrderedModelSet
@@ -88,7 +89,13 @@ class HMM(DiscreteLatentModel):
             path = hk.viterbi(batch, pc_llhs) if state_path is None else state_path
             gamma, xi, g0 = hk.path_posteriors(batch, path, want_xi=trans_posts)
         else:
-            gamma, xi, g0, _, flow = hk.forward_backward(batch, pc_llhs, want_xi=trans_posts)
+            per_frame = trans_posts and reference_layout_enabled() and utt_lengths is None
+            gamma, xi, g0, _, flow = hk.forward_backward(batch, pc_llhs,
+                                                         want_xi=trans_posts and not per_frame)
+            if per_frame:
+                # the reference's [T-1, S, S] tensor, hub arcs included: no separate flows
+                xi = hk.trans_posteriors_dense(batch, pc_llhs, gamma, graph.trans_log_probs)
+                flow = None
         state_resps, exp_llh = hk.scatter(batch, pc_llhs, gamma, S_total, scale)
         self.cache['resps'] = gamma.view(T, -1)
         if trans_posts:
@@ -198,6 +205,8 @@ class PhoneLoop(HMM):
         its hub: `hub_flow` then holds the whole sum.'''
         ends, starts = self._index_tensors(gamma0.device)
         counts = gamma0[starts].to(torch.float64)
+        if xi_sum is not None and xi_sum.dim() == 3:          # per frame (reference layout)
+            xi_sum = xi_sum.sum(dim=0)
         if xi_sum is not None:
             counts = counts + xi_sum[:, starts][ends, :].sum(dim=0)
         if hub_flow is not None:

@@ -129,8 +129,9 @@ class SBCategorical(Model):
         pairs = torch.empty(counts.shape[0], 2, dtype=counts.dtype, device=counts.device)
         _hip.call('beer_sb_transform_stats', _hip.dtype_code(counts.dtype), counts.shape[0],
                   _hip.ptr(counts), _hip.ptr(ordering), _hip.ptr(pairs))
-        self.ordering = ordering
-        self.stickbreaking.stats = pairs
+        home = self.stickbreaking.stats.device                 # where the model lives
+        self.ordering = ordering.to(home)
+        self.stickbreaking.stats = pairs.to(home)
 
     def _log_weights_and_tail(self):
         '(E[ln pi] [P] in the categories order, sum_i E[ln(1 - v_i)] as a 0-dim tensor).'
@@ -153,11 +154,12 @@ class SBCategorical(Model):
     @property
     def mean(self):
         'E[pi] under independent sticks: E[v_i] prod_{j before i} E[1 - v_j].'
-        ab = self.stickbreaking.posterior.params.concentrations[self.ordering]
+        conc = self.stickbreaking.posterior.params.concentrations
+        ab = conc[self.ordering.to(conc.device)]
         total = ab.sum(dim=-1) + torch.finfo(ab.dtype).eps
         stick, rest = ab[:, 0] / total, (ab[:, 1] / total).cumprod(dim=0)
         stick[1:] = stick[1:] * rest[:-1]
-        return stick[self.reverse_ordering]
+        return stick[self.reverse_ordering.to(stick.device)]
 
     def sufficient_statistics(self, data):
         return data
@@ -169,7 +171,7 @@ class SBCategorical(Model):
         return self._log_weights_and_tail()[0]
 
     def expected_log_likelihood(self, stats):
-        return stats @ self.log_weights().to(stats.dtype)
+        return stats @ self.log_weights().to(dtype=stats.dtype, device=stats.device)
 
     def accumulate(self, stats):
         return {self.stickbreaking: stats.sum(dim=0)}
@@ -201,5 +203,5 @@ class SBCategoricalHyperPrior(SBCategorical):
     def _on_stickbreaking_update(self):
         _, tail = self._log_weights_and_tail()
         n_sticks = torch.full_like(tail, float(len(self.ordering)))
-        self.concentration.stats = torch.stack([tail, n_sticks])
+        self.concentration.stats = torch.stack([tail, n_sticks]).to(self.concentration.stats.device)
         self.concentration.natural_grad_update(lrate=1.)

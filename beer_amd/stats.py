@@ -12,7 +12,40 @@ import torch
 
 from . import _hip
 
-__all__ = ['FrameStats']
+__all__ = ['FrameStats', 'reference_layout', 'reference_layout_enabled']
+
+_REFERENCE_LAYOUT = [False]
+
+
+def reference_layout_enabled():
+    return _REFERENCE_LAYOUT[0]
+
+
+class reference_layout:
+    '''Switch (also a context manager) to the reference's own return shapes where
+    beer_amd normally keeps something cheaper:
+
+    * `model.sufficient_statistics(X)` returns the dense `[T, Q]` tensor
+      (beer/dists/normalwishart.py:30-38) instead of the lazy `FrameStats`;
+    * `CompiledGraph.posteriors(llhs, trans_posteriors=True)` and
+      `HMM.cache['trans_resps']` hold the transition posteriors per frame,
+      `[T-1, S, S]` (beer/graph.py:308-323), instead of their sum over time.
+
+    Meant for small inputs (notebooks, code that inspects these tensors): the
+    statistics are 6.6 KB per frame at D = 40, the transition posteriors 8 S^2 bytes
+    per frame.  `beer_amd.reference_layout(True)` switches it on for the process,
+    `with beer_amd.reference_layout():` for a block.'''
+
+    def __init__(self, enabled=True):
+        self._previous = _REFERENCE_LAYOUT[0]
+        _REFERENCE_LAYOUT[0] = bool(enabled)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        _REFERENCE_LAYOUT[0] = self._previous
+        return False
 
 
 class FrameStats:

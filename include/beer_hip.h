@@ -463,6 +463,17 @@ int beer_hmm_posteriors_fused(int dtype, const beer_batch* batch_h, int S_total,
                               double* gamma0_sum, double* hub_flow, double* utt_llh,
                               void* stream);
 
+/* Per-frame transition posteriors in the reference's own layout, xi [T-1, S, S]
+ * (beer/graph.py:308-323: normalised per frame, NaN -> 0), for ONE utterance,
+ * from what beer_hmm_forward_backward left behind: `alpha` (its fp64 workspace
+ * [T,S]), `gamma` [T,S], the emission log-likelihoods `llhs` [T,S] it was given
+ * and the dense transition log-probabilities `trans` [S,S].  The batched path
+ * never forms this tensor (8 S^2 bytes per frame); it exists for callers that
+ * switch the reference layout on (beer_amd.reference_layout). */
+int beer_hmm_trans_posteriors(int dtype, int64_t T, int S, const double* alpha,
+                              const void* llhs, const void* gamma, const void* trans,
+                              void* xi, void* stream);
+
 /* Viterbi + backtrack, CompiledGraph.best_path (beer/graph.py:329-344):
  * first-index tie-break, -inf safe, int64 state path per frame (packed like
  * the frames).  `bt_ws` is int32 scratch with the layout of pc_llhs.  With `map_pdf` != 0 the path is mapped through pdf_id_mapping as

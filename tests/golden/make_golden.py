@@ -715,7 +715,32 @@ def g15_features():
     save('g15_features', out)
 
 
+def g16_notebooks():
+    '''The example notebooks' call sequences (tests/golden/notebook_cells.py) run on
+    the reference: inputs and what the cells print / plot.'''
+    sys.path.insert(0, HERE)
+    import notebook_cells as nb
+    out = {}
+    data = nb.mixture_data()
+    out['mixture.data'] = data
+    for variant in ('dirichlet', 'sb', 'sb_hyper'):
+        for key, val in nb.mixture_model(beer, data, variant, epochs=8).items():
+            out[f'mixture.{variant}.{key}'] = val
+    data, states = nb.hmm_data()
+    out['hmm.data'], out['hmm.states'] = data, states
+    for key, val in nb.hmm(beer, data, epochs=8).items():
+        out[f'hmm.{key}'] = val
+    data, states = nb.align_data()
+    out['align.data'], out['align.states'] = data, states
+    for key, val in nb.hmm_align(beer, data, epochs=6).items():
+        out[f'align.{key}'] = val
+    save('g16_notebooks', out)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'notebooks':
+        g16_notebooks()
+        sys.exit(0)
     g1_g3_g11()
     g4(torch.float64, '')
     g4(torch.float32, '_f32')
@@ -728,3 +753,4 @@ if __name__ == '__main__':
     g_pickles()
     g14_vae()
     g15_features()
+    g16_notebooks()
