@@ -329,9 +329,14 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
     // (pc_llh only, or G == 1 log_norm only) pass 1 alone is enough.
     const bool need_norm = (log_norm || comp_resps || llh_sum) && !labels;
     void* w_buf = comp_resps;
-    const bool mfma_ok = !labels && !pc_llh && stat_scale == 1.0 && ws &&
-                         beer_mfma::supported_llh(D, S, G) &&
-                         ws_bytes >= beer_mfma::estep_workspace_bytes(sizeof(T), cov, D, S, G) &&
+    // group-aligned shapes on every arithmetic; any G on the split path when only the
+    // log-normalisers are wanted (groups padded to a power of two)
+    const bool aligned = beer_mfma::supported_llh(D, S, G) &&
+                         ws_bytes >= beer_mfma::estep_workspace_bytes(sizeof(T), cov, D, S, G);
+    const bool padded = sizeof(T) == 4 && !exact && !comp_resps &&
+                        beer_mfma::supported_llh_split(D, S, G) &&
+                        ws_bytes >= beer_mfma::estep16_workspace_bytes(cov, D, S, G);
+    const bool mfma_ok = !labels && !pc_llh && stat_scale == 1.0 && ws && (aligned || padded) &&
                          (log_norm || comp_resps || llh_sum);
     if (need_norm && !w_buf && !mfma_ok) {
         // G == 1: log_norm == w; let pass 1 write into log_norm directly (the
@@ -348,7 +353,8 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
     if (mfma_ok) {
         // gfx950 matrix-core path: GEMM + (grouped) softmax fused, one kernel
         if (sizeof(T) == 4 && !exact &&
-            ws_bytes >= beer_mfma::estep16_workspace_bytes(cov, D, S, G))
+            ws_bytes >= beer_mfma::estep16_workspace_bytes(cov, D, S, G) &&
+            (padded || beer_mfma::supported_llh(D, S, G)))
             return beer_mfma::estep_f16x3(cov, nframes, D, S, G, (const float*)X,
                                           (const float*)expT, (const float*)logw,
                                           (float*)comp_resps, (float*)log_norm, llh_sum, ws,

@@ -191,17 +191,22 @@ __device__ inline double entry_value(int cov, int D, int K, int k, int slab, int
 
 // One workgroup per (padded) component: column scale, then its fp16 hi / lo
 // images at P16[chunk][kstep][tile][hi 64 x 8 | lo 64 x 8] halves, and 1 / scale.
+// Component SLOT blockIdx.x of the image is component (slot / Gp) * G + slot % Gp when
+// slot % Gp < G, else padding (G <= Gp: the groups of a mixture set padded to a power
+// of two, so that any number of components per state runs on the group-aligned
+// kernels; G == Gp: slots are components).
 __global__ void pack16_kernel(int cov, int D, int K, int NT, const float* __restrict__ E,
                               const float* __restrict__ logw, const float* __restrict__ sc,
                               _Float16* __restrict__ P, float* __restrict__ inv_scale,
-                              int* __restrict__ tab) {
+                              int* __restrict__ tab, int G = 1, int Gp = 1) {
     __shared__ double red[8];
     const int nk = nk16_of(cov, D), nent = nk * 32;
-    const int k = blockIdx.x;
-    const int chunk = k / (NT * 16), kk = k % (NT * 16);
+    const int slot = blockIdx.x;
+    const int k = slot % Gp < G ? (slot / Gp) * G + slot % Gp : K;     // K: a padded slot
+    const int chunk = slot / (NT * 16), kk = slot % (NT * 16);
     const int c = 4 * (kk / 64) + (kk % 4), i = (kk % 64) / 4;
     const float* isx = sc + 64;
-    if (k == 0)
+    if (slot == 0)
         for (int s = threadIdx.x; s < (nk + 1) * 8; s += blockDim.x) {
             // padding slabs read the zero columns behind the "1" of a frame row
             const int Dp = 4 * d4_of(D);
@@ -220,7 +225,7 @@ __global__ void pack16_kernel(int cov, int D, int K, int NT, const float* __rest
         frexp(mx, &e);                                       // mx < 2^e
         scale = ldexp(1.0, kColBits - e);
     }
-    if (threadIdx.x == 0) inv_scale[k] = k < K ? (float)(1.0 / scale) : 1.0e30f;
+    if (threadIdx.x == 0) inv_scale[slot] = k < K ? (float)(1.0 / scale) : 1.0e30f;
     _Float16* base = P + ((size_t)chunk * nk * NT) * 1024;
     for (int q = threadIdx.x; q < nent; q += blockDim.x) {
         bool is_const;
@@ -1159,11 +1164,11 @@ constexpr int kAfMaxFramesPerWave = 4096; // fp32 roundings per sum: 128
 
 template <int NTC, int NQT, bool G4, int WAVES, int kXP>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
-    int64_t nframes, int D, int K, int S, int G, int nk, int nslab, const float* __restrict__ X,
-    const _Float16* __restrict__ Pall, const float* __restrict__ inv_scale,
-    const float* __restrict__ sc, const int* __restrict__ tab,
-    const float* __restrict__ log_norm, const float* __restrict__ sr,
-    int64_t frames_per_block, double* __restrict__ Sp, int dbg) {
+    int64_t nframes, int D, int K, int S, int G, int Greal, int nk, int nslab,
+    const float* __restrict__ X, const _Float16* __restrict__ Pall,
+    const float* __restrict__ inv_scale, const float* __restrict__ sc,
+    const int* __restrict__ tab, const float* __restrict__ log_norm,
+    const float* __restrict__ sr, int64_t frames_per_block, double* __restrict__ Sp, int dbg) {
     constexpr int MT = 2, FW = 32, QT = NTC / 4, NTHREADS = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D4 = d4_of(D), Dp = 4 * D4, LD = ld16_of(D), nq = nslab * 4;
@@ -1505,8 +1510,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
         for (int c = 0; c < NTC; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int k = kbase + 64 * (c >> 2) + 4 * (4 * g + r) + (c & 3);
-                if (k < K) atomicAdd(Sp + (size_t)k * nq + q, (double)sacc[c][uu][r] * unscale);
+                const int slot = kbase + 64 * (c >> 2) + 4 * (4 * g + r) + (c & 3);
+                // slot -> component (padded slots of a group and slots past the end: none)
+                const int gi = slot % G;
+                if (slot < K && gi < Greal)
+                    atomicAdd(Sp + (size_t)((slot / G) * Greal + gi) * nq + q,
+                              (double)sacc[c][uu][r] * unscale);
             }
     }
 }
@@ -1519,11 +1528,26 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
 inline int accf_ntc(int cov, int D) { return 4; }
 inline int accf_nqt(int cov, int D) { return nslab_of(cov, D) * 4 <= 96 ? 6 : 9; }
 
+// groups of a mixture set padded to a power of two (>= 4: a lane's 4 components then
+// share their state)
+inline int group_pad(int G) {
+    int p = 1;
+    while (p < G) p <<= 1;
+    return p;
+}
+// the fused accumulation needs a multiple of 4 only (no group reductions)
+inline int accf_group_pad(int S, int G) { return (G + 3) / 4 * 4; }
+inline bool supported_llh_padded(int D, int S, int G) {
+    return supported_llh(D, S, S > 1 ? group_pad(G) : G);
+}
+
 inline int nt16_for(int S, int K) { return S > 1 ? 16 : (K <= 64 ? 4 : (K <= 128 ? 8 : 16)); }
 inline int nchunks16_for(int S, int K) { return S > 1 ? (K + 255) / 256 : 1; }
 size_t up256(size_t n) { return (n + 255) / 256 * 256; }
 
 }  // namespace
+
+bool supported_llh_split(int D, int S, int G) { return supported_llh_padded(D, S, G); }
 
 int f16_range_hazard(int64_t nframes, int D, const float* X, void* scratch, int* hazard,
                      hipStream_t s) {
@@ -1590,7 +1614,8 @@ int unpack_resps(int64_t nframes, int K, const void* packed, float* resps, hipSt
 }
 
 size_t estep16_workspace_bytes(int cov, int D, int S, int G) {
-    if (!supported_llh(D, S, G)) return 0;
+    if (!supported_llh_padded(D, S, G)) return 0;
+    if (S > 1) G = group_pad(G);
     const int K = S * G, NT = nt16_for(S, K), nchunks = nchunks16_for(S, K);
     const size_t kpad = (size_t)nchunks * NT * 16;
     return up256(((size_t)nchunks * nk16_of(cov, D) * NT + kPadBlocks) * 2048) +
@@ -1601,10 +1626,16 @@ size_t estep16_workspace_bytes(int cov, int D, int S, int G) {
 int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, const float* expT,
                 const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
                 size_t ws_bytes, hipStream_t s, bool packed) {
-    const int K = S * G;
     if (packed && S != 1) return BEER_EINVAL;
-    if (!supported_llh(D, S, G) || ws_bytes < estep16_workspace_bytes(cov, D, S, G))
+    if (!supported_llh_padded(D, S, G) || ws_bytes < estep16_workspace_bytes(cov, D, S, G))
         return BEER_EINVAL;
+    // mixture sets whose G is not a power of two: groups padded to Gp slots (logit
+    // -1e30), log-normalisers only (the responsibilities would come out in the padded
+    // layout)
+    const int Greal = G, Kreal = S * G;
+    if (S > 1) G = group_pad(G);
+    if (G != Greal && resps) return BEER_EINVAL;
+    const int K = S * G;
     const int NT = nt16_for(S, K), nchunks = nchunks16_for(S, K), nk = nk16_of(cov, D);
     const int kpad = nchunks * NT * 16;
     char* w = reinterpret_cast<char*>(ws);
@@ -1618,8 +1649,8 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
     float* sc = reinterpret_cast<float*>(w + 256);
     const int rc = launch_scales(X, nframes, D, absmax, sc, s);
     if (rc != BEER_OK) return rc;
-    hipLaunchKernelGGL(pack16_kernel, dim3(kpad), dim3(256), 0, s, cov, D, K, NT, expT, logw, sc, P,
-                       inv_scale, tab);
+    hipLaunchKernelGGL(pack16_kernel, dim3(kpad), dim3(256), 0, s, cov, D, Kreal, NT, expT, logw, sc,
+                       P, inv_scale, tab, Greal, G);
     BEER_LAUNCH_CHECK();
 #define BEER_LLH16(NT_, MT_, GQ_)                                                                \
     return launch_llh16<NT_, MT_, GQ_>(nframes, D, K, S, G, gl, jw, nchunks, nk, X, P, inv_scale, \
@@ -1780,18 +1811,20 @@ int acc_f16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, con
 // statistics per Gaussian small enough for a wave's register tile: diagonal and
 // isotropic covariances up to D = 64 (nq <= 144)
 bool supported_accf(int cov, int D, int S, int G) {
-    return cov != BEER_FULL && D >= 1 && D <= 64 && S >= 1 && G >= 1 &&
+    return cov != BEER_FULL && D >= 1 && D <= 64 && S >= 1 && G >= 1 && G <= 256 &&
            nslab_of(cov, D) * 4 <= 144;
 }
 
 size_t accf_workspace_bytes(int cov, int D, int S, int G) {
     if (!supported_accf(cov, D, S, G)) return 0;
+    const int Kreal = S * G;
+    G = accf_group_pad(S, G);
     const int K = S * G, NTC = accf_ntc(cov, D), nk = nk16_of(cov, D);
     const int nchunks = (K + 16 * NTC - 1) / (16 * NTC), nq = nslab_of(cov, D) * 4;
     return up256(((size_t)nchunks * nk * NTC + kPadBlocks) * 2048) +
            up256((size_t)nchunks * NTC * 16 * sizeof(float)) +
            up256((size_t)(nk + 1) * 8 * sizeof(int)) + 1024 +
-           up256((size_t)K * nq * sizeof(double));
+           up256((size_t)Kreal * nq * sizeof(double));
 }
 
 int acc_fused_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X,
@@ -1799,6 +1832,10 @@ int acc_fused_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* 
                     const float* sr, double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!supported_accf(cov, D, S, G) || ws_bytes < accf_workspace_bytes(cov, D, S, G))
         return BEER_EINVAL;
+    // component slots: groups padded to a multiple of 4 (one state per lane's 4
+    // components); the statistics image Sp stays in the components' own order
+    const int Greal = G, Kreal = S * G;
+    G = accf_group_pad(S, G);
     const int K = S * G, NTC = accf_ntc(cov, D), NQT = accf_nqt(cov, D), nk = nk16_of(cov, D);
     const int nchunks = (K + 16 * NTC - 1) / (16 * NTC), kpad = nchunks * NTC * 16;
     const int nslab = nslab_of(cov, D), nq = nslab * 4;
@@ -1813,12 +1850,12 @@ int acc_fused_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* 
     float* sc = reinterpret_cast<float*>(w + 256);
     w += 1024;
     double* Sp = reinterpret_cast<double*>(w);
-    hipError_t e = hipMemsetAsync(Sp, 0, (size_t)K * nq * sizeof(double), s);
+    hipError_t e = hipMemsetAsync(Sp, 0, (size_t)Kreal * nq * sizeof(double), s);
     if (e != hipSuccess) return -(int)e;
     const int rc = launch_scales(X, nframes, D, absmax, sc, s);
     if (rc != BEER_OK) return rc;
-    hipLaunchKernelGGL(pack16_kernel, dim3(kpad), dim3(256), 0, s, cov, D, K, NTC, expT, logw, sc, P,
-                       inv_scale, tab);
+    hipLaunchKernelGGL(pack16_kernel, dim3(kpad), dim3(256), 0, s, cov, D, Kreal, NTC, expT, logw,
+                       sc, P, inv_scale, tab, Greal, G);
     BEER_LAUNCH_CHECK();
     // waves per workgroup: 8 (two per SIMD) with 64-component chunks, 4 with 128
     const int waves = (NTC == 4 && NQT == 6) ? 8 : 4;
@@ -1846,16 +1883,16 @@ int acc_fused_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* 
             reinterpret_cast<const void*>(accf_kernel<NTC_, NQT_, G4_, W_, XP_>),                \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
         hipLaunchKernelGGL((accf_kernel<NTC_, NQT_, G4_, W_, XP_>), grid, dim3(64 * W_), lds, s, \
-                           nframes, D, K, S, G, nk, nslab, X, P, inv_scale, sc, tab, log_norm,   \
-                           sr, fpb, Sp, dbg);                                                    \
+                           nframes, D, K, S, G, Greal, nk, nslab, X, P, inv_scale, sc, tab,      \
+                           log_norm, sr, fpb, Sp, dbg);                                          \
     } while (0)
     if (NQT == 6) { if (g4) BEER_ACCF(4, 6, true, 8); else BEER_ACCF(4, 6, false, 8); }
     else { if (g4) BEER_ACCF(4, 9, true, 4); else BEER_ACCF(4, 9, false, 4); }
 #undef BEER_ACCF
     BEER_LAUNCH_CHECK();
-    const int64_t total = (int64_t)K * stats_dim(cov, D);
+    const int64_t total = (int64_t)Kreal * stats_dim(cov, D);
     hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cov,
-                       D, K, Sp, acc);
+                       D, Kreal, Sp, acc);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }

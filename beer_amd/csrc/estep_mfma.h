@@ -17,6 +17,9 @@ size_t acc_workspace_bytes(int cov, int D, int K);
 // fp32 models on the fp16 matrix pipes (estep_f16.hip): every fp32 operand is
 // split into two fp16 halves, three fp16 MFMAs per product, fp32 accumulation.
 size_t estep16_workspace_bytes(int cov, int D, int S, int G);
+// shapes the split path takes when NO responsibilities are wanted: mixture sets with
+// any number of components per state (groups padded to a power of two)
+bool supported_llh_split(int D, int S, int G);
 // `packed`: S = 1 only; `resps` (packed_resps_bytes) then receives the fp16 hi / lo
 // image the accumulation kernel consumes (estep_tiles.h: softmax_epilogue<PACKED>).
 int estep_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,

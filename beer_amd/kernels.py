@@ -64,13 +64,19 @@ def mixtureset_estep(stats, exp_stats, log_weights, S, G, cov_type, labels=None,
     ws, ws_bytes = _hip.workspace('beer_estep_workspace_bytes', X.dtype,
                                   _hip.COV_CODE[cov_type], D, S, G, X.device)
     # the generic kernels normalise in place in the responsibilities buffer; the
-    # matrix-core kernels (workspace given) keep them in registers
-    need_resps = want_resps or (G > 1 and (ws is None or labels is not None or st.scale != 1.0))
+    # matrix-core kernels keep them in registers.  Those take group-aligned shapes
+    # (one mixture, or G a power of two) in every arithmetic, and any G on the
+    # float32 split path when no responsibilities are wanted (padded groups).
+    exact = _exact(X)
+    aligned = S == 1 or (G & (G - 1)) == 0
+    on_matrix_cores = ws is not None and labels is None and st.scale == 1.0 and \
+        (aligned or (X.dtype == torch.float32 and not exact and not want_resps))
+    need_resps = want_resps or (G > 1 and not on_matrix_cores)
     resps = torch.empty(T, K, dtype=X.dtype, device=X.device) if need_resps else None
     lab = None
     if labels is not None:
         lab = _hip.on_device(torch.as_tensor(labels)).to(torch.int64).contiguous()
-    _hip.call('beer_mixtureset_estep', _hip.dtype_code(X.dtype, _exact(X)),
+    _hip.call('beer_mixtureset_estep', _hip.dtype_code(X.dtype, exact),
               _hip.COV_CODE[cov_type], T, D, S, G, _hip.ptr(X), _hip.ptr(E), _hip.ptr(lw),
               _hip.ptr(lab), st.scale, None, _hip.ptr(log_norm), _hip.ptr(resps),
               _hip.ptr(llh_sum), _hip.ptr(ws), ws_bytes)

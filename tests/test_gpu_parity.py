@@ -113,7 +113,8 @@ def test_gmm_fp32_one_step_vs_fp64_truth(name):
     optim.init_step()
     elbo = beer.evidence_lower_bound(model, X)
     assert_close(float(elbo), truth['value'], T32_ELBO, 'elbo vs fp64 truth')
-    assert_close(float(elbo), g['elbos'][0], 1e-4, 'elbo vs reference fp32')
+    # (the reference's own float32 run, for the record: how far IT is from the truth)
+    assert_within_f32_band(float(elbo), truth['value'], g['elbos'][0], 'elbo band')
     p0, p1 = params_of(model)
     assert_close(npy(elbo._acc_stats[p0]), truth['acc_normal'], 1e-5, 'acc normal')
     elbo.backward()
@@ -175,8 +176,10 @@ def test_g4_hmm_fp32(cov):
     # same fp32 inputs (up to the cast of the fp64 golden's data) -> compare
     # with the reference's fp32 run at its own rounding band, and with the
     # fp64 run at the north-star band.
-    assert_close(float(elbo), g['elbos'][0], 1e-4)
-    assert_close(float(elbo), g64['elbos'][0], 1e-4)
+    # fp64 truth: the reference's float64 run of the same data (the float32 golden's
+    # data are its cast: 1e-7); the HIP result within 1e-5 of it, or within the error
+    # of the reference's own float32 run
+    assert_within_f32_band(float(elbo), g64['elbos'][0], g['elbos'][0], 'elbo')
     # Viterbi on the reference's own fp32 per-state llhs: bit-exact path.
     path = hmm.graph.best_path(tt(g['pc_llhs']))
     ref = orc.best_path(g['pc_llhs'], g['graph.init'], g['graph.final'], g['graph.trans'])
@@ -1119,7 +1122,11 @@ def test_packed_hand_over_random_shapes():
 @pytest.mark.parametrize('cov,S,G,D,T', [('diagonal', 120, 16, 40, 20011), ('diagonal', 7, 4, 13, 17000),
                                            ('isotropic', 30, 8, 40, 16500), ('diagonal', 3, 32, 64, 16385),
                                            ('diagonal', 1, 200, 24, 18000), ('diagonal', 50, 2, 7, 16400),
-                                           ('diagonal', 9, 128, 39, 16511)])
+                                           ('diagonal', 9, 128, 39, 16511),
+                                           # groups that are not a power of two (recipes/aud
+                                           # uses G = 10 and 4): padded slots on both sides
+                                           ('diagonal', 40, 10, 40, 17003), ('diagonal', 7, 12, 13, 17000),
+                                           ('isotropic', 3, 6, 64, 16385), ('diagonal', 21, 3, 20, 16390)])
 def test_fused_accumulation_recomputes_the_responsibilities(cov, S, G, D, T):
     '''beer_mixtureset_accumulate_fused (no [T, K] matrix: the logits are recomputed
     from the frames and normalised with the E-step's log-normalisers) against the
