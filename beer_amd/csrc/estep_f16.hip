@@ -1069,6 +1069,203 @@ __global__ __launch_bounds__(64 * WAVES, 1) void acc16p_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// K2 for packed responsibilities, second form: LDS-DMA staging, 4 statistic tiles
+// per wave.  acc16p_kernel above is bound by the CU's load path: every 64-frame
+// tile (44 KB at D = 40) is fetched by the 4 workgroups that own the 4 blocks of
+// statistic columns, through registers -- 5.7 GB per launch at config 2, ~10 B/clk
+// per CU, which is what a CU streams when every CU does (MI355X_MICROARCH.md).
+// Here
+//  * a wave owns 4 statistic tiles (a workgroup 512 columns: 2 blocks instead of
+//    4 cover the 928 columns of D = 40, so the R tiles cross L2 -> CU twice, not
+//    four times), with the A fragments of the 8 component tiles loaded in two
+//    halves so that 128 accumulators + 4 B fragments + 4 A fragments fit 256
+//    registers at two waves per SIMD;
+//  * the tiles are copied global -> LDS by the DMA path (global_load_lds_dwordx4:
+//    the images are lane-linear by construction), no staging registers, no
+//    ds_write; tile t + 1 is in flight while tile t is multiplied, one barrier per
+//    tile.
+// ---------------------------------------------------------------------------
+template <int NX>
+__global__ __launch_bounds__(512, 2) void acc16d_kernel(
+    int64_t nframes, int D, int K, int nslab, const float* __restrict__ Xt,
+    const unsigned* __restrict__ Rimg, const int* __restrict__ tab,
+    const float* __restrict__ sc, int64_t frames_per_block, double* __restrict__ Sp, int gx,
+    int gy, int gz) {
+    constexpr int MC = kA16MC, NQ = 4, WAVES = 8;
+    constexpr int NR = 16 * MC * kA16RS * 2 * 2 / kPiece;        // R pieces (hi + lo images)
+    constexpr int NI = NX + NR, NKB = NI * (kPiece / 1024);       // 1 KiB DMA blocks per tile
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int D4 = d4_of(D), Dp = 4 * D4, nq = nslab * 4;
+    const int id = blockIdx.x, xcd = id & 7, slot0 = id >> 3;
+    const int bx = slot0 % gx;
+    const int yz = (slot0 / gx) * 8 + xcd;
+    if (yz >= gy * gz) return;
+    const int by = yz % gy, bz = yz / gy;
+    const int tile0 = (bx * WAVES + wave) * NQ;
+    const int kc0 = by * (16 * MC);
+    const int64_t tb = (int64_t)bz * frames_per_block;
+    const int64_t te = tb + frames_per_block < nframes ? tb + frames_per_block : nframes;
+    const int ntiles = (int)((te - tb + kA16FT - 1) / kA16FT);
+    const int64_t tau0 = tb / kA16FT;
+    constexpr int buf_bytes = NI * kPiece;
+    constexpr int r_off = NX * kPiece, lo_off = 16 * MC * kA16RS * 2;
+    const int nblk = (K + 16 * MC - 1) / (16 * MC);
+
+    auto factors = [&](int uu, int& a, int& b) {
+        const int col = 16 * (tile0 + uu) + i, slab = col >> 2;
+        a = b = Dp + 1;
+        if (slab < nslab) {
+            const int t = tab[slab];
+            b = ((t >> 8) & 0xff) + (col & 3);
+            a = (t >> 16) ? b : (t & 0xff);
+        }
+    };
+    int xa_off[NQ], xb_off[NQ];
+#pragma unroll
+    for (int uu = 0; uu < NQ; ++uu) {
+        int a, b;
+        factors(uu, a, b);
+        xa_off[uu] = ((a < D ? a : (a == Dp ? D : D + 1)) * kA16XS + 8 * g) * 4;
+        xb_off[uu] = ((b < D ? b : (b == Dp ? D : D + 1)) * kA16XS + 8 * g) * 4;
+    }
+    int a_off[kA16FT / 32];
+#pragma unroll
+    for (int ks = 0; ks < kA16FT / 32; ++ks)
+        a_off[ks] = r_off + (i * kA16RS + (((4 * ks + g) ^ (i & 7)) << 3)) * 2;
+
+    f32x4 acc[MC][NQ];
+#pragma unroll
+    for (int c = 0; c < MC; ++c)
+#pragma unroll
+        for (int uu = 0; uu < NQ; ++uu) acc[c][uu] = f32x4{0, 0, 0, 0};
+
+    // DMA of tile `tile` into buffer `buf`: 1 KiB blocks kb = wave, wave + 8, ...;
+    // blocks < 4 NX from the X image, the others from the R image of block `by`
+    const char* xsrc = reinterpret_cast<const char*>(Xt);
+    const char* rsrc = reinterpret_cast<const char*>(Rimg);
+    auto stage = [&](int tile, int buf) {
+        const int64_t tau = tau0 + tile;
+#pragma unroll
+        for (int n = 0; n < (NKB + WAVES - 1) / WAVES; ++n) {
+            const int kb = wave + WAVES * n;
+            if (kb < NKB) {
+                const char* src = kb < 4 * NX
+                    ? xsrc + (tau * NX) * (size_t)kPiece + (size_t)kb * 1024
+                    : rsrc + ((tau * nblk + by) * NR) * (size_t)kPiece + (size_t)(kb - 4 * NX) * 1024;
+                __builtin_amdgcn_global_load_lds(
+                    reinterpret_cast<const u32x4*>(src) + lane,
+                    (__attribute__((address_space(3))) void*)(smem + buf * buf_bytes + kb * 1024),
+                    16, 0, 0);
+            }
+        }
+    };
+    if (ntiles > 0) stage(0, 0);
+    __syncthreads();
+    const bool active = tile0 * 16 < nq;
+    // Operand fragments are loaded IN PLACE one step ahead of the MFMAs that use them:
+    // the A fragments of the next half of the component tiles during the last
+    // statistic tile of the current half (each register right after its last use),
+    // the B fragment of statistic tile uu for the next k-step as soon as the second
+    // half is done with it.  No second register set, no exposed LDS latency.
+    h8 ah[MC / 2], al[MC / 2], bh[NQ], bl[NQ];
+    auto a_ptr = [&](int b, int ks, int c) {
+        return smem + a_off[ks] + (b * buf_bytes + c * 16 * kA16RS * 2);
+    };
+    auto gen_b = [&](int b, int ks, int uu, h8& h, h8& l) {
+        const char* pa = smem + xa_off[uu] + (b * buf_bytes + 128 * ks);
+        const char* pb = smem + xb_off[uu] + (b * buf_bytes + 128 * ks);
+        const f32x4 xa0 = *reinterpret_cast<const f32x4*>(pa);
+        const f32x4 xa1 = *reinterpret_cast<const f32x4*>(pa + 16);
+        const f32x4 xb0 = *reinterpret_cast<const f32x4*>(pb);
+        const f32x4 xb1 = *reinterpret_cast<const f32x4*>(pb + 16);
+        split8(xa0 * xb0, xa1 * xb1, h, l);
+    };
+    if (active && ntiles > 0) {
+#pragma unroll
+        for (int c = 0; c < MC / 2; ++c) {
+            ah[c] = *reinterpret_cast<const h8*>(a_ptr(0, 0, c));
+            al[c] = *reinterpret_cast<const h8*>(a_ptr(0, 0, c) + lo_off);
+        }
+#pragma unroll
+        for (int uu = 0; uu < NQ; ++uu) gen_b(0, 0, uu, bh[uu], bl[uu]);
+    }
+    // One tile out of buffer `buf` (a constant once inlined): 16 steps of 12 MFMAs.
+    // ONE barrier per tile, in front of step 12: by then this wave has read
+    // everything it needs from `buf` (the operands of steps 12..15 were loaded
+    // before), so the steps behind it may load the first operands of tile + 1 from
+    // the other buffer -- whose DMA, issued at the start of this tile, the barrier's
+    // vmcnt(0) has seen land -- and the next tile may overwrite `buf`.
+    auto iteration = [&](int tile, int buf) __attribute__((always_inline)) {
+        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
+        if (active) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int uu = 0; uu < NQ; ++uu) {
+                        const int st = (ks * 2 + half) * NQ + uu;
+                        if (st == 3 * NQ) __syncthreads();
+                        const bool last_uu = uu == NQ - 1;
+                        // where the next A half / the next B fragment come from
+                        const int nks = half ? (ks + 1) & 1 : ks, nhalf = half ^ 1;
+                        const int nbuf = (half && ks == 1) ? buf ^ 1 : buf;
+#pragma unroll
+                        for (int c = 0; c < MC / 2; ++c) {
+                            f32x4& d = acc[half * (MC / 2) + c][uu];
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], bh[uu], d, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int c = 0; c < MC / 2; ++c) {
+                            f32x4& d = acc[half * (MC / 2) + c][uu];
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c], bl[uu], d, 0, 0, 0);
+                            if (last_uu)
+                                ah[c] = *reinterpret_cast<const h8*>(
+                                    a_ptr(nbuf, nks, nhalf * (MC / 2) + c));
+                        }
+#pragma unroll
+                        for (int c = 0; c < MC / 2; ++c) {
+                            f32x4& d = acc[half * (MC / 2) + c][uu];
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c], bh[uu], d, 0, 0, 0);
+                            if (last_uu)
+                                al[c] = *reinterpret_cast<const h8*>(
+                                    a_ptr(nbuf, nks, nhalf * (MC / 2) + c) + lo_off);
+                        }
+                        if (half) gen_b(nbuf, nks, uu, bh[uu], bl[uu]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+        } else {
+            __syncthreads();
+        }
+    };
+    for (int tile = 0; tile < ntiles; tile += 2) {
+        iteration(tile, 0);
+        if (tile + 1 < ntiles) iteration(tile + 1, 1);
+    }
+    const float* isx = sc + 64;
+#pragma unroll
+    for (int uu = 0; uu < NQ; ++uu) {
+        const int q = (tile0 + uu) * 16 + i;
+        if (q >= nq) continue;
+        int a, b;
+        factors(uu, a, b);
+        const double unscale = (a < D ? (double)isx[a] : 1.0) * (b < D ? (double)isx[b] : 1.0) /
+                               (double)(1 << kRespBits);
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = kc0 + 16 * c + 4 * g + r;
+                if (k < K) atomicAdd(Sp + (size_t)k * nq + q, (double)acc[c][uu][r] * unscale);
+            }
+    }
+}
+
 // packed responsibilities -> float32 (tests, callers that want to look at them)
 __global__ void unpack_resps_kernel(int64_t nframes, int K, const unsigned* __restrict__ Rimg,
                                     float* __restrict__ R) {
@@ -1761,6 +1958,44 @@ int acc_f16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, con
         BEER_LAUNCH_CHECK();
     }
     const int ntiles = (nq + 15) / 16;
+    static const int form = [] { const char* e = getenv("BEER_ACC16P"); return e ? atoi(e) : 2; }();
+    if (form == 2 && ntiles > 16) {
+        // second form: 4 statistic tiles per wave, LDS-DMA staging (see acc16d_kernel)
+        const int gx = (ntiles + 31) / 32;
+        const int gy = (K + 16 * kA16MC - 1) / (16 * kA16MC);
+        int64_t gz = (256 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy);
+        const int64_t max_z = (nframes + 1023) / 1024,
+                      min_z = (nframes + kA16MaxFrames - 1) / kA16MaxFrames;
+        if (gz > max_z) gz = max_z;
+        if (gz < min_z) gz = min_z;
+        if (gz < 1) gz = 1;
+        int64_t fpb = (nframes + gz - 1) / gz;
+        fpb = (fpb + kA16FT - 1) / kA16FT * kA16FT;
+        gz = (nframes + fpb - 1) / fpb;
+        const size_t lds = 2 * (size_t)(NX + 8) * kPiece;
+        const int64_t nyz = ((int64_t)gy * gz + 7) / 8 * 8;
+        const dim3 grid((unsigned)(nyz * gx));
+#define BEER_ACC16D(NX_)                                                                         \
+    do {                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc16d_kernel<NX_>),             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        hipLaunchKernelGGL((acc16d_kernel<NX_>), grid, dim3(512), lds, s, nframes, D, K, nslab,  \
+                           Xt, reinterpret_cast<const unsigned*>(Rimg), tab, sc, fpb, Sp, gx,    \
+                           gy, (int)gz);                                                         \
+    } while (0)
+        if (NX == 1) BEER_ACC16D(1);
+        else if (NX == 2) BEER_ACC16D(2);
+        else if (NX == 3) BEER_ACC16D(3);
+        else if (NX == 4) BEER_ACC16D(4);
+        else BEER_ACC16D(5);
+#undef BEER_ACC16D
+        BEER_LAUNCH_CHECK();
+        const int64_t total2 = (int64_t)K * stats_dim(cov, D);
+        hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, s,
+                           cov, D, K, Sp, acc);
+        BEER_LAUNCH_CHECK();
+        return BEER_OK;
+    }
     // 8 waves, two per SIMD (256 registers each): measured faster than 4 waves with
     // twice the statistic tiles each (1.26 against 1.31 ms at K = 256, D = 40, full)
     const int waves = 8;
