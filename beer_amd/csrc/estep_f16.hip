@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     const float* __restrict__ X, const _Float16* __restrict__ Pall,
     const float* __restrict__ inv_scale, const float* __restrict__ sc,
     const int* __restrict__ tab, float* __restrict__ resps, float* __restrict__ log_norm,
-    double* __restrict__ llh_sum, float* __restrict__ xt_out, int xt_floats) {
+    double* __restrict__ llh_sum, float* __restrict__ xt_out, int xt_floats, int nku) {
     using acc_t = f32x4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D4 = d4_of(D), Dp = 4 * D4, LD = ld16_of(D);    // 16-byte aligned rows
@@ -450,9 +450,10 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
 #pragma unroll
     for (int hh = 0; hh < MT * 2; ++hh) make_half(0, hh % MT, hh / MT, f0);
     load_b(0, b0);
-    for (int s = 0; s < nk; s += 2) {                // nk is padded to an even count
+    // (the image is padded to an even number of k-steps; only those that hold slabs run)
+    for (int s = 0; s < nku; s += 2) {
         kstep(s, f0, f1, b0, b1);
-        kstep(s + 1, f1, f0, b0, b1);
+        if (s + 1 < nku) kstep(s + 1, f1, f0, b0, b1);
     }
 
     // undo the column scaling: column (tile c, lane-column i) is component
@@ -475,19 +476,25 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     }
 }
 
+// covariance type of the E-step being launched (the launch helpers below take the
+// shape, not the type; SQ = false kernels are full covariance by construction)
+thread_local int g_cov_of_launch = BEER_FULL;
+
 template <int NT, int MT, int GQ, bool PACKED = false, int KS = 1, bool SQ = true, bool LNO = false>
 int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nchunks, int nk,
                  const float* X, const _Float16* P, const float* inv_scale, const float* sc,
                  const int* tab, float* resps, float* log_norm, double* llh_sum, hipStream_t s,
                  float* xt_out = nullptr, int xt_floats = 0) {
     const int LD = ld16_of(D);
+    // k-steps that hold slabs: the slab count is the table's (full: SQ = false)
+    const int nku = (nslab_of(SQ ? g_cov_of_launch : BEER_FULL, D) + 7) / 8;
     constexpr int FB = 16 * MT * (kThreads / 64) / KS;
     const size_t lds = (size_t)FB * LD * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int) +
                        (KS == 2 ? 8 * 16 * MT * sizeof(float) : 0);
     const int64_t blocks = (nframes + FB - 1) / FB;
     hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ, PACKED, KS, SQ, LNO>), dim3((unsigned)blocks, (unsigned)nchunks),
                        dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nk, X, P, inv_scale,
-                       sc, tab, resps, log_norm, llh_sum, xt_out, xt_floats);
+                       sc, tab, resps, log_norm, llh_sum, xt_out, xt_floats, nku);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }
@@ -1835,6 +1842,7 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
     const int K = S * G;
     const int NT = nt16_for(S, K), nchunks = nchunks16_for(S, K), nk = nk16_of(cov, D);
     const int kpad = nchunks * NT * 16;
+    g_cov_of_launch = cov;
     char* w = reinterpret_cast<char*>(ws);
     _Float16* P = reinterpret_cast<_Float16*>(w);
     w += up256(((size_t)nchunks * nk * NT + kPadBlocks) * 2048);

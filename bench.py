@@ -116,6 +116,8 @@ def pmc_traffic(kernel_key):
             # (MI355X_MICROARCH.md): kernels that stream with 16-byte loads are corrected
             read = k['hbm_read_bytes_raw'] * (2. if k.get('wide_loads', kernel_key.startswith('acc'))
                                               else 1.)
+            if not read:
+                continue
             return read + k['hbm_write_bytes']
         except Exception:
             continue
@@ -355,7 +357,7 @@ def run_gmm(args, rank, world, device, backend):
         note = ('achieved = algorithmic flops (2*K*Q per frame, no symmetry discount) / '
                 'HIP-event time of the C-ABI call; the kernels contract only the D(D+1)/2 '
                 'symmetric products (0.56x the multiply-adds), so frac can exceed 1')
-    pmc_key = (('acc16p_kernel' if 'packed' in dom else 'acc16_kernel') if split else 'acc_kernel') \
+    pmc_key = (('acc16d_kernel' if 'packed' in dom else 'acc16_kernel') if split else 'acc_kernel') \
         if 'accumulate' in dom else ('llh16_kernel' if split else 'llh_kernel')
     out = {
         'metric': 'frames/sec per VB iteration (E+M)', 'value': datasize * args.steps / elapsed,
@@ -545,9 +547,9 @@ def run_hmm(args, rank, world, device, backend):
     # 4 D bytes each (B(D) = 160 B / frame), once
     alg_bytes = 4. * D * kern[dom]['frames_per_launch']
     achieved = alg_bytes / (kern[dom]['ms'] * 1e-3) / 1e9
-    pmc_key = {'beer_mixtureset_accumulate_fused': 'accf_kernel',
-               'beer_mixtureset_estep': 'llh16_kernel',
-               'beer_hmm_posteriors_fused': 'fb_wave_kernel'}.get(dom, dom)
+    pmc_key = 'c3_' + {'beer_mixtureset_accumulate_fused': 'accf_kernel',
+                       'beer_mixtureset_estep': 'llh16_kernel',
+                       'beer_hmm_posteriors_fused': 'fb_wave_kernel'}.get(dom, dom)
     Qd = {'diagonal': 2 * D + 2, 'full': D * D + D + 2, 'isotropic': D + 3}[args.cov]
     out = {
         'metric': 'frames/sec per VB iteration (E+M)', 'value': datasize * args.steps / elapsed,

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 PMC passes of `bench.py` into profiles/<round>_pmc.json.
 
-    python tools/pmc_summary.py r01 gpurun_out/pmc_a gpurun_out/pmc_b gpurun_out/pmc_c
+    python tools/pmc_summary.py r02 [--command='python bench.py ...'] [--tag=c3] \
+        gpurun_out/pmc_a gpurun_out/pmc_b gpurun_out/pmc_c
 
 Each directory holds one `rocprofv3 --kernel-trace --pmc ...` pass.  Only the
 full-size launches (1 M frames) of the four E-step kernels are kept; the
@@ -19,13 +20,25 @@ import os
 import sys
 
 KERNELS = {'llh16_kernel': 'llh16_kernel', 'acc16p_kernel': 'acc16p_kernel',
-           'acc16_kernel': 'acc16_kernel',
+           'acc16d_kernel': 'acc16d_kernel', 'acc16_kernel': 'acc16_kernel',
+           'accf_kernel': 'accf_kernel', 'fb_wave_kernel': 'fb_wave_kernel',
            'llh_kernel<': 'llh_kernel', 'acc_kernel<': 'acc_kernel'}
+# kernels whose streaming reads are 16 B per lane: FETCH_SIZE counts half their bytes on
+# gfx950 (MI355X_MICROARCH.md, HBM section); bench.py doubles the read figure for these
+WIDE_LOADS = {'llh16_kernel': True, 'acc16p_kernel': True, 'acc16d_kernel': True,
+              'acc16_kernel': True, 'accf_kernel': True, 'fb_wave_kernel': False,
+              'llh_kernel': True, 'acc_kernel': True}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
     rnd, dirs = sys.argv[1], sys.argv[2:]
+    command = 'python bench.py --steps 3 --warmup 1 --no-cpu-baseline'
+    if dirs and dirs[0].startswith('--command='):
+        command, dirs = dirs[0][len('--command='):], dirs[1:]
+    tag = ''
+    if dirs and dirs[0].startswith('--tag='):
+        tag, dirs = dirs[0][len('--tag='):] + '_', dirs[1:]
     out = collections.defaultdict(dict)
     for i, d in enumerate(dirs, start=1):
         f = (glob.glob(os.path.join(d, '*', '*counter_collection.csv')) +
@@ -46,7 +59,7 @@ def main():
                 full = [(v, t) for v, t in vals if v > .5 * big] or vals     # full-size launches
                 out[key][name] = sum(v for v, _ in full) / len(full)
                 out[key][name + '_ms'] = sum(t for _, t in full) / len(full)
-        with open(os.path.join(ROOT, 'profiles', f'{rnd}_pmc_pass{i}.csv'), 'w', newline='') as g:
+        with open(os.path.join(ROOT, 'profiles', f'{rnd}_pmc_{tag}pass{i}.csv'), 'w', newline='') as g:
             w = csv.DictWriter(g, fieldnames=list(rows[0].keys()))
             w.writeheader()
             w.writerows(keep)
@@ -59,12 +72,14 @@ def main():
             k['hbm_read_bytes_raw'] = k['FETCH_SIZE'] * 1024
         if 'WRITE_SIZE' in k:
             k['hbm_write_bytes'] = k['WRITE_SIZE'] * 1024
+        k['wide_loads'] = WIDE_LOADS.get(key, False)
+        k['command'] = command
     path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc.json')
     old = json.load(open(path))['kernels'] if os.path.exists(path) else {}
-    old.update(out)
-    json.dump({'source': 'rocprofv3 --kernel-trace --pmc (separate passes) -- python bench.py '
-                         '--steps 3 --warmup 1 --no-cpu-baseline; full-size (1 M frame) launches '
-                         'only; see tools/pmc_summary.py', 'kernels': old},
+    old.update({tag + key: k for key, k in out.items()})     # 'c3_accf_kernel', ...
+    json.dump({'source': 'rocprofv3 --kernel-trace --pmc (separate passes) -- <command of the entry>; '
+                         'full-size launches only, averaged per launch; see tools/pmc_summary.py',
+               'kernels': old},
               open(path, 'w'), indent=1)
     for key, k in out.items():
         print(key, {n: round(v, 4) for n, v in k.items() if n in ('mfma_util', 'clock_ghz')},
