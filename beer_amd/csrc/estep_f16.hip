@@ -281,6 +281,19 @@ __device__ __forceinline__ void split8(const f32x4& p0, const f32x4& p1, h8& hi,
 // ---------------------------------------------------------------------------
 // SQ = false: no "square" slabs in the table (full covariance), the per-product
 // select between x_j^2 and x_a x_j drops out of the A-fragment arithmetic.
+// Several component chunks over the same frames: a 1-D grid whose blocks are dealt to
+// the 8 XCDs round-robin, laid out so that the `ny` chunk blocks of one frame block
+// are neighbours on ONE XCD (they read the same frames at about the same time: one
+// L2 miss, ny - 1 hits -- with a (frames, chunks) grid every chunk pass streamed the
+// frames from HBM again).  Grid size xcd_grid(nx, ny); false = padding block.
+inline unsigned xcd_grid(int64_t nx, int ny) { return (unsigned)((nx + 7) / 8 * 8 * ny); }
+__device__ inline bool xcd_block(int64_t nx, int ny, int64_t& bx, int& by) {
+    const unsigned id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    by = (int)(slot % (unsigned)ny);
+    bx = (int64_t)(slot / (unsigned)ny) * 8 + xcd;
+    return bx < nx;
+}
+
 template <int NT, int MT, int GQ, bool PACKED, int KS = 1, bool SQ = true, bool LNO = false>
 __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nk,
@@ -300,7 +313,14 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     const int grp = wave / KS, part = wave % KS;
     float* xw = reinterpret_cast<float*>(smem) + grp * (FW * LD);
     int* tabs = reinterpret_cast<int*>(reinterpret_cast<float*>(smem) + NGRP * FW * LD);
-    const int64_t fb = ((int64_t)blockIdx.x * NGRP + grp) * FW;
+    int64_t bx = blockIdx.x;
+    int by = 0;
+    {
+        const int nch = (K + 16 * NT * KS - 1) / (16 * NT * KS);
+        constexpr int FBK = FW * NGRP;
+        if (nch > 1 && !xcd_block((nframes + FBK - 1) / FBK, nch, bx, by)) return;
+    }
+    const int64_t fb = (bx * NGRP + grp) * FW;
     for (int idx = tid; idx < (nk + 1) * 8; idx += kThreads) tabs[idx] = tab[idx];
 
     if ((D & 3) == 0) {
@@ -364,11 +384,11 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
 #pragma unroll
     for (int m = 0; m < MT; ++m) xrow[m] = xw + (m * 16 + i) * LD;
 
-    const int kbase = blockIdx.y * (16 * NT * KS) + part * (16 * NT);
+    const int kbase = by * (16 * NT * KS) + part * (16 * NT);
     // the B stream of this chunk is one linear sequence of (k-step, tile) blocks
     // of 2 KiB = 128 u4 (hi 64 lanes x 16 B, lo 64 lanes x 16 B); with KS = 2 a
     // k-step has 2 NT tiles and this wave reads tiles part * NT ..
-    const u4* Pl = reinterpret_cast<const u4*>(Pall + (size_t)blockIdx.y * nk * (NT * KS) * 1024) +
+    const u4* Pl = reinterpret_cast<const u4*>(Pall + (size_t)by * nk * (NT * KS) * 1024) +
                    lane + (size_t)part * NT * 128;
     const int* tl = tabs + 2 * g;
 
@@ -492,7 +512,9 @@ int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, in
     const size_t lds = (size_t)FB * LD * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int) +
                        (KS == 2 ? 8 * 16 * MT * sizeof(float) : 0);
     const int64_t blocks = (nframes + FB - 1) / FB;
-    hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ, PACKED, KS, SQ, LNO>), dim3((unsigned)blocks, (unsigned)nchunks),
+    if (nchunks != (K + 16 * NT * KS - 1) / (16 * NT * KS)) return BEER_EINVAL;
+    hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ, PACKED, KS, SQ, LNO>),
+                       dim3(nchunks > 1 ? xcd_grid(blocks, nchunks) : (unsigned)blocks),
                        dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nk, X, P, inv_scale,
                        sc, tab, resps, log_norm, llh_sum, xt_out, xt_floats, nku);
     BEER_LAUNCH_CHECK();
@@ -1375,6 +1397,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
     const float* __restrict__ sr, int64_t frames_per_block, double* __restrict__ Sp, int dbg) {
     constexpr int MT = 2, FW = 32, QT = NTC / 4, NTHREADS = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    int64_t bx;
+    int by;
+    if (!xcd_block((nframes + frames_per_block - 1) / frames_per_block,
+                   (K + 16 * NTC - 1) / (16 * NTC), bx, by))
+        return;
     const int D4 = d4_of(D), Dp = 4 * D4, LD = ld16_of(D), nq = nslab * 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1392,7 +1419,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
     float* xt = xw + FW * LD;
     if (tid < 64) scales[tid] = sc[tid];
     {
-        const u4* src = reinterpret_cast<const u4*>(Pall + (size_t)blockIdx.y * nk * NTC * 1024);
+        const u4* src = reinterpret_cast<const u4*>(Pall + (size_t)by * nk * NTC * 1024);
         for (int idx = tid; idx < p_u4; idx += NTHREADS) Ps[idx] = src[idx];
     }
     for (int idx = tid; idx < (nk + 1) * 8; idx += NTHREADS) tabs[idx] = tab[idx];
@@ -1407,9 +1434,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
     }
     __syncthreads();
 
-    const int kbase = blockIdx.y * (16 * NTC);
+    const int kbase = by * (16 * NTC);
     const int nk_used = (nslab + 7) / 8;
-    const int64_t tb = (int64_t)blockIdx.x * frames_per_block;
+    const int64_t tb = bx * frames_per_block;
     const int64_t te = tb + frames_per_block < nframes ? tb + frames_per_block : nframes;
     const u4* Pl = Ps + lane;
     const int* tl = tabs + 2 * g;
@@ -2104,7 +2131,9 @@ int acc_fused_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* 
     const int waves = (NTC == 4 && NQT == 6) ? 8 : 4;
     // frames per workgroup: <= kAfMaxFramesPerWave per wave, about one workgroup of
     // 8 waves (two of 4) per CU and round
-    int64_t gz = ((waves == 8 ? 256 : 512) * 3 + nchunks - 1) / nchunks;
+    static const int rounds = [] { const char* e = getenv("BEER_ACCF_ROUNDS"); return e ? atoi(e) : 6; }();
+    int64_t gz = ((waves == 8 ? 256 : 512) * rounds + nchunks - 1) / nchunks;
+    gz = (gz + 7) / 8 * 8;                       // whole rows of the XCD-aware grid
     const int64_t min_z = (nframes + (int64_t)waves * kAfMaxFramesPerWave - 1) /
                           ((int64_t)waves * kAfMaxFramesPerWave);
     const int64_t max_z = (nframes + 32 * waves - 1) / (32 * waves);
@@ -2116,7 +2145,7 @@ int acc_fused_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* 
     gz = (nframes + fpb - 1) / fpb;
     const size_t lds = (size_t)nk * NTC * 2048 + (size_t)(nk + 1) * 8 * sizeof(int) + 256 +
                        (size_t)waves * (32 * ld16_of(D) + (D + 2) * kAfXS) * sizeof(float);
-    const dim3 grid((unsigned)gz, (unsigned)nchunks);
+    const dim3 grid(xcd_grid(gz, nchunks));
     const bool g4 = (G % 4) == 0;
     static const int dbg = [] { const char* e = getenv("BEER_ACCF_DBG"); return e ? atoi(e) : 0; }();
 #define BEER_ACCF(NTC_, NQT_, G4_, W_)                                                           \

@@ -308,7 +308,7 @@ __device__ __forceinline__ void softmax_epilogue(
         // and for m = 1: one v_permlane16_swap per word leaves the even-g lane with
         // the whole chunk of m = 0 and the odd-g lane with that of m = 1, so that
         // every lane stores 16 bytes and 4 lanes fill a 64-byte segment of the row.
-        static_assert(!PACKED || MT == 2, "the lane pairs exchange the two frame tiles");
+        static_assert(!PACKED || MT % 2 == 0, "the lane pairs exchange two frame tiles");
         typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
         typedef float float4_t __attribute__((ext_vector_type(4)));
         typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
@@ -317,44 +317,48 @@ __device__ __forceinline__ void softmax_epilogue(
         const float up = (float)(1 << kPackedRespBits);
         const int nblk = (K + kPackedComps - 1) / kPackedComps;
         const int64_t tiles = (nframes + kPackedFrames - 1) / kPackedFrames;
-        // the chunk this lane stores after the exchange
-        const int64_t fc = fb + 16 * (g & 1) + 8 * (g >> 1);
-        const int64_t tau = fc / kPackedFrames;
-        const int f6 = (int)(fc - tau * kPackedFrames);
-        const bool chunk_ok = out && fc < tiles * kPackedFrames;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            __builtin_amdgcn_sched_barrier(0);
-            const int k = kbase + 64 * (nt >> 2) + 4 * i + (nt & 3);
-            uint2_t hi[2], lo[2];
+        for (int mp = 0; mp < MT / 2; ++mp) {
+            // the chunk this lane stores after the exchange
+            const int64_t fc = fb + 32 * mp + 16 * (g & 1) + 8 * (g >> 1);
+            const int64_t tau = fc / kPackedFrames;
+            const int f6 = (int)(fc - tau * kPackedFrames);
+            const bool chunk_ok = out && fc < tiles * kPackedFrames;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int64_t f0 = fb + m * 16 + M::row(g, 0);
-                float4_t v;
+            for (int nt = 0; nt < NT; ++nt) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int k = kbase + 64 * (nt >> 2) + 4 * i + (nt & 3);
+                uint2_t hi[2], lo[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] = f0 + r < nframes && k < K ? (float)acc[m][nt][r] * up : 0.f;
-                const half4_t h = __builtin_convertvector(v, half4_t);
-                const half4_t l = __builtin_convertvector(
-                    v - __builtin_convertvector(h, float4_t), half4_t);
-                hi[m] = __builtin_bit_cast(uint2_t, h);
-                lo[m] = __builtin_bit_cast(uint2_t, l);
-            }
-            uint4_t ch, cl;
+                for (int mm = 0; mm < 2; ++mm) {
+                    const int m = 2 * mp + mm;
+                    const int64_t f0 = fb + m * 16 + M::row(g, 0);
+                    float4_t v;
 #pragma unroll
-            for (int wd = 0; wd < 2; ++wd) {
-                const auto sh = __builtin_amdgcn_permlane16_swap(hi[0][wd], hi[1][wd], false, false);
-                const auto sl = __builtin_amdgcn_permlane16_swap(lo[0][wd], lo[1][wd], false, false);
-                ch[wd] = sh[0]; ch[2 + wd] = sh[1];
-                cl[wd] = sl[0]; cl[2 + wd] = sl[1];
-            }
-            if (chunk_ok && k < nblk * kPackedComps) {
-                unsigned int* dst = out + packed_word(tau, nblk, k / kPackedComps,
-                                                      k & (kPackedComps - 1), f6);
-                // non-temporal: 1 GB streamed once; keeps the packed parameters in L2
-                __builtin_nontemporal_store(ch, reinterpret_cast<uint4_t*>(dst));
-                __builtin_nontemporal_store(
-                    cl, reinterpret_cast<uint4_t*>(dst + kPackedComps * kPackedFrames / 2));
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = f0 + r < nframes && k < K ? (float)acc[m][nt][r] * up : 0.f;
+                    const half4_t h = __builtin_convertvector(v, half4_t);
+                    const half4_t l = __builtin_convertvector(
+                        v - __builtin_convertvector(h, float4_t), half4_t);
+                    hi[mm] = __builtin_bit_cast(uint2_t, h);
+                    lo[mm] = __builtin_bit_cast(uint2_t, l);
+                }
+                uint4_t ch, cl;
+#pragma unroll
+                for (int wd = 0; wd < 2; ++wd) {
+                    const auto sh = __builtin_amdgcn_permlane16_swap(hi[0][wd], hi[1][wd], false, false);
+                    const auto sl = __builtin_amdgcn_permlane16_swap(lo[0][wd], lo[1][wd], false, false);
+                    ch[wd] = sh[0]; ch[2 + wd] = sh[1];
+                    cl[wd] = sl[0]; cl[2 + wd] = sl[1];
+                }
+                if (chunk_ok && k < nblk * kPackedComps) {
+                    unsigned int* dst = out + packed_word(tau, nblk, k / kPackedComps,
+                                                          k & (kPackedComps - 1), f6);
+                    // non-temporal: streamed once; keeps the packed parameters in L2
+                    __builtin_nontemporal_store(ch, reinterpret_cast<uint4_t*>(dst));
+                    __builtin_nontemporal_store(
+                        cl, reinterpret_cast<uint4_t*>(dst + kPackedComps * kPackedFrames / 2));
+                }
             }
         }
     }
