@@ -104,6 +104,7 @@ SIGNATURES = {
     'beer_hip_version': [],
     'beer_hip_device_count': [],
     'beer_hip_has_rocblas': [],
+    'beer_mixtureset_packed_supported': [c_i, c_i, c_i, c_i],
     'beer_nw_expected_stats': _four, 'beer_nw_log_norm': _four, 'beer_nw_natural': _four,
     'beer_nw_from_natural': _from,
     'beer_nw_expected_stats_log_norm': [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
@@ -129,6 +130,10 @@ SIGNATURES = {
     'beer_mixture_estep_packed': [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_z,
                                   c_p],
     'beer_normal_accumulate_packed': [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_z, c_p],
+    'beer_mixtureset_estep_packed': [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                     c_z, c_p],
+    'beer_mixtureset_accumulate_packed': [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_z,
+                                          c_p],
     'beer_unpack_resps': [c_l, c_i, c_p, c_p, c_p],
     'beer_mixtureset_accumulate_fused': [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p,
                                          c_p, c_z, c_p],
@@ -182,6 +187,7 @@ SIZE_QUERIES = {
     'beer_packed_resps_bytes': [c_l, c_i, c_i],
     'beer_accumulate_fused_workspace_bytes': [c_i, c_i, c_i, c_i],
     'beer_accumulate_packed_workspace_bytes': [c_i, c_l, c_i, c_i],
+    'beer_mixtureset_accumulate_packed_workspace_bytes': [c_i, c_l, c_i, c_i, c_i],
 }
 
 
@@ -344,10 +350,15 @@ def workspace(query, dtype, cov, D, S, G, device):
     return buf, nbytes
 
 
-def packed_workspace(cov, T, D, K, device):
+def packed_workspace(cov, T, D, K, device, sets=None):
     '''(tensor, nbytes) scratch of `beer_normal_accumulate_packed` (grows with T:
-    it holds the transposed frames); one buffer per (shape, stream), grown on demand.'''
-    nbytes = lib().beer_accumulate_packed_workspace_bytes(cov, T, D, K)
+    it holds the transposed frames) or, with `sets = (S, G)`, of
+    `beer_mixtureset_accumulate_packed` (... and state posteriors); one buffer per
+    (shape, stream), grown on demand.'''
+    if sets is None:
+        nbytes = lib().beer_accumulate_packed_workspace_bytes(cov, T, D, K)
+    else:
+        nbytes = lib().beer_mixtureset_accumulate_packed_workspace_bytes(cov, T, D, *sets)
     if nbytes == 0:
         return None, 0
     key = ('packed', cov, D, K, device, torch.cuda.current_stream().cuda_stream)

@@ -541,6 +541,44 @@ int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float*
                                        workspace_bytes, as_stream(stream));
 }
 
+int beer_mixtureset_packed_supported(int cov, int D, int S, int G) {
+    return cov >= 0 && cov <= 2 && D >= 1 && D <= 64 && S >= 1 && G >= 1 &&
+           beer_mfma::supported_llh_packed_sets(cov, D, S, G) &&
+           beer_mfma::supported_acc_sets(cov, D, S, G);
+}
+
+size_t beer_mixtureset_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int S, int G) {
+    if (T < 0 || !beer_mixtureset_packed_supported(cov, D, S, G)) return 0;
+    return beer_mfma::acc16s_workspace_bytes(cov, T, D, S, G);
+}
+
+int beer_mixtureset_estep_packed(int cov, int64_t T, int D, int S, int G, const float* X,
+                                 const float* exp_stats, const float* log_weights,
+                                 float* log_norm, void* packed_resps, double* llh_sum,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    BEER_REQUIRE(T >= 0 && D >= 1 && S >= 1 && G >= 1 && cov >= 0 && cov <= 2);
+    BEER_REQUIRE(X && exp_stats && packed_resps && workspace);
+    BEER_REQUIRE(beer_mixtureset_packed_supported(cov, D, S, G));
+    BEER_REQUIRE(workspace_bytes >= beer_mfma::estep16_workspace_bytes(cov, D, S, G));
+    if (T == 0) return BEER_OK;
+    return beer_mfma::estep_f16x3(cov, T, D, S, G, X, exp_stats, log_weights,
+                                  reinterpret_cast<float*>(packed_resps), log_norm, llh_sum,
+                                  workspace, workspace_bytes, as_stream(stream), true);
+}
+
+int beer_mixtureset_accumulate_packed(int cov, int64_t T, int D, int S, int G, const float* X,
+                                      const void* packed_resps, const float* state_resps,
+                                      double* acc, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    BEER_REQUIRE(T >= 0 && D >= 1 && S >= 1 && G >= 1 && cov >= 0 && cov <= 2);
+    BEER_REQUIRE(X && packed_resps && state_resps && acc && workspace);
+    BEER_REQUIRE(beer_mixtureset_packed_supported(cov, D, S, G));
+    BEER_REQUIRE(workspace_bytes >= beer_mfma::acc16s_workspace_bytes(cov, T, D, S, G));
+    if (T == 0) return BEER_OK;
+    return beer_mfma::acc_f16x3_packed(cov, T, D, S * G, X, packed_resps, acc, workspace,
+                                       workspace_bytes, as_stream(stream), S, G, state_resps);
+}
+
 size_t beer_accumulate_fused_workspace_bytes(int cov, int D, int S, int G) {
     if (cov < 0 || cov > 2 || D < 1 || S < 1 || G < 1) return 0;
     return beer_mfma::accf_workspace_bytes(cov, D, S, G);

@@ -294,7 +294,8 @@ __device__ inline bool xcd_block(int64_t nx, int ny, int64_t& bx, int& by) {
     return bx < nx;
 }
 
-template <int NT, int MT, int GQ, bool PACKED, int KS = 1, bool SQ = true, bool LNO = false>
+template <int NT, int MT, int GQ, bool PACKED, int KS = 1, bool SQ = true, bool LNO = false,
+          bool SETS = false>
 __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nk,
     const float* __restrict__ X, const _Float16* __restrict__ Pall,
@@ -385,6 +386,9 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     for (int m = 0; m < MT; ++m) xrow[m] = xw + (m * 16 + i) * LD;
 
     const int kbase = by * (16 * NT * KS) + part * (16 * NT);
+    // mixture sets: a wave whose half of the last chunk lies behind the last component
+    // has staged its share of the frames and is done (no barrier below for it)
+    if (KS == 2 && (SETS || !PACKED) && kbase >= K) return;
     // the B stream of this chunk is one linear sequence of (k-step, tile) blocks
     // of 2 KiB = 128 u4 (hi 64 lanes x 16 B, lo 64 lanes x 16 B); with KS = 2 a
     // k-step has 2 NT tiles and this wave reads tiles part * NT ..
@@ -486,7 +490,8 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m][4 * q + j] *= inv[j];
     }
-    if constexpr (KS == 2 && PACKED) {
+    // SETS: packed output of a mixture SET (groups inside one wave's components)
+    if constexpr (KS == 2 && PACKED && !SETS) {
         float* xch = reinterpret_cast<float*>(tabs + (nk + 1) * 8);
         softmax_epilogue_pair<NT, MT>(acc, fb, nframes, kbase, K, i, g, lane, wave, xch, resps,
                                       log_norm, llh_sum);
@@ -500,7 +505,8 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
 // shape, not the type; SQ = false kernels are full covariance by construction)
 thread_local int g_cov_of_launch = BEER_FULL;
 
-template <int NT, int MT, int GQ, bool PACKED = false, int KS = 1, bool SQ = true, bool LNO = false>
+template <int NT, int MT, int GQ, bool PACKED = false, int KS = 1, bool SQ = true, bool LNO = false,
+          bool SETS = false>
 int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nchunks, int nk,
                  const float* X, const _Float16* P, const float* inv_scale, const float* sc,
                  const int* tab, float* resps, float* log_norm, double* llh_sum, hipStream_t s,
@@ -513,7 +519,7 @@ int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, in
                        (KS == 2 ? 8 * 16 * MT * sizeof(float) : 0);
     const int64_t blocks = (nframes + FB - 1) / FB;
     if (nchunks != (K + 16 * NT * KS - 1) / (16 * NT * KS)) return BEER_EINVAL;
-    hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ, PACKED, KS, SQ, LNO>),
+    hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ, PACKED, KS, SQ, LNO, SETS>),
                        dim3(nchunks > 1 ? xcd_grid(blocks, nchunks) : (unsigned)blocks),
                        dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nk, X, P, inv_scale,
                        sc, tab, resps, log_norm, llh_sum, xt_out, xt_floats, nku);
@@ -1115,13 +1121,24 @@ __global__ __launch_bounds__(64 * WAVES, 1) void acc16p_kernel(
 //    ds_write; tile t + 1 is in flight while tile t is multiplied, one barrier per
 //    tile.
 // ---------------------------------------------------------------------------
-template <int NX>
+// SR (mixture sets): the tiles hold the responsibilities WITHIN each state's mixture
+// (what the E-step knows); the state posteriors of the forward-backward pass that ran
+// in between arrive as transposed tiles Gt [64-frame tile][state][64 frames] and are
+// multiplied in while the tile sits in LDS, each element once per workgroup:
+// (hi + lo) * gamma in fp32, split again.  Three LDS buffers: tile t + 2 in flight
+// (DMA), tile t + 1 being folded in place -- every thread its own 2 x 8 elements,
+// spread over the steps before the barrier --, tile t multiplied.  lgG = log2 of the
+// components per state (8 .. 128: the states of a 128-component block fit 4 KiB).
+#ifndef BEER_SR_ABL
+#define BEER_SR_ABL 0          // ablation builds only (tools/ab_build.sh)
+#endif
+template <int NX, bool SR>
 __global__ __launch_bounds__(512, 2) void acc16d_kernel(
     int64_t nframes, int D, int K, int nslab, const float* __restrict__ Xt,
     const unsigned* __restrict__ Rimg, const int* __restrict__ tab,
     const float* __restrict__ sc, int64_t frames_per_block, double* __restrict__ Sp, int gx,
-    int gy, int gz) {
-    constexpr int MC = kA16MC, NQ = 4, WAVES = 8;
+    int gy, int gz, const float* __restrict__ Gt, int lgG) {
+    constexpr int MC = kA16MC, NQ = 4, WAVES = 8, NB = SR ? 3 : 2;
     constexpr int NR = 16 * MC * kA16RS * 2 * 2 / kPiece;        // R pieces (hi + lo images)
     constexpr int NI = NX + NR, NKB = NI * (kPiece / 1024);       // 1 KiB DMA blocks per tile
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -1143,7 +1160,10 @@ __global__ __launch_bounds__(512, 2) void acc16d_kernel(
     const int64_t tau0 = tb / kA16FT;
     constexpr int buf_bytes = NI * kPiece;
     constexpr int r_off = NX * kPiece, lo_off = 16 * MC * kA16RS * 2;
+    constexpr int g_base = NB * buf_bytes;                        // SR: NB x 4 KiB of gamma^T
     const int nblk = (K + 16 * MC - 1) / (16 * MC);
+    const int gbytes = SR ? ((16 * MC) >> lgG) * kA16FT * 4 : 0;  // gamma^T of one block-tile
+    const int gkb = (gbytes + 1023) >> 10;
 
     auto factors = [&](int uu, int& a, int& b) {
         const int col = 16 * (tile0 + uu) + i, slab = col >> 2;
@@ -1180,7 +1200,7 @@ __global__ __launch_bounds__(512, 2) void acc16d_kernel(
     auto stage = [&](int tile, int buf) {
         const int64_t tau = tau0 + tile;
 #pragma unroll
-        for (int n = 0; n < (NKB + WAVES - 1) / WAVES; ++n) {
+        for (int n = 0; n < (NKB + (SR ? 4 : 0) + WAVES - 1) / WAVES; ++n) {
             const int kb = wave + WAVES * n;
             if (kb < NKB) {
                 const char* src = kb < 4 * NX
@@ -1190,11 +1210,56 @@ __global__ __launch_bounds__(512, 2) void acc16d_kernel(
                     reinterpret_cast<const u32x4*>(src) + lane,
                     (__attribute__((address_space(3))) void*)(smem + buf * buf_bytes + kb * 1024),
                     16, 0, 0);
+            } else if (SR && kb - NKB < gkb) {
+                const char* src = reinterpret_cast<const char*>(Gt) +
+                                  (tau * nblk + by) * (size_t)gbytes + (size_t)(kb - NKB) * 1024;
+                __builtin_amdgcn_global_load_lds(
+                    reinterpret_cast<const u32x4*>(src) + lane,
+                    (__attribute__((address_space(3))) void*)(smem + g_base + buf * 4096 +
+                                                              (kb - NKB) * 1024),
+                    16, 0, 0);
             }
         }
     };
+    // SR: quarter q (of 4) of this thread's share of the R image in `buf`: 4 frames of
+    // row c (chunk position pos = frames 8 (pos ^ (c & 7)) .., half q & 1 of it), hi and
+    // lo, times the state's gamma.  A quarter at a time: few registers live at once.
+    auto fold = [&](int buf, int q) {
+#if BEER_SR_ABL == 1
+        return;
+#endif
+        int tq = tid;                       // (opaque: the addresses are recomputed per
+        asm volatile("" : "+v"(tq));        //  call, not kept in registers across the tile)
+        const int p = tq + 512 * (q >> 1), c = p >> 3, pos = p & 7, ch = pos ^ (c & 7);
+        char* ph = smem + buf * buf_bytes + r_off + c * (kA16RS * 2) + pos * 16 + 8 * (q & 1);
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 hi = *reinterpret_cast<const h4*>(ph);
+        const h4 lo = *reinterpret_cast<const h4*>(ph + lo_off);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(
+            reinterpret_cast<const float*>(smem + g_base + buf * 4096) +
+            ((c >> lgG) * kA16FT + 8 * ch + 4 * (q & 1)));
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf((float)hi[e], gm[e], (float)lo[e] * gm[e]);
+        hp2 h0, l0, h1, l1;
+        split2(v[0], v[1], h0, l0);
+        split2(v[2], v[3], h1, l1);
+#if BEER_SR_ABL == 2
+        if (gm[0] == 12345.f)
+#endif
+        {
+            *reinterpret_cast<h4*>(ph) = h4{h0[0], h0[1], h1[0], h1[1]};
+            *reinterpret_cast<h4*>(ph + lo_off) = h4{l0[0], l0[1], l1[0], l1[1]};
+        }
+    };
     if (ntiles > 0) stage(0, 0);
+    if (SR && ntiles > 1) stage(1, 1);
     __syncthreads();
+    if (SR && ntiles > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fold(0, q);
+        __syncthreads();
+    }
     const bool active = tile0 * 16 < nq;
     // Operand fragments are loaded IN PLACE one step ahead of the MFMAs that use them:
     // the A fragments of the next half of the component tiles during the last
@@ -1230,7 +1295,10 @@ __global__ __launch_bounds__(512, 2) void acc16d_kernel(
     // the other buffer -- whose DMA, issued at the start of this tile, the barrier's
     // vmcnt(0) has seen land -- and the next tile may overwrite `buf`.
     auto iteration = [&](int tile, int buf) __attribute__((always_inline)) {
-        if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
+        const int next = (buf + 1) % NB;
+        if (SR) { if (tile + 2 < ntiles) stage(tile + 2, (buf + 2) % NB); }
+        else if (tile + 1 < ntiles) stage(tile + 1, next);
+        const bool fold_next = SR && tile + 1 < ntiles;
         if (active) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -1240,10 +1308,12 @@ __global__ __launch_bounds__(512, 2) void acc16d_kernel(
                     for (int uu = 0; uu < NQ; ++uu) {
                         const int st = (ks * 2 + half) * NQ + uu;
                         if (st == 3 * NQ) __syncthreads();
+                        if (SR && st >= 1 && st <= 10 && st % 3 == 1 && fold_next)
+                            fold(next, st / 3);
                         const bool last_uu = uu == NQ - 1;
                         // where the next A half / the next B fragment come from
                         const int nks = half ? (ks + 1) & 1 : ks, nhalf = half ^ 1;
-                        const int nbuf = (half && ks == 1) ? buf ^ 1 : buf;
+                        const int nbuf = (half && ks == 1) ? next : buf;
 #pragma unroll
                         for (int c = 0; c < MC / 2; ++c) {
                             f32x4& d = acc[half * (MC / 2) + c][uu];
@@ -1269,12 +1339,17 @@ __global__ __launch_bounds__(512, 2) void acc16d_kernel(
                         __builtin_amdgcn_sched_barrier(0);
                     }
         } else {
+            if (fold_next) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fold(next, q);
+            }
             __syncthreads();
         }
     };
-    for (int tile = 0; tile < ntiles; tile += 2) {
+    for (int tile = 0; tile < ntiles; tile += NB) {
         iteration(tile, 0);
         if (tile + 1 < ntiles) iteration(tile + 1, 1);
+        if (NB == 3 && tile + 2 < ntiles) iteration(tile + 2, 2);
     }
     const float* isx = sc + 64;
 #pragma unroll
@@ -1292,6 +1367,26 @@ __global__ __launch_bounds__(512, 2) void acc16d_kernel(
                 const int k = kc0 + 16 * c + 4 * g + r;
                 if (k < K) atomicAdd(Sp + (size_t)k * nq + q, (double)acc[c][uu][r] * unscale);
             }
+    }
+}
+
+// State posteriors [T, S] -> transposed tiles Gt [tile of 64 frames][Spad states][64
+// frames] (Spad = states of the padded component blocks; frames >= T and states >= S
+// are 0): what acc16d_kernel<.., SR> copies to LDS next to a tile of responsibilities.
+__global__ __launch_bounds__(256) void gt_image_kernel(int64_t nframes, int S, int Spad,
+                                                       const float* __restrict__ sr,
+                                                       float* __restrict__ Gt) {
+    __shared__ float tile[64 * 65];
+    const int64_t tau = blockIdx.x, t0 = tau * kA16FT;
+    const int s0 = blockIdx.y * 64;
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int f = idx >> 6, st = idx & 63;
+        tile[f * 65 + st] = (t0 + f < nframes && s0 + st < S) ? sr[(t0 + f) * S + s0 + st] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int st = idx >> 6, f = idx & 63;
+        if (s0 + st < Spad) Gt[(tau * Spad + s0 + st) * kA16FT + f] = tile[f * 65 + st];
     }
 }
 
@@ -1779,6 +1874,12 @@ size_t up256(size_t n) { return (n + 255) / 256 * 256; }
 }  // namespace
 
 bool supported_llh_split(int D, int S, int G) { return supported_llh_padded(D, S, G); }
+// Mixture sets whose responsibilities can leave the E-step as packed tiles: full
+// covariance (the two-wave kernel), groups of 4 .. 128 components, a power of two
+bool supported_llh_packed_sets(int cov, int D, int S, int G) {
+    return cov == BEER_FULL && S > 1 && G >= 4 && G <= 128 && (G & (G - 1)) == 0 &&
+           supported_llh_padded(D, S, G) && supported_acc(D, S * G);
+}
 
 int f16_range_hazard(int64_t nframes, int D, const float* X, void* scratch, int* hazard,
                      hipStream_t s) {
@@ -1857,7 +1958,7 @@ size_t estep16_workspace_bytes(int cov, int D, int S, int G) {
 int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, const float* expT,
                 const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
                 size_t ws_bytes, hipStream_t s, bool packed) {
-    if (packed && S != 1) return BEER_EINVAL;
+    if (packed && S != 1 && !supported_llh_packed_sets(cov, D, S, G)) return BEER_EINVAL;
     if (!supported_llh_padded(D, S, G) || ws_bytes < estep16_workspace_bytes(cov, D, S, G))
         return BEER_EINVAL;
     // mixture sets whose G is not a power of two: groups padded to Gp slots (logit
@@ -1922,6 +2023,19 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
     // Full covariance (a long parameter stream per frame tile): groups of at most
     // 128 components fit one wave's half of a 256-component chunk, so the waves can
     // split the components as in the packed kernel (half the stream per MFMA).
+    if (cov == BEER_FULL && G <= 128 && packed) {
+        // ... and hand the responsibilities over as the accumulation's LDS tiles
+        if (hipMemcpyAsync(resps, sc, kPackedHeader, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return BEER_EINVAL;
+        resps += kPackedHeader / sizeof(float);
+        if (gq == 1)
+            return launch_llh16<8, 4, 1, true, 2, false, false, true>(
+                nframes, D, K, S, G, gl, jw, nchunks, nk, X, P, inv_scale, sc, tab, resps, log_norm,
+                llh_sum, s);
+        return launch_llh16<8, 4, 2, true, 2, false, false, true>(
+            nframes, D, K, S, G, gl, jw, nchunks, nk, X, P, inv_scale, sc, tab, resps, log_norm,
+            llh_sum, s);
+    }
     if (cov == BEER_FULL && G <= 128) {
         if (gq == 1)
             return launch_llh16<8, 4, 1, false, 2, false>(nframes, D, K, S, G, gl, jw, nchunks, nk,
@@ -1965,9 +2079,30 @@ size_t acc16p_workspace_bytes(int cov, int64_t nframes, int D, int K) {
     return base + (size_t)tiles * xt_pieces(D) * kPiece;
 }
 
+// ... with state posteriors multiplied in by the accumulation kernel: S states of G
+// components (a power of two, 8 .. 128), more than 16 statistic tiles, X^T tiles of at
+// most 3 pieces (D <= 43: three LDS buffers have to fit)
+bool supported_acc_sets(int cov, int D, int S, int G) {
+    return S >= 1 && G >= 8 && G <= 128 && (G & (G - 1)) == 0 && supported_acc(D, S * G) &&
+           (nslab_of(cov, D) * 4 + 15) / 16 > 16 && xt_pieces(D) <= 3;
+}
+inline int acc_sets_spad(int S, int G) {
+    return (S * G + kPackedComps - 1) / kPackedComps * (kPackedComps / G);
+}
+size_t acc16s_workspace_bytes(int cov, int64_t nframes, int D, int S, int G) {
+    if (!supported_acc_sets(cov, D, S, G)) return 0;
+    const int64_t tiles = (nframes + kA16FT - 1) / kA16FT;
+    return up256(acc16p_workspace_bytes(cov, nframes, D, S * G)) +
+           (size_t)tiles * acc_sets_spad(S, G) * kA16FT * sizeof(float) + 1024;
+}
+
 int acc_f16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, const void* Rimg,
-                     double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
+                     double* acc, void* ws, size_t ws_bytes, hipStream_t s, int S, int G,
+                     const float* SR) {
     if (!supported_acc(D, K) || ws_bytes < acc16p_workspace_bytes(cov, nframes, D, K))
+        return BEER_EINVAL;
+    if (SR && (S * G != K || !supported_acc_sets(cov, D, S, G) ||
+               ws_bytes < acc16s_workspace_bytes(cov, nframes, D, S, G)))
         return BEER_EINVAL;
     const int nslab = nslab_of(cov, D), nq = nslab * 4;
     char* w = reinterpret_cast<char*>(ws);
@@ -1984,7 +2119,8 @@ int acc_f16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, con
     BEER_LAUNCH_CHECK();
     const int64_t tiles = (nframes + kA16FT - 1) / kA16FT;
     const int NX = xt_pieces(D);
-    if (packed_has_xt(K)) {                  // the E-step kernel left the image behind the tiles
+    if (packed_has_xt(K) && !SR) {           // the E-step kernel left the image behind the tiles
+                                             // (one mixture; the kernel of a set does not)
         Xt = reinterpret_cast<float*>(const_cast<char*>(reinterpret_cast<const char*>(Rimg)) +
                                       packed_tiles_bytes(nframes, K));
     } else {
@@ -1994,7 +2130,18 @@ int acc_f16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, con
     }
     const int ntiles = (nq + 15) / 16;
     static const int form = [] { const char* e = getenv("BEER_ACC16P"); return e ? atoi(e) : 2; }();
-    if (form == 2 && ntiles > 16) {
+    float* Gt = nullptr;
+    int lgG = 0;
+    if (SR) {
+        Gt = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) +
+                                      up256(acc16p_workspace_bytes(cov, nframes, D, K)));
+        const int spad = acc_sets_spad(S, G);
+        hipLaunchKernelGGL(gt_image_kernel, dim3((unsigned)tiles, (unsigned)((spad + 63) / 64)),
+                           dim3(256), 0, s, nframes, S, spad, SR, Gt);
+        BEER_LAUNCH_CHECK();
+        while ((1 << lgG) < G) ++lgG;
+    }
+    if (SR || (form == 2 && ntiles > 16)) {
         // second form: 4 statistic tiles per wave, LDS-DMA staging (see acc16d_kernel)
         const int gx = (ntiles + 31) / 32;
         const int gy = (K + 16 * kA16MC - 1) / (16 * kA16MC);
@@ -2007,22 +2154,28 @@ int acc_f16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, con
         int64_t fpb = (nframes + gz - 1) / gz;
         fpb = (fpb + kA16FT - 1) / kA16FT * kA16FT;
         gz = (nframes + fpb - 1) / fpb;
-        const size_t lds = 2 * (size_t)(NX + 8) * kPiece;
+        const size_t lds = SR ? 3 * ((size_t)(NX + 8) * kPiece + 4096)
+                              : 2 * (size_t)(NX + 8) * kPiece;
         const int64_t nyz = ((int64_t)gy * gz + 7) / 8 * 8;
         const dim3 grid((unsigned)(nyz * gx));
-#define BEER_ACC16D(NX_)                                                                         \
+#define BEER_ACC16D(NX_, SR_)                                                                    \
     do {                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc16d_kernel<NX_>),             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc16d_kernel<NX_, SR_>),        \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-        hipLaunchKernelGGL((acc16d_kernel<NX_>), grid, dim3(512), lds, s, nframes, D, K, nslab,  \
-                           Xt, reinterpret_cast<const unsigned*>(Rimg), tab, sc, fpb, Sp, gx,    \
-                           gy, (int)gz);                                                         \
+        hipLaunchKernelGGL((acc16d_kernel<NX_, SR_>), grid, dim3(512), lds, s, nframes, D, K,    \
+                           nslab, Xt, reinterpret_cast<const unsigned*>(Rimg), tab, sc, fpb, Sp, \
+                           gx, gy, (int)gz, Gt, lgG);                                            \
     } while (0)
-        if (NX == 1) BEER_ACC16D(1);
-        else if (NX == 2) BEER_ACC16D(2);
-        else if (NX == 3) BEER_ACC16D(3);
-        else if (NX == 4) BEER_ACC16D(4);
-        else BEER_ACC16D(5);
+        if (SR) {
+            if (NX == 1) BEER_ACC16D(1, true);
+            else if (NX == 2) BEER_ACC16D(2, true);
+            else BEER_ACC16D(3, true);
+        }
+        else if (NX == 1) BEER_ACC16D(1, false);
+        else if (NX == 2) BEER_ACC16D(2, false);
+        else if (NX == 3) BEER_ACC16D(3, false);
+        else if (NX == 4) BEER_ACC16D(4, false);
+        else BEER_ACC16D(5, false);
 #undef BEER_ACC16D
         BEER_LAUNCH_CHECK();
         const int64_t total2 = (int64_t)K * stats_dim(cov, D);

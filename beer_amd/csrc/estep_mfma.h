@@ -20,7 +20,7 @@ size_t estep16_workspace_bytes(int cov, int D, int S, int G);
 // shapes the split path takes when NO responsibilities are wanted: mixture sets with
 // any number of components per state (groups padded to a power of two)
 bool supported_llh_split(int D, int S, int G);
-// `packed`: S = 1 only; `resps` (packed_resps_bytes) then receives the fp16 hi / lo
+// `packed`: S = 1, or a set that is supported_llh_packed_sets; `resps` (packed_resps_bytes) then receives the fp16 hi / lo
 // image the accumulation kernel consumes (estep_tiles.h: softmax_epilogue<PACKED>).
 int estep_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
                 const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
@@ -42,7 +42,15 @@ int acc_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const flo
 size_t packed_resps_bytes(int64_t T, int D, int K);
 size_t acc16p_workspace_bytes(int cov, int64_t T, int D, int K);
 int acc_f16x3_packed(int cov, int64_t T, int D, int K, const float* X, const void* Rimg,
-                     double* acc, void* ws, size_t ws_bytes, hipStream_t s);
+                     double* acc, void* ws, size_t ws_bytes, hipStream_t s, int S = 1, int G = 0,
+                     const float* SR = nullptr);
+// Mixture sets on the packed hand-over (full covariance): the E-step leaves the
+// responsibilities within each state's mixture as packed tiles (estep_f16x3 with
+// packed = true, S > 1), the accumulation multiplies the state posteriors SR [T, S]
+// in while a tile sits in LDS (workspace: acc16s_workspace_bytes).
+bool supported_llh_packed_sets(int cov, int D, int S, int G);
+bool supported_acc_sets(int cov, int D, int S, int G);
+size_t acc16s_workspace_bytes(int cov, int64_t T, int D, int S, int G);
 
 // Mixture sets with diagonal / isotropic Gaussians: accumulation that recomputes the
 // component responsibilities from the frames and the per-state log-normalisers

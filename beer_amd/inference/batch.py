@@ -184,14 +184,24 @@ def _mixture_batch(model, X, lengths, datasize, labels, max_frames):
 
 def _emission_estep(groups, stats, dtype, for_accumulate=False):
     '''pc_all [T, S_total] + per group what its accumulation needs: the component
-    responsibilities [T, S*G], or -- where the accumulation recomputes them from
+    responsibilities [T, S*G] (float32 matrix, or `PackedResps` where
+    `kernels.packed_sets_ok`), or -- where the accumulation recomputes them from
     the frames (`kernels.fused_accumulate_ok`) -- the group's log-normalisers.'''
     cols, comps = [], []
     for grp, S, G in groups:
         ns = _normalset(grp)
         lw = grp._log_weights() if isinstance(grp, MixtureSet) else None
+        gstats = FrameStats(stats.data, ns.cov_type)
         fused = for_accumulate and G > 1 and \
-            kernels.fused_accumulate_ok(FrameStats(stats.data, ns.cov_type), S, G, ns.cov_type)
+            kernels.fused_accumulate_ok(gstats, S, G, ns.cov_type)
+        if for_accumulate and G > 1 and not fused and \
+                kernels.packed_sets_ok(gstats, S, G, ns.cov_type):
+            # full covariance: responsibilities as the accumulation kernel's tiles
+            log_norm, packed = kernels.mixtureset_estep_packed(
+                gstats, ns.means_precisions.natural_form(), lw, S, G, ns.cov_type)
+            cols.append(log_norm)
+            comps.append(packed)
+            continue
         log_norm, resps = kernels.mixtureset_estep(
             stats, ns.means_precisions.natural_form(), lw, S, G, ns.cov_type,
             want_resps=for_accumulate and G > 1 and not fused)

@@ -135,6 +135,43 @@ def mixture_estep_packed(stats, exp_stats, log_weights, K, cov_type, llh_sum=Non
     return log_norm, PackedResps(words, T, K)
 
 
+def packed_sets_ok(stats, S, G, cov_type):
+    '''True when a mixture SET can hand the responsibilities within its states'
+    mixtures to the accumulation as packed tiles, the state posteriors being
+    multiplied in by the accumulation kernel (include/beer_hip.h:
+    beer_mixtureset_estep_packed): float32 frames on the fp16-split path, full
+    covariance, G a power of two in 8..128.'''
+    st = _frames(stats)
+    X = st.data
+    if st.scale != 1.0 or X.dtype != torch.float32 or not _hip.f32_split_ok(X):
+        return False
+    return bool(_hip.lib().beer_mixtureset_packed_supported(_hip.COV_CODE[cov_type], X.shape[1],
+                                                            S, G))
+
+
+def mixtureset_estep_packed(stats, exp_stats, log_weights, S, G, cov_type, llh_sum=None):
+    '''(log_norm [T,S], PackedResps [T, S*G]) of a mixture set: `mixtureset_estep`
+    whose responsibilities go to `normal_accumulate(..., state_resps)` in packed
+    form.  Only where `packed_sets_ok`.'''
+    st = _frames(stats)
+    X = st.data
+    T, D = X.shape
+    K = S * G
+    E = _hip.on_device(exp_stats, X.dtype)
+    lw = None if log_weights is None else _hip.on_device(log_weights, X.dtype)
+    if E.shape[0] != K or (lw is not None and lw.numel() != K):
+        raise ValueError(f'{E.shape[0]} Gaussians for {S} x {G} components')
+    log_norm = torch.empty(T, S, dtype=X.dtype, device=X.device)
+    words = torch.empty(_hip.lib().beer_packed_resps_bytes(T, D, K) // 4, dtype=torch.int32,
+                        device=X.device)
+    ws, ws_bytes = _hip.workspace('beer_estep_workspace_bytes', X.dtype,
+                                  _hip.COV_CODE[cov_type], D, S, G, X.device)
+    _hip.call('beer_mixtureset_estep_packed', _hip.COV_CODE[cov_type], T, D, S, G, _hip.ptr(X),
+              _hip.ptr(E), _hip.ptr(lw), _hip.ptr(log_norm), _hip.ptr(words), _hip.ptr(llh_sum),
+              _hip.ptr(ws), ws_bytes)
+    return log_norm, PackedResps(words, T, K)
+
+
 def pack_resps(stats, comp_resps, state_resps, S, G):
     '''PackedResps of float32 responsibilities [T, S*G] (times `state_resps`
     [T, S] broadcast over each state's G components).'''
@@ -177,10 +214,22 @@ def normal_accumulate(stats, comp_resps, state_resps, S, G, cov_type, acc=None):
     Q = st.shape[1]
     if acc is None:
         acc = torch.zeros(K, Q, dtype=torch.float64, device=X.device)
+    if isinstance(comp_resps, PackedResps) and state_resps is not None:
+        # mixture set: the state posteriors are multiplied in by the kernel
+        if tuple(comp_resps.shape) != (T, K) or not packed_sets_ok(st, S, G, cov_type):
+            raise ValueError('packed responsibilities of a mixture set: same frames and '
+                             'components, a shape with `packed_sets_ok`')
+        sr = _hip.on_device(state_resps, X.dtype)
+        if tuple(sr.shape) != (T, S):
+            raise ValueError(f'state responsibilities {tuple(sr.shape)}, expected {(T, S)}')
+        code = _hip.COV_CODE[cov_type]
+        ws, ws_bytes = _hip.packed_workspace(code, T, D, K, X.device, sets=(S, G))
+        _hip.call('beer_mixtureset_accumulate_packed', code, T, D, S, G, _hip.ptr(X),
+                  _hip.ptr(comp_resps.words), _hip.ptr(sr), _hip.ptr(acc), _hip.ptr(ws), ws_bytes)
+        return acc
     if isinstance(comp_resps, PackedResps):
-        if state_resps is not None or tuple(comp_resps.shape) != (T, K):
-            raise ValueError('packed responsibilities: same frames and components, no state '
-                             'responsibilities')
+        if tuple(comp_resps.shape) != (T, K):
+            raise ValueError('packed responsibilities: same frames and components')
         ws, ws_bytes = _hip.packed_workspace(_hip.COV_CODE[cov_type], T, D, K, X.device)
         _hip.call('beer_normal_accumulate_packed', _hip.COV_CODE[cov_type], T, D, K,
                   _hip.ptr(X), _hip.ptr(comp_resps.words), _hip.ptr(acc), _hip.ptr(ws), ws_bytes)

@@ -520,7 +520,8 @@ def run_hmm(args, rank, world, device, backend):
 
     names = ('beer_mixtureset_estep', 'beer_hmm_posteriors_fused', 'beer_hmm_forward_backward',
              'beer_mixtureset_accumulate_fused', 'beer_normal_accumulate',
-             'beer_normal_accumulate_packed', 'beer_pack_resps')
+             'beer_normal_accumulate_packed', 'beer_pack_resps',
+             'beer_mixtureset_estep_packed', 'beer_mixtureset_accumulate_packed')
     for _ in range(args.warmup):
         step()
     import gc
@@ -548,6 +549,8 @@ def run_hmm(args, rank, world, device, backend):
     alg_bytes = 4. * D * kern[dom]['frames_per_launch']
     achieved = alg_bytes / (kern[dom]['ms'] * 1e-3) / 1e9
     pmc_key = 'c3_' + {'beer_mixtureset_accumulate_fused': 'accf_kernel',
+                       'beer_mixtureset_estep_packed': 'llh16_kernel',
+                       'beer_mixtureset_accumulate_packed': 'acc16d_kernel',
                        'beer_mixtureset_estep': 'llh16_kernel',
                        'beer_hmm_posteriors_fused': 'fb_wave_kernel'}.get(dom, dom)
     Qd = {'diagonal': 2 * D + 2, 'full': D * D + D + 2, 'isotropic': D + 3}[args.cov]

@@ -276,6 +276,35 @@ int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float*
                                   const void* packed_resps, double* acc,
                                   void* workspace, size_t workspace_bytes,
                                   void* stream);
+/* The same hand-over for a mixture SET around the forward-backward pass (float32,
+ * split arithmetic, full covariance; S states of G components, G a power of two
+ * in 8..128, D <= 43): beer_mixtureset_estep_packed leaves `log_norm` [T, S] and
+ * the responsibilities WITHIN each state's mixture as packed tiles (layout above,
+ * K = S * G; no frame tiles behind them); after the forward-backward pass
+ * beer_mixtureset_accumulate_packed multiplies the state posteriors
+ * `state_resps` [T, S] in while a tile sits in LDS -- (hi + lo) * gamma in fp32,
+ * split again, each element once per workgroup -- and accumulates
+ *     acc[k,:] += sum_t r[t,k] state_resps[t, k / G] phi(x_t)           (fp64, +=)
+ * MixtureSet.expected_log_likelihood / accumulate (beer/models/mixtureset.py:85-112)
+ * around HMM.expected_log_likelihood (beer/models/hmm.py:73-92): neither the
+ * [T, K] float32 responsibilities nor their product with the state posteriors is
+ * ever stored.  beer_mixtureset_packed_supported: 1 where both calls have a
+ * kernel; EINVAL elsewhere (callers then use beer_mixtureset_estep +
+ * beer_normal_accumulate).  Workspaces: beer_estep_workspace_bytes(BEER_F32, ...)
+ * and beer_mixtureset_accumulate_packed_workspace_bytes (grows with T: the
+ * transposed frames and state posteriors). */
+int beer_mixtureset_packed_supported(int cov, int D, int S, int G);
+size_t beer_mixtureset_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int S,
+                                                         int G);
+int beer_mixtureset_estep_packed(int cov, int64_t T, int D, int S, int G, const float* X,
+                                 const float* exp_stats, const float* log_weights,
+                                 float* log_norm, void* packed_resps, double* llh_sum,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+int beer_mixtureset_accumulate_packed(int cov, int64_t T, int D, int S, int G,
+                                      const float* X, const void* packed_resps,
+                                      const float* state_resps, double* acc,
+                                      void* workspace, size_t workspace_bytes,
+                                      void* stream);
 /* The packed buffer from float32 responsibilities: comp_resps [T, S*G], times
  * state_resps[t, k / G] when given (the joint responsibilities of
  * MixtureSet.accumulate, mixtureset.py:100-112), split and tiled as above, with

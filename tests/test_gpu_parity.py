@@ -1199,6 +1199,52 @@ def test_pack_resps_and_repacked_accumulation(cov, S, G, D):
         torch.testing.assert_close(acc32, acc_p, rtol=0, atol=1e-9 * float(acc_p.abs().max()))
 
 
+@pytest.mark.parametrize('S,G,D,T', [(12, 16, 40, 20011), (120, 16, 40, 16500), (5, 8, 24, 17000),
+                                       (3, 128, 30, 16390), (7, 32, 36, 16450)])
+def test_packed_hand_over_of_a_mixture_set(S, G, D, T):
+    '''Full-covariance mixture sets around a forward-backward pass:
+    beer_mixtureset_estep_packed leaves the log-normalisers and the responsibilities
+    within each state's mixture as packed tiles (unpacked they are the float32
+    responsibilities), beer_mixtureset_accumulate_packed multiplies the state
+    posteriors in inside the kernel -- against the fp64 kernels on the same inputs:
+    MixtureSet.expected_log_likelihood / accumulate, beer/models/mixtureset.py:85-112.'''
+    from beer_amd import kernels
+    torch.manual_seed(S + G + D)
+    K, cov = S * G, 'full'
+    mu = torch.randn(K, D, dtype=torch.float64) * 1.5
+    X = (mu[torch.randint(0, K, (T,))] + torch.randn(T, D, dtype=torch.float64)).to(DEV)
+    ns = beer.NormalSet.create(torch.zeros(D), torch.ones(D), size=K, prior_strength=1.,
+                               noise_std=1.5, cov_type=cov)
+    ms = beer.MixtureSet.create(S, ns, prior_strength=1.).double().to(DEV)
+    E64, lw64 = ns.means_precisions.natural_form(), ms._log_weights()
+    sr64 = torch.rand(T, S, dtype=torch.float64, device=DEV)
+    sr64 = sr64 * (torch.rand(T, S, dtype=torch.float64, device=DEV) < .3)     # sparse posteriors
+    st64, st32 = beer.FrameStats(X, cov), beer.FrameStats(X.float(), cov)
+    ln64, r64 = kernels.mixtureset_estep(st64, E64, lw64, S, G, cov)
+    acc64 = kernels.normal_accumulate(st64, r64, sr64, S, G, cov)
+    assert kernels.packed_sets_ok(st32, S, G, cov)
+    ln32, packed = kernels.mixtureset_estep_packed(st32, E64.float(), lw64.float(), S, G, cov)
+    assert float((ln32.double() - ln64).abs().max() / ln64.abs().max()) <= 1e-6
+    got = kernels.normal_accumulate(st32, packed, sr64.float(), S, G, cov)
+    # yardstick: the float32 path with the responsibilities through memory (same
+    # kernel, same roundings up to the split of r * 2^12 into two fp16 halves)
+    _, r32 = kernels.mixtureset_estep(st32, E64.float(), lw64.float(), S, G, cov)
+    torch.testing.assert_close(packed.unpack(), r32, rtol=0, atol=1e-6)
+    assert float((r32.double() - r64).abs().max()) <= 1e-4
+    two = kernels.normal_accumulate(st32, r32, sr64.float(), S, G, cov)
+    scale = float(acc64.abs().max())
+    err, err2 = float((got - acc64).abs().max()) / scale, float((two - acc64).abs().max()) / scale
+    assert bool(torch.isfinite(got).all())
+    assert err <= max(2e-6, 3. * err2), (S, G, D, err, err2)
+    # the counts: sum_t r[t,k] gamma[t, state(k)] to 1e-6 of the largest
+    n64 = (r64 * sr64.repeat_interleave(G, dim=1)).sum(0)
+    Q = acc64.shape[1]
+    torch.testing.assert_close(got[:, Q - 1] * 2, n64, rtol=0, atol=5e-6 * float(n64.max()))
+    # += semantics
+    again = kernels.normal_accumulate(st32, packed, sr64.float(), S, G, cov, acc=got.clone())
+    torch.testing.assert_close(again, 2 * got, rtol=1e-9, atol=1e-9 * scale)
+
+
 def test_elbo_round_trip_through_the_flat_device_buffer():
     '''What an RCCL all-reduce does to an ELBO object, minus the collective:
     flatten on the device, unflatten (the counts stay 0-dim device tensors: no
