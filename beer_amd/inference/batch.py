@@ -17,6 +17,8 @@ acc_stats = sum_u acc_u, minibatchsize = sum_u T_u.  The KL term is computed
 once.  Sufficient statistics are accumulated in fp64 across the whole shard.
 """
 
+import os
+
 import torch
 
 from .. import _hip, hmm_kernels as hk, kernels
@@ -32,7 +34,9 @@ from .objectives import EvidenceLowerBoundInstance
 __all__ = ['accumulate_elbo', 'pack_utterances', 'decode_batch']
 
 # Responsibilities [frames, K] are the largest scratch buffer; bound it.
-_SCRATCH_BYTES = 6 << 30
+# scratch of one sub-batch (responsibilities, per-state likelihoods, trellis); the
+# device has 288 GB and up to three sub-batches are in flight (BEER_SCRATCH_GB overrides)
+_SCRATCH_BYTES = int(os.environ.get('BEER_SCRATCH_GB', '24')) << 30
 
 
 def pack_utterances(utterances):
@@ -346,7 +350,7 @@ def _vae_batch(model, X, lengths, datasize, nsamples, llh_weight, kl_weight):
 
 
 def accumulate_elbo(model, utterances, datasize=-1, inference_graphs=None, scale=1.,
-                    viterbi=False, state_paths=None, labels=None, max_frames=1 << 20,
+                    viterbi=False, state_paths=None, labels=None, max_frames=1 << 22,
                     nsamples=1, llh_weight=1., kl_weight=1.):
     '''ELBO + accumulated statistics of a shard of utterances, identical to the
     sum of per-utterance `evidence_lower_bound(model, utt, datasize=datasize,
