@@ -13,6 +13,8 @@
 // Reference restated: beer/dists/normalgamma.py:55-59 (llh = stats @ E[T]^T +
 // log base measure), beer/models/normalset.py:121-123 (resps^T @ stats).
 
+#include <mutex>
+#include <unordered_map>
 #include <dlfcn.h>
 #include <rocblas/rocblas.h>             // types and prototypes only: the library is dlopen'ed
 
@@ -229,14 +231,28 @@ struct RocBlas {
         sgemm = reinterpret_cast<decltype(sgemm)>(dlsym(lib, "rocblas_sgemm"));
         sgemm_sb = reinterpret_cast<decltype(sgemm_sb)>(
             dlsym(lib, "rocblas_sgemm_strided_batched"));
-        ok = create && set_stream && sgemm && sgemm_sb &&
-             create(&handle) == rocblas_status_success;
+        ok = create && set_stream && sgemm && sgemm_sb;
     }
 };
+// One rocBLAS handle per stream, bound to it once (a handle carries its stream and
+// its workspace: sharing one between streams, re-pointed per call, would make
+// concurrent callers race on it).  Handles live as long as the process.
 RocBlas* blas_for(hipStream_t s) {
-    static RocBlas rb;                         // one handle: calls are serialised by the caller
-    if (!rb.ok || rb.set_stream(rb.handle, s) != rocblas_status_success) return nullptr;
-    return &rb;
+    static RocBlas lib;                        // the library's entry points, no handle
+    if (!lib.ok) return nullptr;
+    static std::mutex mu;
+    static std::unordered_map<hipStream_t, RocBlas*> per_stream;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = per_stream.find(s);
+    if (it != per_stream.end()) return it->second;
+    RocBlas* rb = new RocBlas(lib);
+    if (lib.create(&rb->handle) != rocblas_status_success ||
+        lib.set_stream(rb->handle, s) != rocblas_status_success) {
+        delete rb;
+        rb = nullptr;
+    }
+    per_stream[s] = rb;
+    return rb;
 }
 inline bool blas_shape(int64_t T_, int Q, int K) {
     return Q >= kBlasMinQ && T_ >= kBlasMinT && T_ < (int64_t)1 << 31 && K >= 1;
