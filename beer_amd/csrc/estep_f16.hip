@@ -282,16 +282,28 @@ __device__ __forceinline__ void split8(const f32x4& p0, const f32x4& p1, h8& hi,
 // SQ = false: no "square" slabs in the table (full covariance), the per-product
 // select between x_j^2 and x_a x_j drops out of the A-fragment arithmetic.
 // Several component chunks over the same frames: a 1-D grid whose blocks are dealt to
-// the 8 XCDs round-robin, laid out so that the `ny` chunk blocks of one frame block
-// are neighbours on ONE XCD (they read the same frames at about the same time: one
-// L2 miss, ny - 1 hits -- with a (frames, chunks) grid every chunk pass streamed the
-// frames from HBM again).  Grid size xcd_grid(nx, ny); false = padding block.
-inline unsigned xcd_grid(int64_t nx, int ny) { return (unsigned)((nx + 7) / 8 * 8 * ny); }
-__device__ inline bool xcd_block(int64_t nx, int ny, int64_t& bx, int& by) {
-    const unsigned id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-    by = (int)(slot % (unsigned)ny);
-    bx = (int64_t)(slot / (unsigned)ny) * 8 + xcd;
-    return bx < nx;
+// the 8 XCDs round-robin, laid out so that the chunk blocks of one frame block are
+// neighbours on ONE XCD (they read the same frames at about the same time: one L2
+// miss, the others hit -- with a (frames, chunks) grid every chunk pass streamed the
+// frames from HBM again).  The chunks are taken `cg` at a time (all frame blocks for
+// chunks 0 .. cg-1, then the next cg): the packed parameters of the cg chunks an XCD
+// works on must stay in its 4 MiB L2 -- with all 8 full-covariance chunks of config 3
+// interleaved (7.6 MB) the parameter stream missed L2 instead of the frames.
+// Grid size xcd_grid(nx, ny, cg); false = padding block.
+inline int xcd_chunk_group(int ny, size_t chunk_bytes) {
+    int cg = (int)((size_t)(2 << 20) / (chunk_bytes ? chunk_bytes : 1));
+    return cg < 1 ? 1 : (cg > ny ? ny : cg);
+}
+inline unsigned xcd_grid(int64_t nx, int ny, int cg) {
+    return (unsigned)((nx + 7) / 8 * 8 * cg * ((ny + cg - 1) / cg));
+}
+__device__ inline bool xcd_block(int64_t nx, int ny, int cg, int64_t& bx, int& by) {
+    const unsigned per_group = (unsigned)((nx + 7) / 8 * 8 * cg);
+    const unsigned grp = blockIdx.x / per_group, rem = blockIdx.x - grp * per_group;
+    const unsigned xcd = rem & 7, slot = rem >> 3;
+    by = (int)(grp * cg + slot % (unsigned)cg);
+    bx = (int64_t)(slot / (unsigned)cg) * 8 + xcd;
+    return bx < nx && by < ny;
 }
 
 template <int NT, int MT, int GQ, bool PACKED, int KS = 1, bool SQ = true, bool LNO = false,
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     const float* __restrict__ X, const _Float16* __restrict__ Pall,
     const float* __restrict__ inv_scale, const float* __restrict__ sc,
     const int* __restrict__ tab, float* __restrict__ resps, float* __restrict__ log_norm,
-    double* __restrict__ llh_sum, float* __restrict__ xt_out, int xt_floats, int nku) {
+    double* __restrict__ llh_sum, float* __restrict__ xt_out, int xt_floats, int nku, int cg) {
     using acc_t = f32x4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int D4 = d4_of(D), Dp = 4 * D4, LD = ld16_of(D);    // 16-byte aligned rows
@@ -319,7 +331,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
     {
         const int nch = (K + 16 * NT * KS - 1) / (16 * NT * KS);
         constexpr int FBK = FW * NGRP;
-        if (nch > 1 && !xcd_block((nframes + FBK - 1) / FBK, nch, bx, by)) return;
+        if (nch > 1 && !xcd_block((nframes + FBK - 1) / FBK, nch, cg, bx, by)) return;
     }
     const int64_t fb = (bx * NGRP + grp) * FW;
     for (int idx = tid; idx < (nk + 1) * 8; idx += kThreads) tabs[idx] = tab[idx];
@@ -519,10 +531,11 @@ int launch_llh16(int64_t nframes, int D, int K, int S, int G, int gl, int jw, in
                        (KS == 2 ? 8 * 16 * MT * sizeof(float) : 0);
     const int64_t blocks = (nframes + FB - 1) / FB;
     if (nchunks != (K + 16 * NT * KS - 1) / (16 * NT * KS)) return BEER_EINVAL;
+    const int cg = xcd_chunk_group(nchunks, (size_t)nku * NT * KS * 2048);
     hipLaunchKernelGGL((llh16_kernel<NT, MT, GQ, PACKED, KS, SQ, LNO, SETS>),
-                       dim3(nchunks > 1 ? xcd_grid(blocks, nchunks) : (unsigned)blocks),
+                       dim3(nchunks > 1 ? xcd_grid(blocks, nchunks, cg) : (unsigned)blocks),
                        dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nk, X, P, inv_scale,
-                       sc, tab, resps, log_norm, llh_sum, xt_out, xt_floats, nku);
+                       sc, tab, resps, log_norm, llh_sum, xt_out, xt_floats, nku, cg);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }
@@ -1494,9 +1507,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int64_t bx;
     int by;
-    if (!xcd_block((nframes + frames_per_block - 1) / frames_per_block,
-                   (K + 16 * NTC - 1) / (16 * NTC), bx, by))
-        return;
+    {
+        const int nch = (K + 16 * NTC - 1) / (16 * NTC);      // (24 KB of parameters each)
+        if (!xcd_block((nframes + frames_per_block - 1) / frames_per_block, nch, nch, bx, by))
+            return;
+    }
     const int D4 = d4_of(D), Dp = 4 * D4, LD = ld16_of(D), nq = nslab * 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2298,7 +2313,7 @@ int acc_fused_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* 
     gz = (nframes + fpb - 1) / fpb;
     const size_t lds = (size_t)nk * NTC * 2048 + (size_t)(nk + 1) * 8 * sizeof(int) + 256 +
                        (size_t)waves * (32 * ld16_of(D) + (D + 2) * kAfXS) * sizeof(float);
-    const dim3 grid(xcd_grid(gz, nchunks));
+    const dim3 grid(xcd_grid(gz, nchunks, nchunks));
     const bool g4 = (G % 4) == 0;
     static const int dbg = [] { const char* e = getenv("BEER_ACCF_DBG"); return e ? atoi(e) : 0; }();
 #define BEER_ACCF(NTC_, NQT_, G4_, W_)                                                           \

@@ -548,7 +548,8 @@ def run_hmm(args, rank, world, device, backend):
     # 4 D bytes each (B(D) = 160 B / frame), once
     alg_bytes = 4. * D * kern[dom]['frames_per_launch']
     achieved = alg_bytes / (kern[dom]['ms'] * 1e-3) / 1e9
-    pmc_key = 'c3_' + {'beer_mixtureset_accumulate_fused': 'accf_kernel',
+    pmc_key = ('c3full_' if args.cov == 'full' else 'c3_') + {
+                       'beer_mixtureset_accumulate_fused': 'accf_kernel',
                        'beer_mixtureset_estep_packed': 'llh16_kernel',
                        'beer_mixtureset_accumulate_packed': 'acc16d_kernel',
                        'beer_mixtureset_estep': 'llh16_kernel',
