@@ -188,6 +188,7 @@ SIZE_QUERIES = {
     'beer_accumulate_fused_workspace_bytes': [c_i, c_i, c_i, c_i],
     'beer_accumulate_packed_workspace_bytes': [c_i, c_l, c_i, c_i],
     'beer_mixtureset_accumulate_packed_workspace_bytes': [c_i, c_l, c_i, c_i, c_i],
+    'beer_hmm_fb_scratch_doubles': [c_i, c_p, c_i],
 }
 
 

@@ -164,13 +164,28 @@ struct FbLayout {            // byte offsets into dynamic LDS, from the batch ma
     }
 };
 
-template <typename T>
-__global__ __launch_bounds__(kFbThreads) void fb_kernel(
-    beer_batch b, const T* __restrict__ pc_llhs, double* __restrict__ alpha_ws,
+// BIG: a graph whose arc lists do not fit a CU's LDS (a dense 100-state HMM has
+// 10 000 arcs).  Same phases; the topology is read where it lies (the graph image in
+// global memory: L2 resident, int32 indices), the per-arc scratch (p_e, xi) and the
+// per-segment partials live in a slice of `arc_ws` per workgroup (2 max_arcs +
+// max_segs doubles), only the per-state arrays stay in LDS, and a bounded number of
+// workgroups walks the utterances (so that the scratch is bounded too).
+constexpr size_t kLdsBytes = 160 * 1024;
+inline size_t fb_lds_bytes(const beer_batch* b, int dtype, bool has_xi, bool big) {
+    return FbLayout(b->max_states, big ? 0 : b->max_arcs, big ? 0 : b->max_segs, !big && has_xi,
+                    dtype == BEER_F32 ? 4 : 8).total;
+}
+template <bool BIG> struct FbIdx { typedef int16_t type; };
+template <> struct FbIdx<true> { typedef int32_t type; };
+constexpr int kFbBigBlocks = 512;
+
+template <typename T, bool BIG>
+__device__ __forceinline__ void fb_utterance(
+    const beer_batch& b, int u, const T* __restrict__ pc_llhs, double* __restrict__ alpha_ws,
     T* __restrict__ gamma, double* __restrict__ xi_sum, double* __restrict__ gamma0_sum,
-    T* __restrict__ lognorm_mean) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int u = blockIdx.x, tid = threadIdx.x, nt_ = blockDim.x;
+    T* __restrict__ lognorm_mean, double* __restrict__ arc_ws, char* smem) {
+    typedef typename FbIdx<BIG>::type idx_t;
+    const int tid = threadIdx.x, nt_ = blockDim.x;
     const beer_graph g = b.graphs[b.graph_id[u]];
     const int S = g.n_states, nnz = g.n_arcs, nsi = g.n_in_seg, nso = g.n_out_seg;
     const int64_t T_ = b.frame_off[u + 1] - b.frame_off[u];
@@ -181,39 +196,55 @@ __global__ __launch_bounds__(kFbThreads) void fb_kernel(
     const T* init = (const T*)g.init;
     const T* fin = (const T*)g.final;
 
-    const FbLayout L(b.max_states, b.max_arcs, b.max_segs, xi_sum != nullptr, sizeof(T));
+    const FbLayout L(b.max_states, BIG ? 0 : b.max_arcs, BIG ? 0 : b.max_segs,
+                     !BIG && xi_sum != nullptr, sizeof(T));
     double* cur = reinterpret_cast<double*>(smem + L.cur);      // alpha_{t-1} / beta_t
     double* nxt = reinterpret_cast<double*>(smem + L.nxt);      // alpha_t / s_i / gamma_t/s_i
     double* lb = reinterpret_cast<double*>(smem + L.lb);        // llh_{t+1} + beta_{t+1}
     double* mx = reinterpret_cast<double*>(smem + L.mx);        // per-state max
     double* red = reinterpret_cast<double*>(smem + L.red);
-    double* v = reinterpret_cast<double*>(smem + L.v);          // per-arc scratch
-    double* xi = reinterpret_cast<double*>(smem + L.xi);
-    double* pseg = reinterpret_cast<double*>(smem + L.pseg);    // per-segment partials
-    T* w_in = reinterpret_cast<T*>(smem + L.w_in);
-    T* w_out = reinterpret_cast<T*>(smem + L.w_out);
-    int16_t* src_in = reinterpret_cast<int16_t*>(smem + L.src_in);
-    int16_t* dst_in = reinterpret_cast<int16_t*>(smem + L.dst_in);
-    int16_t* dst_out = reinterpret_cast<int16_t*>(smem + L.dst_out);
-    int16_t* src_out = reinterpret_cast<int16_t*>(smem + L.src_out);
-    int* seg_in = reinterpret_cast<int*>(smem + L.seg_in);
     int* rseg_in = reinterpret_cast<int*>(smem + L.rseg_in);
-    int* seg_out = reinterpret_cast<int*>(smem + L.seg_out);
     int* rseg_out = reinterpret_cast<int*>(smem + L.rseg_out);
-    const double NINF = neg_inf(), PINF = __builtin_huge_val();
-
-    // ---- topology -> LDS ----
-    for (int e = tid; e < nnz; e += nt_) {
-        w_in[e] = ((const T*)g.in_w)[e];
-        w_out[e] = ((const T*)g.out_w)[e];
-        src_in[e] = (int16_t)g.in_src[e];
-        dst_in[e] = (int16_t)g.in_dst[e];
-        dst_out[e] = (int16_t)g.out_dst[e];
-        src_out[e] = (int16_t)g.out_src[e];
-        if (xi_sum) xi[e] = 0.0;
+    double *v, *xi, *pseg;                  // per-arc scratch, per-segment partials
+    const T *w_in, *w_out;
+    const idx_t *src_in, *dst_in, *dst_out, *src_out;
+    const int *seg_in, *seg_out;
+    if constexpr (BIG) {
+        double* mine = arc_ws + (size_t)blockIdx.x * (2 * (size_t)b.max_arcs + b.max_segs);
+        v = mine; xi = mine + b.max_arcs; pseg = mine + 2 * (size_t)b.max_arcs;
+        w_in = (const T*)g.in_w; w_out = (const T*)g.out_w;
+        src_in = g.in_src; dst_in = g.in_dst; dst_out = g.out_dst; src_out = g.out_src;
+        seg_in = g.in_seg; seg_out = g.out_seg;
+        if (xi_sum)
+            for (int e = tid; e < nnz; e += nt_) xi[e] = 0.0;
+    } else {
+        // ---- topology -> LDS ----
+        v = reinterpret_cast<double*>(smem + L.v);
+        xi = reinterpret_cast<double*>(smem + L.xi);
+        pseg = reinterpret_cast<double*>(smem + L.pseg);
+        T* wi = reinterpret_cast<T*>(smem + L.w_in);
+        T* wo = reinterpret_cast<T*>(smem + L.w_out);
+        int16_t* si = reinterpret_cast<int16_t*>(smem + L.src_in);
+        int16_t* di = reinterpret_cast<int16_t*>(smem + L.dst_in);
+        int16_t* dO = reinterpret_cast<int16_t*>(smem + L.dst_out);
+        int16_t* sO = reinterpret_cast<int16_t*>(smem + L.src_out);
+        int* sgi = reinterpret_cast<int*>(smem + L.seg_in);
+        int* sgo = reinterpret_cast<int*>(smem + L.seg_out);
+        for (int e = tid; e < nnz; e += nt_) {
+            wi[e] = ((const T*)g.in_w)[e];
+            wo[e] = ((const T*)g.out_w)[e];
+            si[e] = (int16_t)g.in_src[e];
+            di[e] = (int16_t)g.in_dst[e];
+            dO[e] = (int16_t)g.out_dst[e];
+            sO[e] = (int16_t)g.out_src[e];
+            if (xi_sum) xi[e] = 0.0;
+        }
+        for (int k = tid; k <= nsi; k += nt_) sgi[k] = g.in_seg[k];
+        for (int k = tid; k <= nso; k += nt_) sgo[k] = g.out_seg[k];
+        w_in = wi; w_out = wo; src_in = si; dst_in = di; dst_out = dO; src_out = sO;
+        seg_in = sgi; seg_out = sgo;
     }
-    for (int k = tid; k <= nsi; k += nt_) seg_in[k] = g.in_seg[k];
-    for (int k = tid; k <= nso; k += nt_) seg_out[k] = g.out_seg[k];
+    const double NINF = neg_inf(), PINF = __builtin_huge_val();
     for (int k = tid; k <= S; k += nt_) { rseg_in[k] = g.in_row_seg[k]; rseg_out[k] = g.out_row_seg[k]; }
 
     // ---- forward ----
@@ -353,6 +384,19 @@ __global__ __launch_bounds__(kFbThreads) void fb_kernel(
         __syncthreads();
         for (int e = tid; e < nnz; e += nt_)
             atomicAdd(xi_sum + (size_t)src_out[e] * S + dst_out[e], xi[e]);
+    }
+}
+
+template <typename T, bool BIG>
+__global__ __launch_bounds__(kFbThreads) void fb_kernel(
+    beer_batch b, const T* __restrict__ pc_llhs, double* __restrict__ alpha_ws,
+    T* __restrict__ gamma, double* __restrict__ xi_sum, double* __restrict__ gamma0_sum,
+    T* __restrict__ lognorm_mean, double* __restrict__ arc_ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int u = blockIdx.x; u < b.nutt; u += gridDim.x) {       // (one pass unless BIG)
+        fb_utterance<T, BIG>(b, u, pc_llhs, alpha_ws, gamma, xi_sum, gamma0_sum, lognorm_mean,
+                             arc_ws, smem);
+        __syncthreads();                                         // LDS reused by the next one
     }
 }
 
@@ -1368,25 +1412,38 @@ int beer_hmm_forward_backward(int dtype, const beer_batch* b, const void* pc_llh
         BEER_LAUNCH_CHECK();
         return BEER_OK;
     }
-    const FbLayout L(b->max_states, b->max_arcs, b->max_segs, xi_sum != nullptr,
-                     dtype == BEER_F32 ? 4 : 8);
-    const size_t lds = L.total;
-    BEER_REQUIRE(lds <= 160 * 1024);          // graph too large for one CU's LDS
-    if (dtype == BEER_F32) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fb_kernel<float>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(fb_kernel<float>, dim3(b->nutt), dim3(kFbThreads), lds, s, *b,
-                           (const float*)pc_llhs, alpha_ws, (float*)gamma, xi_sum,
-                           gamma0_sum, (float*)lognorm_mean);
+    const size_t lds = fb_lds_bytes(b, dtype, xi_sum != nullptr, false);
+    const bool big = lds > kLdsBytes;
+#define BEER_FB(T_, BIG_, LDS_, GRID_)                                                           \
+    do {                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fb_kernel<T_, BIG_>),            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_));      \
+        hipLaunchKernelGGL((fb_kernel<T_, BIG_>), dim3(GRID_), dim3(kFbThreads), LDS_, s, *b,    \
+                           (const T_*)pc_llhs, alpha_ws, (T_*)gamma, xi_sum, gamma0_sum,         \
+                           (T_*)lognorm_mean, hub_ws);                                           \
+    } while (0)
+    if (!big) {
+        if (dtype == BEER_F32) BEER_FB(float, false, lds, b->nutt);
+        else BEER_FB(double, false, lds, b->nutt);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fb_kernel<double>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(fb_kernel<double>, dim3(b->nutt), dim3(kFbThreads), lds, s, *b,
-                           (const double*)pc_llhs, alpha_ws, (double*)gamma, xi_sum,
-                           gamma0_sum, (double*)lognorm_mean);
+        // arc lists beyond a CU's LDS: per-arc scratch in `hub_ws`
+        // (beer_hmm_fb_scratch_doubles), the per-state arrays must still fit
+        const size_t lds_big = fb_lds_bytes(b, dtype, xi_sum != nullptr, true);
+        BEER_REQUIRE(lds_big <= kLdsBytes && hub_ws);
+        const int grid = b->nutt < kFbBigBlocks ? b->nutt : kFbBigBlocks;
+        if (dtype == BEER_F32) BEER_FB(float, true, lds_big, grid);
+        else BEER_FB(double, true, lds_big, grid);
     }
+#undef BEER_FB
     BEER_LAUNCH_CHECK();
     return BEER_OK;
+}
+
+size_t beer_hmm_fb_scratch_doubles(int dtype, const beer_batch* b, int want_xi) {
+    if (!b || (dtype != BEER_F32 && dtype != BEER_F64) || b->nutt <= 0) return 0;
+    if (fb_lds_bytes(b, dtype, want_xi != 0, false) <= kLdsBytes) return 0;
+    const size_t blocks = b->nutt < kFbBigBlocks ? b->nutt : kFbBigBlocks;
+    return blocks * (2 * (size_t)b->max_arcs + (size_t)b->max_segs);
 }
 
 int beer_hmm_trans_posteriors(int dtype, int64_t T, int S, const double* alpha, const void* llhs,

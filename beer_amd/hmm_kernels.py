@@ -139,7 +139,12 @@ def forward_backward(batch, pc_llhs, want_xi=False, want_lognorm=False, dense_xi
         batch.struct.all_lowdeg = 0
     gamma = torch.empty(batch.n_elems, dtype=dt, device=dev)
     alpha = torch.empty(batch.n_elems, dtype=torch.float64, device=dev)
-    hub_ws = torch.empty(_hip.MAX_HUBS * batch.n_frames, dtype=torch.float64, device=dev)
+    # hub values per frame, or -- graphs too dense for the arc lists to sit in LDS --
+    # the general kernel's per-arc scratch
+    n_ws = max(_hip.MAX_HUBS * batch.n_frames,
+               _hip.lib().beer_hmm_fb_scratch_doubles(_hip.dtype_code(dt), batch.ref(),
+                                                      int(want_xi)))
+    hub_ws = torch.empty(n_ws, dtype=torch.float64, device=dev)
     xi = g0 = ln = flow = None
     if want_xi:
         if not batch.shared_graph:
@@ -158,11 +163,10 @@ def forward_backward(batch, pc_llhs, want_xi=False, want_lognorm=False, dense_xi
         st = batch.struct
         if 'invalid argument' in str(err) and not st.all_lowdeg:
             raise _hip.HipError(
-                f'forward-backward: a graph of the batch ({st.max_states} states, {st.max_arcs} '
-                'arcs) does not fit the general kernel, which keeps the whole arc list in the '
-                "CU's 160 KB of LDS (about 4000 arcs with transition posteriors, 6500 without); "
-                'sparser graphs, or graphs with at most 8 arcs per state besides a declared '
-                'hub (CompiledGraph.set_hub), run at any size') from err
+                f'forward-backward: a graph of the batch has {st.max_states} states; the general '
+                "kernel keeps five per-state arrays in the CU's 160 KB of LDS (about 4000 states). "
+                'Graphs with at most 8 arcs per state besides a declared hub '
+                '(CompiledGraph.set_hub) run at any size') from err
         raise
     batch.last_alpha = alpha              # (for `trans_posteriors_dense`)
     return gamma, xi, g0, ln, flow

@@ -468,6 +468,15 @@ int beer_hmm_forward_backward(int dtype, const beer_batch* batch_h,
                               const void* pc_llhs, double* alpha_ws, double* hub_ws,
                               void* gamma, double* xi_sum, double* gamma0_sum,
                               double* hub_flow, void* lognorm_mean, void* stream);
+/* Doubles `hub_ws` of beer_hmm_forward_backward must hold BESIDES the hub values
+ * (BEER_MAX_HUBS per frame) for this batch: 0 while the arc lists of its largest
+ * graph fit a CU's LDS (about 4000 arcs with transition posteriors in float32);
+ * beyond that the general kernel keeps its per-arc scratch there -- 2 max_arcs +
+ * max_segs doubles for each of at most 512 workgroups -- and reads the topology
+ * from the graph image, so that graphs of any density run (the reference's dense
+ * recursion, graph.py:270-326, has no size limit); only the per-state arrays
+ * stay in LDS (up to ~4000 states). */
+size_t beer_hmm_fb_scratch_doubles(int dtype, const beer_batch* batch_h, int want_xi);
 
 /* The HMM inference step of a whole shard in ONE launch, for batches whose
  * graphs all carry a `lowdeg` image with at most one hub of at most 64 sources /

@@ -814,6 +814,42 @@ def test_forward_backward_kernels_agree_with_oracle_on_long_chains(n_states):
                                   orc.best_path(llhs, init, final, trans))
 
 
+@pytest.mark.parametrize('n_states,dtype,tol', [(100, torch.float64, 1e-9), (100, torch.float32, 2e-5),
+                                               (180, torch.float64, 1e-9)])
+def test_forward_backward_on_dense_graphs_beyond_lds(n_states, dtype, tol):
+    '''An ergodic HMM with every transition present: 10 000 / 32 400 arcs, more than a
+    CU's LDS holds (the reference's dense recursion, graph.py:270-326, has no such
+    limit).  The general kernel then reads the topology from the graph image and keeps
+    its per-arc scratch in global memory; several utterances share the scratch slices.'''
+    rng = np.random.RandomState(n_states)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    trans = np.log(rng.dirichlet(np.ones(n_states) * .5, size=n_states)).astype(npdt)
+    init = np.log(rng.dirichlet(np.ones(n_states))).astype(npdt)
+    final = np.log(rng.dirichlet(np.ones(n_states))).astype(npdt)
+    lens = [37, 5, 64]
+    llhs = [(rng.randn(T, n_states) * 3).astype(npdt) for T in lens]
+    graph = beer.graph.CompiledGraph(tt(init), tt(final), tt(trans), list(range(n_states)))
+    from beer_amd import hmm_kernels as hk, _hip
+    batch = hk.HmmBatch([graph], [0] * len(lens), lens, dtype)
+    assert _hip.lib().beer_hmm_fb_scratch_doubles(_hip.dtype_code(dtype), batch.ref(), 1) > 0
+    packed = torch.cat([tt(l).reshape(-1) for l in llhs])
+    g, x, g0, ln, flow = hk.forward_backward(batch, packed, want_xi=True, want_lognorm=True)
+    g = npy(g).astype(np.float64)
+    xi_sum, gam0, off = 0., 0., 0
+    for T, l in zip(lens, llhs):
+        gam, xi, lnm = orc.posteriors(l.astype(np.float64), init.astype(np.float64),
+                                      final.astype(np.float64), trans.astype(np.float64), True)
+        assert_close(g[off:off + T * n_states].reshape(T, -1), gam, tol, 'gamma')
+        xi_sum, gam0, off = xi_sum + xi.sum(0), gam0 + gam[0], off + T * n_states
+    assert_close(npy(x), xi_sum, tol, 'xi')
+    assert_close(npy(g0), gam0, tol, 'gamma0')
+    # the model-level entry point: HMM-style posteriors of one utterance
+    post = graph.posteriors(tt(llhs[0]))[0]
+    gam, _, _ = orc.posteriors(llhs[0].astype(np.float64), init.astype(np.float64),
+                               final.astype(np.float64), trans.astype(np.float64), True)
+    assert_close(npy(post).astype(np.float64), gam, tol, 'CompiledGraph.posteriors')
+
+
 def test_hmm_batch_with_one_frame_utterances():
     g = load_golden('g04_hmm_diagonal')
     hmm = build_hmm(g)
