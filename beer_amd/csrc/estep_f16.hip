@@ -55,6 +55,7 @@ __host__ __device__ inline int ld16_of(int D) {
     const int ld = 4 * d4_of(D) + 8;
     return (ld / 4) % 2 ? ld : ld + 4;
 }
+constexpr float kConstEps = 0.00048828125f;   // 2^-11: second constant of a frame row
 constexpr int kPadBlocks = 16;         // look-ahead blocks behind the P image (a quarter k-step
                                        // of the second component half, see KS)
 
@@ -195,11 +196,12 @@ __device__ inline double entry_value(int cov, int D, int K, int k, int slab, int
 // slot % Gp < G, else padding (G <= Gp: the groups of a mixture set padded to a power
 // of two, so that any number of components per state runs on the group-aligned
 // kernels; G == Gp: slots are components).
-__global__ void pack16_kernel(int cov, int D, int K, int NT, const float* __restrict__ E,
+__global__ __launch_bounds__(1024) void pack16_kernel(int cov, int D, int K, int NT, const float* __restrict__ E,
                               const float* __restrict__ logw, const float* __restrict__ sc,
                               _Float16* __restrict__ P, float* __restrict__ inv_scale,
                               int* __restrict__ tab, int G = 1, int Gp = 1) {
-    __shared__ double red[8];
+    __shared__ double red[16];
+    extern __shared__ __attribute__((aligned(16))) char pack_lds[];
     const int nk = nk16_of(cov, D), nent = nk * 32;
     const int slot = blockIdx.x;
     const int k = slot % Gp < G ? (slot / Gp) * G + slot % Gp : K;     // K: a padded slot
@@ -208,7 +210,7 @@ __global__ void pack16_kernel(int cov, int D, int K, int NT, const float* __rest
     const float* isx = sc + 64;
     if (slot == 0)
         for (int s = threadIdx.x; s < (nk + 1) * 8; s += blockDim.x) {
-            // padding slabs read the zero columns behind the "1" of a frame row
+            // padding slabs read the zero columns behind the constants of a frame row
             const int Dp = 4 * d4_of(D);
             tab[s] = s < nslab_of(cov, D) ? slab_entry(cov, D, s) : ((Dp + 1) | ((Dp + 4) << 8));
         }
@@ -226,7 +228,59 @@ __global__ void pack16_kernel(int cov, int D, int K, int NT, const float* __rest
         scale = ldexp(1.0, kColBits - e);
     }
     if (threadIdx.x == 0) inv_scale[slot] = k < K ? (float)(1.0 / scale) : 1.0e30f;
+
+    // The component's own first and second moments, for the compensation below:
+    // mu = E[Lambda]^-1 E[Lambda mu], Sigma = E[Lambda]^-1, from the expected
+    // statistics themselves (E = [Lambda mu, -Lambda / 2, ...]).
+    const int Dp = 4 * d4_of(D), Q = stats_dim(cov, D);
+    double* S2 = reinterpret_cast<double*>(pack_lds);        // full: Sigma [D, D]; else var [D]
+    double* mu = S2 + (cov == BEER_FULL ? D * D : D);
+    double* cr = mu + D;                                     // 2 D (spd_inverse scratch)
+    if (k < K) {
+        const float* row = E + (size_t)k * Q;
+        if (cov == BEER_FULL) {
+            for (int idx = threadIdx.x; idx < D * D; idx += blockDim.x) {
+                const int a = idx / D, b = idx - a * D;
+                S2[idx] = -((double)row[D + a * D + b] + (double)row[D + b * D + a]);
+            }
+            spd_inverse(S2, D, cr, true);
+            for (int a = threadIdx.x; a < D; a += blockDim.x) {
+                double m = 0.0;
+                for (int b = 0; b < D; ++b) m += S2[a * D + b] * (double)row[b];
+                mu[a] = m;
+            }
+        } else {
+            for (int b = threadIdx.x; b < D; b += blockDim.x) {
+                const double lam = -2.0 * (double)row[cov == BEER_ISO ? D : D + b];
+                S2[b] = 1.0 / lam;
+                mu[b] = (double)row[b] / lam;
+            }
+        }
+    }
+    __syncthreads();
+    // E[phi~_q(x s)] of entry q under N(mu, Sigma): what the entry multiplies on average
+    // over the frames the component explains (s = the frame scales)
+    auto expect = [&](int slab, int e) -> double {
+        if (slab >= nslab_of(cov, D)) return 0.0;
+        const int t = slab_entry(cov, D, slab);
+        const int a = t & 0xff, b = ((t >> 8) & 0xff) + e, sq = t >> 16;
+        if (sq) return b < D ? (mu[b] * mu[b] + S2[b]) * (double)sc[b] * (double)sc[b] : 0.0;
+        if (a < D) {
+            if (b >= D || b < a) return 0.0;
+            return (mu[a] * mu[b] + S2[a * D + b]) * (double)sc[a] * (double)sc[b];
+        }
+        if (a == Dp && b - e == Dp) return 0.0;              // the constant: handled below
+        return b < D ? mu[b] * (double)sc[b] : 0.0;
+    };
     _Float16* base = P + ((size_t)chunk * nk * NT) * 1024;
+    auto put = [&](int q, _Float16 hi, _Float16 lo) {
+        const int s = q / 32, g = (q % 32) / 8, j = q % 8;
+        _Float16* dst = base + ((size_t)s * NT + c) * 1024 + (g * 16 + i) * 8 + j;
+        dst[0] = hi;
+        dst[512] = lo;
+    };
+    double bias = 0.0, cs = 0.0;
+    int qc = -1;                                              // the constant's entry (e = 0)
     for (int q = threadIdx.x; q < nent; q += blockDim.x) {
         bool is_const;
         double v = entry_value(cov, D, K, k, q / 4, q % 4, E, logw, isx, &is_const) * scale;
@@ -234,11 +288,44 @@ __global__ void pack16_kernel(int cov, int D, int K, int NT, const float* __rest
         const float vf = (float)v;
         const _Float16 hi = (_Float16)vf;
         const _Float16 lo = (_Float16)(vf - (float)hi);
-        const int s = q / 32, g = (q % 32) / 8, j = q % 8;
-        _Float16* dst = base + ((size_t)s * NT + c) * 1024 + (g * 16 + i) * 8 + j;
-        dst[0] = hi;
-        dst[512] = lo;
+        // (the constant and its remainder entry are written once, below)
+        bool const_slab = false;
+        if (k < K && q / 4 < nslab_of(cov, D)) {
+            const int t = slab_entry(cov, D, q / 4);
+            const_slab = (t & 0xff) == Dp && ((t >> 8) & 0xff) == Dp && (t >> 16) == 0;
+        }
+        if (!(const_slab && q % 4 < 2)) put(q, hi, lo);
+        if (is_const) { qc = q; cs = v; }
+        else if (k < K && v != 0.0) bias += ((double)hi + (double)lo - v) * expect(q / 4, q % 4);
     }
+    // Compensation of the image's own rounding.  An entry carries 22 bits; its error is
+    // the same for every frame, so over the frames of the component the logit is off by
+    // sum_q err_q E[phi_q] -- a bias that does not average out in the statistics
+    // (measured 1e-5 .. 7e-5 of the counts).  It is known here: subtract it from the
+    // constant, which gets 22 more bits for the purpose -- the frame rows carry 2^-11
+    // next to their 1, and the constant slab's second entry holds the remainder * 2^11.
+    bias = block_sum(bias, red);
+    if (qc >= 0 && k < K) {
+        const double want = (bias == bias && fabs(bias) < 1.0) ? cs - bias : cs;
+        const float vf = (float)want;
+        const _Float16 hi = (_Float16)vf;
+        const _Float16 lo = (_Float16)((float)(want - (double)hi));
+        const double rem = (want - (double)hi - (double)lo) * (1.0 / (double)kConstEps);
+        const bool ok = want == want && fabs(want) < 65000.0;        // (-inf weight: as is)
+        const float rf = ok ? (float)rem : 0.f;
+        const _Float16 h1 = (_Float16)rf;
+        put(qc, hi, lo);
+        put(qc + 1, h1, (_Float16)(rf - (float)h1));
+    }
+}
+
+// One workgroup per component; full covariance inverts a D x D matrix in it, which is
+// pure latency: 1024 threads while there is about one matrix per CU (cf. nw_threads)
+inline int pack16_threads(int cov, int D, int slots) {
+    return cov == BEER_FULL && D >= 16 && slots <= 512 ? 1024 : 256;
+}
+inline size_t pack16_lds(int cov, int D) {
+    return (size_t)((cov == BEER_FULL ? D * D : D) + 3 * D) * sizeof(double);
 }
 
 // v = hi + lo with hi = fp16(v), lo = fp16(v - hi), both round-to-nearest
@@ -352,7 +439,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
         for (int idx = part * 64 + lane; idx < FW * 2; idx += 64 * KS) {
             const int r = idx >> 1, h = idx & 1;
             *reinterpret_cast<f32x4*>(xw + r * LD + D + 4 * h) =
-                f32x4{h == 0 ? 1.f : 0.f, 0.f, 0.f, 0.f};
+                f32x4{h == 0 ? 1.f : 0.f, h == 0 ? kConstEps : 0.f, 0.f, 0.f};
         }
     } else {
         for (int idx = part * 64 + lane; idx < FW * LD; idx += 64 * KS) {
@@ -361,6 +448,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
             float v = 0.f;
             if (c < D) { if (f < nframes) v = X[f * D + c] * sc[c]; }
             else if (c == Dp) v = 1.f;
+            else if (c == Dp + 1) v = kConstEps;
             xw[idx] = v;
         }
     }
@@ -1536,7 +1624,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
     {   // constant rows / columns, once
         for (int r = lane; r < FW; r += 64)
 #pragma unroll 1
-            for (int c = D; c < LD; ++c) xw[r * LD + c] = c == Dp ? 1.f : 0.f;
+            for (int c = D; c < LD; ++c)
+                xw[r * LD + c] = c == Dp ? 1.f : (c == Dp + 1 ? kConstEps : 0.f);
         for (int f = lane; f < kAfXS; f += 64) {
             xt[D * kAfXS + f] = 1.f;
             xt[(D + 1) * kAfXS + f] = 0.f;
@@ -1997,7 +2086,7 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
     float* sc = reinterpret_cast<float*>(w + 256);
     const int rc = launch_scales(X, nframes, D, absmax, sc, s);
     if (rc != BEER_OK) return rc;
-    hipLaunchKernelGGL(pack16_kernel, dim3(kpad), dim3(256), 0, s, cov, D, Kreal, NT, expT, logw, sc,
+    hipLaunchKernelGGL(pack16_kernel, dim3(kpad), dim3(pack16_threads(cov, D, kpad)), pack16_lds(cov, D), s, cov, D, Kreal, NT, expT, logw, sc,
                        P, inv_scale, tab, Greal, G);
     BEER_LAUNCH_CHECK();
 #define BEER_LLH16(NT_, MT_, GQ_)                                                                \
@@ -2292,7 +2381,7 @@ int acc_fused_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* 
     if (e != hipSuccess) return -(int)e;
     const int rc = launch_scales(X, nframes, D, absmax, sc, s);
     if (rc != BEER_OK) return rc;
-    hipLaunchKernelGGL(pack16_kernel, dim3(kpad), dim3(256), 0, s, cov, D, Kreal, NTC, expT, logw,
+    hipLaunchKernelGGL(pack16_kernel, dim3(kpad), dim3(pack16_threads(cov, D, kpad)), pack16_lds(cov, D), s, cov, D, Kreal, NTC, expT, logw,
                        sc, P, inv_scale, tab, Greal, G);
     BEER_LAUNCH_CHECK();
     // waves per workgroup: 8 (two per SIMD) with 64-component chunks, 4 with 128

@@ -28,53 +28,7 @@ constexpr int kMaxFullDim = 128;   // D*D fp64 must fit one CU's 160 KiB LDS
 // row-major fp64 in LDS).
 // ---------------------------------------------------------------------------
 
-// In-place inverse of the SPD matrix A by Gauss-Jordan elimination without
-// pivoting (backward stable for SPD matrices); returns log|A| = sum of the log
-// pivots (all threads).  Two barriers per column and D*D / nt entry updates per
-// thread and column -- against a Cholesky factorisation plus a triangular
-// inverse whose substitution runs D*D / 2 dependent LDS reads deep in ONE thread
-// per column (76 -> ~20 us per launch at D = 40: these kernels are pure latency,
-// one workgroup per matrix).  `cr` = LDS scratch of 2 D doubles.  With
-// `want_inverse` false only the trailing (Schur) updates are made: log|A| alone.
-__device__ double spd_inverse(double* A, int D, double* cr, bool want_inverse) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    double* col = cr;
-    double* row = cr + D;
-    const int i0 = tid / D, k0 = tid - i0 * D, di = nt / D, dk = nt - di * D;
-    double mant = 1.0;                      // log|A| = log(mant) + expo * log 2
-    int expo = 0;
-    for (int j = 0; j < D; ++j) {
-        __syncthreads();
-        const double p = A[j * D + j], ip = 1.0 / p;
-        int e;
-        mant *= frexp(p, &e);
-        expo += e;
-        if ((j & 31) == 31) { mant = frexp(mant, &e); expo += e; }
-        // log|A| alone: the lower triangle is enough (column j serves as row j)
-        for (int i = tid; i < D; i += nt) {
-            col[i] = A[i * D + j];
-            row[i] = (want_inverse ? A[j * D + i] : A[i * D + j]) * ip;
-        }
-        __syncthreads();
-        int i = i0, k = k0;
-        for (int idx = tid; idx < D * D; idx += nt) {
-            if (want_inverse) {
-                double v;
-                if (i == j) v = (k == j) ? ip : row[k];
-                else if (k == j) v = -col[i] * ip;
-                else v = A[idx] - col[i] * row[k];
-                A[idx] = v;
-            } else if (k > j && k <= i) {
-                A[idx] -= col[i] * row[k];
-            }
-            i += di;
-            k += dk;
-            if (k >= D) { k -= D; ++i; }
-        }
-    }
-    __syncthreads();
-    return log(mant) + (double)expo * 0.69314718055994530942;
-}
+// (spd_inverse: common.h -- also used when the E-step packs its parameters)
 
 // ---------------------------------------------------------------------------
 // Normal-Wishart

@@ -167,9 +167,13 @@ def _mixture_batch(model, X, lengths, datasize, labels, max_frames):
         f0, f1 = int(off[run[0]]), int(off[run[-1] + 1])
         stats = FrameStats(X[f0:f1], cov)
         lab = None if lab_dev is None else lab_dev[f0:f1]
+        wide = kernels.wide_mixture_split(stats, K, cov) if lab is None else None
         if lab is None and kernels.packed_path_ok(stats, K, cov):
             # responsibilities go to the accumulation already split for its fp16 products
             log_norm, resps = kernels.mixture_estep_packed(stats, exp_T, lw, K, cov)
+        elif wide:
+            # K > 256: blocks of components on the mixture-set kernels, two-level softmax
+            log_norm, resps = kernels.wide_mixture_estep(stats, exp_T, lw, K, cov, wide)
         else:
             log_norm, resps = kernels.mixtureset_estep(stats, exp_T, lw, 1, K, cov, labels=lab)
         seg = off_dev[run[0]:run[-1] + 2] - f0

@@ -172,6 +172,67 @@ def mixtureset_estep_packed(stats, exp_stats, log_weights, S, G, cov_type, llh_s
     return log_norm, PackedResps(words, T, K)
 
 
+# ---- one mixture with more than 256 components ---------------------------------------------
+
+class WideResps:
+    '''Responsibilities [T, K] of ONE mixture with more than 256 components, in the
+    factored form the matrix-core kernels of a mixture set work with: the
+    components are cut into S2 blocks of G2; `block_lse` [T, S2] are the blocks'
+    log-sum-exps, `block_resps` [T, S2] = exp(block_lse - log_norm) the blocks' shares,
+    and within a block r = exp(l - block_lse) is recomputed from the frames
+    (diagonal / isotropic) or held as packed tiles (full covariance).  The softmax
+    over K components is the two-level softmax of these.  `dense()` gives the
+    [T, K] matrix.'''
+
+    def __init__(self, stats, exp_stats, log_weights, split, cov_type, block_lse, block_resps,
+                 packed):
+        self.stats, self.exp_stats, self.log_weights = stats, exp_stats, log_weights
+        self.split, self.cov_type = split, cov_type
+        self.block_lse, self.block_resps, self.packed = block_lse, block_resps, packed
+
+    def dense(self):
+        S2, G2 = self.split
+        within = self.packed.unpack() if self.packed is not None else mixtureset_estep(
+            self.stats, self.exp_stats, self.log_weights, S2, G2, self.cov_type)[1]
+        return within * self.block_resps.repeat_interleave(G2, dim=1)
+
+
+def wide_mixture_split(stats, K, cov_type):
+    '''(S2, G2), K = S2 * G2, when a mixture of K > 256 components over `stats` runs
+    on the matrix-core kernels as S2 blocks of G2 components (two-level softmax);
+    None otherwise (the generic kernels take it).'''
+    st = _frames(stats)
+    X = st.data
+    if K <= 256 or st.scale != 1.0 or X.dtype != torch.float32 or not _hip.f32_split_ok(X):
+        return None
+    first = -(-K // 256)
+    for S2 in range(first, min(K // 8, first + 64) + 1):
+        if K % S2:
+            continue
+        G2 = K // S2
+        ok = packed_sets_ok(st, S2, G2, cov_type) if cov_type == 'full' else \
+            fused_accumulate_ok(st, S2, G2, cov_type)
+        if ok:
+            return S2, G2
+    return None
+
+
+def wide_mixture_estep(stats, exp_stats, log_weights, K, cov_type, split):
+    '''(log_norm [T, 1], WideResps) of one mixture over `split` = wide_mixture_split(...):
+    Mixture.expected_log_likelihood (beer/models/mixture.py:70-93) for K > 256.'''
+    S2, G2 = split
+    st = _frames(stats)
+    E = _hip.on_device(exp_stats, st.data.dtype)
+    lw = _hip.on_device(log_weights, st.data.dtype).reshape(S2, G2)
+    packed = None
+    if cov_type == 'full':
+        lse, packed = mixtureset_estep_packed(st, E, lw, S2, G2, cov_type)
+    else:
+        lse, _ = mixtureset_estep(st, E, lw, S2, G2, cov_type, want_resps=False)
+    log_norm, share = dense_softmax(lse, None, 1, S2)
+    return log_norm, WideResps(st, E, lw, split, cov_type, lse, share, packed)
+
+
 def pack_resps(stats, comp_resps, state_resps, S, G):
     '''PackedResps of float32 responsibilities [T, S*G] (times `state_resps`
     [T, S] broadcast over each state's G components).'''
@@ -214,6 +275,16 @@ def normal_accumulate(stats, comp_resps, state_resps, S, G, cov_type, acc=None):
     Q = st.shape[1]
     if acc is None:
         acc = torch.zeros(K, Q, dtype=torch.float64, device=X.device)
+    if isinstance(comp_resps, WideResps):
+        # one mixture, K > 256: the blocks' shares play the state posteriors' part
+        wr = comp_resps
+        S2, G2 = wr.split
+        if state_resps is not None or S2 * G2 != K or wr.stats.data.data_ptr() != X.data_ptr():
+            raise ValueError('factored responsibilities: one mixture, the frames they came from')
+        if wr.packed is not None:
+            return normal_accumulate(st, wr.packed, wr.block_resps, S2, G2, cov_type, acc=acc)
+        return mixtureset_accumulate_fused(st, wr.exp_stats, wr.log_weights, wr.block_lse,
+                                           wr.block_resps, S2, G2, cov_type, acc=acc)
     if isinstance(comp_resps, PackedResps) and state_resps is not None:
         # mixture set: the state posteriors are multiplied in by the kernel
         if tuple(comp_resps.shape) != (T, K) or not packed_sets_ok(st, S, G, cov_type):

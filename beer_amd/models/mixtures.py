@@ -75,9 +75,17 @@ class Mixture(DiscreteLatentModel):
         K = len(ns)
         if kernels.is_dense(stats):
             return self._dense_expected_log_likelihood(stats, labels)
-        log_norm, resps = kernels.mixtureset_estep(
-            stats, ns.means_precisions.natural_form(), self._log_weights().view(1, K),
-            1, K, ns.cov_type, labels=labels)
+        wide = kernels.wide_mixture_split(stats, K, ns.cov_type) if labels is None else None
+        if wide:
+            # more than 256 components: blocks on the matrix cores, two-level softmax;
+            # the cache holds the factored responsibilities (`.dense()` -> [T, K])
+            log_norm, resps = kernels.wide_mixture_estep(
+                stats, ns.means_precisions.natural_form(), self._log_weights().view(1, K), K,
+                ns.cov_type, wide)
+        else:
+            log_norm, resps = kernels.mixtureset_estep(
+                stats, ns.means_precisions.natural_form(), self._log_weights().view(1, K),
+                1, K, ns.cov_type, labels=labels)
         self.cache['resps'] = resps
         return log_norm.view(-1)
 

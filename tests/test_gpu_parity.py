@@ -452,13 +452,16 @@ def _oracle_gmm_chunked(Xn, cov, post, prior, w_post, w_prior, chunk=8192):
     return dict(value=per_frame - kl, acc_normal=acc_n, acc_weights=acc_w, kl=kl)
 
 
-# Statistics / posterior band of the split arithmetic at these shapes: the packed
-# parameter image carries 22 bits per entry (two fp16 halves), and its rounding is
-# the same for every frame of a component -- a bias of ~1e-5 in the component's
-# logits that does not average out (measured 1.0e-5 .. 1.2e-5 on the worst
-# entries of the statistics, 1.5e-5 on the updated posterior).  The exact-fp32 mode (below) is held to the
-# reference's own float32 error.
-SPLIT_STATS_BAND = 2e-5
+# Statistics / posterior band of the split arithmetic at these shapes.  An entry of the
+# packed parameter image carries 22 bits (two fp16 halves) and its rounding is the same
+# for every frame of a component: a bias in the component's logits that does not average
+# out over frames.  The packing kernel compensates it to first order (the bias at the
+# component's own moments goes into the constant, which carries 22 more bits for the
+# purpose: DESIGN.md section 8) -- 1.0e-5 .. 1.5e-5 on the worst statistics before,
+# within north_star's 1e-5 at the bench shape now; with diagonal covariances the worst
+# entry of the updated means sits at 1.07e-5.  The exact-fp32 mode (below) is held to
+# 1e-5 or the reference's own float32 error.
+SPLIT_STATS_BAND = {'full': 1e-5, 'diagonal': 1.5e-5}
 
 
 @pytest.mark.parametrize('cov,K', [('full', 256), ('diagonal', 256), ('full', 160)])
@@ -513,9 +516,9 @@ def test_bench_kernel_variant_vs_oracle(cov, K):
     assert_close(float(elbo), truth['value'], 1e-5, 'elbo')
     acc = npy(elbo._acc_stats[p0]).astype(np.float64)
     assert_within_f32_band(acc, truth['acc_normal'], ref32['acc_normal'], 'acc normal',
-                           SPLIT_STATS_BAND)
+                           SPLIT_STATS_BAND[cov])
     assert_within_f32_band(npy(elbo._acc_stats[p1]).astype(np.float64), truth['acc_weights'],
-                           ref32['acc_weights'], 'acc weights', SPLIT_STATS_BAND)
+                           ref32['acc_weights'], 'acc weights', SPLIT_STATS_BAND[cov])
     elbo.backward()
     optim.step()
     new_post, new_w = orc.gmm_mstep(cov, post, prior, w_post, w_prior, truth['acc_normal'],
@@ -527,10 +530,10 @@ def test_bench_kernel_variant_vs_oracle(cov, K):
     for n, ref, r32 in zip(p0.posterior._std_params_def, new_post, ref_post):
         got = npy(getattr(p0.posterior.params, n)).astype(np.float64)
         assert_within_f32_band(got.reshape(ref.shape), ref, r32.reshape(ref.shape), 'posterior ' + n,
-                               SPLIT_STATS_BAND)
+                               SPLIT_STATS_BAND[cov])
     assert_within_f32_band(
         npy(p1.posterior.params.concentrations).astype(np.float64).reshape(new_w.shape), new_w,
-        ref_w.reshape(new_w.shape), 'posterior weights', SPLIT_STATS_BAND)
+        ref_w.reshape(new_w.shape), 'posterior weights', SPLIT_STATS_BAND[cov])
     # the same step on the exact fp32 MFMA: within 1e-5, or the reference's own fp32 error
     from beer_amd import _hip
     torch.manual_seed(7)
@@ -774,6 +777,62 @@ def test_gmm_matrix_core_path_all_cov_types_vs_oracle(cov, dtype, tol, K, D):
     assert_close(float(elbo), truth['value'], tol, 'elbo')
     assert_close(npy(elbo._acc_stats[p0]), truth['acc_normal'], tol * 5, 'acc normal')
     assert_close(npy(elbo._acc_stats[p1]), truth['acc_weights'], tol * 5, 'acc weights')
+
+
+@pytest.mark.parametrize('cov,K,D,split', [('full', 512, 40, (4, 128)), ('diagonal', 512, 40, (2, 256)),
+                                            ('full', 320, 24, (5, 64)), ('diagonal', 500, 30, (2, 250)),
+                                            ('isotropic', 768, 16, (3, 256))])
+def test_gmm_with_more_than_256_components_on_the_matrix_cores(cov, K, D, split):
+    '''A float32 mixture of K > 256 components runs as blocks of components on the
+    mixture-set kernels with a two-level softmax (kernels.wide_mixture_estep), through
+    both entry points -- evidence_lower_bound and accumulate_elbo -- against the
+    numpy oracle: Mixture.expected_log_likelihood / accumulate, mixture.py:70-101.'''
+    from beer_amd import kernels
+    T = 17000
+    rng = np.random.RandomState(K + D)
+    means = rng.randn(K, D) * 2
+    Xn = (means[rng.randint(0, K, T)] + rng.randn(T, D) * (1 + .3 * rng.rand(D))).astype(np.float32)
+    X = torch.from_numpy(Xn)
+    torch.manual_seed(5)
+    var = X.var(0) if cov != 'full' else torch.diag(X.var(0))
+    ns = beer.NormalSet.create(X.mean(0), var, size=K, prior_strength=1., noise_std=1.,
+                               cov_type=cov)
+    model = beer.Mixture.create(ns).to(DEV)
+    p0, p1 = params_of(model)
+    as64 = lambda d: [npy(getattr(d.params, n)).astype(np.float64) for n in d._std_params_def]
+    post, prior = as64(p0.posterior), as64(p0.prior)
+    (w_post,), (w_prior,) = as64(p1.posterior), as64(p1.prior)
+    truth = orc.gmm_elbo_step(Xn.astype(np.float64), cov, post, prior, w_post, w_prior)
+    f32 = lambda arrs: [a.astype(np.float32) for a in arrs]
+    ref32 = orc.gmm_elbo_step(Xn, cov, f32(post), f32(prior), w_post.astype(np.float32),
+                              w_prior.astype(np.float32))
+    # ~30 frames per component here: a statistic is the sum of a few responsibilities,
+    # each carrying the split arithmetic's logit error (DESIGN.md section 8) -- 3e-5 on
+    # the worst entry, where the bench shape (256 frames per component) averages to 1e-5
+    band = 4e-5
+    assert kernels.wide_mixture_split(beer.FrameStats(X.to(DEV), cov), K, cov) == split
+    taken = []
+    orig = kernels.wide_mixture_estep
+    kernels.wide_mixture_estep = lambda *a, **k: (taken.append(1), orig(*a, **k))[1]
+    try:
+        elbo = beer.evidence_lower_bound(model, X.to(DEV))
+        batched = beer.accumulate_elbo(model, (X.to(DEV), [T]), datasize=T)
+    finally:
+        kernels.wide_mixture_estep = orig
+    assert len(taken) == 2
+    for e in (elbo, batched):
+        assert_close(float(e), truth['value'], 1e-5, 'elbo')
+        assert_within_f32_band(npy(e._acc_stats[p0]).astype(np.float64), truth['acc_normal'],
+                               ref32['acc_normal'], 'acc normal', band)
+        assert_within_f32_band(npy(e._acc_stats[p1]).astype(np.float64), truth['acc_weights'],
+                               ref32['acc_weights'], 'acc weights', band)
+    # the factored responsibilities as a matrix
+    st = beer.FrameStats(X.to(DEV), cov)
+    _, wr = kernels.wide_mixture_estep(st, p0.natural_form(), model._log_weights().view(1, K), K,
+                                       cov, split)
+    r = npy(wr.dense()).astype(np.float64)
+    assert np.abs(r.sum(1) - 1).max() < 5e-5
+    assert np.abs(r - truth['resps']).max() < 2e-4
 
 
 def _chain_graph(n_states, rng, dtype):
