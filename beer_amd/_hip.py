@@ -127,8 +127,9 @@ SIGNATURES = {
                               c_p, c_p, c_p, c_p, c_p, c_z, c_p],
     'beer_normal_accumulate': [c_i, c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_z,
                                c_p],
-    'beer_mixture_estep_packed': [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_z,
-                                  c_p],
+    'beer_mixture_estep_packed': [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                  c_z, c_p],
+    'beer_frame_scales': [c_l, c_i, c_p, c_p, c_p, c_p],
     'beer_normal_accumulate_packed': [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_z, c_p],
     'beer_mixtureset_estep_packed': [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                      c_z, c_p],
@@ -309,6 +310,28 @@ def f32_split_ok(X):
         flag = torch.empty(1, dtype=torch.int32, device=X.device)
         call('beer_f32_split_hazard', X.shape[0], X.shape[1], ptr(X), ptr(scratch), ptr(flag))
         hit = int(flag.item()) == 0
+        if len(memo[1]) > 256:
+            memo[1].clear()
+        memo[1][key] = hit
+    return hit
+
+
+def frame_scales(X):
+    '''The split arithmetic's per-dimension scales of float32 frames `X` [T, D]
+    (`beer_frame_scales`: [128] float32 on the device), computed once per tensor
+    version and remembered on the tensor like the range check above -- the frames
+    of a training run are the same in every VB iteration.'''
+    owner = _range_owner(X)
+    memo = owner.__dict__.get('_beer_scales_memo')
+    if memo is None or memo[0] != owner._version:
+        memo = (owner._version, {})
+        owner.__dict__['_beer_scales_memo'] = memo
+    key = (X.storage_offset(), tuple(X.shape), tuple(X.stride()))
+    hit = memo[1].get(key)
+    if hit is None:
+        hit = torch.empty(128, dtype=torch.float32, device=X.device)
+        scratch = torch.empty(256, dtype=torch.uint8, device=X.device)
+        call('beer_frame_scales', X.shape[0], X.shape[1], ptr(X), ptr(hit), ptr(scratch))
         if len(memo[1]) > 256:
             memo[1].clear()
         memo[1][key] = hit

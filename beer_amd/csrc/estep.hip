@@ -515,10 +515,16 @@ int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G, c
                   state_resps, acc, workspace, workspace_bytes, stream, exact);
 }
 
+int beer_frame_scales(int64_t T, int D, const float* X, float* scales, void* scratch,
+                      void* stream) {
+    BEER_REQUIRE(T >= 0 && D >= 1 && D <= 64 && scales && scratch && (X || T == 0));
+    return beer_mfma::frame_scales(T, D, X, scales, scratch, as_stream(stream));
+}
+
 int beer_mixture_estep_packed(int cov, int64_t T, int D, int K, const float* X,
                               const float* exp_stats, const float* log_weights, float* log_norm,
-                              void* packed_resps, double* llh_sum, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+                              void* packed_resps, double* llh_sum, const float* frame_scales,
+                              void* workspace, size_t workspace_bytes, void* stream) {
     BEER_REQUIRE(T >= 0 && D >= 1 && K >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(X && exp_stats && log_weights && packed_resps && workspace);
     BEER_REQUIRE(beer_mfma::supported_llh(D, 1, K));
@@ -526,7 +532,8 @@ int beer_mixture_estep_packed(int cov, int64_t T, int D, int K, const float* X,
     if (T == 0) return BEER_OK;
     return beer_mfma::estep_f16x3(cov, T, D, 1, K, X, exp_stats, log_weights,
                                   reinterpret_cast<float*>(packed_resps), log_norm, llh_sum,
-                                  workspace, workspace_bytes, as_stream(stream), true);
+                                  workspace, workspace_bytes, as_stream(stream), true,
+                                  frame_scales);
 }
 
 int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float* X,

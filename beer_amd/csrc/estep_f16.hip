@@ -2049,6 +2049,12 @@ int unpack_resps(int64_t nframes, int K, const void* packed, float* resps, hipSt
     return BEER_OK;
 }
 
+int frame_scales(int64_t nframes, int D, const float* X, float* scales, void* scratch,
+                 hipStream_t s) {
+    if (D < 1 || D > 64 || nframes < 0) return BEER_EINVAL;
+    return launch_scales(X, nframes, D, reinterpret_cast<unsigned*>(scratch), scales, s);
+}
+
 size_t estep16_workspace_bytes(int cov, int D, int S, int G) {
     if (!supported_llh_padded(D, S, G)) return 0;
     if (S > 1) G = group_pad(G);
@@ -2061,7 +2067,7 @@ size_t estep16_workspace_bytes(int cov, int D, int S, int G) {
 
 int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, const float* expT,
                 const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
-                size_t ws_bytes, hipStream_t s, bool packed) {
+                size_t ws_bytes, hipStream_t s, bool packed, const float* given_scales) {
     if (packed && S != 1 && !supported_llh_packed_sets(cov, D, S, G)) return BEER_EINVAL;
     if (!supported_llh_padded(D, S, G) || ws_bytes < estep16_workspace_bytes(cov, D, S, G))
         return BEER_EINVAL;
@@ -2083,9 +2089,13 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
     int* tab = reinterpret_cast<int*>(w);
     w += up256((size_t)(nk + 1) * 8 * sizeof(int));
     unsigned* absmax = reinterpret_cast<unsigned*>(w);
-    float* sc = reinterpret_cast<float*>(w + 256);
-    const int rc = launch_scales(X, nframes, D, absmax, sc, s);
-    if (rc != BEER_OK) return rc;
+    const float* sc = given_scales;               // the caller's (frame_scales), or made here
+    if (!sc) {
+        float* mine = reinterpret_cast<float*>(w + 256);
+        const int rc = launch_scales(X, nframes, D, absmax, mine, s);
+        if (rc != BEER_OK) return rc;
+        sc = mine;
+    }
     hipLaunchKernelGGL(pack16_kernel, dim3(kpad), dim3(pack16_threads(cov, D, kpad)), pack16_lds(cov, D), s, cov, D, Kreal, NT, expT, logw, sc,
                        P, inv_scale, tab, Greal, G);
     BEER_LAUNCH_CHECK();

@@ -24,7 +24,12 @@ bool supported_llh_split(int D, int S, int G);
 // image the accumulation kernel consumes (estep_tiles.h: softmax_epilogue<PACKED>).
 int estep_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
                 const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
-                size_t ws_bytes, hipStream_t s, bool packed = false);
+                size_t ws_bytes, hipStream_t s, bool packed = false,
+                const float* given_scales = nullptr);
+// The per-dimension frame scales of the split arithmetic (64 scales, 64 inverses) on
+// their own: a caller that runs many E-steps over the same frames computes them once
+// and hands them to estep_f16x3 (`given_scales`).  scratch >= 256 bytes.
+int frame_scales(int64_t T, int D, const float* X, float* scales, void* scratch, hipStream_t s);
 
 // 1 in *hazard (device) when the split path would lose accuracy on these frames
 // (a dimension whose maximum is > 2^9 times its mean magnitude); scratch >= 768 B.

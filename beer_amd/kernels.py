@@ -131,7 +131,7 @@ def mixture_estep_packed(stats, exp_stats, log_weights, K, cov_type, llh_sum=Non
                                   _hip.COV_CODE[cov_type], D, 1, K, X.device)
     _hip.call('beer_mixture_estep_packed', _hip.COV_CODE[cov_type], T, D, K, _hip.ptr(X),
               _hip.ptr(E), _hip.ptr(lw), _hip.ptr(log_norm), _hip.ptr(words), _hip.ptr(llh_sum),
-              _hip.ptr(ws), ws_bytes)
+              _hip.ptr(_hip.frame_scales(X)), _hip.ptr(ws), ws_bytes)
     return log_norm, PackedResps(words, T, K)
 
 

@@ -272,7 +272,17 @@ size_t beer_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int K);
 int beer_mixture_estep_packed(int cov, int64_t T, int D, int K, const float* X,
                               const float* exp_stats, const float* log_weights,
                               float* log_norm, void* packed_resps, double* llh_sum,
-                              void* workspace, size_t workspace_bytes, void* stream);
+                              const float* frame_scales, void* workspace,
+                              size_t workspace_bytes, void* stream);
+/* The per-dimension frame scales of the split arithmetic -- 128 floats: 64 powers
+ * of two s_d with |x_d s_d| < 2^7 over all T frames, then their 64 inverses -- as
+ * the E-step computes them with one pass over X at the start of every call.  The
+ * frames of a VB training run do not change between iterations: a caller computes
+ * the scales once per shard and passes them as `frame_scales` (NULL: the call
+ * makes them itself, in its workspace).  `scratch` >= 256 bytes.  No reference
+ * counterpart (the reference multiplies in float32). */
+int beer_frame_scales(int64_t T, int D, const float* X, float* scales, void* scratch,
+                      void* stream);
 int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float* X,
                                   const void* packed_resps, double* acc,
                                   void* workspace, size_t workspace_bytes,
