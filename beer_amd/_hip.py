@@ -108,6 +108,7 @@ SIGNATURES = {
     'beer_nw_expected_stats': _four, 'beer_nw_log_norm': _four, 'beer_nw_natural': _four,
     'beer_nw_from_natural': _from,
     'beer_nw_expected_stats_log_norm': [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'beer_nw_update': [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     'beer_ng_expected_stats': _four, 'beer_ng_log_norm': _four, 'beer_ng_natural': _four,
     'beer_ng_from_natural': _from,
     'beer_ing_expected_stats': _four, 'beer_ing_log_norm': _four, 'beer_ing_natural': _four,
@@ -128,11 +129,11 @@ SIGNATURES = {
     'beer_normal_accumulate': [c_i, c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_z,
                                c_p],
     'beer_mixture_estep_packed': [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
-                                  c_z, c_p],
+                                  c_p, c_z, c_p],
     'beer_frame_scales': [c_l, c_i, c_p, c_p, c_p, c_p],
     'beer_normal_accumulate_packed': [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_z, c_p],
     'beer_mixtureset_estep_packed': [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
-                                     c_z, c_p],
+                                     c_p, c_z, c_p],
     'beer_mixtureset_accumulate_packed': [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_z,
                                           c_p],
     'beer_unpack_resps': [c_l, c_i, c_p, c_p, c_p],

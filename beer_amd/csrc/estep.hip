@@ -524,7 +524,8 @@ int beer_frame_scales(int64_t T, int D, const float* X, float* scales, void* scr
 int beer_mixture_estep_packed(int cov, int64_t T, int D, int K, const float* X,
                               const float* exp_stats, const float* log_weights, float* log_norm,
                               void* packed_resps, double* llh_sum, const float* frame_scales,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+                              const float* moments, void* workspace, size_t workspace_bytes,
+                              void* stream) {
     BEER_REQUIRE(T >= 0 && D >= 1 && K >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(X && exp_stats && log_weights && packed_resps && workspace);
     BEER_REQUIRE(beer_mfma::supported_llh(D, 1, K));
@@ -533,7 +534,7 @@ int beer_mixture_estep_packed(int cov, int64_t T, int D, int K, const float* X,
     return beer_mfma::estep_f16x3(cov, T, D, 1, K, X, exp_stats, log_weights,
                                   reinterpret_cast<float*>(packed_resps), log_norm, llh_sum,
                                   workspace, workspace_bytes, as_stream(stream), true,
-                                  frame_scales);
+                                  frame_scales, moments);
 }
 
 int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float* X,
@@ -562,7 +563,8 @@ size_t beer_mixtureset_accumulate_packed_workspace_bytes(int cov, int64_t T, int
 int beer_mixtureset_estep_packed(int cov, int64_t T, int D, int S, int G, const float* X,
                                  const float* exp_stats, const float* log_weights,
                                  float* log_norm, void* packed_resps, double* llh_sum,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+                                 const float* moments, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
     BEER_REQUIRE(T >= 0 && D >= 1 && S >= 1 && G >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(X && exp_stats && packed_resps && workspace);
     BEER_REQUIRE(beer_mixtureset_packed_supported(cov, D, S, G));
@@ -570,7 +572,8 @@ int beer_mixtureset_estep_packed(int cov, int64_t T, int D, int S, int G, const 
     if (T == 0) return BEER_OK;
     return beer_mfma::estep_f16x3(cov, T, D, S, G, X, exp_stats, log_weights,
                                   reinterpret_cast<float*>(packed_resps), log_norm, llh_sum,
-                                  workspace, workspace_bytes, as_stream(stream), true);
+                                  workspace, workspace_bytes, as_stream(stream), true, nullptr,
+                                  moments);
 }
 
 int beer_mixtureset_accumulate_packed(int cov, int64_t T, int D, int S, int G, const float* X,

@@ -199,7 +199,8 @@ __device__ inline double entry_value(int cov, int D, int K, int k, int slab, int
 __global__ __launch_bounds__(1024) void pack16_kernel(int cov, int D, int K, int NT, const float* __restrict__ E,
                               const float* __restrict__ logw, const float* __restrict__ sc,
                               _Float16* __restrict__ P, float* __restrict__ inv_scale,
-                              int* __restrict__ tab, int G = 1, int Gp = 1) {
+                              int* __restrict__ tab, int G = 1, int Gp = 1,
+                              const float* __restrict__ moments = nullptr) {
     __shared__ double red[16];
     extern __shared__ __attribute__((aligned(16))) char pack_lds[];
     const int nk = nk16_of(cov, D), nent = nk * 32;
@@ -236,7 +237,12 @@ __global__ __launch_bounds__(1024) void pack16_kernel(int cov, int D, int K, int
     double* S2 = reinterpret_cast<double*>(pack_lds);        // full: Sigma [D, D]; else var [D]
     double* mu = S2 + (cov == BEER_FULL ? D * D : D);
     double* cr = mu + D;                                     // 2 D (spd_inverse scratch)
-    if (k < K) {
+    if (k < K && moments && cov == BEER_FULL) {
+        // ... or as the caller has them from the M-step (beer_nw_update): no inverse here
+        const float* mk = moments + (size_t)k * (D + D * D);
+        for (int a = threadIdx.x; a < D; a += blockDim.x) mu[a] = (double)mk[a];
+        for (int idx = threadIdx.x; idx < D * D; idx += blockDim.x) S2[idx] = (double)mk[D + idx];
+    } else if (k < K) {
         const float* row = E + (size_t)k * Q;
         if (cov == BEER_FULL) {
             for (int idx = threadIdx.x; idx < D * D; idx += blockDim.x) {
@@ -2067,7 +2073,8 @@ size_t estep16_workspace_bytes(int cov, int D, int S, int G) {
 
 int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, const float* expT,
                 const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
-                size_t ws_bytes, hipStream_t s, bool packed, const float* given_scales) {
+                size_t ws_bytes, hipStream_t s, bool packed, const float* given_scales,
+                const float* moments) {
     if (packed && S != 1 && !supported_llh_packed_sets(cov, D, S, G)) return BEER_EINVAL;
     if (!supported_llh_padded(D, S, G) || ws_bytes < estep16_workspace_bytes(cov, D, S, G))
         return BEER_EINVAL;
@@ -2096,8 +2103,9 @@ int estep_f16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, c
         if (rc != BEER_OK) return rc;
         sc = mine;
     }
-    hipLaunchKernelGGL(pack16_kernel, dim3(kpad), dim3(pack16_threads(cov, D, kpad)), pack16_lds(cov, D), s, cov, D, Kreal, NT, expT, logw, sc,
-                       P, inv_scale, tab, Greal, G);
+    hipLaunchKernelGGL(pack16_kernel, dim3(kpad),
+                       dim3(moments ? 256 : pack16_threads(cov, D, kpad)), pack16_lds(cov, D), s,
+                       cov, D, Kreal, NT, expT, logw, sc, P, inv_scale, tab, Greal, G, moments);
     BEER_LAUNCH_CHECK();
 #define BEER_LLH16(NT_, MT_, GQ_)                                                                \
     return launch_llh16<NT_, MT_, GQ_>(nframes, D, K, S, G, gl, jw, nchunks, nk, X, P, inv_scale, \

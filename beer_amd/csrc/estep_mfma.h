@@ -25,7 +25,7 @@ bool supported_llh_split(int D, int S, int G);
 int estep_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
                 const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
                 size_t ws_bytes, hipStream_t s, bool packed = false,
-                const float* given_scales = nullptr);
+                const float* given_scales = nullptr, const float* moments = nullptr);
 // The per-dimension frame scales of the split arithmetic (64 scales, 64 inverses) on
 // their own: a caller that runs many E-steps over the same frames computes them once
 // and hands them to estep_f16x3 (`given_scales`).  scratch >= 256 bytes.

@@ -179,6 +179,90 @@ __global__ __launch_bounds__(kNwThreads) void nw_from_natural_kernel(
     }
 }
 
+// The M-step of a Normal-Wishart posterior in ONE launch: natural parameters ->
+// standard parameters (nw_from_natural_kernel) AND, from the same elimination, what
+// the next iteration asks of the new posterior -- E[T], the log-normaliser
+// (nw_expected_stats_kernel) and the moments of its expected Gaussian (mean, E[Lambda]^-1
+// = W^-1 / nu: the matrix that is being inverted here anyway).  The inverse of W^-1
+// yields W and log|W^-1| = -log|W| together: one factorisation where the separate
+// calls make two.  E[T] and the log-normaliser are computed from the parameters as
+// they are STORED (rounded to T), like the separate calls, except for log|W| (taken
+// from the unrounded elimination; the difference is below T's rounding of the
+// result).
+template <typename T>
+__global__ __launch_bounds__(kNwThreads) void nw_update_kernel(
+    int D, const T* __restrict__ eta, T* __restrict__ mean, T* __restrict__ scale,
+    T* __restrict__ W, T* __restrict__ dof, T* __restrict__ out, T* __restrict__ lnorm,
+    T* __restrict__ moments) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* A = reinterpret_cast<double*>(smem);       // D*D
+    double* m = A + D * D;                              // D
+    double* pm = m + D;                                 // D : nu W m
+    double* red = pm + D;                               // 8 (+ 2 D of spd_inverse behind)
+    const int k = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int Q = D * D + D + 2;
+    const T* e = eta + (size_t)k * Q;
+    const T kappa_t = (T)(-2.0 * (double)e[D + D * D]);
+    const T nu_t = (T)(2.0 * (double)e[D + D * D + 1] + (double)D);
+    const double kappa = (double)kappa_t, nu = (double)nu_t;
+    const double kappa_u = -2.0 * (double)e[D + D * D];
+    for (int i = tid; i < D; i += nt) {
+        const double mu = (double)e[i] / kappa_u;
+        const T mt = (T)mu;
+        mean[(size_t)k * D + i] = mt;
+        m[i] = mu;
+        if (moments) moments[(size_t)k * (D + D * D) + i] = mt;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < D * D; idx += nt) {
+        const int i = idx / D, j = idx % D;
+        const double b = 0.5 * ((double)e[D + i * D + j] + (double)e[D + j * D + i]);
+        const double winv = -2.0 * b - kappa_u * m[i] * m[j];
+        A[idx] = winv;
+        if (moments) moments[(size_t)k * (D + D * D) + D + idx] = (T)(winv / nu);
+    }
+    const double logdet = -spd_inverse(A, D, red + 8, true);        // log|W|
+    T* Wk = W + (size_t)k * D * D;
+    T* o = out + (size_t)k * Q;
+    __syncthreads();
+    for (int i = tid; i < D; i += nt) m[i] = (double)mean[(size_t)k * D + i];   // as stored
+    __syncthreads();
+    for (int idx = tid; idx < D * D; idx += nt) {
+        const int i = idx / D, j = idx - i * D;
+        const T w = (T)(0.5 * (A[i * D + j] + A[j * D + i]));
+        Wk[idx] = w;
+        o[D + idx] = (T)(nu * (double)w);
+    }
+    __syncthreads();
+    for (int i = tid; i < D; i += nt) {
+        double sacc = 0.0;
+        for (int j = 0; j < D; ++j) sacc += (double)Wk[i * D + j] * m[j];
+        pm[i] = nu * sacc;
+        o[i] = (T)pm[i];
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int i = tid; i < D; i += nt) part += pm[i] * m[i];
+    const double tr = block_sum(part, red);
+    double dg = 0.0, lg = 0.0;
+    for (int i = tid; i < D; i += nt) {
+        dg += digamma(0.5 * (nu + 1.0 - (double)(i + 1)));
+        lg += lgamma(0.5 * (nu + 1.0 - (double)(i + 1)));
+    }
+    const double dgs = block_sum(dg, red);
+    const double lgs = block_sum(lg, red);
+    if (tid == 0) {
+        scale[k] = kappa_t;
+        dof[k] = nu_t;
+        o[D + D * D] = (T)((double)D / kappa + tr);
+        o[D + D * D + 1] = (T)(dgs + (double)D * kLog2 + logdet);
+        const double d = (double)D;
+        lnorm[k] = (T)(0.5 * nu * logdet + 0.5 * nu * d * kLog2 +
+                       0.25 * d * (d - 1.0) * kLogPi + lgs - 0.5 * d * log(kappa) +
+                       0.5 * d * kLog2Pi);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Normal-Gamma (diag) and isotropic Normal-Gamma: one thread per pdf.
 // ---------------------------------------------------------------------------
@@ -466,6 +550,22 @@ int nw_from_natural_launch(int K, int D, const void* eta, void* mean, void* scal
     return BEER_OK;
 }
 
+template <typename T>
+int nw_update_launch(int K, int D, const void* eta, void* mean, void* scale, void* W, void* dof,
+                     void* out, void* lnorm, void* moments, void* stream) {
+    BEER_REQUIRE(K >= 0 && D >= 1 && D <= kMaxFullDim);
+    if (K == 0) return BEER_OK;
+    BEER_REQUIRE(eta && mean && scale && W && dof && out && lnorm);
+    const size_t lds = ((size_t)D * D + 4 * D + 16) * sizeof(double);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nw_update_kernel<T>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nw_update_kernel<T>, dim3(K), dim3(nw_threads(K, D)), lds,
+                       as_stream(stream), D, (const T*)eta, (T*)mean, (T*)scale, (T*)W, (T*)dof,
+                       (T*)out, (T*)lnorm, (T*)moments);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
 template <typename T, bool ISO>
 int ng_launch(int which, int K, int D, const void* mean, const void* scale,
               const void* shape, const void* rates, void* out, void* stream) {
@@ -694,6 +794,12 @@ int beer_nw_natural(int dtype, int K, int D, const void* mean, const void* scale
 int beer_nw_from_natural(int dtype, int K, int D, const void* eta, void* mean, void* scale,
                          void* W, void* dof, void* stream) {
     BEER_DISPATCH(dtype, nw_from_natural_launch, K, D, eta, mean, scale, W, dof, stream);
+}
+
+int beer_nw_update(int dtype, int K, int D, const void* eta, void* mean, void* scale, void* W,
+                   void* dof, void* exp_stats, void* log_norm, void* moments, void* stream) {
+    BEER_DISPATCH(dtype, nw_update_launch, K, D, eta, mean, scale, W, dof, exp_stats, log_norm,
+                  moments, stream);
 }
 
 #define NG_ENTRY(NAME, ISO, WHICH)                                                        \

@@ -27,6 +27,17 @@ def _exact(X):
     return X.dtype == torch.float32 and not _hip.f32_split_ok(X)
 
 
+def _moments(exp_stats, K, D, device):
+    '''The components' moments that travel with a Normal-Wishart's expected statistics
+    (`dists.NormalWishart` attaches them after an update), as the packed E-steps take
+    them: float32 [K, D + D*D] on `device`, or None.'''
+    m = getattr(exp_stats, '_beer_moments', None)
+    if m is None or m.dtype != torch.float32 or m.device != device or \
+            tuple(m.shape) != (K, D + D * D):
+        return None
+    return m
+
+
 def _frames(stats):
     if not isinstance(stats, FrameStats):
         raise TypeError('expected the lazy statistics returned by '
@@ -124,6 +135,7 @@ def mixture_estep_packed(stats, exp_stats, log_weights, K, cov_type, llh_sum=Non
     lw = _hip.on_device(log_weights, X.dtype)
     if E.shape[0] != K or lw.numel() != K:
         raise ValueError(f'{E.shape[0]} Gaussians, {lw.numel()} weights for {K} components')
+    mom = _moments(exp_stats, K, D, X.device) if cov_type == 'full' else None
     log_norm = torch.empty(T, 1, dtype=X.dtype, device=X.device)
     words = torch.empty(_hip.lib().beer_packed_resps_bytes(T, D, K) // 4, dtype=torch.int32,
                         device=X.device)
@@ -131,7 +143,7 @@ def mixture_estep_packed(stats, exp_stats, log_weights, K, cov_type, llh_sum=Non
                                   _hip.COV_CODE[cov_type], D, 1, K, X.device)
     _hip.call('beer_mixture_estep_packed', _hip.COV_CODE[cov_type], T, D, K, _hip.ptr(X),
               _hip.ptr(E), _hip.ptr(lw), _hip.ptr(log_norm), _hip.ptr(words), _hip.ptr(llh_sum),
-              _hip.ptr(_hip.frame_scales(X)), _hip.ptr(ws), ws_bytes)
+              _hip.ptr(_hip.frame_scales(X)), _hip.ptr(mom), _hip.ptr(ws), ws_bytes)
     return log_norm, PackedResps(words, T, K)
 
 
@@ -166,9 +178,10 @@ def mixtureset_estep_packed(stats, exp_stats, log_weights, S, G, cov_type, llh_s
                         device=X.device)
     ws, ws_bytes = _hip.workspace('beer_estep_workspace_bytes', X.dtype,
                                   _hip.COV_CODE[cov_type], D, S, G, X.device)
+    mom = _moments(exp_stats, K, D, X.device) if cov_type == 'full' else None
     _hip.call('beer_mixtureset_estep_packed', _hip.COV_CODE[cov_type], T, D, S, G, _hip.ptr(X),
               _hip.ptr(E), _hip.ptr(lw), _hip.ptr(log_norm), _hip.ptr(words), _hip.ptr(llh_sum),
-              _hip.ptr(ws), ws_bytes)
+              _hip.ptr(mom), _hip.ptr(ws), ws_bytes)
     return log_norm, PackedResps(words, T, K)
 
 

@@ -104,6 +104,19 @@ int beer_nw_from_natural(int dtype, int K, int D, const void* eta, void* mean,
                          void* scale, void* scale_matrix, void* dof,
                          void* stream);
 
+/* The M-step of a Normal-Wishart posterior in one launch:
+ * from_natural_parameters (normalwishart.py:110-141) and, from the same
+ * elimination, what the next iteration asks of the new posterior: `exp_stats`
+ * [K, D*D+D+2] (expected_sufficient_statistics, normalwishart.py:170-210),
+ * `log_norm` [K] (normalwishart.py:219-236) and, when `moments` is not NULL, the
+ * moments of its expected Gaussian, [K, D + D*D] = (mean, E[Lambda]^-1 = W^-1 / nu)
+ * -- what the split E-step compensates its parameter rounding with
+ * (beer_mixture_estep_packed).  One factorisation where the three separate calls
+ * make two and an inverse. */
+int beer_nw_update(int dtype, int K, int D, const void* eta, void* mean, void* scale,
+                   void* scale_matrix, void* dof, void* exp_stats, void* log_norm,
+                   void* moments, void* stream);
+
 /* NormalGamma (diagonal covariance), beer/dists/normalgamma.py:118-146,
  * 151-157, 163-180, 77-94.  mean [K,D], scale [K], shape [K], rates [K,D]. */
 int beer_ng_expected_stats(int dtype, int K, int D, const void* mean,
@@ -272,8 +285,14 @@ size_t beer_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int K);
 int beer_mixture_estep_packed(int cov, int64_t T, int D, int K, const float* X,
                               const float* exp_stats, const float* log_weights,
                               float* log_norm, void* packed_resps, double* llh_sum,
-                              const float* frame_scales, void* workspace,
-                              size_t workspace_bytes, void* stream);
+                              const float* frame_scales, const float* moments,
+                              void* workspace, size_t workspace_bytes, void* stream);
+/* `moments` (nullable; full covariance): [K, D + D*D] = the mean and the matrix
+ * E[Lambda]^-1 of every component, as beer_nw_update leaves them.  The split
+ * arithmetic's parameter image carries 22 bits per entry; the kernel that builds
+ * it folds the resulting bias of every component's logits -- evaluated at these
+ * moments -- into a 44-bit constant term.  NULL: it derives
+ * the moments from `exp_stats` itself (one D x D inverse per component). */
 /* The per-dimension frame scales of the split arithmetic -- 128 floats: 64 powers
  * of two s_d with |x_d s_d| < 2^7 over all T frames, then their 64 inverses -- as
  * the E-step computes them with one pass over X at the start of every call.  The
@@ -310,7 +329,8 @@ size_t beer_mixtureset_accumulate_packed_workspace_bytes(int cov, int64_t T, int
 int beer_mixtureset_estep_packed(int cov, int64_t T, int D, int S, int G, const float* X,
                                  const float* exp_stats, const float* log_weights,
                                  float* log_norm, void* packed_resps, double* llh_sum,
-                                 void* workspace, size_t workspace_bytes, void* stream);
+                                 const float* moments, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 int beer_mixtureset_accumulate_packed(int cov, int64_t T, int D, int S, int G,
                                       const float* X, const void* packed_resps,
                                       const float* state_resps, double* acc,

@@ -835,6 +835,57 @@ def test_gmm_with_more_than_256_components_on_the_matrix_cores(cov, K, D, split)
     assert np.abs(r - truth['resps']).max() < 2e-4
 
 
+def test_m_step_in_one_launch_and_the_moments_it_hands_to_the_e_step():
+    '''beer_nw_update (natural -> standard parameters, E[T], log-normaliser, moments in
+    one launch) against the separate calls, and the packed E-step with the moments it
+    leaves on E[T] against the same call deriving them itself.'''
+    from beer_amd import kernels
+    from beer_amd.dists import NormalWishart
+    torch.manual_seed(11)
+    K, D, T = 128, 24, 20000
+    means = torch.randn(K, D) * 2
+    X = (means[torch.randint(0, K, (T,))] + torch.randn(T, D)).to(DEV)
+    ns = beer.NormalSet.create(X.mean(0).cpu(), torch.diag(X.var(0).cpu()), size=K,
+                               prior_strength=1., noise_std=1., cov_type='full')
+    model = beer.Mixture.create(ns, prior_strength=1.).to(DEV)
+    optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), 1.)
+    optim.init_step()
+    elbo = beer.accumulate_elbo(model, (X, [T]), datasize=T)
+    elbo.backward()
+    optim.step()
+    post = ns.means_precisions.posterior
+    E = post.expected_sufficient_statistics()
+    mom = E._beer_moments
+    # the separate calls on the parameters the update stored
+    ref = NormalWishart.from_std_parameters(*[t.clone() for t in post._tensors()])
+    torch.testing.assert_close(E, ref.expected_sufficient_statistics(), rtol=2e-6, atol=1e-5)
+    torch.testing.assert_close(post.log_norm(), ref.log_norm(), rtol=1e-6, atol=1e-4)
+    torch.testing.assert_close(post.natural_parameters(), ref.natural_parameters(), rtol=1e-4,
+                               atol=1e-4)
+    p = post.params
+    torch.testing.assert_close(mom[:, :D], p.mean)
+    sigma = mom[:, D:].view(K, D, D).double()
+    eye = sigma @ (p.dof.view(K, 1, 1).double() * p.scale_matrix.double())
+    assert float((eye - torch.eye(D, device=DEV, dtype=torch.float64)).abs().max()) < 1e-4
+    # E-step with the handed-over moments == E-step that inverts for itself
+    st = beer.FrameStats(X, 'full')
+    lw = model._log_weights().view(1, K)
+    assert kernels._moments(E, K, D, X.device) is mom
+    ln_a, r_a = kernels.mixture_estep_packed(st, E, lw, K, 'full')
+    acc_a = kernels.normal_accumulate(st, r_a, None, K, 1, 'full')
+    bare = E.clone()
+    assert kernels._moments(bare, K, D, X.device) is None
+    ln_b, r_b = kernels.mixture_estep_packed(st, bare, lw, K, 'full')
+    acc_b = kernels.normal_accumulate(st, r_b, None, K, 1, 'full')
+    torch.testing.assert_close(ln_a, ln_b, rtol=0, atol=2e-4)
+    assert float((acc_a - acc_b).abs().max() / acc_b.abs().max()) < 3e-6
+    # and both against the fp64 kernels
+    st64 = beer.FrameStats(X.double(), 'full')
+    _, r64 = kernels.mixtureset_estep(st64, E.double(), lw.double(), 1, K, 'full')
+    acc64 = kernels.normal_accumulate(st64, r64, None, K, 1, 'full')
+    assert float((acc_a - acc64).abs().max() / acc64.abs().max()) < 1e-5
+
+
 def _chain_graph(n_states, rng, dtype):
     'Left-to-right alignment-like graph with skips: in/out degree <= 3.'
     trans = np.full((n_states, n_states), -np.inf)
