@@ -164,7 +164,8 @@ int launch_scales(const float* X, int64_t nframes, int D, unsigned* absmax, floa
 // pack_kernel in estep_mfma.hip) times the inverse frame scaling.
 __device__ inline double entry_value(int cov, int D, int K, int k, int slab, int e,
                                      const float* __restrict__ E, const float* __restrict__ logw,
-                                     const float* __restrict__ isx, bool* is_const) {
+                                     const float* __restrict__ isx, bool* is_const,
+                                     const float* row_in = nullptr) {
     const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(cov, D), Q = stats_dim(cov, D);
     *is_const = false;
     if (slab >= nslab) return 0.0;
@@ -173,7 +174,7 @@ __device__ inline double entry_value(int cov, int D, int K, int k, int slab, int
     const bool constant = (a == Dp && b - e == Dp);
     if (constant) *is_const = (e == 0);
     if (k >= K) return 0.0;
-    const float* row = E + (size_t)k * Q;
+    const float* row = row_in ? row_in : E + (size_t)k * Q;
     if (sq)
         return b < D ? -0.5 * (double)row[cov == BEER_ISO ? D : D + b] * (double)isx[b] * (double)isx[b]
                      : 0.0;
@@ -188,6 +189,12 @@ __device__ inline double entry_value(int cov, int D, int K, int k, int slab, int
     const double zero = cov == BEER_ISO ? 0.5 * (double)D : 0.5;
     return -0.5 * (double)row[Q - 2] + zero * (double)row[Q - 1] - 0.5 * (double)D * kLog2Pi +
            (logw ? (double)logw[k] : 0.0);
+}
+
+// dynamic LDS of pack16_kernel: [moments: Sigma (D*D, or D variances), mu (D), 2 D of
+// elimination scratch] as doubles, then the component's row of E as floats
+__host__ __device__ inline size_t pack16_moment_bytes(int cov, int D) {
+    return (size_t)((cov == BEER_FULL ? D * D : D) + 3 * D) * sizeof(double);
 }
 
 // One workgroup per (padded) component: column scale, then its fp16 hi / lo
@@ -215,10 +222,17 @@ __global__ __launch_bounds__(1024) void pack16_kernel(int cov, int D, int K, int
             const int Dp = 4 * d4_of(D);
             tab[s] = s < nslab_of(cov, D) ? slab_entry(cov, D, s) : ((Dp + 1) | ((Dp + 4) << 8));
         }
+    // the component's expected statistics, staged once (the entries are gathered from
+    // all over the row: from global memory every gather was a dependent L2 round trip)
+    const int Qs = stats_dim(cov, D);
+    float* rowl = reinterpret_cast<float*>(pack_lds + pack16_moment_bytes(cov, D));
+    if (k < K)
+        for (int q = threadIdx.x; q < Qs; q += blockDim.x) rowl[q] = E[(size_t)k * Qs + q];
+    __syncthreads();
     double mx = 0.0;
     bool dummy;
     for (int q = threadIdx.x; q < nent; q += blockDim.x) {
-        const double v = fabs(entry_value(cov, D, K, k, q / 4, q % 4, E, logw, isx, &dummy));
+        const double v = fabs(entry_value(cov, D, K, k, q / 4, q % 4, E, logw, isx, &dummy, rowl));
         mx = v > mx ? v : mx;
     }
     mx = block_max(mx, red);
@@ -243,7 +257,7 @@ __global__ __launch_bounds__(1024) void pack16_kernel(int cov, int D, int K, int
         for (int a = threadIdx.x; a < D; a += blockDim.x) mu[a] = (double)mk[a];
         for (int idx = threadIdx.x; idx < D * D; idx += blockDim.x) S2[idx] = (double)mk[D + idx];
     } else if (k < K) {
-        const float* row = E + (size_t)k * Q;
+        const float* row = rowl;
         if (cov == BEER_FULL) {
             for (int idx = threadIdx.x; idx < D * D; idx += blockDim.x) {
                 const int a = idx / D, b = idx - a * D;
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(1024) void pack16_kernel(int cov, int D, int K, int
     int qc = -1;                                              // the constant's entry (e = 0)
     for (int q = threadIdx.x; q < nent; q += blockDim.x) {
         bool is_const;
-        double v = entry_value(cov, D, K, k, q / 4, q % 4, E, logw, isx, &is_const) * scale;
+        double v = entry_value(cov, D, K, k, q / 4, q % 4, E, logw, isx, &is_const, rowl) * scale;
         if (k >= K) v = is_const ? -1.0 : 0.0;            // padded component: logit -1e30
         const float vf = (float)v;
         const _Float16 hi = (_Float16)vf;
@@ -331,7 +345,7 @@ inline int pack16_threads(int cov, int D, int slots) {
     return cov == BEER_FULL && D >= 16 && slots <= 512 ? 1024 : 256;
 }
 inline size_t pack16_lds(int cov, int D) {
-    return (size_t)((cov == BEER_FULL ? D * D : D) + 3 * D) * sizeof(double);
+    return pack16_moment_bytes(cov, D) + (size_t)stats_dim(cov, D) * sizeof(float);
 }
 
 // v = hi + lo with hi = fp16(v), lo = fp16(v - hi), both round-to-nearest
