@@ -132,6 +132,31 @@ def _cached_batch(graph, run_lengths, dtype):
     return batch
 
 
+_side_streams = {}
+_KL_BESIDE = os.environ.get('BEER_KL_SIDE_STREAM', '1') != '0'
+
+
+def _kl_beside_the_estep(model, device):
+    '''KL(q || p) of the model's parameters on a side stream: a dozen small launches
+    (expected statistics and log-normalisers of the Dirichlets, the KL kernels, their
+    sums) that depend on the parameters only, not on the frames -- queued beside the
+    E-step kernels instead of in front of them.  Returns (kl, event or None); the
+    caller makes its stream wait for the event before it uses `kl`.  The side stream
+    starts behind everything queued so far (the previous M-step), and the next call
+    starts behind this one's consumers: tensors it allocates are not recycled early.'''
+    if not _KL_BESIDE or isinstance(model, VAE) or device.type != 'cuda':
+        return torch.as_tensor(model.kl_div_posterior_prior()), None
+    main = torch.cuda.current_stream(device)
+    side = _side_streams.get(device)
+    if side is None:
+        side = _side_streams[device] = torch.cuda.Stream(device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        kl = torch.as_tensor(model.kl_div_posterior_prior())
+        done = side.record_event()
+    return kl, done
+
+
 def _finish(model, value_terms, kl, nutt, acc, datasize, total_frames):
     value = value_terms - float(nutt) * kl.to(value_terms.device, torch.float64)
     return EvidenceLowerBoundInstance(value, acc, model.bayesian_parameters(),
@@ -381,7 +406,7 @@ def accumulate_elbo(model, utterances, datasize=-1, inference_graphs=None, scale
         datasize = total
     if len(lengths) == 0:
         return EvidenceLowerBoundInstance(0., {}, [], 0, datasize)
-    kl = torch.as_tensor(model.kl_div_posterior_prior())
+    kl, kl_done = _kl_beside_the_estep(model, X.device)
     if isinstance(model, Mixture):
         value_terms, acc = _mixture_batch(model, X, lengths, datasize, labels, max_frames)
     elif isinstance(model, HMM):
@@ -393,6 +418,8 @@ def accumulate_elbo(model, utterances, datasize=-1, inference_graphs=None, scale
     else:
         raise NotImplementedError(f'no batched E-step for {type(model).__name__}')
     model.clear_cache()
+    if kl_done is not None:
+        torch.cuda.current_stream(X.device).wait_event(kl_done)
     return _finish(model, value_terms, kl, len(lengths), acc, datasize, total)
 
 
