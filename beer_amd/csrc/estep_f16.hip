@@ -579,9 +579,23 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
                 acc[m][q * QT + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                     frag(cur.lo[m]), b.hi[c], acc[m][q * QT + c], 0, 0, 0);
         }
+#if BEER_K1_SCHED == 1
+        // the quarter's LDS reads first, their arithmetic two thirds of an MFMA block
+        // later (an LDS read waited for at once stalls the wave ~100 cycles, 8 times a
+        // k-step), the arithmetic itself in the issue gaps of the MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x020, 2 * QT, 0);          // VMEM reads
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);               // DS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * QT, 0);         // MFMA
+#pragma unroll
+        for (int r = 0; r < 2 * MT * QT; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);           // VALU
+        }
+#else
         __builtin_amdgcn_sched_group_barrier(0x020, 2 * QT, 0);          // VMEM reads
         __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);              // DS reads
         __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT * QT, 0);     // MFMA
+#endif
     };
     auto kstep = [&](int s, const AFrag& cur, AFrag& nxt, BFrag& b0, BFrag& b1) {
         quarter(s, 0, cur, nxt, b0, b1);
@@ -1250,6 +1264,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void acc16p_kernel(
 // (DMA), tile t + 1 being folded in place -- every thread its own 2 x 8 elements,
 // spread over the steps before the barrier --, tile t multiplied.  lgG = log2 of the
 // components per state (8 .. 128: the states of a 128-component block fit 4 KiB).
+#ifndef BEER_K1_SCHED
+#define BEER_K1_SCHED 0        // experiment builds (tools/ab_build.sh)
+#endif
 #ifndef BEER_SR_ABL
 #define BEER_SR_ABL 0          // ablation builds only (tools/ab_build.sh)
 #endif
