@@ -2,7 +2,7 @@
 # Round-2 profiles: kernel-trace stats + three PMC passes of the two bench commands.
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/j27; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/j27; rm -rf $O; mkdir -p $O
 C2="python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 C3="python bench.py --config 3 --steps 3 --warmup 1 --no-cpu-baseline"
 P1="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
