@@ -538,6 +538,13 @@ def run_hmm(args, rank, world, device, backend):
     elapsed = max_over_ranks(elapsed, world, device, backend)
     if rank != 0:
         return None
+    # size-independent check at the full size: every frame's state posteriors and
+    # component responsibilities sum to one, so the mixture-weight counts of the
+    # whole (all-reduced, datasize-scaled) job must add up to the number of frames
+    counts = [v for p, v in elbo._acc_stats.items() if v.dim() == 2 and v.shape[-1] == N_COMP]
+    # (a row of the statistics is (N_1 .. N_G-1, N_1 + .. + N_G): beer/dists/dirichlet.py:18-21)
+    conservation = abs(float(counts[0].double()[:, -1].sum()) - datasize) / datasize \
+        if counts else None
     kern = {}
     for nm in names:
         ms, n = kt.mean_ms(nm)
@@ -569,6 +576,7 @@ def run_hmm(args, rank, world, device, backend):
                    'parallelism': f'dp{world}', 'frames_total': datasize,
                    'frames_rank0': n_local, 'utterances': len(lengths_all)},
         'elbo_per_frame': float(elbo) / (len(lengths_all) * datasize),
+        'count_conservation_rel_err': conservation,
         'f32_mode': beer.get_f32_mode(),
         'all_reduce_ms': phases.mean_ms('all_reduce'), 'm_step_ms': phases.mean_ms('m_step'),
         'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': PEAK_HBM_GBS,
