@@ -1,10 +1,16 @@
+#!/usr/bin/env python
+"""How far the fp16-split E-step + accumulation are from the fp64 kernels on mixtures
+with few frames per component (K = 512 .. 768, D = 16 / 40, 17 000 frames), next to the
+generic float32 kernels: the numbers quoted in DESIGN.md section 8.  Needs an MI355X.
+
+    python tools/split_precision_probe.py
+"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import numpy as np, torch
 import beer_amd as beer
 from beer_amd import kernels
-from helpers import orc
 DEV = torch.device('cuda')
 def run(cov, K, D, splits):
     T = 17000
