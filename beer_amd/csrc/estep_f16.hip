@@ -1762,6 +1762,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
         xrc[it] = (rows4 && idx < npieces) ? (r | (c4 << 8)) : FW;
     }
     const float* scl = scales;
+    // Second mapping, when a row is an even number of pieces (D = 8, 16, 24, 32, 40 ..):
+    // lane = (row r, half h of the row), pieces h, h + 2, h + 4 .. of it.  Row and half
+    // are fixed per lane, so every address below is ONE per-lane base plus a
+    // compile-time constant per piece -- global source, scales, row-major and
+    // transposed destinations -- where the linear mapping above spends ~30 VALU per
+    // piece on decoding (r, c4) and forming five addresses (a third of the kernel's
+    // VALU instructions went into this staging).  Rows past the end are read from the
+    // last row: their responsibilities get weight 0 below, any finite value will do.
+    const bool rowlane = rows4 && (C4 & 1) == 0 && (C4 >> 1) <= kXP;
+    const int NP = C4 >> 1, lr = lane & 31, lh = lane >> 5;
+    float* xw_l = xw + lr * LD + 4 * lh;                       // + 8 it
+    float* xt_l = xt + 4 * lh * kAfXS + lr;                    // + (8 it + j) kAfXS
+    const float* scl_l = scl + 4 * lh;                         // + 8 it
     // frame tiles of this wave: tb + 32 (wave + WAVES n)
     for (int64_t fb = tb + (int64_t)wave * FW; fb < te; fb += WAVES * FW) {
         const int rows = (int)(te - fb < FW ? te - fb : FW);              // >= 1
@@ -1769,7 +1782,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
         f32x4 xv[kXP];
-        if (rows4) {
+        if (rowlane) {
+            const f32x4* src = X4 + (fb + (lr < rows ? lr : rows - 1)) * C4 + lh;
+#pragma unroll
+            for (int it = 0; it < kXP; ++it) xv[it] = src[2 * (it < NP ? it : NP - 1)];
+        } else if (rows4) {
             const f32x4* Xt4 = X4 + fb * C4;
             const int last = rows * C4 - 1;
 #pragma unroll
@@ -1828,7 +1845,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
                             for (int j = 0; j < NST; ++j) wg[q][m][r][j] = 1.f;
             }
         }
-        if (rows4) {
+        if (rowlane) {
+#pragma unroll
+            for (int it = 0; it < kXP; ++it) {
+                if (it >= NP) break;
+                const f32x4 v = xv[it] * *reinterpret_cast<const f32x4*>(scl_l + 8 * it);
+                *reinterpret_cast<f32x4*>(xw_l + 8 * it) = v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xt_l[(8 * it + j) * kAfXS] = v[j];
+            }
+        } else if (rows4) {
 #pragma unroll
             for (int it = 0; it < kXP; ++it) {
                 int rc = xrc[it];
