@@ -10,9 +10,11 @@ where /root/reference is importable, and times BOTH on the same inputs:
   utterances): `beer.evidence_lower_bound` + `backward` + optimizer step of the
   imported reference against `torch_port.gmm_iteration`, at 1 and 8 threads.
 
-It also compares the two ELBO values (they are the same arithmetic).  The HMM port
-is pinned numerically by tests/test_oracle_golden.py (1e-14 vs the oracle); its timing
-is not cross-checked here.  Output:
+  config 3 shape (HMM, 120 states in a phone-loop-like graph, 16 diagonal Gaussians per
+  state, D = 40, float32, 300-frame utterances): `beer.evidence_lower_bound(hmm, x)` per
+  utterance against `torch_port.hmm_elbo`, at 1 and 8 threads.
+
+It also compares the two ELBO values (they are the same arithmetic).  Output:
 one JSON object, committed as profiles/r02_cpu_baseline_crosscheck.json.
 
     python tools/ref_timing_check.py > profiles/r02_cpu_baseline_crosscheck.json
@@ -87,6 +89,62 @@ def gmm_case(beer, tp, threads):
             'elbo_rel_diff': abs(v_ref - v_port) / abs(v_ref)}
 
 
+def hmm_case(beer, tp, threads):
+    'Config-3 shaped HMM: 120 states in a loop, 16 diagonal Gaussians per state, D = 40.'
+    S, G, D, nutt = 120, 16, 40, 3
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(5)
+    graph = beer.graph.Graph()
+    start, end = graph.add_state(), graph.add_state()
+    graph.start_state, graph.end_state = start, end
+    states = [graph.add_state(pdf_id=s) for s in range(S)]
+    for s in range(S):
+        graph.add_arc(states[s], states[s])
+        if s % 3 < 2:
+            graph.add_arc(states[s], states[s + 1])
+        else:
+            graph.add_arc(states[s], end)
+            for t in range(0, S, 3):
+                graph.add_arc(states[s], states[t])
+        if s % 3 == 0:
+            graph.add_arc(start, states[s])
+    graph.normalize()
+    cgraph = graph.compile()
+    ns = beer.NormalSet.create(torch.zeros(D), torch.ones(D), size=S * G, prior_strength=1.,
+                               noise_std=1., cov_type='diagonal')
+    ms = beer.MixtureSet.create(S, ns, prior_strength=1.)
+    hmm = beer.HMM.create(cgraph, ms).float()
+    mp = ns.means_precisions
+    names = ('mean', 'scale', 'shape', 'rates')
+    post = tuple(getattr(mp.posterior.params, a).clone() for a in names)
+    prior = tuple(getattr(mp.prior.params, a).clone() for a in names)
+    wp = ms.categoricalset.weights
+    w_post = wp.posterior.params.concentrations.clone()
+    w_prior = wp.prior.params.concentrations.clone()
+    init, fin, trans = (cgraph.init_log_probs.float(), cgraph.final_log_probs.float(),
+                        cgraph.trans_log_probs.float())
+    utts = [torch.randn(300, D, generator=g) for _ in range(nutt)]
+    N = 10_000_000
+
+    def reference():
+        return sum(float(beer.evidence_lower_bound(hmm, x, datasize=N)) for x in utts)
+
+    def port():
+        return sum(float(tp.hmm_elbo(x, post, prior, w_post, w_prior, init, fin, trans, N)[0])
+                   for x in utts)
+
+    t_port, v_port = _best_of(port, 2)
+    t_ref, v_ref = _best_of(reference, 2)
+    n = 300 * nutt
+    return {'workload': f'HMM {S} states x {G} diagonal Gaussians, D={D}, float32, {nutt} x 300 '
+                        'frames, E-step + statistics (no update)',
+            'threads': threads, 'reference_s': t_ref, 'port_s': t_port,
+            'reference_frames_per_s': n / t_ref, 'port_frames_per_s': n / t_port,
+            'port_over_reference_speed': t_ref / t_port,
+            'elbo_reference': v_ref, 'elbo_port': v_port,
+            'elbo_rel_diff': abs(v_ref - v_port) / abs(v_ref)}
+
+
 def main():
     sys.path.insert(0, REF)
     import beer                                             # the reference itself
@@ -98,6 +156,8 @@ def main():
            'cases': []}
     for threads in (1, 8):
         out['cases'].append(gmm_case(beer, tp, threads))
+    for threads in (1, 8):
+        out['cases'].append(hmm_case(beer, tp, threads))
     print(json.dumps(out, indent=1))
 
 
