@@ -448,6 +448,29 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llh16_kernel(
         const int C4 = D >> 2;
         const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
         const f32x4* sc4 = reinterpret_cast<const f32x4*>(sc);
+        static_assert(64 * KS == 2 * FW, "two lanes per frame row");
+        if ((C4 & 1) == 0 && C4 <= 16) {
+            // a lane = (row, half of the row): source, scales and destination are one
+            // per-lane base plus a constant per piece (no division, no address per piece)
+            const int lg = part * 64 + lane, r = lg & (FW - 1), h = lg / FW;
+            const int64_t f = fb + r;
+            const bool valid = f < nframes;
+            const f32x4* src = X4 + (valid ? f : nframes - 1) * C4 + h;
+            float* dst = xw + r * LD + 4 * h;
+            // (all loads first, on clamped piece numbers: a load behind a branch is
+            // issued and waited for on its own)
+            const int np = C4 >> 1;
+            f32x4 xv[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) xv[it] = src[2 * (it < np ? it : np - 1)];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                if (it >= np) break;
+                f32x4 v = xv[it] * sc4[h + 2 * it];
+                if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(dst + 8 * it) = v;
+            }
+        } else
         for (int idx = part * 64 + lane; idx < FW * C4; idx += 64 * KS) {
             const int r = idx / C4, c4 = idx - r * C4;
             const int64_t f = fb + r;
