@@ -1868,6 +1868,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
                             for (int j = 0; j < NST; ++j) wg[q][m][r][j] = 1.f;
             }
         }
+        // A tile none of whose frames gives the chunk's states any posterior contributes
+        // exactly nothing: skip it (alignment graphs: most of the model's states are
+        // absent from an utterance, their posteriors are exact zeros)
+        if (sr) {
+            float any = 0.f;
+#pragma unroll
+            for (int q = 0; q < QT; ++q)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < NST; ++j)
+                            any = __builtin_fmaxf(any, __builtin_fabsf(wg[q][m][r][j]));
+#ifndef BEER_ACCF_NOSKIP
+            if (__builtin_amdgcn_ballot_w64(any != 0.f) == 0) continue;
+#endif
+        }
         if (rowlane) {
 #pragma unroll
             for (int it = 0; it < kXP; ++it) {

@@ -1289,6 +1289,10 @@ def test_fused_accumulation_recomputes_the_responsibilities(cov, S, G, D, T):
     E64, lw64 = ns.means_precisions.natural_form(), ms._log_weights()
     sr64 = torch.rand(T, S, dtype=torch.float64, device=DEV)
     sr64 = sr64 * (torch.rand(T, S, dtype=torch.float64, device=DEV) < .3)     # sparse posteriors
+    # ... and states that are absent from long stretches of frames, as with alignment
+    # graphs: the kernel skips frame tiles whose posteriors are all zero
+    sr64[1000:9000, ::2] = 0.
+    sr64[12000:, 1::3] = 0.
     st64 = beer.FrameStats(X, cov)
     _, r64 = kernels.mixtureset_estep(st64, E64, lw64, S, G, cov)
     acc64 = kernels.normal_accumulate(st64, r64, sr64, S, G, cov)
