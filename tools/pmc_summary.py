@@ -41,8 +41,9 @@ def main():
         tag, dirs = dirs[0][len('--tag='):] + '_', dirs[1:]
     out = collections.defaultdict(dict)
     for i, d in enumerate(dirs, start=1):
-        f = (glob.glob(os.path.join(d, '*', '*counter_collection.csv')) +
-             glob.glob(os.path.join(d, '*counter_collection.csv')))[0]
+        # (gpurun merges a new run's files into the local directory: take the newest)
+        f = max(glob.glob(os.path.join(d, '*', '*counter_collection.csv')) +
+                glob.glob(os.path.join(d, '*counter_collection.csv')), key=os.path.getmtime)
         rows = list(csv.DictReader(open(f)))
         keep = []
         per = collections.defaultdict(lambda: collections.defaultdict(list))
