@@ -128,12 +128,11 @@ SIGNATURES = {
                               c_p, c_p, c_p, c_p, c_p, c_z, c_p],
     'beer_normal_accumulate': [c_i, c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_z,
                                c_p],
-    'beer_mixture_estep_packed': [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
-                                  c_p, c_z, c_p],
-    'beer_frame_scales': [c_l, c_i, c_p, c_p, c_p, c_p],
+    'beer_mixture_estep_packed': [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_z,
+                                  c_p],
     'beer_normal_accumulate_packed': [c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_z, c_p],
     'beer_mixtureset_estep_packed': [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
-                                     c_p, c_z, c_p],
+                                     c_z, c_p],
     'beer_mixtureset_accumulate_packed': [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_z,
                                           c_p],
     'beer_unpack_resps': [c_l, c_i, c_p, c_p, c_p],
@@ -162,7 +161,6 @@ SIGNATURES = {
                              ctypes.c_int32, c_p, c_p, c_p],
     'beer_features_cmn': [ctypes.c_int32, c_p, ctypes.c_int32, ctypes.c_int32, c_p, c_p],
     'beer_copy_pinned': [c_p, c_p, c_z, c_p],
-    'beer_f32_split_hazard': [c_l, c_i, c_p, c_p, c_p, c_p],
     'beer_suffstats_mean': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p],
     'beer_suffstats_backward': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
 }
@@ -211,7 +209,7 @@ def _declare(l):
 
 def dtype_code(dtype, exact=False):
     '''BEER_F32 / BEER_F64 of a torch dtype; `exact` adds BEER_EXACT (float32
-    products on the exact fp32 MFMA instead of the split-fp16 arithmetic).'''
+    products on the exact fp32 MFMA instead of the bf16x3 arithmetic).'''
     if dtype == torch.float32:
         return F32 | EXACT if exact else F32
     if dtype == torch.float64:
@@ -255,16 +253,18 @@ def call(name, *args):
 
 
 EXACT = 0x10                # BEER_EXACT of include/beer_hip.h: `dtype | EXACT`
-F32_MODES = ('exact', 'split_f16')
+F32_MODES = ('exact', 'bf16x3')
 # Host-side policy (the library itself keeps no mode: the arithmetic is an
-# argument of every call): initial value from BEER_F32_MODE=exact | split_f16.
-_f32_mode = ['exact' if os.environ.get('BEER_F32_MODE') in ('exact', 'f32') else 'split_f16']
+# argument of every call): initial value from BEER_F32_MODE=exact | bf16x3.
+_f32_mode = ['exact' if os.environ.get('BEER_F32_MODE') in ('exact', 'f32') else 'bf16x3']
 
 
 def set_f32_mode(mode):
     '''How float32 models multiply on the matrix cores: 'exact' (fp32 MFMA,
-    bitwise an fmaf chain) or 'split_f16' (default: two fp16 halves per
-    operand, three fp16 MFMAs per product, fp32 accumulation; 5x the rate).'''
+    bitwise an fmaf chain) or 'bf16x3' (default: every operand exactly as three
+    bf16 pieces, the six leading partial products of each multiplication on the
+    bf16 MFMA, fp32 accumulation -- fp32's own operands and accumulation, product
+    error <= 2^-23, at 2.7x the fp32 pipe's rate).'''
     if mode not in F32_MODES:
         raise ValueError(f'f32 mode {mode!r}: expected one of {F32_MODES}')
     _f32_mode[0] = mode
@@ -274,69 +274,18 @@ def get_f32_mode():
     return _f32_mode[0]
 
 
-# frames smaller than this always take the exact fp32 path (it costs microseconds
-# there, and the range check below would cost a synchronisation per utterance)
-SPLIT_MIN_FRAMES = 16384
+# fewer frames than this always take the exact fp32 kernels: they cost
+# microseconds there, and the bf16x3 path has per-call set-up (the packed
+# parameter image, the tile images of the hand-over)
+FAST_MIN_FRAMES = 16384
 
 
-def _range_owner(X):
-    '''The tensor object the range verdicts of `X` live on: its base when `X` is
-    a view (a slice of a resident shard), so that every sub-batch of one shard
-    shares one memo, and the memo dies with the data.'''
-    base = X._base
-    return X if base is None else base
-
-
-def f32_split_ok(X):
-    '''True when float32 frames `X` [T, D] may take the fp16-split matrix path:
-    the mode is on, there are enough frames, and no dimension has outliers more
-    than 2^9 times its mean magnitude (checked on the GPU, one small
-    synchronisation the first time a tensor is seen).  The verdict is remembered
-    ON the tensor (its base for views) together with the version counter -- never
-    by address: a new minibatch that the allocator places where an old one lived
-    is a new object and is checked again.'''
-    if X.dtype != torch.float32 or get_f32_mode() != 'split_f16':
-        return False
-    if X.shape[0] < SPLIT_MIN_FRAMES or X.shape[1] > 64:
-        return False
-    owner = _range_owner(X)
-    memo = owner.__dict__.get('_beer_range_memo')
-    if memo is None or memo[0] != owner._version:
-        memo = (owner._version, {})
-        owner.__dict__['_beer_range_memo'] = memo
-    key = (X.storage_offset(), tuple(X.shape), tuple(X.stride()))
-    hit = memo[1].get(key)
-    if hit is None:
-        scratch = torch.empty(1024, dtype=torch.uint8, device=X.device)
-        flag = torch.empty(1, dtype=torch.int32, device=X.device)
-        call('beer_f32_split_hazard', X.shape[0], X.shape[1], ptr(X), ptr(scratch), ptr(flag))
-        hit = int(flag.item()) == 0
-        if len(memo[1]) > 256:
-            memo[1].clear()
-        memo[1][key] = hit
-    return hit
-
-
-def frame_scales(X):
-    '''The split arithmetic's per-dimension scales of float32 frames `X` [T, D]
-    (`beer_frame_scales`: [128] float32 on the device), computed once per tensor
-    version and remembered on the tensor like the range check above -- the frames
-    of a training run are the same in every VB iteration.'''
-    owner = _range_owner(X)
-    memo = owner.__dict__.get('_beer_scales_memo')
-    if memo is None or memo[0] != owner._version:
-        memo = (owner._version, {})
-        owner.__dict__['_beer_scales_memo'] = memo
-    key = (X.storage_offset(), tuple(X.shape), tuple(X.stride()))
-    hit = memo[1].get(key)
-    if hit is None:
-        hit = torch.empty(128, dtype=torch.float32, device=X.device)
-        scratch = torch.empty(256, dtype=torch.uint8, device=X.device)
-        call('beer_frame_scales', X.shape[0], X.shape[1], ptr(X), ptr(hit), ptr(scratch))
-        if len(memo[1]) > 256:
-            memo[1].clear()
-        memo[1][key] = hit
-    return hit
+def f32_fast_ok(X):
+    '''True when float32 frames `X` [T, D] take the bf16x3 matrix path: the mode
+    is on and there are enough frames.  No look at the data is needed -- three
+    bf16 pieces hold any float32 value exactly -- so the answer costs nothing.'''
+    return X.dtype == torch.float32 and get_f32_mode() == 'bf16x3' and \
+        X.shape[0] >= FAST_MIN_FRAMES and X.shape[1] <= 64
 
 
 class exact_f32:

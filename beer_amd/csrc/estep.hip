@@ -335,7 +335,7 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
                          ws_bytes >= beer_mfma::estep_workspace_bytes(sizeof(T), cov, D, S, G);
     const bool padded = sizeof(T) == 4 && !exact && !comp_resps &&
                         beer_mfma::supported_llh_split(D, S, G) &&
-                        ws_bytes >= beer_mfma::estep16_workspace_bytes(cov, D, S, G);
+                        ws_bytes >= beer_mfma::estepx_workspace_bytes(cov, D, S, G);
     const bool mfma_ok = !labels && !pc_llh && stat_scale == 1.0 && ws && (aligned || padded) &&
                          (log_norm || comp_resps || llh_sum);
     if (need_norm && !w_buf && !mfma_ok) {
@@ -353,12 +353,12 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
     if (mfma_ok) {
         // gfx950 matrix-core path: GEMM + (grouped) softmax fused, one kernel
         if (sizeof(T) == 4 && !exact &&
-            ws_bytes >= beer_mfma::estep16_workspace_bytes(cov, D, S, G) &&
+            ws_bytes >= beer_mfma::estepx_workspace_bytes(cov, D, S, G) &&
             (padded || beer_mfma::supported_llh(D, S, G)))
-            return beer_mfma::estep_f16x3(cov, nframes, D, S, G, (const float*)X,
-                                          (const float*)expT, (const float*)logw,
-                                          (float*)comp_resps, (float*)log_norm, llh_sum, ws,
-                                          ws_bytes, s);
+            return beer_mfma::estep_bf16x3(cov, nframes, D, S, G, (const float*)X,
+                                           (const float*)expT, (const float*)logw,
+                                           (float*)comp_resps, (float*)log_norm, llh_sum, ws,
+                                           ws_bytes, s);
         return sizeof(T) == 4
                    ? beer_mfma::estep_f32(cov, nframes, D, S, G, (const float*)X,
                                           (const float*)expT, (const float*)logw,
@@ -437,12 +437,12 @@ int accumulate_launch(int cov, int64_t nframes, int D, int S, int G, const void*
     BEER_REQUIRE(X && acc);
     if (nframes == 0) return BEER_OK;
     hipStream_t s = as_stream(stream);
+    // (float32 responsibilities [T, K] in memory: the exact fp32 / fp64 MFMA kernels;
+    // the bf16x3 accumulation takes packed tiles -- beer_pack_resps +
+    // beer_normal_accumulate_packed -- whose size depends on T)
+    (void)exact;
     if (cr && ws && beer_mfma::supported_acc(D, S * G) &&
         ws_bytes >= beer_mfma::acc_workspace_bytes(cov, D, S * G)) {
-        if (sizeof(T) == 4 && !exact &&
-            ws_bytes >= beer_mfma::acc16_workspace_bytes(cov, D, S * G))
-            return beer_mfma::acc_f16x3(cov, nframes, D, S, G, (const float*)X, (const float*)cr,
-                                        (const float*)sr, acc, ws, ws_bytes, s);
         return sizeof(T) == 4
                    ? beer_mfma::acc_f32(cov, nframes, D, S, G, (const float*)X, (const float*)cr,
                                         (const float*)sr, acc, ws, ws_bytes, s)
@@ -486,25 +486,14 @@ size_t beer_estep_workspace_bytes(int dtype, int cov, int D, int S, int G) {
     dtype &= ~BEER_EXACT;
     const size_t exact = beer_mfma::estep_workspace_bytes(dtype == BEER_F64 ? 8 : 4, cov, D, S, G);
     if (dtype == BEER_F64) return exact;
-    const size_t split = beer_mfma::estep16_workspace_bytes(cov, D, S, G);
+    const size_t split = beer_mfma::estepx_workspace_bytes(cov, D, S, G);
     return exact > split ? exact : split;                 // either fp32 mode fits
-}
-
-int beer_f32_split_hazard(int64_t T, int D, const void* X, void* scratch, int* hazard,
-                          void* stream) {
-    BEER_REQUIRE(T >= 0 && D >= 1 && D <= 64 && scratch && hazard);
-    if (T == 0) return hipMemsetAsync(hazard, 0, sizeof(int), as_stream(stream)) == hipSuccess
-                           ? BEER_OK : BEER_EINVAL;
-    BEER_REQUIRE(X);
-    return beer_mfma::f16_range_hazard(T, D, (const float*)X, scratch, hazard, as_stream(stream));
 }
 
 size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G) {
     if (cov < 0 || cov > 2) return 0;
-    dtype &= ~BEER_EXACT;
-    const size_t exact = beer_mfma::acc_workspace_bytes(cov, D, S * G);
-    const size_t split = dtype == BEER_F64 ? 0 : beer_mfma::acc16_workspace_bytes(cov, D, S * G);
-    return exact > split ? exact : split;
+    (void)dtype;
+    return beer_mfma::acc_workspace_bytes(cov, D, S * G);
 }
 
 int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G, const void* X,
@@ -515,26 +504,18 @@ int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G, c
                   state_resps, acc, workspace, workspace_bytes, stream, exact);
 }
 
-int beer_frame_scales(int64_t T, int D, const float* X, float* scales, void* scratch,
-                      void* stream) {
-    BEER_REQUIRE(T >= 0 && D >= 1 && D <= 64 && scales && scratch && (X || T == 0));
-    return beer_mfma::frame_scales(T, D, X, scales, scratch, as_stream(stream));
-}
-
 int beer_mixture_estep_packed(int cov, int64_t T, int D, int K, const float* X,
                               const float* exp_stats, const float* log_weights, float* log_norm,
-                              void* packed_resps, double* llh_sum, const float* frame_scales,
-                              const float* moments, void* workspace, size_t workspace_bytes,
-                              void* stream) {
+                              void* packed_resps, double* llh_sum, void* workspace,
+                              size_t workspace_bytes, void* stream) {
     BEER_REQUIRE(T >= 0 && D >= 1 && K >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(X && exp_stats && log_weights && packed_resps && workspace);
     BEER_REQUIRE(beer_mfma::supported_llh(D, 1, K));
-    BEER_REQUIRE(workspace_bytes >= beer_mfma::estep16_workspace_bytes(cov, D, 1, K));
+    BEER_REQUIRE(workspace_bytes >= beer_mfma::estepx_workspace_bytes(cov, D, 1, K));
     if (T == 0) return BEER_OK;
-    return beer_mfma::estep_f16x3(cov, T, D, 1, K, X, exp_stats, log_weights,
-                                  reinterpret_cast<float*>(packed_resps), log_norm, llh_sum,
-                                  workspace, workspace_bytes, as_stream(stream), true,
-                                  frame_scales, moments);
+    return beer_mfma::estep_bf16x3(cov, T, D, 1, K, X, exp_stats, log_weights,
+                                   reinterpret_cast<float*>(packed_resps), log_norm, llh_sum,
+                                   workspace, workspace_bytes, as_stream(stream), true);
 }
 
 int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float* X,
@@ -543,10 +524,10 @@ int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float*
     BEER_REQUIRE(T >= 0 && D >= 1 && K >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(X && packed_resps && acc && workspace);
     BEER_REQUIRE(beer_mfma::supported_acc(D, K));
-    BEER_REQUIRE(workspace_bytes >= beer_mfma::acc16p_workspace_bytes(cov, T, D, K));
+    BEER_REQUIRE(workspace_bytes >= beer_mfma::accx_workspace_bytes(cov, T, D, K));
     if (T == 0) return BEER_OK;
-    return beer_mfma::acc_f16x3_packed(cov, T, D, K, X, packed_resps, acc, workspace,
-                                       workspace_bytes, as_stream(stream));
+    return beer_mfma::acc_bf16x3_packed(cov, T, D, K, X, packed_resps, acc, workspace,
+                                        workspace_bytes, as_stream(stream));
 }
 
 int beer_mixtureset_packed_supported(int cov, int D, int S, int G) {
@@ -557,23 +538,21 @@ int beer_mixtureset_packed_supported(int cov, int D, int S, int G) {
 
 size_t beer_mixtureset_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int S, int G) {
     if (T < 0 || !beer_mixtureset_packed_supported(cov, D, S, G)) return 0;
-    return beer_mfma::acc16s_workspace_bytes(cov, T, D, S, G);
+    return beer_mfma::accxs_workspace_bytes(cov, T, D, S, G);
 }
 
 int beer_mixtureset_estep_packed(int cov, int64_t T, int D, int S, int G, const float* X,
                                  const float* exp_stats, const float* log_weights,
                                  float* log_norm, void* packed_resps, double* llh_sum,
-                                 const float* moments, void* workspace, size_t workspace_bytes,
-                                 void* stream) {
+                                 void* workspace, size_t workspace_bytes, void* stream) {
     BEER_REQUIRE(T >= 0 && D >= 1 && S >= 1 && G >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(X && exp_stats && packed_resps && workspace);
     BEER_REQUIRE(beer_mixtureset_packed_supported(cov, D, S, G));
-    BEER_REQUIRE(workspace_bytes >= beer_mfma::estep16_workspace_bytes(cov, D, S, G));
+    BEER_REQUIRE(workspace_bytes >= beer_mfma::estepx_workspace_bytes(cov, D, S, G));
     if (T == 0) return BEER_OK;
-    return beer_mfma::estep_f16x3(cov, T, D, S, G, X, exp_stats, log_weights,
-                                  reinterpret_cast<float*>(packed_resps), log_norm, llh_sum,
-                                  workspace, workspace_bytes, as_stream(stream), true, nullptr,
-                                  moments);
+    return beer_mfma::estep_bf16x3(cov, T, D, S, G, X, exp_stats, log_weights,
+                                   reinterpret_cast<float*>(packed_resps), log_norm, llh_sum,
+                                   workspace, workspace_bytes, as_stream(stream), true);
 }
 
 int beer_mixtureset_accumulate_packed(int cov, int64_t T, int D, int S, int G, const float* X,
@@ -583,10 +562,10 @@ int beer_mixtureset_accumulate_packed(int cov, int64_t T, int D, int S, int G, c
     BEER_REQUIRE(T >= 0 && D >= 1 && S >= 1 && G >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(X && packed_resps && state_resps && acc && workspace);
     BEER_REQUIRE(beer_mixtureset_packed_supported(cov, D, S, G));
-    BEER_REQUIRE(workspace_bytes >= beer_mfma::acc16s_workspace_bytes(cov, T, D, S, G));
+    BEER_REQUIRE(workspace_bytes >= beer_mfma::accxs_workspace_bytes(cov, T, D, S, G));
     if (T == 0) return BEER_OK;
-    return beer_mfma::acc_f16x3_packed(cov, T, D, S * G, X, packed_resps, acc, workspace,
-                                       workspace_bytes, as_stream(stream), S, G, state_resps);
+    return beer_mfma::acc_bf16x3_packed(cov, T, D, S * G, X, packed_resps, acc, workspace,
+                                        workspace_bytes, as_stream(stream), S, G, state_resps);
 }
 
 size_t beer_accumulate_fused_workspace_bytes(int cov, int D, int S, int G) {
@@ -604,9 +583,9 @@ int beer_mixtureset_accumulate_fused(int cov, int64_t T, int D, int S, int G, co
     BEER_REQUIRE(workspace && workspace_bytes >= beer_mfma::accf_workspace_bytes(cov, D, S, G));
     if (T == 0) return BEER_OK;
     BEER_REQUIRE(X && exp_stats && log_norm && acc);
-    return beer_mfma::acc_fused_f16x3(cov, T, D, S, G, X, exp_stats, log_weights, log_norm,
-                                      state_resps, acc, workspace, workspace_bytes,
-                                      as_stream(stream));
+    return beer_mfma::acc_fused_bf16x3(cov, T, D, S, G, X, exp_stats, log_weights, log_norm,
+                                       state_resps, acc, workspace, workspace_bytes,
+                                       as_stream(stream));
 }
 
 size_t beer_packed_resps_bytes(int64_t T, int D, int K) {
@@ -615,7 +594,7 @@ size_t beer_packed_resps_bytes(int64_t T, int D, int K) {
 
 size_t beer_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int K) {
     if (cov < 0 || cov > 2 || T < 0 || D < 1 || K < 1) return 0;
-    return beer_mfma::acc16p_workspace_bytes(cov, T, D, K);
+    return beer_mfma::accx_workspace_bytes(cov, T, D, K);
 }
 
 int beer_pack_resps(int64_t T, int D, int S, int G, const float* X, const float* comp_resps,

@@ -1,0 +1,1565 @@
+// fp32 E-step on the bf16 matrix pipes ("bf16x3").
+//
+// gfx950 runs v_mfma_f32_16x16x4_f32 at 1/16 of the rate of
+// v_mfma_f32_16x16x32_bf16 (MI355X_MICROARCH.md: 157 TF vs 2.5 PF dense).  Both
+// GEMMs of the E-step are therefore evaluated with every fp32 operand held
+// EXACTLY as three bf16 pieces, v = p0 + p1 + p2 (3 x 8 significand bits = the 24
+// of fp32; bf16 has fp32's exponent range: no scaling, no range hazards), and the
+// six leading partial products of each multiplication, accumulated in fp32:
+//
+//     a * b  ~=  a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0)
+//
+// What is dropped (a1 b2 + a2 b1 + a2 b2) is below 2^-23 |a b| in the worst case
+// and 2^-25 |a b| typically, with no systematic sign (the pieces are rounded to
+// nearest): the operands are fp32's own, each product is as accurate as an fp32
+// multiply, the accumulation IS fp32 -- 6 MFMAs of 16 cycles per 32-deep step
+// against 8 MFMAs of 32 cycles on the fp32 pipe: 2.7x its rate.
+//
+// Same slab enumeration, component interleave and softmax epilogue as
+// estep_mfma.hip; one k-step of the bf16 MFMA (32 deep) covers 8 slabs, lane
+// k-block g (8 values) = slabs 8s+2g and 8s+2g+1.
+//
+// Operand mapping of v_mfma_f32_16x16x32_bf16 (lane l: i = l & 15, g = l >> 4):
+// A[i][k = 8g..8g+7], B[k = 8g..8g+7][n = i], C/D row 4g + r, column i.
+//
+// Reference restated: beer/dists/normalwishart.py:30-38, 88-92,
+// beer/models/mixture.py:79-101, beer/models/mixtureset.py:85-112,
+// beer/models/normalset.py:117-123.
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "estep_mfma.h"
+#include "estep_tiles.h"
+
+namespace beer_mfma {
+
+namespace {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NP = kPackedPieces;      // pieces per operand
+// the six products (piece of A, piece of B), by decreasing weight
+constexpr int kProdA[6] = {0, 0, 1, 0, 1, 2};
+constexpr int kProdB[6] = {0, 1, 0, 2, 1, 0};
+
+__device__ __forceinline__ bf8 as_bf8(const u4& w) { return __builtin_bit_cast(bf8, w); }
+__device__ __forceinline__ f32x4 mfma_bf16(const u4& a, const u4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(a), as_bf8(b), c, 0, 0, 0);
+}
+
+// k-steps (8 slabs each), padded to an even count: the K1 loop is unrolled by two
+__host__ __device__ inline int nk16_of(int cov, int D) {
+    return ((nslab_of(cov, D) + 7) / 8 + 1) / 2 * 2;
+}
+// Row stride (floats) of K1's LDS frame tile: the D values, the constants 1 and
+// 2^-24 and at least 6 zeros (the padding slabs read them), with stride / 4 odd --
+// the 16 rows of an A-fragment ds_read_b128 then start in 16 different 16-byte
+// slots of the 256-byte bank row.
+__host__ __device__ inline int ld16_of(int D) {
+    const int ld = 4 * d4_of(D) + 8;
+    return (ld / 4) % 2 ? ld : ld + 4;
+}
+// A frame row carries 2^-24 next to its 1: the constant term of a component
+// (-.5 E[.] + .5 E[.] - D/2 ln 2 pi + ln w, a sum of the size of the logit itself) is
+// stored as fp32 value + remainder * 2^24 in the second entry of the constant slab,
+// 48 bits in all -- its own rounding (up to 4e-6 at |c| ~ 100, the same for every
+// frame of the component) would otherwise be the largest systematic term left.
+constexpr float kConstEps = 5.9604644775390625e-8f;      // 2^-24
+constexpr int kBlockU4 = NP * 64;      // u4 per (k-step, tile) block of the P image: 3 KiB
+
+// Value of contraction entry (slab, e) for component k (the logic of pack_kernel in
+// estep_mfma.hip); the constant slabs are filled by the caller (const_share).
+__device__ inline double entry_value(int cov, int D, int K, int k, int slab, int e,
+                                     const float* __restrict__ row, bool* is_const) {
+    const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(cov, D);
+    *is_const = false;
+    if (slab >= nslab) return 0.0;
+    const int t = slab_entry(cov, D, slab);
+    const int a = t & 0xff, b = ((t >> 8) & 0xff) + e, sq = t >> 16;
+    if (a == Dp && b - e == Dp) {
+        *is_const = true;
+        return 0.0;
+    }
+    if (k >= K) return 0.0;
+    if (sq) return b < D ? -0.5 * (double)row[cov == BEER_ISO ? D : D + b] : 0.0;
+    if (a < D) {
+        if (b >= D || b < a) return 0.0;
+        return b == a ? -0.5 * (double)row[D + a * D + a]
+                      : -0.5 * ((double)row[D + a * D + b] + (double)row[D + b * D + a]);
+    }
+    return b < D ? (double)row[b] : 0.0;
+}
+
+// c0[0] = the largest constant term of any component (-1/2 E[.] + 1/2 E[.] - D/2 ln 2 pi
+// + ln w): at a freshly initialised model the constants (log-determinants ...) are two
+// thirds of a logit and nearly the same for every component.  A softmax does not see a
+// common offset, the accumulators' rounding does (it happens at the size of the
+// running sum): the packed image carries every constant minus c0 and the epilogue
+// adds c0 back to the log-normalisers.
+__global__ __launch_bounds__(256) void const_max_kernel(int cov, int D, int K,
+                                                        const float* __restrict__ E,
+                                                        const float* __restrict__ logw,
+                                                        float* __restrict__ c0) {
+    __shared__ double red[8];
+    const int Q = stats_dim(cov, D);
+    double m = -1.0e300;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const double v = const_total(cov, D, E + (size_t)k * Q, logw ? (double)logw[k] : 0.0);
+        if (v == v && v > m && v < 1.0e300) m = v;
+    }
+    m = block_max(m, red);
+    if (threadIdx.x == 0) c0[0] = m > -1.0e300 ? (float)m : 0.f;
+}
+
+// One workgroup per (padded) component: its three bf16 planes at
+// P[chunk][kstep][tile][piece][64 lanes x 8] and the slab table.  Component SLOT
+// blockIdx.x of the image is component (slot / Gp) * G + slot % Gp when slot % Gp < G,
+// else padding (G <= Gp: the groups of a mixture set padded so that any number of
+// components per state runs on the group-aligned kernels; G == Gp: slots are
+// components).  Padded slots carry the logit -1e30.
+__global__ __launch_bounds__(256) void packx_kernel(int cov, int D, int K, int NT,
+                                                    const float* __restrict__ E,
+                                                    const float* __restrict__ logw,
+                                                    unsigned short* __restrict__ P,
+                                                    int* __restrict__ tab, int G, int Gp,
+                                                    const float* __restrict__ c0) {
+    extern __shared__ __attribute__((aligned(16))) char pack_lds[];
+    const int nk = nk16_of(cov, D), nent = nk * 32;
+    const int slot = blockIdx.x;
+    const int k = slot % Gp < G ? (slot / Gp) * G + slot % Gp : K;     // K: a padded slot
+    const int chunk = slot / (NT * 16), kk = slot % (NT * 16);
+    const int c = 4 * (kk / 64) + (kk % 4), i = (kk % 64) / 4;
+    if (slot == 0)
+        for (int s = threadIdx.x; s < (nk + 1) * 8; s += blockDim.x) {
+            // padding slabs read the zero columns behind the constants of a frame row
+            const int Dp = 4 * d4_of(D);
+            tab[s] = s < nslab_of(cov, D) ? slab_entry(cov, D, s) : ((Dp + 2) | ((Dp + 4) << 8));
+        }
+    // the component's expected statistics, staged once (the entries are gathered from
+    // all over the row: from global memory every gather was a dependent L2 round trip)
+    const int Qs = stats_dim(cov, D);
+    float* rowl = reinterpret_cast<float*>(pack_lds);
+    if (k < K)
+        for (int q = threadIdx.x; q < Qs; q += blockDim.x) rowl[q] = E[(size_t)k * Qs + q];
+    __syncthreads();
+    unsigned short* base = P + ((size_t)chunk * nk * NT) * (NP * 512);
+    auto put = [&](int q, float v) {
+        const int s = q / 32, g = (q % 32) / 8, j = q % 8;
+        unsigned short* dst = base + ((size_t)s * NT + c) * (NP * 512) + (g * 16 + i) * 8 + j;
+        unsigned short p[3];
+        split3_scalar(v, p);
+        dst[0] = p[0];
+        dst[512] = p[1];
+        dst[1024] = p[2];
+    };
+    const int nslab = nslab_of(cov, D);
+    for (int q = threadIdx.x; q < nent; q += blockDim.x) {
+        bool is_const;
+        const double v = entry_value(cov, D, K, k, q / 4, q % 4, rowl, &is_const);
+        if (!is_const) {
+            put(q, (float)v);
+        } else if (q % 4 == 0) {
+            // value + remainder * 2^24: entries (constant slab, 0) and (constant slab, 1);
+            // a padded component gets its -1e30 in the final constant slab
+            const bool last = q / 4 == nslab - 1;
+            const double want = k < K ? const_share(cov, D, q / 4, rowl, logw ? (double)logw[k] : 0.0) -
+                                            (last ? (double)c0[0] : 0.0)
+                                      : (last ? kPadLogit : 0.0);
+            const float hi = (float)want;
+            const double rem = (want - (double)hi) * (1.0 / (double)kConstEps);
+            put(q, hi);
+            put(q + 1, (rem == rem && fabs(rem) < 1.0e30) ? (float)rem : 0.f);
+            put(q + 2, 0.f);
+            put(q + 3, 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Several component chunks over the same frames: a 1-D grid whose blocks are dealt to
+// the 8 XCDs round-robin, laid out so that the chunk blocks of one frame block are
+// neighbours on ONE XCD (they read the same frames at about the same time: one L2
+// miss, the others hit -- with a (frames, chunks) grid every chunk pass streamed the
+// frames from HBM again).  The chunks are taken `cg` at a time (all frame blocks for
+// chunks 0 .. cg-1, then the next cg): the packed parameters of the cg chunks an XCD
+// works on must stay in its 4 MiB L2.  Grid size xcd_grid(nx, ny, cg); false =
+// padding block.
+// ---------------------------------------------------------------------------
+inline int xcd_chunk_group(int ny, size_t chunk_bytes) {
+    int cg = (int)((size_t)(2 << 20) / (chunk_bytes ? chunk_bytes : 1));
+    return cg < 1 ? 1 : (cg > ny ? ny : cg);
+}
+inline unsigned xcd_grid(int64_t nx, int ny, int cg) {
+    return (unsigned)((nx + 7) / 8 * 8 * cg * ((ny + cg - 1) / cg));
+}
+__device__ inline bool xcd_block(int64_t nx, int ny, int cg, int64_t& bx, int& by) {
+    const unsigned per_group = (unsigned)((nx + 7) / 8 * 8 * cg);
+    const unsigned grp = blockIdx.x / per_group, rem = blockIdx.x - grp * per_group;
+    const unsigned xcd = rem & 7, slot = rem >> 3;
+    by = (int)(grp * cg + slot % (unsigned)cg);
+    bx = (int64_t)(slot / (unsigned)cg) * 8 + xcd;
+    return bx < nx && by < ny;
+}
+
+// Rows of a frame tile from global memory into a wave's LDS image: FW rows, LPR =
+// 64 / FW lanes per row, a lane takes the 16-byte pieces h, h + LPR, .. of its row.
+// All loads are issued back to back on clamped piece numbers (a load behind a branch
+// is issued and waited for on its own); rows past the end are zeros.
+template <int FW>
+__device__ __forceinline__ void stage_rows(const float* __restrict__ X, int64_t fb,
+                                           int64_t nframes, int D, int LD, int lane,
+                                           float* __restrict__ xw) {
+    const int Dp = 4 * d4_of(D);
+    if ((D & 3) == 0) {
+        constexpr int LPR = 64 / FW, NPC = 16 / LPR;          // pieces per lane (D <= 64)
+        const int C4 = D >> 2, r = lane & (FW - 1), h = lane / FW;
+        const int64_t f = fb + r;
+        const bool valid = f < nframes;
+        const f32x4* src = reinterpret_cast<const f32x4*>(X) + (valid ? f : nframes - 1) * C4;
+        f32x4 xv[NPC];
+#pragma unroll
+        for (int it = 0; it < NPC; ++it) {
+            const int pc = h + LPR * it;
+            xv[it] = src[pc < C4 ? pc : C4 - 1];
+        }
+#pragma unroll
+        for (int it = 0; it < NPC; ++it) {
+            const int pc = h + LPR * it;
+            if (pc < C4)
+                *reinterpret_cast<f32x4*>(xw + r * LD + 4 * pc) =
+                    valid ? xv[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // columns D .. LD - 1: the constants 1, 2^-24 at Dp (= D), zeros behind them
+        for (int idx = lane; idx < FW * ((LD - D) / 4); idx += 64) {
+            const int rr = idx / ((LD - D) / 4), hh = idx - rr * ((LD - D) / 4);
+            *reinterpret_cast<f32x4*>(xw + rr * LD + D + 4 * hh) =
+                f32x4{hh == 0 ? 1.f : 0.f, hh == 0 ? kConstEps : 0.f, 0.f, 0.f};
+        }
+    } else {
+        for (int idx = lane; idx < FW * LD; idx += 64) {
+            const int r = idx / LD, c = idx - r * LD;
+            const int64_t f = fb + r;
+            float v = 0.f;
+            if (c < D) { if (f < nframes) v = X[f * D + c]; }
+            else if (c == Dp) v = 1.f;
+            else if (c == Dp + 1) v = kConstEps;
+            xw[idx] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1 on the bf16 pipes: one wave owns 16 MT frames x 16 NT components (a chunk of
+// the K components: blockIdx via xcd_block when there are several).  The large
+// form (MT = 4, NT = 16: 64 frames x 256 components, 256 accumulators, one wave per
+// SIMD) builds every A fragment once for 256 components: the fragment arithmetic
+// (4 products + 4.5 VALU per element for the three-way split) is what the fp16
+// two-piece kernel of round 2 was bound by, with half the MFMAs per element.
+// A fragments are built one k-step ahead, in slices between the MFMA batches; B
+// fragments (three 16-byte loads per tile from the packed image) one batch of BT
+// tiles ahead.
+// SQ = false: no "square" slabs in the table (full covariance), the per-product
+// select between x_j^2 and x_a x_j drops out of the A-fragment arithmetic.
+// ---------------------------------------------------------------------------
+template <int NT, int MT, int GQ, bool PACKED, bool SQ, bool LNO>
+__global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
+    int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nk,
+    const float* __restrict__ X, const u4* __restrict__ Pall, const int* __restrict__ tab,
+    float* __restrict__ resps, float* __restrict__ log_norm, double* __restrict__ llh_sum,
+    float* __restrict__ xt_out, int xt_floats, int nku, int cg, const float* __restrict__ c0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int LD = ld16_of(D);                                // 16-byte aligned rows
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    constexpr int FW = 16 * MT, NW = kThreads / 64;
+    float* xw = reinterpret_cast<float*>(smem) + wave * (FW * LD);
+    int* tabs = reinterpret_cast<int*>(reinterpret_cast<float*>(smem) + NW * FW * LD);
+    int64_t bx = blockIdx.x;
+    int by = 0;
+    {
+        const int nch = (K + 16 * NT - 1) / (16 * NT);
+        constexpr int FBK = FW * NW;
+        if (nch > 1 && !xcd_block((nframes + FBK - 1) / FBK, nch, cg, bx, by)) return;
+    }
+    const int64_t fb = (bx * NW + wave) * FW;
+    for (int idx = tid; idx < (nk + 1) * 8; idx += kThreads) tabs[idx] = tab[idx];
+    stage_rows<FW>(X, fb, nframes, D, LD, lane, xw);
+    __syncthreads();
+    if constexpr (FW == 64) {
+        // The wave's 64 frames are one tile of the accumulation kernel: leave them
+        // behind transposed, [D + 2][68] (rows D, D + 1 = 1, 0; see xt_image_kernel,
+        // which this replaces -- one pass over the frames less).
+        if (xt_out && by == 0 && fb < (nframes + 63) / 64 * 64) {
+            float* img = xt_out + (fb / 64) * (size_t)xt_floats;
+            constexpr int XS = 68, C4 = XS / 4;
+            for (int e4 = lane; e4 < xt_floats / 4; e4 += 64) {
+                const int row = e4 / C4, c = 4 * (e4 - row * C4);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row < D) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = c + j < 64 ? xw[(c + j) * LD + row] : 0.f;
+                } else if (row == D) {
+                    v = f32x4{1.f, 1.f, 1.f, 1.f};
+                }
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(img + 4 * e4));
+            }
+        }
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[m][c] = f32x4{0, 0, 0, 0};
+
+    const float* xrow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xrow[m] = xw + (m * 16 + i) * LD;
+
+    const int kbase = by * (16 * NT);
+    // the B stream of this chunk is one linear sequence of (k-step, tile) blocks of
+    // 3 KiB = 192 u4 (three planes of 64 lanes x 16 B)
+    const u4* Pl = Pall + (size_t)by * nk * NT * kBlockU4 + lane;
+    const int* tl = tabs + 2 * g;
+
+    // A fragments as 32-bit words (two bf16 each): word w of piece q of tile m holds
+    // the entries 2w, 2w+1 of the lane's 8-deep k-block (w < 2: first slab).
+    struct AFrag { u4 w[NP][MT]; };
+    // one slab (half a k-block) of tile m of k-step s: LDS reads, 4 products, the
+    // three-way split -> words 2h, 2h+1 of every piece
+    auto make_half = [&](int s, int m, int h, AFrag& f) {
+        const int t = tl[8 * s + h];
+        const int a = t & 0xff, j = (t >> 8) & 0xff;
+        const bool sq = SQ && (t >> 16) != 0;
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(xrow[m] + j);
+        const float xx = xrow[m][a];
+        f32x4 p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[e] = bb[e] * (sq ? bb[e] : xx);     // v_cndmask, no branch
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            unsigned w3[3];
+            split3(p[2 * e], p[2 * e + 1], w3);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) f.w[q][m][2 * h + e] = w3[q];
+        }
+    };
+    // B fragments: BT column tiles per batch, loaded one batch ahead of their MFMAs
+    // (sched_group_barrier pins the loads above the MFMA block: hipcc otherwise sinks
+    // every load next to its first use)
+    constexpr int BT = 2, NBATCH = NT / BT;
+    static_assert(NT % BT == 0 && NBATCH % 2 == 0, "B batches alternate between two buffers");
+    struct BFrag { u4 p[BT][NP]; };
+    auto load_b = [&](int64_t blk, BFrag& b) {               // blocks blk .. blk + BT - 1
+#pragma unroll
+        for (int c = 0; c < BT; ++c)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) b.p[c][q] = Pl[(size_t)(blk + c) * kBlockU4 + 64 * q];
+    };
+    auto batch = [&](int s, int bi, const AFrag& cur, AFrag& nxt, const BFrag& b, BFrag& bn) {
+        // P is padded by one batch (bi + 1 = NBATCH: first batch of the next k-step)
+        load_b((int64_t)s * NT + (bi + 1) * BT, bn);
+        // slices of the next A: MT * 2 halves over the NBATCH batches
+        // (half-major: the halves of one batch share the table entry)
+#pragma unroll
+        for (int hh = bi * MT * 2 / NBATCH; hh < (bi + 1) * MT * 2 / NBATCH; ++hh)
+            make_half(s + 1, hh % MT, hh / MT, nxt);         // the table is padded by one k-step
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+            for (int c = 0; c < BT; ++c)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m][bi * BT + c] = mfma_bf16(cur.w[kProdA[pr]][m], b.p[c][kProdB[pr]],
+                                                    acc[m][bi * BT + c]);
+        __builtin_amdgcn_sched_group_barrier(0x020, NP * BT, 0);         // VMEM reads
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * ((MT * 2 + NBATCH - 1) / NBATCH), 0);   // DS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT * BT, 0);     // MFMA
+    };
+    auto kstep = [&](int s, const AFrag& cur, AFrag& nxt, BFrag& b0, BFrag& b1) {
+#pragma unroll
+        for (int bi = 0; bi < NBATCH; bi += 2) {
+            batch(s, bi, cur, nxt, b0, b1);
+            batch(s, bi + 1, cur, nxt, b1, b0);
+        }
+    };
+    AFrag f0, f1;
+    BFrag b0, b1;
+#pragma unroll
+    for (int hh = 0; hh < MT * 2; ++hh) make_half(0, hh % MT, hh / MT, f0);
+    load_b(0, b0);
+    // (the image is padded to an even number of k-steps; only those that hold slabs run)
+    for (int s = 0; s < nku; s += 2) {
+        kstep(s, f0, f1, b0, b1);
+        if (s + 1 < nku) kstep(s + 1, f1, f0, b0, b1);
+    }
+    softmax_epilogue<float, NT, MT, GQ, PACKED, LNO>(acc, fb, nframes, kbase, K, S, G, gl, jw, i,
+                                                     g, lane, resps, log_norm, llh_sum, c0[0]);
+}
+
+// covariance type of the E-step being launched (the launch helpers below take the
+// shape, not the type; SQ = false kernels are full covariance by construction)
+thread_local int g_cov_of_launch = BEER_FULL;
+
+template <int NT, int MT, int GQ, bool PACKED = false, bool SQ = true, bool LNO = false>
+int launch_llhx(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nchunks, int nk,
+                const float* X, const void* P, const int* tab, const float* c0, float* resps,
+                float* log_norm, double* llh_sum, hipStream_t s, float* xt_out = nullptr,
+                int xt_floats = 0) {
+    const int LD = ld16_of(D);
+    // k-steps that hold slabs: the slab count is the table's (full: SQ = false)
+    const int nku = (nslab_of(SQ ? g_cov_of_launch : BEER_FULL, D) + 7) / 8;
+    constexpr int FB = 16 * MT * (kThreads / 64);
+    const size_t lds = (size_t)FB * LD * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int);
+    const int64_t blocks = (nframes + FB - 1) / FB;
+    if (nchunks != (K + 16 * NT - 1) / (16 * NT)) return BEER_EINVAL;
+    const int cg = xcd_chunk_group(nchunks, (size_t)nku * NT * kBlockU4 * 16);
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(llhx_kernel<NT, MT, GQ, PACKED, SQ, LNO>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((llhx_kernel<NT, MT, GQ, PACKED, SQ, LNO>),
+                       dim3(nchunks > 1 ? xcd_grid(blocks, nchunks, cg) : (unsigned)blocks),
+                       dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nk, X,
+                       reinterpret_cast<const u4*>(P), tab, resps, log_norm, llh_sum, xt_out,
+                       xt_floats, nku, cg, c0);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+// ---------------------------------------------------------------------------
+// K2 on the bf16 pipes: S[k, q] += sum_t r[t,k] * PHI_q(x_t) with frames as the
+// contraction index (32 per MFMA), both operands as ready-made LDS images -- R as
+// K1 packed it (estep_tiles.h: three planes per 64 x 128 tile), X as K1 /
+// xt_image_kernel transposed it -- copied global -> LDS by the DMA path
+// (global_load_lds_dwordx4: the images are lane-linear by construction), tile t + 1
+// in flight while tile t is multiplied, one barrier per tile.
+// Workgroup = 4 waves, one per SIMD; a wave owns 128 components x 8 statistic
+// tiles (256 accumulators): A fragments = three ds_read_b128 per component tile,
+// loaded once per k-step and reused by the 8 statistic tiles; B fragments =
+// products of two X^T rows over the lane's 8 frames, split on the fly, reused by
+// the 8 component tiles.  A workgroup sums at most kAxMaxFrames frames in fp32 --
+// one rounding per 32-frame MFMA -- and adds its partial sums to the fp64 image
+// with atomics.
+// SR (mixture sets): the tiles hold the responsibilities WITHIN each state's
+// mixture (what the E-step knows); the state posteriors of the forward-backward
+// pass that ran in between arrive as transposed tiles Gt [64-frame tile][state][64
+// frames] and are multiplied in while the tile sits in LDS, each element once per
+// workgroup: (p0 + p1 + p2) * gamma in fp32, split again (in place, between the
+// arrival of the tile and its first use).  lgG = log2 of the components per state
+// (8 .. 128: the states of a 128-component block fit 4 KiB).
+// ---------------------------------------------------------------------------
+constexpr int kAxFT = 64;             // frames per LDS tile (2 k-steps)
+constexpr int kAxXS = kAxFT + 4;      // X^T row stride (floats), 16-byte aligned
+// Frames per workgroup = length of an fp32 accumulation chain (one MFMA per 32
+// frames).  The bf16 MFMA aligns its 32 products to the largest addend -- the
+// accumulator, once it has grown -- and TRUNCATES each of them toward zero at about
+// ulp(C) / 32 (measured: tools/probes/mfma_round.hip): a chain over products of one
+// sign (N_k = sum r, sum r x^2) loses ~ulp(C) / 2 per instruction, i.e. n * 2e-8 of
+// the sum after n accumulations -- 1e-5 for the 16384-frame chains of round 2, which
+// is what that round's "parameter rounding bias" really was.  64 accumulations keep
+// it at 1e-6; the partial sums of the workgroups are added in fp64.
+constexpr int kAxMaxFrames = 2048;
+constexpr int kPiece = 4096;          // granule of the X^T image (bytes)
+constexpr int kAxMC = 8, kAxNQ = 8, kAxWaves = 4;
+
+inline int xt_rows(int D) { return D + 2; }                              // + ones, zeros
+inline int xt_pieces(int D) { return (xt_rows(D) * kAxXS * 4 + kPiece - 1) / kPiece; }
+
+// X [T, D] -> per 64-frame tile the image [D + 2][kAxXS] of the frames (rows D,
+// D + 1 = the constants 1, 0; frames past T = 0), padded to whole pieces
+__global__ __launch_bounds__(256) void xt_image_kernel(int64_t nframes, int D, int NX,
+                                                       const float* __restrict__ X,
+                                                       float* __restrict__ Xt) {
+    __shared__ float tile[kAxFT * 65];
+    const int64_t tau = blockIdx.x, t0 = tau * kAxFT;
+    const int rows = (int)(nframes - t0 < kAxFT ? nframes - t0 : kAxFT);
+    for (int e = threadIdx.x; e < rows * D; e += 256) {
+        const int f = e / D, d = e - f * D;
+        tile[f * 65 + d] = X[t0 * D + e];
+    }
+    __syncthreads();
+    float* out = Xt + tau * ((size_t)NX * (kPiece / 4));
+    for (int e = threadIdx.x; e < NX * (kPiece / 4); e += 256) {
+        const int row = e / kAxXS, col = e - row * kAxXS;
+        float v = 0.f;
+        if (row < D) v = col < rows ? tile[col * 65 + row] : 0.f;
+        else if (row == D) v = 1.f;
+        __builtin_nontemporal_store(v, out + e);
+    }
+}
+
+template <int NX, bool SR>
+__global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
+    int64_t nframes, int D, int K, int nslab, const float* __restrict__ Xt,
+    const unsigned* __restrict__ Rimg, const int* __restrict__ tab,
+    int64_t frames_per_block, double* __restrict__ Sp, int gx, int gy, int gz,
+    const float* __restrict__ Gt, int lgG) {
+    constexpr int MC = kAxMC, NQ = kAxNQ, WAVES = kAxWaves, NB = 2;
+    static_assert(16 * MC == kPackedComps && kAxFT == kPackedFrames, "the packed image is this kernel's LDS tile");
+    constexpr int plane = kPackedPlaneWords * 4;                  // bytes of one piece plane
+    constexpr int NKB = NX * (kPiece / 1024) + NP * plane / 1024; // 1 KiB DMA blocks per tile
+    constexpr int buf_bytes = NKB * 1024, r_off = NX * kPiece;
+    constexpr int g_base = NB * buf_bytes;                        // SR: NB x 4 KiB of gamma^T
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int D4 = d4_of(D), Dp = 4 * D4, nq = nslab * 4;
+    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs, each with
+    // its own L2.  The gx statistic blocks that read the same R tile get ids
+    // congruent mod 8, i.e. the same XCD back to back: one of them misses in L2,
+    // the others hit.
+    const int id = blockIdx.x, xcd = id & 7, slot0 = id >> 3;
+    const int bx = slot0 % gx;
+    const int yz = (slot0 / gx) * 8 + xcd;
+    if (yz >= gy * gz) return;
+    const int by = yz % gy, bz = yz / gy;
+    const int tile0 = (bx * WAVES + wave) * NQ;
+    const int kc0 = by * (16 * MC);
+    const int64_t tb = (int64_t)bz * frames_per_block;
+    const int64_t te = tb + frames_per_block < nframes ? tb + frames_per_block : nframes;
+    const int ntiles = (int)((te - tb + kAxFT - 1) / kAxFT);
+    const int64_t tau0 = tb / kAxFT;
+    const int nblk = (K + 16 * MC - 1) / (16 * MC);
+    const int gbytes = SR ? ((16 * MC) >> lgG) * kAxFT * 4 : 0;   // gamma^T of one block-tile
+    const int gkb = (gbytes + 1023) >> 10;
+
+    auto factors = [&](int uu, int& a, int& b) {
+        const int col = 16 * (tile0 + uu) + i, slab = col >> 2;
+        a = b = Dp + 2;
+        if (slab < nslab) {
+            const int t = tab[slab];
+            b = ((t >> 8) & 0xff) + (col & 3);
+            a = (t >> 16) ? b : (t & 0xff);
+        }
+    };
+    // byte offsets of the lane's 8 frames (k-step 0) in the two X^T rows of its
+    // statistic column, per tile of the wave (row D = ones, row D + 1 = zeros)
+    int xa_off[NQ], xb_off[NQ];
+#pragma unroll
+    for (int uu = 0; uu < NQ; ++uu) {
+        int a, b;
+        factors(uu, a, b);
+        xa_off[uu] = ((a < D ? a : (a == Dp ? D : D + 1)) * kAxXS + 8 * g) * 4;
+        xb_off[uu] = ((b < D ? b : (b == Dp ? D : D + 1)) * kAxXS + 8 * g) * 4;
+    }
+    // A fragments: row i of component tile c, chunk (4 ks + g) ^ (i & 7)
+    int a_off[kAxFT / 32];
+#pragma unroll
+    for (int ks = 0; ks < kAxFT / 32; ++ks)
+        a_off[ks] = r_off + (i * kPackedFrames + (((4 * ks + g) ^ (i & 7)) << 3)) * 2;
+
+    f32x4 acc[MC][NQ];
+#pragma unroll
+    for (int c = 0; c < MC; ++c)
+#pragma unroll
+        for (int uu = 0; uu < NQ; ++uu) acc[c][uu] = f32x4{0, 0, 0, 0};
+
+    // DMA of tile `tile` into buffer `buf`: 1 KiB blocks kb = wave, wave + 4, ...;
+    // blocks < 4 NX from the X image, the others from the R image of block `by`
+    const char* xsrc = reinterpret_cast<const char*>(Xt);
+    const char* rsrc = reinterpret_cast<const char*>(Rimg);
+    auto stage = [&](int tile, int buf) {
+        const int64_t tau = tau0 + tile;
+#pragma unroll
+        for (int n = 0; n < (NKB + (SR ? 4 : 0) + WAVES - 1) / WAVES; ++n) {
+            const int kb = wave + WAVES * n;
+            if (kb < NKB) {
+                const char* src = kb < 4 * NX
+                    ? xsrc + (tau * NX) * (size_t)kPiece + (size_t)kb * 1024
+                    : rsrc + ((tau * nblk + by) * (size_t)(NP * plane)) + (size_t)(kb - 4 * NX) * 1024;
+                __builtin_amdgcn_global_load_lds(
+                    reinterpret_cast<const u4*>(src) + lane,
+                    (__attribute__((address_space(3))) void*)(smem + buf * buf_bytes + kb * 1024),
+                    16, 0, 0);
+            } else if (SR && kb - NKB < gkb) {
+                const char* src = reinterpret_cast<const char*>(Gt) +
+                                  (tau * nblk + by) * (size_t)gbytes + (size_t)(kb - NKB) * 1024;
+                __builtin_amdgcn_global_load_lds(
+                    reinterpret_cast<const u4*>(src) + lane,
+                    (__attribute__((address_space(3))) void*)(smem + g_base + buf * 4096 +
+                                                              (kb - NKB) * 1024),
+                    16, 0, 0);
+            }
+        }
+    };
+    // SR: this thread's share of the R image in `buf`: 4 chunks of 8 frames (row c,
+    // chunk position pos holds frames 8 (pos ^ (c & 7)) ..), all three planes, times
+    // the state's gamma
+    auto fold = [&](int buf) {
+#pragma unroll 1
+        for (int n = 0; n < 16 * MC * 8 / (64 * WAVES); ++n) {
+            const int p = tid + 64 * WAVES * n, c = p >> 3, pos = p & 7, ch = pos ^ (c & 7);
+            char* ph = smem + buf * buf_bytes + r_off + c * (kPackedFrames * 2) + pos * 16;
+            const u4 w0 = *reinterpret_cast<const u4*>(ph);
+            const u4 w1 = *reinterpret_cast<const u4*>(ph + plane);
+            const u4 w2 = *reinterpret_cast<const u4*>(ph + 2 * plane);
+            const float* gm = reinterpret_cast<const float*>(smem + g_base + buf * 4096) +
+                              ((c >> lgG) * kAxFT + 8 * ch);
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gm);
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(gm + 4);
+            u4 o0, o1, o2;
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd) {
+                // p1 + p2 is exact (16 bits), + p0 restores the float32 value
+                const float lo = (__builtin_bit_cast(float, w1[wd] << 16) +
+                                  __builtin_bit_cast(float, w2[wd] << 16)) +
+                                 __builtin_bit_cast(float, w0[wd] << 16);
+                const float hi = (__builtin_bit_cast(float, w1[wd] & 0xffff0000u) +
+                                  __builtin_bit_cast(float, w2[wd] & 0xffff0000u)) +
+                                 __builtin_bit_cast(float, w0[wd] & 0xffff0000u);
+                const float ga = wd < 2 ? g0[2 * wd] : g1[2 * wd - 4];
+                const float gb = wd < 2 ? g0[2 * wd + 1] : g1[2 * wd - 3];
+                unsigned w3[3];
+                split3(lo * ga, hi * gb, w3);
+                o0[wd] = w3[0]; o1[wd] = w3[1]; o2[wd] = w3[2];
+            }
+            *reinterpret_cast<u4*>(ph) = o0;
+            *reinterpret_cast<u4*>(ph + plane) = o1;
+            *reinterpret_cast<u4*>(ph + 2 * plane) = o2;
+        }
+    };
+    if (ntiles > 0) stage(0, 0);
+    __syncthreads();
+    if (SR && ntiles > 0) {
+        fold(0);
+        __syncthreads();
+    }
+    const bool active = tile0 * 16 < nq;
+    // Operand fragments are loaded IN PLACE ahead of the MFMAs that use them: the A
+    // fragments of the next k-step during the last statistic tile of the current one
+    // (each register right after its last use), the B fragment of statistic tile
+    // uu + 1 while tile uu is multiplied.
+    u4 af[MC][NP], bf[2][NP];
+    auto a_ptr = [&](int b, int ks, int c) {
+        return smem + a_off[ks] + (b * buf_bytes + c * 16 * kPackedFrames * 2);
+    };
+    auto gen_b = [&](int b, int ks, int uu, u4 (&out)[NP]) {
+        const char* pa = smem + xa_off[uu] + (b * buf_bytes + 128 * ks);
+        const char* pb = smem + xb_off[uu] + (b * buf_bytes + 128 * ks);
+        const f32x4 xa0 = *reinterpret_cast<const f32x4*>(pa);
+        const f32x4 xa1 = *reinterpret_cast<const f32x4*>(pa + 16);
+        const f32x4 xb0 = *reinterpret_cast<const f32x4*>(pb);
+        const f32x4 xb1 = *reinterpret_cast<const f32x4*>(pb + 16);
+        const f32x4 p0 = xa0 * xb0, p1 = xa1 * xb1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned w3[3];
+            split3(e < 2 ? p0[2 * e] : p1[2 * e - 4], e < 2 ? p0[2 * e + 1] : p1[2 * e - 3], w3);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) out[q][e] = w3[q];
+        }
+    };
+    if (active && ntiles > 0) {
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                af[c][q] = *reinterpret_cast<const u4*>(a_ptr(0, 0, c) + q * plane);
+        gen_b(0, 0, 0, bf[0]);
+    }
+    // One tile out of buffer `buf` (a constant once inlined): 16 steps of 48 MFMAs.
+    // ONE barrier per tile (two with SR), in front of the last step: by then this
+    // wave has read everything it needs from `buf` (the operands of the last step
+    // were loaded before), so the last step may load the first operands of tile + 1
+    // from the other buffer -- whose DMA, issued at the start of this tile, the
+    // barrier's vmcnt(0) has seen land -- and the next tile may overwrite `buf`.
+    auto iteration = [&](int tile, int buf) __attribute__((always_inline)) {
+        const int next = buf ^ 1;
+        if (tile + 1 < ntiles) stage(tile + 1, next);
+        const bool fold_next = SR && tile + 1 < ntiles;
+        if (active) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int uu = 0; uu < NQ; ++uu) {
+                    const bool last_uu = uu == NQ - 1, last_step = ks == 1 && last_uu;
+                    if (last_step) {
+                        __syncthreads();
+                        if (SR) {
+                            if (fold_next) fold(next);
+                            __syncthreads();
+                        }
+                    }
+                    // where the next A fragments / the next B fragment come from
+                    const int nks = last_uu ? (ks + 1) & 1 : ks;
+                    const int nbuf = last_step ? next : buf;
+                    const int cur = uu & 1;
+                    gen_b(nbuf, nks, last_uu ? 0 : uu + 1, bf[cur ^ 1]);
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                        for (int c = 0; c < MC; ++c) {
+                            acc[c][uu] = mfma_bf16(af[c][kProdA[pr]], bf[cur][kProdB[pr]], acc[c][uu]);
+                            // products 3, 4, 5 are the last users of pieces 0, 1, 2 of A[c]
+                            if (last_uu && pr >= 3)
+                                af[c][pr - 3] = *reinterpret_cast<const u4*>(
+                                    a_ptr(nbuf, nks, c) + (pr - 3) * plane);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        } else {
+            __syncthreads();
+            if (SR) {
+                if (fold_next) fold(next);
+                __syncthreads();
+            }
+        }
+    };
+    for (int tile = 0; tile < ntiles; tile += NB) {
+        iteration(tile, 0);
+        if (tile + 1 < ntiles) iteration(tile + 1, 1);
+    }
+#pragma unroll
+    for (int uu = 0; uu < NQ; ++uu) {
+        const int q = (tile0 + uu) * 16 + i;
+        if (q >= nq) continue;
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = kc0 + 16 * c + 4 * g + r;
+                if (k < K) atomicAdd(Sp + (size_t)k * nq + q, (double)acc[c][uu][r]);
+            }
+    }
+}
+
+// State posteriors [T, S] -> transposed tiles Gt [tile of 64 frames][Spad states][64
+// frames] (Spad = states of the padded component blocks; frames >= T and states >= S
+// are 0): what accx_kernel<.., SR> copies to LDS next to a tile of responsibilities.
+__global__ __launch_bounds__(256) void gt_image_kernel(int64_t nframes, int S, int Spad,
+                                                       const float* __restrict__ sr,
+                                                       float* __restrict__ Gt) {
+    __shared__ float tile[64 * 65];
+    const int64_t tau = blockIdx.x, t0 = tau * kAxFT;
+    const int s0 = blockIdx.y * 64;
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int f = idx >> 6, st = idx & 63;
+        tile[f * 65 + st] = (t0 + f < nframes && s0 + st < S) ? sr[(t0 + f) * S + s0 + st] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int st = idx >> 6, f = idx & 63;
+        if (s0 + st < Spad) Gt[(tau * Spad + s0 + st) * kAxFT + f] = tile[f * 65 + st];
+    }
+}
+
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) {
+    return __builtin_bit_cast(float, w & 0xffff0000u);
+}
+
+// packed responsibilities -> float32 (tests, callers that want to look at them)
+__global__ void unpack_resps_kernel(int64_t nframes, int K, const unsigned* __restrict__ Rimg,
+                                    float* __restrict__ R) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // (frame, k)
+    if (idx >= nframes * K) return;
+    const int64_t f = idx / K;
+    const int k = (int)(idx - f * K);
+    const int nblk = (K + kPackedComps - 1) / kPackedComps;
+    const int f6 = (int)(f % kPackedFrames);
+    const unsigned* w = Rimg + packed_word(f / kPackedFrames, nblk, k / kPackedComps,
+                                           k % kPackedComps, f6 & ~1);
+    float v[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+        v[q] = (f6 & 1) ? bf16_hi(w[q * kPackedPlaneWords]) : bf16_lo(w[q * kPackedPlaneWords]);
+    R[idx] = (v[1] + v[2]) + v[0];
+}
+
+// float32 responsibilities [T, K] (times state responsibilities [T, S]) -> packed
+// tiles: one workgroup per tile of 64 frames x 128 components, transposed through
+// LDS (rows of 129 words: conflict-free both ways), split, stored as whole
+// 16-byte chunks.
+__global__ __launch_bounds__(256) void pack_resps_kernel(int64_t nframes, int K, int S, int G,
+                                                         const float* __restrict__ R,
+                                                         const float* __restrict__ SR,
+                                                         unsigned* __restrict__ out) {
+    __shared__ float tile[kPackedFrames * 129];
+    const int64_t tau = blockIdx.x, t0 = tau * kPackedFrames;
+    const int beta = blockIdx.y, nblk = gridDim.y, kc0 = beta * kPackedComps;
+    const int rows = (int)(nframes - t0 < kPackedFrames ? nframes - t0 : kPackedFrames);
+    for (int e = threadIdx.x; e < kPackedFrames * (kPackedComps / 4); e += 256) {
+        const int f = e / (kPackedComps / 4), c4 = 4 * (e - f * (kPackedComps / 4)), k = kc0 + c4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (f < rows && k < K) {                               // K % 4 == 0
+            v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(R + (t0 + f) * K + k));
+            if (SR) {
+                const float* sr = SR + (t0 + f) * S;
+                if ((G & 3) == 0) {
+                    v *= sr[k / G];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= sr[(k + j) / G];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[f * 129 + c4 + j] = v[j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kPackedComps * 8; e += 256) {
+        const int kk = e >> 3, c8 = e & 7;
+        u4 o[NP];
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd) {
+            unsigned w3[3];
+            split3(tile[(8 * c8 + 2 * wd) * 129 + kk], tile[(8 * c8 + 2 * wd + 1) * 129 + kk], w3);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) o[q][wd] = w3[q];
+        }
+        unsigned* dst = out + packed_word(tau, nblk, beta, kk, 8 * c8);
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            __builtin_nontemporal_store(o[q], reinterpret_cast<u4*>(dst + q * kPackedPlaneWords));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fused accumulation for mixture sets with few statistics per Gaussian (diagonal
+// / isotropic covariances): S[k, q] += sum_t r[t,k] sr[t, k / G] PHI_q(x_t) WITHOUT
+// the responsibilities in memory.  The E-step only leaves the per-state
+// log-normalisers [T, S]; after the forward-backward pass this kernel recomputes
+// the component logits of a tile of 32 frames x 16 NTC components on the matrix
+// cores (the k-loop of llhx_kernel: same packed parameters, same products in the
+// same order, so that exp(l - log_norm) is exactly pass 1's responsibility), turns
+// them into r sr = exp(l - log_norm[t, s]) sr[t, s] in registers -- no maximum, no
+// sum: the normaliser is known -- and feeds them straight back to the matrix cores
+// as the A operand of the statistics product: the C layout of the logits (lane
+// (i, g): component i, frames 4g..4g+3 of both 16-frame tiles) IS the A layout of a
+// 16 x 32 [component x frame] operand when the 32 frames of the contraction are
+// taken in the order (tile 0: 4g..4g+3, tile 1: 4g..4g+3), and the B operand
+// PHI_q(x_f) is generated from the transposed frame tile in that same order.
+// A wave keeps its 16 NTC x 16 NQT statistics tile in registers over all the
+// frame tiles it walks (fp32, <= 4096 frames), then adds it to the fp64 image.
+// ---------------------------------------------------------------------------
+constexpr int kAfXS = 36;                 // row stride (floats) of the transposed frame tile
+constexpr int kAfMaxFramesPerWave = 1024; // MFMA accumulations per sum: 32 (see kAxMaxFrames)
+
+template <int NTC, int NQT, bool G4, int WAVES, int kXP>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
+    int64_t nframes, int D, int K, int S, int G, int Greal, int nk, int nslab,
+    const float* __restrict__ X, const u4* __restrict__ Pall, const int* __restrict__ tab,
+    const float* __restrict__ log_norm, const float* __restrict__ sr,
+    int64_t frames_per_block, double* __restrict__ Sp, const float* __restrict__ c0p) {
+    constexpr int MT = 2, FW = 32, QT = NTC / 4, NTHREADS = 64 * WAVES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int64_t bx;
+    int by;
+    {
+        const int nch = (K + 16 * NTC - 1) / (16 * NTC);
+        if (!xcd_block((nframes + frames_per_block - 1) / frames_per_block, nch, nch, bx, by))
+            return;
+    }
+    const int D4 = d4_of(D), Dp = 4 * D4, LD = ld16_of(D), nq = nslab * 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int xt_floats = (D + 2) * kAfXS;
+    const int nk_used = (nslab + 7) / 8;
+    // LDS: the chunk's packed parameters (nk_used x NTC blocks of 3 KiB, read by every
+    // wave for every frame tile), the slab table, then per wave the frame tile
+    // row-major (A fragments of the logits) and transposed (B fragments of the
+    // statistics)
+    const int p_u4 = nk_used * NTC * kBlockU4;
+    u4* Ps = reinterpret_cast<u4*>(smem);
+    int* tabs = reinterpret_cast<int*>(Ps + p_u4);
+    float* xw = reinterpret_cast<float*>(tabs + (nk + 1) * 8) + wave * (FW * LD + xt_floats);
+    float* xt = xw + FW * LD;
+    {
+        const u4* src = Pall + (size_t)by * nk * NTC * kBlockU4;
+        for (int idx = tid; idx < p_u4; idx += NTHREADS) Ps[idx] = src[idx];
+    }
+    for (int idx = tid; idx < (nk + 1) * 8; idx += NTHREADS) tabs[idx] = tab[idx];
+    {   // constant rows / columns, once
+        for (int r = lane; r < FW; r += 64)
+#pragma unroll 1
+            for (int c = D; c < LD; ++c)
+                xw[r * LD + c] = c == Dp ? 1.f : (c == Dp + 1 ? kConstEps : 0.f);
+        for (int f = lane; f < kAfXS; f += 64) {
+            xt[D * kAfXS + f] = 1.f;
+            xt[(D + 1) * kAfXS + f] = 0.f;
+        }
+    }
+    __syncthreads();
+
+    const int kbase = by * (16 * NTC);
+    const float c0 = c0p[0];
+    const int64_t tb = bx * frames_per_block;
+    const int64_t te = tb + frames_per_block < nframes ? tb + frames_per_block : nframes;
+    const u4* Pl = Ps + lane;
+    const int* tl = tabs + 2 * g;
+    const float* xrow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xrow[m] = xw + (m * 16 + i) * LD;
+
+    auto factors = [&](int uu, int& a, int& b) {
+        const int col = 16 * uu + i, slab = col >> 2;
+        a = b = Dp + 2;
+        if (slab < nslab) {
+            const int t = tabs[slab];
+            b = ((t >> 8) & 0xff) + (col & 3);
+            a = (t >> 16) ? b : (t & 0xff);
+        }
+    };
+    int xa_off[NQT], xb_off[NQT];
+#pragma unroll
+    for (int uu = 0; uu < NQT; ++uu) {
+        int a, b;
+        factors(uu, a, b);
+        xa_off[uu] = (a < D ? a : (a == Dp ? D : D + 1)) * kAfXS + 4 * g;
+        xb_off[uu] = (b < D ? b : (b == Dp ? D : D + 1)) * kAfXS + 4 * g;
+    }
+    // states of the lane's components (G4: one per block of 64 components)
+    constexpr int NST = G4 ? 1 : 4;
+    int st_of[QT][NST];
+#pragma unroll
+    for (int q = 0; q < QT; ++q)
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int s0 = (kbase + 64 * q + 4 * i + j) / G;
+            st_of[q][j] = s0 < S ? s0 : S - 1;
+        }
+
+    f32x4 sacc[NTC][NQT];
+#pragma unroll
+    for (int c = 0; c < NTC; ++c)
+#pragma unroll
+        for (int uu = 0; uu < NQT; ++uu) sacc[c][uu] = f32x4{0, 0, 0, 0};
+
+    struct AFrag { u4 w[NP][MT]; };
+    auto make_half = [&](int s, int m, int h, AFrag& f) {
+        const int t = tl[8 * s + h];
+        const int a = t & 0xff, j = (t >> 8) & 0xff;
+        const bool sq = (t >> 16) != 0;
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(xrow[m] + j);
+        const float xx = xrow[m][a];
+        f32x4 p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[e] = bb[e] * (sq ? bb[e] : xx);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            unsigned w3[3];
+            split3(p[2 * e], p[2 * e + 1], w3);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) f.w[q][m][2 * h + e] = w3[q];
+        }
+    };
+
+    const int C4 = D >> 2;
+    const bool rows4 = (D & 3) == 0;
+    const f32x4* X4 = reinterpret_cast<const f32x4*>(X);
+    // lane = (row r, half h of the row), pieces h, h + 2, h + 4 .. of it: every address
+    // below is ONE per-lane base plus a compile-time constant per piece.  Rows past the
+    // end are read from the last row: their responsibilities get weight 0 below.
+    const int NPC = (C4 + 1) >> 1, lr = lane & 31, lh = lane >> 5;
+    float* xw_l = xw + lr * LD + 4 * lh;                       // + 8 it
+    float* xt_l = xt + 4 * lh * kAfXS + lr;                    // + (8 it + j) kAfXS
+    // frame tiles of this wave: tb + 32 (wave + WAVES n)
+    for (int64_t fb = tb + (int64_t)wave * FW; fb < te; fb += WAVES * FW) {
+        const int rows = (int)(te - fb < FW ? te - fb : FW);              // >= 1
+        // ---- the frame tile, row-major and transposed (wave-private LDS) ----
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        f32x4 xv[kXP];
+        if (rows4) {
+            const f32x4* src = X4 + (fb + (lr < rows ? lr : rows - 1)) * C4;
+#pragma unroll
+            for (int it = 0; it < kXP; ++it) {
+                const int pc = lh + 2 * it;
+                xv[it] = src[pc < C4 ? pc : C4 - 1];
+            }
+        } else {
+            const float* Xt = X + fb * D;
+            for (int idx = lane; idx < FW * D; idx += 64) {
+                const int r = idx / D, c = idx - r * D;
+                const float v = r < rows ? Xt[idx] : 0.f;
+                xw[r * LD + c] = v;
+                xt[c * kAfXS + r] = v;
+            }
+        }
+        // the per-state normalisers and posteriors of the tile's rows, loaded now and
+        // used after the k-loop: (frame 16 m + 4 g + r, state of the lane's components)
+        // (unconditional loads on clamped rows, validity applied to constants: a select
+        // or a branch on the loaded value makes hipcc load and wait one at a time)
+        float nl2[QT][MT][4][NST], wg[QT][MT][4][NST];
+        {
+            const float* ln_t = log_norm + fb * S;
+            const float* sr_t = sr + fb * S;
+#pragma unroll
+            for (int q = 0; q < QT; ++q)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * m + 4 * g + r;
+                        const int rc = row < rows ? row : rows - 1;
+#pragma unroll
+                        for (int j = 0; j < NST; ++j) nl2[q][m][r][j] = ln_t[rc * S + st_of[q][j]];
+                    }
+            if (sr) {
+#pragma unroll
+                for (int q = 0; q < QT; ++q)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * m + 4 * g + r;
+                            const int rc = row < rows ? row : rows - 1;
+#pragma unroll
+                            for (int j = 0; j < NST; ++j) wg[q][m][r][j] = sr_t[rc * S + st_of[q][j]];
+                        }
+            } else {
+#pragma unroll
+                for (int q = 0; q < QT; ++q)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int j = 0; j < NST; ++j) wg[q][m][r][j] = 1.f;
+            }
+        }
+        // A tile none of whose frames gives the chunk's states any posterior contributes
+        // exactly nothing: skip it (alignment graphs: most of the model's states are
+        // absent from an utterance, their posteriors are exact zeros)
+        if (sr) {
+            float any = 0.f;
+#pragma unroll
+            for (int q = 0; q < QT; ++q)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < NST; ++j)
+                            any = __builtin_fmaxf(any, __builtin_fabsf(wg[q][m][r][j]));
+            if (__builtin_amdgcn_ballot_w64(any != 0.f) == 0) continue;
+        }
+        if (rows4) {
+#pragma unroll
+            for (int it = 0; it < kXP; ++it) {
+                if (it >= NPC) break;
+                if (lh + 2 * it < C4) {
+                    const f32x4 v = xv[it];
+                    *reinterpret_cast<f32x4*>(xw_l + 8 * it) = v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xt_l[(8 * it + j) * kAfXS] = v[j];
+                }
+            }
+        }
+        // rows past the end: weight 0, and a normaliser that keeps the exponential at 0
+        // (0 x inf would be NaN)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // (the recomputed logits lack the common constant c0, see const_max_kernel)
+                const bool ok = 16 * m + 4 * g + r < rows;
+                const float pen = ok ? c0 : -1.0e30f, mult = ok ? 1.f : 0.f;
+#pragma unroll
+                for (int q = 0; q < QT; ++q)
+#pragma unroll
+                    for (int j = 0; j < NST; ++j) {
+                        nl2[q][m][r][j] = pen - nl2[q][m][r][j];
+                        wg[q][m][r][j] *= mult;
+                    }
+            }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+
+        // ---- logits of 32 frames x 16 NTC components ----
+        f32x4 acc[MT][NTC];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int c = 0; c < NTC; ++c) acc[m][c] = f32x4{0, 0, 0, 0};
+        AFrag f0, f1;
+        auto kstep = [&](int s, const AFrag& cur, AFrag& nxt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // a slice of the next k-step's A fragments (the table is padded by one k-step)
+#pragma unroll
+                for (int hh = q * MT * 2 / 4; hh < (q + 1) * MT * 2 / 4; ++hh)
+                    make_half(s + 1, hh % MT, hh / MT, nxt);
+#pragma unroll
+                for (int c = q * QT; c < (q + 1) * QT; ++c) {
+                    u4 bp[NP];
+#pragma unroll
+                    for (int pq = 0; pq < NP; ++pq) bp[pq] = Pl[(s * NTC + c) * kBlockU4 + 64 * pq];
+                    // (the products in the order of llhx_kernel: same roundings)
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[m][c] = mfma_bf16(cur.w[kProdA[pr]][m], bp[kProdB[pr]], acc[m][c]);
+                }
+            }
+        };
+#pragma unroll
+        for (int hh = 0; hh < MT * 2; ++hh) make_half(0, hh % MT, hh / MT, f0);
+        // (only the k-steps that hold slabs: the image's padding to an even count is zeros)
+        for (int s = 0; s < nk_used; s += 2) {
+            kstep(s, f0, f1);
+            if (s + 1 < nk_used) kstep(s + 1, f1, f0);
+        }
+
+        // ---- r sr = exp(l - log_norm) sr, split into the A fragments ----
+        // A fragment of component tile nt: words 0, 1 = frames 4g..4g+3 of tile 0,
+        // words 2, 3 = the same rows of tile 1
+        u4 ar[NTC][NP];
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) {
+            const int q = nt >> 2, jj = G4 ? 0 : (nt & 3);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    // l - log_norm first (one rounding of a small difference), THEN the change
+                    // of base: scaling l (|l| ~ 100) and log_norm separately by a rounded
+                    // log2(e) left a systematic 4e-6 in r
+                    v[r] = __builtin_amdgcn_exp2f((acc[m][nt][r] + nl2[q][m][r][jj]) *
+                                                  1.44269504088896340736f) *
+                           wg[q][m][r][jj];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    unsigned w3[3];
+                    split3(v[2 * e], v[2 * e + 1], w3);
+#pragma unroll
+                    for (int pq = 0; pq < NP; ++pq) ar[nt][pq][2 * m + e] = w3[pq];
+                }
+            }
+        }
+
+        // ---- statistics: sacc[c][uu] += A'(c) x B'(uu) ----
+        auto gen_b = [&](int uu, u4 (&out)[NP]) {
+            const f32x4 xa0 = *reinterpret_cast<const f32x4*>(xt + xa_off[uu]);
+            const f32x4 xa1 = *reinterpret_cast<const f32x4*>(xt + xa_off[uu] + 16);
+            const f32x4 xb0 = *reinterpret_cast<const f32x4*>(xt + xb_off[uu]);
+            const f32x4 xb1 = *reinterpret_cast<const f32x4*>(xt + xb_off[uu] + 16);
+            const f32x4 p0 = xa0 * xb0, p1 = xa1 * xb1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned w3[3];
+                split3(e < 2 ? p0[2 * e] : p1[2 * e - 4], e < 2 ? p0[2 * e + 1] : p1[2 * e - 3],
+                       w3);
+#pragma unroll
+                for (int pq = 0; pq < NP; ++pq) out[pq][e] = w3[pq];
+            }
+        };
+        u4 bq[2][NP];
+        gen_b(0, bq[0]);
+#pragma unroll
+        for (int uu = 0; uu < NQT; ++uu) {
+            const int cur = uu & 1;
+            if (uu + 1 < NQT) gen_b(uu + 1, bq[cur ^ 1]);
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int c = 0; c < NTC; ++c)
+                    sacc[c][uu] = mfma_bf16(ar[c][kProdA[pr]], bq[cur][kProdB[pr]], sacc[c][uu]);
+        }
+    }
+
+    // ---- flush: rows = components kbase + 64 (c / 4) + 4 (4 g + r) + c % 4 ----
+#pragma unroll
+    for (int uu = 0; uu < NQT; ++uu) {
+        const int q = 16 * uu + i;
+        if (q >= nq) continue;
+#pragma unroll
+        for (int c = 0; c < NTC; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int slot = kbase + 64 * (c >> 2) + 4 * (4 * g + r) + (c & 3);
+                // slot -> component (padded slots of a group and slots past the end: none)
+                const int gi = slot % G;
+                if (slot < K && gi < Greal)
+                    atomicAdd(Sp + (size_t)((slot / G) * Greal + gi) * nq + q,
+                              (double)sacc[c][uu][r]);
+            }
+    }
+}
+
+// component tiles per wave: 4 (64 components).  With at most 96 statistic columns
+// (D <= 40) a wave's tile leaves room for two waves per SIMD: one wave's epilogue and
+// fragment arithmetic run under the other's MFMAs.
+inline int accf_ntc(int cov, int D) { return 4; }
+inline int accf_nqt(int cov, int D) {
+    const int nq = nslab_of(cov, D) * 4;
+    return nq <= 96 ? 6 : (nq <= 144 ? 9 : 10);
+}
+
+// groups of a mixture set padded to a power of two (>= 4: a lane's 4 components then
+// share their state)
+inline int group_pad(int G) {
+    int p = 1;
+    while (p < G) p <<= 1;
+    return p;
+}
+// the fused accumulation needs a multiple of 4 only (no group reductions)
+inline int accf_group_pad(int S, int G) { return (G + 3) / 4 * 4; }
+inline bool supported_llh_padded(int D, int S, int G) {
+    return supported_llh(D, S, S > 1 ? group_pad(G) : G);
+}
+
+inline int ntx_for(int S, int K) { return S > 1 ? 16 : (K <= 64 ? 4 : (K <= 128 ? 8 : 16)); }
+inline int nchunksx_for(int S, int K) { return S > 1 ? (K + 255) / 256 : 1; }
+size_t up256(size_t n) { return (n + 255) / 256 * 256; }
+
+// bytes of the P image: nchunks x nk x NT blocks + one look-ahead batch
+inline size_t p_image_bytes(int nchunks, int nk, int NT) {
+    return up256(((size_t)nchunks * nk * NT + 4) * kBlockU4 * 16);
+}
+
+}  // namespace
+
+bool supported_llh_split(int D, int S, int G) { return supported_llh_padded(D, S, G); }
+// Mixture sets whose responsibilities can leave the E-step as packed tiles: full
+// covariance, groups of 4 .. 128 components, a power of two
+bool supported_llh_packed_sets(int cov, int D, int S, int G) {
+    return cov == BEER_FULL && S > 1 && G >= 4 && G <= 128 && (G & (G - 1)) == 0 &&
+           supported_llh_padded(D, S, G) && supported_acc(D, S * G);
+}
+
+// 129 .. 256 components of ONE mixture: the E-step kernel also leaves the
+// transposed frames behind its tiles -- [R tiles][X^T tiles]
+inline bool packed_has_xt(int K) { return K > kPackedComps && K <= 2 * kPackedComps; }
+inline size_t packed_tiles_bytes(int64_t nframes, int K) {
+    const int64_t tiles = (nframes + kPackedFrames - 1) / kPackedFrames;
+    const int nblk = (K + kPackedComps - 1) / kPackedComps;
+    return (size_t)tiles * nblk * NP * kPackedPlaneWords * 4;
+}
+size_t packed_resps_bytes(int64_t nframes, int D, int K) {
+    const int64_t tiles = (nframes + kPackedFrames - 1) / kPackedFrames;
+    return packed_tiles_bytes(nframes, K) +
+           (packed_has_xt(K) ? (size_t)tiles * xt_pieces(D) * kPiece : 0) + 256;
+}
+
+int pack_resps(int64_t nframes, int D, int S, int G, const float* X, const float* R,
+               const float* SR, void* packed, hipStream_t s) {
+    const int K = S * G;
+    if ((K & 3) || D < 1 || D > 64) return BEER_EINVAL;
+    if (nframes == 0) return BEER_OK;
+    unsigned* tiles = reinterpret_cast<unsigned*>(packed);
+    const int64_t ntile = (nframes + kPackedFrames - 1) / kPackedFrames;
+    const int nblk = (K + kPackedComps - 1) / kPackedComps;
+    hipLaunchKernelGGL(pack_resps_kernel, dim3((unsigned)ntile, (unsigned)nblk), dim3(256), 0, s,
+                       nframes, K, S, G, R, SR, tiles);
+    if (packed_has_xt(K))               // what the E-step kernel would have left behind
+        hipLaunchKernelGGL(xt_image_kernel, dim3((unsigned)ntile), dim3(256), 0, s, nframes, D,
+                           xt_pieces(D), X,
+                           reinterpret_cast<float*>(reinterpret_cast<char*>(tiles) +
+                                                    packed_tiles_bytes(nframes, K)));
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+int unpack_resps(int64_t nframes, int K, const void* packed, float* resps, hipStream_t s) {
+    const int64_t n = nframes * K;
+    if (n == 0) return BEER_OK;
+    hipLaunchKernelGGL(unpack_resps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       nframes, K, reinterpret_cast<const unsigned*>(packed), resps);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+size_t estepx_workspace_bytes(int cov, int D, int S, int G) {
+    if (!supported_llh_padded(D, S, G)) return 0;
+    if (S > 1) G = group_pad(G);
+    const int K = S * G, NT = ntx_for(S, K), nchunks = nchunksx_for(S, K);
+    return p_image_bytes(nchunks, nk16_of(cov, D), NT) +
+           up256((size_t)(nk16_of(cov, D) + 1) * 8 * sizeof(int)) + 256;
+}
+
+int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, const float* expT,
+                 const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
+                 size_t ws_bytes, hipStream_t s, bool packed) {
+    if (packed && S != 1 && !supported_llh_packed_sets(cov, D, S, G)) return BEER_EINVAL;
+    if (!supported_llh_padded(D, S, G) || ws_bytes < estepx_workspace_bytes(cov, D, S, G))
+        return BEER_EINVAL;
+    // mixture sets whose G is not a power of two: groups padded to Gp slots (logit
+    // -1e30), log-normalisers only (the responsibilities would come out in the padded
+    // layout)
+    const int Greal = G, Kreal = S * G;
+    if (S > 1) G = group_pad(G);
+    if (G != Greal && resps) return BEER_EINVAL;
+    const int K = S * G;
+    const int NT = ntx_for(S, K), nchunks = nchunksx_for(S, K), nk = nk16_of(cov, D);
+    const int kpad = nchunks * NT * 16;
+    g_cov_of_launch = cov;
+    char* w = reinterpret_cast<char*>(ws);
+    void* P = w;
+    w += p_image_bytes(nchunks, nk, NT);
+    int* tab = reinterpret_cast<int*>(w);
+    w += up256((size_t)(nk + 1) * 8 * sizeof(int));
+    float* c0 = reinterpret_cast<float*>(w);
+    hipLaunchKernelGGL(const_max_kernel, dim3(1), dim3(256), 0, s, cov, D, Kreal, expT, logw, c0);
+    hipLaunchKernelGGL(packx_kernel, dim3(kpad), dim3(256),
+                       (size_t)stats_dim(cov, D) * sizeof(float), s, cov, D, Kreal, NT, expT, logw,
+                       reinterpret_cast<unsigned short*>(P), tab, Greal, G, c0);
+    BEER_LAUNCH_CHECK();
+    const bool full = cov == BEER_FULL;
+#define BEER_LLHX(NT_, MT_, GQ_, PK_, LNO_, ...)                                                  \
+    do {                                                                                          \
+        if (full)                                                                                 \
+            return launch_llhx<NT_, MT_, GQ_, PK_, false, LNO_>(nframes, D, K, S, G, gl, jw,      \
+                                                                nchunks, nk, X, P, tab, c0,       \
+                                                                resps, log_norm, llh_sum, s,      \
+                                                                ##__VA_ARGS__);                   \
+        return launch_llhx<NT_, MT_, GQ_, PK_, true, LNO_>(nframes, D, K, S, G, gl, jw, nchunks,  \
+                                                           nk, X, P, tab, c0, resps, log_norm,    \
+                                                           llh_sum, s, ##__VA_ARGS__);            \
+    } while (0)
+    if (S == 1) {
+        const int gl = 16, jw = 4;
+        if (packed) {
+            if (NT == 4) BEER_LLHX(4, 2, 1, true, false);
+            if (NT == 8) BEER_LLHX(8, 2, 2, true, false);
+            // 129 .. 256 components: a wave's 64 frames are one tile of the accumulation;
+            // it leaves them behind transposed
+            float* xt = reinterpret_cast<float*>(reinterpret_cast<char*>(resps) +
+                                                 packed_tiles_bytes(nframes, K));
+            const int xtf = xt_pieces(D) * (kPiece / 4);
+            BEER_LLHX(16, 4, 4, true, false, xt, xtf);
+        }
+        if (NT == 4) BEER_LLHX(4, 2, 1, false, false);
+        if (NT == 8) BEER_LLHX(8, 2, 2, false, false);
+        BEER_LLHX(16, 2, 4, false, false);
+    }
+    const int jw = G < 4 ? G : 4;
+    const int gl = G < 4 ? 1 : (G < 64 ? G / 4 : 16);
+    const int gq = G <= 64 ? 1 : G / 64;
+    if (packed) {
+        // the responsibilities within each state's mixture as the accumulation's LDS tiles
+        switch (gq) {
+            case 1: BEER_LLHX(16, 4, 1, true, false);
+            default: BEER_LLHX(16, 4, 2, true, false);
+        }
+    }
+    if (!resps && jw == 4) {
+        // log-normalisers only (the accumulation recomputes the responsibilities)
+        switch (gq) {
+            case 1: BEER_LLHX(16, 2, 1, false, true);
+            case 2: BEER_LLHX(16, 2, 2, false, true);
+            default: BEER_LLHX(16, 2, 4, false, true);
+        }
+    }
+    switch (gq) {
+        case 1: BEER_LLHX(16, 2, 1, false, false);
+        case 2: BEER_LLHX(16, 2, 2, false, false);
+        default: BEER_LLHX(16, 2, 4, false, false);
+    }
+#undef BEER_LLHX
+}
+
+size_t accx_base_workspace_bytes(int cov, int D, int K) {
+    if (!supported_acc(D, K)) return 0;
+    const int nslab = nslab_of(cov, D);
+    return up256((size_t)K * nslab * 4 * sizeof(double)) + up256((size_t)nslab * sizeof(int)) + 1024;
+}
+
+size_t accx_workspace_bytes(int cov, int64_t nframes, int D, int K) {
+    const size_t base = accx_base_workspace_bytes(cov, D, K);
+    if (base == 0) return 0;
+    const int64_t tiles = (nframes + kAxFT - 1) / kAxFT;
+    return base + (size_t)tiles * xt_pieces(D) * kPiece;
+}
+
+// ... with state posteriors multiplied in by the accumulation kernel: S states of G
+// components (a power of two, 8 .. 128)
+bool supported_acc_sets(int cov, int D, int S, int G) {
+    return S >= 1 && G >= 8 && G <= 128 && (G & (G - 1)) == 0 && supported_acc(D, S * G) &&
+           xt_pieces(D) <= 5;
+}
+inline int acc_sets_spad(int S, int G) {
+    return (S * G + kPackedComps - 1) / kPackedComps * (kPackedComps / G);
+}
+size_t accxs_workspace_bytes(int cov, int64_t nframes, int D, int S, int G) {
+    if (!supported_acc_sets(cov, D, S, G)) return 0;
+    const int64_t tiles = (nframes + kAxFT - 1) / kAxFT;
+    return up256(accx_workspace_bytes(cov, nframes, D, S * G)) +
+           (size_t)tiles * acc_sets_spad(S, G) * kAxFT * sizeof(float) + 1024;
+}
+
+int acc_bf16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, const void* Rimg,
+                      double* acc, void* ws, size_t ws_bytes, hipStream_t s, int S, int G,
+                      const float* SR) {
+    if (!supported_acc(D, K) || ws_bytes < accx_workspace_bytes(cov, nframes, D, K))
+        return BEER_EINVAL;
+    if (SR && (S * G != K || !supported_acc_sets(cov, D, S, G) ||
+               ws_bytes < accxs_workspace_bytes(cov, nframes, D, S, G)))
+        return BEER_EINVAL;
+    const int nslab = nslab_of(cov, D), nq = nslab * 4;
+    char* w = reinterpret_cast<char*>(ws);
+    double* Sp = reinterpret_cast<double*>(w);
+    w += up256((size_t)K * nq * sizeof(double));
+    int* tab = reinterpret_cast<int*>(w);
+    float* Xt = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) +
+                                         accx_base_workspace_bytes(cov, D, K));
+    hipError_t e = hipMemsetAsync(Sp, 0, (size_t)K * nq * sizeof(double), s);
+    if (e != hipSuccess) return -(int)e;
+    hipLaunchKernelGGL(tab_kernel, dim3(1), dim3(256), 0, s, cov, D, tab);
+    BEER_LAUNCH_CHECK();
+    const int64_t tiles = (nframes + kAxFT - 1) / kAxFT;
+    const int NX = xt_pieces(D);
+    if (packed_has_xt(K) && !SR) {           // the E-step kernel left the image behind the tiles
+                                             // (one mixture; the kernel of a set does not)
+        Xt = reinterpret_cast<float*>(const_cast<char*>(reinterpret_cast<const char*>(Rimg)) +
+                                      packed_tiles_bytes(nframes, K));
+    } else {
+        hipLaunchKernelGGL(xt_image_kernel, dim3((unsigned)tiles), dim3(256), 0, s, nframes, D, NX,
+                           X, Xt);
+        BEER_LAUNCH_CHECK();
+    }
+    const int ntiles = (nq + 15) / 16;
+    float* Gt = nullptr;
+    int lgG = 0;
+    if (SR) {
+        Gt = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) +
+                                      up256(accx_workspace_bytes(cov, nframes, D, K)));
+        const int spad = acc_sets_spad(S, G);
+        hipLaunchKernelGGL(gt_image_kernel, dim3((unsigned)tiles, (unsigned)((spad + 63) / 64)),
+                           dim3(256), 0, s, nframes, S, spad, SR, Gt);
+        BEER_LAUNCH_CHECK();
+        while ((1 << lgG) < G) ++lgG;
+    }
+    const int gx = (ntiles + kAxNQ * kAxWaves - 1) / (kAxNQ * kAxWaves);
+    const int gy = (K + 16 * kAxMC - 1) / (16 * kAxMC);
+    // one workgroup per CU (120 KB of LDS, 512 registers per lane): whole rounds of 256
+    // workgroups, at most kAxMaxFrames frames each
+    const int64_t max_z = (nframes + 511) / 512,
+                  min_z = (nframes + kAxMaxFrames - 1) / kAxMaxFrames;
+    const int64_t rounds = ((int64_t)gx * gy * min_z + 255) / 256;
+    int64_t gz = rounds * 256 / ((int64_t)gx * gy);
+    if (gz < min_z) gz = min_z;
+    if (gz > max_z) gz = max_z;
+    if (gz < 1) gz = 1;
+    int64_t fpb = (nframes + gz - 1) / gz;
+    fpb = (fpb + kAxFT - 1) / kAxFT * kAxFT;
+    gz = (nframes + fpb - 1) / fpb;
+    const size_t lds = 2 * ((size_t)NX * kPiece + (size_t)NP * kPackedPlaneWords * 4) +
+                       (SR ? 2 * 4096 : 0);
+    const int64_t nyz = ((int64_t)gy * gz + 7) / 8 * 8;
+    const dim3 grid((unsigned)(nyz * gx));
+#define BEER_ACCX(NX_, SR_)                                                                      \
+    do {                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(accx_kernel<NX_, SR_>),          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        hipLaunchKernelGGL((accx_kernel<NX_, SR_>), grid, dim3(64 * kAxWaves), lds, s, nframes,  \
+                           D, K, nslab, Xt, reinterpret_cast<const unsigned*>(Rimg), tab, fpb,   \
+                           Sp, gx, gy, (int)gz, Gt, lgG);                                        \
+    } while (0)
+    if (SR) {
+        if (NX == 1) BEER_ACCX(1, true);
+        else if (NX == 2) BEER_ACCX(2, true);
+        else if (NX == 3) BEER_ACCX(3, true);
+        else if (NX == 4) BEER_ACCX(4, true);
+        else BEER_ACCX(5, true);
+    }
+    else if (NX == 1) BEER_ACCX(1, false);
+    else if (NX == 2) BEER_ACCX(2, false);
+    else if (NX == 3) BEER_ACCX(3, false);
+    else if (NX == 4) BEER_ACCX(4, false);
+    else BEER_ACCX(5, false);
+#undef BEER_ACCX
+    BEER_LAUNCH_CHECK();
+    const int64_t total = (int64_t)K * stats_dim(cov, D);
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cov,
+                       D, K, Sp, acc);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+// statistics per Gaussian small enough for a wave's register tile: diagonal and
+// isotropic covariances up to D = 64 (nq <= 160)
+bool supported_accf(int cov, int D, int S, int G) {
+    return cov != BEER_FULL && D >= 1 && D <= 64 && S >= 1 && G >= 1 && G <= 256 &&
+           nslab_of(cov, D) * 4 <= 160;
+}
+
+size_t accf_workspace_bytes(int cov, int D, int S, int G) {
+    if (!supported_accf(cov, D, S, G)) return 0;
+    const int Kreal = S * G;
+    G = accf_group_pad(S, G);
+    const int K = S * G, NTC = accf_ntc(cov, D), nk = nk16_of(cov, D);
+    const int nchunks = (K + 16 * NTC - 1) / (16 * NTC), nq = nslab_of(cov, D) * 4;
+    return p_image_bytes(nchunks, nk, NTC) + up256((size_t)(nk + 1) * 8 * sizeof(int)) + 1024 +
+           up256((size_t)Kreal * nq * sizeof(double));
+}
+
+int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X,
+                     const float* expT, const float* logw, const float* log_norm,
+                     const float* sr, double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!supported_accf(cov, D, S, G) || ws_bytes < accf_workspace_bytes(cov, D, S, G))
+        return BEER_EINVAL;
+    // component slots: groups padded to a multiple of 4 (one state per lane's 4
+    // components); the statistics image Sp stays in the components' own order
+    const int Greal = G, Kreal = S * G;
+    G = accf_group_pad(S, G);
+    const int K = S * G, NTC = accf_ntc(cov, D), NQT = accf_nqt(cov, D), nk = nk16_of(cov, D);
+    const int nchunks = (K + 16 * NTC - 1) / (16 * NTC), kpad = nchunks * NTC * 16;
+    const int nslab = nslab_of(cov, D), nq = nslab * 4;
+    char* w = reinterpret_cast<char*>(ws);
+    void* P = w;
+    w += p_image_bytes(nchunks, nk, NTC);
+    int* tab = reinterpret_cast<int*>(w);
+    w += up256((size_t)(nk + 1) * 8 * sizeof(int));
+    float* c0 = reinterpret_cast<float*>(w);
+    w += 1024;
+    double* Sp = reinterpret_cast<double*>(w);
+    hipError_t e = hipMemsetAsync(Sp, 0, (size_t)Kreal * nq * sizeof(double), s);
+    if (e != hipSuccess) return -(int)e;
+    hipLaunchKernelGGL(const_max_kernel, dim3(1), dim3(256), 0, s, cov, D, Kreal, expT, logw, c0);
+    hipLaunchKernelGGL(packx_kernel, dim3(kpad), dim3(256),
+                       (size_t)stats_dim(cov, D) * sizeof(float), s, cov, D, Kreal, NTC, expT, logw,
+                       reinterpret_cast<unsigned short*>(P), tab, Greal, G, c0);
+    BEER_LAUNCH_CHECK();
+    // waves per workgroup: 8 (two per SIMD) with 64-component chunks, 4 with 128
+    const int waves = (NTC == 4 && NQT == 6) ? 8 : 4;
+    // frames per workgroup: <= kAfMaxFramesPerWave per wave, about one workgroup of
+    // 8 waves (two of 4) per CU and round
+    static const int rounds = [] { const char* e = getenv("BEER_ACCF_ROUNDS"); return e ? atoi(e) : 6; }();
+    int64_t gz = ((waves == 8 ? 256 : 512) * rounds + nchunks - 1) / nchunks;
+    gz = (gz + 7) / 8 * 8;                       // whole rows of the XCD-aware grid
+    const int64_t min_z = (nframes + (int64_t)waves * kAfMaxFramesPerWave - 1) /
+                          ((int64_t)waves * kAfMaxFramesPerWave);
+    const int64_t max_z = (nframes + 32 * waves - 1) / (32 * waves);
+    if (gz > max_z) gz = max_z;
+    if (gz < min_z) gz = min_z;
+    if (gz < 1) gz = 1;
+    int64_t fpb = (nframes + gz - 1) / gz;
+    fpb = (fpb + 32 * waves - 1) / (32 * waves) * (32 * waves);
+    gz = (nframes + fpb - 1) / fpb;
+    const int nk_used = (nslab + 7) / 8;
+    const size_t lds = (size_t)nk_used * NTC * kBlockU4 * 16 + (size_t)(nk + 1) * 8 * sizeof(int) +
+                       (size_t)waves * (32 * ld16_of(D) + (D + 2) * kAfXS) * sizeof(float);
+    const dim3 grid(xcd_grid(gz, nchunks, nchunks));
+    const bool g4 = (G % 4) == 0;
+#define BEER_ACCF(NTC_, NQT_, G4_, W_)                                                           \
+    do {                                                                                         \
+        constexpr int XP_ = NQT_ == 6 ? 5 : 8;      /* D <= 40 <=> C4 <= 10 <=> nq <= 96 */       \
+        (void)hipFuncSetAttribute(                                                               \
+            reinterpret_cast<const void*>(accf_kernel<NTC_, NQT_, G4_, W_, XP_>),                \
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+        hipLaunchKernelGGL((accf_kernel<NTC_, NQT_, G4_, W_, XP_>), grid, dim3(64 * W_), lds, s, \
+                           nframes, D, K, S, G, Greal, nk, nslab, X,                             \
+                           reinterpret_cast<const u4*>(P), tab, log_norm, sr, fpb, Sp, c0);      \
+    } while (0)
+    if (NQT == 6) { if (g4) BEER_ACCF(4, 6, true, 8); else BEER_ACCF(4, 6, false, 8); }
+    else if (NQT == 9) { if (g4) BEER_ACCF(4, 9, true, 4); else BEER_ACCF(4, 9, false, 4); }
+    else { if (g4) BEER_ACCF(4, 10, true, 4); else BEER_ACCF(4, 10, false, 4); }
+#undef BEER_ACCF
+    BEER_LAUNCH_CHECK();
+    const int64_t total = (int64_t)Kreal * stats_dim(cov, D);
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cov,
+                       D, Kreal, Sp, acc);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+}  // namespace beer_mfma

@@ -14,58 +14,48 @@ bool supported_acc(int D, int K);
 size_t estep_workspace_bytes(size_t elem, int cov, int D, int S, int G);
 size_t acc_workspace_bytes(int cov, int D, int K);
 
-// fp32 models on the fp16 matrix pipes (estep_f16.hip): every fp32 operand is
-// split into two fp16 halves, three fp16 MFMAs per product, fp32 accumulation.
-size_t estep16_workspace_bytes(int cov, int D, int S, int G);
-// shapes the split path takes when NO responsibilities are wanted: mixture sets with
+// fp32 models on the bf16 matrix pipes (estep_bf16.hip): every fp32 operand is held
+// exactly as three bf16 pieces, the six leading partial products of every
+// multiplication, fp32 accumulation.
+size_t estepx_workspace_bytes(int cov, int D, int S, int G);
+// shapes that path takes when NO responsibilities are wanted: mixture sets with
 // any number of components per state (groups padded to a power of two)
 bool supported_llh_split(int D, int S, int G);
-// `packed`: S = 1, or a set that is supported_llh_packed_sets; `resps` (packed_resps_bytes) then receives the fp16 hi / lo
-// image the accumulation kernel consumes (estep_tiles.h: softmax_epilogue<PACKED>).
-int estep_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
-                const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
-                size_t ws_bytes, hipStream_t s, bool packed = false,
-                const float* given_scales = nullptr, const float* moments = nullptr);
-// The per-dimension frame scales of the split arithmetic (64 scales, 64 inverses) on
-// their own: a caller that runs many E-steps over the same frames computes them once
-// and hands them to estep_f16x3 (`given_scales`).  scratch >= 256 bytes.
-int frame_scales(int64_t T, int D, const float* X, float* scales, void* scratch, hipStream_t s);
+// `packed`: S = 1, or a set that is supported_llh_packed_sets; `resps`
+// (packed_resps_bytes) then receives the three-plane bf16 image the accumulation
+// kernel consumes (estep_tiles.h: softmax_epilogue<PACKED>).
+int estep_bf16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
+                 const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
+                 size_t ws_bytes, hipStream_t s, bool packed = false);
 
-// 1 in *hazard (device) when the split path would lose accuracy on these frames
-// (a dimension whose maximum is > 2^9 times its mean magnitude); scratch >= 768 B.
 int unpack_resps(int64_t T, int K, const void* packed, float* resps, hipStream_t s);
-// comp_resps [T, S*G] (x state_resps [T, S], nullable) -> packed tiles + scale header
+// comp_resps [T, S*G] (x state_resps [T, S], nullable) -> packed tiles
 int pack_resps(int64_t T, int D, int S, int G, const float* X, const float* R, const float* SR,
                void* packed, hipStream_t s);
-int f16_range_hazard(int64_t T, int D, const float* X, void* scratch, int* hazard,
-                     hipStream_t s);
-size_t acc16_workspace_bytes(int cov, int D, int K);
-int acc_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* R,
-              const float* SR, double* acc, void* ws, size_t ws_bytes, hipStream_t s);
-// One mixture with the responsibilities as estep_f16x3(..., packed = true) wrote them
+// The responsibilities as estep_bf16x3(..., packed = true) wrote them
 // (packed_resps_bytes); the workspace also holds the transposed frames, hence T.
 size_t packed_resps_bytes(int64_t T, int D, int K);
-size_t acc16p_workspace_bytes(int cov, int64_t T, int D, int K);
-int acc_f16x3_packed(int cov, int64_t T, int D, int K, const float* X, const void* Rimg,
-                     double* acc, void* ws, size_t ws_bytes, hipStream_t s, int S = 1, int G = 0,
-                     const float* SR = nullptr);
+size_t accx_workspace_bytes(int cov, int64_t T, int D, int K);
+int acc_bf16x3_packed(int cov, int64_t T, int D, int K, const float* X, const void* Rimg,
+                      double* acc, void* ws, size_t ws_bytes, hipStream_t s, int S = 1, int G = 0,
+                      const float* SR = nullptr);
 // Mixture sets on the packed hand-over (full covariance): the E-step leaves the
-// responsibilities within each state's mixture as packed tiles (estep_f16x3 with
+// responsibilities within each state's mixture as packed tiles (estep_bf16x3 with
 // packed = true, S > 1), the accumulation multiplies the state posteriors SR [T, S]
-// in while a tile sits in LDS (workspace: acc16s_workspace_bytes).
+// in while a tile sits in LDS (workspace: accxs_workspace_bytes).
 bool supported_llh_packed_sets(int cov, int D, int S, int G);
 bool supported_acc_sets(int cov, int D, int S, int G);
-size_t acc16s_workspace_bytes(int cov, int64_t T, int D, int S, int G);
+size_t accxs_workspace_bytes(int cov, int64_t T, int D, int S, int G);
 
 // Mixture sets with diagonal / isotropic Gaussians: accumulation that recomputes the
 // component responsibilities from the frames and the per-state log-normalisers
 // [T, S] of the E-step (times the state responsibilities sr [T, S], nullable)
-// instead of reading them from memory (estep_f16.hip: accf_kernel).
+// instead of reading them from memory (estep_bf16.hip: accf_kernel).
 bool supported_accf(int cov, int D, int S, int G);
 size_t accf_workspace_bytes(int cov, int D, int S, int G);
-int acc_fused_f16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
-                    const float* logw, const float* log_norm, const float* sr, double* acc,
-                    void* ws, size_t ws_bytes, hipStream_t s);
+int acc_fused_bf16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
+                     const float* logw, const float* log_norm, const float* sr, double* acc,
+                     void* ws, size_t ws_bytes, hipStream_t s);
 
 int estep_f32(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
               const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,

@@ -46,10 +46,29 @@ namespace {
 // P[chunk][slab][64 lanes][NT] (each lane's NT B-fragment values contiguous)
 // and the slab table.
 // ---------------------------------------------------------------------------
+// c0[0] = the largest constant term of any component: taken out of every logit (the
+// accumulators round at the size of the running sum, the softmax does not see a common
+// offset) and added back to the log-normalisers by the epilogue.
+template <typename T>
+__global__ __launch_bounds__(256) void const_max_kernel(int cov, int D, int K,
+                                                        const T* __restrict__ E,
+                                                        const T* __restrict__ logw,
+                                                        T* __restrict__ c0) {
+    __shared__ double red[8];
+    const int Q = stats_dim(cov, D);
+    double m = -1.0e300;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const double v = const_total(cov, D, E + (size_t)k * Q, logw ? (double)logw[k] : 0.0);
+        if (v == v && v > m && v < 1.0e300) m = v;
+    }
+    m = block_max(m, red);
+    if (threadIdx.x == 0) c0[0] = m > -1.0e300 ? (T)m : (T)0;
+}
+
 template <typename T>
 __global__ void pack_kernel(int cov, int D, int K, int NT, int nchunks,
                             const T* __restrict__ E, const T* __restrict__ logw,
-                            T* __restrict__ P, int* __restrict__ tab) {
+                            T* __restrict__ P, int* __restrict__ tab, const T* __restrict__ c0) {
     const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(cov, D);
     const int Q = stats_dim(cov, D);
     const int64_t per_chunk = (int64_t)nslab_padded(cov, D) * 64 * NT;
@@ -82,12 +101,11 @@ __global__ void pack_kernel(int cov, int D, int K, int NT, int nchunks,
                                  : -0.5 * ((double)e[D + a * D + b] + (double)e[D + b * D + a]);
             } else if (b - g < Dp) {                      // linear
                 if (b < D) v = (double)e[b];
-            } else if (g == 0) {                          // constant
-                const double zero = cov == BEER_ISO ? 0.5 * (double)D : 0.5;
-                v = -0.5 * (double)e[Q - 2] + zero * (double)e[Q - 1] -
-                    0.5 * (double)D * kLog2Pi + (logw ? (double)logw[k] : 0.0);
+            } else if (g == 0) {                          // constant (its share: const_share)
+                v = const_share(cov, D, s, e, logw ? (double)logw[k] : 0.0) -
+                    (s == nslab - 1 ? (double)c0[0] : 0.0);
             }
-        } else if (a == Dp && b - g == Dp && g == 0) {
+        } else if (a == Dp && b - g == Dp && g == 0 && s == nslab - 1) {
             v = kPadLogit;                          // padded component: exp() -> 0
         }
         P[idx] = (T)v;
@@ -108,7 +126,8 @@ template <typename T, int NT, int MT, int GQ>
 __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 && MT * NT <= 32) ? 2 : 1) void llh_kernel(
     int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nslab,
     const T* __restrict__ X, const T* __restrict__ Pall, const int* __restrict__ tab,
-    T* __restrict__ resps, T* __restrict__ log_norm, double* __restrict__ llh_sum) {
+    T* __restrict__ resps, T* __restrict__ log_norm, double* __restrict__ llh_sum,
+    const T* __restrict__ c0) {
     using M = Mma<T>;
     using acc_t = typename M::acc_t;
     using vec4_t = typename M::vec4_t;
@@ -188,7 +207,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 && MT * NT <= 32) ? 2 : 1
     }
 
     softmax_epilogue<T, NT, MT, GQ>(acc, fb, nframes, kbase, K, S, G, gl, jw, i, g, lane, resps,
-                                    log_norm, llh_sum);
+                                    log_norm, llh_sum, c0[0]);
 }
 
 // ---------------------------------------------------------------------------
@@ -389,15 +408,15 @@ inline int nchunks_for(int S, int K) { return S > 1 ? (K + 255) / 256 : 1; }
 
 template <typename T, int NT, int MT, int GQ>
 int launch_llh(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nchunks,
-               int nslab, const T* X, const T* P, const int* tab, T* resps, T* log_norm,
-               double* llh_sum, hipStream_t s) {
+               int nslab, const T* X, const T* P, const int* tab, const T* c0, T* resps,
+               T* log_norm, double* llh_sum, hipStream_t s) {
     const int D4 = d4_of(D), LD = 4 * D4 + 5;
     constexpr int FB = 16 * MT * (kThreads / 64);
     const size_t lds = (size_t)FB * LD * sizeof(T);
     const int64_t blocks = (nframes + FB - 1) / FB;
     hipLaunchKernelGGL((llh_kernel<T, NT, MT, GQ>), dim3((unsigned)blocks, (unsigned)nchunks),
                        dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nslab, X, P, tab,
-                       resps, log_norm, llh_sum);
+                       resps, log_norm, llh_sum, c0);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }
@@ -418,13 +437,17 @@ int estep_impl(int cov, int64_t nframes, int D, int S, int G, const T* X, const 
     const int64_t total = (int64_t)nchunks * nsp * 64 * NT;
     int64_t pblocks = (total + 255) / 256;
     if (pblocks > 65535) pblocks = 65535;
+    // (the constant's slot: behind the slab table, inside the workspace's spare 256 bytes)
+    T* c0 = reinterpret_cast<T*>(reinterpret_cast<char*>(tab) +
+                                 ((size_t)nsp * sizeof(int) + 15) / 16 * 16);
+    hipLaunchKernelGGL(const_max_kernel<T>, dim3(1), dim3(256), 0, s, cov, D, K, expT, logw, c0);
     hipLaunchKernelGGL(pack_kernel<T>, dim3((unsigned)pblocks), dim3(256), 0, s, cov, D, K, NT,
-                       nchunks, expT, logw, P, tab);
+                       nchunks, expT, logw, P, tab, c0);
     BEER_LAUNCH_CHECK();
     constexpr int MT = sizeof(T) == 4 ? 2 : 1;
 #define BEER_LLH(NT_, GQ_) \
     return launch_llh<T, NT_, MT, GQ_>(nframes, D, K, S, G, gl, jw, nchunks, nslab, X, P, tab, \
-                                       resps, log_norm, llh_sum, s)
+                                       c0, resps, log_norm, llh_sum, s)
     if (S == 1) {                                   // one group = the whole (padded) chunk
         const int gl = 16, jw = 4;
         if (NT == 4) BEER_LLH(4, 1);

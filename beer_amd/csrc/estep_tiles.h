@@ -1,5 +1,5 @@
 // Shared pieces of the matrix-core E-step kernels (estep_mfma.hip: exact
-// fp32 / fp64 MFMA; estep_f16.hip: fp32 operands split into two fp16 halves):
+// fp32 / fp64 MFMA; estep_bf16.hip: fp32 operands as three bf16 pieces):
 // MFMA traits, DPP row reductions, the slab enumeration of the contraction
 // index and the in-register softmax epilogue.  See estep_mfma.hip for the design.
 #pragma once
@@ -85,36 +85,107 @@ __device__ __forceinline__ T group_sum(T v, int gl) {
 
 __host__ __device__ inline int d4_of(int D) { return (D + 3) / 4; }
 
-// Slab enumeration per covariance type (see the header comment).  Diagonal and
-// isotropic models only have D4 "square" slabs xe[4j+g]^2 (flag bit 16 in the
-// table), D4 linear slabs and the constant slab.
+// Slab enumeration per covariance type (see the header comment of estep_mfma.hip).
+//
+// Diagonal and isotropic models have D4 "square" slabs xe[4q+g]^2 (flag bit 16 in the
+// table), D4 linear slabs 1 * xe[4q+g] and constant slabs 1 * (1, eps, 0, 0).  Their
+// order is chosen for the ACCUMULATOR: the terms of a logit, -1/2 lambda x^2 +
+// lambda mu x - 1/2 lambda mu^2, are each an order of magnitude larger than their
+// sum, and every accumulation rounds (the bf16 MFMA truncates) at the size of the
+// running sum.  So the square and the linear slab of the same four dimensions are
+// neighbours, and every group of 8 slabs (one k-step of the 32-deep MFMA) is closed
+// by a constant slab that carries the -1/2 lambda mu^2 of the dimensions seen so far
+// (`const_share`): after every k-step the accumulator holds
+// sum_d -1/2 lambda_d (x_d - mu_d)^2 -- small for the components that matter.
+//   kind 0 = square, 1 = linear, 2 = closing constant, 3 = final constant
+__host__ __device__ inline int diag_walk(int D, int s_query, int* kind, int* quad) {
+    // slab s_query -> (kind, quad); returns the slab count when s_query is not a slab
+    const int nitems = 2 * d4_of(D);
+    int it = 0;
+    for (int s = 0;; ++s) {
+        int k, q = 0;
+        if (it == nitems) k = 3;
+        else if ((s & 7) == 7) k = 2;
+        else { k = it & 1; q = it >> 1; ++it; }
+        if (s == s_query) { *kind = k; *quad = q; return s; }
+        if (k == 3) return s + 1;
+    }
+}
 __host__ __device__ inline int nslab_of(int cov, int D) {
     const int D4 = d4_of(D);
+    if (cov != BEER_FULL) { int k, q; return diag_walk(D, -1, &k, &q); }
     int n = D4 + 1;                                   // linear + constant
-    if (cov != BEER_FULL) return n + D4;
     for (int a = 0; a < D; ++a) n += D4 - a / 4;
     return n;
 }
 // slab s -> table entry  a | (4j << 8) | (square << 16)
 __host__ __device__ inline int slab_entry(int cov, int D, int s) {
     const int D4 = d4_of(D), Dp = 4 * D4, nslab = nslab_of(cov, D);
+    if (s >= nslab) return (Dp + 2) | (Dp << 8);          // padding: zero column
+    if (cov != BEER_FULL) {
+        int k, q;
+        diag_walk(D, s, &k, &q);
+        if (k == 0) return Dp | ((4 * q) << 8) | (1 << 16);
+        return k == 1 ? (Dp | ((4 * q) << 8)) : (Dp | (Dp << 8));
+    }
     const int nquad = nslab - (D4 + 1);
-    if (s >= nslab) return (Dp + 1) | (Dp << 8);          // padding: zero column
     if (s >= nquad) return Dp | ((4 * (s - nquad)) << 8);  // linear / constant
-    if (cov != BEER_FULL) return Dp | ((4 * s) << 8) | (1 << 16);
     int rem = s, a = 0;
     for (;;) { const int len = D4 - a / 4; if (rem < len) break; rem -= len; ++a; }
     return a | ((4 * (a / 4 + rem)) << 8);
 }
 // index of the quadratic slab holding x_a * x_b (a <= b), of linear slab j
-// (a == Dp) and of the constant slab (a == Dp, j == D4)
+// (a == Dp) and of the (final) constant slab (a == Dp, j == D4)
 __host__ __device__ inline int slab_index(int cov, int D, int a, int j) {
     const int D4 = d4_of(D);
+    if (cov != BEER_FULL) {
+        const int nslab = nslab_of(cov, D);
+        if (a >= D && j >= D4) return nslab - 1;
+        const int want = a >= D ? 1 : 0;                 // linear / square slab of quad j
+        for (int s = 0; s < nslab; ++s) {
+            int k, q;
+            diag_walk(D, s, &k, &q);
+            if (k == want && q == j) return s;
+        }
+        return nslab - 1;
+    }
     if (a >= D) return nslab_of(cov, D) - (D4 + 1) + j;
-    if (cov != BEER_FULL) return j;                       // square slab of x_{4j..4j+3}
     const int q = a / 4, r = a % 4;
     const int before = 4 * (q * D4 - q * (q - 1) / 2) + r * (D4 - q);
     return before + (j - q);
+}
+// The constant term of component `row` (E[T], any float type) that constant slab
+// `slab` carries.  Full covariance: one slab, the whole constant.  Diagonal /
+// isotropic: a closing slab holds -1/2 sum_d (lambda mu)_d^2 / lambda_d over the
+// dimensions whose linear slab lies between the previous constant slab and itself;
+// the final one the rest, so that the shares add up to the constant exactly.
+template <typename T>
+__host__ __device__ inline double const_total(int cov, int D, const T* row, double logw) {
+    const int Q = stats_dim(cov, D);
+    const double zero = cov == BEER_ISO ? 0.5 * (double)D : 0.5;
+    return -0.5 * (double)row[Q - 2] + zero * (double)row[Q - 1] - 0.5 * (double)D * kLog2Pi + logw;
+}
+template <typename T>
+__host__ __device__ inline double const_share(int cov, int D, int slab, const T* row, double logw) {
+    const double total = const_total(cov, D, row, logw);
+    if (cov == BEER_FULL) return total;
+    double given = 0.0, pending = 0.0;
+    const int nslab = nslab_of(cov, D);
+    for (int s = 0; s < nslab; ++s) {
+        int k, q;
+        diag_walk(D, s, &k, &q);
+        if (k == 1) {
+            for (int d = 4 * q; d < 4 * q + 4 && d < D; ++d) {
+                const double lam = (double)row[cov == BEER_ISO ? D : D + d], lm = (double)row[d];
+                if (lam > 0.0) pending -= 0.5 * lm * lm / lam;
+            }
+        } else if (k >= 2) {
+            if (s == slab) return k == 3 ? total - given : pending;
+            given += pending;
+            pending = 0.0;
+        }
+    }
+    return 0.0;
 }
 
 // slabs in the packed parameter image: an even count (the K1 loop is unrolled
@@ -177,20 +248,60 @@ __global__ void unpack_kernel(int cov, int D, int K, const double* __restrict__ 
 // ---------------------------------------------------------------------------
 // PACKED (float only): instead of float32 responsibilities, `resps` receives
 // them as the accumulation kernel's LDS image, so that it copies them there
-// without arithmetic.  The image is cut into tiles of 64 frames x 128
-// components (tile index tau * nblk + beta, 32 KB each): first the fp16 high
-// halves of r * 2^12 as rows [component][64 frames] of 128 bytes whose 16-byte
-// chunks (8 frames) are stored at position chunk ^ (component & 7) -- the
-// swizzle that makes the MFMA fragment reads conflict-free -- then the low
-// halves in the same arrangement.  Frames past T and components past K are 0.
-constexpr int kPackedRespBits = 12;
-constexpr int kPackedFrames = 64, kPackedComps = 128;
+// without arithmetic.  Every responsibility is held EXACTLY as three bf16 pieces,
+// r = p0 + p1 + p2 (split3 below: 3 x 8 significand bits = the 24 of float32, bf16
+// has float32's exponent range, so there is no scaling and nothing to undo).  The
+// image is cut into tiles of 64 frames x 128 components (tile index
+// tau * nblk + beta, 48 KB each): three planes of 16 KB, plane q = the pieces p_q
+// as rows [component][64 frames] of 128 bytes whose 16-byte chunks (8 frames) are
+// stored at position chunk ^ (component & 7) -- the swizzle that makes the MFMA
+// fragment reads conflict-free.  Frames past T and components past K are 0.
+constexpr int kPackedFrames = 64, kPackedComps = 128, kPackedPieces = 3;
+constexpr int kPackedPlaneWords = kPackedComps * kPackedFrames / 2;       // 32-bit words
 
-// 32-bit word index of the hi half of (component kk of block beta, frame f6 of
-// tile tau); the lo half is kPackedComps * kPackedFrames / 2 words further
+// 32-bit word index of piece 0 of (component kk of block beta, frame f6 of tile
+// tau); piece q is q * kPackedPlaneWords words further
 __host__ __device__ inline size_t packed_word(int64_t tau, int nblk, int beta, int kk, int f6) {
     const int half = kk * kPackedFrames + (((f6 >> 3) ^ (kk & 7)) << 3) + (f6 & 7);
-    return ((size_t)tau * nblk + beta) * (kPackedComps * kPackedFrames) + (half >> 1);
+    return ((size_t)tau * nblk + beta) * (kPackedPieces * kPackedPlaneWords) + (half >> 1);
+}
+
+// A pair of float32 values as three words of two bf16 each, v = p0 + p1 + p2
+// EXACTLY: p0 = bf16(v) (round to nearest even, v_cvt_pk_bf16_f32), the remainder
+// v - p0 is exact in float32 and has at most 16 significant bits, p1 = bf16 of it,
+// the second remainder has at most 8 and is a bf16 itself.  Rounding to nearest
+// (not truncation) keeps the pieces' signs independent, so that the products a
+// six-term multiplication drops (p1 q2 + p2 p1', 2^-24 of the product) carry no
+// systematic sign.  The low half of a word is the first value of the pair.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2_t));
+}
+__device__ __forceinline__ void split3(float a, float b, unsigned (&p)[3]) {
+    p[0] = cvt_pk_bf16(a, b);
+    float ra = a - __builtin_bit_cast(float, p[0] << 16);
+    float rb = b - __builtin_bit_cast(float, p[0] & 0xffff0000u);
+    p[1] = cvt_pk_bf16(ra, rb);
+    ra -= __builtin_bit_cast(float, p[1] << 16);
+    rb -= __builtin_bit_cast(float, p[1] & 0xffff0000u);
+    p[2] = cvt_pk_bf16(ra, rb);
+}
+// the same on the host / in scalar device code (parameter packing): bf16 bits
+__host__ __device__ inline unsigned short bf16_rne(float v) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);   // inf / nan
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__host__ __device__ inline void split3_scalar(float v, unsigned short (&p)[3]) {
+    p[0] = bf16_rne(v);
+    float r = v - __builtin_bit_cast(float, (unsigned)p[0] << 16);
+    if (!(r == r) || r - r != 0.f) r = 0.f;                 // v = +-inf: the first piece holds it
+    p[1] = bf16_rne(r);
+    r -= __builtin_bit_cast(float, (unsigned)p[1] << 16);
+    p[2] = bf16_rne(r);
 }
 
 // LNO: only the log-normalisers are wanted (the accumulation recomputes the
@@ -199,7 +310,9 @@ template <typename T, int NT, int MT, int GQ, bool PACKED = false, bool LNO = fa
 __device__ __forceinline__ void softmax_epilogue(
     typename Mma<T>::acc_t (&acc)[MT][NT], int64_t fb, int64_t nframes, int kbase, int K, int S,
     int G, int gl, int jw, int i, int g, int lane, T* __restrict__ resps,
-    T* __restrict__ log_norm, double* __restrict__ llh_sum) {
+    T* __restrict__ log_norm, double* __restrict__ llh_sum, T shift = 0) {
+    // `shift`: a constant the caller took out of every logit (softmax is invariant to
+    // it); it goes back into the log-normalisers here
     using M = Mma<T>;
     using vec4_t = typename M::vec4_t;
     double llh_local = 0.0;
@@ -230,7 +343,7 @@ __device__ __forceinline__ void softmax_epilogue(
                             sum += e[qq][j];
                         }
                     sum = group_sum(sum, gl);
-                    const T lse = mx + M::log_sum(sum);
+                    const T lse = (mx + M::log_sum(sum)) + shift;
                     if (!LNO) {
                         const T inv = M::recip(sum);
 #pragma unroll
@@ -251,7 +364,7 @@ __device__ __forceinline__ void softmax_epilogue(
                         if (jw == 2) {
                             const T mx = a0 > a1 ? a0 : a1;
                             const T e0 = M::exp_neg(a0 - mx), e1 = M::exp_neg(a1 - mx);
-                            const T lse = mx + M::log_sum(e0 + e1);
+                            const T lse = (mx + M::log_sum(e0 + e1)) + shift;
                             e[0][j0] = e0 / (e0 + e1);
                             e[0][j0 + 1] = e1 / (e0 + e1);
                             const int state = (kq + j0) / G;
@@ -264,12 +377,12 @@ __device__ __forceinline__ void softmax_epilogue(
                             e[0][j0 + 1] = 1;
                             if (f < nframes) {
                                 if (kq + j0 < K) {
-                                    if (log_norm) log_norm[f * S + kq + j0] = a0;
-                                    llh_local += (double)a0;
+                                    if (log_norm) log_norm[f * S + kq + j0] = a0 + shift;
+                                    llh_local += (double)(a0 + shift);
                                 }
                                 if (kq + j0 + 1 < K) {
-                                    if (log_norm) log_norm[f * S + kq + j0 + 1] = a1;
-                                    llh_local += (double)a1;
+                                    if (log_norm) log_norm[f * S + kq + j0 + 1] = a1 + shift;
+                                    llh_local += (double)(a1 + shift);
                                 }
                             }
                         }
@@ -309,12 +422,8 @@ __device__ __forceinline__ void softmax_epilogue(
         // the whole chunk of m = 0 and the odd-g lane with that of m = 1, so that
         // every lane stores 16 bytes and 4 lanes fill a 64-byte segment of the row.
         static_assert(!PACKED || MT % 2 == 0, "the lane pairs exchange two frame tiles");
-        typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-        typedef float float4_t __attribute__((ext_vector_type(4)));
-        typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
         typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
         unsigned int* out = reinterpret_cast<unsigned int*>(resps);
-        const float up = (float)(1 << kPackedRespBits);
         const int nblk = (K + kPackedComps - 1) / kPackedComps;
         const int64_t tiles = (nframes + kPackedFrames - 1) / kPackedFrames;
 #pragma unroll
@@ -328,36 +437,37 @@ __device__ __forceinline__ void softmax_epilogue(
             for (int nt = 0; nt < NT; ++nt) {
                 __builtin_amdgcn_sched_barrier(0);
                 const int k = kbase + 64 * (nt >> 2) + 4 * i + (nt & 3);
-                uint2_t hi[2], lo[2];
+                unsigned pw[2][2][kPackedPieces];              // [tile of the pair][word][piece]
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm) {
                     const int m = 2 * mp + mm;
                     const int64_t f0 = fb + m * 16 + M::row(g, 0);
-                    float4_t v;
+                    float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        v[r] = f0 + r < nframes && k < K ? (float)acc[m][nt][r] * up : 0.f;
-                    const half4_t h = __builtin_convertvector(v, half4_t);
-                    const half4_t l = __builtin_convertvector(
-                        v - __builtin_convertvector(h, float4_t), half4_t);
-                    hi[mm] = __builtin_bit_cast(uint2_t, h);
-                    lo[mm] = __builtin_bit_cast(uint2_t, l);
+                        v[r] = f0 + r < nframes && k < K ? (float)acc[m][nt][r] : 0.f;
+                    split3(v[0], v[1], pw[mm][0]);
+                    split3(v[2], v[3], pw[mm][1]);
                 }
-                uint4_t ch, cl;
+                // (the exchange is a cross-lane operation: every lane takes part, only the
+                // store is conditional)
+                uint4_t ch[kPackedPieces];
 #pragma unroll
-                for (int wd = 0; wd < 2; ++wd) {
-                    const auto sh = __builtin_amdgcn_permlane16_swap(hi[0][wd], hi[1][wd], false, false);
-                    const auto sl = __builtin_amdgcn_permlane16_swap(lo[0][wd], lo[1][wd], false, false);
-                    ch[wd] = sh[0]; ch[2 + wd] = sh[1];
-                    cl[wd] = sl[0]; cl[2 + wd] = sl[1];
-                }
+                for (int q = 0; q < kPackedPieces; ++q)
+#pragma unroll
+                    for (int wd = 0; wd < 2; ++wd) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(pw[0][wd][q], pw[1][wd][q],
+                                                                         false, false);
+                        ch[q][wd] = sw[0]; ch[q][2 + wd] = sw[1];
+                    }
                 if (chunk_ok && k < nblk * kPackedComps) {
                     unsigned int* dst = out + packed_word(tau, nblk, k / kPackedComps,
                                                           k & (kPackedComps - 1), f6);
                     // non-temporal: streamed once; keeps the packed parameters in L2
-                    __builtin_nontemporal_store(ch, reinterpret_cast<uint4_t*>(dst));
-                    __builtin_nontemporal_store(
-                        cl, reinterpret_cast<uint4_t*>(dst + kPackedComps * kPackedFrames / 2));
+#pragma unroll
+                    for (int q = 0; q < kPackedPieces; ++q)
+                        __builtin_nontemporal_store(
+                            ch[q], reinterpret_cast<uint4_t*>(dst + q * kPackedPlaneWords));
                 }
             }
         }
@@ -365,138 +475,6 @@ __device__ __forceinline__ void softmax_epilogue(
     if (llh_sum) {
         llh_local = wave_sum(llh_local);
         if (lane == 0) atomicAdd(llh_sum, llh_local);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Epilogue of K1 when TWO waves share the frames of a tile and own one half of
-// the components each (one mixture, float, packed output): the logsumexp over
-// all components needs the partner's partial maximum and partial sum, exchanged
-// through LDS (`xch`: 2 x 4 waves x 16 MT floats; two workgroup barriers).
-// acc[m][nt] of a wave = component kbase + 64 (nt / 4) + 4 i + nt % 4 (kbase
-// includes the wave's half), frames fb + 16 m + 4 g + (0..3).  Writes the packed
-// tiles (see PACKED above), log_norm and llh_sum (from the even wave).
-// ---------------------------------------------------------------------------
-template <int NT, int MT>
-__device__ __forceinline__ void softmax_epilogue_pair(
-    f32x4 (&acc)[MT][NT], int64_t fb, int64_t nframes, int kbase, int K, int i, int g, int lane,
-    int wave, float* __restrict__ xch, float* __restrict__ resps, float* __restrict__ log_norm,
-    double* __restrict__ llh_sum) {
-    using M = Mma<float>;
-    static_assert(MT % 2 == 0, "lane pairs exchange two frame tiles");
-    constexpr int ROWS = 16 * MT;
-    float* mine = xch + wave * ROWS;
-    const float* theirs = xch + (wave ^ 1) * ROWS;
-    float mx[MT][4];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = acc[m][0][r];
-#pragma unroll
-            for (int nt = 1; nt < NT; ++nt) v = acc[m][nt][r] > v ? acc[m][nt][r] : v;
-            v = group_max(v, 16);
-            mx[m][r] = v;
-            if (i == 0) mine[m * 16 + M::row(g, r)] = v;
-        }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float o = theirs[m * 16 + M::row(g, r)];
-            mx[m][r] = o > mx[m][r] ? o : mx[m][r];
-        }
-    float* mine_s = mine + 4 * ROWS;
-    const float* theirs_s = theirs + 4 * ROWS;
-    float sum[MT][4];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            __builtin_amdgcn_sched_barrier(0);
-            float sacc = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float e = M::exp_neg(acc[m][nt][r] - mx[m][r]);
-                acc[m][nt][r] = e;
-                sacc += e;
-            }
-            sacc = group_sum(sacc, 16);
-            sum[m][r] = sacc;
-            if (i == 0) mine_s[m * 16 + M::row(g, r)] = sacc;
-        }
-    __syncthreads();
-    double llh_local = 0.0;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float total = sum[m][r] + theirs_s[m * 16 + M::row(g, r)];
-            const float inv = M::recip(total);
-            const int64_t f = fb + m * 16 + M::row(g, r);
-            if ((wave & 1) == 0 && i == 0 && f < nframes) {
-                const float lse = mx[m][r] + M::log_sum(total);
-                if (log_norm) log_norm[f] = lse;
-                llh_local += (double)lse;
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[m][nt][r] *= inv;
-        }
-    // packing: as in softmax_epilogue<PACKED>, per pair of frame tiles
-    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-    typedef float float4_t __attribute__((ext_vector_type(4)));
-    typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
-    typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
-    unsigned int* out = reinterpret_cast<unsigned int*>(resps);
-    const float up = (float)(1 << kPackedRespBits);
-    const int nblk = (K + kPackedComps - 1) / kPackedComps;
-    const int64_t tiles = (nframes + kPackedFrames - 1) / kPackedFrames;
-#pragma unroll
-    for (int mp = 0; mp < MT / 2; ++mp) {
-        const int64_t fc = fb + 32 * mp + 16 * (g & 1) + 8 * (g >> 1);
-        const int64_t tau = fc / kPackedFrames;
-        const int f6 = (int)(fc - tau * kPackedFrames);
-        const bool chunk_ok = out && fc < tiles * kPackedFrames;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            __builtin_amdgcn_sched_barrier(0);
-            const int k = kbase + 64 * (nt >> 2) + 4 * i + (nt & 3);
-            uint2_t hi[2], lo[2];
-#pragma unroll
-            for (int mm = 0; mm < 2; ++mm) {
-                const int m = 2 * mp + mm;
-                const int64_t f0 = fb + m * 16 + M::row(g, 0);
-                float4_t v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] = f0 + r < nframes && k < K ? acc[m][nt][r] * up : 0.f;
-                const half4_t h = __builtin_convertvector(v, half4_t);
-                const half4_t l = __builtin_convertvector(
-                    v - __builtin_convertvector(h, float4_t), half4_t);
-                hi[mm] = __builtin_bit_cast(uint2_t, h);
-                lo[mm] = __builtin_bit_cast(uint2_t, l);
-            }
-            uint4_t ch, cl;
-#pragma unroll
-            for (int wd = 0; wd < 2; ++wd) {
-                const auto sh = __builtin_amdgcn_permlane16_swap(hi[0][wd], hi[1][wd], false, false);
-                const auto sl = __builtin_amdgcn_permlane16_swap(lo[0][wd], lo[1][wd], false, false);
-                ch[wd] = sh[0]; ch[2 + wd] = sh[1];
-                cl[wd] = sl[0]; cl[2 + wd] = sl[1];
-            }
-            if (chunk_ok && k < nblk * kPackedComps) {
-                unsigned int* dst = out + packed_word(tau, nblk, k / kPackedComps,
-                                                      k & (kPackedComps - 1), f6);
-                __builtin_nontemporal_store(ch, reinterpret_cast<uint4_t*>(dst));
-                __builtin_nontemporal_store(
-                    cl, reinterpret_cast<uint4_t*>(dst + kPackedComps * kPackedFrames / 2));
-            }
-        }
-    }
-    if (llh_sum) {
-        llh_local = wave_sum(llh_local);
-        if (lane == 0 && (wave & 1) == 0) atomicAdd(llh_sum, llh_local);
     }
 }
 

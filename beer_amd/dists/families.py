@@ -227,9 +227,7 @@ class NormalWishart(_NormalFamily):
     def update_from_natural_parameters(self, natural_params):
         '''The M-step in one launch (`beer_nw_update`): standard parameters from the
         natural ones and -- from the same factorisation -- E[T] and the log-normaliser
-        of the new posterior, which the next iteration asks for (they go into the memo),
-        plus the moments of its expected Gaussian, attached to E[T] for the packed
-        E-step (`kernels._moments`).'''
+        of the new posterior, which the next iteration asks for (they go into the memo).'''
         eta = natural_params.detach()
         if eta.dim() != 2:
             return super().update_from_natural_parameters(natural_params)
@@ -240,14 +238,13 @@ class NormalWishart(_NormalFamily):
         dev = deta.device
         new = lambda *shape: torch.empty(*shape, dtype=dtype, device=dev)          # noqa: E731
         mean, scale, W, dof = new(K, D), new(K, 1), new(K, D, D), new(K, 1)
-        exp, lnorm, moments = new(K, Q), new(K), new(K, D + D * D)
+        exp, lnorm = new(K, Q), new(K)
         _hip.call('beer_nw_update', _hip.dtype_code(dtype), K, D, _hip.ptr(deta), _hip.ptr(mean),
                   _hip.ptr(scale), _hip.ptr(W), _hip.ptr(dof), _hip.ptr(exp), _hip.ptr(lnorm),
-                  _hip.ptr(moments))
+                  None)
         self.params = self._std_params_cls(*[t.to(home) for t in (mean, scale, W, dof)])
         self.__dict__['_memo'] = {}
         exp, lnorm = exp.to(home), lnorm.to(home)
-        exp._beer_moments = moments
         self._memoised('nat', lambda: eta)
         self._memoised('exp', lambda: exp)
         self._memoised('lnorm', lambda: lnorm)

@@ -22,20 +22,9 @@ def is_dense(stats):
 
 
 def _exact(X):
-    '''Whether this call multiplies float32 frames exactly: the fp16-split matrix
-    path is only for frames that are numerous and well ranged (`_hip.f32_split_ok`).'''
-    return X.dtype == torch.float32 and not _hip.f32_split_ok(X)
-
-
-def _moments(exp_stats, K, D, device):
-    '''The components' moments that travel with a Normal-Wishart's expected statistics
-    (`dists.NormalWishart` attaches them after an update), as the packed E-steps take
-    them: float32 [K, D + D*D] on `device`, or None.'''
-    m = getattr(exp_stats, '_beer_moments', None)
-    if m is None or m.dtype != torch.float32 or m.device != device or \
-            tuple(m.shape) != (K, D + D * D):
-        return None
-    return m
+    '''Whether this call multiplies float32 frames on the exact fp32 MFMA: small
+    inputs, or the caller asked for it (`_hip.f32_fast_ok`).'''
+    return X.dtype == torch.float32 and not _hip.f32_fast_ok(X)
 
 
 def _frames(stats):
@@ -77,7 +66,7 @@ def mixtureset_estep(stats, exp_stats, log_weights, S, G, cov_type, labels=None,
     # the generic kernels normalise in place in the responsibilities buffer; the
     # matrix-core kernels keep them in registers.  Those take group-aligned shapes
     # (one mixture, or G a power of two) in every arithmetic, and any G on the
-    # float32 split path when no responsibilities are wanted (padded groups).
+    # float32 bf16x3 path when no responsibilities are wanted (padded groups).
     exact = _exact(X)
     aligned = S == 1 or (G & (G - 1)) == 0
     on_matrix_cores = ws is not None and labels is None and st.scale == 1.0 and \
@@ -95,10 +84,10 @@ def mixtureset_estep(stats, exp_stats, log_weights, S, G, cov_type, labels=None,
 
 
 class PackedResps:
-    '''Responsibilities [T, K] of one mixture in the form the fp16 accumulation
+    '''Responsibilities [T, K] of one mixture in the form the bf16x3 accumulation
     kernel multiplies with (include/beer_hip.h: beer_mixture_estep_packed):
-    `words` int32, the tiles of 64 frames x 128 components that kernel copies
-    to LDS.  `unpack()` gives the float32 matrix.'''
+    `words` int32, the three-plane tiles of 64 frames x 128 components that kernel
+    copies to LDS.  `unpack()` gives the float32 matrix (exactly).'''
 
     def __init__(self, words, nframes, ncomp):
         self.words, self.shape = words, (nframes, ncomp)
@@ -113,10 +102,10 @@ class PackedResps:
 def packed_path_ok(stats, K, cov_type):
     '''True when the E-step of a K-component mixture over `stats` can hand its
     responsibilities to the accumulation in packed form: float32 frames on the
-    fp16-split path, unscaled, shapes with a matrix-core kernel on both sides.'''
+    bf16x3 path, unscaled, shapes with a matrix-core kernel on both sides.'''
     st = _frames(stats)
     X = st.data
-    if st.scale != 1.0 or not _hip.f32_split_ok(X):
+    if st.scale != 1.0 or not _hip.f32_fast_ok(X):
         return False
     code, D = _hip.COV_CODE[cov_type], X.shape[1]
     lib, dt = _hip.lib(), _hip.dtype_code(X.dtype)
@@ -135,7 +124,6 @@ def mixture_estep_packed(stats, exp_stats, log_weights, K, cov_type, llh_sum=Non
     lw = _hip.on_device(log_weights, X.dtype)
     if E.shape[0] != K or lw.numel() != K:
         raise ValueError(f'{E.shape[0]} Gaussians, {lw.numel()} weights for {K} components')
-    mom = _moments(exp_stats, K, D, X.device) if cov_type == 'full' else None
     log_norm = torch.empty(T, 1, dtype=X.dtype, device=X.device)
     words = torch.empty(_hip.lib().beer_packed_resps_bytes(T, D, K) // 4, dtype=torch.int32,
                         device=X.device)
@@ -143,7 +131,7 @@ def mixture_estep_packed(stats, exp_stats, log_weights, K, cov_type, llh_sum=Non
                                   _hip.COV_CODE[cov_type], D, 1, K, X.device)
     _hip.call('beer_mixture_estep_packed', _hip.COV_CODE[cov_type], T, D, K, _hip.ptr(X),
               _hip.ptr(E), _hip.ptr(lw), _hip.ptr(log_norm), _hip.ptr(words), _hip.ptr(llh_sum),
-              _hip.ptr(_hip.frame_scales(X)), _hip.ptr(mom), _hip.ptr(ws), ws_bytes)
+              _hip.ptr(ws), ws_bytes)
     return log_norm, PackedResps(words, T, K)
 
 
@@ -151,11 +139,11 @@ def packed_sets_ok(stats, S, G, cov_type):
     '''True when a mixture SET can hand the responsibilities within its states'
     mixtures to the accumulation as packed tiles, the state posteriors being
     multiplied in by the accumulation kernel (include/beer_hip.h:
-    beer_mixtureset_estep_packed): float32 frames on the fp16-split path, full
+    beer_mixtureset_estep_packed): float32 frames on the bf16x3 path, full
     covariance, G a power of two in 8..128.'''
     st = _frames(stats)
     X = st.data
-    if st.scale != 1.0 or X.dtype != torch.float32 or not _hip.f32_split_ok(X):
+    if st.scale != 1.0 or X.dtype != torch.float32 or not _hip.f32_fast_ok(X):
         return False
     return bool(_hip.lib().beer_mixtureset_packed_supported(_hip.COV_CODE[cov_type], X.shape[1],
                                                             S, G))
@@ -178,10 +166,9 @@ def mixtureset_estep_packed(stats, exp_stats, log_weights, S, G, cov_type, llh_s
                         device=X.device)
     ws, ws_bytes = _hip.workspace('beer_estep_workspace_bytes', X.dtype,
                                   _hip.COV_CODE[cov_type], D, S, G, X.device)
-    mom = _moments(exp_stats, K, D, X.device) if cov_type == 'full' else None
     _hip.call('beer_mixtureset_estep_packed', _hip.COV_CODE[cov_type], T, D, S, G, _hip.ptr(X),
               _hip.ptr(E), _hip.ptr(lw), _hip.ptr(log_norm), _hip.ptr(words), _hip.ptr(llh_sum),
-              _hip.ptr(mom), _hip.ptr(ws), ws_bytes)
+              _hip.ptr(ws), ws_bytes)
     return log_norm, PackedResps(words, T, K)
 
 
@@ -216,7 +203,7 @@ def wide_mixture_split(stats, K, cov_type):
     None otherwise (the generic kernels take it).'''
     st = _frames(stats)
     X = st.data
-    if K <= 256 or st.scale != 1.0 or X.dtype != torch.float32 or not _hip.f32_split_ok(X):
+    if K <= 256 or st.scale != 1.0 or X.dtype != torch.float32 or not _hip.f32_fast_ok(X):
         return None
     first = -(-K // 256)
     for S2 in range(first, min(K // 8, first + 64) + 1):
@@ -269,7 +256,7 @@ def _repack_pays(stats, K, cov_type):
     the packed kernel is faster (K = 1920, D = 40: 11.8 -> 6 ms per 500 k frames).'''
     X = stats.data
     if cov_type != 'full' or stats.shape[1] <= 512 or K % 4 or stats.scale != 1.0 or \
-            not _hip.f32_split_ok(X):
+            not _hip.f32_fast_ok(X):
         return False
     return _hip.lib().beer_accumulate_workspace_bytes(
         _hip.dtype_code(X.dtype), _hip.COV_CODE[cov_type], X.shape[1], 1, K) > 0
@@ -333,11 +320,11 @@ def normal_accumulate(stats, comp_resps, state_resps, S, G, cov_type, acc=None):
 
 def fused_accumulate_ok(stats, S, G, cov_type):
     '''True when `mixtureset_accumulate_fused` takes the call: float32 frames on the
-    fp16-split path, unscaled, diagonal / isotropic Gaussians (few statistics per
+    bf16x3 path, unscaled, diagonal / isotropic Gaussians (few statistics per
     Gaussian) -- the E-step then needs to leave no responsibilities behind.'''
     st = _frames(stats)
     X = st.data
-    if st.scale != 1.0 or not _hip.f32_split_ok(X):
+    if st.scale != 1.0 or not _hip.f32_fast_ok(X):
         return False
     # the E-step that leaves the log-normalisers must be the matrix-core one: the
     # recomputed logits then carry the same roundings as the normalisers (against the

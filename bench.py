@@ -40,7 +40,7 @@ from beer_amd.distributed import all_reduce_elbo, shard_utterances   # noqa: E40
 K, D = 256, 40
 Q = D * D + D + 2
 # MI355X_MICROARCH.md: dense MFMA peaks (f32 operands; f16 operands / f32 accumulate), HBM3E
-PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6, 'f16': 2500.}
+PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6, 'bf16': 2500.}
 PEAK_HBM_GBS = 8000.
 
 
@@ -326,7 +326,7 @@ def run_gmm(args, rank, world, device, backend):
     mode = beer.get_f32_mode()
     # secondary: the same iteration on the exact fp32 MFMA (every product an fmaf)
     exact = None
-    if mode == 'split_f16' and not args.no_exact:
+    if mode == 'bf16x3' and not args.no_exact:
         with _hip.exact_f32():
             e_steps = max(2, min(5, args.steps))
             e_elapsed, e_kt, _ = timed_loop(e_steps, 1)
@@ -343,22 +343,23 @@ def run_gmm(args, rank, world, device, backend):
         return None
     ms_per_step = 1e3 * elapsed / args.steps
     dom = max(kern, key=lambda nm: kern[nm]['ms'] * kern[nm]['launches'])
-    split = mode == 'split_f16'
-    peak = PEAK_TFLOPS['f16' if split else 'f32']
+    split = mode == 'bf16x3'
+    peak = PEAK_TFLOPS['bf16' if split else 'f32']
     if split:
-        note = ('fp32 operands are split into two fp16 halves and every product is three '
-                'v_mfma_f32_16x16x32_f16 (fp32 accumulate), so the peak is the dense fp16 MFMA '
-                'peak; achieved = algorithmic flops (2*K*Q per frame, no symmetry discount, '
-                'one flop pair per product) / HIP-event time of the C-ABI call.  The matrix '
-                'cores execute 3 * 2*K*928 flop per frame (1.70x the algorithmic count): '
-                'hardware rate = 1.70 * achieved.  f32_exact: the same iteration on the exact '
+        note = ('every fp32 operand is held exactly as three bf16 pieces and every product is '
+                'the six leading partial products on v_mfma_f32_16x16x32_bf16 (fp32 accumulate): '
+                'operands and accumulation are fp32, product error <= 2^-23.  The peak is the '
+                'dense bf16 MFMA peak; achieved = algorithmic flops (2*K*Q per frame, no symmetry '
+                'discount, one flop pair per product) / HIP-event time of the C-ABI call.  The '
+                'matrix cores execute 6 * 2*K*928 flop per frame (3.39x the algorithmic count): '
+                'hardware rate = 3.39 * achieved.  f32_exact: the same iteration on the exact '
                 'fp32 MFMA (peak 157.3).')
     else:
         note = ('achieved = algorithmic flops (2*K*Q per frame, no symmetry discount) / '
                 'HIP-event time of the C-ABI call; the kernels contract only the D(D+1)/2 '
                 'symmetric products (0.56x the multiply-adds), so frac can exceed 1')
-    pmc_key = (('acc16d_kernel' if 'packed' in dom else 'acc16_kernel') if split else 'acc_kernel') \
-        if 'accumulate' in dom else ('llh16_kernel' if split else 'llh_kernel')
+    pmc_key = ('accx_kernel' if split else 'acc_kernel') \
+        if 'accumulate' in dom else ('llhx_kernel' if split else 'llh_kernel')
     out = {
         'metric': 'frames/sec per VB iteration (E+M)', 'value': datasize * args.steps / elapsed,
         'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -557,9 +558,9 @@ def run_hmm(args, rank, world, device, backend):
     achieved = alg_bytes / (kern[dom]['ms'] * 1e-3) / 1e9
     pmc_key = ('c3full_' if args.cov == 'full' else 'c3_') + {
                        'beer_mixtureset_accumulate_fused': 'accf_kernel',
-                       'beer_mixtureset_estep_packed': 'llh16_kernel',
-                       'beer_mixtureset_accumulate_packed': 'acc16d_kernel',
-                       'beer_mixtureset_estep': 'llh16_kernel',
+                       'beer_mixtureset_estep_packed': 'llhx_kernel',
+                       'beer_mixtureset_accumulate_packed': 'accx_kernel',
+                       'beer_mixtureset_estep': 'llhx_kernel',
                        'beer_hmm_posteriors_fused': 'fb_wave_kernel'}.get(dom, dom)
     Qd = {'diagonal': 2 * D + 2, 'full': D * D + D + 2, 'isotropic': D + 3}[args.cov]
     out = {

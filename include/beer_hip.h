@@ -54,21 +54,16 @@ int beer_hip_device_count(void);
 
 /* How float32 models multiply on the matrix cores is chosen PER CALL (float64
  * models always use the exact fp64 MFMA): the `dtype` argument of
- * beer_mixtureset_estep and beer_normal_accumulate is BEER_F32 for the default,
- * split arithmetic -- every fp32 operand split into two fp16 halves, three
- * v_mfma_f32_16x16x32_f16 per product, fp32 accumulation: product error <= 2^-21
- * relative (fp32: 2^-24) at 5.3x the MFMA rate -- or BEER_F32 | BEER_EXACT for
- * v_mfma_f32_16x16x4_f32, bitwise an fmaf chain.  The library keeps no mode. */
+ * beer_mixtureset_estep is BEER_F32 for the default arithmetic, "bf16x3" -- every
+ * fp32 operand is held EXACTLY as three bf16 pieces (3 x 8 significand bits = the
+ * 24 of fp32, fp32's exponent range: no scaling, no range restrictions) and every
+ * product is the six leading partial products on v_mfma_f32_16x16x32_bf16, fp32
+ * accumulation: operands and accumulation are fp32's own, what a product drops is
+ * <= 2^-23 of it (2^-25 typically, no systematic sign), at 2.7x the rate of the
+ * fp32 pipe -- or BEER_F32 | BEER_EXACT for v_mfma_f32_16x16x4_f32, bitwise an
+ * fmaf chain.  The packed hand-over calls below (beer_mixture_estep_packed, ...)
+ * are bf16x3 by construction.  The library keeps no mode. */
 #define BEER_EXACT 0x10
-/* Range check for the split arithmetic on float32 frames X [T, D] (D <= 64):
- * *hazard (device int) = 1 when some dimension's largest magnitude exceeds 2^9
- * times its mean magnitude (or is not finite).  The split path scales every
- * dimension so that its maximum is 2^7; values that far below the maximum
- * would have their products rounded in fp16's subnormal range.  The host
- * layer runs this once per data tensor and uses the exact path for such data.
- * scratch: >= 768 bytes of device memory. */
-int beer_f32_split_hazard(int64_t T, int D, const void* X, void* scratch,
-                          int* hazard, void* stream);
 
 /* ------------------------------------------------------------------------
  * Exponential-family parameter kernels (once per VB iteration, K = number of
@@ -109,10 +104,8 @@ int beer_nw_from_natural(int dtype, int K, int D, const void* eta, void* mean,
  * elimination, what the next iteration asks of the new posterior: `exp_stats`
  * [K, D*D+D+2] (expected_sufficient_statistics, normalwishart.py:170-210),
  * `log_norm` [K] (normalwishart.py:219-236) and, when `moments` is not NULL, the
- * moments of its expected Gaussian, [K, D + D*D] = (mean, E[Lambda]^-1 = W^-1 / nu)
- * -- what the split E-step compensates its parameter rounding with
- * (beer_mixture_estep_packed).  One factorisation where the three separate calls
- * make two and an inverse. */
+ * moments of its expected Gaussian, [K, D + D*D] = (mean, E[Lambda]^-1 = W^-1 / nu).
+ * One factorisation where the three separate calls make two and an inverse. */
 int beer_nw_update(int dtype, int K, int D, const void* eta, void* mean, void* scale,
                    void* scale_matrix, void* dof, void* exp_stats, void* log_norm,
                    void* moments, void* stream);
@@ -257,26 +250,21 @@ int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G,
                            const void* state_resps, double* acc, void* workspace,
                            size_t workspace_bytes, void* stream);
 
-/* The E-step -> accumulate hand-over of a single mixture (S = 1, float32, split
- * arithmetic) without the float32 responsibilities in
- * between.  `packed_resps` (beer_packed_resps_bytes(T, D, K) bytes: a 512-byte
- * header -- the per-dimension frame scales the E-step computed, reused by the
- * accumulation -- then 4 bytes per element with T rounded up to 64 and K to
- * 128, then, for 129..256 components, the transposed range-scaled frames the
+/* The E-step -> accumulate hand-over of a single mixture (S = 1, float32, bf16x3
+ * arithmetic) without the float32 responsibilities in between.  `packed_resps`
+ * (beer_packed_resps_bytes(T, D, K) bytes: 6 bytes per element with T rounded up
+ * to 64 and K to 128, then, for 129..256 components, the transposed frames the
  * E-step kernel leaves behind for the accumulation) receives each responsibility
- * already split into the fp16 pair the accumulation kernel multiplies with,
- * laid out as that kernel's LDS tiles: per (64 frames, 128 components) 32 KB =
- * the high halves of r * 2^12 as rows [component][64 frames] whose 16-byte
- * chunks sit at position chunk ^ (component & 7), then the low halves in the
- * same arrangement; frames >= T and components >= K are 0.  The accumulation
- * kernel copies the tiles to LDS as they are.  The values are the ones
- * beer_mixtureset_estep / beer_normal_accumulate compute in the split mode
- * (same roundings), so the statistics equal the two-call path up to the order
- * of the fp64 sums.  Same reference functions as the two calls above
- * (mixture.py:86-101 for the responsibilities, normalset.py:121-123 for the
- * statistics).  beer_unpack_resps restores the [T,K] float32 matrix
- * (hi + lo) / 2^12.  The accumulation workspace also holds the frames
- * transposed into 64-frame tiles, hence its own size query with T.
+ * already split into the three bf16 pieces the accumulation kernel multiplies
+ * with (r = p0 + p1 + p2 exactly), laid out as that kernel's LDS tiles: per
+ * (64 frames, 128 components) 48 KB = three planes of 16 KB, plane q = the pieces
+ * p_q as rows [component][64 frames] whose 16-byte chunks sit at position
+ * chunk ^ (component & 7); frames >= T and components >= K are 0.  The
+ * accumulation kernel copies the tiles to LDS as they are (LDS-DMA).  Same
+ * reference functions as the two calls above (mixture.py:86-101 for the
+ * responsibilities, normalset.py:121-123 for the statistics).  beer_unpack_resps
+ * restores the [T,K] float32 matrix exactly.  The accumulation workspace also
+ * holds the frames transposed into 64-frame tiles, hence its own size query with T.
  * EINVAL: shape without a matrix-core path, workspace NULL / too small (sizes
  * from beer_estep_workspace_bytes(BEER_F32, ...) and
  * beer_accumulate_packed_workspace_bytes). */
@@ -285,35 +273,19 @@ size_t beer_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int K);
 int beer_mixture_estep_packed(int cov, int64_t T, int D, int K, const float* X,
                               const float* exp_stats, const float* log_weights,
                               float* log_norm, void* packed_resps, double* llh_sum,
-                              const float* frame_scales, const float* moments,
                               void* workspace, size_t workspace_bytes, void* stream);
-/* `moments` (nullable; full covariance): [K, D + D*D] = the mean and the matrix
- * E[Lambda]^-1 of every component, as beer_nw_update leaves them.  The split
- * arithmetic's parameter image carries 22 bits per entry; the kernel that builds
- * it folds the resulting bias of every component's logits -- evaluated at these
- * moments -- into a 44-bit constant term.  NULL: it derives
- * the moments from `exp_stats` itself (one D x D inverse per component). */
-/* The per-dimension frame scales of the split arithmetic -- 128 floats: 64 powers
- * of two s_d with |x_d s_d| < 2^7 over all T frames, then their 64 inverses -- as
- * the E-step computes them with one pass over X at the start of every call.  The
- * frames of a VB training run do not change between iterations: a caller computes
- * the scales once per shard and passes them as `frame_scales` (NULL: the call
- * makes them itself, in its workspace).  `scratch` >= 256 bytes.  No reference
- * counterpart (the reference multiplies in float32). */
-int beer_frame_scales(int64_t T, int D, const float* X, float* scales, void* scratch,
-                      void* stream);
 int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float* X,
                                   const void* packed_resps, double* acc,
                                   void* workspace, size_t workspace_bytes,
                                   void* stream);
 /* The same hand-over for a mixture SET around the forward-backward pass (float32,
- * split arithmetic, full covariance; S states of G components, G a power of two
- * in 8..128, D <= 43): beer_mixtureset_estep_packed leaves `log_norm` [T, S] and
+ * bf16x3 arithmetic, full covariance; S states of G components, G a power of two
+ * in 8..128): beer_mixtureset_estep_packed leaves `log_norm` [T, S] and
  * the responsibilities WITHIN each state's mixture as packed tiles (layout above,
  * K = S * G; no frame tiles behind them); after the forward-backward pass
  * beer_mixtureset_accumulate_packed multiplies the state posteriors
- * `state_resps` [T, S] in while a tile sits in LDS -- (hi + lo) * gamma in fp32,
- * split again, each element once per workgroup -- and accumulates
+ * `state_resps` [T, S] in while a tile sits in LDS -- (p0 + p1 + p2) * gamma in
+ * fp32, split again, each element once per workgroup -- and accumulates
  *     acc[k,:] += sum_t r[t,k] state_resps[t, k / G] phi(x_t)           (fp64, +=)
  * MixtureSet.expected_log_likelihood / accumulate (beer/models/mixtureset.py:85-112)
  * around HMM.expected_log_likelihood (beer/models/hmm.py:73-92): neither the
@@ -329,8 +301,7 @@ size_t beer_mixtureset_accumulate_packed_workspace_bytes(int cov, int64_t T, int
 int beer_mixtureset_estep_packed(int cov, int64_t T, int D, int S, int G, const float* X,
                                  const float* exp_stats, const float* log_weights,
                                  float* log_norm, void* packed_resps, double* llh_sum,
-                                 const float* moments, void* workspace,
-                                 size_t workspace_bytes, void* stream);
+                                 void* workspace, size_t workspace_bytes, void* stream);
 int beer_mixtureset_accumulate_packed(int cov, int64_t T, int D, int S, int G,
                                       const float* X, const void* packed_resps,
                                       const float* state_resps, double* acc,
@@ -338,10 +309,9 @@ int beer_mixtureset_accumulate_packed(int cov, int64_t T, int D, int S, int G,
                                       void* stream);
 /* The packed buffer from float32 responsibilities: comp_resps [T, S*G], times
  * state_resps[t, k / G] when given (the joint responsibilities of
- * MixtureSet.accumulate, mixtureset.py:100-112), split and tiled as above, with
- * the frame scales of X in the header; (S*G) % 4 == 0.  Lets accumulations that
- * re-read the responsibilities several times (full covariance) run on the packed
- * kernel. */
+ * MixtureSet.accumulate, mixtureset.py:100-112), split and tiled as above;
+ * (S*G) % 4 == 0.  This is how float32 responsibilities that exist in memory
+ * (labels, generic E-step) reach the bf16x3 accumulation kernel. */
 int beer_pack_resps(int64_t T, int D, int S, int G, const float* X,
                     const float* comp_resps, const float* state_resps,
                     void* packed_resps, void* stream);
@@ -349,7 +319,7 @@ int beer_unpack_resps(int64_t T, int K, const void* packed_resps, float* resps,
                       void* stream);
 
 /* The accumulation of a mixture set WITHOUT its responsibilities in memory
- * (float32, split arithmetic; diagonal / isotropic covariances, D <= 64: few
+ * (float32, bf16x3 arithmetic; diagonal / isotropic covariances, D <= 64: few
  * statistics per Gaussian).  beer_mixtureset_estep is then called with
  * comp_resps = NULL and leaves only the per-state log-normalisers `log_norm`
  * [T, S]; after the forward-backward pass this call recomputes the component

@@ -63,12 +63,15 @@ def assert_close(a, b, tol, what=''):
     assert err <= tol, f'{what}: rel err {err:.3e} > {tol:.1e}'
 
 
-def assert_within_f32_band(got, truth, ref32, what='', tol=1e-5):
+def assert_within_f32_band(got, truth, ref32, what='', tol=1e-5, slack=1.):
     '''float32 results against the fp64 truth of the same float32 inputs: within
     north_star's 1e-5, or -- where float32 arithmetic itself cannot do that --
     within the error of the reference's own float32 op sequence (`ref32`: the
-    oracle run in float32, or the reference's float32 golden).'''
-    band = max(tol, rel_err(ref32, truth))
+    oracle run in float32, or the reference's float32 golden).  `slack` > 1 only
+    where `ref32`'s error is ONE realisation of rounding noise amplified by an
+    ill-conditioned step (a posterior scale matrix from less than a frame per
+    component), i.e. an estimate of float32's error there, not a bound on it.'''
+    band = max(tol, slack * rel_err(ref32, truth))
     err = rel_err(got, truth)
     assert err <= band, f'{what}: rel err {err:.3e} > band {band:.3e} (reference fp32: ' \
                         f'{rel_err(ref32, truth):.3e})'

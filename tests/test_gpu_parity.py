@@ -31,19 +31,61 @@ def test_native_library_is_loaded():
 
 # --- G10: distribution kernels ------------------------------------------------
 
+_G10_FAMILY = {'nw': 'full', 'ng': 'diagonal', 'ing': 'isotropic'}
+
+
+def _g10_oracle(name, q, p):
+    'natural, E[T], log_norm, KL(q || p), round trip of the oracle at parameters q, p (numpy).'
+    if name in _G10_FAMILY:
+        f = orc.FAMILIES[_G10_FAMILY[name]]
+        nat, exp, lnorm, from_nat = f['nat'], f['exp'], f['lnorm'], f['from_nat']
+    else:
+        nat, exp, lnorm = orc.dir_natural, orc.dir_expected_stats, orc.dir_log_norm
+        from_nat = lambda eta: (orc.dir_from_natural(eta),)                     # noqa: E731
+    kl = orc.kl_div(exp(*q), nat(*q), nat(*p), lnorm(*q), lnorm(*p))
+    return dict(natural=nat(*q), exp_stats=exp(*q), log_norm=lnorm(*q), kl=kl,
+                roundtrip=from_nat(nat(*q)))
+
+
 @pytest.mark.parametrize('name', ['nw', 'ng', 'ing', 'dir', 'dirset'])
-@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-10), (torch.float32, 2e-5)])
-def test_g10_dists(name, dtype, tol):
+def test_g10_dists_fp64(name):
+    'Distribution kernels in fp64 against the reference goldens (G10).'
     g = load_golden('g10_dists')
-    q, p = build_dist(g, f'{name}.q', dtype), build_dist(g, f'{name}.p', dtype)
-    assert_close(npy(q.natural_parameters()), g[f'{name}.natural'], tol, 'natural')
-    assert_close(npy(q.expected_sufficient_statistics()), g[f'{name}.exp_stats'], tol, 'E[T]')
-    assert_close(npy(q.log_norm()), g[f'{name}.log_norm'], tol, 'log_norm')
-    assert_close(npy(beer.dists.kl_div(q, p)), g[f'{name}.kl'], max(tol * 50, 1e-9), 'kl')
+    q, p = build_dist(g, f'{name}.q'), build_dist(g, f'{name}.p')
+    assert_close(npy(q.natural_parameters()), g[f'{name}.natural'], 1e-10, 'natural')
+    assert_close(npy(q.expected_sufficient_statistics()), g[f'{name}.exp_stats'], 1e-10, 'E[T]')
+    assert_close(npy(q.log_norm()), g[f'{name}.log_norm'], 1e-10, 'log_norm')
+    assert_close(npy(beer.dists.kl_div(q, p)), g[f'{name}.kl'], 5e-9, 'kl')
     rt = q.params.from_natural_parameters(q.natural_parameters())
     for pn in q._std_params_def:
         ref = g[f'{name}.roundtrip.{pn}']
-        assert_close(npy(getattr(rt, pn)).reshape(ref.shape), ref, tol * 20, 'roundtrip ' + pn)
+        assert_close(npy(getattr(rt, pn)).reshape(ref.shape), ref, 2e-9, 'roundtrip ' + pn)
+
+
+@pytest.mark.parametrize('name', ['nw', 'ng', 'ing', 'dir', 'dirset'])
+def test_g10_dists_fp32(name):
+    '''The same kernels on float32 parameters, against the fp64 oracle AT those float32
+    parameters (the golden's fp64 parameters rounded to float32 are different inputs):
+    1e-5, or the error of the reference's own float32 op sequence where float32
+    cannot do that (the KL divergence is a difference of terms 1000x its size).'''
+    g = load_golden('g10_dists')
+    q, p = build_dist(g, f'{name}.q', torch.float32), build_dist(g, f'{name}.p', torch.float32)
+    q32 = [npy(getattr(q.params, n)) for n in q._std_params_def]
+    p32 = [npy(getattr(p.params, n)) for n in p._std_params_def]
+    truth = _g10_oracle(name, [a.astype(np.float64) for a in q32],
+                        [a.astype(np.float64) for a in p32])
+    ref32 = _g10_oracle(name, q32, p32)
+    shaped = lambda t, ref: npy(t).astype(np.float64).reshape(np.shape(ref))    # noqa: E731
+    for key, got in (('natural', q.natural_parameters()),
+                     ('exp_stats', q.expected_sufficient_statistics()),
+                     ('log_norm', q.log_norm()), ('kl', beer.dists.kl_div(q, p))):
+        assert_within_f32_band(shaped(got, truth[key]), np.asarray(truth[key]),
+                               np.asarray(ref32[key], dtype=np.float64), key)
+    rt = q.params.from_natural_parameters(q.natural_parameters())
+    for pn, ref, r32 in zip(q._std_params_def, truth['roundtrip'], ref32['roundtrip']):
+        assert_within_f32_band(shaped(getattr(rt, pn), ref), ref,
+                               np.asarray(r32, dtype=np.float64).reshape(ref.shape),
+                               'roundtrip ' + pn)
 
 
 def test_g10_gamma_and_dense_stats():
@@ -74,7 +116,7 @@ def test_gmm_fp64_iterations(name, tol):
     assert_close(npy(ns.expected_log_likelihood(stats)), g['pc_llh'], tol, 'pc_llh')
     assert_close(npy(model._log_weights()), g['log_weights'].reshape(-1), tol, 'log weights')
     assert_close(npy(model.expected_log_likelihood(stats)), g['per_frame'], tol, 'per frame')
-    assert_close(npy(model.cache['resps']), g['resps'], tol * 10, 'resps')
+    assert_close(npy(model.cache['resps']), g['resps'], 1e-8, 'resps')
     model.clear_cache()
     assert_close(npy(model.kl_div_posterior_prior()), g['kl'], 1e-8, 'kl')
     optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.)
@@ -404,8 +446,9 @@ def _c2_model(K, D, dtype, seed=7):
     return means, rng
 
 
-@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-5)])
-def test_c2_shape_one_step_vs_oracle(dtype, tol):
+@pytest.mark.parametrize('dtype,tol,tol_post', [(torch.float64, 1e-9, 1e-8),
+                                                (torch.float32, 1e-5, 1e-5)])
+def test_c2_shape_one_step_vs_oracle(dtype, tol, tol_post):
     'K=256 full-covariance, D=40, 8192 frames: E-step + M-step vs the oracle.'
     K, D, T = 256, 40, 8192
     rng = np.random.RandomState(1)
@@ -439,7 +482,7 @@ def test_c2_shape_one_step_vs_oracle(dtype, tol):
                                     truth['acc_weights'])
     for n, ref in zip(p0.posterior._std_params_def, new_post):
         got = npy(getattr(p0.posterior.params, n)).astype(np.float64)
-        assert_close(got.reshape(ref.shape), ref, tol * 10, 'posterior ' + n)
+        assert_close(got.reshape(ref.shape), ref, tol_post, 'posterior ' + n)
 
 
 def _oracle_gmm_chunked(Xn, cov, post, prior, w_post, w_prior, chunk=8192):
@@ -452,25 +495,13 @@ def _oracle_gmm_chunked(Xn, cov, post, prior, w_post, w_prior, chunk=8192):
     return dict(value=per_frame - kl, acc_normal=acc_n, acc_weights=acc_w, kl=kl)
 
 
-# Statistics / posterior band of the split arithmetic at these shapes.  An entry of the
-# packed parameter image carries 22 bits (two fp16 halves) and its rounding is the same
-# for every frame of a component: a bias in the component's logits that does not average
-# out over frames.  The packing kernel compensates it to first order (the bias at the
-# component's own moments goes into the constant, which carries 22 more bits for the
-# purpose: DESIGN.md section 8) -- 1.0e-5 .. 1.5e-5 on the worst statistics before,
-# within north_star's 1e-5 at the bench shape now; with diagonal covariances the worst
-# entry of the updated means sits at 1.07e-5.  The exact-fp32 mode (below) is held to
-# 1e-5 or the reference's own float32 error.
-SPLIT_STATS_BAND = {'full': 1e-5, 'diagonal': 1.5e-5}
-
-
 @pytest.mark.parametrize('cov,K', [('full', 256), ('diagonal', 256), ('full', 160)])
 def test_bench_kernel_variant_vs_oracle(cov, K):
     '''The kernels `bench.py` times -- float32, K = 256 full covariance, D = 40, the
-    fp16-split E-step with the components split over two waves writing packed
-    responsibilities (`beer_mixture_estep_packed`) + `beer_normal_accumulate_packed`
-    -- against the numpy oracle on the same 65,536 frames: ELBO, accumulated
-    statistics and the posterior after one step, at north_star's 1e-5.
+    bf16x3 E-step writing packed responsibilities (`beer_mixture_estep_packed`) +
+    `beer_normal_accumulate_packed` -- against the numpy oracle on the same 65,536
+    frames: ELBO, accumulated statistics and the posterior after one step, all at
+    north_star's 1e-5 (or the reference's own float32 error where that is larger).
     Reference: beer/models/mixture.py:70-102.'''
     from beer_amd import kernels
     D, T = 40, 65536
@@ -512,13 +543,12 @@ def test_bench_kernel_variant_vs_oracle(cov, K):
     finally:
         kernels.mixture_estep_packed, kernels._hip.call = orig_e, orig_call
     assert calls['estep'] == 1 and calls['acc'] == 1, calls      # the packed kernels ran
-    assert beer.get_f32_mode() == 'split_f16'
+    assert beer.get_f32_mode() == 'bf16x3'
     assert_close(float(elbo), truth['value'], 1e-5, 'elbo')
     acc = npy(elbo._acc_stats[p0]).astype(np.float64)
-    assert_within_f32_band(acc, truth['acc_normal'], ref32['acc_normal'], 'acc normal',
-                           SPLIT_STATS_BAND[cov])
+    assert_within_f32_band(acc, truth['acc_normal'], ref32['acc_normal'], 'acc normal')
     assert_within_f32_band(npy(elbo._acc_stats[p1]).astype(np.float64), truth['acc_weights'],
-                           ref32['acc_weights'], 'acc weights', SPLIT_STATS_BAND[cov])
+                           ref32['acc_weights'], 'acc weights')
     elbo.backward()
     optim.step()
     new_post, new_w = orc.gmm_mstep(cov, post, prior, w_post, w_prior, truth['acc_normal'],
@@ -529,11 +559,10 @@ def test_bench_kernel_variant_vs_oracle(cov, K):
                                     ref32['acc_weights'].astype(np.float32))
     for n, ref, r32 in zip(p0.posterior._std_params_def, new_post, ref_post):
         got = npy(getattr(p0.posterior.params, n)).astype(np.float64)
-        assert_within_f32_band(got.reshape(ref.shape), ref, r32.reshape(ref.shape), 'posterior ' + n,
-                               SPLIT_STATS_BAND[cov])
+        assert_within_f32_band(got.reshape(ref.shape), ref, r32.reshape(ref.shape), 'posterior ' + n)
     assert_within_f32_band(
         npy(p1.posterior.params.concentrations).astype(np.float64).reshape(new_w.shape), new_w,
-        ref_w.reshape(new_w.shape), 'posterior weights', SPLIT_STATS_BAND[cov])
+        ref_w.reshape(new_w.shape), 'posterior weights')
     # the same step on the exact fp32 MFMA: within 1e-5, or the reference's own fp32 error
     from beer_amd import _hip
     torch.manual_seed(7)
@@ -645,11 +674,11 @@ def _oracle_groups(ploop):
                  w_post=as64(w.posterior)[0], w_prior=as64(w.prior)[0])]
 
 
-@pytest.mark.parametrize('cov,dtype,tol', [('full', torch.float64, 1e-8),
-                                           ('full', torch.float32, 1e-5),
-                                           ('diagonal', torch.float64, 1e-8),
-                                           ('diagonal', torch.float32, 1e-5)])
-def test_c3_shape_batched_phone_loop_vs_oracle(cov, dtype, tol):
+@pytest.mark.parametrize('cov,dtype,tol,tol_stats', [('full', torch.float64, 1e-8, 1e-7),
+                                                     ('full', torch.float32, 1e-5, 1e-5),
+                                                     ('diagonal', torch.float64, 1e-8, 1e-7),
+                                                     ('diagonal', torch.float32, 1e-5, 1e-5)])
+def test_c3_shape_batched_phone_loop_vs_oracle(cov, dtype, tol, tol_stats):
     P, G, D = 8, 8, 12                       # S = 24 states, K = 192 Gaussians
     ploop = _phone_loop(P, G, D, cov, dtype, seed=21)
     rng = np.random.RandomState(8)
@@ -678,28 +707,30 @@ def test_c3_shape_batched_phone_loop_vs_oracle(cov, dtype, tol):
     elbo = beer.accumulate_elbo(ploop, [tt(x) for x in utts], datasize=N)
     assert_close(float(elbo), value, tol, 'elbo')
     ms = ploop.modelset.original_modelset.modelsets[0]
-    assert_close(npy(elbo._acc_stats[ms.modelset.means_precisions]), acc_n, tol * 10, 'acc normal')
-    assert_close(npy(elbo._acc_stats[ms.categoricalset.weights]), acc_w, tol * 10, 'acc weights')
-    assert_close(npy(elbo._acc_stats[cat]), counts, tol * 10, 'phone counts')
+    assert_close(npy(elbo._acc_stats[ms.modelset.means_precisions]), acc_n, tol_stats, 'acc normal')
+    assert_close(npy(elbo._acc_stats[ms.categoricalset.weights]), acc_w, tol_stats, 'acc weights')
+    assert_close(npy(elbo._acc_stats[cat]), counts, tol_stats, 'phone counts')
 
 
-def _oracle_phone_loop_shard(ploop, utts, N, with_counts=True):
+def _oracle_phone_loop_shard(ploop, utts, N, with_counts=True, dtype=np.float64):
     '''Sum of orc.hmm_elbo_step over utterances (free phone loop): value and
     statistics (phone counts need the [T-1, S, S] transition posteriors: most of
-    the oracle's time at S = 120).'''
-    groups = _oracle_groups(ploop)
+    the oracle's time at S = 120).  `dtype` = np.float32 runs the oracle -- the
+    reference's op sequence -- in float32: the reference's own float32 error.'''
+    cast = lambda a: np.asarray(a).astype(dtype)                              # noqa: E731
+    groups = [dict(g, post=[cast(a) for a in g['post']], prior=[cast(a) for a in g['prior']],
+                   w_post=cast(g['w_post']), w_prior=cast(g['w_prior']))
+              for g in _oracle_groups(ploop)]
     gr = ploop.graph
-    graph = dict(init=npy(gr.init_log_probs).astype(np.float64),
-                 final=npy(gr.final_log_probs).astype(np.float64),
-                 trans=npy(gr.trans_log_probs).astype(np.float64),
-                 order=np.asarray(gr.pdf_id_mapping))
+    graph = dict(init=cast(npy(gr.init_log_probs)), final=cast(npy(gr.final_log_probs)),
+                 trans=cast(npy(gr.trans_log_probs)), order=np.asarray(gr.pdf_id_mapping))
     cat = ploop.categorical.weights
-    extra_kl = orc.dir_kl(npy(cat.posterior.params.concentrations).astype(np.float64),
-                          npy(cat.prior.params.concentrations).astype(np.float64)).sum()
+    extra_kl = orc.dir_kl(cast(npy(cat.posterior.params.concentrations)),
+                          cast(npy(cat.prior.params.concentrations))).sum()
     value, acc_n, acc_w, counts = 0., 0., 0., 0.
     starts, ends = list(ploop.start_pdf.values()), list(ploop.end_pdf.values())
     for x in utts:
-        r = orc.hmm_elbo_step(x.astype(np.float64), groups, graph, datasize=N,
+        r = orc.hmm_elbo_step(x.astype(dtype), groups, graph, datasize=N,
                               trans_posteriors=with_counts, extra_kl=extra_kl)
         value += r['value']
         acc_n, acc_w = acc_n + r['acc'][0][0], acc_w + r['acc'][0][1]
@@ -709,20 +740,23 @@ def _oracle_phone_loop_shard(ploop, utts, N, with_counts=True):
     return value, acc_n, acc_w, counts
 
 
-@pytest.mark.parametrize('cov,dtype,nutt,tol', [('diagonal', torch.float64, 3, 1e-8),
-                                                ('full', torch.float64, 3, 1e-8),
-                                                ('diagonal', torch.float32, 4, 1e-5),
-                                                ('full', torch.float32, 4, 1e-5),
-                                                ('diagonal', torch.float32, 56, 1e-5),
-                                                ('full', torch.float32, 56, 1e-5)])
-def test_c3_real_dimensions_phone_loop_vs_oracle(cov, dtype, nutt, tol):
+@pytest.mark.parametrize('cov,dtype,nutt,tol,tol_stats',
+                         [('diagonal', torch.float64, 3, 1e-8, 1e-7),
+                          ('full', torch.float64, 3, 1e-8, 1e-7),
+                          ('diagonal', torch.float32, 4, 1e-5, 1e-5),
+                          ('full', torch.float32, 4, 1e-5, 1e-5),
+                          ('diagonal', torch.float32, 56, 1e-5, 1e-5),
+                          ('full', torch.float32, 56, 1e-5, 1e-5)])
+def test_c3_real_dimensions_phone_loop_vs_oracle(cov, dtype, nutt, tol, tol_stats):
     '''BASELINE config 3 at its real dimensions -- 40 phones x 3 states (S = 120,
     a 40-phone hub), G = 16 Gaussians per state (K = 1920: 8 component chunks),
     D = 40 -- utterances of ~300 frames through the batched E-step vs the oracle's
-    per-utterance loop (beer/models/hmm.py:73-100, mixtureset.py:85-112).  The
-    56-utterance float32 cases (> 16384 frames) take the fp16-split matrix kernels
-    (phone counts not re-checked there: they do not depend on the emission
-    kernels' arithmetic), the 4-utterance ones the exact float32 kernels.'''
+    per-utterance loop (beer/models/hmm.py:73-100, mixtureset.py:85-112): ELBO, the
+    accumulated statistics of the Gaussians, the mixture weights and the phone
+    counts, and the emission posteriors after the M-step (objectives.py:92-107,
+    parameters.py:134-141), float32 at a flat 1e-5.  The 56-utterance float32 cases
+    (> 16384 frames) take the bf16x3 matrix kernels, the 4-utterance ones the exact
+    float32 kernels.'''
     P, G, D = 40, 16, 40
     ploop = _phone_loop(P, G, D, cov, dtype, seed=33)
     rng = np.random.RandomState(12)
@@ -738,25 +772,61 @@ def test_c3_real_dimensions_phone_loop_vs_oracle(cov, dtype, nutt, tol):
         comp = 16 * (3 * seq + rng.randint(0, 3, T)) + rng.randint(0, G, T)
         utts.append((mu[comp] + rng.randn(T, D) * 1.5).astype(npdt))
     N = 10_000_000
-    value, acc_n, acc_w, counts = _oracle_phone_loop_shard(ploop, utts, N, with_counts=nutt < 10)
-    if dtype == torch.float32:
+    groups = _oracle_groups(ploop)
+    value, acc_n, acc_w, counts = _oracle_phone_loop_shard(ploop, utts, N)
+    f32 = dtype == torch.float32
+    if f32:
         from beer_amd import _hip
         X = torch.cat([tt(x) for x in utts])
-        assert _hip.f32_split_ok(X) == (sum(lens) >= _hip.SPLIT_MIN_FRAMES)
+        assert _hip.f32_fast_ok(X) == (sum(lens) >= _hip.FAST_MIN_FRAMES)
+        # the reference's own float32 run: where float32 cannot reach 1e-5, its error
+        # is the band (assert_within_f32_band)
+        _, acc_n32, acc_w32, _ = _oracle_phone_loop_shard(ploop, utts, N, with_counts=False,
+                                                          dtype=np.float32)
+
+    def check(got, truth, ref32, what):
+        got = np.asarray(got, dtype=np.float64).reshape(np.shape(truth))
+        if f32 and ref32 is not None:
+            # (posteriors of components that saw less than a frame: the inverse amplifies
+            # float32 rounding a thousandfold -- for the reference as for anybody)
+            assert_within_f32_band(got, np.asarray(truth), np.asarray(ref32, dtype=np.float64), what,
+                                   slack=2.)
+        else:
+            assert_close(got, truth, tol_stats, what)
+    optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.)
+    optim.init_step()
     elbo = beer.accumulate_elbo(ploop, [tt(x) for x in utts], datasize=N)
     assert_close(float(elbo), value, tol, 'elbo')
     ms = ploop.modelset.original_modelset.modelsets[0]
     cat = ploop.categorical.weights
-    assert_close(npy(elbo._acc_stats[ms.modelset.means_precisions]), acc_n, tol * 10, 'acc normal')
-    assert_close(npy(elbo._acc_stats[ms.categoricalset.weights]), acc_w, tol * 10, 'acc weights')
-    if nutt < 10:
-        assert_close(npy(elbo._acc_stats[cat]), counts, tol * 10, 'phone counts')
+    assert_close(npy(elbo._acc_stats[ms.modelset.means_precisions]), acc_n, tol_stats, 'acc normal')
+    assert_close(npy(elbo._acc_stats[ms.categoricalset.weights]), acc_w, tol_stats, 'acc weights')
+    assert_close(npy(elbo._acc_stats[cat]), counts, tol_stats, 'phone counts')
+    # the M-step on these statistics (scale N / frames, objectives.py:98)
+    elbo.backward()
+    optim.step()
+    scale = N / float(sum(lens))
+    new = orc.emissions_mstep(groups, [(acc_n, acc_w)], scale)[0]
+    new32 = None
+    if f32:
+        g32 = [dict(g, post=[a.astype(np.float32) for a in g['post']],
+                    prior=[a.astype(np.float32) for a in g['prior']],
+                    w_post=g['w_post'].astype(np.float32), w_prior=g['w_prior'].astype(np.float32))
+               for g in groups]
+        new32 = orc.emissions_mstep(g32, [(acc_n32, acc_w32)], np.float32(scale))[0]
+    p = ms.modelset.means_precisions
+    for i, (n, ref) in enumerate(zip(p.posterior._std_params_def, new['post'])):
+        check(npy(getattr(p.posterior.params, n)), ref, new32['post'][i] if new32 else None,
+              'posterior ' + n)
+    check(npy(ms.categoricalset.weights.posterior.params.concentrations), new['w_post'],
+          new32['w_post'] if new32 else None, 'posterior weights')
 
 
 @pytest.mark.parametrize('cov', ['diagonal', 'isotropic', 'full'])
-@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-9), (torch.float32, 1e-5)])
+@pytest.mark.parametrize('dtype,tol,tol_stats', [(torch.float64, 1e-9, 1e-8),
+                                                 (torch.float32, 1e-5, 1e-5)])
 @pytest.mark.parametrize('K,D', [(32, 13), (48, 40)])
-def test_gmm_matrix_core_path_all_cov_types_vs_oracle(cov, dtype, tol, K, D):
+def test_gmm_matrix_core_path_all_cov_types_vs_oracle(cov, dtype, tol, tol_stats, K, D):
     'K >= 16 takes the MFMA kernels for every covariance type; odd D exercises padding.'
     T = 3000
     rng = np.random.RandomState(K + D)
@@ -775,8 +845,8 @@ def test_gmm_matrix_core_path_all_cov_types_vs_oracle(cov, dtype, tol, K, D):
     truth = orc.gmm_elbo_step(Xn.astype(np.float64), cov, post, prior, w_post, w_prior)
     elbo = beer.evidence_lower_bound(model, X.to(DEV))
     assert_close(float(elbo), truth['value'], tol, 'elbo')
-    assert_close(npy(elbo._acc_stats[p0]), truth['acc_normal'], tol * 5, 'acc normal')
-    assert_close(npy(elbo._acc_stats[p1]), truth['acc_weights'], tol * 5, 'acc weights')
+    assert_close(npy(elbo._acc_stats[p0]), truth['acc_normal'], tol_stats, 'acc normal')
+    assert_close(npy(elbo._acc_stats[p1]), truth['acc_weights'], tol_stats, 'acc weights')
 
 
 @pytest.mark.parametrize('cov,K,D,split', [('full', 512, 40, (4, 128)), ('diagonal', 512, 40, (2, 256)),
@@ -806,10 +876,6 @@ def test_gmm_with_more_than_256_components_on_the_matrix_cores(cov, K, D, split)
     f32 = lambda arrs: [a.astype(np.float32) for a in arrs]
     ref32 = orc.gmm_elbo_step(Xn, cov, f32(post), f32(prior), w_post.astype(np.float32),
                               w_prior.astype(np.float32))
-    # ~30 frames per component here: a statistic is the sum of a few responsibilities,
-    # each carrying the split arithmetic's logit error -- 3e-5 on
-    # the worst entry, where the bench shape (256 frames per component) averages to 1e-5
-    band = 4e-5
     assert kernels.wide_mixture_split(beer.FrameStats(X.to(DEV), cov), K, cov) == split
     taken = []
     orig = kernels.wide_mixture_estep
@@ -823,9 +889,9 @@ def test_gmm_with_more_than_256_components_on_the_matrix_cores(cov, K, D, split)
     for e in (elbo, batched):
         assert_close(float(e), truth['value'], 1e-5, 'elbo')
         assert_within_f32_band(npy(e._acc_stats[p0]).astype(np.float64), truth['acc_normal'],
-                               ref32['acc_normal'], 'acc normal', band)
+                               ref32['acc_normal'], 'acc normal')
         assert_within_f32_band(npy(e._acc_stats[p1]).astype(np.float64), truth['acc_weights'],
-                               ref32['acc_weights'], 'acc weights', band)
+                               ref32['acc_weights'], 'acc weights')
     # the factored responsibilities as a matrix
     st = beer.FrameStats(X.to(DEV), cov)
     _, wr = kernels.wide_mixture_estep(st, p0.natural_form(), model._log_weights().view(1, K), K,
@@ -835,11 +901,10 @@ def test_gmm_with_more_than_256_components_on_the_matrix_cores(cov, K, D, split)
     assert np.abs(r - truth['resps']).max() < 2e-4
 
 
-def test_m_step_in_one_launch_and_the_moments_it_hands_to_the_e_step():
-    '''beer_nw_update (natural -> standard parameters, E[T], log-normaliser, moments in
-    one launch) against the separate calls, and the packed E-step with the moments it
-    leaves on E[T] against the same call deriving them itself.'''
-    from beer_amd import kernels
+def test_m_step_in_one_launch():
+    '''beer_nw_update (natural -> standard parameters, E[T] and log-normaliser in one
+    launch, normalwishart.py:110-141, 170-210, 219-236) against the separate calls on
+    the parameters the update stored.'''
     from beer_amd.dists import NormalWishart
     torch.manual_seed(11)
     K, D, T = 128, 24, 20000
@@ -855,35 +920,11 @@ def test_m_step_in_one_launch_and_the_moments_it_hands_to_the_e_step():
     optim.step()
     post = ns.means_precisions.posterior
     E = post.expected_sufficient_statistics()
-    mom = E._beer_moments
-    # the separate calls on the parameters the update stored
     ref = NormalWishart.from_std_parameters(*[t.clone() for t in post._tensors()])
     torch.testing.assert_close(E, ref.expected_sufficient_statistics(), rtol=2e-6, atol=1e-5)
     torch.testing.assert_close(post.log_norm(), ref.log_norm(), rtol=1e-6, atol=1e-4)
     torch.testing.assert_close(post.natural_parameters(), ref.natural_parameters(), rtol=1e-4,
                                atol=1e-4)
-    p = post.params
-    torch.testing.assert_close(mom[:, :D], p.mean)
-    sigma = mom[:, D:].view(K, D, D).double()
-    eye = sigma @ (p.dof.view(K, 1, 1).double() * p.scale_matrix.double())
-    assert float((eye - torch.eye(D, device=DEV, dtype=torch.float64)).abs().max()) < 1e-4
-    # E-step with the handed-over moments == E-step that inverts for itself
-    st = beer.FrameStats(X, 'full')
-    lw = model._log_weights().view(1, K)
-    assert kernels._moments(E, K, D, X.device) is mom
-    ln_a, r_a = kernels.mixture_estep_packed(st, E, lw, K, 'full')
-    acc_a = kernels.normal_accumulate(st, r_a, None, K, 1, 'full')
-    bare = E.clone()
-    assert kernels._moments(bare, K, D, X.device) is None
-    ln_b, r_b = kernels.mixture_estep_packed(st, bare, lw, K, 'full')
-    acc_b = kernels.normal_accumulate(st, r_b, None, K, 1, 'full')
-    torch.testing.assert_close(ln_a, ln_b, rtol=0, atol=2e-4)
-    assert float((acc_a - acc_b).abs().max() / acc_b.abs().max()) < 3e-6
-    # and both against the fp64 kernels
-    st64 = beer.FrameStats(X.double(), 'full')
-    _, r64 = kernels.mixtureset_estep(st64, E.double(), lw.double(), 1, K, 'full')
-    acc64 = kernels.normal_accumulate(st64, r64, None, K, 1, 'full')
-    assert float((acc_a - acc64).abs().max() / acc64.abs().max()) < 1e-5
 
 
 def _chain_graph(n_states, rng, dtype):
@@ -1011,15 +1052,16 @@ def test_sparse_alignment_graphs_equal_dense_graphs():
     assert abs(float(e1) - float(e2)) <= 1e-13 * abs(float(e1))
 
 
-# --- float32 models: exact fp32 MFMA vs the fp16-split matrix path ------------------------------------
+# --- float32 models: exact fp32 MFMA vs the bf16x3 matrix path ----------------------------------------
 
 @pytest.mark.parametrize('cov,K,D', [('full', 256, 40), ('diagonal', 64, 24), ('full', 48, 13)])
 def test_f32_modes_agree_with_fp64(cov, K, D):
-    '''Both ways of multiplying float32 on the matrix cores (exact fp32 MFMA;
-    two fp16 halves per operand, three fp16 MFMAs per product) against the fp64
-    kernels on the same inputs: per-frame log-normaliser, responsibilities and
-    accumulated statistics.  Badly scaled features (one dimension 1000x the
-    others, an offset of 50) exercise the power-of-two range scaling.'''
+    '''Both ways of multiplying float32 on the matrix cores (exact fp32 MFMA; three
+    bf16 pieces per operand, six bf16 MFMAs per product) against the fp64 kernels on
+    the same inputs: per-frame log-normaliser, responsibilities and accumulated
+    statistics.  Badly scaled features (one dimension 1000x the others, another
+    1/1000, an offset of 50): bf16 pieces have float32's exponent range, nothing is
+    rescaled.'''
     from beer_amd import kernels
     torch.manual_seed(3)
     T = 20000
@@ -1038,7 +1080,7 @@ def test_f32_modes_agree_with_fp64(cov, K, D):
     old = beer.get_f32_mode()
     err = {}
     try:
-        for mode in ('exact', 'split_f16'):
+        for mode in ('exact', 'bf16x3'):
             beer.set_f32_mode(mode)
             assert beer.get_f32_mode() == mode
             ln, r = kernels.mixtureset_estep(st32, E64.float(), lw64.float(), 1, K, cov)
@@ -1049,46 +1091,64 @@ def test_f32_modes_agree_with_fp64(cov, K, D):
                          abs(float(-2 * acc[:, -2].sum()) - T) / T)
     finally:
         beer.set_f32_mode(old)
-    # the split path may lose a small factor against the exact fp32 products
-    # (2^-21 vs 2^-24 per product, same fp32 accumulation), never more
-    for e_exact, e_split in zip(err['exact'], err['split_f16']):
-        assert e_split <= 4. * e_exact + 1e-7, (err['exact'], err['split_f16'])
-    assert err['split_f16'][1] <= 2e-6 and err['split_f16'][3] <= 2e-6, err['split_f16']
+    # same operands, same fp32 accumulation: the two arithmetics differ by rounding
+    # noise only (the MFMA chains are of different lengths), never by a factor
+    for e_exact, e_fast in zip(err['exact'], err['bf16x3']):
+        assert e_fast <= 4. * e_exact + 1e-7, (err['exact'], err['bf16x3'])
+    assert err['bf16x3'][1] <= 2e-6 and err['bf16x3'][3] <= 2e-6, err['bf16x3']
 
 
-def test_f32_split_path_is_skipped_for_outliers_and_small_inputs():
-    '''Frames with an outlier 10^5 times the typical magnitude (or too few
-    frames) take the exact fp32 path even in split mode: identical results.'''
+def test_fast_path_takes_outliers_and_any_range():
+    '''Round 2's fp16 split had to send frames with outliers (or a dimension spanning
+    more than 2^10) to the exact kernels after a range check on the device.  Three bf16
+    pieces hold any float32 value: frames with an outlier 10^5 times the typical
+    magnitude, a dimension of magnitude 1e-6 and one of 1e+6 take the bf16x3 kernels
+    and agree with the fp64 kernels as well as the exact fp32 MFMA does.  Small
+    inputs still take the exact kernels (set-up cost, not accuracy).'''
     from beer_amd import _hip, kernels
     torch.manual_seed(5)
     T, D, K = 20000, 16, 32
-    X = torch.randn(T, D, device=DEV)
-    ns = beer.NormalSet.create(torch.zeros(D), torch.ones(D), size=K, cov_type='full')
-    model = beer.Mixture.create(ns).to(DEV)
-    E, lw = ns.means_precisions.natural_form(), model._log_weights().view(1, K)
-    assert _hip.get_f32_mode() == 'split_f16'
-    assert _hip.f32_split_ok(X)
-    assert not _hip.f32_split_ok(X[:1000])                       # small: exact
-    Xo = X.clone()
-    Xo[123, 3] = 1.0e5
-    assert not _hip.f32_split_ok(Xo)
-    ln_auto, r_auto = kernels.mixtureset_estep(beer.FrameStats(Xo, 'full'), E, lw, 1, K, 'full')
+    X = torch.randn(T, D, dtype=torch.float64, device=DEV)
+    X[123, 3] = 1.0e5
+    X[:, 5] *= 1.0e-6
+    X[:, 6] *= 1.0e6
+    var = torch.ones(D)
+    var[5], var[6] = 1e-12, 1e12
+    ns = beer.NormalSet.create(torch.zeros(D), torch.diag(var), size=K, cov_type='full',
+                               noise_std=0.)
+    # (distinct means: the components must differ)
+    ns.means_precisions.posterior.params.mean.add_(torch.randn(K, D) * var.sqrt())
+    model = beer.Mixture.create(ns).double().to(DEV)
+    E64, lw64 = ns.means_precisions.natural_form(), model._log_weights().view(1, K)
+    st64 = beer.FrameStats(X, 'full')
+    ln64, r64 = kernels.mixtureset_estep(st64, E64, lw64, 1, K, 'full')
+    acc64 = kernels.normal_accumulate(st64, r64, None, 1, K, 'full')
+    X32 = X.float()
+    st32 = beer.FrameStats(X32, 'full')
+    assert _hip.get_f32_mode() == 'bf16x3'
+    assert _hip.f32_fast_ok(X32) and kernels.packed_path_ok(st32, K, 'full')
+    assert not _hip.f32_fast_ok(X32[:1000])                       # small: exact kernels
+    ln_f, packed = kernels.mixture_estep_packed(st32, E64.float(), lw64.float(), K, 'full')
+    acc_f = kernels.normal_accumulate(st32, packed, None, 1, K, 'full')
     with _hip.exact_f32():
-        ln_exact, r_exact = kernels.mixtureset_estep(beer.FrameStats(Xo, 'full'), E, lw, 1, K,
-                                                     'full')
-    assert torch.equal(ln_auto, ln_exact) and torch.equal(r_auto, r_exact)
-    assert _hip.get_f32_mode() == 'split_f16'
-    # in-place modification of the data is noticed (tensor version)
-    Y = X.clone()
-    assert _hip.f32_split_ok(Y)
-    Y[5, 2] = float('inf')
-    assert not _hip.f32_split_ok(Y)
+        ln_e, r_e = kernels.mixtureset_estep(st32, E64.float(), lw64.float(), 1, K, 'full')
+        acc_e = kernels.normal_accumulate(st32, r_e, None, 1, K, 'full')
+    assert bool(torch.isfinite(ln_f).all()) and bool(torch.isfinite(acc_f).all())
+    # per-frame log-normalisers: relative to each frame's own magnitude (the outlier
+    # frame's is ~1e10)
+    rel = lambda ln: float(((ln.double() - ln64).abs() / (1. + ln64.abs())).max())   # noqa: E731
+    assert rel(ln_f) <= 4. * rel(ln_e) + 1e-6, (rel(ln_f), rel(ln_e))
+    # statistics: per column (the columns' magnitudes span 24 orders)
+    col = acc64.abs().amax(0, keepdim=True) + 1e-300
+    e_f = float(((acc_f - acc64).abs() / col).max())
+    e_e = float(((acc_e - acc64).abs() / col).max())
+    assert e_f <= 4. * e_e + 2e-6, (e_f, e_e)
 
 
 @pytest.mark.parametrize('cov,S,G,D', [('diagonal', 30, 16, 40), ('full', 12, 16, 20),
                                          ('diagonal', 40, 4, 13), ('full', 5, 64, 16)])
-def test_f32_split_path_mixture_sets(cov, S, G, D):
-    '''The fp16-split kernels on the shapes of HMM emissions (S mixtures of G
+def test_fast_path_mixture_sets(cov, S, G, D):
+    '''The bf16x3 kernels on the shapes of HMM emissions (S mixtures of G
     components: grouped softmax, component chunks of 256, state responsibilities
     multiplied into the accumulation) against the fp64 kernels.'''
     from beer_amd import _hip, kernels
@@ -1105,9 +1165,9 @@ def test_f32_split_path_mixture_sets(cov, S, G, D):
     ln64, r64 = kernels.mixtureset_estep(st64, E64, lw64, S, G, cov)
     acc64 = kernels.normal_accumulate(st64, r64, sr64, S, G, cov)
     st32 = beer.FrameStats(X.float(), cov)
-    assert _hip.f32_split_ok(st32.data)
+    assert _hip.f32_fast_ok(st32.data)
     err = {}
-    for mode in ('exact', 'split_f16'):
+    for mode in ('exact', 'bf16x3'):
         old = beer.get_f32_mode()
         beer.set_f32_mode(mode)
         try:
@@ -1118,9 +1178,9 @@ def test_f32_split_path_mixture_sets(cov, S, G, D):
         err[mode] = (float((ln.double() - ln64).abs().max()),
                      float((r.double() - r64).abs().max()),
                      float((acc - acc64).abs().max() / acc64.abs().max()))
-    for e_exact, e_split in zip(err['exact'], err['split_f16']):
-        assert e_split <= 4. * e_exact + 1e-7, err
-    assert err['split_f16'][2] <= 2e-6, err
+    for e_exact, e_fast in zip(err['exact'], err['bf16x3']):
+        assert e_fast <= 4. * e_exact + 1e-7, err
+    assert err['bf16x3'][2] <= 2e-6, err
 
 
 @pytest.mark.parametrize('cov,K,D,T', [('full', 256, 40, 40001), ('diagonal', 256, 40, 33000),
@@ -1129,14 +1189,14 @@ def test_f32_split_path_mixture_sets(cov, S, G, D):
                                        ('diagonal', 132, 64, 16500), ('full', 32, 5, 16447),
                                        ('diagonal', 252, 3, 20063)])
 def test_packed_responsibilities_match_the_two_call_path(cov, K, D, T):
-    '''E-step -> accumulate with the responsibilities handed over as fp16
-    hi / lo pairs (beer_mixture_estep_packed, beer_normal_accumulate_packed):
-    same log-normalisers (to the last bits) and, up to the order of the sums, the
-    same statistics as the float32 hand-over of the split path; and within the
-    float32 tolerance of the fp64 kernels.  T not a multiple of 64: the last tile
-    is partly empty; K = 100, 132, 200, 252: component tiles / blocks past K (and,
-    above 128, the two-wave softmax); D = 3 .. 64: 1 .. 5 pieces of transposed
-    frames per tile.'''
+    '''E-step -> accumulate with the responsibilities handed over as three bf16
+    planes (beer_mixture_estep_packed, beer_normal_accumulate_packed): the same
+    log-normalisers and -- the three pieces hold a float32 exactly -- bit for bit the
+    same responsibilities as the float32 hand-over of the same kernel; statistics
+    within float32 rounding of the exact-fp32 accumulation of those responsibilities,
+    and within the float32 tolerance of the fp64 kernels.  T not a multiple of 64:
+    the last tile is partly empty; K = 100, 132, 200, 252: component tiles / blocks
+    past K; D = 3 .. 64: 1 .. 5 pieces of transposed frames per tile.'''
     from beer_amd import _hip, kernels
     torch.manual_seed(5)
     X = torch.randn(T, D, dtype=torch.float64, device=DEV) * 2. - 1.
@@ -1157,12 +1217,11 @@ def test_packed_responsibilities_match_the_two_call_path(cov, K, D, T):
                                                 llh_sum=total)
     assert packed.shape == (T, K)
     acc_p = kernels.normal_accumulate(st32, packed, None, 1, K, cov)
-    # (K > 128: the packed kernel sums the softmax over two waves, another order)
-    torch.testing.assert_close(ln_p, ln, rtol=2e-7, atol=2e-6)
+    assert torch.equal(ln_p, ln)
     torch.testing.assert_close(total, ln_p.double().sum(), rtol=1e-12, atol=0)
-    # hi + lo holds 22 bits of r * 2^12
-    torch.testing.assert_close(packed.unpack(), r, rtol=2e-6, atol=1e-9)
-    torch.testing.assert_close(acc_p, acc, rtol=0, atol=3e-7 * float(acc.abs().max()))
+    assert torch.equal(packed.unpack(), r)                     # p0 + p1 + p2 == r exactly
+    # (`acc`: those float32 responsibilities on the exact fp32 MFMA, or repacked)
+    torch.testing.assert_close(acc_p, acc, rtol=0, atol=2e-6 * float(acc.abs().max()))
     # float32 logits of magnitude ~1e2 carry ~1e-5 of absolute error, the
     # responsibilities the same relative error: the yardstick is the exact fp32 path
     with _hip.exact_f32():
@@ -1215,11 +1274,13 @@ def test_packed_path_is_what_a_mixture_batch_takes():
     assert calls
     with _no_packed():
         elbo_u = B.accumulate_elbo(model, utts)
-    assert abs(float(elbo_p) - float(elbo_u)) <= 1e-9 * abs(float(elbo_u))
+    assert abs(float(elbo_p) - float(elbo_u)) <= 1e-7 * abs(float(elbo_u))
     for (pa, a), (pb, b) in zip(sorted(elbo_p._acc_stats.items(), key=lambda kv: id(kv[0])),
                                 sorted(elbo_u._acc_stats.items(), key=lambda kv: id(kv[0]))):
         assert pa is pb
-        torch.testing.assert_close(a, b, rtol=1e-9, atol=1e-9 * float(b.abs().max()))
+        # (two arithmetics on the same responsibilities: bf16x3 on the packed tiles, the
+        # exact fp32 MFMA on the float32 matrix -- float32 rounding apart)
+        torch.testing.assert_close(a, b, rtol=0, atol=1e-6 * float(b.abs().max()))
 
 
 def test_packed_hand_over_random_shapes():
@@ -1311,7 +1372,10 @@ def test_fused_accumulation_recomputes_the_responsibilities(cov, S, G, D, T):
         two = kernels.normal_accumulate(st32, r32, state, S, G, cov)
         err2 = float((two - ref).abs().max() / ref.abs().max())
         assert bool(torch.isfinite(got).all())
-        assert err <= max(2e-6, 3. * err2), (cov, S, G, D, err, err2)
+        # (the fused path normalises with the log-normalisers as they are STORED: float32
+        # values of magnitude ~100 carry up to 3.8e-6 of rounding, zero-mean per frame,
+        # which scales a frame's responsibilities; the two-call path never stores them)
+        assert err <= max(5e-6, 3. * err2), (cov, S, G, D, err, err2)
     # += semantics
     again = kernels.mixtureset_accumulate_fused(st32, E64.float(), lw64.float(), ln32, None, S, G,
                                                 cov, acc=got.clone())

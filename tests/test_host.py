@@ -304,7 +304,7 @@ def test_f32_mode_is_a_per_call_flag_not_library_state():
     assert _hip.dtype_code(torch.float32, exact=True) == _hip.F32 | _hip.EXACT
     assert _hip.dtype_code(torch.float64, exact=True) == _hip.F64
     old = _hip.get_f32_mode()
-    for mode in ('exact', 'split_f16'):
+    for mode in ('exact', 'bf16x3'):
         _hip.set_f32_mode(mode)
         assert _hip.get_f32_mode() == mode
     with pytest.raises(ValueError):
@@ -315,36 +315,29 @@ def test_f32_mode_is_a_per_call_flag_not_library_state():
     assert _hip.get_f32_mode() == old
 
 
-def test_range_memo_is_keyed_on_the_tensor_not_its_address():
-    '''a verdict remembered by (address, shape, version) would be
-    handed to a different minibatch that the allocator placed at the same
-    address.  The memo lives on the tensor object (its base for views).'''
+def test_fast_f32_path_needs_no_look_at_the_data():
+    '''The bf16x3 arithmetic holds every float32 operand exactly (three bf16 pieces,
+    fp32's exponent range): whether a tensor takes it depends on dtype, size and the
+    host-side mode only -- no range check on the device, no synchronisation, nothing
+    to memoise (round 2's fp16 split needed all three).'''
     calls = []
     orig = _hip.call
-
-    def fake(name, *args):
-        assert name == 'beer_f32_split_hazard'
-        calls.append(name)
-    a = torch.zeros(_hip.SPLIT_MIN_FRAMES + 8, 4)
-    flag_value = [0]
-
-    class _Flag:
-        def item(self):
-            return flag_value[0]
-    real_empty = torch.empty
-    _hip.call = fake
-    torch.empty = lambda *s, **kw: _Flag() if kw.get('dtype') == torch.int32 else \
-        real_empty(*s, **{k: v for k, v in kw.items() if k != 'device'})
-    _hip.ptr, real_ptr = (lambda t: None), _hip.ptr
+    _hip.call = lambda name, *args: calls.append(name)
     try:
-        assert _hip.f32_split_ok(a) and len(calls) == 1
-        assert _hip.f32_split_ok(a) and len(calls) == 1                 # remembered
-        assert _hip.f32_split_ok(a[8:]) and len(calls) == 2             # another view: checked
-        assert _hip.f32_split_ok(a[8:]) and len(calls) == 2             # ... once
-        a.add_(1.)                                                      # new version
-        assert _hip.f32_split_ok(a) and len(calls) == 3
-        b = torch.zeros_like(a)                     # same shape, version 0: a new object
-        flag_value[0] = 1
-        assert not _hip.f32_split_ok(b) and len(calls) == 4
+        a = torch.zeros(_hip.FAST_MIN_FRAMES + 8, 4)
+        assert _hip.f32_fast_ok(a) and _hip.f32_fast_ok(a[8:])
+        assert not _hip.f32_fast_ok(a[:100])                         # small: exact kernels
+        assert not _hip.f32_fast_ok(a.double())
+        assert not _hip.f32_fast_ok(torch.zeros(_hip.FAST_MIN_FRAMES, 65))
+        huge = a.clone()
+        huge[0, 0] = 3e38                                            # any float32 value will do
+        huge[1, 1] = 1e-30
+        assert _hip.f32_fast_ok(huge)
+        with _hip.exact_f32():
+            assert not _hip.f32_fast_ok(a)
+        assert _hip.f32_fast_ok(a)
     finally:
-        _hip.call, torch.empty, _hip.ptr = orig, real_empty, real_ptr
+        _hip.call = orig
+    assert calls == []
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    assert not hasattr(lib, 'beer_f32_split_hazard') and not hasattr(lib, 'beer_frame_scales')

@@ -17,7 +17,7 @@ for T in (8192, 100000, 1000000):
     st = FrameStats(X, 'full')
     beer.set_f32_mode('exact')
     a = kernels.normal_accumulate(st, R, None, K, 1, 'full')
-    beer.set_f32_mode('split_f16')
+    beer.set_f32_mode('bf16x3')
     b = kernels.normal_accumulate(st, R, None, K, 1, 'full')
     ref = (R.double().t() @ st.dense().double())
     ea = ((a - ref).abs().max() / ref.abs().max()).item()
