@@ -32,6 +32,17 @@
 #include "estep_mfma.h"
 #include "estep_tiles.h"
 
+// Timing experiments (tools/ab_build.sh; all but 0 give wrong results):
+#ifndef BEER_K1_ABL
+#define BEER_K1_ABL 0      // K1: 1 = no fragment arithmetic, 2 = and no parameter loads, 3 = and no epilogue
+#endif
+#ifndef BEER_K2_ABL
+#define BEER_K2_ABL 0      // K2: 1 = no B fragments, 2 = and no A loads, 3 = and no atomics
+#endif
+#ifndef BEER_K1_FENCE
+#define BEER_K1_FENCE 0    // K1: scheduling fence every n MFMAs of the hand-placed stream (0 = none)
+#endif
+
 namespace beer_mfma {
 
 namespace {
@@ -48,6 +59,29 @@ constexpr int kProdB[6] = {0, 1, 0, 2, 1, 0};
 __device__ __forceinline__ bf8 as_bf8(const u4& w) { return __builtin_bit_cast(bf8, w); }
 __device__ __forceinline__ f32x4 mfma_bf16(const u4& a, const u4& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(a), as_bf8(b), c, 0, 0, 0);
+}
+// The same MFMA with its accumulator tied IN PLACE to an AGPR quad.  A kernel with 256
+// accumulators (64 x 256 or 128 x 128 per wave, one wave per SIMD) fills the AGPR half
+// of the register file exactly; given the builtin, hipcc's allocator treats
+// accumulators and fragments as one "any vector register" class and shuffles them
+// between the two halves -- 0.55 v_accvgpr_* per MFMA and, in K2, 110 scratch accesses
+// per tile pair (tools/isa_stats.py).  With "+a" / "v" constraints nothing moves.  What
+// hipcc then no longer does is pad hazards around the instruction
+// (cdna_hip_programming.md section 5.7): FIRST = the fragment operands may have been
+// written by the VALU instruction just before (2 wait states), and the accumulators
+// must not be read before mfma_drain().  Dependent MFMAs of an accumulation chain need
+// none.
+template <bool FIRST>
+__device__ __forceinline__ void mfma_bf16_pinned(f32x4& acc, const u4& a, const u4& b) {
+    if (FIRST)
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// after the last pinned MFMA, before anything reads an accumulator
+__device__ __forceinline__ void mfma_drain() {
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // k-steps (8 slabs each), padded to an even count: the K1 loop is unrolled by two
@@ -276,6 +310,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     constexpr int FW = 16 * MT, NW = kThreads / 64;
+    constexpr bool PIN = MT * NT > 32;                        // 256 accumulators: see mfma_bf16_pinned
     float* xw = reinterpret_cast<float*>(smem) + wave * (FW * LD);
     int* tabs = reinterpret_cast<int*>(reinterpret_cast<float*>(smem) + NW * FW * LD);
     int64_t bx = blockIdx.x;
@@ -289,23 +324,27 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
     for (int idx = tid; idx < (nk + 1) * 8; idx += kThreads) tabs[idx] = tab[idx];
     stage_rows<FW>(X, fb, nframes, D, LD, lane, xw);
     __syncthreads();
-    if constexpr (FW == 64) {
-        // The wave's 64 frames are one tile of the accumulation kernel: leave them
-        // behind transposed, [D + 2][68] (rows D, D + 1 = 1, 0; see xt_image_kernel,
-        // which this replaces -- one pass over the frames less).
+    {
+        // The wave's frames are (a part of) one 64-frame tile of the accumulation kernel:
+        // leave them behind transposed, [D + 2][68] (rows D, D + 1 = 1, 0; see
+        // xt_image_kernel, which this replaces -- one pass over the frames less).  A wave
+        // of 32 frames writes its 32 columns; the one that holds the tile's last frames
+        // also writes the 4 columns of padding.
+        static_assert(64 % FW == 0, "whole waves per 64-frame tile");
         if (xt_out && by == 0 && fb < (nframes + 63) / 64 * 64) {
             float* img = xt_out + (fb / 64) * (size_t)xt_floats;
-            constexpr int XS = 68, C4 = XS / 4;
-            for (int e4 = lane; e4 < xt_floats / 4; e4 += 64) {
-                const int row = e4 / C4, c = 4 * (e4 - row * C4);
+            const int c0 = (int)(fb % 64);
+            const int ncol4 = FW / 4 + (c0 + FW == 64 ? 1 : 0);
+            for (int e4 = lane; e4 < (D + 2) * ncol4; e4 += 64) {
+                const int row = e4 / ncol4, c = 4 * (e4 - row * ncol4);      // column c0 + c
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (row < D) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = c + j < 64 ? xw[(c + j) * LD + row] : 0.f;
+                    for (int j = 0; j < 4; ++j) v[j] = c + j < FW ? xw[(c + j) * LD + row] : 0.f;
                 } else if (row == D) {
                     v = f32x4{1.f, 1.f, 1.f, 1.f};
                 }
-                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(img + 4 * e4));
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(img + row * 68 + c0 + c));
             }
         }
     }
@@ -361,6 +400,66 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
             for (int q = 0; q < NP; ++q) b.p[c][q] = Pl[(size_t)(blk + c) * kBlockU4 + 64 * q];
     };
     auto batch = [&](int s, int bi, const AFrag& cur, AFrag& nxt, const BFrag& b, BFrag& bn) {
+        if constexpr (PIN) {
+            // Hand-placed stream: one wave per SIMD issues in order, so whatever is not
+            // interleaved with the MFMAs runs while the matrix pipe idles (the block form
+            // below measured 52 % MFMA busy).  48 pinned MFMAs, each followed by at most
+            // one filler: the 6 loads of the next B batch, then ONE half A fragment of the
+            // next k-step -- table entry, 2 LDS reads, 4 products, 2 x 7 steps of the
+            // three-way split -- and a scheduling fence, so that hipcc keeps the order.
+            static_assert(!PIN || (MT * 2 == NBATCH && 6 * BT * MT == 48), "one half fragment per batch");
+            const int hm = bi % MT, hh = bi / MT;             // the half built in this batch
+            const int64_t blk = (int64_t)s * NT + (bi + 1) * BT;
+            int t = 0;
+            f32x4 bb = {0.f, 0.f, 0.f, 0.f}, p = {0.f, 0.f, 0.f, 0.f};
+            float xx = 0.f;
+            Split3Steps st[2];
+#pragma unroll
+            for (int n = 0; n < 48; ++n) {
+                const int pr = n / (BT * MT), c = (n / MT) % BT, m = n % MT;
+                mfma_bf16_pinned<false>(acc[m][bi * BT + c], cur.w[kProdA[pr]][m],
+                                        b.p[c][kProdB[pr]]);
+                if (BEER_K1_ABL >= 1 && n >= NP * BT) {
+                } else if (BEER_K1_ABL >= 2) {
+                } else if (n < NP * BT) {
+#ifdef BEER_K1_FAKEB
+                    // (timing experiment: every load hits the same 12 KB -- wrong results)
+                    bn.p[n / NP][n % NP] = Pl[(size_t)((blk + n / NP) & 3) * kBlockU4 + 64 * (n % NP)];
+#else
+                    bn.p[n / NP][n % NP] = Pl[(size_t)(blk + n / NP) * kBlockU4 + 64 * (n % NP)];
+#endif
+                } else if (n == 8) {
+                    t = tl[8 * (s + 1) + hh];                 // (the table is padded by one k-step)
+                } else if (n == 12) {
+                    bb = *reinterpret_cast<const f32x4*>(xrow[hm] + ((t >> 8) & 0xff));
+                    xx = xrow[hm][t & 0xff];
+                } else if (n >= 18 && n < 22) {
+                    const bool sq = SQ && (t >> 16) != 0;
+                    float v = bb[n - 18] * (sq ? bb[n - 18] : xx);
+                    pin(v);
+                    p[n - 18] = v;
+                } else if (n >= 22 && n < 29) {
+                    split3_step(n - 22, p[0], p[1], st[0]);
+                } else if (n >= 29 && n < 36) {
+                    split3_step(n - 29, p[2], p[3], st[1]);
+                }
+                if (BEER_K1_FENCE > 0 && n % BEER_K1_FENCE == BEER_K1_FENCE - 1)
+                    __builtin_amdgcn_sched_barrier(0);
+            }
+            if (BEER_K1_ABL >= 1) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) nxt.w[q][hm] = cur.w[q][hm];
+                if (BEER_K1_ABL >= 2) bn = b;
+                return;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                nxt.w[0][hm][2 * hh + e] = st[e].w0;
+                nxt.w[1][hm][2 * hh + e] = st[e].w1;
+                nxt.w[2][hm][2 * hh + e] = st[e].w2;
+            }
+            return;
+        }
         // P is padded by one batch (bi + 1 = NBATCH: first batch of the next k-step)
         load_b((int64_t)s * NT + (bi + 1) * BT, bn);
         // slices of the next A: MT * 2 halves over the NBATCH batches
@@ -396,6 +495,11 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
     for (int s = 0; s < nku; s += 2) {
         kstep(s, f0, f1, b0, b1);
         if (s + 1 < nku) kstep(s + 1, f1, f0, b0, b1);
+    }
+    if constexpr (PIN) mfma_drain();
+    if (PIN && BEER_K1_ABL >= 3) {
+        if (acc[0][0][0] == 1.2345f) log_norm[0] = 1.f;
+        return;
     }
     softmax_epilogue<float, NT, MT, GQ, PACKED, LNO>(acc, fb, nframes, kbase, K, S, G, gl, jw, i,
                                                      g, lane, resps, log_norm, llh_sum, c0[0]);
@@ -460,9 +564,12 @@ constexpr int kAxXS = kAxFT + 4;      // X^T row stride (floats), 16-byte aligne
 // ulp(C) / 32 (measured: tools/probes/mfma_round.hip): a chain over products of one
 // sign (N_k = sum r, sum r x^2) loses ~ulp(C) / 2 per instruction, i.e. n * 2e-8 of
 // the sum after n accumulations -- 1e-5 for the 16384-frame chains of round 2, which
-// is what that round's "parameter rounding bias" really was.  64 accumulations keep
-// it at 1e-6; the partial sums of the workgroups are added in fp64.
-constexpr int kAxMaxFrames = 2048;
+// is what that round's "parameter rounding bias" really was.  Measured on the counts of
+// a 1 M-frame, 256-component mixture (tools/probes/chain_len.py): -1.1e-7 with chains of
+// 1024 frames, -3.3e-7 with 4096, -1.5e-6 with 16384.  4096 it is; the partial sums of the
+// workgroups are added in fp64 (the flush costs 0.1 ms per 1 M frames and 2048 frames of
+// chain at K = 256).
+constexpr int kAxMaxFrames = 4096;
 constexpr int kPiece = 4096;          // granule of the X^T image (bytes)
 constexpr int kAxMC = 8, kAxNQ = 8, kAxWaves = 4;
 
@@ -630,13 +737,23 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
         __syncthreads();
     }
     const bool active = tile0 * 16 < nq;
-    // Operand fragments are loaded IN PLACE ahead of the MFMAs that use them: the A
-    // fragments of the next k-step during the last statistic tile of the current one
-    // (each register right after its last use), the B fragment of statistic tile
-    // uu + 1 while tile uu is multiplied.
+    // A k-step (32 frames): the A fragments of the 8 component tiles are loaded at its
+    // start -- all three pieces at once, into registers that are dead by then; the
+    // products run piece 0 of A first, so only those 8 reads are waited for --, the B
+    // fragment of statistic tile uu + 1 is built while tile uu is multiplied (the one of
+    // the next k-step's tile 0 during tile 7).
     u4 af[MC][NP], bf[2][NP];
+    // the six products with the pieces of A in ascending order: (A, B) =
+    constexpr int kPA[6] = {0, 0, 0, 1, 1, 2}, kPB[6] = {0, 1, 2, 0, 1, 0};
     auto a_ptr = [&](int b, int ks, int c) {
         return smem + a_off[ks] + (b * buf_bytes + c * 16 * kPackedFrames * 2);
+    };
+    auto load_a = [&](int b, int ks) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int c = 0; c < MC; ++c)
+                af[c][q] = *reinterpret_cast<const u4*>(a_ptr(b, ks, c) + q * plane);
     };
     auto gen_b = [&](int b, int ks, int uu, u4 (&out)[NP]) {
         const char* pa = smem + xa_off[uu] + (b * buf_bytes + 128 * ks);
@@ -654,65 +771,81 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
             for (int q = 0; q < NP; ++q) out[q][e] = w3[q];
         }
     };
-    if (active && ntiles > 0) {
-#pragma unroll
-        for (int c = 0; c < MC; ++c)
-#pragma unroll
-            for (int q = 0; q < NP; ++q)
-                af[c][q] = *reinterpret_cast<const u4*>(a_ptr(0, 0, c) + q * plane);
-        gen_b(0, 0, 0, bf[0]);
-    }
-    // One tile out of buffer `buf` (a constant once inlined): 16 steps of 48 MFMAs.
-    // ONE barrier per tile (two with SR), in front of the last step: by then this
-    // wave has read everything it needs from `buf` (the operands of the last step
-    // were loaded before), so the last step may load the first operands of tile + 1
-    // from the other buffer -- whose DMA, issued at the start of this tile, the
-    // barrier's vmcnt(0) has seen land -- and the next tile may overwrite `buf`.
+    if (active && ntiles > 0) gen_b(0, 0, 0, bf[0]);
+    // One tile out of buffer `buf` (a constant once inlined): 16 steps of 48 MFMAs, then
+    // ONE barrier (two with SR): every wave is done reading `buf`, and the DMA of tile
+    // + 1 into the other buffer, issued at the start of this tile, has landed (the
+    // barrier's vmcnt(0)).
     auto iteration = [&](int tile, int buf) __attribute__((always_inline)) {
         const int next = buf ^ 1;
         if (tile + 1 < ntiles) stage(tile + 1, next);
         const bool fold_next = SR && tile + 1 < ntiles;
         if (active) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks) {
+                if (BEER_K2_ABL < 2 || (tile == 0 && ks == 0)) load_a(buf, ks);
 #pragma unroll
                 for (int uu = 0; uu < NQ; ++uu) {
-                    const bool last_uu = uu == NQ - 1, last_step = ks == 1 && last_uu;
-                    if (last_step) {
-                        __syncthreads();
-                        if (SR) {
-                            if (fold_next) fold(next);
-                            __syncthreads();
+                    const int cur = uu & 1;
+                    // The B fragment of the next statistic tile (of tile 0 of the next
+                    // k-step; the one of the next TILE comes from the other buffer, after
+                    // the barrier), built behind this tile's 48 MFMAs, one filler each, every
+                    // result pinned where it is computed (see K1): 4 LDS reads, 8 products,
+                    // 4 x 7 steps of the three-way split.
+                    const bool build = BEER_K2_ABL < 1 && (uu + 1 < NQ || ks == 0);
+                    const int nks = uu + 1 < NQ ? ks : 1, nuu = uu + 1 < NQ ? uu + 1 : 0;
+                    const char* pa = smem + xa_off[nuu] + (buf * buf_bytes + 128 * nks);
+                    const char* pb = smem + xb_off[nuu] + (buf * buf_bytes + 128 * nks);
+                    f32x4 xa[2], xb[2];
+                    float pp[8];
+                    Split3Steps st[4];
+#pragma unroll
+                    for (int n = 0; n < 6 * MC; ++n) {
+                        const int pr = n / MC, c = n % MC;
+                        mfma_bf16_pinned<false>(acc[c][uu], af[c][kPA[pr]], bf[cur][kPB[pr]]);
+                        if (!build) continue;
+                        if (n == 1) xa[0] = *reinterpret_cast<const f32x4*>(pa);
+                        else if (n == 2) xa[1] = *reinterpret_cast<const f32x4*>(pa + 16);
+                        else if (n == 3) xb[0] = *reinterpret_cast<const f32x4*>(pb);
+                        else if (n == 4) xb[1] = *reinterpret_cast<const f32x4*>(pb + 16);
+                        else if (n >= 12 && n < 20) {
+                            const int e = n - 12;
+                            pp[e] = xa[e >> 2][e & 3] * xb[e >> 2][e & 3];
+                            pin(pp[e]);
+                        } else if (n >= 20) {
+                            const int e = (n - 20) / 7;
+                            split3_step((n - 20) % 7, pp[2 * e], pp[2 * e + 1], st[e]);
                         }
                     }
-                    // where the next A fragments / the next B fragment come from
-                    const int nks = last_uu ? (ks + 1) & 1 : ks;
-                    const int nbuf = last_step ? next : buf;
-                    const int cur = uu & 1;
-                    gen_b(nbuf, nks, last_uu ? 0 : uu + 1, bf[cur ^ 1]);
+                    if (build) {
 #pragma unroll
-                    for (int pr = 0; pr < 6; ++pr)
-#pragma unroll
-                        for (int c = 0; c < MC; ++c) {
-                            acc[c][uu] = mfma_bf16(af[c][kProdA[pr]], bf[cur][kProdB[pr]], acc[c][uu]);
-                            // products 3, 4, 5 are the last users of pieces 0, 1, 2 of A[c]
-                            if (last_uu && pr >= 3)
-                                af[c][pr - 3] = *reinterpret_cast<const u4*>(
-                                    a_ptr(nbuf, nks, c) + (pr - 3) * plane);
+                        for (int e = 0; e < 4; ++e) {
+                            bf[cur ^ 1][0][e] = st[e].w0;
+                            bf[cur ^ 1][1][e] = st[e].w1;
+                            bf[cur ^ 1][2][e] = st[e].w2;
                         }
-                    __builtin_amdgcn_sched_barrier(0);
+                    } else if (BEER_K2_ABL >= 1) {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) bf[cur ^ 1][q] = bf[cur][q];
+                    }
                 }
-        } else {
-            __syncthreads();
-            if (SR) {
-                if (fold_next) fold(next);
-                __syncthreads();
             }
         }
+        __syncthreads();
+        if (SR) {
+            if (fold_next) fold(next);
+            __syncthreads();
+        }
+        if (active && tile + 1 < ntiles) gen_b(next, 0, 0, bf[0]);
     };
     for (int tile = 0; tile < ntiles; tile += NB) {
         iteration(tile, 0);
         if (tile + 1 < ntiles) iteration(tile + 1, 1);
+    }
+    mfma_drain();
+    if (BEER_K2_ABL >= 3) {
+        if (acc[0][0][0] == 1.2345f) Sp[0] = 1.0;
+        return;
     }
 #pragma unroll
     for (int uu = 0; uu < NQ; ++uu) {
@@ -1218,6 +1351,27 @@ inline size_t p_image_bytes(int nchunks, int nk, int NT) {
 
 }  // namespace
 
+#ifdef BEER_KERNEL_PROBE
+// ISA experiments (tools/isa_stats.py): only the hot kernels, no host code
+namespace {
+template __global__ void llhx_kernel<16, 4, 4, true, false, false>(
+    int64_t, int, int, int, int, int, int, int, const float*, const u4*, const int*, float*, float*,
+    double*, float*, int, int, int, const float*);
+template __global__ void llhx_kernel<16, 2, 1, false, true, true>(
+    int64_t, int, int, int, int, int, int, int, const float*, const u4*, const int*, float*, float*,
+    double*, float*, int, int, int, const float*);
+template __global__ void accx_kernel<3, false>(int64_t, int, int, int, const float*, const unsigned*,
+                                               const int*, int64_t, double*, int, int, int,
+                                               const float*, int);
+template __global__ void accx_kernel<3, true>(int64_t, int, int, int, const float*, const unsigned*,
+                                              const int*, int64_t, double*, int, int, int,
+                                              const float*, int);
+template __global__ void accf_kernel<4, 6, true, 8, 5>(int64_t, int, int, int, int, int, int, int,
+                                                       const float*, const u4*, const int*,
+                                                       const float*, const float*, int64_t, double*,
+                                                       const float*);
+}  // namespace
+#else
 bool supported_llh_split(int D, int S, int G) { return supported_llh_padded(D, S, G); }
 // Mixture sets whose responsibilities can leave the E-step as packed tiles: full
 // covariance, groups of 4 .. 128 components, a power of two
@@ -1325,7 +1479,15 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
             float* xt = reinterpret_cast<float*>(reinterpret_cast<char*>(resps) +
                                                  packed_tiles_bytes(nframes, K));
             const int xtf = xt_pieces(D) * (kPiece / 4);
-            BEER_LLHX(16, 4, 4, true, false, xt, xtf);
+            // 32 frames x 256 components per wave, two waves per SIMD: the epilogue of one
+            // wave (its 48 KB of packed tiles leave at the CU's store-issue rate) runs under
+            // the other's MFMAs.  Measured at K = 256, D = 40, 1 M frames: 2.0 ms against
+            // 2.3 ms for 64 x 256 per wave with one wave per SIMD (BEER_K1_WIDE=1), whose
+            // hand-placed main loop runs at 90 % of the MFMA rate but whose epilogue, 0.4 ms,
+            // nothing covers.
+            static const bool wide = [] { const char* e = getenv("BEER_K1_WIDE"); return e && atoi(e); }();
+            if (wide) BEER_LLHX(16, 4, 4, true, false, xt, xtf);
+            BEER_LLHX(16, 2, 4, true, false, xt, xtf);
         }
         if (NT == 4) BEER_LLHX(4, 2, 1, false, false);
         if (NT == 8) BEER_LLHX(8, 2, 2, false, false);
@@ -1432,8 +1594,8 @@ int acc_bf16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, co
     const int gy = (K + 16 * kAxMC - 1) / (16 * kAxMC);
     // one workgroup per CU (120 KB of LDS, 512 registers per lane): whole rounds of 256
     // workgroups, at most kAxMaxFrames frames each
-    const int64_t max_z = (nframes + 511) / 512,
-                  min_z = (nframes + kAxMaxFrames - 1) / kAxMaxFrames;
+    static const int chain = [] { const char* e = getenv("BEER_AX_MAXFRAMES"); return e ? atoi(e) : kAxMaxFrames; }();
+    const int64_t max_z = (nframes + 511) / 512, min_z = (nframes + chain - 1) / chain;
     const int64_t rounds = ((int64_t)gx * gy * min_z + 255) / 256;
     int64_t gz = rounds * 256 / ((int64_t)gx * gy);
     if (gz < min_z) gz = min_z;
@@ -1561,5 +1723,7 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }
+
+#endif  // BEER_KERNEL_PROBE
 
 }  // namespace beer_mfma

@@ -280,6 +280,12 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2_t));
 }
 __device__ __forceinline__ void split3(float a, float b, unsigned (&p)[3]) {
+    // (no contraction: `a` is usually a product, and a - p0 fused with it into an fma would
+    // decompose the UNROUNDED product -- harmless, but then two kernels that hipcc
+    // happens to compile differently no longer produce the same bits, and the fused
+    // accumulation relies on recomputing the E-step's logits exactly.  The pieces
+    // decompose fl32(x_a x_b), the reference's own statistic.)
+#pragma clang fp contract(off)
     p[0] = cvt_pk_bf16(a, b);
     float ra = a - __builtin_bit_cast(float, p[0] << 16);
     float rb = b - __builtin_bit_cast(float, p[0] & 0xffff0000u);
@@ -287,6 +293,28 @@ __device__ __forceinline__ void split3(float a, float b, unsigned (&p)[3]) {
     ra -= __builtin_bit_cast(float, p[1] << 16);
     rb -= __builtin_bit_cast(float, p[1] & 0xffff0000u);
     p[2] = cvt_pk_bf16(ra, rb);
+}
+// split3 one instruction group at a time (k = 0 .. 6), for kernels that place the
+// fragment arithmetic by hand between their MFMAs
+// (`pin`: an empty volatile asm that redefines the value.  Volatile asms keep their
+// order, so a value pinned between two pinned MFMAs is computed between them --
+// hipcc's IR passes otherwise sink the whole computation to its first use, a k-step
+// later, and keep its inputs alive until then.)
+template <typename V>
+__device__ __forceinline__ void pin(V& v) { asm volatile("" : "+v"(v)); }
+struct Split3Steps { unsigned w0, w1, w2; float r0, r1; };
+__device__ __forceinline__ void split3_step(int k, float a, float b, Split3Steps& t) {
+#pragma clang fp contract(off)
+    switch (k) {
+        case 0: t.w0 = cvt_pk_bf16(a, b); pin(t.w0); break;
+        case 1: t.r0 = a - __builtin_bit_cast(float, t.w0 << 16); pin(t.r0); break;
+        case 2: t.r1 = b - __builtin_bit_cast(float, t.w0 & 0xffff0000u); pin(t.r1); break;
+        case 3: t.w1 = cvt_pk_bf16(t.r0, t.r1); pin(t.w1); break;
+        case 4: t.r0 -= __builtin_bit_cast(float, t.w1 << 16); pin(t.r0); break;
+        case 5: t.r1 -= __builtin_bit_cast(float, t.w1 & 0xffff0000u); pin(t.r1); break;
+        case 6: t.w2 = cvt_pk_bf16(t.r0, t.r1); pin(t.w2); break;
+        default: break;
+    }
 }
 // the same on the host / in scalar device code (parameter packing): bf16 bits
 __host__ __device__ inline unsigned short bf16_rne(float v) {

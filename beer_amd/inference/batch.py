@@ -33,10 +33,23 @@ from .objectives import EvidenceLowerBoundInstance
 
 __all__ = ['accumulate_elbo', 'pack_utterances', 'decode_batch']
 
-# Responsibilities [frames, K] are the largest scratch buffer; bound it.
-# scratch of one sub-batch (responsibilities, per-state likelihoods, trellis); the
-# device has 288 GB and up to three sub-batches are in flight (BEER_SCRATCH_GB overrides)
-_SCRATCH_BYTES = int(os.environ.get('BEER_SCRATCH_GB', '24')) << 30
+# Scratch of one sub-batch (responsibilities, per-state likelihoods, trellis): up to
+# three sub-batches are in flight, so a sub-batch may take an eighth of what is free on
+# the device when the first batch is cut, at most 24 GB (a 288 GB MI355X to itself:
+# 24 GB; a smaller or shared device: less).  BEER_SCRATCH_GB overrides.
+_SCRATCH_CAP = 24 << 30
+_scratch_bytes = [int(os.environ['BEER_SCRATCH_GB']) << 30 if 'BEER_SCRATCH_GB' in os.environ
+                  else None]
+
+
+def _scratch_budget():
+    if _scratch_bytes[0] is None:
+        try:
+            free, _ = torch.cuda.mem_get_info()
+            _scratch_bytes[0] = max(1 << 28, min(_SCRATCH_CAP, free // 8))
+        except Exception:                                   # no device: the caller raises later
+            _scratch_bytes[0] = _SCRATCH_CAP
+    return _scratch_bytes[0]
 
 
 def pack_utterances(utterances):
@@ -79,7 +92,7 @@ def _sub_batches(lengths, bytes_per_frame, max_frames):
     filled greedily: equal-sized scratch tensors are recycled by the caching
     allocator, unequal ones make it hipMalloc / hipFree gigabytes every
     iteration (25 ms stalls at config 3).'''
-    budget = max(1, min(max_frames, _SCRATCH_BYTES // max(1, bytes_per_frame)))
+    budget = max(1, min(max_frames, _scratch_budget() // max(1, bytes_per_frame)))
     total = sum(lengths)
     n_runs = max(1, -(-total // budget))
     target = -(-total // n_runs)
@@ -147,6 +160,18 @@ def _kl_beside_the_estep(model, device):
     if not _KL_BESIDE or isinstance(model, VAE) or device.type != 'cuda':
         return torch.as_tensor(model.kl_div_posterior_prior()), None
     main = torch.cuda.current_stream(device)
+    # Everything the distributions memoise -- expected statistics (which the E-step
+    # reads: `natural_form()`), log-normalisers, natural parameters -- is produced HERE,
+    # on the main stream: a memo entry written by a side-stream kernel would be picked up
+    # by the main stream's E-step with nothing ordering the two.  What is left for the
+    # side stream are the KL kernels and their sums, whose results nobody reads before
+    # the caller has waited for the event.
+    for param in model.bayesian_parameters():
+        for dist in (getattr(param, 'posterior', None), getattr(param, 'prior', None)):
+            if dist is not None and hasattr(dist, 'expected_sufficient_statistics'):
+                dist.expected_sufficient_statistics()
+                dist.log_norm()
+                dist.natural_parameters()
     side = _side_streams.get(device)
     if side is None:
         side = _side_streams[device] = torch.cuda.Stream(device)
