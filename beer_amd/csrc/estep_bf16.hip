@@ -666,38 +666,43 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
 #pragma unroll
         for (int uu = 0; uu < NQ; ++uu) acc[c][uu] = f32x4{0, 0, 0, 0};
 
-    // DMA of tile `tile` into buffer `buf`: 1 KiB blocks kb = wave, wave + 4, ...;
-    // blocks < 4 NX from the X image, the others from the R image of block `by`
-    const char* xsrc = reinterpret_cast<const char*>(Xt);
-    const char* rsrc = reinterpret_cast<const char*>(Rimg);
+    // DMA of tile `tile` into buffer `buf`: every wave-instruction moves 1 KiB; wave w
+    // takes the blocks w, w + 4, ... of the X image (4 NX blocks), of the three planes of
+    // the R image of block `by` (48 blocks) and, with SR, of gamma^T (<= 4 blocks).  The
+    // regions are whole multiples of the 4 waves, so which region a piece belongs to is
+    // known at compile time: no branches, one per-lane base address per region.  (A
+    // branch chain per piece cost scalar registers; their spill reloads came with
+    // s_waitcnt vmcnt(0), which also waits for the DMA issued just before -- 16 serialised
+    // memory round trips per tile, 46 k cycles where the MFMAs need 12 k.)
+    static_assert((NX * (kPiece / 1024)) % WAVES == 0 && (NP * plane / 1024) % WAVES == 0,
+                  "regions are whole rounds of the waves");
+    const char* xsrc = reinterpret_cast<const char*>(Xt) + wave * 1024 + lane * 16;
+    const char* rsrc = reinterpret_cast<const char*>(Rimg) + wave * 1024 + lane * 16;
+    const char* gsrc = SR ? reinterpret_cast<const char*>(Gt) + wave * 1024 + lane * 16 : nullptr;
     auto stage = [&](int tile, int buf) {
         const int64_t tau = tau0 + tile;
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        const char* xs = xsrc + tau * (size_t)(NX * kPiece);
+        const char* rs = rsrc + (tau * nblk + by) * (size_t)(NP * plane);
+        char* dst = smem + buf * buf_bytes + wave * 1024;
 #pragma unroll
-        for (int n = 0; n < (NKB + (SR ? 4 : 0) + WAVES - 1) / WAVES; ++n) {
-            const int kb = wave + WAVES * n;
-            if (kb < NKB) {
-                const char* src = kb < 4 * NX
-                    ? xsrc + (tau * NX) * (size_t)kPiece + (size_t)kb * 1024
-                    : rsrc + ((tau * nblk + by) * (size_t)(NP * plane)) + (size_t)(kb - 4 * NX) * 1024;
-                __builtin_amdgcn_global_load_lds(
-                    reinterpret_cast<const u4*>(src) + lane,
-                    (__attribute__((address_space(3))) void*)(smem + buf * buf_bytes + kb * 1024),
-                    16, 0, 0);
-            } else if (SR && kb - NKB < gkb) {
-                const char* src = reinterpret_cast<const char*>(Gt) +
-                                  (tau * nblk + by) * (size_t)gbytes + (size_t)(kb - NKB) * 1024;
-                __builtin_amdgcn_global_load_lds(
-                    reinterpret_cast<const u4*>(src) + lane,
-                    (__attribute__((address_space(3))) void*)(smem + g_base + buf * 4096 +
-                                                              (kb - NKB) * 1024),
-                    16, 0, 0);
-            }
-        }
+        for (int n = 0; n < NX * (kPiece / 1024) / WAVES; ++n)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const u4*>(xs + n * (WAVES * 1024)),
+                                             (lds_ptr)(dst + n * (WAVES * 1024)), 16, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NP * plane / 1024 / WAVES; ++n)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const u4*>(rs + n * (WAVES * 1024)),
+                                             (lds_ptr)(dst + r_off + n * (WAVES * 1024)), 16, 0, 0);
+        if (SR && wave < gkb)
+            __builtin_amdgcn_global_load_lds(
+                reinterpret_cast<const u4*>(gsrc + (tau * nblk + by) * (size_t)gbytes),
+                (lds_ptr)(smem + g_base + buf * 4096 + wave * 1024), 16, 0, 0);
     };
     // SR: this thread's share of the R image in `buf`: 4 chunks of 8 frames (row c,
     // chunk position pos holds frames 8 (pos ^ (c & 7)) ..), all three planes, times
     // the state's gamma
     auto fold = [&](int buf) {
+        if (BEER_K2_ABL == 4) return;                       // (timing experiment: no fold)
 #pragma unroll 1
         for (int n = 0; n < 16 * MC * 8 / (64 * WAVES); ++n) {
             const int p = tid + 64 * WAVES * n, c = p >> 3, pos = p & 7, ch = pos ^ (c & 7);
@@ -1498,9 +1503,16 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
     const int gq = G <= 64 ? 1 : G / 64;
     if (packed) {
         // the responsibilities within each state's mixture as the accumulation's LDS tiles
+        static const bool wide = [] { const char* e = getenv("BEER_K1_WIDE"); return e && atoi(e); }();
+        if (wide) {
+            switch (gq) {
+                case 1: BEER_LLHX(16, 4, 1, true, false);
+                default: BEER_LLHX(16, 4, 2, true, false);
+            }
+        }
         switch (gq) {
-            case 1: BEER_LLHX(16, 4, 1, true, false);
-            default: BEER_LLHX(16, 4, 2, true, false);
+            case 1: BEER_LLHX(16, 2, 1, true, false);
+            default: BEER_LLHX(16, 2, 2, true, false);
         }
     }
     if (!resps && jw == 4) {
