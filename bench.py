@@ -1,16 +1,23 @@
 #!/usr/bin/env python
 """Headline benchmark: frames/sec per VB iteration (E-step + all-reduce + M-step).
 
-    python bench.py --gpus N --steps K --warmup W            # BASELINE config 2 (default)
-    python bench.py --gpus N --config 3 [--frames 10000000]   # BASELINE config 3
+    python bench.py --gpus N --steps K --warmup W            # the driver's line
+    python bench.py --gpus N --config 3 [--cov full] [--frames 10000000]   # config 3 alone
 
-* config 2 (`configs[1]`, the configuration the metric is quoted on): GMM, K = 256
-  full-covariance Gaussians, D = 40, 1,000,000 fp32 frames PER GPU in 8192-frame
-  "utterances" (weak scaling).
-* config 3 (`configs[2]`): monophone phone-loop HMM, 40 phones x 3 states x 16
-  diagonal Gaussians, D = 40, a FIXED corpus of 10 M frames in ~33 k utterances
-  sharded over the ranks by frame count (strong scaling), forward-backward + VB
-  update.
+The default line is BASELINE config 2 (`configs[1]`, the configuration the metric is
+quoted on): GMM, K = 256 full-covariance Gaussians, D = 40, 1,000,000 fp32 frames PER
+GPU in 8192-frame "utterances" (weak scaling; `--scaling strong` shards 1 M frames over
+the ranks instead).  It carries two sub-objects for BASELINE config 3 (`configs[2]`),
+measured by the same process(es) right after: `config3` -- monophone phone-loop HMM, 40
+phones x 3 states x 16 diagonal Gaussians, D = 40, a FIXED corpus of 10 M frames in ~33 k
+utterances sharded over the ranks by frame count (strong scaling), forward-backward + VB
+update -- and `config3_full`, the same model with full covariances on 2 M frames
+(`--no-config3` skips both).
+
+float32 models multiply on the bf16 matrix pipes with every operand held exactly as three
+bf16 pieces and six partial products per multiplication (fp32 accumulation): operands and
+accumulation are float32's own -- `value` is on that arithmetic; `f32_exact` repeats the
+iteration on the exact fp32 MFMA.
 
 One process per GPU, ONE RCCL all-reduce of the accumulated statistics per
 iteration, replicated M-step.  With --gpus N > 1 and no launcher in the
@@ -39,7 +46,8 @@ from beer_amd.distributed import all_reduce_elbo, shard_utterances   # noqa: E40
 
 K, D = 256, 40
 Q = D * D + D + 2
-# MI355X_MICROARCH.md: dense MFMA peaks (f32 operands; f16 operands / f32 accumulate), HBM3E
+# MI355X_MICROARCH.md: dense MFMA peaks (f32 operands; bf16 operands / f32 accumulate), the fp32
+# vector peak (= the f32 MFMA peak), HBM3E
 PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6, 'bf16': 2500.}
 PEAK_HBM_GBS = 8000.
 
@@ -122,6 +130,31 @@ def pmc_traffic(kernel_key):
         except Exception:
             continue
     return None
+
+
+def pmc_entry(kernel_key):
+    'The committed PMC summary of a kernel (profiles/r*_pmc.json), newest round first; {} if absent.'
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')), reverse=True):
+        try:
+            return json.load(open(path))['kernels'][kernel_key]
+        except Exception:
+            continue
+    return {}
+
+
+def rank_census(world, device, backend, n_local):
+    '''Evidence for an N > 1 line: the number of ranks the collective really spans (an
+    all-reduce of ones) and the frames per rank (max / mean).'''
+    if world == 1:
+        return {'rccl_ranks': 1, 'frames_per_rank': {'max': n_local, 'mean': float(n_local)}}
+    dev = device if backend == 'nccl' else 'cpu'
+    t = torch.tensor([1., float(n_local)], dtype=torch.float64, device=dev)
+    m = torch.tensor([float(n_local)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    return {'rccl_ranks': int(t[0].item()), 'backend': backend,
+            'frames_per_rank': {'max': int(m.item()), 'mean': float(t[1].item()) / world}}
 
 
 def fence(world):
@@ -269,16 +302,20 @@ def gmm_parity_check(model, X, n=65536, chunk=8192):
 
 
 def run_gmm(args, rank, world, device, backend):
-    X = synth_frames(args.frames, device, seed=1 + rank)
-    lengths = [args.chunk] * (args.frames // args.chunk)
-    if args.frames % args.chunk:
-        lengths.append(args.frames % args.chunk)
-    datasize = args.frames * world
+    frames = args.frames
+    if args.scaling == 'strong':              # a fixed corpus of args.frames, sharded
+        frames = args.frames // world + (1 if rank < args.frames % world else 0)
+    X = synth_frames(frames, device, seed=1 + rank)
+    lengths = [args.chunk] * (frames // args.chunk)
+    if frames % args.chunk:
+        lengths.append(frames % args.chunk)
+    datasize = args.frames * world if args.scaling == 'weak' else args.frames
+    census = rank_census(world, device, backend, frames)
     model = make_gmm(device)             # identical on every rank
     optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.)
     elbo_err = stats_err = None
     if rank == 0 and not args.no_check:
-        elbo_err, stats_err = gmm_parity_check(model, X, n=min(65536, args.frames))
+        elbo_err, stats_err = gmm_parity_check(model, X, n=min(65536, frames))
     phases = PhaseTimer()
 
     def step():
@@ -316,7 +353,7 @@ def run_gmm(args, rank, world, device, backend):
                 continue
             # algorithmic work of one launch (2*K*Q flop per frame per GEMM,
             # no symmetry discount), for the frames one launch processes
-            flops = 2. * K * Q * args.frames * steps / max(1, n)
+            flops = 2. * K * Q * frames * steps / max(1, n)
             kern[nm] = {'ms': ms, 'launches': n, 'tflops': flops / (ms * 1e-3) / 1e12}
         return kern
 
@@ -337,6 +374,7 @@ def run_gmm(args, rank, world, device, backend):
                  'achieved': e_kern[e_dom]['tflops'], 'peak': PEAK_TFLOPS['f32'],
                  'frac': e_kern[e_dom]['tflops'] / PEAK_TFLOPS['f32'],
                  'avg_launch_ms': e_kern[e_dom]['ms'],
+                 'traffic': pmc_traffic('acc_kernel' if 'accumulate' in e_dom else 'llh_kernel'),
                  'note': 'v_mfma_f32_16x16x4_f32, bitwise an fmaf chain; the kernels contract only '
                          'the D(D+1)/2 symmetric products, so frac can exceed 1'}
     if rank != 0:
@@ -363,18 +401,26 @@ def run_gmm(args, rank, world, device, backend):
     out = {
         'metric': 'frames/sec per VB iteration (E+M)', 'value': datasize * args.steps / elapsed,
         'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling,
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'configs[1]: GMM K=256 full-covariance, D=40, '
-                               f'{args.frames} fp32 frames per GPU in {args.chunk}-frame '
-                               'utterances, 1 VB iteration = E-step + all-reduce + M-step',
-                   'parallelism': f'dp{world}', 'frames_per_gpu': args.frames,
+                               + (f'{args.frames} fp32 frames per GPU' if args.scaling == 'weak'
+                                  else f'{args.frames} fp32 frames sharded over the GPUs')
+                               + f' in {args.chunk}-frame utterances, 1 VB iteration = E-step + '
+                               'all-reduce + M-step',
+                   'parallelism': f'dp{world}', 'frames_per_gpu': frames,
                    'components': K, 'dim': D},
+        **census,
         'elbo_rel_err_vs_cpu_fp64': elbo_err, 'stats_rel_err_vs_cpu_fp64': stats_err,
         'parity_check': 'first 65536 frames through the timed kernels (packed hand-over) vs the '
                         'fp64 numpy oracle',
         'elbo_per_frame': float(elbo) / (len(lengths) * world * datasize),
-        'f32_mode': mode, 'all_reduce_ms': allreduce_ms, 'm_step_ms': mstep_ms,
+        'f32_mode': mode,
+        'f32_arithmetic': 'bf16x3: every fp32 operand exactly as three bf16 pieces, six partial '
+                          'products per multiplication on v_mfma_f32_16x16x32_bf16, fp32 '
+                          'accumulation (not narrower than fp32: 24-bit operands, product error '
+                          '<= 2^-23)' if split else 'v_mfma_f32_16x16x4_f32',
+        'all_reduce_ms': allreduce_ms, 'm_step_ms': mstep_ms,
         'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'],
                      'peak': peak, 'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / peak,
                      'traffic': pmc_traffic(pmc_key), 'avg_launch_ms': kern[dom]['ms'],
@@ -495,8 +541,11 @@ def cpu_baseline_hmm(budget_s=20.):
                       f'torch-CPU replay of the reference op sequence, {dt:.1f} s'}
 
 
-def run_hmm(args, rank, world, device, backend):
-    total_frames = args.frames
+def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, steps=None,
+            warmup=None, with_cpu_baseline=True):
+    cov = cov or args.cov
+    total_frames = total_frames or args.frames
+    steps, warmup = steps or args.steps, args.warmup if warmup is None else warmup
     lengths_all = hmm_corpus(total_frames)
     datasize = sum(lengths_all)
     mine = shard_utterances(lengths_all, world, rank)        # balanced by frame count
@@ -504,7 +553,8 @@ def run_hmm(args, rank, world, device, backend):
     n_local = sum(lengths)
     g = torch.Generator(device=device).manual_seed(2 + rank)
     X = torch.randn(n_local, D, generator=g, device=device)
-    ploop = make_phone_loop(args.cov, device)                # identical on every rank
+    ploop = make_phone_loop(cov, device)                     # identical on every rank
+    census = rank_census(world, device, backend, n_local)
     optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.)
     phases = PhaseTimer()
 
@@ -523,7 +573,7 @@ def run_hmm(args, rank, world, device, backend):
              'beer_mixtureset_accumulate_fused', 'beer_normal_accumulate',
              'beer_normal_accumulate_packed', 'beer_pack_resps',
              'beer_mixtureset_estep_packed', 'beer_mixtureset_accumulate_packed')
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     import gc
     gc.collect()
@@ -532,7 +582,7 @@ def run_hmm(args, rank, world, device, backend):
     fence(world)
     with KernelTimer(names) as kt:
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             elbo = step()
         fence(world)
         elapsed = time.perf_counter() - t0
@@ -546,55 +596,85 @@ def run_hmm(args, rank, world, device, backend):
     # (a row of the statistics is (N_1 .. N_G-1, N_1 + .. + N_G): beer/dists/dirichlet.py:18-21)
     conservation = abs(float(counts[0].double()[:, -1].sum()) - datasize) / datasize \
         if counts else None
+    Kc = 3 * N_PHONES * N_COMP
+    Qd = {'diagonal': 2 * D + 2, 'full': D * D + D + 2, 'isotropic': D + 3}[cov]
     kern = {}
     for nm in names:
         ms, n = kt.mean_ms(nm)
         if n:
-            kern[nm] = {'ms': ms, 'launches': n, 'frames_per_launch': n_local * args.steps / n}
+            fpl = n_local * steps / n
+            kern[nm] = {'ms': ms, 'launches': n, 'frames_per_launch': fpl}
+            if 'estep' in nm or 'accumulate' in nm:
+                # 2*K*Q algorithmic flop per frame for each of the two products
+                kern[nm]['tflops'] = 2. * Kc * Qd * fpl / (ms * 1e-3) / 1e12
     dom = max(kern, key=lambda nm: kern[nm]['ms'] * kern[nm]['launches'])
-    # HBM roofline of the dominant call: its algorithmic traffic is the frames it reads,
-    # 4 D bytes each (B(D) = 160 B / frame), once
-    alg_bytes = 4. * D * kern[dom]['frames_per_launch']
-    achieved = alg_bytes / (kern[dom]['ms'] * 1e-3) / 1e9
-    pmc_key = ('c3full_' if args.cov == 'full' else 'c3_') + {
-                       'beer_mixtureset_accumulate_fused': 'accf_kernel',
-                       'beer_mixtureset_estep_packed': 'llhx_kernel',
-                       'beer_mixtureset_accumulate_packed': 'accx_kernel',
-                       'beer_mixtureset_estep': 'llhx_kernel',
-                       'beer_hmm_posteriors_fused': 'fb_wave_kernel'}.get(dom, dom)
-    Qd = {'diagonal': 2 * D + 2, 'full': D * D + D + 2, 'isotropic': D + 3}[args.cov]
+    kname = {'beer_mixtureset_accumulate_fused': 'accf_kernel',
+             'beer_mixtureset_estep_packed': 'llhx_kernel',
+             'beer_mixtureset_accumulate_packed': 'accx_kernel',
+             'beer_mixtureset_estep': 'llhx_kernel',
+             'beer_hmm_posteriors_fused': 'fb_wave_kernel'}.get(dom, dom)
+    pmc_key = ('c3full_' if cov == 'full' else 'c3_') + kname
+    pmc = pmc_entry(pmc_key)
+    # SURVEY 8d names the roofline: matrix pipe for full covariances; VALU + transcendental
+    # throughput for diagonal ones (Q is small: per frame and Gaussian one exponential, the
+    # three-way split of its responsibility and a share of the fragment arithmetic stand
+    # beside 4 Q multiply-adds).  Peaks: dense bf16 MFMA (the pipe the kernels run on) /
+    # the fp32 vector rate.
+    bound = 'mfma' if cov == 'full' else 'valu'
+    peak = PEAK_TFLOPS['bf16' if cov == 'full' else 'f32']
+    achieved = kern[dom].get('tflops')
+    if achieved is None:                     # (the forward-backward call dominating: no flop count)
+        bound, peak, achieved = 'hbm', PEAK_HBM_GBS, 4. * D * kern[dom]['frames_per_launch'] / \
+            (kern[dom]['ms'] * 1e-3) / 1e9
+    fpl = kern[dom]['frames_per_launch']
+    roof = {'bound': bound, 'kernel': dom, 'achieved': achieved, 'peak': peak,
+            'unit': 'GB/s' if bound == 'hbm' else 'TFLOP/s', 'frac': achieved / peak,
+            'traffic': pmc_traffic(pmc_key), 'avg_launch_ms': kern[dom]['ms'],
+            'frac_of_bf16_mfma_peak': None if bound == 'hbm' else achieved / PEAK_TFLOPS['bf16'],
+            'valu_wave_insts_per_frame': (pmc['SQ_INSTS_VALU'] / fpl) if 'SQ_INSTS_VALU' in pmc else None,
+            'counter_bytes_per_frame': (pmc_traffic(pmc_key) / fpl) if pmc_traffic(pmc_key) else None,
+            'algorithmic_bytes_per_frame': 4 * D,
+            'note': 'achieved = algorithmic flops of the dominant call (2*K*Q per frame: one of '
+                    'the two products of the iteration; the fused accumulation also recomputes '
+                    'the logits, which is not counted) / its HIP-event time.  `valu`: the fp32 '
+                    'vector peak (SURVEY 8d: VALU + transcendental bound); the kernels run their '
+                    'products on the bf16 MFMA with three pieces per operand (6 MFMAs per '
+                    f'product), see frac_of_bf16_mfma_peak.  Iteration: 4*K*Q = {4 * Kc * Qd} '
+                    'flop per frame, 160 B of frames per frame.'}
     out = {
-        'metric': 'frames/sec per VB iteration (E+M)', 'value': datasize * args.steps / elapsed,
-        'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+        'metric': 'frames/sec per VB iteration (E+M)', 'value': datasize * steps / elapsed,
+        'unit': 'frames/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+        'ms_per_step': 1e3 * elapsed / steps, 'higher_is_better': True,
         'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'configs[2]: monophone phone-loop HMM, {N_PHONES} phones x 3 states, '
-                               f'{N_COMP} {args.cov} Gaussians per state (K={3 * N_PHONES * N_COMP}), '
+                               f'{N_COMP} {cov} Gaussians per state (K={Kc}), '
                                f'D={D}, {datasize} fp32 frames in {len(lengths_all)} utterances '
                                f'sharded over the ranks by frame count (free phone loop), 1 VB '
                                'iteration = emission E-step + forward-backward + statistics + '
                                'all-reduce + M-step',
                    'parallelism': f'dp{world}', 'frames_total': datasize,
                    'frames_rank0': n_local, 'utterances': len(lengths_all)},
+        **census,
         'elbo_per_frame': float(elbo) / (len(lengths_all) * datasize),
         'count_conservation_rel_err': conservation,
         'f32_mode': beer.get_f32_mode(),
         'all_reduce_ms': phases.mean_ms('all_reduce'), 'm_step_ms': phases.mean_ms('m_step'),
-        'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': PEAK_HBM_GBS,
-                     'unit': 'GB/s', 'frac': achieved / PEAK_HBM_GBS,
-                     'traffic': pmc_traffic(pmc_key), 'avg_launch_ms': kern[dom]['ms'],
-                     'note': 'achieved = algorithmic bytes (the frames the call reads: 4*D = 160 B '
-                             'per frame) / HIP-event time of the C-ABI call.  The call is bound by '
-                             'matrix-core and VALU work, not by HBM: with the responsibilities '
-                             'recomputed in registers its counter traffic is the frames (re-read '
-                             'per 64-component chunk, mostly from L2), the per-state normalisers '
-                             'and posteriors; algorithmic flops of the iteration are '
-                             f'4*K*Q = {4 * 3 * N_PHONES * N_COMP * Qd} per frame.'},
+        'roofline': roof,
         'kernels': kern,
     }
-    if not args.no_cpu_baseline and world == 1 and args.cov == 'diagonal':
+    if with_cpu_baseline and not args.no_cpu_baseline and world == 1 and cov == 'diagonal':
         out['cpu_baseline'] = cpu_baseline_hmm()
     return out
+
+
+def config3_subobject(line):
+    'The keys of a config-3 line that go into the default line as a sub-object.'
+    keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'f32_mode', 'kernels',
+            'roofline', 'cpu_baseline', 'count_conservation_rel_err', 'elbo_per_frame',
+            'all_reduce_ms', 'm_step_ms', 'frames_per_rank', 'rccl_ranks')
+    sub = {k: line[k] for k in keep if k in line}
+    sub['workload'] = line['config']['workload']
+    return sub
 
 
 # --------------------------------------------------------------------------------------------
@@ -621,6 +701,19 @@ def worker(args):
             dist.init_process_group(backend, rank=rank, world_size=world)
     run = run_gmm if args.config == 2 else run_hmm
     out = run(args, rank, world, device, backend)
+    if args.config == 2 and not args.no_config3:
+        # BASELINE config 3 inside the same line: diagonal emissions on the 10 M-frame
+        # corpus, full covariances on 2 M frames (every rank takes part: the corpus is
+        # sharded over them)
+        torch.cuda.empty_cache()
+        c3 = run_hmm(args, rank, world, device, backend, cov='diagonal', total_frames=10_000_000,
+                     steps=3, warmup=1)
+        torch.cuda.empty_cache()
+        c3f = run_hmm(args, rank, world, device, backend, cov='full', total_frames=2_000_000,
+                      steps=3, warmup=1, with_cpu_baseline=False)
+        if rank == 0:
+            out['config3'] = config3_subobject(c3)
+            out['config3_full'] = config3_subobject(c3f)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -651,6 +744,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-exact', action='store_true', help='config 2: skip the f32_exact leg')
     ap.add_argument('--no-check', action='store_true', help='config 2: skip the oracle check')
+    ap.add_argument('--no-config3', action='store_true',
+                    help='default line: skip the config3 / config3_full sub-objects')
+    ap.add_argument('--scaling', default='weak', choices=('weak', 'strong'),
+                    help='config 2: 1 M frames per GPU (weak, default) or --frames in total (strong)')
     args = ap.parse_args()
     if args.frames is None:
         args.frames = 1_000_000 if args.config == 2 else 10_000_000
