@@ -594,6 +594,26 @@ def g_pickles():
     save('g13_cli_reference_run', out)
 
 
+def g13_fp64():
+    '''The free-loop accumulate + update of g13 run by the REFERENCE in float64 (model and
+    features cast to double): the fp64 truth of the float32 CLI replay, so that the test
+    does not have to take it from the build's own fp64 path.'''
+    import pickle
+    ploop = pickle.load(open(os.path.join(HERE, 'ref_phoneloop.pkl'), 'rb')).double()
+    feats = np.load(os.path.join(HERE, 'ref_feats.npz'))
+    N = sum(len(feats[u]) for u in feats.files)
+    optim = beer.VBConjugateOptimizer(ploop.conjugate_bayesian_parameters(keepgroups=True), 1.)
+    optim.init_step()
+    free = beer.evidence_lower_bound(datasize=N)
+    for utt in sorted(feats.files):
+        free += beer.evidence_lower_bound(ploop, torch.from_numpy(feats[utt]).double(), datasize=N)
+    out = {'free_elbo': np.asarray(float(free))}
+    free.backward()
+    optim.step()
+    dump_params(out, 'updated', ploop)
+    save('g13_cli_reference_run_fp64', out)
+
+
 def g14_vae():
     """Statistics-in path of the VAE models (vae.py:63-89): the prior gets
     dense sample-averaged statistics and is differentiated w.r.t. them."""
@@ -661,6 +681,45 @@ def g14_vae():
     dump_params(out, 'init', vae)
     dump_acc(out, 'acc', vae, elbo._acc_stats)
     save('g14_vae_gmm_step', out)
+
+
+def g14_hmm_vae():
+    """BASELINE config 4 at its own dimensions, small T: one ELBO + backward of an HMM-VAE
+    (vae.py:63-89 over hmm.py:73-100) -- D = 40 features, residual encoder / decoder, a
+    64-dimensional latent variable, HMM prior with diagonal Gaussians -- with the noise of
+    the reparameterisation recorded."""
+    rng = np.random.RandomState(144)
+    Dx, Dz, T, nsamp = 40, 64, 48, 2
+    torch.manual_seed(144)
+    X = torch.from_numpy(rng.randn(T, Dx)).double()
+    enc = beer.nnet.ResidualFeedForwardNet(dim_in=Dx, nblocks=2, block_width=32)
+    dec = beer.nnet.ResidualFeedForwardNet(dim_in=Dz, nblocks=2, block_width=32)
+    nset = beer.NormalSet.create(torch.zeros(Dz), torch.ones(Dz), size=3, prior_strength=1.,
+                                 noise_std=.5, cov_type='diagonal')
+    vae = beer.VAE(beer.HMM.create(notebook_graph(), nset), enc, dec).double()
+    noise = []
+    real_randn = torch.randn
+
+    def recording_randn(*a, **k):
+        t = real_randn(*a, **k)
+        noise.append(t)
+        return t
+    torch.randn = recording_randn
+    try:
+        elbo = beer.evidence_lower_bound(vae, X, nsamples=nsamp, datasize=10 * T)
+    finally:
+        torch.randn = real_randn
+    assert len(noise) == 1
+    elbo.backward()
+    out = {'X': npy(X), 'noise': npy(noise[0]), 'nsamples': np.array(nsamp),
+           'datasize': np.array(10 * T), 'elbo': np.asarray(float(elbo))}
+    for name, p in vae.named_parameters():
+        out['nn.' + name] = npy(p)
+        out['nngrad.' + name] = npy(p.grad)
+    dump_params(out, 'init', vae)
+    dump_acc(out, 'acc', vae, elbo._acc_stats)
+    dump_graph(out, 'graph', vae.prior.graph)
+    save('g14_hmm_vae_step', out)
 
 
 def g15_features():
@@ -741,6 +800,10 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'notebooks':
         g16_notebooks()
         sys.exit(0)
+    if len(sys.argv) > 1:                    # python make_golden.py g13_fp64 g14_hmm_vae ...
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1_g3_g11()
     g4(torch.float64, '')
     g4(torch.float32, '_f32')
@@ -752,5 +815,7 @@ if __name__ == '__main__':
     g_graph()
     g_pickles()
     g14_vae()
+    g14_hmm_vae()
+    g13_fp64()
     g15_features()
     g16_notebooks()

@@ -154,26 +154,20 @@ def test_cli_accumulate_update_decode_reproduce_the_reference_run(tmp_path):
     assert (c1, c2) == (2, 1)
     assert_close(float(e1 + e2), g['free_elbo'], 2e-5)
     new = pickle.load(open(tmp_path / '1.mdl', 'rb'))
-    # fp64 truth of the same float32 inputs: the same iteration with the model and the
-    # features in float64 (the fp64 path is pinned on the reference's fp64 goldens at
-    # 1e-9).  The float32 CLI run must be within 1e-5 of it, or within the error of
-    # the reference's own float32 run where float32 cannot do that.
+    # fp64 truth of the same float32 inputs: the same iteration run by the REFERENCE with
+    # the model and the features cast to float64 (golden g13_cli_reference_run_fp64,
+    # make_golden.py:g13_fp64).  The float32 CLI run must be within 1e-5 of it, or within
+    # the error of the reference's own float32 run where float32 cannot do that.
     from helpers import assert_within_f32_band
-    dataset = pickle.load(open(tmp_path / 'ds.pkl', 'rb'))
-    truth_model = compat.load(open(mdl, 'rb')).double().to('cuda')
-    arch = np.load(feats)
-    utts = [torch.from_numpy(arch[u]).double() for u in ('utt0', 'utt1', 'utt2')]
-    t_optim = beer.VBConjugateOptimizer(truth_model.mean_field_factorization(), 1.)
-    t_optim.init_step()
-    t_elbo = beer.accumulate_elbo(truth_model, utts, datasize=dataset.size)
-    assert_within_f32_band(float(e1 + e2), float(t_elbo), g['free_elbo'], 'free-loop ELBO')
-    t_elbo.backward()
-    t_optim.step()
-    for i, (p, q) in enumerate(zip(new.bayesian_parameters(), truth_model.bayesian_parameters())):
-        for name, ref in zip(p.posterior._std_params_def, std_params(g, f'updated.p{i}.posterior')):
+    g64 = load_golden('g13_cli_reference_run_fp64')
+    assert_within_f32_band(float(e1 + e2), float(g64['free_elbo']), g['free_elbo'], 'free-loop ELBO')
+    for i, p in enumerate(new.bayesian_parameters()):
+        for name, ref, truth in zip(p.posterior._std_params_def,
+                                    std_params(g, f'updated.p{i}.posterior'),
+                                    std_params(g64, f'updated.p{i}.posterior')):
             got = getattr(p.posterior.params, name).cpu().numpy()
-            truth = getattr(q.posterior.params, name).cpu().numpy().reshape(ref.shape)
-            assert_within_f32_band(got.reshape(ref.shape), truth, ref, f'updated p{i}.{name}')
+            assert_within_f32_band(got.reshape(ref.shape), truth.reshape(ref.shape), ref,
+                                   f'updated p{i}.{name}')
     assert torch.load(tmp_path / 'optim.pth') == {'lrate': 1., 'update_count': 1}
     out = run(['hmm', 'decode', '--per-frame', mdl, str(tmp_path / 'ds.pkl')])
     lines = dict(l.split(' ', 1) for l in out.strip().split('\n'))

@@ -608,6 +608,59 @@ def test_full_size_properties_linearity_and_monotone_elbo():
         optim.step()
 
 
+def test_config2_full_size_one_million_frames():
+    '''BASELINE config 2 at its FULL size -- K = 256 full covariance, D = 40, 1,000,000
+    float32 frames in 8192-frame utterances, the kernels bench.py times.  The oracle cannot
+    replay a million frames in seconds; what it can do is a strided 65,536-frame subset:
+    the per-frame log-normalisers of those frames out of the FULL-size launch are held to
+    the oracle's, and so are the statistics accumulated from the subset alone (same
+    kernels, same model).  Over the whole: the counts add up to the number of frames, and
+    the statistics of the million equal the sum over its two halves.'''
+    from beer_amd import kernels
+    K, D, T = 256, 40, 1_000_000
+    g = torch.Generator(device='cpu').manual_seed(5)
+    means = torch.randn(K, D, generator=g) * 2
+    X = (means[torch.randint(0, K, (T,), generator=g)] + torch.randn(T, D, generator=g)).to(DEV)
+    torch.manual_seed(11)
+    ns = beer.NormalSet.create(X[:65536].mean(0).cpu(), X[:65536].var(0).cpu().diag(), size=K,
+                               prior_strength=1., noise_std=1., cov_type='full')
+    model = beer.Mixture.create(ns, prior_strength=1.).to(DEV)
+    p0, p1 = params_of(model)
+    as64 = lambda d: [npy(getattr(d.params, n)).astype(np.float64) for n in d._std_params_def]
+    post, prior = as64(p0.posterior), as64(p0.prior)
+    (w_post,), (w_prior,) = as64(p1.posterior), as64(p1.prior)
+    lengths = [8192] * (T // 8192) + [T % 8192]
+    whole = beer.accumulate_elbo(model, (X, lengths), datasize=T)
+    acc = npy(whole._acc_stats[p0]).astype(np.float64)
+    # (i) conservation over the million
+    assert abs(-2 * acc[:, -2].sum() - T) <= 1e-6 * T
+    assert_close(npy(whole._acc_stats[p1])[-1], float(T), 1e-6)
+    # (ii) linearity: two halves
+    half = 61 * 8192
+    a = beer.accumulate_elbo(model, (X[:half], [8192] * 61), datasize=T)
+    b = beer.accumulate_elbo(model, (X[half:], lengths[61:]), datasize=T)
+    assert_close(npy(a._acc_stats[p0]).astype(np.float64) + npy(b._acc_stats[p0]).astype(np.float64),
+                 acc, 1e-6, 'halves')
+    # (iii) the full-size E-step launch against the oracle on a strided subset of its frames
+    st = beer.FrameStats(X, 'full')
+    E, lw = ns.means_precisions.natural_form(), model._log_weights().view(1, K)
+    assert kernels.packed_path_ok(st, K, 'full')
+    ln, _ = kernels.mixture_estep_packed(st, E, lw, K, 'full')
+    idx = torch.arange(0, T, T // 65536, device=DEV)[:65536]
+    Xs = X[idx].contiguous()
+    truth = _oracle_gmm_chunked(npy(Xs).astype(np.float64), 'full', post, prior, w_post, w_prior)
+    per_frame = npy(ln[idx, 0]).astype(np.float64)
+    assert_close(per_frame.sum(), truth['value'] + truth['kl'], 1e-6, 'sum of log-normalisers')
+    # ... and the statistics the same kernels accumulate from that subset
+    sub = beer.accumulate_elbo(model, (Xs, [65536]), datasize=65536)
+    ref32 = _oracle_gmm_chunked(npy(Xs), 'full', [a_.astype(np.float32) for a_ in post],
+                                [a_.astype(np.float32) for a_ in prior], w_post.astype(np.float32),
+                                w_prior.astype(np.float32))
+    assert_close(float(sub), truth['value'], 1e-5, 'elbo (subset)')
+    assert_within_f32_band(npy(sub._acc_stats[p0]).astype(np.float64), truth['acc_normal'],
+                           ref32['acc_normal'], 'acc normal (subset)')
+
+
 def test_empty_and_ragged_inputs():
     g = load_golden('g09_elbo_bookkeeping')
     model = build_mixture(g)

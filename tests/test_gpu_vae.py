@@ -106,6 +106,36 @@ def test_vae_step_against_reference(monkeypatch):
                      1e-9, f'acc p{i}')
 
 
+def test_hmm_vae_step_at_config4_dimensions(monkeypatch):
+    '''BASELINE config 4's model at its own dimensions -- D = 40, 64-dimensional latent
+    variable, HMM prior with diagonal Gaussians -- one ELBO + backward with the reference's
+    weights and noise: value, gradients of every network weight, accumulated statistics
+    (golden g14_hmm_vae_step; vae.py:63-89, hmm.py:73-100).'''
+    import beer_amd as beer
+    from beer_amd.dists import normaldiag
+    from gpu_helpers import build_hmm, npy, params_of, tt
+    g = load_golden('g14_hmm_vae_step')
+    X = tt(g['X'])
+    Dx, Dz = X.shape[1], g['noise'].shape[-1]
+    assert (Dx, Dz) == (40, 64)
+    enc = beer.nnet.ResidualFeedForwardNet(dim_in=Dx, nblocks=2, block_width=32)
+    dec = beer.nnet.ResidualFeedForwardNet(dim_in=Dz, nblocks=2, block_width=32)
+    vae = beer.VAE(build_hmm(g), enc, dec, reference_broadcast=True).double().to('cuda')
+    with torch.no_grad():
+        for name, p in vae.named_parameters():
+            p.copy_(tt(g['nn.' + name]))
+    monkeypatch.setattr(normaldiag, '_randn', lambda *a, **k: tt(g['noise']))
+    elbo = beer.evidence_lower_bound(vae, X, nsamples=int(g['nsamples']),
+                                     datasize=int(g['datasize']))
+    assert abs(float(elbo) - float(g['elbo'])) <= 1e-9 * abs(float(g['elbo']))
+    elbo.backward()
+    for name, p in vae.named_parameters():
+        assert_close(npy(p.grad), g['nngrad.' + name], 1e-7, 'grad ' + name)
+    for i, p in enumerate(params_of(vae)):
+        assert_close(npy(elbo._acc_stats[p]).reshape(g[f'acc.p{i}'].shape), g[f'acc.p{i}'],
+                     1e-9, f'acc p{i}')
+
+
 def test_vae_trains():
     'HMM-VAE (config 4 shape, reduced): the ELBO improves over a few epochs.'
     import beer_amd as beer
