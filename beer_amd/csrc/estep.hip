@@ -331,7 +331,7 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
     void* w_buf = comp_resps;
     // group-aligned shapes on every arithmetic; any G on the split path when only the
     // log-normalisers are wanted (groups padded to a power of two)
-    const bool aligned = beer_mfma::supported_llh(D, S, G) &&
+    const bool aligned = beer_mfma::supported_llh(D, S, G, sizeof(T)) &&
                          ws_bytes >= beer_mfma::estep_workspace_bytes(sizeof(T), cov, D, S, G);
     const bool padded = sizeof(T) == 4 && !exact && !comp_resps &&
                         beer_mfma::supported_llh_split(D, S, G) &&
@@ -354,7 +354,7 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
         // gfx950 matrix-core path: GEMM + (grouped) softmax fused, one kernel
         if (sizeof(T) == 4 && !exact &&
             ws_bytes >= beer_mfma::estepx_workspace_bytes(cov, D, S, G) &&
-            (padded || beer_mfma::supported_llh(D, S, G)))
+            (padded || beer_mfma::supported_llh(D, S, G, sizeof(T))))
             return beer_mfma::estep_bf16x3(cov, nframes, D, S, G, (const float*)X,
                                            (const float*)expT, (const float*)logw,
                                            (float*)comp_resps, (float*)log_norm, llh_sum, ws,
@@ -441,8 +441,8 @@ int accumulate_launch(int cov, int64_t nframes, int D, int S, int G, const void*
     // the bf16x3 accumulation takes packed tiles -- beer_pack_resps +
     // beer_normal_accumulate_packed -- whose size depends on T)
     (void)exact;
-    if (cr && ws && beer_mfma::supported_acc(D, S * G) &&
-        ws_bytes >= beer_mfma::acc_workspace_bytes(cov, D, S * G)) {
+    if (cr && ws && beer_mfma::supported_acc(D, S * G, sizeof(T)) &&
+        ws_bytes >= beer_mfma::acc_workspace_bytes(cov, D, S * G, sizeof(T))) {
         return sizeof(T) == 4
                    ? beer_mfma::acc_f32(cov, nframes, D, S, G, (const float*)X, (const float*)cr,
                                         (const float*)sr, acc, ws, ws_bytes, s)
@@ -492,8 +492,7 @@ size_t beer_estep_workspace_bytes(int dtype, int cov, int D, int S, int G) {
 
 size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G) {
     if (cov < 0 || cov > 2) return 0;
-    (void)dtype;
-    return beer_mfma::acc_workspace_bytes(cov, D, S * G);
+    return beer_mfma::acc_workspace_bytes(cov, D, S * G, (dtype & ~BEER_EXACT) == BEER_F64 ? 8 : 4);
 }
 
 int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G, const void* X,
@@ -531,7 +530,7 @@ int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float*
 }
 
 int beer_mixtureset_packed_supported(int cov, int D, int S, int G) {
-    return cov >= 0 && cov <= 2 && D >= 1 && D <= 64 && S >= 1 && G >= 1 &&
+    return cov >= 0 && cov <= 2 && D >= 1 && D <= beer_mfma::kMaxDimF32 && S >= 1 && G >= 1 &&
            beer_mfma::supported_llh_packed_sets(cov, D, S, G) &&
            beer_mfma::supported_acc_sets(cov, D, S, G);
 }
@@ -589,7 +588,7 @@ int beer_mixtureset_accumulate_fused(int cov, int64_t T, int D, int S, int G, co
 }
 
 size_t beer_packed_resps_bytes(int64_t T, int D, int K) {
-    return T < 0 || D < 1 || D > 64 || K < 1 ? 0 : beer_mfma::packed_resps_bytes(T, D, K);
+    return T < 0 || D < 1 || D > beer_mfma::kMaxDimF32 || K < 1 ? 0 : beer_mfma::packed_resps_bytes(T, D, K);
 }
 
 size_t beer_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int K) {
@@ -599,7 +598,7 @@ size_t beer_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int K) 
 
 int beer_pack_resps(int64_t T, int D, int S, int G, const float* X, const float* comp_resps,
                     const float* state_resps, void* packed_resps, void* stream) {
-    BEER_REQUIRE(T >= 0 && D >= 1 && D <= 64 && S >= 1 && G >= 1 && (S * G) % 4 == 0);
+    BEER_REQUIRE(T >= 0 && D >= 1 && D <= beer_mfma::kMaxDimF32 && S >= 1 && G >= 1 && (S * G) % 4 == 0);
     BEER_REQUIRE(T == 0 || (X && comp_resps && packed_resps));
     return beer_mfma::pack_resps(T, D, S, G, X, comp_resps, state_resps, packed_resps,
                                  as_stream(stream));

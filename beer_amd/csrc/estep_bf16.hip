@@ -248,7 +248,7 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ X, int64_t 
                                            float* __restrict__ xw) {
     const int Dp = 4 * d4_of(D);
     if ((D & 3) == 0) {
-        constexpr int LPR = 64 / FW, NPC = 16 / LPR;          // pieces per lane (D <= 64)
+        constexpr int LPR = 64 / FW, NPC = kMaxDimF32 / 4 / LPR;   // pieces per lane
         const int C4 = D >> 2, r = lane & (FW - 1), h = lane / FW;
         const int64_t f = fb + r;
         const bool valid = f < nframes;
@@ -581,36 +581,37 @@ inline int xt_pieces(int D) { return (xt_rows(D) * kAxXS * 4 + kPiece - 1) / kPi
 __global__ __launch_bounds__(256) void xt_image_kernel(int64_t nframes, int D, int NX,
                                                        const float* __restrict__ X,
                                                        float* __restrict__ Xt) {
-    __shared__ float tile[kAxFT * 65];
+    constexpr int LD = kMaxDimF32 + 1;            // odd: the transposed reads spread over the banks
+    __shared__ float tile[kAxFT * LD];
     const int64_t tau = blockIdx.x, t0 = tau * kAxFT;
     const int rows = (int)(nframes - t0 < kAxFT ? nframes - t0 : kAxFT);
     for (int e = threadIdx.x; e < rows * D; e += 256) {
         const int f = e / D, d = e - f * D;
-        tile[f * 65 + d] = X[t0 * D + e];
+        tile[f * LD + d] = X[t0 * D + e];
     }
     __syncthreads();
     float* out = Xt + tau * ((size_t)NX * (kPiece / 4));
     for (int e = threadIdx.x; e < NX * (kPiece / 4); e += 256) {
         const int row = e / kAxXS, col = e - row * kAxXS;
         float v = 0.f;
-        if (row < D) v = col < rows ? tile[col * 65 + row] : 0.f;
+        if (row < D) v = col < rows ? tile[col * LD + row] : 0.f;
         else if (row == D) v = 1.f;
         __builtin_nontemporal_store(v, out + e);
     }
 }
 
-template <int NX, bool SR>
+template <bool SR>
 __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
-    int64_t nframes, int D, int K, int nslab, const float* __restrict__ Xt,
+    int64_t nframes, int D, int K, int nslab, int NX, const float* __restrict__ Xt,
     const unsigned* __restrict__ Rimg, const int* __restrict__ tab,
     int64_t frames_per_block, double* __restrict__ Sp, int gx, int gy, int gz,
     const float* __restrict__ Gt, int lgG) {
     constexpr int MC = kAxMC, NQ = kAxNQ, WAVES = kAxWaves, NB = 2;
     static_assert(16 * MC == kPackedComps && kAxFT == kPackedFrames, "the packed image is this kernel's LDS tile");
     constexpr int plane = kPackedPlaneWords * 4;                  // bytes of one piece plane
-    constexpr int NKB = NX * (kPiece / 1024) + NP * plane / 1024; // 1 KiB DMA blocks per tile
-    constexpr int buf_bytes = NKB * 1024, r_off = NX * kPiece;
-    constexpr int g_base = NB * buf_bytes;                        // SR: NB x 4 KiB of gamma^T
+    // NX = 4 KiB pieces of the transposed frame tile (1 .. 7: D <= 96)
+    const int r_off = NX * kPiece, buf_bytes = r_off + NP * plane;
+    const int g_base = NB * buf_bytes;                            // SR: NB x 4 KiB of gamma^T
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -674,7 +675,7 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
     // branch chain per piece cost scalar registers; their spill reloads came with
     // s_waitcnt vmcnt(0), which also waits for the DMA issued just before -- 16 serialised
     // memory round trips per tile, 46 k cycles where the MFMAs need 12 k.)
-    static_assert((NX * (kPiece / 1024)) % WAVES == 0 && (NP * plane / 1024) % WAVES == 0,
+    static_assert((kPiece / 1024) % WAVES == 0 && (NP * plane / 1024) % WAVES == 0,
                   "regions are whole rounds of the waves");
     const char* xsrc = reinterpret_cast<const char*>(Xt) + wave * 1024 + lane * 16;
     const char* rsrc = reinterpret_cast<const char*>(Rimg) + wave * 1024 + lane * 16;
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
         const char* xs = xsrc + tau * (size_t)(NX * kPiece);
         const char* rs = rsrc + (tau * nblk + by) * (size_t)(NP * plane);
         char* dst = smem + buf * buf_bytes + wave * 1024;
-#pragma unroll
+#pragma unroll 1
         for (int n = 0; n < NX * (kPiece / 1024) / WAVES; ++n)
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const u4*>(xs + n * (WAVES * 1024)),
                                              (lds_ptr)(dst + n * (WAVES * 1024)), 16, 0, 0);
@@ -1365,12 +1366,12 @@ template __global__ void llhx_kernel<16, 4, 4, true, false, false>(
 template __global__ void llhx_kernel<16, 2, 1, false, true, true>(
     int64_t, int, int, int, int, int, int, int, const float*, const u4*, const int*, float*, float*,
     double*, float*, int, int, int, const float*);
-template __global__ void accx_kernel<3, false>(int64_t, int, int, int, const float*, const unsigned*,
-                                               const int*, int64_t, double*, int, int, int,
-                                               const float*, int);
-template __global__ void accx_kernel<3, true>(int64_t, int, int, int, const float*, const unsigned*,
-                                              const int*, int64_t, double*, int, int, int,
-                                              const float*, int);
+template __global__ void accx_kernel<false>(int64_t, int, int, int, int, const float*, const unsigned*,
+                                            const int*, int64_t, double*, int, int, int,
+                                            const float*, int);
+template __global__ void accx_kernel<true>(int64_t, int, int, int, int, const float*, const unsigned*,
+                                           const int*, int64_t, double*, int, int, int,
+                                           const float*, int);
 template __global__ void accf_kernel<4, 6, true, 8, 5>(int64_t, int, int, int, int, int, int, int,
                                                        const float*, const u4*, const int*,
                                                        const float*, const float*, int64_t, double*,
@@ -1402,7 +1403,7 @@ size_t packed_resps_bytes(int64_t nframes, int D, int K) {
 int pack_resps(int64_t nframes, int D, int S, int G, const float* X, const float* R,
                const float* SR, void* packed, hipStream_t s) {
     const int K = S * G;
-    if ((K & 3) || D < 1 || D > 64) return BEER_EINVAL;
+    if ((K & 3) || D < 1 || D > kMaxDimF32) return BEER_EINVAL;
     if (nframes == 0) return BEER_OK;
     unsigned* tiles = reinterpret_cast<unsigned*>(packed);
     const int64_t ntile = (nframes + kPackedFrames - 1) / kPackedFrames;
@@ -1547,8 +1548,7 @@ size_t accx_workspace_bytes(int cov, int64_t nframes, int D, int K) {
 // ... with state posteriors multiplied in by the accumulation kernel: S states of G
 // components (a power of two, 8 .. 128)
 bool supported_acc_sets(int cov, int D, int S, int G) {
-    return S >= 1 && G >= 8 && G <= 128 && (G & (G - 1)) == 0 && supported_acc(D, S * G) &&
-           xt_pieces(D) <= 5;
+    return S >= 1 && G >= 8 && G <= 128 && (G & (G - 1)) == 0 && supported_acc(D, S * G);
 }
 inline int acc_sets_spad(int S, int G) {
     return (S * G + kPackedComps - 1) / kPackedComps * (kPackedComps / G);
@@ -1620,26 +1620,16 @@ int acc_bf16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, co
                        (SR ? 2 * 4096 : 0);
     const int64_t nyz = ((int64_t)gy * gz + 7) / 8 * 8;
     const dim3 grid((unsigned)(nyz * gx));
-#define BEER_ACCX(NX_, SR_)                                                                      \
+#define BEER_ACCX(SR_)                                                                           \
     do {                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(accx_kernel<NX_, SR_>),          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(accx_kernel<SR_>),               \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-        hipLaunchKernelGGL((accx_kernel<NX_, SR_>), grid, dim3(64 * kAxWaves), lds, s, nframes,  \
-                           D, K, nslab, Xt, reinterpret_cast<const unsigned*>(Rimg), tab, fpb,   \
-                           Sp, gx, gy, (int)gz, Gt, lgG);                                        \
+        hipLaunchKernelGGL((accx_kernel<SR_>), grid, dim3(64 * kAxWaves), lds, s, nframes, D, K, \
+                           nslab, NX, Xt, reinterpret_cast<const unsigned*>(Rimg), tab, fpb, Sp, \
+                           gx, gy, (int)gz, Gt, lgG);                                            \
     } while (0)
-    if (SR) {
-        if (NX == 1) BEER_ACCX(1, true);
-        else if (NX == 2) BEER_ACCX(2, true);
-        else if (NX == 3) BEER_ACCX(3, true);
-        else if (NX == 4) BEER_ACCX(4, true);
-        else BEER_ACCX(5, true);
-    }
-    else if (NX == 1) BEER_ACCX(1, false);
-    else if (NX == 2) BEER_ACCX(2, false);
-    else if (NX == 3) BEER_ACCX(3, false);
-    else if (NX == 4) BEER_ACCX(4, false);
-    else BEER_ACCX(5, false);
+    if (SR) BEER_ACCX(true);
+    else BEER_ACCX(false);
 #undef BEER_ACCX
     BEER_LAUNCH_CHECK();
     const int64_t total = (int64_t)K * stats_dim(cov, D);

@@ -9,10 +9,15 @@
 
 namespace beer_mfma {
 
-bool supported_llh(int D, int S, int G);
-bool supported_acc(int D, int K);
+// Largest feature dimension of the matrix-core paths: float32 96 (the accumulation kernels
+// keep two tiles of transposed frames + responsibilities in a CU's 160 KiB of LDS),
+// float64 64.  Beyond: the generic kernels of estep.hip.
+constexpr int kMaxDimF32 = 96, kMaxDimF64 = 64;
+inline int max_dim(size_t elem) { return elem == 8 ? kMaxDimF64 : kMaxDimF32; }
+bool supported_llh(int D, int S, int G, size_t elem = 4);
+bool supported_acc(int D, int K, size_t elem = 4);
 size_t estep_workspace_bytes(size_t elem, int cov, int D, int S, int G);
-size_t acc_workspace_bytes(int cov, int D, int K);
+size_t acc_workspace_bytes(int cov, int D, int K, size_t elem = 4);
 
 // fp32 models on the bf16 matrix pipes (estep_bf16.hip): every fp32 operand is held
 // exactly as three bf16 pieces, the six leading partial products of every

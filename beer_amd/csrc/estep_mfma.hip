@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 2 : 1) void acc_kernel(
 
     // Staging registers: the next tile is loaded from global memory while the
     // MFMAs of the current tile run, then written to the other LDS buffer.
-    constexpr int XPT = kAccFT * 64 / kThreads;                     // D <= 64
+    constexpr int XPT = kAccFT * (sizeof(T) == 8 ? kMaxDimF64 : kMaxDimF32) / kThreads;
     constexpr int RPT = kAccFT * RC / 4 / kThreads;                 // vec4 per thread
     const int xcount = kAccFT * D;
     T xreg[XPT];
@@ -426,7 +426,7 @@ int estep_impl(int cov, int64_t nframes, int D, int S, int G, const T* X, const 
                const T* logw, T* resps, T* log_norm, double* llh_sum, void* ws, size_t ws_bytes,
                hipStream_t s) {
     const int K = S * G;
-    if (!supported_llh(D, S, G) || ws_bytes < estep_workspace_bytes(sizeof(T), cov, D, S, G))
+    if (!supported_llh(D, S, G, sizeof(T)) || ws_bytes < estep_workspace_bytes(sizeof(T), cov, D, S, G))
         return BEER_EINVAL;
     const int NT = nt_for(S, K), nchunks = nchunks_for(S, K);
     const int nsp = nslab_padded(cov, D);
@@ -469,7 +469,8 @@ template <typename T>
 int acc_impl(int cov, int64_t nframes, int D, int S, int G, const T* X, const T* R, const T* SR,
              double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
     const int K = S * G;
-    if (!supported_acc(D, K) || ws_bytes < acc_workspace_bytes(cov, D, K)) return BEER_EINVAL;
+    if (!supported_acc(D, K, sizeof(T)) || ws_bytes < acc_workspace_bytes(cov, D, K, sizeof(T)))
+        return BEER_EINVAL;
     const int nslab = nslab_of(cov, D), nq = nslab * 4;
     double* Sp = reinterpret_cast<double*>(ws);
     int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) +
@@ -519,31 +520,31 @@ int acc_impl(int cov, int64_t nframes, int D, int S, int G, const T* X, const T*
 
 }  // namespace
 
-bool supported_llh(int D, int S, int G) {
+bool supported_llh(int D, int S, int G, size_t elem) {
     // 8-bit slab-table fields: Dp + 4 <= 255.  GMM (S = 1): any K in [16, 256]
     // (a whole softmax row inside one wave's accumulators, padded to 64 / 128 /
     // 256 columns).  Mixture set (S > 1): G a power of two <= 256 so that the
     // groups align with lanes / column tiles; K is cut into chunks of 256.
-    if (D < 1 || D > 64 || S < 1 || G < 1) return false;
+    if (D < 1 || D > max_dim(elem) || S < 1 || G < 1) return false;
     const int K = S * G;
     if (S == 1) return K >= 16 && K <= 256;
     return K >= 16 && G <= 256 && (G & (G - 1)) == 0;
 }
 
-bool supported_acc(int D, int K) {
-    return D >= 1 && D <= 64 && K >= 16 && K % 4 == 0;
+bool supported_acc(int D, int K, size_t elem) {
+    return D >= 1 && D <= max_dim(elem) && K >= 16 && K % 4 == 0;
 }
 
 size_t estep_workspace_bytes(size_t elem, int cov, int D, int S, int G) {
-    if (!supported_llh(D, S, G)) return 0;
+    if (!supported_llh(D, S, G, elem)) return 0;
     const int nslab = nslab_padded(cov, D), K = S * G;
     return (size_t)(((size_t)nchunks_for(S, K) * nslab * 64 * nt_for(S, K) * elem + 255) / 256 *
                     256) +
            (size_t)nslab * sizeof(int) + 256;
 }
 
-size_t acc_workspace_bytes(int cov, int D, int K) {
-    if (!supported_acc(D, K)) return 0;
+size_t acc_workspace_bytes(int cov, int D, int K, size_t elem) {
+    if (!supported_acc(D, K, elem)) return 0;
     const int nslab = nslab_of(cov, D);
     return (size_t)(((size_t)K * nslab * 4 * sizeof(double) + 255) / 256 * 256) +
            (size_t)nslab * sizeof(int) + 256;

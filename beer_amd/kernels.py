@@ -181,38 +181,43 @@ class WideResps:
     log-sum-exps, `block_resps` [T, S2] = exp(block_lse - log_norm) the blocks' shares,
     and within a block r = exp(l - block_lse) is recomputed from the frames
     (diagonal / isotropic) or held as packed tiles (full covariance).  The softmax
-    over K components is the two-level softmax of these.  `dense()` gives the
-    [T, K] matrix.'''
+    over K components is the two-level softmax of these.  When K is not S2 * G2 the
+    last block is filled up with phantom components of weight exp(-1e30) = 0
+    (`exp_stats` / `log_weights` are the padded arrays, `K` the real count).
+    `dense()` gives the [T, K] matrix.'''
 
     def __init__(self, stats, exp_stats, log_weights, split, cov_type, block_lse, block_resps,
-                 packed):
+                 packed, K=None):
         self.stats, self.exp_stats, self.log_weights = stats, exp_stats, log_weights
         self.split, self.cov_type = split, cov_type
         self.block_lse, self.block_resps, self.packed = block_lse, block_resps, packed
+        self.K = split[0] * split[1] if K is None else K
 
     def dense(self):
         S2, G2 = self.split
         within = self.packed.unpack() if self.packed is not None else mixtureset_estep(
             self.stats, self.exp_stats, self.log_weights, S2, G2, self.cov_type)[1]
-        return within * self.block_resps.repeat_interleave(G2, dim=1)
+        return (within * self.block_resps.repeat_interleave(G2, dim=1))[:, :self.K]
 
 
 def wide_mixture_split(stats, K, cov_type):
-    '''(S2, G2), K = S2 * G2, when a mixture of K > 256 components over `stats` runs
-    on the matrix-core kernels as S2 blocks of G2 components (two-level softmax);
-    None otherwise (the generic kernels take it).'''
+    '''(S2, G2), S2 * G2 >= K, when a mixture of K > 256 components over `stats` runs on
+    the matrix-core kernels as S2 blocks of G2 components (two-level softmax); None
+    otherwise (small inputs, exact mode: the generic kernels take it).  An exact
+    factorisation is preferred; any other K gets its last block padded.'''
     st = _frames(stats)
     X = st.data
     if K <= 256 or st.scale != 1.0 or X.dtype != torch.float32 or not _hip.f32_fast_ok(X):
         return None
+    ok = (lambda S2, G2: packed_sets_ok(st, S2, G2, cov_type)) if cov_type == 'full' else \
+        (lambda S2, G2: fused_accumulate_ok(st, S2, G2, cov_type))
     first = -(-K // 256)
     for S2 in range(first, min(K // 8, first + 64) + 1):
-        if K % S2:
-            continue
-        G2 = K // S2
-        ok = packed_sets_ok(st, S2, G2, cov_type) if cov_type == 'full' else \
-            fused_accumulate_ok(st, S2, G2, cov_type)
-        if ok:
+        if K % S2 == 0 and ok(S2, K // S2):
+            return S2, K // S2
+    for G2 in ((128, 64) if cov_type == 'full' else (256, 128)):
+        S2 = -(-K // G2)
+        if ok(S2, G2):
             return S2, G2
     return None
 
@@ -223,14 +228,22 @@ def wide_mixture_estep(stats, exp_stats, log_weights, K, cov_type, split):
     S2, G2 = split
     st = _frames(stats)
     E = _hip.on_device(exp_stats, st.data.dtype)
-    lw = _hip.on_device(log_weights, st.data.dtype).reshape(S2, G2)
+    lw = _hip.on_device(log_weights, st.data.dtype).reshape(-1)
+    pad = S2 * G2 - K
+    if pad:
+        # phantom components: any finite parameters, log-weight -1e30 (exp underflows to an
+        # exact 0: their responsibilities and statistics are zeros; not -inf, which the
+        # multi-piece products would turn into 0 * inf)
+        E = torch.cat([E, E[:1].expand(pad, -1)]).contiguous()
+        lw = torch.cat([lw, torch.full((pad,), -1.0e30, dtype=lw.dtype, device=lw.device)])
+    lw = lw.reshape(S2, G2)
     packed = None
     if cov_type == 'full':
         lse, packed = mixtureset_estep_packed(st, E, lw, S2, G2, cov_type)
     else:
         lse, _ = mixtureset_estep(st, E, lw, S2, G2, cov_type, want_resps=False)
     log_norm, share = dense_softmax(lse, None, 1, S2)
-    return log_norm, WideResps(st, E, lw, split, cov_type, lse, share, packed)
+    return log_norm, WideResps(st, E, lw, split, cov_type, lse, share, packed, K=K)
 
 
 def pack_resps(stats, comp_resps, state_resps, S, G):
@@ -279,12 +292,18 @@ def normal_accumulate(stats, comp_resps, state_resps, S, G, cov_type, acc=None):
         # one mixture, K > 256: the blocks' shares play the state posteriors' part
         wr = comp_resps
         S2, G2 = wr.split
-        if state_resps is not None or S2 * G2 != K or wr.stats.data.data_ptr() != X.data_ptr():
+        if state_resps is not None or wr.K != K or wr.stats.data.data_ptr() != X.data_ptr():
             raise ValueError('factored responsibilities: one mixture, the frames they came from')
+        # (a padded last block: the phantom components' rows are zeros, dropped here)
+        full = acc if S2 * G2 == K else torch.zeros(S2 * G2, Q, dtype=torch.float64, device=X.device)
         if wr.packed is not None:
-            return normal_accumulate(st, wr.packed, wr.block_resps, S2, G2, cov_type, acc=acc)
-        return mixtureset_accumulate_fused(st, wr.exp_stats, wr.log_weights, wr.block_lse,
-                                           wr.block_resps, S2, G2, cov_type, acc=acc)
+            normal_accumulate(st, wr.packed, wr.block_resps, S2, G2, cov_type, acc=full)
+        else:
+            mixtureset_accumulate_fused(st, wr.exp_stats, wr.log_weights, wr.block_lse,
+                                        wr.block_resps, S2, G2, cov_type, acc=full)
+        if full is not acc:
+            acc += full[:K]
+        return acc
     if isinstance(comp_resps, PackedResps) and state_resps is not None:
         # mixture set: the state posteriors are multiplied in by the kernel
         if tuple(comp_resps.shape) != (T, K) or not packed_sets_ok(st, S, G, cov_type):

@@ -904,7 +904,10 @@ def test_gmm_matrix_core_path_all_cov_types_vs_oracle(cov, dtype, tol, tol_stats
 
 @pytest.mark.parametrize('cov,K,D,split', [('full', 512, 40, (4, 128)), ('diagonal', 512, 40, (2, 256)),
                                             ('full', 320, 24, (5, 64)), ('diagonal', 500, 30, (2, 250)),
-                                            ('isotropic', 768, 16, (3, 256))])
+                                            ('isotropic', 768, 16, (3, 256)),
+                                            # no factorisation: the last block is padded
+                                            ('full', 300, 24, (3, 128)), ('diagonal', 523, 20, (3, 256)),
+                                            ('full', 257, 13, (3, 128))])
 def test_gmm_with_more_than_256_components_on_the_matrix_cores(cov, K, D, split):
     '''A float32 mixture of K > 256 components runs as blocks of components on the
     mixture-set kernels with a two-level softmax (kernels.wide_mixture_estep), through
@@ -952,6 +955,51 @@ def test_gmm_with_more_than_256_components_on_the_matrix_cores(cov, K, D, split)
     r = npy(wr.dense()).astype(np.float64)
     assert np.abs(r.sum(1) - 1).max() < 5e-5
     assert np.abs(r - truth['resps']).max() < 2e-4
+
+
+@pytest.mark.parametrize('cov,K,D', [('full', 64, 80), ('diagonal', 200, 96), ('full', 32, 72)])
+def test_matrix_core_paths_beyond_64_dimensions(cov, K, D):
+    '''Round 2 sent D > 64 to the generic VALU kernels; the float32 matrix-core kernels now
+    take D <= 96 (the reference has no such limit: beer/dists/normalwishart.py:30-38).
+    A mixture at D = 72 / 80 / 96 through accumulate_elbo: the packed E-step and the
+    packed accumulation are the calls that run (spied), and the results are the
+    oracle's.'''
+    from beer_amd import kernels
+    T = 17000
+    rng = np.random.RandomState(K + D)
+    means = rng.randn(K, D) * 2
+    Xn = (means[rng.randint(0, K, T)] + rng.randn(T, D) * (1 + .3 * rng.rand(D))).astype(np.float32)
+    X = torch.from_numpy(Xn)
+    torch.manual_seed(5)
+    var = X.var(0) if cov != 'full' else torch.diag(X.var(0))
+    ns = beer.NormalSet.create(X.mean(0), var, size=K, prior_strength=1., noise_std=1., cov_type=cov)
+    model = beer.Mixture.create(ns).to(DEV)
+    p0, p1 = params_of(model)
+    as64 = lambda d: [npy(getattr(d.params, n)).astype(np.float64) for n in d._std_params_def]
+    post, prior = as64(p0.posterior), as64(p0.prior)
+    (w_post,), (w_prior,) = as64(p1.posterior), as64(p1.prior)
+    truth = _oracle_gmm_chunked(Xn.astype(np.float64), cov, post, prior, w_post, w_prior)
+    f32 = lambda arrs: [a.astype(np.float32) for a in arrs]
+    ref32 = _oracle_gmm_chunked(Xn, cov, f32(post), f32(prior), w_post.astype(np.float32),
+                                w_prior.astype(np.float32))
+    calls = []
+    orig = kernels._hip.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    kernels._hip.call = spy
+    try:
+        elbo = beer.accumulate_elbo(model, (X.to(DEV), [T]), datasize=T)
+    finally:
+        kernels._hip.call = orig
+    assert 'beer_mixture_estep_packed' in calls and 'beer_normal_accumulate_packed' in calls
+    assert 'beer_mixtureset_estep' not in calls and 'beer_normal_accumulate' not in calls
+    assert_close(float(elbo), truth['value'], 1e-5, 'elbo')
+    assert_within_f32_band(npy(elbo._acc_stats[p0]).astype(np.float64), truth['acc_normal'],
+                           ref32['acc_normal'], 'acc normal')
+    assert_within_f32_band(npy(elbo._acc_stats[p1]).astype(np.float64), truth['acc_weights'],
+                           ref32['acc_weights'], 'acc weights')
 
 
 def test_m_step_in_one_launch():
