@@ -103,7 +103,6 @@ _gam = [c_i, c_i, c_p, c_p, c_p, c_p]
 SIGNATURES = {
     'beer_hip_version': [],
     'beer_hip_device_count': [],
-    'beer_hip_has_rocblas': [],
     'beer_mixtureset_packed_supported': [c_i, c_i, c_i, c_i],
     'beer_nw_expected_stats': _four, 'beer_nw_log_norm': _four, 'beer_nw_natural': _four,
     'beer_nw_from_natural': _from,

@@ -13,12 +13,8 @@
 // Reference restated: beer/dists/normalgamma.py:55-59 (llh = stats @ E[T]^T +
 // log base measure), beer/models/normalset.py:121-123 (resps^T @ stats).
 
-#include <mutex>
-#include <unordered_map>
-#include <dlfcn.h>
-#include <rocblas/rocblas.h>             // types and prototypes only: the library is dlopen'ed
-
 #include "common.h"
+#include "estep_tiles.h"                 // split3: a float32 pair as three words of bf16 pieces
 
 using namespace beer;
 
@@ -202,155 +198,247 @@ __global__ void suffstats_backward_kernel(int cov, int64_t T_, int ns, int D,
 
 // ---------------------------------------------------------------------------
 // Large float32 products (full-covariance latent: Q = D*D + D + 2 in the
-// thousands) go to rocBLAS: plain GEMMs with a long inner or outer dimension,
-// where the LDS-tiled VALU kernel above runs at 25 TFLOP/s and the library's
-// fp32 MFMA kernels at several times that.  The library is looked up at run time
-// by its soname (inside a PyTorch process that is the copy PyTorch already
-// loaded); without it, or for small / fp64 problems, the kernel above runs.
-// Products are exact fp32 with fp32 accumulation; sums over frames are cut into
-// kChunk-frame partial sums that are added in fp64.
+// thousands): plain GEMMs with a long inner or outer dimension, where the LDS-tiled
+// VALU kernel above runs at 25 TFLOP/s.  They run on the matrix cores in the same
+// arithmetic as the E-step (estep_bf16.hip): every float32 operand held exactly as
+// three bf16 pieces, the six leading partial products per element on
+// v_mfma_f32_16x16x32_bf16, float32 accumulation -- float32 products to rounding
+// level, no library underneath.
+//
+// One kernel serves the three products, C[m,n] = sum_k A(m,k) B(k,n) with arbitrary
+// strides.  A workgroup (4 waves) owns a tile of 16 WM WAVES_M x 16 WN WAVES_N
+// outputs and walks the inner dimension 32 at a time: every thread fetches quads of
+// A and B (four consecutive k of one row; consecutive lanes along whichever index is
+// contiguous in memory) one step ahead into registers, splits them ONCE into pieces
+// and writes three bf16 planes to LDS (rows of 32 + 8 bf16: 16-byte chunks at an odd
+// stride, conflict-free for the fragment reads); a wave reads its WM + WN fragments
+// per plane and issues 6 WM WN MFMAs.
+//
+// Sums over frames (ATOMIC): the matrix core truncates when it aligns its addends
+// (estep_bf16.hip, "chains"), so a chain of positive products drifts low by about
+// 2^-25 per 32 frames.  A workgroup therefore sums at most kG3Chain frames (grid.z
+// splits them) and adds its float32 sums to the fp64 accumulator with atomics.
 // ---------------------------------------------------------------------------
-constexpr int kBlasMinQ = 512;
-constexpr int64_t kBlasMinT = 8192;
-constexpr int kChunk = 4096;
+constexpr int kBigMinQ = 512;
+constexpr int64_t kBigMinT = 8192;
+constexpr int kG3K = 32, kG3LD = 40;        // bf16 per LDS row (32 of them padding-free + 8)
+constexpr int kG3Chain = 4096;
 
-struct RocBlas {
-    decltype(&rocblas_create_handle) create = nullptr;
-    decltype(&rocblas_set_stream) set_stream = nullptr;
-    decltype(&rocblas_sgemm) sgemm = nullptr;
-    decltype(&rocblas_sgemm_strided_batched) sgemm_sb = nullptr;
-    rocblas_handle handle = nullptr;
-    bool ok = false;
-    RocBlas() {
-        if (const char* e = getenv("BEER_NO_ROCBLAS")) { if (e[0] == '1') return; }
-        void* lib = dlopen("librocblas.so.5", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) return;
-        create = reinterpret_cast<decltype(create)>(dlsym(lib, "rocblas_create_handle"));
-        set_stream = reinterpret_cast<decltype(set_stream)>(dlsym(lib, "rocblas_set_stream"));
-        sgemm = reinterpret_cast<decltype(sgemm)>(dlsym(lib, "rocblas_sgemm"));
-        sgemm_sb = reinterpret_cast<decltype(sgemm_sb)>(
-            dlsym(lib, "rocblas_sgemm_strided_batched"));
-        ok = create && set_stream && sgemm && sgemm_sb;
+inline bool big_shape(int64_t T_, int Q, int K) {
+    return Q >= kBigMinQ && T_ >= kBigMinT && K >= 1;
+}
+
+typedef unsigned int g3u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int g3u2 __attribute__((ext_vector_type(2)));
+typedef __bf16 g3bf8 __attribute__((ext_vector_type(8)));
+
+// AK / BK: A / B is contiguous along k (else along its row index m / n).  Rows past
+// M and columns past N are fetched from the last valid one (their outputs are never
+// stored); only the last, partial step of the inner dimension checks k.
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool AK, bool BK, bool ATOMIC>
+__global__ __launch_bounds__(256, 2) void gemm3_kernel(
+    int64_t M, int64_t N, int64_t Kd, const float* __restrict__ A, int sam, int sak,
+    const float* __restrict__ B, int sbk, int sbn, void* __restrict__ Cout,
+    const float* __restrict__ row_scale, float beta, int64_t k_per_block,
+    const float* __restrict__ a_scale, int a_group, int a_ld) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    constexpr int TMx = 16 * WM * WAVES_M, TNx = 16 * WN * WAVES_N;
+    constexpr int QA = TMx * 8 / 256, QB = TNx * 8 / 256;          // quads per thread and step
+    __shared__ __attribute__((aligned(16))) unsigned short As[3][TMx][kG3LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3][TNx][kG3LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int64_t m0 = (int64_t)blockIdx.x * TMx, n0 = (int64_t)blockIdx.y * TNx;
+    const int64_t kb = (int64_t)blockIdx.z * k_per_block;
+    const int64_t ke = Kd < kb + k_per_block ? Kd : kb + k_per_block;
+    const int ask = AK ? 1 : sak, bsk = BK ? 1 : sbk;
+
+    // quad i of this thread: row of the tile, first k of the step, element offset of
+    // (row, k = 0) from the tile's corner (32 bits: the host checks the strides)
+    int arow[QA], ak[QA], brow[QB], bk[QB];
+    unsigned aoff[QA], boff[QB], soff[QA];
+#pragma unroll
+    for (int i = 0; i < QA; ++i) {
+        const int idx = tid + 256 * i;
+        if (AK) { ak[i] = (idx & 7) * 4; arow[i] = idx >> 3; }
+        else { arow[i] = idx % TMx; ak[i] = (idx / TMx) * 4; }
+        const int64_t m = m0 + arow[i] < M ? m0 + arow[i] : M - 1;
+        aoff[i] = (unsigned)(m - m0) * (unsigned)sam;
+        soff[i] = a_scale ? (unsigned)(m / a_group) : 0u;
     }
-};
-// One rocBLAS handle per stream, bound to it once (a handle carries its stream and
-// its workspace: sharing one between streams, re-pointed per call, would make
-// concurrent callers race on it).  Handles live as long as the process.
-RocBlas* blas_for(hipStream_t s) {
-    static RocBlas lib;                        // the library's entry points, no handle
-    if (!lib.ok) return nullptr;
-    static std::mutex mu;
-    static std::unordered_map<hipStream_t, RocBlas*> per_stream;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = per_stream.find(s);
-    if (it != per_stream.end()) return it->second;
-    RocBlas* rb = new RocBlas(lib);
-    if (lib.create(&rb->handle) != rocblas_status_success ||
-        lib.set_stream(rb->handle, s) != rocblas_status_success) {
-        delete rb;
-        rb = nullptr;
+#pragma unroll
+    for (int i = 0; i < QB; ++i) {
+        const int idx = tid + 256 * i;
+        if (BK) { bk[i] = (idx & 7) * 4; brow[i] = idx >> 3; }
+        else { brow[i] = idx % TNx; bk[i] = (idx / TNx) * 4; }
+        const int64_t n = n0 + brow[i] < N ? n0 + brow[i] : N - 1;
+        boff[i] = (unsigned)(n - n0) * (unsigned)sbn;
     }
-    per_stream[s] = rb;
-    return rb;
-}
-inline bool blas_shape(int64_t T_, int Q, int K) {
-    return Q >= kBlasMinQ && T_ >= kBlasMinT && T_ < (int64_t)1 << 31 && K >= 1;
+    float pa[QA][4], pb[QB][4];
+    auto fetch = [&](int64_t k0) {
+        const float* __restrict__ Ab = A + m0 * sam + k0 * ask;
+        const float* __restrict__ Bb = B + n0 * sbn + k0 * bsk;
+        const float* __restrict__ Sb = a_scale ? a_scale + k0 * a_ld : nullptr;
+        if (k0 + kG3K <= ke) {
+#pragma unroll
+            for (int i = 0; i < QA; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pa[i][j] = Ab[aoff[i] + (unsigned)((ak[i] + j) * ask)];
+            if (a_scale) {
+#pragma unroll
+                for (int i = 0; i < QA; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        pa[i][j] *= Sb[soff[i] + (unsigned)((ak[i] + j) * a_ld)];
+            }
+#pragma unroll
+            for (int i = 0; i < QB; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pb[i][j] = Bb[boff[i] + (unsigned)((bk[i] + j) * bsk)];
+        } else {
+            const int last = (int)(ke - 1 - k0);
+#pragma unroll
+            for (int i = 0; i < QA; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = ak[i] + j, kc = k < last ? k : last;
+                    float v = Ab[aoff[i] + (unsigned)(kc * ask)];
+                    if (a_scale) v *= Sb[soff[i] + (unsigned)(kc * a_ld)];
+                    pa[i][j] = k <= last ? v : 0.f;
+                }
+#pragma unroll
+            for (int i = 0; i < QB; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = bk[i] + j, kc = k < last ? k : last;
+                    const float v = Bb[boff[i] + (unsigned)(kc * bsk)];
+                    pb[i][j] = k <= last ? v : 0.f;
+                }
+        }
+    };
+    auto put = [&]() {
+#pragma unroll
+        for (int i = 0; i < QA; ++i) {
+            unsigned lo[3], hi[3];
+            beer_mfma::split3(pa[i][0], pa[i][1], lo);
+            beer_mfma::split3(pa[i][2], pa[i][3], hi);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                *reinterpret_cast<g3u2*>(&As[q][arow[i]][ak[i]]) = g3u2{lo[q], hi[q]};
+        }
+#pragma unroll
+        for (int i = 0; i < QB; ++i) {
+            unsigned lo[3], hi[3];
+            beer_mfma::split3(pb[i][0], pb[i][1], lo);
+            beer_mfma::split3(pb[i][2], pb[i][3], hi);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                *reinterpret_cast<g3u2*>(&Bs[q][brow[i]][bk[i]]) = g3u2{lo[q], hi[q]};
+        }
+    };
+
+    beer_mfma::f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = beer_mfma::f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fi = lane & 15, fg = lane >> 4;
+    if (kb < ke) fetch(kb);
+    for (int64_t k0 = kb; k0 < ke; k0 += kG3K) {
+        __syncthreads();                       // the previous step's fragments are read
+        put();
+        __syncthreads();
+        if (k0 + kG3K < ke) fetch(k0 + kG3K);
+        // smallest products first; with (B fragment, A fragment) as the MFMA's (first,
+        // second) operand a lane holds C[m = tile row fi][n = 4 fg + e]
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+        g3u4 af[WM][3], bf[WN][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                af[i][q] = *reinterpret_cast<const g3u4*>(&As[q][(wm * WM + i) * 16 + fi][fg * 8]);
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                bf[j][q] = *reinterpret_cast<const g3u4*>(&Bs[q][(wn * WN + j) * 16 + fi][fg * 8]);
+        }
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(g3bf8, bf[j][PB[pr]]),
+                        __builtin_bit_cast(g3bf8, af[i][PA[pr]]), acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int64_t m = m0 + (wm * WM + i) * 16 + fi;
+        if (m >= M) continue;
+        const float sc = row_scale ? row_scale[m] : 1.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int64_t nb = n0 + (wn * WN + j) * 16 + fg * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (nb + e >= N) continue;
+                if (ATOMIC)
+                    atomicAdd(reinterpret_cast<double*>(Cout) + m * N + nb + e,
+                              (double)acc[i][j][e]);
+                else
+                    reinterpret_cast<float*>(Cout)[m * N + nb + e] = sc * acc[i][j][e] + beta;
+            }
+        }
+    }
 }
 
-__global__ void fill_kernel(int64_t n, float v, float* __restrict__ out) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n) out[idx] = v;
-}
-// out[t,k] = w[t,k] * (g ? g[t] : 1) * (sr ? sr[t, k / G] : 1)
-__global__ void scale_rows_kernel(int64_t T_, int K, int G, const float* __restrict__ w,
-                                  const float* __restrict__ g, const float* __restrict__ sr,
-                                  float* __restrict__ out) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= T_ * K) return;
-    const int64_t t = idx / K;
-    const int k = (int)(idx - t * K);
-    float v = w[idx];
-    if (g) v *= g[t];
-    if (sr) v *= sr[t * (K / G) + k / G];
-    out[idx] = v;
-}
-// acc[i] += sum_b part[b][i]  (fp64)
-__global__ void add_partials_kernel(int64_t n, int nb, const float* __restrict__ part,
-                                    double* __restrict__ acc) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    double sacc = 0.0;
-    for (int b = 0; b < nb; ++b) sacc += (double)part[(size_t)b * n + idx];
-    acc[idx] += sacc;
+// Do the strides fit the kernel's 32-bit offsets inside a tile?
+inline bool gemm3_fits(int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t a_ld) {
+    const int64_t lim = (int64_t)1 << 22;             // x 128 rows (or 32 k) x 4 bytes < 2^31
+    return sam < lim && sak < lim && sbk < lim && sbn < lim && a_ld < lim;
 }
 
-// rocBLAS is column-major: a row-major [r, c] array is its [c, r] matrix with ld = c.
-// out[T,K] = stats[T,Q] @ E[K,Q]^T + base
-int blas_llh(RocBlas* rb, int64_t T_, int Q, int K, const float* stats, const float* E,
-             double base, float* out, hipStream_t s) {
-    const int64_t n = T_ * K;
-    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n,
-                       (float)base, out);
+// C [M, N] float32 = row_scale[m] * (A B) + beta, or (acc64) acc64 [M, N] += A B
+template <bool AK, bool BK>
+int gemm3(int64_t M, int64_t N, int64_t Kd, const float* A, int64_t sam, int64_t sak,
+          const float* B, int64_t sbk, int64_t sbn, float* C, double* acc64,
+          const float* row_scale, double beta, const float* a_scale, int a_group, int a_ld,
+          hipStream_t s) {
+#define BEER_G3(WM_, WN_, WVM, WVN)                                                            \
+    do {                                                                                       \
+        constexpr int TMx = 16 * WM_ * WVM, TNx = 16 * WN_ * WVN;                              \
+        const int64_t gx = (M + TMx - 1) / TMx, gy = (N + TNx - 1) / TNx;                      \
+        if (acc64) {                                                                           \
+            /* frames over grid.z: chains of at most kG3Chain frames, and among those the  */ \
+            /* split that leaves the fewest idle workgroup slots (2 per CU) in the last round */\
+            const int64_t min_z = (Kd + kG3Chain - 1) / kG3Chain, slots = 512;                 \
+            int64_t gz = min_z, best = INT64_MAX;                                              \
+            for (int64_t z = min_z; z <= 2 * min_z || z * gx * gy <= 2 * slots; ++z) {         \
+                if (z * kG3K > Kd && z > min_z) break;                                         \
+                const int64_t cost = ((z * gx * gy + slots - 1) / slots) * ((Kd + z - 1) / z); \
+                if (cost < best) { best = cost; gz = z; }                                      \
+            }                                                                                  \
+            int64_t kpb = (Kd + gz - 1) / gz;                                                  \
+            kpb = (kpb + kG3K - 1) / kG3K * kG3K;                                              \
+            gz = (Kd + kpb - 1) / kpb;                                                         \
+            hipLaunchKernelGGL((gemm3_kernel<WM_, WN_, WVM, WVN, AK, BK, true>),               \
+                               dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(256), 0, s,\
+                               M, N, Kd, A, (int)sam, (int)sak, B, (int)sbk, (int)sbn,         \
+                               (void*)acc64, row_scale, 0.f, kpb, a_scale, a_group, a_ld);     \
+        } else {                                                                               \
+            hipLaunchKernelGGL((gemm3_kernel<WM_, WN_, WVM, WVN, AK, BK, false>),              \
+                               dim3((unsigned)gx, (unsigned)gy, 1), dim3(256), 0, s, M, N, Kd, \
+                               A, (int)sam, (int)sak, B, (int)sbk, (int)sbn, (void*)C,         \
+                               row_scale, (float)beta, Kd, a_scale, a_group, a_ld);            \
+        }                                                                                      \
+    } while (0)
+    if (M <= 64) BEER_G3(4, 2, 1, 4);           // 64 x 128
+    else if (N <= 64) BEER_G3(2, 4, 4, 1);      // 128 x 64
+    else BEER_G3(4, 4, 2, 2);                   // 128 x 128
+#undef BEER_G3
     BEER_LAUNCH_CHECK();
-    const float one = 1.f;
-    return rb->sgemm(rb->handle, rocblas_operation_transpose, rocblas_operation_none, K, (int)T_,
-                     Q, &one, E, Q, stats, Q, &one, out, K) == rocblas_status_success
-               ? BEER_OK : BEER_EINVAL;
-}
-// out[T,Q] = g_t * sum_k w[t,k] E[k,q]
-int blas_backward(RocBlas* rb, int64_t T_, int K, int Q, const float* w, const float* g,
-                  const float* E, float* out, hipStream_t s) {
-    float* wg = nullptr;
-    const int64_t n = T_ * K;
-    if (g) {
-        if (hipMallocAsync(reinterpret_cast<void**>(&wg), (size_t)n * sizeof(float), s) !=
-            hipSuccess)
-            return BEER_EINVAL;
-        hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                           T_, K, 1, w, g, (const float*)nullptr, wg);
-    }
-    const float one = 1.f, zero = 0.f;
-    const rocblas_status st =
-        rb->sgemm(rb->handle, rocblas_operation_none, rocblas_operation_none, Q, (int)T_, K, &one,
-                  E, Q, g ? wg : w, K, &zero, out, Q);
-    if (wg) (void)hipFreeAsync(wg, s);
-    return st == rocblas_status_success ? BEER_OK : BEER_EINVAL;
-}
-// acc[K,Q] += sum_t w[t,k] sr[t, k / G] stats[t,q]
-int blas_accumulate(RocBlas* rb, int64_t T_, int K, int Q, int G, const float* w,
-                    const float* sr, const float* stats, double* acc, hipStream_t s) {
-    const int nfull = (int)(T_ / kChunk), rest = (int)(T_ - (int64_t)nfull * kChunk);
-    const int nb = nfull + (rest ? 1 : 0);
-    const int64_t n = T_ * K, kq = (int64_t)K * Q;
-    float* buf = nullptr;                       // [joint weights T*K (if sr)] [partials nb*K*Q]
-    const size_t wj_floats = sr ? (size_t)n : 0;
-    if (hipMallocAsync(reinterpret_cast<void**>(&buf),
-                       (wj_floats + (size_t)nb * kq) * sizeof(float), s) != hipSuccess)
-        return BEER_EINVAL;
-    const float* wj = w;
-    if (sr) {
-        hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                           T_, K, G, w, (const float*)nullptr, sr, buf);
-        wj = buf;
-    }
-    float* part = buf + wj_floats;
-    const float one = 1.f, zero = 0.f;
-    rocblas_status st = rocblas_status_success;
-    // P_b [K,Q] (row-major) = wj_b^T stats_b  ==  col-major [Q,K] = stats_b^T[Q,Tb] * wj_b[Tb,K]
-    if (nfull)
-        st = rb->sgemm_sb(rb->handle, rocblas_operation_none, rocblas_operation_transpose, Q, K,
-                          kChunk, &one, stats, Q, (rocblas_stride)kChunk * Q, wj, K,
-                          (rocblas_stride)kChunk * K, &zero, part, Q, (rocblas_stride)kq, nfull);
-    if (st == rocblas_status_success && rest)
-        st = rb->sgemm(rb->handle, rocblas_operation_none, rocblas_operation_transpose, Q, K, rest,
-                       &one, stats + (size_t)nfull * kChunk * Q, Q, wj + (size_t)nfull * kChunk * K,
-                       K, &zero, part + (size_t)nfull * kq, Q);
-    if (st == rocblas_status_success)
-        hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)((kq + 255) / 256)), dim3(256), 0, s,
-                           kq, nb, part, acc);
-    (void)hipFreeAsync(buf, s);
-    return st == rocblas_status_success ? BEER_OK : BEER_EINVAL;
+    return BEER_OK;
 }
 
 // Full covariance: the upstream gradient of a frame holds a D x D block G, and
@@ -408,10 +496,9 @@ int dense_llh_launch(int64_t T_, int Q, int K, const void* stats, const void* ex
     BEER_REQUIRE(T_ >= 0 && Q >= 1 && K >= 1 && stats && expT && out);
     if (T_ == 0) return BEER_OK;
     // out[t,k] = sum_q stats[t,q] expT[k,q] + base
-    if (sizeof(T) == 4 && blas_shape(T_, Q, K))
-        if (RocBlas* rb = blas_for(as_stream(stream)))
-            return blas_llh(rb, T_, Q, K, (const float*)stats, (const float*)expT, base,
-                            (float*)out, as_stream(stream));
+    if (sizeof(T) == 4 && big_shape(T_, Q, K) && gemm3_fits(Q, 1, 1, Q, 0))
+        return gemm3<true, true>(T_, K, Q, (const float*)stats, Q, 1, (const float*)expT, 1, Q, (float*)out,
+                     nullptr, nullptr, base, nullptr, 1, 0, as_stream(stream));
     return gemm_plain<T>(T_, K, Q, (const T*)stats, Q, 1, (const T*)expT, 1, Q, (T*)out, nullptr,
                          base, as_stream(stream));
 }
@@ -422,10 +509,9 @@ int dense_backward_launch(int64_t T_, int K, int Q, const void* w, const void* g
     BEER_REQUIRE(T_ >= 0 && Q >= 1 && K >= 1 && w && expT && out);
     if (T_ == 0) return BEER_OK;
     // out[t,q] = g_t * sum_k w[t,k] expT[k,q]
-    if (sizeof(T) == 4 && blas_shape(T_, Q, K))
-        if (RocBlas* rb = blas_for(as_stream(stream)))
-            return blas_backward(rb, T_, K, Q, (const float*)w, (const float*)g,
-                                 (const float*)expT, (float*)out, as_stream(stream));
+    if (sizeof(T) == 4 && big_shape(T_, Q, K) && gemm3_fits(K, 1, Q, 1, 0))
+        return gemm3<true, false>(T_, Q, K, (const float*)w, K, 1, (const float*)expT, Q, 1, (float*)out,
+                     nullptr, (const float*)g, 0.0, nullptr, 1, 0, as_stream(stream));
     return gemm_plain<T>(T_, Q, K, (const T*)w, K, 1, (const T*)expT, Q, 1, (T*)out, (const T*)g,
                          0.0, as_stream(stream));
 }
@@ -436,10 +522,9 @@ int dense_accumulate_launch(int64_t T_, int K, int Q, int G, const void* w, cons
     BEER_REQUIRE(T_ >= 0 && Q >= 1 && K >= 1 && G >= 1 && K % G == 0 && w && stats && acc);
     if (T_ == 0) return BEER_OK;
     // acc[k,q] += sum_t w[t,k] stats[t,q]; frames split over grid.z, fp64 atomics
-    if (sizeof(T) == 4 && blas_shape(T_, Q, K))
-        if (RocBlas* rb = blas_for(as_stream(stream)))
-            return blas_accumulate(rb, T_, K, Q, G, (const float*)w, (const float*)sr,
-                                   (const float*)stats, acc, as_stream(stream));
+    if (sizeof(T) == 4 && big_shape(T_, Q, K) && gemm3_fits(1, K, Q, 1, K / G))
+        return gemm3<false, false>(K, Q, T_, (const float*)w, 1, K, (const float*)stats, Q, 1, nullptr, acc,
+                     nullptr, 0.0, (const float*)sr, G, K / G, as_stream(stream));
     const int gx = (K + TM - 1) / TM, gy = (Q + TN - 1) / TN;
     int64_t gz = (2048 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy);
     const int64_t max_z = (T_ + 255) / 256;
@@ -519,8 +604,6 @@ int suffstats_backward_launch(int cov, int64_t T_, int ns, int D, const void* X,
 }  // namespace
 
 extern "C" {
-
-int beer_hip_has_rocblas(void) { return blas_for(nullptr) ? 1 : 0; }
 
 int beer_dense_llh(int dtype, int64_t T, int Q, int K, const void* stats, const void* exp_stats,
                    double base, void* out, void* stream) {

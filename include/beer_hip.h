@@ -18,8 +18,7 @@
  *   - matrices are row-major and dense, no padding;
  *   - `stream` is a hipStream_t (0 = default stream); calls are asynchronous,
  *     never synchronise, never allocate device memory, keep no state between
- *     calls and are re-entrant per stream (one documented exception: the
- *     rocBLAS route of the statistics-in products, see beer_hip_has_rocblas);
+ *     calls and are re-entrant per stream;
  *   - return value: 0 on success, BEER_EINVAL for a bad argument, or
  *     -(hipError_t) if a launch failed.  Nothing throws.
  *   - `cov`: BEER_FULL / BEER_DIAG / BEER_ISO selects the layout of the
@@ -549,17 +548,11 @@ int beer_segment_sum(int dtype, int32_t nutt, const int64_t* frame_off,
  * phi(z) over the samples of the latent variable) instead of frames, and its
  * expected log-likelihood is differentiated w.r.t. them. */
 
-/* 1 when rocBLAS was found at run time (dlopen by soname): the float32
- * statistics-in products below with Q >= 512 and T >= 8192 then run on its fp32
- * MFMA GEMMs (exact fp32 products, fp32 accumulation, sums over frames in
- * 4096-frame partials added in fp64), everything else on the library's own
- * kernels.  These three calls are the one exception to the conventions at the
- * top: on the rocBLAS route they take temporaries from the stream-ordered
- * allocator (hipMallocAsync / hipFreeAsync on `stream`) and use one rocBLAS
- * handle per stream, created on the stream's first call and kept for the life
- * of the process (so they stay re-entrant per stream).  BEER_NO_ROCBLAS=1 in
- * the environment keeps them on the library's own kernels. */
-int beer_hip_has_rocblas(void);
+/* float32 products with Q >= 512 and T >= 8192 (full-covariance latent) run on
+ * the matrix cores in the E-step's bf16x3 arithmetic (float32 operands held
+ * exactly as three bf16 pieces, float32 accumulation; sums over frames in chains
+ * of 4096 frames, fp64 between workgroups); everything else, and fp64, on an
+ * LDS-tiled kernel that accumulates in fp64.  No library underneath. */
 
 /* out[t,k] = sum_q stats[t,q] * exp_stats[k,q] + base   -> [T, K]
  * (ConjugateLikelihood.__call__, beer/dists/normalgamma.py:55-59; base is the

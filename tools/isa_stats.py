@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """ISA statistics of the hot bf16x3 kernels (build container; no GPU needed).
 
-    python tools/isa_stats.py [extra hipcc flags ...]
+    python tools/isa_stats.py [other_source.hip] [extra hipcc flags ...]
 
 Compiles beer_amd/csrc/estep_bf16.hip with -DBEER_KERNEL_PROBE (only the hot kernels are
 instantiated) to assembly and prints, per kernel: registers, scratch, and for its
@@ -11,6 +11,8 @@ import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'beer_amd', 'csrc', 'estep_bf16.hip')
 OUT = '/tmp/isa_probe.s'
+if len(sys.argv) > 1 and sys.argv[1].endswith('.hip'):      # another source of the library
+    SRC = os.path.join(ROOT, 'beer_amd', 'csrc', sys.argv.pop(1))
 cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-mllvm',
        '-pragma-unroll-threshold=262144', '-Wno-unused-function', '-DBEER_KERNEL_PROBE',
        '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.dirname(SRC), '-S',
@@ -22,7 +24,7 @@ for f in re.split(r'\n\t\.globl\t', s)[1:]:
     if 'kernel' not in name or name.endswith('.kd'):
         continue
     dem = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip()
-    dem = dem.replace('beer_mfma::(anonymous namespace)::', '').replace('void ', '')
+    dem = dem.replace('beer_mfma::(anonymous namespace)::', '').replace('(anonymous namespace)::', '').replace('void ', '')
     dem = re.sub(r'\(.*', '', dem)
     lines = f.split('\n')
     meta = {k: re.search(r'\.%s:?\s+(\d+)' % k, f) for k in ('vgpr_count', 'agpr_count')}
