@@ -501,8 +501,23 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
         if (acc[0][0][0] == 1.2345f) log_norm[0] = 1.f;
         return;
     }
-    softmax_epilogue<float, NT, MT, GQ, PACKED, LNO>(acc, fb, nframes, kbase, K, S, G, gl, jw, i,
-                                                     g, lane, resps, log_norm, llh_sum, c0[0]);
+    if constexpr (LNO) {
+        // (jw == 4 by construction of the dispatch; gl = lanes per group, uniform)
+#define BEER_LN(GL_) lognorm_epilogue<NT, MT, GQ, GL_>(acc, fb, nframes, kbase, S, G, i, g, lane, \
+                                                       log_norm, llh_sum, c0[0])
+        switch (gl) {
+            case 1: BEER_LN(1); break;
+            case 2: BEER_LN(2); break;
+            case 4: BEER_LN(4); break;
+            case 8: BEER_LN(8); break;
+            default: BEER_LN(16); break;
+        }
+#undef BEER_LN
+    } else {
+        softmax_epilogue<float, NT, MT, GQ, PACKED, LNO>(acc, fb, nframes, kbase, K, S, G, gl, jw,
+                                                         i, g, lane, resps, log_norm, llh_sum,
+                                                         c0[0]);
+    }
 }
 
 // covariance type of the E-step being launched (the launch helpers below take the

@@ -506,4 +506,60 @@ __device__ __forceinline__ void softmax_epilogue(
     }
 }
 
+// The LNO epilogue of the float kernels on its own (mixture sets with G >= 4: a group
+// is 4 values of a lane x GL lanes): the log-normalisers [T, S] and their sum, nothing
+// else.  Everything that does not depend on the row -- the states of the lane's groups
+// (an integer division each), which lanes write, the row pointers -- is taken out of
+// the 16 MT x NT / 4 element loop, and the group width is a compile-time constant (the
+// generic epilogue above spends 6000 instructions per tile of 32 x 256 logits on
+// these, four times its arithmetic; the diagonal-covariance E-step was bound by it).
+template <int NT, int MT, int GQ, int GL>
+__device__ __forceinline__ void lognorm_epilogue(
+    f32x4 (&acc)[MT][NT], int64_t fb, int64_t nframes, int kbase, int S, int G, int i, int g,
+    int lane, float* __restrict__ log_norm, double* __restrict__ llh_sum, float shift) {
+    using M = Mma<float>;
+    constexpr int NG = NT / 4 / GQ;
+    int state[NG];
+    bool writes[NG];
+#pragma unroll
+    for (int tq = 0; tq < NG; ++tq) {
+        state[tq] = (kbase + 64 * tq * GQ + 4 * (i & ~(GL - 1))) / G;
+        writes[tq] = (i & (GL - 1)) == 0 && state[tq] < S;
+        if (!writes[tq]) state[tq] = 0;
+    }
+    double llh_local = 0.0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int64_t f = fb + m * 16 + M::row(g, r);
+            const bool ok = f < nframes;
+            float* row = log_norm + (ok ? f : 0) * S;
+            float rowsum = 0.f;
+#pragma unroll
+            for (int tq = 0; tq < NG; ++tq) {
+                float mx = acc[m][4 * tq * GQ][r];
+#pragma unroll
+                for (int c = 1; c < 4 * GQ; ++c) mx = M::mx(mx, acc[m][4 * tq * GQ + c][r]);
+                mx = group_max(mx, GL);
+                float sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4 * GQ; ++c) sum += M::exp_neg(acc[m][4 * tq * GQ + c][r] - mx);
+                sum = group_sum(sum, GL);
+                const float lse = (mx + M::log_sum(sum)) + shift;
+                if (ok && writes[tq]) {
+                    if (log_norm) row[state[tq]] = lse;
+                    rowsum += lse;
+                }
+            }
+            llh_local += (double)rowsum;
+        }
+    }
+    if (llh_sum) {
+        llh_local = wave_sum(llh_local);
+        if (lane == 0) atomicAdd(llh_sum, llh_local);
+    }
+}
+
 }  // namespace beer_mfma
