@@ -39,6 +39,9 @@
 #ifndef BEER_K2_ABL
 #define BEER_K2_ABL 0      // K2: 1 = no B fragments, 2 = and no A loads, 3 = and no atomics
 #endif
+#ifndef BEER_AF_ABL
+#define BEER_AF_ABL 0      // fused accumulation, bits: 1 no flush, 2 no normaliser / posterior loads, 4 frames staged once,
+#endif                     // 8 no exp / split, 16 no statistics B fragments, 32 no logit A fragments, 64 no tile skipping
 #ifndef BEER_K1_FENCE
 #define BEER_K1_FENCE 0    // K1: scheduling fence every n MFMAs of the hand-placed stream (0 = none)
 #endif
@@ -994,7 +997,12 @@ __global__ __launch_bounds__(256) void pack_resps_kernel(int64_t nframes, int K,
 constexpr int kAfXS = 36;                 // row stride (floats) of the transposed frame tile
 constexpr int kAfMaxFramesPerWave = 1024; // MFMA accumulations per sum: 32 (see kAxMaxFrames)
 
-template <int NTC, int NQT, bool G4, int WAVES, int kXP>
+// BLK: the states of a 64-component chunk are at most 4 consecutive ones (G >= 16): a
+// lane fetches the 4 normalisers or posteriors of one frame row in one go, ONE TILE
+// AHEAD (as it does the frames), parks them in LDS when their tile starts and the
+// exponentials read them from there -- instead of 16 four-byte gathers per lane whose
+// latency every tile waited for.
+template <int NTC, int NQT, bool G4, int WAVES, int kXP, bool BLK>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
     int64_t nframes, int D, int K, int S, int G, int Greal, int nk, int nslab,
     const float* __restrict__ X, const u4* __restrict__ Pall, const int* __restrict__ tab,
@@ -1022,8 +1030,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
     const int p_u4 = nk_used * NTC * kBlockU4;
     u4* Ps = reinterpret_cast<u4*>(smem);
     int* tabs = reinterpret_cast<int*>(Ps + p_u4);
-    float* xw = reinterpret_cast<float*>(tabs + (nk + 1) * 8) + wave * (FW * LD + xt_floats);
+    constexpr int kLs = BLK ? 2 * FW * 4 : 0;          // [ln | sr][row][4 states]
+    int* offs = tabs + (nk + 1) * 8;                   // [2 NQT][64 lanes]: see xa_off below
+    float* xw = reinterpret_cast<float*>(offs + 2 * NQT * 64) + wave * (FW * LD + xt_floats + kLs);
     float* xt = xw + FW * LD;
+    float* lsw = xt + xt_floats;
     {
         const u4* src = Pall + (size_t)by * nk * NTC * kBlockU4;
         for (int idx = tid; idx < p_u4; idx += NTHREADS) Ps[idx] = src[idx];
@@ -1060,14 +1071,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
             a = (t >> 16) ? b : (t & 0xff);
         }
     };
-    int xa_off[NQT], xb_off[NQT];
+    // offsets (floats, in the transposed tile) of the two factors of the lane's column of
+    // statistic tile uu: a lane-indexed table in LDS, read back where it is used (12
+    // registers that the next tile's frames now wait in)
+    if (wave == 0) {
 #pragma unroll
-    for (int uu = 0; uu < NQT; ++uu) {
-        int a, b;
-        factors(uu, a, b);
-        xa_off[uu] = (a < D ? a : (a == Dp ? D : D + 1)) * kAfXS + 4 * g;
-        xb_off[uu] = (b < D ? b : (b == Dp ? D : D + 1)) * kAfXS + 4 * g;
+        for (int uu = 0; uu < NQT; ++uu) {
+            int a, b;
+            factors(uu, a, b);
+            offs[(2 * uu) * 64 + lane] = (a < D ? a : (a == Dp ? D : D + 1)) * kAfXS + 4 * g;
+            offs[(2 * uu + 1) * 64 + lane] = (b < D ? b : (b == Dp ? D : D + 1)) * kAfXS + 4 * g;
+        }
     }
+    __syncthreads();
     // states of the lane's components (G4: one per block of 64 components)
     constexpr int NST = G4 ? 1 : 4;
     int st_of[QT][NST];
@@ -1078,6 +1094,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
             const int s0 = (kbase + 64 * q + 4 * i + j) / G;
             st_of[q][j] = s0 < S ? s0 : S - 1;
         }
+
+    // BLK: the 4 states fetched per row start at st0c; the lane's state is st0c + sidx
+    int st0c = 0, sidx = 0;
+    if (BLK) {
+        const int st0 = kbase / G < S ? kbase / G : S - 1;
+        st0c = st0 < S - 4 ? st0 : S - 4;
+        sidx = st_of[0][0] - st0c;
+    }
 
     f32x4 sacc[NTC][NQT];
 #pragma unroll
@@ -1113,87 +1137,34 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
     const int NPC = (C4 + 1) >> 1, lr = lane & 31, lh = lane >> 5;
     float* xw_l = xw + lr * LD + 4 * lh;                       // + 8 it
     float* xt_l = xt + 4 * lh * kAfXS + lr;                    // + (8 it + j) kAfXS
-    // frame tiles of this wave: tb + 32 (wave + WAVES n)
-    for (int64_t fb = tb + (int64_t)wave * FW; fb < te; fb += WAVES * FW) {
-        const int rows = (int)(te - fb < FW ? te - fb : FW);              // >= 1
-        // ---- the frame tile, row-major and transposed (wave-private LDS) ----
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-        f32x4 xv[kXP];
+    // The loads of a tile (frames; BLK: normalisers / posteriors) into registers, rows
+    // clamped to the block's last frame
+    f32x4 xv[kXP], lsv = f32x4{0, 0, 0, 0};
+    auto issue = [&](int64_t fbn) {
+        const int rows_n = (int)(te - fbn < FW ? te - fbn : FW);
+        const int64_t rown = fbn + (lr < rows_n ? lr : rows_n - 1);
         if (rows4) {
-            const f32x4* src = X4 + (fb + (lr < rows ? lr : rows - 1)) * C4;
+            const f32x4* src = X4 + rown * C4;
 #pragma unroll
             for (int it = 0; it < kXP; ++it) {
                 const int pc = lh + 2 * it;
                 xv[it] = src[pc < C4 ? pc : C4 - 1];
             }
-        } else {
-            const float* Xt = X + fb * D;
-            for (int idx = lane; idx < FW * D; idx += 64) {
-                const int r = idx / D, c = idx - r * D;
-                const float v = r < rows ? Xt[idx] : 0.f;
-                xw[r * LD + c] = v;
-                xt[c * kAfXS + r] = v;
-            }
         }
-        // the per-state normalisers and posteriors of the tile's rows, loaded now and
-        // used after the k-loop: (frame 16 m + 4 g + r, state of the lane's components)
-        // (unconditional loads on clamped rows, validity applied to constants: a select
-        // or a branch on the loaded value makes hipcc load and wait one at a time)
-        float nl2[QT][MT][4][NST], wg[QT][MT][4][NST];
-        {
-            const float* ln_t = log_norm + fb * S;
-            const float* sr_t = sr + fb * S;
+        if (BLK) {
+            const float* src = ((lh && sr) ? sr : log_norm) + rown * S + st0c;
 #pragma unroll
-            for (int q = 0; q < QT; ++q)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * m + 4 * g + r;
-                        const int rc = row < rows ? row : rows - 1;
-#pragma unroll
-                        for (int j = 0; j < NST; ++j) nl2[q][m][r][j] = ln_t[rc * S + st_of[q][j]];
-                    }
-            if (sr) {
-#pragma unroll
-                for (int q = 0; q < QT; ++q)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = 16 * m + 4 * g + r;
-                            const int rc = row < rows ? row : rows - 1;
-#pragma unroll
-                            for (int j = 0; j < NST; ++j) wg[q][m][r][j] = sr_t[rc * S + st_of[q][j]];
-                        }
-            } else {
-#pragma unroll
-                for (int q = 0; q < QT; ++q)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-#pragma unroll
-                            for (int j = 0; j < NST; ++j) wg[q][m][r][j] = 1.f;
-            }
+            for (int j = 0; j < 4; ++j) lsv[j] = src[j];
         }
-        // A tile none of whose frames gives the chunk's states any posterior contributes
-        // exactly nothing: skip it (alignment graphs: most of the model's states are
-        // absent from an utterance, their posteriors are exact zeros)
-        if (sr) {
-            float any = 0.f;
-#pragma unroll
-            for (int q = 0; q < QT; ++q)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int j = 0; j < NST; ++j)
-                            any = __builtin_fmaxf(any, __builtin_fabsf(wg[q][m][r][j]));
-            if (__builtin_amdgcn_ballot_w64(any != 0.f) == 0) continue;
-        }
+    };
+    const int64_t fb0 = tb + (int64_t)wave * FW;
+    if (fb0 < te) issue(fb0);
+    // frame tiles of this wave: tb + 32 (wave + WAVES n)
+    for (int64_t fb = fb0; fb < te; fb += WAVES * FW) {
+        const int rows = (int)(te - fb < FW ? te - fb : FW);              // >= 1
+        // ---- the frame tile, row-major and transposed (wave-private LDS) ----
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
         if (rows4) {
 #pragma unroll
             for (int it = 0; it < kXP; ++it) {
@@ -1205,6 +1176,106 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
                     for (int j = 0; j < 4; ++j) xt_l[(8 * it + j) * kAfXS] = v[j];
                 }
             }
+        } else {
+            const float* Xt = X + fb * D;
+            for (int idx = lane; idx < FW * D; idx += 64) {
+                const int r = idx / D, c = idx - r * D;
+                const float v = r < rows ? Xt[idx] : 0.f;
+                xw[r * LD + c] = v;
+                xt[c * kAfXS + r] = v;
+            }
+        }
+        // the per-state normalisers and posteriors of the tile's rows: (frame 16 m + 4 g
+        // + r, state of the lane's components)
+        float nl2[QT][MT][4][NST], wg[QT][MT][4][NST];
+        bool skip = false;
+        if (BLK) {
+            *reinterpret_cast<f32x4*>(lsw + (lh * FW + lr) * 4) = lsv;
+            // A tile none of whose frames gives the chunk's states any posterior
+            // contributes exactly nothing: skip it (alignment graphs: most of the model's
+            // states are absent from an utterance, their posteriors are exact zeros)
+            if (sr && !(BEER_AF_ABL & 64)) {
+                float any = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) any = __builtin_fmaxf(any, __builtin_fabsf(lsv[j]));
+                skip = __builtin_amdgcn_ballot_w64(lh == 1 && lr < rows && any != 0.f) == 0;
+            }
+            // the next tile's loads fly while this one is worked on
+            if (fb + WAVES * FW < te) issue(fb + WAVES * FW);
+            if (skip) continue;
+        } else {
+            // (unconditional loads on clamped rows, validity applied to constants: a select
+            // or a branch on the loaded value makes hipcc load and wait one at a time)
+            const float* ln_t = log_norm + fb * S;
+            const float* sr_t = sr + fb * S;
+#pragma unroll
+            for (int q = 0; q < QT; ++q)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * m + 4 * g + r;
+                        const int rc = row < rows ? row : rows - 1;
+#pragma unroll
+                        for (int j = 0; j < NST; ++j) {
+                            nl2[q][m][r][j] = ln_t[rc * S + st_of[q][j]];
+                            wg[q][m][r][j] = sr ? sr_t[rc * S + st_of[q][j]] : 1.f;
+                        }
+                    }
+            if (fb + WAVES * FW < te) issue(fb + WAVES * FW);
+            if (sr && !(BEER_AF_ABL & 64)) {
+                float any = 0.f;
+#pragma unroll
+                for (int q = 0; q < QT; ++q)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int j = 0; j < NST; ++j)
+                                any = __builtin_fmaxf(any, __builtin_fabsf(wg[q][m][r][j]));
+                if (__builtin_amdgcn_ballot_w64(any != 0.f) == 0) continue;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+
+        // ---- logits of 32 frames x 16 NTC components ----
+        f32x4 acc[MT][NTC];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int c = 0; c < NTC; ++c) acc[m][c] = f32x4{0, 0, 0, 0};
+        // (A fragments of a k-step are built right before its MFMAs: with two waves per
+        // SIMD the other wave's MFMAs cover the arithmetic, and a second set of fragments
+        // in flight cost 24 registers -- the ones the next tile's frames now wait in)
+        for (int s = 0; s < nk_used; ++s) {
+            AFrag cur;
+#pragma unroll
+            for (int hh = 0; hh < MT * 2; ++hh) make_half(s, hh % MT, hh / MT, cur);
+#pragma unroll
+            for (int c = 0; c < NTC; ++c) {
+                u4 bp[NP];
+#pragma unroll
+                for (int pq = 0; pq < NP; ++pq) bp[pq] = Pl[(s * NTC + c) * kBlockU4 + 64 * pq];
+                // (the products in the order of llhx_kernel: same roundings)
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m][c] = mfma_bf16(cur.w[kProdA[pr]][m], bp[kProdB[pr]], acc[m][c]);
+            }
+        }
+
+        if (BLK) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * m + 4 * g + r;
+                    nl2[0][m][r][0] = lsw[row * 4 + sidx];
+                    wg[0][m][r][0] = sr ? lsw[(FW + row) * 4 + sidx] : 1.f;
+                }
         }
         // rows past the end: weight 0, and a normaliser that keeps the exponential at 0
         // (0 x inf would be NaN)
@@ -1223,45 +1294,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
                         wg[q][m][r][j] *= mult;
                     }
             }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-
-        // ---- logits of 32 frames x 16 NTC components ----
-        f32x4 acc[MT][NTC];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int c = 0; c < NTC; ++c) acc[m][c] = f32x4{0, 0, 0, 0};
-        AFrag f0, f1;
-        auto kstep = [&](int s, const AFrag& cur, AFrag& nxt) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // a slice of the next k-step's A fragments (the table is padded by one k-step)
-#pragma unroll
-                for (int hh = q * MT * 2 / 4; hh < (q + 1) * MT * 2 / 4; ++hh)
-                    make_half(s + 1, hh % MT, hh / MT, nxt);
-#pragma unroll
-                for (int c = q * QT; c < (q + 1) * QT; ++c) {
-                    u4 bp[NP];
-#pragma unroll
-                    for (int pq = 0; pq < NP; ++pq) bp[pq] = Pl[(s * NTC + c) * kBlockU4 + 64 * pq];
-                    // (the products in the order of llhx_kernel: same roundings)
-#pragma unroll
-                    for (int pr = 0; pr < 6; ++pr)
-#pragma unroll
-                        for (int m = 0; m < MT; ++m)
-                            acc[m][c] = mfma_bf16(cur.w[kProdA[pr]][m], bp[kProdB[pr]], acc[m][c]);
-                }
-            }
-        };
-#pragma unroll
-        for (int hh = 0; hh < MT * 2; ++hh) make_half(0, hh % MT, hh / MT, f0);
-        // (only the k-steps that hold slabs: the image's padding to an even count is zeros)
-        for (int s = 0; s < nk_used; s += 2) {
-            kstep(s, f0, f1);
-            if (s + 1 < nk_used) kstep(s + 1, f1, f0);
-        }
-
         // ---- r sr = exp(l - log_norm) sr, split into the A fragments ----
         // A fragment of component tile nt: words 0, 1 = frames 4g..4g+3 of tile 0,
         // words 2, 3 = the same rows of tile 1
@@ -1277,12 +1309,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
                     // l - log_norm first (one rounding of a small difference), THEN the change
                     // of base: scaling l (|l| ~ 100) and log_norm separately by a rounded
                     // log2(e) left a systematic 4e-6 in r
-                    v[r] = __builtin_amdgcn_exp2f((acc[m][nt][r] + nl2[q][m][r][jj]) *
+                    v[r] = (BEER_AF_ABL & 8) ? acc[m][nt][r] + nl2[q][m][r][jj] + wg[q][m][r][jj] :
+                           __builtin_amdgcn_exp2f((acc[m][nt][r] + nl2[q][m][r][jj]) *
                                                   1.44269504088896340736f) *
                            wg[q][m][r][jj];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     unsigned w3[3];
+                    if (BEER_AF_ABL & 8) {
+                        w3[0] = __builtin_bit_cast(unsigned, v[2 * e]);
+                        w3[1] = __builtin_bit_cast(unsigned, v[2 * e + 1]);
+                        w3[2] = w3[0] ^ w3[1];
+                    } else
                     split3(v[2 * e], v[2 * e + 1], w3);
 #pragma unroll
                     for (int pq = 0; pq < NP; ++pq) ar[nt][pq][2 * m + e] = w3[pq];
@@ -1292,10 +1330,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
 
         // ---- statistics: sacc[c][uu] += A'(c) x B'(uu) ----
         auto gen_b = [&](int uu, u4 (&out)[NP]) {
-            const f32x4 xa0 = *reinterpret_cast<const f32x4*>(xt + xa_off[uu]);
-            const f32x4 xa1 = *reinterpret_cast<const f32x4*>(xt + xa_off[uu] + 16);
-            const f32x4 xb0 = *reinterpret_cast<const f32x4*>(xt + xb_off[uu]);
-            const f32x4 xb1 = *reinterpret_cast<const f32x4*>(xt + xb_off[uu] + 16);
+            const int xa_off = offs[(2 * uu) * 64 + lane], xb_off = offs[(2 * uu + 1) * 64 + lane];
+            const f32x4 xa0 = *reinterpret_cast<const f32x4*>(xt + xa_off);
+            const f32x4 xa1 = *reinterpret_cast<const f32x4*>(xt + xa_off + 16);
+            const f32x4 xb0 = *reinterpret_cast<const f32x4*>(xt + xb_off);
+            const f32x4 xb1 = *reinterpret_cast<const f32x4*>(xt + xb_off + 16);
             const f32x4 p0 = xa0 * xb0, p1 = xa1 * xb1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1311,7 +1350,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
 #pragma unroll
         for (int uu = 0; uu < NQT; ++uu) {
             const int cur = uu & 1;
-            if (uu + 1 < NQT) gen_b(uu + 1, bq[cur ^ 1]);
+            if (uu + 1 < NQT) {
+                if (BEER_AF_ABL & 16) {
+#pragma unroll
+                    for (int pq = 0; pq < NP; ++pq) bq[cur ^ 1][pq] = bq[cur][pq];
+                } else
+                gen_b(uu + 1, bq[cur ^ 1]);
+            }
 #pragma unroll
             for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
@@ -1321,6 +1366,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
     }
 
     // ---- flush: rows = components kbase + 64 (c / 4) + 4 (4 g + r) + c % 4 ----
+    if (BEER_AF_ABL & 1) {
+        float t = 0.f;
+#pragma unroll
+        for (int uu = 0; uu < NQT; ++uu)
+#pragma unroll
+            for (int c = 0; c < NTC; ++c) t += sacc[c][uu][0] + sacc[c][uu][1] + sacc[c][uu][2] + sacc[c][uu][3];
+        if (t == 1.2345f) Sp[0] = 1.0;
+        return;
+    }
 #pragma unroll
     for (int uu = 0; uu < NQT; ++uu) {
         const int q = 16 * uu + i;
@@ -1387,7 +1441,7 @@ template __global__ void accx_kernel<false>(int64_t, int, int, int, int, const f
 template __global__ void accx_kernel<true>(int64_t, int, int, int, int, const float*, const unsigned*,
                                            const int*, int64_t, double*, int, int, int,
                                            const float*, int);
-template __global__ void accf_kernel<4, 6, true, 8, 5>(int64_t, int, int, int, int, int, int, int,
+template __global__ void accf_kernel<4, 6, true, 8, 5, true>(int64_t, int, int, int, int, int, int, int,
                                                        const float*, const u4*, const int*,
                                                        const float*, const float*, int64_t, double*,
                                                        const float*);
@@ -1715,23 +1769,31 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
     fpb = (fpb + 32 * waves - 1) / (32 * waves) * (32 * waves);
     gz = (nframes + fpb - 1) / fpb;
     const int nk_used = (nslab + 7) / 8;
+    // (groups are padded to a multiple of 4: a lane's 4 components share their state.)
+    // The states of every 64-component chunk fit a block of 4 consecutive ones?
+    bool blk = S >= 4;
+    for (int c = 0; c < nchunks && blk; ++c) {
+        const int lo = c * 16 * NTC / G, hi = (c * 16 * NTC + 60) / G;
+        if ((hi < S ? hi : S - 1) - (lo < S ? lo : S - 1) > 3) blk = false;
+    }
     const size_t lds = (size_t)nk_used * NTC * kBlockU4 * 16 + (size_t)(nk + 1) * 8 * sizeof(int) +
-                       (size_t)waves * (32 * ld16_of(D) + (D + 2) * kAfXS) * sizeof(float);
+                       (size_t)2 * NQT * 64 * sizeof(int) +
+                       (size_t)waves * (32 * ld16_of(D) + (D + 2) * kAfXS + (blk ? 256 : 0)) *
+                           sizeof(float);
     const dim3 grid(xcd_grid(gz, nchunks, nchunks));
-    const bool g4 = (G % 4) == 0;
-#define BEER_ACCF(NTC_, NQT_, G4_, W_)                                                           \
+#define BEER_ACCF(NTC_, NQT_, W_, BLK_)                                                          \
     do {                                                                                         \
         constexpr int XP_ = NQT_ == 6 ? 5 : 8;      /* D <= 40 <=> C4 <= 10 <=> nq <= 96 */       \
         (void)hipFuncSetAttribute(                                                               \
-            reinterpret_cast<const void*>(accf_kernel<NTC_, NQT_, G4_, W_, XP_>),                \
+            reinterpret_cast<const void*>(accf_kernel<NTC_, NQT_, true, W_, XP_, BLK_>),         \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-        hipLaunchKernelGGL((accf_kernel<NTC_, NQT_, G4_, W_, XP_>), grid, dim3(64 * W_), lds, s, \
-                           nframes, D, K, S, G, Greal, nk, nslab, X,                             \
+        hipLaunchKernelGGL((accf_kernel<NTC_, NQT_, true, W_, XP_, BLK_>), grid, dim3(64 * W_),  \
+                           lds, s, nframes, D, K, S, G, Greal, nk, nslab, X,                     \
                            reinterpret_cast<const u4*>(P), tab, log_norm, sr, fpb, Sp, c0);      \
     } while (0)
-    if (NQT == 6) { if (g4) BEER_ACCF(4, 6, true, 8); else BEER_ACCF(4, 6, false, 8); }
-    else if (NQT == 9) { if (g4) BEER_ACCF(4, 9, true, 4); else BEER_ACCF(4, 9, false, 4); }
-    else { if (g4) BEER_ACCF(4, 10, true, 4); else BEER_ACCF(4, 10, false, 4); }
+    if (NQT == 6) { if (blk) BEER_ACCF(4, 6, 8, true); else BEER_ACCF(4, 6, 8, false); }
+    else if (NQT == 9) { if (blk) BEER_ACCF(4, 9, 4, true); else BEER_ACCF(4, 9, 4, false); }
+    else { if (blk) BEER_ACCF(4, 10, 4, true); else BEER_ACCF(4, 10, 4, false); }
 #undef BEER_ACCF
     BEER_LAUNCH_CHECK();
     const int64_t total = (int64_t)Kreal * stats_dim(cov, D);
