@@ -7,7 +7,7 @@ reference's attribute names (buffers `mean`, `scale`, ...; `means_precisions`,
 import importlib
 import pickle
 
-__all__ = ['load', 'loads', 'Unpickler', 'reference_aliases']
+__all__ = ['load', 'loads', 'load_npz', 'Unpickler', 'reference_aliases']
 
 _SEARCH = ('beer_amd.models', 'beer_amd.dists', 'beer_amd.graph', 'beer_amd.inference',
            'beer_amd.inference.objectives', 'beer_amd.cli.dataset', 'beer_amd.dists.expfam',
@@ -36,6 +36,36 @@ def loads(data):
     return load(io.BytesIO(data))
 
 
+def load_npz(path):
+    """{name: array} of an `.npz` archive whose object arrays may pickle `beer.*`
+    classes (the `alis.npz` of `beer hmm mkaligraph`): every member is read with
+    numpy's own header parser and, where it holds objects, unpickled by `Unpickler`
+    above -- no entry of `sys.modules` is touched, so a real `beer` package
+    imported elsewhere in the process (another thread, a CPU baseline) is never
+    shadowed."""
+    import zipfile
+    import numpy as np
+    from numpy.lib import format as npf
+    out = {}
+    with zipfile.ZipFile(path) as archive:
+        for member in archive.namelist():
+            name = member[:-4] if member.endswith('.npy') else member
+            with archive.open(member) as fp:
+                version = npf.read_magic(fp)
+                if version == (1, 0):
+                    shape, fortran, dtype = npf.read_array_header_1_0(fp)
+                elif version == (2, 0):
+                    shape, fortran, dtype = npf.read_array_header_2_0(fp)
+                else:
+                    raise ValueError(f'{path}:{member}: .npy format version {version}')
+                if dtype.hasobject:
+                    out[name] = Unpickler(fp).load()
+                else:
+                    data = np.frombuffer(fp.read(), dtype=dtype)
+                    out[name] = data.reshape(shape[::-1]).T if fortran else data.reshape(shape)
+    return out
+
+
 class _Alias:
     'Stand-in for a `beer.*` module: attribute lookups resolve in beer_amd.'
 
@@ -62,7 +92,9 @@ _REFERENCE_MODULES = (
 
 
 class reference_aliases:
-    '''Context manager: while active, pickles that name `beer.*` classes (e.g.
+    '''(Kept for callers that unpickle through third-party code; `load` / `load_npz`
+    need no aliasing and are what the command line uses.)
+    Context manager: while active, pickles that name `beer.*` classes (e.g.
     the object arrays inside an `alis.npz` written by the reference) resolve to
     beer_amd classes -- always, whether or not a `beer` package is installed next
     to beer_amd: the product path never hands its objects to the reference.  The

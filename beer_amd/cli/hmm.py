@@ -348,9 +348,7 @@ def _load_alis(path):
     written by the reference are remapped to beer_amd classes.'''
     if not path:
         return None
-    with compat.reference_aliases():
-        raw = np.load(path, allow_pickle=True)
-        return {key: raw[key] for key in raw.files}
+    return compat.load_npz(path)
 
 
 class accumulate:

@@ -40,8 +40,8 @@
 #define BEER_K2_ABL 0      // K2: 1 = no B fragments, 2 = and no A loads, 3 = and no atomics
 #endif
 #ifndef BEER_AF_ABL
-#define BEER_AF_ABL 0      // fused accumulation, bits: 1 no flush, 2 no normaliser / posterior loads, 4 frames staged once,
-#endif                     // 8 no exp / split, 16 no statistics B fragments, 32 no logit A fragments, 64 no tile skipping
+#define BEER_AF_ABL 0      // fused accumulation, bits: 1 no flush, 8 no exp / split, 16 no statistics B fragments,
+#endif                     // 32 no logit A fragments, 64 no tile skipping
 #ifndef BEER_K1_FENCE
 #define BEER_K1_FENCE 0    // K1: scheduling fence every n MFMAs of the hand-placed stream (0 = none)
 #endif
@@ -1375,21 +1375,43 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
         if (t == 1.2345f) Sp[0] = 1.0;
         return;
     }
+    // The WAVES waves of the workgroup hold sums over different frames of the same 64
+    // components: added up through LDS (the parameters' region, no longer needed; fp64)
+    // one statistic tile at a time, so that the fp64 image sees one atomic per
+    // workgroup and element instead of one per wave.
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);          // [WAVES][16 = c * 4 + r][64 lanes]
+    constexpr int EPT = 16 * 64 / NTHREADS;               // elements per thread and tile
+    static_assert(16 * 64 % NTHREADS == 0, "whole elements per thread");
+    int64_t dst_row[EPT];
+    int dst_i[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int el = tid + e * NTHREADS, j = el >> 6, ln = el & 63;
+        const int c = j >> 2, r = j & 3, gg = ln >> 4;
+        const int slot = kbase + 64 * (c >> 2) + 4 * (4 * gg + r) + (c & 3);
+        // slot -> component (padded slots of a group and slots past the end: none)
+        const int gi = slot % G;
+        dst_row[e] = slot < K && gi < Greal ? (int64_t)((slot / G) * Greal + gi) * nq : -1;
+        dst_i[e] = ln & 15;
+    }
 #pragma unroll
     for (int uu = 0; uu < NQT; ++uu) {
-        const int q = 16 * uu + i;
-        if (q >= nq) continue;
 #pragma unroll
         for (int c = 0; c < NTC; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int slot = kbase + 64 * (c >> 2) + 4 * (4 * g + r) + (c & 3);
-                // slot -> component (padded slots of a group and slots past the end: none)
-                const int gi = slot % G;
-                if (slot < K && gi < Greal)
-                    atomicAdd(Sp + (size_t)((slot / G) * Greal + gi) * nq + q,
-                              (double)sacc[c][uu][r]);
-            }
+            for (int r = 0; r < 4; ++r) red[(wave * 16 + c * 4 + r) * 64 + lane] = sacc[c][uu][r];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int el = tid + e * NTHREADS;
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) t += (double)red[w * 1024 + el];
+            const int q = 16 * uu + dst_i[e];
+            if (dst_row[e] >= 0 && q < nq) atomicAdd(Sp + dst_row[e] + q, t);
+        }
+        __syncthreads();
     }
 }
 

@@ -76,10 +76,23 @@ def mixtureset_estep(stats, exp_stats, log_weights, S, G, cov_type, labels=None,
     lab = None
     if labels is not None:
         lab = _hip.on_device(torch.as_tensor(labels)).to(torch.int64).contiguous()
-    _hip.call('beer_mixtureset_estep', _hip.dtype_code(X.dtype, exact),
-              _hip.COV_CODE[cov_type], T, D, S, G, _hip.ptr(X), _hip.ptr(E), _hip.ptr(lw),
-              _hip.ptr(lab), st.scale, None, _hip.ptr(log_norm), _hip.ptr(resps),
-              _hip.ptr(llh_sum), _hip.ptr(ws), ws_bytes)
+    def launch(resps):
+        _hip.call('beer_mixtureset_estep', _hip.dtype_code(X.dtype, exact),
+                  _hip.COV_CODE[cov_type], T, D, S, G, _hip.ptr(X), _hip.ptr(E), _hip.ptr(lw),
+                  _hip.ptr(lab), st.scale, None, _hip.ptr(log_norm), _hip.ptr(resps),
+                  _hip.ptr(llh_sum), _hip.ptr(ws), ws_bytes)
+    try:
+        launch(resps)
+    except _hip.HipError:
+        # `on_matrix_cores` above restates the library's own dispatch; should the two
+        # ever disagree, the library refuses a G > 1 call without a responsibilities
+        # buffer (the generic kernels normalise in it): give it one
+        if resps is not None or G == 1:
+            raise
+        resps = torch.empty(T, K, dtype=X.dtype, device=X.device)
+        launch(resps)
+        if not want_resps:
+            resps = None
     return log_norm, resps
 
 
