@@ -136,7 +136,8 @@ SIGNATURES = {
                                           c_p],
     'beer_unpack_resps': [c_l, c_i, c_p, c_p, c_p],
     'beer_mixtureset_accumulate_fused': [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p,
-                                         c_p, c_z, c_p],
+                                         c_p, c_p, c_z, c_p],
+    'beer_frame_image': [c_i, c_l, c_i, c_p, c_p, c_z, c_p],
     'beer_pack_resps': [c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     'beer_weights_from_acc': [c_i, c_i, c_i, c_p, c_p, c_p],
     'beer_hmm_gather': [c_i, c_p, c_i, c_p, c_d, c_p, c_p],
@@ -185,6 +186,7 @@ SIZE_QUERIES = {
     'beer_accumulate_workspace_bytes': [c_i, c_i, c_i, c_i, c_i],
     'beer_packed_resps_bytes': [c_l, c_i, c_i],
     'beer_accumulate_fused_workspace_bytes': [c_i, c_i, c_i, c_i],
+    'beer_frame_image_bytes': [c_i, c_l, c_i],
     'beer_accumulate_packed_workspace_bytes': [c_i, c_l, c_i, c_i],
     'beer_mixtureset_accumulate_packed_workspace_bytes': [c_i, c_l, c_i, c_i, c_i],
     'beer_hmm_fb_scratch_doubles': [c_i, c_p, c_i],

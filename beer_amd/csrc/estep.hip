@@ -572,18 +572,31 @@ size_t beer_accumulate_fused_workspace_bytes(int cov, int D, int S, int G) {
     return beer_mfma::accf_workspace_bytes(cov, D, S, G);
 }
 
+size_t beer_frame_image_bytes(int cov, int64_t T, int D) {
+    if (cov < 0 || cov > 2 || T < 0 || D < 1) return 0;
+    return beer_mfma::frame_image_bytes(cov, T, D);
+}
+
+int beer_frame_image(int cov, int64_t T, int D, const float* X, void* image, size_t image_bytes,
+                     void* stream) {
+    BEER_REQUIRE(cov >= 0 && cov <= 2 && T >= 0 && D >= 1);
+    const size_t need = beer_mfma::frame_image_bytes(cov, T, D);
+    BEER_REQUIRE(need > 0 && image && image_bytes >= need && (T == 0 || X));
+    return beer_mfma::frame_image(cov, T, D, X, image, as_stream(stream));
+}
+
 int beer_mixtureset_accumulate_fused(int cov, int64_t T, int D, int S, int G, const float* X,
                                      const float* exp_stats, const float* log_weights,
                                      const float* log_norm, const float* state_resps,
-                                     double* acc, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+                                     const void* frame_image, double* acc, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
     BEER_REQUIRE(T >= 0 && D >= 1 && S >= 1 && G >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(beer_mfma::supported_accf(cov, D, S, G));
     BEER_REQUIRE(workspace && workspace_bytes >= beer_mfma::accf_workspace_bytes(cov, D, S, G));
     if (T == 0) return BEER_OK;
     BEER_REQUIRE(X && exp_stats && log_norm && acc);
     return beer_mfma::acc_fused_bf16x3(cov, T, D, S, G, X, exp_stats, log_weights, log_norm,
-                                       state_resps, acc, workspace, workspace_bytes,
+                                       state_resps, frame_image, acc, workspace, workspace_bytes,
                                        as_stream(stream));
 }
 

@@ -28,6 +28,7 @@
 
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "estep_mfma.h"
 #include "estep_tiles.h"
@@ -53,6 +54,18 @@ namespace {
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// compile-time loops / indices for the hand-placed instruction streams (everything that
+// selects a register must be a constant when the code is generated, not after unrolling)
+template <int V> using ic = std::integral_constant<int, V>;
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(ic<I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
 
 constexpr int NP = kPackedPieces;      // pieces per operand
 // the six products (piece of A, piece of B), by decreasing weight
@@ -80,6 +93,14 @@ __device__ __forceinline__ void mfma_bf16_pinned(f32x4& acc, const u4& a, const 
         asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
     else
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// ... and with the accumulator in a VGPR quad (accumulators that VALU code reads next)
+template <bool FIRST>
+__device__ __forceinline__ void mfma_bf16_pinned_v(f32x4& acc, const u4& a, const u4& b) {
+    if (FIRST)
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    else
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 // after the last pinned MFMA, before anything reads an accumulator
 __device__ __forceinline__ void mfma_drain() {
@@ -1415,6 +1436,329 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Frame fragment images.  The fused accumulation is bound by VECTOR INSTRUCTION ISSUE,
+// not by the matrix pipe (PMC round 3: 1050 VALU + 288 MFMA instructions per wave-tile at
+// 4 issue cycles each is more than the 4608 cycles the MFMAs execute for; no schedule
+// -- two waves per SIMD, one wave hand-interleaved -- can go below the issue count).  700
+// of the 1050 VALU instructions rebuild operands that depend on the frames only: the A
+// fragments of the logits and the B fragments of the statistics, identical for all 30
+// component chunks of K = 1920 and for every VB iteration over the same frames.
+// frame_image_kernel builds them once per frame tile, in exactly the registers' layout:
+//   img[tile of 32 frames][ k-step s ][ piece q ][ frame tile m ][ 64 lanes ] u4   (A)
+//   img[tile            ][ NKU*6 +  statistic tile uu * 3 + piece q ][ 64 lanes ] u4   (B)
+// (1152 B per frame at D = 40: 3.8 GB per 3.33 M frames, read by the 30 chunk blocks of
+// a frame block that xcd_block() puts on one XCD next to each other.)  accfi_kernel is
+// accf_kernel with every fragment a 16-byte load.
+// ---------------------------------------------------------------------------
+__host__ __device__ inline size_t frame_image_tile_u4(int nk_used, int nqt) { return (size_t)(nk_used * NP * 2 + nqt * NP) * 64; }
+
+__global__ __launch_bounds__(256) void frame_image_kernel(int64_t nframes, int D, int nk, int nslab,
+                                                          int nqt, const float* __restrict__ X,
+                                                          const int* __restrict__ tab,
+                                                          u4* __restrict__ img) {
+    constexpr int MT = 2, FW = 32, NW = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D4 = d4_of(D), Dp = 4 * D4, LD = ld16_of(D);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int nk_used = (nslab + 7) / 8, xt_floats = (D + 2) * kAfXS;
+    int* tabs = reinterpret_cast<int*>(smem);
+    float* xw = reinterpret_cast<float*>(tabs + (nk + 1) * 8) + wave * (FW * LD + xt_floats);
+    float* xt = xw + FW * LD;
+    for (int idx = tid; idx < (nk + 1) * 8; idx += 256) tabs[idx] = tab[idx];
+    const int64_t tile = (int64_t)blockIdx.x * NW + wave, fb = tile * FW;
+    stage_rows<FW>(X, fb < nframes ? fb : 0, nframes, D, LD, lane, xw);   // (a wave past the end stages tile 0)
+    __syncthreads();
+    if (fb >= nframes) return;
+    for (int idx = lane; idx < (D + 2) * FW; idx += 64) {
+        const int c = idx / FW, r = idx - c * FW;
+        xt[c * kAfXS + r] = c < D ? xw[r * LD + c] : (c == D ? 1.f : 0.f);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    u4* out = img + tile * frame_image_tile_u4(nk_used, nqt) + lane;
+    const int* tl = tabs + 2 * g;
+    for (int s = 0; s < nk_used; ++s) {
+        u4 w[NP][MT];
+#pragma unroll
+        for (int hh = 0; hh < 2 * MT; ++hh) {
+            const int m = hh % MT, h = hh / MT;
+            const float* xrow = xw + (m * 16 + i) * LD;
+            const int t = tl[8 * s + h];
+            const int a = t & 0xff, j = (t >> 8) & 0xff;
+            const bool sq = (t >> 16) != 0;
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(xrow + j);
+            const float xx = xrow[a];
+            f32x4 p;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p[e] = bb[e] * (sq ? bb[e] : xx);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                unsigned w3[3];
+                split3(p[2 * e], p[2 * e + 1], w3);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) w[q][m][2 * h + e] = w3[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) out[((s * NP + q) * MT + m) * 64] = w[q][m];
+    }
+    out += (size_t)nk_used * NP * MT * 64;
+    for (int uu = 0; uu < nqt; ++uu) {
+        const int col = 16 * uu + i, slab = col >> 2;
+        int a = Dp + 2, b = Dp + 2;
+        if (slab < nslab) {
+            const int t = tabs[slab];
+            b = ((t >> 8) & 0xff) + (col & 3);
+            a = (t >> 16) ? b : (t & 0xff);
+        }
+        const int xa_off = (a < D ? a : (a == Dp ? D : D + 1)) * kAfXS + 4 * g;
+        const int xb_off = (b < D ? b : (b == Dp ? D : D + 1)) * kAfXS + 4 * g;
+        const f32x4 xa0 = *reinterpret_cast<const f32x4*>(xt + xa_off);
+        const f32x4 xa1 = *reinterpret_cast<const f32x4*>(xt + xa_off + 16);
+        const f32x4 xb0 = *reinterpret_cast<const f32x4*>(xt + xb_off);
+        const f32x4 xb1 = *reinterpret_cast<const f32x4*>(xt + xb_off + 16);
+        const f32x4 p0 = xa0 * xb0, p1 = xa1 * xb1;
+        u4 o[NP];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned w3[3];
+            split3(e < 2 ? p0[2 * e] : p1[2 * e - 4], e < 2 ? p0[2 * e + 1] : p1[2 * e - 3], w3);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) o[q][e] = w3[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) out[(uu * NP + q) * 64] = o[q];
+    }
+}
+
+template <int NKU>
+__global__ __launch_bounds__(512, 2) void accfi_kernel(
+    int64_t nframes, int K, int S, int G, int Greal, int nk, int nslab,
+    const u4* __restrict__ img, const u4* __restrict__ Pall, const float* __restrict__ log_norm,
+    const float* __restrict__ sr, int64_t frames_per_block, double* __restrict__ Sp,
+    const float* __restrict__ c0p) {
+    constexpr int NTC = 4, NQT = 6, MT = 2, FW = 32, WAVES = 8, NTHREADS = 64 * WAVES;
+    constexpr int kTileU4 = (NKU * NP * MT + NQT * NP) * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int64_t bx;
+    int by;
+    {
+        const int nch = (K + 16 * NTC - 1) / (16 * NTC);
+        if (!xcd_block((nframes + frames_per_block - 1) / frames_per_block, nch, nch, bx, by))
+            return;
+    }
+    const int nq = nslab * 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    // LDS: the chunk's packed parameters, then per wave the normalisers / posteriors of a tile
+    constexpr int p_u4 = NKU * NTC * kBlockU4;
+    u4* Ps = reinterpret_cast<u4*>(smem);
+    float* lsw = reinterpret_cast<float*>(Ps + p_u4) + wave * (2 * FW * 4);
+    {
+        const u4* src = Pall + (size_t)by * nk * NTC * kBlockU4;
+        for (int idx = tid; idx < p_u4; idx += NTHREADS) Ps[idx] = src[idx];
+    }
+    __syncthreads();
+    const int kbase = by * (16 * NTC);
+    const float c0 = c0p[0];
+    const int64_t tb = bx * frames_per_block;
+    const int64_t te = tb + frames_per_block < nframes ? tb + frames_per_block : nframes;
+    const u4* Pl = Ps + lane;
+    int sidx, st0c;
+    {
+        const int s0 = (kbase + 4 * i) / G, st = s0 < S ? s0 : S - 1;
+        const int st0 = kbase / G < S ? kbase / G : S - 1;
+        st0c = st0 < S - 4 ? st0 : S - 4;
+        sidx = st - st0c;
+    }
+    f32x4 sacc[NTC][NQT];
+#pragma unroll
+    for (int c = 0; c < NTC; ++c)
+#pragma unroll
+        for (int uu = 0; uu < NQT; ++uu) sacc[c][uu] = f32x4{0, 0, 0, 0};
+
+    const int lr = lane & 31, lh = lane >> 5;
+    f32x4 lsv = f32x4{0, 0, 0, 0};
+    auto issue = [&](int64_t fbn) {
+        const int rows_n = (int)(te - fbn < FW ? te - fbn : FW);
+        const int64_t rown = fbn + (lr < rows_n ? lr : rows_n - 1);
+        const float* src = ((lh && sr) ? sr : log_norm) + rown * S + st0c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lsv[j] = src[j];
+    };
+    const int64_t fb0 = tb + (int64_t)wave * FW;
+    if (fb0 < te) issue(fb0);
+    // The fragment loads run far ahead of their MFMAs (L2 latency, 40 % of the wave time
+    // when they were issued one batch ahead): a tile's first A fragments during the
+    // statistics of the tile before, its first two B fragments when its logits start.
+    u4 af[2][NP][MT];
+    u4 bq[3][NP];
+    bool a0_ready = false;
+    for (int64_t fb = fb0; fb < te; fb += WAVES * FW) {
+        const int rows = (int)(te - fb < FW ? te - fb : FW);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        *reinterpret_cast<f32x4*>(lsw + (lh * FW + lr) * 4) = lsv;
+        bool skip = false;
+        if (sr) {
+            float any = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) any = __builtin_fmaxf(any, __builtin_fabsf(lsv[j]));
+            skip = __builtin_amdgcn_ballot_w64(lh == 1 && lr < rows && any != 0.f) == 0;
+        }
+        if (fb + WAVES * FW < te) issue(fb + WAVES * FW);
+        if (skip) {
+            a0_ready = false;
+            continue;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        const u4* ti = img + (fb / FW) * (int64_t)kTileU4 + lane;
+        const bool has_next = fb + WAVES * FW < te;
+        const u4* tn = ti + (has_next ? (int64_t)WAVES * kTileU4 : 0);
+
+        // ---- logits of 32 frames x 64 components: A fragments straight from the image ----
+        f32x4 acc[MT][NTC];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int c = 0; c < NTC; ++c) acc[m][c] = f32x4{0, 0, 0, 0};
+        if (!a0_ready) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[0][q][m] = ti[(q * MT + m) * 64];
+        }
+        // the first two B fragments of the statistics
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) bq[uu][q] = ti[(NKU * NP * MT + uu * NP + q) * 64];
+#pragma unroll
+        for (int s = 0; s < NKU; ++s) {
+            if (s + 1 < NKU) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        af[(s + 1) & 1][q][m] = ti[(((s + 1) * NP + q) * MT + m) * 64];
+            }
+#pragma unroll
+            for (int c = 0; c < NTC; ++c) {
+                u4 bp[NP];
+#pragma unroll
+                for (int pq = 0; pq < NP; ++pq) bp[pq] = Pl[(s * NTC + c) * kBlockU4 + 64 * pq];
+                // (the products in the order of llhx_kernel: same roundings)
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m][c] = mfma_bf16(af[s & 1][kProdA[pr]][m], bp[kProdB[pr]], acc[m][c]);
+            }
+            // the loads of this k-step first (the counts must match what is issued here, or
+            // hipcc moves other loads in to fill the group)
+            if (s == 0) __builtin_amdgcn_sched_group_barrier(0x020, NKU > 1 ? 12 : 6, 0);
+            else if (s + 1 < NKU) __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT * NTC, 0);
+        }
+
+        // ---- r sr = exp(l - log_norm) sr, split into the A fragments of the statistics ----
+        u4 ar[NTC][NP];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * m + 4 * g + r;
+                const bool ok = row < rows;
+                // (the recomputed logits lack the common constant c0; rows past the end:
+                // weight 0 and a normaliser that keeps the exponential at 0)
+                const float nl2 = (ok ? c0 : -1.0e30f) - lsw[row * 4 + sidx];
+                const float wg = (sr ? lsw[(FW + row) * 4 + sidx] : 1.f) * (ok ? 1.f : 0.f);
+#pragma unroll
+                for (int nt = 0; nt < NTC; ++nt)
+                    acc[m][nt][r] = __builtin_amdgcn_exp2f((acc[m][nt][r] + nl2) *
+                                                           1.44269504088896340736f) * wg;
+            }
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    unsigned w3[3];
+                    split3(acc[m][nt][2 * e], acc[m][nt][2 * e + 1], w3);
+#pragma unroll
+                    for (int pq = 0; pq < NP; ++pq) ar[nt][pq][2 * m + e] = w3[pq];
+                }
+
+        // ---- statistics: sacc[c][uu] += A'(c) x B'(uu), B' from the image two tiles ahead ----
+#pragma unroll
+        for (int uu = 0; uu < NQT; ++uu) {
+            if (uu + 2 < NQT) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    bq[(uu + 2) % 3][q] = ti[(NKU * NP * MT + (uu + 2) * NP + q) * 64];
+            }
+            if (uu == NQT - 3) {
+                // (no next tile: this one again, harmlessly)
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) af[0][q][m] = tn[(q * MT + m) * 64];
+                a0_ready = has_next;
+            }
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int c = 0; c < NTC; ++c)
+                    sacc[c][uu] = mfma_bf16(ar[c][kProdA[pr]], bq[uu % 3][kProdB[pr]], sacc[c][uu]);
+            if (uu == NQT - 3) __builtin_amdgcn_sched_group_barrier(0x020, 9, 0);
+            else if (uu + 2 < NQT) __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NTC, 0);
+        }
+    }
+
+    // ---- flush: the waves' partial sums through LDS (fp64), one atomic per element ----
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);          // [WAVES][16 = c * 4 + r][64 lanes]
+    constexpr int EPT = 16 * 64 / NTHREADS;
+    int64_t dst_row[EPT];
+    int dst_i[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int el = tid + e * NTHREADS, j = el >> 6, ln = el & 63;
+        const int c = j >> 2, r = j & 3, gg = ln >> 4;
+        const int slot = kbase + 64 * (c >> 2) + 4 * (4 * gg + r) + (c & 3);
+        const int gi = slot % G;
+        dst_row[e] = slot < K && gi < Greal ? (int64_t)((slot / G) * Greal + gi) * nq : -1;
+        dst_i[e] = ln & 15;
+    }
+#pragma unroll
+    for (int uu = 0; uu < NQT; ++uu) {
+#pragma unroll
+        for (int c = 0; c < NTC; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * 16 + c * 4 + r) * 64 + lane] = sacc[c][uu][r];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int el = tid + e * NTHREADS;
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) t += (double)red[w * 1024 + el];
+            const int q = 16 * uu + dst_i[e];
+            if (dst_row[e] >= 0 && q < nq) atomicAdd(Sp + dst_row[e] + q, t);
+        }
+        __syncthreads();
+    }
+}
+
 // component tiles per wave: 4 (64 components).  With at most 96 statistic columns
 // (D <= 40) a wave's tile leaves room for two waves per SIMD: one wave's epilogue and
 // fragment arithmetic run under the other's MFMAs.
@@ -1463,6 +1807,8 @@ template __global__ void accx_kernel<false>(int64_t, int, int, int, int, const f
 template __global__ void accx_kernel<true>(int64_t, int, int, int, int, const float*, const unsigned*,
                                            const int*, int64_t, double*, int, int, int,
                                            const float*, int);
+template __global__ void accfi_kernel<3>(int64_t, int, int, int, int, int, int, const u4*, const u4*,
+                                         const float*, const float*, int64_t, double*, const float*);
 template __global__ void accf_kernel<4, 6, true, 8, 5, true>(int64_t, int, int, int, int, int, int, int,
                                                        const float*, const u4*, const int*,
                                                        const float*, const float*, int64_t, double*,
@@ -1747,9 +2093,43 @@ size_t accf_workspace_bytes(int cov, int D, int S, int G) {
            up256((size_t)Kreal * nq * sizeof(double));
 }
 
+// Frame fragment images (frame_image_kernel): diagonal / isotropic statistics of at most
+// 96 columns in at most 3 k-steps, whole float4 rows
+bool supported_frame_image(int cov, int D) {
+    return cov != BEER_FULL && D >= 4 && (D & 3) == 0 && accf_nqt(cov, D) == 6 &&
+           (nslab_of(cov, D) + 7) / 8 <= 3;
+}
+size_t frame_image_bytes(int cov, int64_t nframes, int D) {
+    if (!supported_frame_image(cov, D) || nframes < 0) return 0;
+    const int nk = nk16_of(cov, D), nk_used = (nslab_of(cov, D) + 7) / 8;
+    const int64_t tiles = (nframes + 31) / 32;
+    return (size_t)tiles * frame_image_tile_u4(nk_used, 6) * 16 + up256((size_t)(nk + 1) * 8 * sizeof(int));
+}
+__global__ void tabx_kernel(int cov, int D, int nk, int* __restrict__ tab) {
+    const int Dp = 4 * d4_of(D);
+    for (int s = threadIdx.x; s < (nk + 1) * 8; s += blockDim.x)
+        tab[s] = s < nslab_of(cov, D) ? slab_entry(cov, D, s) : ((Dp + 2) | ((Dp + 4) << 8));
+}
+int frame_image(int cov, int64_t nframes, int D, const float* X, void* image, hipStream_t s) {
+    if (!supported_frame_image(cov, D)) return BEER_EINVAL;
+    if (nframes == 0) return BEER_OK;
+    const int nk = nk16_of(cov, D), nslab = nslab_of(cov, D), nk_used = (nslab + 7) / 8;
+    const int64_t tiles = (nframes + 31) / 32;
+    int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(image) +
+                                      (size_t)tiles * frame_image_tile_u4(nk_used, 6) * 16);
+    hipLaunchKernelGGL(tabx_kernel, dim3(1), dim3(256), 0, s, cov, D, nk, tab);
+    const size_t lds = (size_t)(nk + 1) * 8 * sizeof(int) +
+                       (size_t)4 * (32 * ld16_of(D) + (D + 2) * kAfXS) * sizeof(float);
+    hipLaunchKernelGGL(frame_image_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), lds, s,
+                       nframes, D, nk, nslab, 6, X, tab, reinterpret_cast<u4*>(image));
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
 int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X,
                      const float* expT, const float* logw, const float* log_norm,
-                     const float* sr, double* acc, void* ws, size_t ws_bytes, hipStream_t s) {
+                     const float* sr, const void* image, double* acc, void* ws, size_t ws_bytes,
+                     hipStream_t s) {
     if (!supported_accf(cov, D, S, G) || ws_bytes < accf_workspace_bytes(cov, D, S, G))
         return BEER_EINVAL;
     // component slots: groups padded to a multiple of 4 (one state per lane's 4
@@ -1774,6 +2154,14 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
                        (size_t)stats_dim(cov, D) * sizeof(float), s, cov, D, Kreal, NTC, expT, logw,
                        reinterpret_cast<unsigned short*>(P), tab, Greal, G, c0);
     BEER_LAUNCH_CHECK();
+    // The states of every 64-component chunk fit a block of 4 consecutive ones?
+    // (groups are padded to a multiple of 4: a lane's 4 components share their state)
+    bool blk = S >= 4;
+    for (int c = 0; c < nchunks && blk; ++c) {
+        const int lo = c * 16 * NTC / G, hi = (c * 16 * NTC + 60) / G;
+        if ((hi < S ? hi : S - 1) - (lo < S ? lo : S - 1) > 3) blk = false;
+    }
+    const int nk_used = (nslab + 7) / 8;
     // waves per workgroup: 8 (two per SIMD) with 64-component chunks, 4 with 128
     const int waves = (NTC == 4 && NQT == 6) ? 8 : 4;
     // frames per workgroup: <= kAfMaxFramesPerWave per wave, about one workgroup of
@@ -1790,19 +2178,33 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
     int64_t fpb = (nframes + gz - 1) / gz;
     fpb = (fpb + 32 * waves - 1) / (32 * waves) * (32 * waves);
     gz = (nframes + fpb - 1) / fpb;
-    const int nk_used = (nslab + 7) / 8;
-    // (groups are padded to a multiple of 4: a lane's 4 components share their state.)
-    // The states of every 64-component chunk fit a block of 4 consecutive ones?
-    bool blk = S >= 4;
-    for (int c = 0; c < nchunks && blk; ++c) {
-        const int lo = c * 16 * NTC / G, hi = (c * 16 * NTC + 60) / G;
-        if ((hi < S ? hi : S - 1) - (lo < S ? lo : S - 1) > 3) blk = false;
-    }
     const size_t lds = (size_t)nk_used * NTC * kBlockU4 * 16 + (size_t)(nk + 1) * 8 * sizeof(int) +
                        (size_t)2 * NQT * 64 * sizeof(int) +
                        (size_t)waves * (32 * ld16_of(D) + (D + 2) * kAfXS + (blk ? 256 : 0)) *
                            sizeof(float);
     const dim3 grid(xcd_grid(gz, nchunks, nchunks));
+    if (image && blk && waves == 8 && supported_frame_image(cov, D)) {
+        // every fragment that depends on the frames only comes from the caller's image
+        const size_t lds_i = (size_t)nk_used * NTC * kBlockU4 * 16 + (size_t)waves * 256 * sizeof(float);
+        const size_t lds_red = (size_t)waves * 16 * 64 * sizeof(float);
+        const size_t lds_f = lds_i > lds_red ? lds_i : lds_red;
+#define BEER_ACCFI(NKU_)                                                                         \
+    do {                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(accfi_kernel<NKU_>),             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);       \
+        hipLaunchKernelGGL((accfi_kernel<NKU_>), grid, dim3(512), lds_f, s, nframes, K, S, G,     \
+                           Greal, nk, nslab, reinterpret_cast<const u4*>(image),                 \
+                           reinterpret_cast<const u4*>(P), log_norm, sr, fpb, Sp, c0);           \
+    } while (0)
+        if (nk_used == 1) BEER_ACCFI(1); else if (nk_used == 2) BEER_ACCFI(2); else BEER_ACCFI(3);
+#undef BEER_ACCFI
+        BEER_LAUNCH_CHECK();
+        const int64_t total_i = (int64_t)Kreal * stats_dim(cov, D);
+        hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total_i + 255) / 256)), dim3(256), 0, s,
+                           cov, D, Kreal, Sp, acc);
+        BEER_LAUNCH_CHECK();
+        return BEER_OK;
+    }
 #define BEER_ACCF(NTC_, NQT_, W_, BLK_)                                                          \
     do {                                                                                         \
         constexpr int XP_ = NQT_ == 6 ? 5 : 8;      /* D <= 40 <=> C4 <= 10 <=> nq <= 96 */       \

@@ -59,8 +59,12 @@ size_t accxs_workspace_bytes(int cov, int64_t T, int D, int S, int G);
 bool supported_accf(int cov, int D, int S, int G);
 size_t accf_workspace_bytes(int cov, int D, int S, int G);
 int acc_fused_bf16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
-                     const float* logw, const float* log_norm, const float* sr, double* acc,
-                     void* ws, size_t ws_bytes, hipStream_t s);
+                     const float* logw, const float* log_norm, const float* sr, const void* image,
+                     double* acc, void* ws, size_t ws_bytes, hipStream_t s);
+// The operands of that kernel that depend on the frames only, built once per block of
+// frames (estep_bf16.hip: frame_image_kernel); `image` above, nullable.
+size_t frame_image_bytes(int cov, int64_t T, int D);
+int frame_image(int cov, int64_t T, int D, const float* X, void* image, hipStream_t s);
 
 int estep_f32(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
               const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,

@@ -664,13 +664,39 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
     }
     if with_cpu_baseline and not args.no_cpu_baseline and world == 1 and cov == 'diagonal':
         out['cpu_baseline'] = cpu_baseline_hmm()
+    fi = frame_image_report(cov, X)
+    if fi:
+        out['frame_image'] = fi
     return out
+
+
+def frame_image_report(cov, X):
+    '''What the fused accumulation's frame images cost (diagonal emissions): bytes held,
+    builds / hits during this run, and the time of one build (they are built in the
+    warm-up iteration, once per block of frames, and reused for as long as the frames
+    stay where they are -- like the frames themselves they are input layout, not model
+    state; BEER_FRAME_IMAGE=0 runs without them).'''
+    from beer_amd import kernels
+    st = dict(kernels._frame_image_stats)
+    if not st['builds']:
+        return None
+    n = min(len(X), 1 << 20)
+    probe = X[:n].clone()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    kernels.frame_image(probe, cov)
+    t1.record()
+    torch.cuda.synchronize()
+    return {'bytes_held': st['bytes'], 'builds': st['builds'], 'hits': st['hits'],
+            'build_ms_per_million_frames': t0.elapsed_time(t1) * 1e6 / n,
+            'note': 'bf16x3 fragments of phi(x) per 32-frame tile, a function of the frames only: '
+                    'built in the warm-up iteration, reused by every timed one'}
 
 
 def config3_subobject(line):
     'The keys of a config-3 line that go into the default line as a sub-object.'
     keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'f32_mode', 'kernels',
-            'roofline', 'cpu_baseline', 'count_conservation_rel_err', 'elbo_per_frame',
+            'roofline', 'cpu_baseline', 'frame_image', 'count_conservation_rel_err', 'elbo_per_frame',
             'all_reduce_ms', 'm_step_ms', 'frames_per_rank', 'rccl_ranks')
     sub = {k: line[k] for k in keep if k in line}
     sub['workload'] = line['config']['workload']

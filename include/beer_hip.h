@@ -337,9 +337,24 @@ size_t beer_accumulate_fused_workspace_bytes(int cov, int D, int S, int G);
 int beer_mixtureset_accumulate_fused(int cov, int64_t T, int D, int S, int G,
                                      const float* X, const float* exp_stats,
                                      const float* log_weights, const float* log_norm,
-                                     const float* state_resps, double* acc,
-                                     void* workspace, size_t workspace_bytes,
+                                     const float* state_resps, const void* frame_image,
+                                     double* acc, void* workspace, size_t workspace_bytes,
                                      void* stream);
+
+/* `frame_image` above (nullable): the operands of that kernel that depend on the
+ * frames only -- phi(x_t) = [x^2, x, 1] of every 32-frame tile as bf16x3 pieces, once in
+ * the layout of the logits' A fragments and once in that of the statistics' B
+ * fragments, 1152 bytes per frame at D = 40.  The kernel is bound by vector
+ * instruction issue and two thirds of its vector instructions rebuild these for each
+ * of the K / 64 component chunks; the frames do not change between the VB iterations
+ * of a training run, so a caller that keeps X resident builds the image once per block
+ * of frames (beer_frame_image; the same T, D, cov as the accumulation call it is handed
+ * to) and the accumulation loads every fragment with 16-byte loads.  Same results bit
+ * for bit.  beer_frame_image_bytes = 0: no image for this shape (full covariance, D not a
+ * multiple of 4 or > 40); the accumulation ignores an image it cannot use. */
+size_t beer_frame_image_bytes(int cov, int64_t T, int D);
+int beer_frame_image(int cov, int64_t T, int D, const float* X, void* image,
+                     size_t image_bytes, void* stream);
 
 /* Mixture-weight statistics from the accumulated Gaussian statistics: the
  * zero-order count is N_k = -2 * acc[k, Q-2]; out[s,g] = N_{s,g} for

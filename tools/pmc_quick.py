@@ -5,7 +5,7 @@
 """
 import collections, csv, glob, os, re, sys
 src = sys.argv[1]
-pats = sys.argv[2:] or ['llhx_kernel', 'accx_kernel', 'accf_kernel', 'fb_wave_kernel', 'llh_kernel<', 'acc_kernel<']
+pats = sys.argv[2:] or ['llhx_kernel', 'accx_kernel', 'accfi_kernel', 'accf_kernel', 'fb_wave_kernel', 'llh_kernel<', 'acc_kernel<']
 files = [src] if src.endswith('.csv') else glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True)
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in files:
