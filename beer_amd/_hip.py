@@ -138,6 +138,8 @@ SIGNATURES = {
     'beer_mixtureset_accumulate_fused': [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p,
                                          c_p, c_p, c_z, c_p],
     'beer_frame_image': [c_i, c_l, c_i, c_p, c_p, c_z, c_p],
+    'beer_mixtureset_lognorm_image': [c_i, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                      c_z, c_p],
     'beer_pack_resps': [c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     'beer_weights_from_acc': [c_i, c_i, c_i, c_p, c_p, c_p],
     'beer_hmm_gather': [c_i, c_p, c_i, c_p, c_d, c_p, c_p],

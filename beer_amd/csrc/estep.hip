@@ -572,6 +572,18 @@ size_t beer_accumulate_fused_workspace_bytes(int cov, int D, int S, int G) {
     return beer_mfma::accf_workspace_bytes(cov, D, S, G);
 }
 
+int beer_mixtureset_lognorm_image(int cov, int64_t T, int D, int S, int G, const float* X,
+                                  const float* exp_stats, const float* log_weights,
+                                  const void* frame_image, float* log_norm, double* llh_sum,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    BEER_REQUIRE(T >= 0 && D >= 1 && S >= 1 && G >= 1 && cov >= 0 && cov <= 2);
+    BEER_REQUIRE(frame_image && workspace && log_norm && (T == 0 || (X && exp_stats)));
+    if (T == 0) return BEER_OK;
+    return beer_mfma::estep_bf16x3(cov, T, D, S, G, X, exp_stats, log_weights, nullptr, log_norm,
+                                   llh_sum, workspace, workspace_bytes, as_stream(stream), false,
+                                   frame_image);
+}
+
 size_t beer_frame_image_bytes(int cov, int64_t T, int D) {
     if (cov < 0 || cov > 2 || T < 0 || D < 1) return 0;
     return beer_mfma::frame_image_bytes(cov, T, D);

@@ -108,6 +108,11 @@ __device__ __forceinline__ void mfma_drain() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// u4 per 32-frame tile of a frame fragment image (frame_image_kernel): A fragments of
+// nk_used k-steps (3 pieces x 2 frame tiles), then B fragments of nqt statistic tiles
+__host__ __device__ inline size_t frame_image_tile_u4(int nk_used, int nqt) {
+    return (size_t)(nk_used * NP * 2 + nqt * NP) * 64;
+}
 // k-steps (8 slabs each), padded to an even count: the K1 loop is unrolled by two
 __host__ __device__ inline int nk16_of(int cov, int D) {
     return ((nslab_of(cov, D) + 7) / 8 + 1) / 2 * 2;
@@ -322,12 +327,17 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ X, int64_t 
 // SQ = false: no "square" slabs in the table (full covariance), the per-product
 // select between x_j^2 and x_a x_j drops out of the A-fragment arithmetic.
 // ---------------------------------------------------------------------------
-template <int NT, int MT, int GQ, bool PACKED, bool SQ, bool LNO>
+// IMG: the A fragments come from the caller's frame fragment image (frame_image_kernel
+// further down: they depend on the frames only), 16-byte loads instead of the staging of
+// the frames and the fragment arithmetic.
+template <int NT, int MT, int GQ, bool PACKED, bool SQ, bool LNO, bool IMG = false>
 __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
     int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nk,
     const float* __restrict__ X, const u4* __restrict__ Pall, const int* __restrict__ tab,
     float* __restrict__ resps, float* __restrict__ log_norm, double* __restrict__ llh_sum,
-    float* __restrict__ xt_out, int xt_floats, int nku, int cg, const float* __restrict__ c0) {
+    float* __restrict__ xt_out, int xt_floats, int nku, int cg, const float* __restrict__ c0,
+    const u4* __restrict__ img = nullptr) {
+    static_assert(!IMG || (MT == 2 && !PACKED && LNO), "the image holds 32-frame tiles");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LD = ld16_of(D);                                // 16-byte aligned rows
     const int tid = threadIdx.x, lane = tid & 63;
@@ -346,8 +356,9 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
     }
     const int64_t fb = (bx * NW + wave) * FW;
     for (int idx = tid; idx < (nk + 1) * 8; idx += kThreads) tabs[idx] = tab[idx];
-    stage_rows<FW>(X, fb, nframes, D, LD, lane, xw);
+    if (!IMG) stage_rows<FW>(X, fb, nframes, D, LD, lane, xw);
     __syncthreads();
+    if (IMG && fb >= nframes) return;
     {
         // The wave's frames are (a part of) one 64-frame tile of the accumulation kernel:
         // leave them behind transposed, [D + 2][68] (rows D, D + 1 = 1, 0; see
@@ -488,9 +499,11 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
         load_b((int64_t)s * NT + (bi + 1) * BT, bn);
         // slices of the next A: MT * 2 halves over the NBATCH batches
         // (half-major: the halves of one batch share the table entry)
+        if constexpr (!IMG) {
 #pragma unroll
-        for (int hh = bi * MT * 2 / NBATCH; hh < (bi + 1) * MT * 2 / NBATCH; ++hh)
-            make_half(s + 1, hh % MT, hh / MT, nxt);         // the table is padded by one k-step
+            for (int hh = bi * MT * 2 / NBATCH; hh < (bi + 1) * MT * 2 / NBATCH; ++hh)
+                make_half(s + 1, hh % MT, hh / MT, nxt);     // the table is padded by one k-step
+        }
 #pragma unroll
         for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
@@ -500,10 +513,25 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
                     acc[m][bi * BT + c] = mfma_bf16(cur.w[kProdA[pr]][m], b.p[c][kProdB[pr]],
                                                     acc[m][bi * BT + c]);
         __builtin_amdgcn_sched_group_barrier(0x020, NP * BT, 0);         // VMEM reads
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * ((MT * 2 + NBATCH - 1) / NBATCH), 0);   // DS reads
+        if constexpr (!IMG)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * ((MT * 2 + NBATCH - 1) / NBATCH), 0);   // DS reads
         __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT * BT, 0);     // MFMA
     };
+    // (IMG) the image tile of this wave: [k-step][piece][frame tile][64 lanes] u4, then the
+    // statistics' fragments, which this kernel does not use
+    const u4* ti = nullptr;
+    if constexpr (IMG)
+        ti = img + (fb / FW) * (int64_t)frame_image_tile_u4(nku, 6) + lane;
+    auto load_a = [&](int s, AFrag& f) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) f.w[q][m] = ti[((s * NP + q) * MT + m) * 64];
+    };
     auto kstep = [&](int s, const AFrag& cur, AFrag& nxt, BFrag& b0, BFrag& b1) {
+        if constexpr (IMG) {
+            if (s + 1 < nku) load_a(s + 1, nxt);
+        }
 #pragma unroll
         for (int bi = 0; bi < NBATCH; bi += 2) {
             batch(s, bi, cur, nxt, b0, b1);
@@ -512,8 +540,12 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
     };
     AFrag f0, f1;
     BFrag b0, b1;
+    if constexpr (IMG) {
+        load_a(0, f0);
+    } else {
 #pragma unroll
-    for (int hh = 0; hh < MT * 2; ++hh) make_half(0, hh % MT, hh / MT, f0);
+        for (int hh = 0; hh < MT * 2; ++hh) make_half(0, hh % MT, hh / MT, f0);
+    }
     load_b(0, b0);
     // (the image is padded to an even number of k-steps; only those that hold slabs run)
     for (int s = 0; s < nku; s += 2) {
@@ -548,11 +580,12 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
 // shape, not the type; SQ = false kernels are full covariance by construction)
 thread_local int g_cov_of_launch = BEER_FULL;
 
-template <int NT, int MT, int GQ, bool PACKED = false, bool SQ = true, bool LNO = false>
+template <int NT, int MT, int GQ, bool PACKED = false, bool SQ = true, bool LNO = false,
+          bool IMG = false>
 int launch_llhx(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nchunks, int nk,
                 const float* X, const void* P, const int* tab, const float* c0, float* resps,
                 float* log_norm, double* llh_sum, hipStream_t s, float* xt_out = nullptr,
-                int xt_floats = 0) {
+                int xt_floats = 0, const void* img = nullptr) {
     const int LD = ld16_of(D);
     // k-steps that hold slabs: the slab count is the table's (full: SQ = false)
     const int nku = (nslab_of(SQ ? g_cov_of_launch : BEER_FULL, D) + 7) / 8;
@@ -562,13 +595,13 @@ int launch_llhx(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int
     if (nchunks != (K + 16 * NT - 1) / (16 * NT)) return BEER_EINVAL;
     const int cg = xcd_chunk_group(nchunks, (size_t)nku * NT * kBlockU4 * 16);
     (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(llhx_kernel<NT, MT, GQ, PACKED, SQ, LNO>),
+        reinterpret_cast<const void*>(llhx_kernel<NT, MT, GQ, PACKED, SQ, LNO, IMG>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((llhx_kernel<NT, MT, GQ, PACKED, SQ, LNO>),
+    hipLaunchKernelGGL((llhx_kernel<NT, MT, GQ, PACKED, SQ, LNO, IMG>),
                        dim3(nchunks > 1 ? xcd_grid(blocks, nchunks, cg) : (unsigned)blocks),
                        dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nk, X,
                        reinterpret_cast<const u4*>(P), tab, resps, log_norm, llh_sum, xt_out,
-                       xt_floats, nku, cg, c0);
+                       xt_floats, nku, cg, c0, reinterpret_cast<const u4*>(img));
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }
@@ -1451,7 +1484,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
 // a frame block that xcd_block() puts on one XCD next to each other.)  accfi_kernel is
 // accf_kernel with every fragment a 16-byte load.
 // ---------------------------------------------------------------------------
-__host__ __device__ inline size_t frame_image_tile_u4(int nk_used, int nqt) { return (size_t)(nk_used * NP * 2 + nqt * NP) * 64; }
 
 __global__ __launch_bounds__(256) void frame_image_kernel(int64_t nframes, int D, int nk, int nslab,
                                                           int nqt, const float* __restrict__ X,
@@ -1797,10 +1829,13 @@ inline size_t p_image_bytes(int nchunks, int nk, int NT) {
 namespace {
 template __global__ void llhx_kernel<16, 4, 4, true, false, false>(
     int64_t, int, int, int, int, int, int, int, const float*, const u4*, const int*, float*, float*,
-    double*, float*, int, int, int, const float*);
+    double*, float*, int, int, int, const float*, const u4*);
 template __global__ void llhx_kernel<16, 2, 1, false, true, true>(
     int64_t, int, int, int, int, int, int, int, const float*, const u4*, const int*, float*, float*,
-    double*, float*, int, int, int, const float*);
+    double*, float*, int, int, int, const float*, const u4*);
+template __global__ void llhx_kernel<16, 2, 1, false, true, true, true>(
+    int64_t, int, int, int, int, int, int, int, const float*, const u4*, const int*, float*, float*,
+    double*, float*, int, int, int, const float*, const u4*);
 template __global__ void accx_kernel<false>(int64_t, int, int, int, int, const float*, const unsigned*,
                                             const int*, int64_t, double*, int, int, int,
                                             const float*, int);
@@ -1873,9 +1908,11 @@ size_t estepx_workspace_bytes(int cov, int D, int S, int G) {
            up256((size_t)(nk16_of(cov, D) + 1) * 8 * sizeof(int)) + 256;
 }
 
+bool supported_frame_image(int cov, int D);
+
 int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, const float* expT,
                  const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
-                 size_t ws_bytes, hipStream_t s, bool packed) {
+                 size_t ws_bytes, hipStream_t s, bool packed, const void* image) {
     if (packed && S != 1 && !supported_llh_packed_sets(cov, D, S, G)) return BEER_EINVAL;
     if (!supported_llh_padded(D, S, G) || ws_bytes < estepx_workspace_bytes(cov, D, S, G))
         return BEER_EINVAL;
@@ -1952,6 +1989,20 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
             case 1: BEER_LLHX(16, 2, 1, true, false);
             default: BEER_LLHX(16, 2, 2, true, false);
         }
+    }
+    if (image && (resps || jw != 4 || full || !supported_frame_image(cov, D))) return BEER_EINVAL;
+    if (image) {
+        // ... with the A fragments from the caller's frame fragment image
+#define BEER_LNI(GQ_)                                                                            \
+    return launch_llhx<16, 2, GQ_, false, true, true, true>(nframes, D, K, S, G, gl, jw, nchunks, \
+                                                            nk, X, P, tab, c0, resps, log_norm,  \
+                                                            llh_sum, s, nullptr, 0, image)
+        switch (gq) {
+            case 1: BEER_LNI(1);
+            case 2: BEER_LNI(2);
+            default: BEER_LNI(4);
+        }
+#undef BEER_LNI
     }
     if (!resps && jw == 4) {
         // log-normalisers only (the accumulation recomputes the responsibilities)

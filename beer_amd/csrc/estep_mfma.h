@@ -31,7 +31,8 @@ bool supported_llh_split(int D, int S, int G);
 // kernel consumes (estep_tiles.h: softmax_epilogue<PACKED>).
 int estep_bf16x3(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
                  const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
-                 size_t ws_bytes, hipStream_t s, bool packed = false);
+                 size_t ws_bytes, hipStream_t s, bool packed = false,
+                 const void* frame_image = nullptr);
 
 int unpack_resps(int64_t T, int K, const void* packed, float* resps, hipStream_t s);
 // comp_resps [T, S*G] (x state_resps [T, S], nullable) -> packed tiles

@@ -79,6 +79,20 @@ def mixtureset_estep(stats, exp_stats, log_weights, S, G, cov_type, labels=None,
     lab = None
     if labels is not None:
         lab = _hip.on_device(torch.as_tensor(labels)).to(torch.int64).contiguous()
+    if not need_resps and on_matrix_cores and S > 1 and G >= 4 and not exact and \
+            X.dtype == torch.float32 and _hip.f32_fast_ok(X):
+        # log-normalisers only, on the bf16x3 path: the logits' A fragments from the frame
+        # fragment image where the frames have one (the fused accumulation uses the same)
+        img = frame_image(X, cov_type)
+        if img is not None:
+            try:
+                _hip.call('beer_mixtureset_lognorm_image', _hip.COV_CODE[cov_type], T, D, S, G,
+                          _hip.ptr(X), _hip.ptr(E), _hip.ptr(lw), _hip.ptr(img),
+                          _hip.ptr(log_norm), _hip.ptr(llh_sum), _hip.ptr(ws), ws_bytes)
+                return log_norm, None
+            except _hip.HipError:
+                pass                                   # (a shape the image kernels do not take)
+
     def launch(resps):
         _hip.call('beer_mixtureset_estep', _hip.dtype_code(X.dtype, exact),
                   _hip.COV_CODE[cov_type], T, D, S, G, _hip.ptr(X), _hip.ptr(E), _hip.ptr(lw),

@@ -569,7 +569,7 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
             optim.step()
         return elbo
 
-    names = ('beer_mixtureset_estep', 'beer_hmm_posteriors_fused', 'beer_hmm_forward_backward',
+    names = ('beer_mixtureset_estep', 'beer_mixtureset_lognorm_image', 'beer_hmm_posteriors_fused', 'beer_hmm_forward_backward',
              'beer_mixtureset_accumulate_fused', 'beer_normal_accumulate',
              'beer_normal_accumulate_packed', 'beer_pack_resps',
              'beer_mixtureset_estep_packed', 'beer_mixtureset_accumulate_packed')
@@ -604,7 +604,7 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
         if n:
             fpl = n_local * steps / n
             kern[nm] = {'ms': ms, 'launches': n, 'frames_per_launch': fpl}
-            if 'estep' in nm or 'accumulate' in nm:
+            if 'estep' in nm or 'accumulate' in nm or 'lognorm' in nm:
                 # 2*K*Q algorithmic flop per frame for each of the two products
                 kern[nm]['tflops'] = 2. * Kc * Qd * fpl / (ms * 1e-3) / 1e12
     dom = max(kern, key=lambda nm: kern[nm]['ms'] * kern[nm]['launches'])
@@ -612,6 +612,7 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
              'beer_mixtureset_estep_packed': 'llhx_kernel',
              'beer_mixtureset_accumulate_packed': 'accx_kernel',
              'beer_mixtureset_estep': 'llhx_kernel',
+             'beer_mixtureset_lognorm_image': 'llhx_kernel',
              'beer_hmm_posteriors_fused': 'fb_wave_kernel'}.get(dom, dom)
     pmc_key = ('c3full_' if cov == 'full' else 'c3_') + kname
     pmc = pmc_entry(pmc_key)

@@ -353,6 +353,16 @@ int beer_mixtureset_accumulate_fused(int cov, int64_t T, int D, int S, int G,
  * for bit.  beer_frame_image_bytes = 0: no image for this shape (full covariance, D not a
  * multiple of 4 or > 40); the accumulation ignores an image it cannot use. */
 size_t beer_frame_image_bytes(int cov, int64_t T, int D);
+/* beer_mixtureset_estep(BEER_F32, ..., comp_resps = NULL) -- the per-state
+ * log-normalisers of a mixture set (mixtureset.py:85-98), all that a forward-backward
+ * pass needs -- with the A fragments of the logits taken from the same frame image:
+ * no staging of the frames, no fragment arithmetic.  Same log_norm bit for bit.
+ * Workspace as beer_estep_workspace_bytes(BEER_F32, cov, D, S, G).  EINVAL where the
+ * image does not exist or G < 4. */
+int beer_mixtureset_lognorm_image(int cov, int64_t T, int D, int S, int G, const float* X,
+                                  const float* exp_stats, const float* log_weights,
+                                  const void* frame_image, float* log_norm, double* llh_sum,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 int beer_frame_image(int cov, int64_t T, int D, const float* X, void* image,
                      size_t image_bytes, void* stream);
 

@@ -1620,7 +1620,11 @@ def test_fused_accumulation_with_frame_image_is_bit_identical(monkeypatch):
     again = kernels.mixtureset_accumulate_fused(st, E, lw, ln, sr, S, G, 'diagonal')
     assert kernels._frame_image_stats['builds'] == before['builds'] + 1
     assert kernels._frame_image_stats['hits'] == before['hits'] + 1
+    # the E-step takes its A fragments from the same image (beer_mixtureset_lognorm_image)
+    ln_img, _ = kernels.mixtureset_estep(st, E, lw, S, G, 'diagonal', want_resps=False)
     monkeypatch.setenv('BEER_FRAME_IMAGE', '0')
+    ln_plain, _ = kernels.mixtureset_estep(st, E, lw, S, G, 'diagonal', want_resps=False)
+    assert torch.equal(ln_img, ln_plain)
     without = kernels.mixtureset_accumulate_fused(st, E, lw, ln, sr, S, G, 'diagonal')
     scale = float(without.abs().max())
     assert float((with_img - without).abs().max()) <= 1e-12 * scale

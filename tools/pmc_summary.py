@@ -20,7 +20,7 @@ import os
 import sys
 
 KERNELS = {'llhx_kernel': 'llhx_kernel', 'accx_kernel': 'accx_kernel',
-           'accf_kernel': 'accf_kernel', 'fb_wave_kernel': 'fb_wave_kernel',
+           'accfi_kernel': 'accf_kernel', 'accf_kernel': 'accf_kernel', 'fb_wave_kernel': 'fb_wave_kernel',
            'llh_kernel<': 'llh_kernel', 'acc_kernel<': 'acc_kernel'}
 # kernels whose streaming reads are 16 B per lane: FETCH_SIZE counts half their bytes on
 # gfx950 (MI355X_MICROARCH.md, HBM section); bench.py doubles the read figure for these
