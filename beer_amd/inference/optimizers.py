@@ -12,7 +12,10 @@ Interface of beer/inference/optimizers.py:5-67 (constructor arguments,
 optimizer states carry).
 """
 
+import os
 import pickle
+
+import torch
 
 __all__ = ['VBConjugateOptimizer', 'VBOptimizer']
 
@@ -22,10 +25,19 @@ _STATE = ('lrate', 'update_count')
 class VBConjugateOptimizer:
     'Round-robin coordinate ascent over mean-field groups of conjugate parameters.'
 
-    def __init__(self, groups, lrate=1.):
+    def __init__(self, groups, lrate=1., graph=None):
         # a model may hand its groups over as generators: materialise them once
         self.groups = [list(members) for members in groups]
         self.lrate, self.update_count = lrate, 0
+        # graph=True (or BEER_MSTEP_GRAPH=1): the update of a group is captured once as a
+        # HIP graph and replayed -- one launch instead of ~20 per parameter
+        self.graph = (os.environ.get('BEER_MSTEP_GRAPH') == '1') if graph is None else bool(graph)
+        self._captured = {}
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_captured'] = {}                   # graphs belong to the process that made them
+        return state
 
     # -- persistent state: the learning rate and whose turn it is
     def state_dict(self):
@@ -48,9 +60,67 @@ class VBConjugateOptimizer:
 
     def step(self):
         'Natural-gradient update of the group whose turn it is.'
-        for param in self._group_in_turn():
-            param.natural_grad_update(self.lrate)
+        members = self._group_in_turn()
+        if not (self.graph and members and self._replay(members)):
+            for param in members:
+                param.natural_grad_update(self.lrate)
         self.update_count += 1
+
+    # -- the M-step of a group as a captured HIP graph ---------------------------
+    # The update of a parameter is ~20 small launches (natural-gradient step, eta -> standard
+    # parameters with a D x D factorisation per Gaussian, E[T], log-normaliser); their GPU
+    # time hides behind the E-step, their host time does not.  Captured once per group,
+    # the kernels read the statistics and the current eta from buffers that stay where they
+    # are and rewrite the posterior's tensors in place; after a replay the posterior's memo
+    # is put back to what the capture produced (same tensors, new contents) and everything
+    # computed lazily since (KL terms, log-weights ...) is dropped.
+    @staticmethod
+    def _capturable(members):
+        for p in members:
+            if getattr(p, '_callbacks', None):
+                return False                      # callbacks run Python (and host copies)
+            tensors = tuple(p.posterior._tensors()) + tuple(p.prior._tensors()) + (p.stats,)
+            if not all(t.is_cuda for t in tensors):
+                return False
+        return True
+
+    def _replay(self, members):
+        key = self.update_count % len(self.groups)
+        entry = self._captured.get(key)
+        if entry is False:
+            return False
+        if entry is None:
+            if not self._capturable(members):
+                self._captured[key] = False
+                return False
+            statics = [p.stats.detach().clone() for p in members]
+            etas = [p.posterior.natural_parameters().detach().clone() for p in members]
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    for p, st, eta in zip(members, statics, etas):
+                        p.stats = st
+                        eta.copy_(p.natural_grad_update(self.lrate, eta_q=eta))
+            except Exception:                     # (a step of this family cannot be captured)
+                self._captured[key] = False
+                raise
+            memos = [dict(p.posterior.__dict__.get('_memo', {})) for p in members]
+            entry = self._captured[key] = (graph, statics, etas, memos, self.lrate)
+        else:
+            graph, statics, etas, memos, lrate = entry
+            if lrate != self.lrate:
+                raise ValueError('the learning rate changed after the M-step was captured')
+            for p, st in zip(members, statics):
+                if p.stats is not st:
+                    st.copy_(p.stats)
+                    p.stats = st
+        graph, statics, etas, memos, _ = entry
+        graph.replay()
+        for p, memo in zip(members, memos):
+            p.posterior.__dict__['_memo'] = dict(memo)
+            p.__dict__.pop('_kl_memo', None)
+        return True
 
 
 class VBOptimizer:

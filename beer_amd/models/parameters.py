@@ -132,11 +132,14 @@ class ConjugateBayesianParameter(BayesianParameter):
         'E_q[T(theta)] -- what the E-step kernels consume.'
         return self.posterior.expected_sufficient_statistics()
 
-    def natural_grad_update(self, lrate):
-        'eta <- eta_q + lrate (eta_p + stats - eta_q); then eta -> std params.'
+    def natural_grad_update(self, lrate, eta_q=None):
+        '''eta <- eta_q + lrate (eta_p + stats - eta_q); then eta -> std params.  Returns the
+        new eta.  `eta_q`: the posterior's natural parameters held by the caller (a
+        captured M-step keeps them in a buffer of its own, see optimizers.py).'''
         self.dispatch(before_update=True)
         eta_p = self.prior.natural_parameters()
-        eta_q = self.posterior.natural_parameters()
+        if eta_q is None:
+            eta_q = self.posterior.natural_parameters()
         home, dtype = eta_q.device, eta_q.dtype
         dp, dq = _hip.on_device(eta_p, dtype), _hip.on_device(eta_q)
         ds = _hip.on_device(self.stats, dtype)
@@ -148,3 +151,4 @@ class ConjugateBayesianParameter(BayesianParameter):
                   _hip.ptr(dp), _hip.ptr(dq), _hip.ptr(ds), float(lrate), _hip.ptr(new))
         self.posterior.update_from_natural_parameters(new.to(home))
         self.dispatch(before_update=False)
+        return new

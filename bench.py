@@ -665,7 +665,7 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
     }
     if with_cpu_baseline and not args.no_cpu_baseline and world == 1 and cov == 'diagonal':
         out['cpu_baseline'] = cpu_baseline_hmm()
-    fi = frame_image_report(cov, X)
+    fi = frame_image_report(cov, X) if cov != 'full' else None
     if fi:
         out['frame_image'] = fi
     return out
