@@ -89,6 +89,8 @@ class VBConjugateOptimizer:
         entry = self._captured.get(key)
         if entry is False:
             return False
+        if entry is not None and entry[4] != self.lrate:
+            entry = None                          # a new learning rate: capture again
         if entry is None:
             if not self._capturable(members):
                 self._captured[key] = False
@@ -108,9 +110,7 @@ class VBConjugateOptimizer:
             memos = [dict(p.posterior.__dict__.get('_memo', {})) for p in members]
             entry = self._captured[key] = (graph, statics, etas, memos, self.lrate)
         else:
-            graph, statics, etas, memos, lrate = entry
-            if lrate != self.lrate:
-                raise ValueError('the learning rate changed after the M-step was captured')
+            graph, statics, etas, memos, _ = entry
             for p, st in zip(members, statics):
                 if p.stats is not st:
                     st.copy_(p.stats)

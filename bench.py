@@ -143,6 +143,14 @@ def pmc_entry(kernel_key):
     return {}
 
 
+def m_step_mode(optim):
+    'How the conjugate M-step ran: replayed from a captured HIP graph, or kernel by kernel.'
+    if any(e not in (None, False) for e in getattr(optim, '_captured', {}).values()):
+        return 'hipGraph (one capture per mean-field group, replayed every iteration)'
+    return 'eager (a parameter of the group has host callbacks, or --no-mstep-graph)' \
+        if getattr(optim, 'graph', False) else 'eager'
+
+
 def rank_census(world, device, backend, n_local):
     '''Evidence for an N > 1 line: the number of ranks the collective really spans (an
     all-reduce of ones) and the frames per rank (max / mean).'''
@@ -312,7 +320,8 @@ def run_gmm(args, rank, world, device, backend):
     datasize = args.frames * world if args.scaling == 'weak' else args.frames
     census = rank_census(world, device, backend, frames)
     model = make_gmm(device)             # identical on every rank
-    optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.)
+    optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.,
+                                      graph=not args.no_mstep_graph)
     elbo_err = stats_err = None
     if rank == 0 and not args.no_check:
         elbo_err, stats_err = gmm_parity_check(model, X, n=min(65536, frames))
@@ -421,6 +430,7 @@ def run_gmm(args, rank, world, device, backend):
                           'accumulation (not narrower than fp32: 24-bit operands, product error '
                           '<= 2^-23)' if split else 'v_mfma_f32_16x16x4_f32',
         'all_reduce_ms': allreduce_ms, 'm_step_ms': mstep_ms,
+        'm_step': m_step_mode(optim),
         'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'],
                      'peak': peak, 'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / peak,
                      'traffic': pmc_traffic(pmc_key), 'avg_launch_ms': kern[dom]['ms'],
@@ -555,7 +565,8 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
     X = torch.randn(n_local, D, generator=g, device=device)
     ploop = make_phone_loop(cov, device)                     # identical on every rank
     census = rank_census(world, device, backend, n_local)
-    optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.)
+    optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.,
+                                      graph=not args.no_mstep_graph)
     phases = PhaseTimer()
 
     def step():
@@ -660,6 +671,7 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
         'count_conservation_rel_err': conservation,
         'f32_mode': beer.get_f32_mode(),
         'all_reduce_ms': phases.mean_ms('all_reduce'), 'm_step_ms': phases.mean_ms('m_step'),
+        'm_step': m_step_mode(optim),
         'roofline': roof,
         'kernels': kern,
     }
@@ -698,7 +710,7 @@ def config3_subobject(line):
     'The keys of a config-3 line that go into the default line as a sub-object.'
     keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'f32_mode', 'kernels',
             'roofline', 'cpu_baseline', 'frame_image', 'count_conservation_rel_err', 'elbo_per_frame',
-            'all_reduce_ms', 'm_step_ms', 'frames_per_rank', 'rccl_ranks')
+            'all_reduce_ms', 'm_step_ms', 'm_step', 'frames_per_rank', 'rccl_ranks')
     sub = {k: line[k] for k in keep if k in line}
     sub['workload'] = line['config']['workload']
     return sub
@@ -757,8 +769,8 @@ def _spawned(rank, args, port):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', type=int, default=2, choices=(2, 3),
                     help='BASELINE.json config: 2 = GMM K=256 full (headline), 3 = phone-loop HMM')
     ap.add_argument('--frames', type=int, default=None,
@@ -771,6 +783,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-exact', action='store_true', help='config 2: skip the f32_exact leg')
     ap.add_argument('--no-check', action='store_true', help='config 2: skip the oracle check')
+    ap.add_argument('--no-mstep-graph', action='store_true',
+                    help='launch the M-step kernel by kernel instead of replaying its captured HIP graph')
     ap.add_argument('--no-config3', action='store_true',
                     help='default line: skip the config3 / config3_full sub-objects')
     ap.add_argument('--scaling', default='weak', choices=('weak', 'strong'),
