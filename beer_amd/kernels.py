@@ -13,7 +13,7 @@ from . import _hip
 from .stats import FrameStats
 
 __all__ = ['normal_llh', 'mixtureset_estep', 'normal_accumulate', 'weights_from_acc',
-           'is_dense', 'dense_llh', 'dense_softmax', 'dense_accumulate', 'rowdot',
+           'frame_image', 'clear_frame_images', 'is_dense', 'dense_llh', 'dense_softmax', 'dense_accumulate', 'rowdot',
            'attach_stats_grad', 'differentiable_stats']
 
 LOG_2PI = 1.8378770664093453
@@ -426,6 +426,12 @@ def _frame_image_budget(device):
     gb = os.environ.get('BEER_FRAME_IMAGE_GB')
     total = torch.cuda.get_device_properties(device).total_memory
     return int(min(float(gb) * 2 ** 30 if gb else 64 * 2 ** 30, total / 4))
+
+
+def clear_frame_images():
+    'Drop every cached frame image (and the references to the frames they were built from).'
+    _frame_images.clear()
+    _frame_image_stats['bytes'] = 0
 
 
 def frame_image(X, cov_type):
