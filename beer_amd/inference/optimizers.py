@@ -100,7 +100,9 @@ class VBConjugateOptimizer:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(graph):
+                # (thread-local capture: other threads of the process -- a collective's
+                # watchdog -- may keep calling into the runtime)
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                     for p, st, eta in zip(members, statics, etas):
                         p.stats = st
                         eta.copy_(p.natural_grad_update(self.lrate, eta_q=eta))

@@ -320,8 +320,10 @@ def run_gmm(args, rank, world, device, backend):
     datasize = args.frames * world if args.scaling == 'weak' else args.frames
     census = rank_census(world, device, backend, frames)
     model = make_gmm(device)             # identical on every rank
+    # (the captured M-step only where it could be validated: one process, no RCCL watchdog
+    # thread next to the capture)
     optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.,
-                                      graph=not args.no_mstep_graph)
+                                      graph=not args.no_mstep_graph and world == 1)
     elbo_err = stats_err = None
     if rank == 0 and not args.no_check:
         elbo_err, stats_err = gmm_parity_check(model, X, n=min(65536, frames))
@@ -566,7 +568,7 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
     ploop = make_phone_loop(cov, device)                     # identical on every rank
     census = rank_census(world, device, backend, n_local)
     optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.,
-                                      graph=not args.no_mstep_graph)
+                                      graph=not args.no_mstep_graph and world == 1)
     phases = PhaseTimer()
 
     def step():
