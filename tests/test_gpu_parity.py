@@ -1594,7 +1594,9 @@ def test_elbo_round_trip_through_the_flat_device_buffer():
 
 
 @pytest.mark.gpu
-def test_fused_accumulation_with_frame_image_is_bit_identical(monkeypatch):
+@pytest.mark.parametrize('cov,T,D,S,G', [('diagonal', 40000, 40, 24, 16), ('diagonal', 33001, 20, 9, 16),
+                                         ('isotropic', 20011, 12, 6, 32), ('diagonal', 17000, 8, 40, 8)])
+def test_fused_accumulation_with_frame_image_is_bit_identical(monkeypatch, cov, T, D, S, G):
     '''beer_frame_image + beer_mixtureset_accumulate_fused(frame_image=...) -- the frames'
     fragments built once and loaded -- against the same call that rebuilds them per
     component chunk: the same numbers (fp64 sums of the same float32 partial sums; the
@@ -1602,37 +1604,38 @@ def test_fused_accumulation_with_frame_image_is_bit_identical(monkeypatch):
     from beer_amd import kernels, _hip
     from gpu_helpers import DEV
     torch.manual_seed(11)
-    T, D, S, G = 40000, 40, 24, 16
     X = torch.randn(T, D, device=DEV) * 2.
     K = S * G
-    ns = beer.NormalSet.create(torch.zeros(D), torch.ones(D), size=K, prior_strength=1.,
-                               noise_std=1.5, cov_type='diagonal')
+    ns = beer.NormalSet.create(torch.zeros(D), torch.ones(D) if cov == 'diagonal' else torch.ones(1),
+                               size=K, prior_strength=1.,
+                               noise_std=1.5, cov_type=cov)
     E = ns.means_precisions.natural_form().float().to(DEV)
     lw = torch.log_softmax(torch.randn(S, G, device=DEV), dim=1)
-    st = beer.FrameStats(X, 'diagonal')
-    ln, _ = kernels.mixtureset_estep(st, E, lw, S, G, 'diagonal', want_resps=False)
+    st = beer.FrameStats(X, cov)
+    ln, _ = kernels.mixtureset_estep(st, E, lw, S, G, cov, want_resps=False)
     sr = torch.softmax(torch.randn(T, S, device=DEV), dim=1)
     sr[:, 3] = 0.
-    assert _hip.lib().beer_frame_image_bytes(_hip.COV_CODE['diagonal'], T, D) > 0
+    sr[T // 3:T // 3 + 5000] = 0.                          # whole tiles without posterior: skipped
+    assert _hip.lib().beer_frame_image_bytes(_hip.COV_CODE[cov], T, D) > 0
     kernels._frame_images.clear()
     before = dict(kernels._frame_image_stats)
-    with_img = kernels.mixtureset_accumulate_fused(st, E, lw, ln, sr, S, G, 'diagonal')
-    again = kernels.mixtureset_accumulate_fused(st, E, lw, ln, sr, S, G, 'diagonal')
+    with_img = kernels.mixtureset_accumulate_fused(st, E, lw, ln, sr, S, G, cov)
+    again = kernels.mixtureset_accumulate_fused(st, E, lw, ln, sr, S, G, cov)
     assert kernels._frame_image_stats['builds'] == before['builds'] + 1
     assert kernels._frame_image_stats['hits'] == before['hits'] + 1
     # the E-step takes its A fragments from the same image (beer_mixtureset_lognorm_image)
-    ln_img, _ = kernels.mixtureset_estep(st, E, lw, S, G, 'diagonal', want_resps=False)
+    ln_img, _ = kernels.mixtureset_estep(st, E, lw, S, G, cov, want_resps=False)
     monkeypatch.setenv('BEER_FRAME_IMAGE', '0')
-    ln_plain, _ = kernels.mixtureset_estep(st, E, lw, S, G, 'diagonal', want_resps=False)
+    ln_plain, _ = kernels.mixtureset_estep(st, E, lw, S, G, cov, want_resps=False)
     assert torch.equal(ln_img, ln_plain)
-    without = kernels.mixtureset_accumulate_fused(st, E, lw, ln, sr, S, G, 'diagonal')
+    without = kernels.mixtureset_accumulate_fused(st, E, lw, ln, sr, S, G, cov)
     scale = float(without.abs().max())
     assert float((with_img - without).abs().max()) <= 1e-12 * scale
     assert float((again - with_img).abs().max()) <= 1e-12 * scale
     X.add_(0.)                                             # an in-place write: a new image
-    kernels.mixtureset_accumulate_fused(st, E, lw, ln, sr, S, G, 'diagonal')
+    kernels.mixtureset_accumulate_fused(st, E, lw, ln, sr, S, G, cov)
     monkeypatch.delenv('BEER_FRAME_IMAGE')
-    kernels.mixtureset_accumulate_fused(st, E, lw, ln, sr, S, G, 'diagonal')
+    kernels.mixtureset_accumulate_fused(st, E, lw, ln, sr, S, G, cov)
     assert kernels._frame_image_stats['builds'] == before['builds'] + 2
 
 
