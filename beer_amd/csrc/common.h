@@ -74,6 +74,11 @@ template <> struct Words<float> {
         return __builtin_bit_cast(float, w[0]);
     }
 };
+template <> struct Words<int> {
+    static constexpr int N = 1;
+    static __device__ __forceinline__ void split(int v, unsigned (&w)[2]) { w[0] = (unsigned)v; }
+    static __device__ __forceinline__ int join(const unsigned (&w)[2]) { return (int)w[0]; }
+};
 template <> struct Words<double> {
     static constexpr int N = 2;
     static __device__ __forceinline__ void split(double v, unsigned (&w)[2]) {

@@ -721,36 +721,465 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
 
 // ---------------------------------------------------------------------------
 // forward-backward, ONE WAVE per utterance (low-degree graphs with at most one
-// hub, <= 256 states)
+// hub, <= 256 states), in the SCALED LINEAR domain
 // ---------------------------------------------------------------------------
-// The workgroup version above is bound by instruction issue, not by the latency
-// of its dependent steps: a CU holds 16 utterances of two waves each and every
-// frame costs each wave hundreds of instructions around 7 workgroup barriers,
-// fp64 cross-lane reductions done by one wave while the other waits, and values
-// recomputed in the backward pass (rocprof: 6000 cycles per frame and utterance at
-// S = 120).  Here a wave owns an utterance alone -- lane l holds states l, l + 64,
-// ... (SPL per lane) -- and the step is one straight line of code:
+// The workgroup kernels above are bound by instruction issue, not by the latency
+// of their dependent steps, and so was the first one-wave kernel: a log-space step
+// costs every state one exponential per arc, a logarithm, conversions around both
+// and fp64 additions -- 344 vector instructions per frame at 120 states (rocprof,
+// round 3), 77 % of the SIMDs' issue slots.  Here a wave owns an utterance alone
+// -- lane l holds states l, l + 64, ... (SPL per lane) -- and the recursions run
+// on probabilities, not on their logarithms:
+//
+//   a_t(j) = b_t(j) (sum_k W_in[j,k] a_{t-1}(src_k) + W_hd[j] H_{t-1}),
+//                                              H_{t-1} = sum_{e in hub} W_hs[e] a_{t-1}(e)
+//   beta'_t(i) = sum_k W_out[i,k] lb_{t+1}(dst_k) + W_hs[i] Hb_{t+1},   lb_t = b_t beta_t
+//   gamma_t = a_t beta'_t / sum_j a_t(j) beta'_t(j)        (per frame, graph.py:304-307)
+//
+// with b_t(j) = exp(l_t(j) - m_t), m_t the float maximum of the frame's
+// log-likelihoods over the states (any shift near it serves), W = exp(log-weight) in
+// fp64 (absent arcs, absent hub links and lanes without a state: weight 0, so the
+// unrolled DEG arc slots need no branch).  All of it is fp64 multiply-adds; ONE
+// exponential per state, frame and direction is left.  After every step the column is
+// multiplied by the power of two that brings its largest entry into [1/2, 1) -- exact,
+// so nothing is rounded by the scaling and fp64's range (2^-1022) is what a state's
+// mass relative to the frame's best may fall to before it is lost; posteriors are
+// ratios inside one frame, the scales cancel.  log p(X) = sum_t m_t - log 2 sum_t
+// shift_t + log sum_j a_{T-1}(j) final_j.
+//  * exp(d) for float models: 2^n 2^f with n = rint(d log2 e) and f in [-1/2, 1/2]
+//    formed in fp64, 2^f by v_exp_f32 -- relative error 1e-7 whatever |d| (rounding
+//    d log2 e to float first would lose |d| 1e-7: states that are the only ones a
+//    graph allows may lie hundreds below the frame's maximum);
+//  * sums over the wave (hub, normaliser): float models add floats when the result
+//    is comfortably inside float's range (the terms are <= 1 by the scaling), fp64
+//    otherwise; fp64 models always fp64;
+//  * the forward column is kept for the backward pass in fp64 (see A_t below);
 //  * the trellis column lives in LDS without any barrier (the LDS operations of
-//    one wave execute in order);
-//  * every log-sum-exp is "relative to an approximate maximum": the terms stay
-//    fp64, their maximum is taken in float (any m near the maximum gives the same
-//    sum; DPP reductions of 32-bit values are one instruction per stage, of 64-bit
-//    values five), differences to it are formed in fp64 and exponentiated, summed
-//    and log'ed in the model's precision (float models: v_exp_f32 / v_log_f32 and
-//    float sums of <= 65 terms <= 1, the precision class of the kernel above);
-//  * absent arcs, absent hub links and lanes without a state carry the weight
-//    -inf: exp(-inf) = 0, so the unrolled arc slots (DEG, the graph's largest
-//    in / out degree) need no branch;
-//  * the hub's forward values are kept from the forward pass (hub_ws) for the
-//    hub flows instead of being recomputed, the lane's own lb value stays in a
-//    register.
+//    one wave execute in order).
 // FUSED: the pdf-id gather (modelset.py:140-146) with the acoustic scale
 // (hmm.py:79) happens when the emission log-likelihoods are read, the scatter
 // back to pdf ids (modelset.py:148-154, hmm.py:95) and the utterance's
 // sum_t sum_s gamma * pc (hmm.py:87) when gamma is written: three launches and
 // two round trips of the [frames, states] arrays less.
-constexpr int kWvWaves = 4;            // utterances (waves) per workgroup
+#ifndef BEER_FB_WAVES
+#define BEER_FB_WAVES 4
+#endif
+constexpr int kWvWaves = BEER_FB_WAVES; // utterances (waves) per workgroup
+#ifndef BEER_FB_PF
+#define BEER_FB_PF 4
+#endif
+constexpr int kWvPF = BEER_FB_PF;      // steps of look-ahead of the global loads
 
+template <typename T> struct Lin;
+template <> struct Lin<float> {
+    // exp(d) in fp64 range, relative error ~1e-7; d = -inf -> 0 (and NaN -> 0: the
+    // kernel flags utterances with NaN log-likelihoods, see `gave_up`)
+    static __device__ __forceinline__ double ex(double d) {
+        const double y = d * 1.4426950408889634074;
+        const double yc = __builtin_fmax(y, -1100.0);
+        const double n = __builtin_rint(yc);
+        const double r = (double)__builtin_amdgcn_exp2f((float)(yc - n));
+        return __builtin_amdgcn_ldexp(r, (int)n);
+    }
+    // sum over the wave of non-negative terms <= ~1
+    static __device__ __forceinline__ double wsum(double v) {
+        const float s = wave_sum((float)v);
+        // (uniform; the float sum has lost nothing that matters unless it is tiny)
+        if (__builtin_amdgcn_readfirstlane(s > 1.0e-30f) != 0) return (double)s;
+        return wave_sum(v);
+    }
+};
+template <> struct Lin<double> {
+    static __device__ __forceinline__ double ex(double d) { return exp(d); }
+    static __device__ __forceinline__ double wsum(double v) { return wave_sum(v); }
+};
+// biased exponent of a non-negative double (0: zero or denormal)
+__device__ __forceinline__ int expo_field(double v) {
+    return (int)((__builtin_bit_cast(unsigned long long, v) >> 52) & 0x7ffull);
+}
+
+template <typename T, int SPL, int DEG, bool FUSED, bool XI>
+__global__ __launch_bounds__(64 * kWvWaves) void fb_wave_kernel(
+    beer_batch b, const T* __restrict__ pc, int S_total, T scale, double* __restrict__ alpha_ws,
+    double* __restrict__ hubf_ws, T* __restrict__ out, T resp_scale, int atomic_out,
+    double* __restrict__ xi_sum, double* __restrict__ gamma0_sum, double* __restrict__ hub_flow,
+    double* __restrict__ utt_llh, T* __restrict__ lognorm_mean) {
+    typedef Lin<T> R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u = blockIdx.x * kWvWaves + wave;
+    if (u >= b.nutt) return;                              // (no workgroup barrier below)
+    const int gid = b.graph_id[u];
+    const beer_graph g = b.graphs[gid];
+    const beer_graph_lowdeg L = *g.lowdeg;
+    const int S = g.n_states;
+    const bool has_hub = L.n_hubs > 0;
+    const int64_t f0 = b.frame_off[u], T_ = b.frame_off[u + 1] - f0;
+    if (T_ <= 0) return;
+    constexpr int NS = 64 * SPL;                          // LDS slots per column
+    // byte addresses in LDS: cur[NS] (a_{t-1}), lb[NS] (b_{t+1} beta_{t+1})
+    const int cur0 = wave * (2 * NS * 8), lb0 = cur0 + NS * 8;
+    auto lds = [&](int addr) -> double& { return *reinterpret_cast<double*>(smem + addr); };
+    const T* in_w = (const T*)L.in_w;
+    const T* out_w = (const T*)L.out_w;
+    const T* hsw = (const T*)L.hub_src_w;
+    const T* hdw = (const T*)L.hub_dst_w;
+    const T* init = (const T*)g.init;
+    const T* fin = (const T*)g.final;
+
+    // ---- the lane's states (lanes without one: weights 0, their own slots) ----
+    int own[SPL], isrc[SPL][DEG], odst[SPL][DEG];          // LDS byte addresses
+    double iw[SPL][DEG], ow[SPL][DEG], hs_w[SPL], hd_w[SPL], fin_w[SPL];
+    bool st[SPL];
+    int64_t ll_off[SPL], a_off[SPL];                       // element offsets per frame 0
+    double xi_r[XI ? SPL : 1][DEG], flow_r[SPL];
+    const int32_t* ids = FUSED ? b.pdf_ids + b.pdf_off[gid] : nullptr;
+#pragma unroll
+    for (int p = 0; p < SPL; ++p) {
+        const int j = lane + 64 * p;
+        st[p] = j < S;
+        own[p] = cur0 + 8 * j;
+        hs_w[p] = hd_w[p] = fin_w[p] = 0.0;
+        flow_r[p] = 0.0;
+        int ib = 0, ie = 0, ob = 0, oe = 0, id = 0;
+        if (st[p]) {
+            ib = L.in_ptr[j]; ie = L.in_ptr[j + 1];
+            ob = L.out_ptr[j]; oe = L.out_ptr[j + 1];
+            if (has_hub && L.hub_src_id[j] >= 0) hs_w[p] = exp((double)hsw[j]);
+            if (has_hub && L.hub_dst_id[j] >= 0) hd_w[p] = exp((double)hdw[j]);
+            fin_w[p] = exp((double)fin[j]);
+            if (FUSED) id = ids[j];
+        }
+        ll_off[p] = st[p] ? (FUSED ? (int64_t)id : (int64_t)j) : 0;    // (always a valid element)
+        a_off[p] = j;
+#pragma unroll
+        for (int k = 0; k < DEG; ++k) {
+            const bool a = ib + k < ie, o = ob + k < oe;
+            isrc[p][k] = a ? cur0 + 8 * L.in_src[ib + k] : own[p];
+            iw[p][k] = a ? exp((double)in_w[ib + k]) : 0.0;
+            odst[p][k] = o ? lb0 + 8 * L.out_dst[ob + k] : own[p] + NS * 8;
+            ow[p][k] = o ? exp((double)out_w[ob + k]) : 0.0;
+            if (XI) xi_r[p][k] = 0.0;
+        }
+    }
+    // the hub's members, one per lane
+    int hm_src = own[0], hm_dst = own[0] + NS * 8;
+    double hw_src = 0.0, hw_dst = 0.0;
+    if (has_hub) {
+        const int sb = L.src_ptr[0], se = L.src_ptr[1], db = L.dst_ptr[0], de = L.dst_ptr[1];
+        if (sb + lane < se) {
+            const int e = L.src_list[sb + lane];
+            hm_src = cur0 + 8 * e;
+            hw_src = exp((double)hsw[e]);
+        }
+        if (db + lane < de) {
+            const int e = L.dst_list[db + lane];
+            hm_dst = lb0 + 8 * e;
+            hw_dst = exp((double)hdw[e]);
+        }
+    }
+    // The wave's LDS writes are visible to its later reads in program order; the
+    // compiler must keep that order (no instruction is emitted for this).
+#define BEER_WAVE_ORDER() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+    const T* llh = FUSED ? pc + f0 * (int64_t)S_total : pc + b.llh_off[u];
+    const int64_t ll_stride = FUSED ? S_total : S;
+    // (kept in fp64 also for float models: a float column loses a state below 2^-126 of
+    // the frame's best -- 87 nats, which evidence after the frame does make up for on real
+    // utterances: the real-dimension parity test failed with float columns.  Measured: 6 %
+    // less time for the 480 bytes per frame, but every utterance that then trips the
+    // normaliser test pays the log-space kernel on top)
+    typedef double A_t;
+    A_t* alpha = reinterpret_cast<A_t*>(alpha_ws + b.llh_off[u]);   // scaled forward columns
+    constexpr double kMinNorm = 0x1p-800;
+    double* hubf = hubf_ws + f0;                          // forward hub value per frame
+    auto load_ll = [&](int64_t t, int p) -> T {
+        const T v = llh[t * ll_stride + ll_off[p]];       // (lanes without a state: element 0)
+        return FUSED ? scale * v : v;
+    };
+    // the shift of a block of NF frames: the float maximum over their states (a frame
+    // whose own maximum lies below it starts out smaller by that factor, which the
+    // scaling behind it takes out again).  A NaN log-likelihood flags the utterance: the
+    // log-space kernel then propagates it as the reference does.
+    bool gave_up = false;
+    auto frames_max = [&](const T (*ll)[SPL], int nf) -> double {
+        float m = -INFINITY;
+        bool bad = false;
+        for (int k = 0; k < nf; ++k)
+#pragma unroll
+            for (int p = 0; p < SPL; ++p) {
+                m = __builtin_fmaxf(m, (float)ll[k][p]);  // (lanes without a state read state 0's)
+                bad |= ll[k][p] != ll[k][p];
+            }
+        m = wave_max(m);
+        gave_up |= __builtin_amdgcn_ballot_w64(bad) != 0;
+        return m > -INFINITY && m < INFINITY ? (double)m : 0.0;
+    };
+    // Giving up.  fp64 holds a state's mass down to 2^-1022 of the column's largest; what
+    // falls below is lost, and harmless unless the OTHER pass weights exactly those
+    // states up by as much (evidence before and after a frame contradicting each other by
+    // hundreds of nats).  Every column whose largest entry, before its scaling, is at
+    // least 2^-800, and every frame whose normaliser sum_j a_t(j) beta'_t(j) is at least
+    // kMinNorm = 2^-800, has lost nothing that matters (the lost terms are 2^-222 of what
+    // is kept); an
+    // utterance that fails either test is flagged (the slot behind its hub values) and
+    // redone in log space by fb_wave_log_kernel, and this kernel adds nothing of it to
+    // the accumulators.
+    // column * 2^shift with its largest entry in [1/2, 1); returns shift (0: all zero)
+    auto rescale = [&](double (&v)[SPL]) -> int {
+        int e = 0;
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) { const int ep = expo_field(v[p]); e = ep > e ? ep : e; }
+        e = wave_max(e);
+        gave_up |= e < 1023 - 800 || e >= 0x7ff;
+        const int sh = (e > 0 && e < 0x7ff) ? 1022 - e : 0;
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) v[p] = __builtin_amdgcn_ldexp(v[p], sh);
+        return sh;
+    };
+
+    // ---- forward ----
+    // The loads of a step are issued PF steps ahead (a ring of registers, the loops
+    // unrolled PF times so that every ring index is a constant): with the recursion on
+    // multiply-adds a step is shorter than a trip to HBM, and one step of look-ahead left
+    // every wave waiting for its 480 bytes.
+    constexpr int PF = kWvPF;
+    double m_sum = 0.0, sh_sum = 0.0;                     // log scale of the stored columns
+    T ll_ring[PF][SPL];
+    {
+        // (the first shift is taken from log-likelihood + initial log-probability)
+        double a[SPL], l0[SPL];
+        float m = -INFINITY;
+        bool bad0 = false;
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            l0[p] = st[p] ? (double)load_ll(0, p) + (double)init[lane + 64 * p] : neg_inf();
+            m = __builtin_fmaxf(m, (float)l0[p]);
+            bad0 |= l0[p] != l0[p];
+        }
+        gave_up |= __builtin_amdgcn_ballot_w64(bad0) != 0;
+        m = wave_max(m);
+        const double m0 = m > -INFINITY && m < INFINITY ? (double)m : 0.0;
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) a[p] = st[p] ? R::ex(l0[p] - m0) : 0.0;
+        const int sh = rescale(a);
+        m_sum += m0;
+        sh_sum += (double)sh;
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            lds(own[p]) = a[p];
+            if (st[p]) alpha[a_off[p]] = (A_t)a[p];
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k)
+#pragma unroll
+            for (int p = 0; p < SPL; ++p) ll_ring[k][p] = load_ll(1 + k < T_ ? 1 + k : T_ - 1, p);
+    }
+    BEER_WAVE_ORDER();
+    auto forward_step = [&](int64_t t, const T (&ll)[SPL], double mt) {
+        double hub = 0.0;
+        if (has_hub) {
+            hub = R::wsum(lds(hm_src) * hw_src);
+            if (lane == 0) hubf[t - 1] = hub;             // H(t-1): flows of the arcs t-1 -> t
+        }
+        double a[SPL];
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            double pred = hub * hd_w[p];
+#pragma unroll
+            for (int k = 0; k < DEG; ++k) pred = __builtin_fma(lds(isrc[p][k]), iw[p][k], pred);
+            a[p] = R::ex((double)ll[p] - mt) * pred;       // (lanes without a state: weights 0)
+        }
+        const int sh = rescale(a);
+        m_sum += mt;
+        sh_sum += (double)sh;
+        BEER_WAVE_ORDER();                                // every read of the column is done
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            lds(own[p]) = a[p];
+            if (st[p]) alpha[t * S + a_off[p]] = (A_t)a[p];
+        }
+        BEER_WAVE_ORDER();
+    };
+    for (int64_t t0 = 1; t0 < T_; t0 += PF) {
+        const double mt = frames_max(ll_ring, PF);        // (frames past the end: the last one again)
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int64_t t = t0 + k;
+            if (t >= T_) break;
+            T ll[SPL];
+#pragma unroll
+            for (int p = 0; p < SPL; ++p) {
+                ll[p] = ll_ring[k][p];
+                ll_ring[k][p] = load_ll(t + PF < T_ ? t + PF : T_ - 1, p);
+            }
+            forward_step(t, ll, mt);
+        }
+    }
+
+    // ---- backward + posteriors ----
+    // frame T-1 first (beta = final, nothing to recurse), then the loop
+    double llh_acc = 0.0, log_px = 0.0;
+    double lb_own[SPL];
+    A_t a_ring[PF][SPL];                           // frames t - 1 - k
+    T lt_ring[PF][SPL];
+    double hf_ring[PF];
+    // beta'_t (before its scaling) -> posteriors of frame t, flows of the arcs t -> t+1,
+    // then lb_t = b_t beta_t for frame t - 1
+    auto finish_frame = [&](int64_t t, const double (&a_cur)[SPL], const T (&lt_cur)[SPL],
+                            double (&beta)[SPL], const double (&lbd)[SPL][DEG], double hf_cur,
+                            bool inner, double mt) {
+        double gq[SPL], gsum = 0.0;
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            gq[p] = a_cur[p] * beta[p];                    // (lanes without a state: 0)
+            gsum += gq[p];
+        }
+        const double norm = R::wsum(gsum);                 // per frame (graph.py:304-307)
+        if (t == T_ - 1) log_px = norm;
+        const bool ok = norm >= kMinNorm && norm < __builtin_huge_val();
+        gave_up |= !ok;
+        // 1 / norm: the hardware's estimate and two Newton steps (a flagged frame's value
+        // is not used)
+        double inv = __builtin_amdgcn_rcp(norm);
+        inv = __builtin_fma(__builtin_fma(-norm, inv, 1.0), inv, inv);
+        inv = __builtin_fma(__builtin_fma(-norm, inv, 1.0), inv, inv);
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            const double gv = gq[p] * inv;
+            if (st[p]) {
+                if (FUSED) {
+                    const T gT = (T)gv;
+                    T* dst = out + (f0 + t) * (int64_t)S_total + ll_off[p];
+                    if (atomic_out) atomicAdd(dst, resp_scale * gT);
+                    else *dst = resp_scale * gT;
+                    llh_acc += (double)(lt_cur[p] * gT);
+                } else {
+                    out[b.llh_off[u] + t * S + a_off[p]] = (T)gv;
+                }
+                if (t == 0 && gamma0_sum && !gave_up) atomicAdd(gamma0_sum + a_off[p], gv);
+            }
+            if (inner && ok) {
+                if (XI) {
+                    const double ai = a_cur[p] * inv;
+#pragma unroll
+                    for (int k = 0; k < DEG; ++k) xi_r[p][k] = __builtin_fma(ai * ow[p][k], lbd[p][k], xi_r[p][k]);
+                }
+                if (has_hub && hub_flow)
+                    flow_r[p] = __builtin_fma(hf_cur * inv * hd_w[p], lb_own[p], flow_r[p]);
+            }
+        }
+        if (t > 0) {
+            (void)rescale(beta);
+#pragma unroll
+            for (int p = 0; p < SPL; ++p)
+                lb_own[p] = R::ex((double)lt_cur[p] - mt) * beta[p];     // for frame t - 1
+        }
+        BEER_WAVE_ORDER();                                 // lb fully read
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) lds(own[p] + NS * 8) = lb_own[p];
+        BEER_WAVE_ORDER();
+    };
+    auto load_back = [&](int64_t tq, A_t (&av)[SPL], T (&lv)[SPL], double& hv) {
+        const int64_t tc = tq > 0 ? tq : 0;                // (clamped: loaded, never used)
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            av[p] = alpha[tc * S + (st[p] ? a_off[p] : 0)];
+            lv[p] = load_ll(tc, p);
+        }
+        hv = has_hub ? hubf[tc] : 0.0;
+    };
+    {
+        const int64_t t = T_ - 1;
+        double a_cur[SPL], beta[SPL], lbd[SPL][DEG];
+        T lt_cur[SPL];
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            a_cur[p] = st[p] ? (double)alpha[t * S + a_off[p]] : 0.0;
+            lt_cur[p] = load_ll(t, p);
+            beta[p] = fin_w[p];
+            lb_own[p] = 0.0;
+#pragma unroll
+            for (int k = 0; k < DEG; ++k) lbd[p][k] = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) load_back(t - 1 - k, a_ring[k], lt_ring[k], hf_ring[k]);
+        T one[1][SPL];
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) one[0][p] = lt_cur[p];
+        finish_frame(t, a_cur, lt_cur, beta, lbd, 0.0, false, frames_max(one, 1));
+    }
+    auto backward_step = [&](int64_t t, const A_t (&a_t)[SPL], const T (&lt_cur)[SPL], double hf_cur,
+                             double mt) {
+        double a_cur[SPL], beta[SPL], lbd[SPL][DEG];
+        double hub = 0.0;
+        if (has_hub) hub = R::wsum(lds(hm_dst) * hw_dst);
+#pragma unroll
+        for (int p = 0; p < SPL; ++p) {
+            a_cur[p] = st[p] ? (double)a_t[p] : 0.0;
+            double acc = hub * hs_w[p];
+#pragma unroll
+            for (int k = 0; k < DEG; ++k) {
+                lbd[p][k] = lds(odst[p][k]);
+                acc = __builtin_fma(lbd[p][k], ow[p][k], acc);
+            }
+            beta[p] = acc;
+        }
+        finish_frame(t, a_cur, lt_cur, beta, lbd, hf_cur, true, mt);
+    };
+    for (int64_t t0 = T_ - 2; t0 >= 0; t0 -= PF) {
+        const double mt = frames_max(lt_ring, PF);        // (frames before the start: frame 0 again)
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int64_t t = t0 - k;
+            if (t < 0) break;
+            A_t a_t[SPL];
+            T lt_cur[SPL];
+#pragma unroll
+            for (int p = 0; p < SPL; ++p) { a_t[p] = a_ring[k][p]; lt_cur[p] = lt_ring[k][p]; }
+            const double hf_cur = hf_ring[k];              // H(t)
+            load_back(t - PF, a_ring[k], lt_ring[k], hf_ring[k]);
+            backward_step(t, a_t, lt_cur, hf_cur, mt);
+        }
+    }
+#undef BEER_WAVE_ORDER
+    if (lane == 0) hubf[T_ - 1] = gave_up ? 1.0 : 0.0;     // (hub values: slots 0 .. T-2)
+    if (gave_up) return;
+    // log p(X): every frame's log-normaliser (graph.py:304-326 averages T equal numbers)
+    if (lognorm_mean && lane == 0)
+        lognorm_mean[u] = (T)(m_sum - sh_sum * 0.69314718055994530942 + log(log_px));
+    if (FUSED && utt_llh) {
+        llh_acc = wave_sum(llh_acc);
+        if (lane == 0) atomicAdd(utt_llh + u, llh_acc);
+    }
+#pragma unroll
+    for (int p = 0; p < SPL; ++p) {
+        if (!st[p]) continue;
+        const int j = lane + 64 * p;
+        if (XI && xi_sum) {
+#pragma unroll
+            for (int k = 0; k < DEG; ++k)
+                if (ow[p][k] > 0.0 && xi_r[p][k] != 0.0)
+                    atomicAdd(xi_sum + (size_t)j * S + (odst[p][k] - lb0) / 8, xi_r[p][k]);
+        }
+        if (hub_flow && hd_w[p] > 0.0) atomicAdd(hub_flow + j, flow_r[p]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// ... and in LOG SPACE, for the utterances the linear-domain kernel gave up on (its
+// flag in hub_ws): round 3's kernel.  A log-space step costs every state one
+// exponential per arc, a logarithm, conversions around both and fp64 additions -- 344
+// vector instructions per frame at 120 states against ~215, most of them multiply-adds
+// -- but its range is unlimited, like the reference's (graph.py:270-326):
+//  * every log-sum-exp is "relative to an approximate maximum": the terms stay
+//    fp64, their maximum is taken in float (any m near the maximum gives the same
+//    sum), differences to it are formed in fp64 and exponentiated, summed and log'ed
+//    in the model's precision;
+//  * absent arcs, absent hub links and lanes without a state carry the weight -inf;
+//  * the forward values are kept in fp64 (their size grows with the utterance).
+// ---------------------------------------------------------------------------
 // arithmetic of a log-sum-exp relative to an approximate maximum
 template <typename T> struct Rel;
 template <> struct Rel<float> {
@@ -783,7 +1212,7 @@ __device__ __forceinline__ double rel_base(R m) {
 }
 
 template <typename T, int SPL, int DEG, bool FUSED, bool XI>
-__global__ __launch_bounds__(64 * kWvWaves) void fb_wave_kernel(
+__global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
     beer_batch b, const T* __restrict__ pc, int S_total, T scale, double* __restrict__ alpha_ws,
     double* __restrict__ hubf_ws, T* __restrict__ out, T resp_scale, int atomic_out,
     double* __restrict__ xi_sum, double* __restrict__ gamma0_sum, double* __restrict__ hub_flow,
@@ -802,6 +1231,7 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_kernel(
     const bool has_hub = L.n_hubs > 0;
     const int64_t f0 = b.frame_off[u], T_ = b.frame_off[u + 1] - f0;
     if (T_ <= 0) return;
+    if (hubf_ws[f0 + T_ - 1] == 0.0) return;             // the linear-domain kernel did this one
     const double NINF = neg_inf();
     constexpr int NS = 64 * SPL;                          // LDS slots per column
     // byte addresses in LDS: cur[NS] (alpha_{t-1}), lb[NS] (llh_{t+1} + beta_{t+1})
@@ -894,6 +1324,12 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_kernel(
         return FUSED ? scale * v : v;
     };
 
+    if (FUSED && atomic_out) {
+        // (the fast kernel may have added posteriors of some of the utterance's frames
+        // before it gave up: the rows are this utterance's alone)
+        for (int64_t e = lane; e < T_ * (int64_t)S_total; e += 64) out[f0 * (int64_t)S_total + e] = (T)0;
+        __threadfence();
+    }
     // ---- forward ----
     T ll_next[SPL];
 #pragma unroll
@@ -1311,10 +1747,16 @@ int wave_fb_launch(const beer_batch* b, const T* pc, int S_total, T scale, doubl
     const int spl = b->max_states <= 64 ? 1 : (b->max_states <= 128 ? 2 : 4);
     const int deg = b->max_degree <= 2 ? 2 : (b->max_degree <= 4 ? 4 : 8);
     const size_t lds = (size_t)kWvWaves * 2 * 64 * spl * sizeof(double);
+    // the linear-domain kernel, then the log-space one for the utterances it flagged
 #define BEER_WV(SPL_, DEG_, XI_)                                                                \
-    hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_>), grid, block, lds, s, *b,   \
-                       pc, S_total, scale, alpha_ws, hub_ws, out, resp_scale, atomic_out,      \
-                       xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean)
+    do {                                                                                        \
+        hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_>), grid, block, lds, s,   \
+                           *b, pc, S_total, scale, alpha_ws, hub_ws, out, resp_scale,          \
+                           atomic_out, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean);   \
+        hipLaunchKernelGGL((fb_wave_log_kernel<T, SPL_, DEG_, FUSED, XI_>), grid, block, lds,  \
+                           s, *b, pc, S_total, scale, alpha_ws, hub_ws, out, resp_scale,       \
+                           atomic_out, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean);   \
+    } while (0)
 #define BEER_WV_DEG(SPL_, XI_)                                                                  \
     do {                                                                                        \
         if (deg == 2) BEER_WV(SPL_, 2, XI_);                                                    \

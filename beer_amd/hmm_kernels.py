@@ -135,7 +135,10 @@ def forward_backward(batch, pc_llhs, want_xi=False, want_lognorm=False, dense_xi
     `hub_flow`; `dense_xi=True` forces the general kernel and a complete
     [S, S] matrix.'''
     dt, dev = batch.dtype, batch.device
-    if dense_xi and want_xi and batch.struct.all_lowdeg:
+    if dense_xi and batch.struct.all_lowdeg:
+        # the general kernel: a complete [S, S] matrix, and log-space forward values in
+        # `alpha` (what `trans_posteriors_dense` reads; the one-wave kernel keeps scaled
+        # probabilities there)
         batch.struct.all_lowdeg = 0
     gamma = torch.empty(batch.n_elems, dtype=dt, device=dev)
     alpha = torch.empty(batch.n_elems, dtype=torch.float64, device=dev)
