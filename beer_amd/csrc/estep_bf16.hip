@@ -1591,20 +1591,10 @@ __global__ __launch_bounds__(512, 2) void accfi_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    // LDS: the chunk's packed parameters, per wave the normalisers / posteriors of a tile,
-    // then the workgroup's statistics [64 components][16 NQT columns] in fp64: a wave
-    // sums at most kAfMaxFramesPerWave frames in its float32 accumulators (the matrix
-    // core's truncating accumulate, see kAxMaxFrames), adds them here (ds_add_f64) and
-    // starts again; the image meets the other workgroups' in global memory ONCE, when the
-    // workgroup has walked its whole block of frames.  (Round 3 ended a workgroup after
-    // 1024 frames per wave: 407 blocks of frames x 30 chunks, each with its parameter load,
-    // an LDS reduction across its waves and 6144 global atomics -- 0.8 of 11.2 ms.)
+    // LDS: the chunk's packed parameters, then per wave the normalisers / posteriors of a tile
     constexpr int p_u4 = NKU * NTC * kBlockU4;
     u4* Ps = reinterpret_cast<u4*>(smem);
     float* lsw = reinterpret_cast<float*>(Ps + p_u4) + wave * (2 * FW * 4);
-    double* Sw = reinterpret_cast<double*>(reinterpret_cast<float*>(Ps + p_u4) + WAVES * (2 * FW * 4));
-    constexpr int kSwLd = 16 * NQT + 2;                   // row stride (doubles)
-    for (int idx = tid; idx < 16 * NTC * kSwLd; idx += NTHREADS) Sw[idx] = 0.0;
     {
         const u4* src = Pall + (size_t)by * nk * NTC * kBlockU4;
         for (int idx = tid; idx < p_u4; idx += NTHREADS) Ps[idx] = src[idx];
@@ -1645,24 +1635,7 @@ __global__ __launch_bounds__(512, 2) void accfi_kernel(
     u4 af[2][NP][MT];
     u4 bq[3][NP];
     bool a0_ready = false;
-    // rows of the lane's accumulators in Sw: component slot 4 (4 g + r) + c, column 16 uu + i
-    auto spill = [&]() {
-#pragma unroll
-        for (int c = 0; c < NTC; ++c)
-#pragma unroll
-            for (int uu = 0; uu < NQT; ++uu)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    atomicAdd(Sw + (4 * (4 * g + r) + c) * kSwLd + 16 * uu + i, (double)sacc[c][uu][r]);
-                    sacc[c][uu][r] = 0.f;
-                }
-    };
-    // (the spill sits outside the tile loop: inside it, its 96 conversions competed with the
-    // loop's registers)
-    for (int64_t fbc = fb0; fbc < te; fbc += (int64_t)(kAfMaxFramesPerWave / FW) * WAVES * FW) {
-    const int64_t ce = fbc + (int64_t)(kAfMaxFramesPerWave / FW) * WAVES * FW < te
-                           ? fbc + (int64_t)(kAfMaxFramesPerWave / FW) * WAVES * FW : te;
-    for (int64_t fb = fbc; fb < ce; fb += WAVES * FW) {
+    for (int64_t fb = fb0; fb < te; fb += WAVES * FW) {
         const int rows = (int)(te - fb < FW ? te - fb : FW);
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
@@ -1787,8 +1760,6 @@ __global__ __launch_bounds__(512, 2) void accfi_kernel(
             __builtin_amdgcn_sched_group_barrier(0x008, 6 * NTC, 0);
         }
     }
-    spill();
-    }
 
     // ---- flush: the waves' partial sums through LDS (fp64), one atomic per element ----
     if (BEER_AFI_ABL & 2) {
@@ -1801,11 +1772,36 @@ __global__ __launch_bounds__(512, 2) void accfi_kernel(
         return;
     }
     __syncthreads();
-    for (int idx = tid; idx < 16 * NTC * 16 * NQT; idx += NTHREADS) {
-        const int row = idx / (16 * NQT), q = idx - row * (16 * NQT);
-        const int slot = kbase + row, gi = slot % G;
-        if (slot < K && gi < Greal && q < nq)
-            atomicAdd(Sp + (int64_t)((slot / G) * Greal + gi) * nq + q, Sw[row * kSwLd + q]);
+    float* red = reinterpret_cast<float*>(smem);          // [WAVES][16 = c * 4 + r][64 lanes]
+    constexpr int EPT = 16 * 64 / NTHREADS;
+    int64_t dst_row[EPT];
+    int dst_i[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int el = tid + e * NTHREADS, j = el >> 6, ln = el & 63;
+        const int c = j >> 2, r = j & 3, gg = ln >> 4;
+        const int slot = kbase + 64 * (c >> 2) + 4 * (4 * gg + r) + (c & 3);
+        const int gi = slot % G;
+        dst_row[e] = slot < K && gi < Greal ? (int64_t)((slot / G) * Greal + gi) * nq : -1;
+        dst_i[e] = ln & 15;
+    }
+#pragma unroll
+    for (int uu = 0; uu < NQT; ++uu) {
+#pragma unroll
+        for (int c = 0; c < NTC; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * 16 + c * 4 + r) * 64 + lane] = sacc[c][uu][r];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int el = tid + e * NTHREADS;
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) t += (double)red[w * 1024 + el];
+            const int q = 16 * uu + dst_i[e];
+            if (dst_row[e] >= 0 && q < nq) atomicAdd(Sp + dst_row[e] + q, t);
+        }
+        __syncthreads();
     }
 }
 
@@ -2253,35 +2249,17 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
                            sizeof(float);
     const dim3 grid(xcd_grid(gz, nchunks, nchunks));
     if (image && blk && waves == 8 && supported_frame_image(cov, D)) {
-        // every fragment that depends on the frames only comes from the caller's image.
-        // Frame blocks: the workgroups keep their sums in LDS however long their block is,
-        // so the grid is whole rounds of one workgroup per CU -- the number of rounds (4 ..
-        // 16) that leaves the fewest idle slots in the last one.
-        int64_t gzi = 8;
-        double best = 1e30;
-        for (int r = 4; r <= 16; ++r) {
-            int64_t z = ((int64_t)256 * r / nchunks) / 8 * 8;
-            if (z < 8) z = 8;
-            const int64_t wgs = z * nchunks, slots = (wgs + 255) / 256 * 256;
-            const double waste = (double)slots / (double)wgs + 0.002 * r;
-            if (waste < best) { best = waste; gzi = z; }
-        }
-        const int64_t max_zi = (nframes + 32 * waves - 1) / (32 * waves);
-        if (gzi > max_zi) gzi = max_zi;
-        if (gzi < 1) gzi = 1;
-        int64_t fpbi = (nframes + gzi - 1) / gzi;
-        fpbi = (fpbi + 32 * waves - 1) / (32 * waves) * (32 * waves);
-        gzi = (nframes + fpbi - 1) / fpbi;
-        const dim3 gridi(xcd_grid(gzi, nchunks, nchunks));
-        const size_t lds_f = (size_t)nk_used * NTC * kBlockU4 * 16 + (size_t)waves * 256 * sizeof(float) +
-                             (size_t)16 * NTC * (16 * NQT + 2) * sizeof(double);
+        // every fragment that depends on the frames only comes from the caller's image
+        const size_t lds_i = (size_t)nk_used * NTC * kBlockU4 * 16 + (size_t)waves * 256 * sizeof(float);
+        const size_t lds_red = (size_t)waves * 16 * 64 * sizeof(float);
+        const size_t lds_f = lds_i > lds_red ? lds_i : lds_red;
 #define BEER_ACCFI(NKU_)                                                                         \
     do {                                                                                         \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(accfi_kernel<NKU_>),             \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);       \
-        hipLaunchKernelGGL((accfi_kernel<NKU_>), gridi, dim3(512), lds_f, s, nframes, K, S, G,    \
+        hipLaunchKernelGGL((accfi_kernel<NKU_>), grid, dim3(512), lds_f, s, nframes, K, S, G,     \
                            Greal, nk, nslab, reinterpret_cast<const u4*>(image),                 \
-                           reinterpret_cast<const u4*>(P), log_norm, sr, fpbi, Sp, c0);          \
+                           reinterpret_cast<const u4*>(P), log_norm, sr, fpb, Sp, c0);           \
     } while (0)
         if (nk_used == 1) BEER_ACCFI(1); else if (nk_used == 2) BEER_ACCFI(2); else BEER_ACCFI(3);
 #undef BEER_ACCFI
