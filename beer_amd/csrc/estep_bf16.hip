@@ -191,13 +191,16 @@ __global__ __launch_bounds__(256) void packx_kernel(int cov, int D, int K, int N
                                                     const float* __restrict__ logw,
                                                     unsigned short* __restrict__ P,
                                                     int* __restrict__ tab, int G, int Gp,
-                                                    const float* __restrict__ c0) {
+                                                    const float* __restrict__ c0, int lane_major) {
     extern __shared__ __attribute__((aligned(16))) char pack_lds[];
     const int nk = nk16_of(cov, D), nent = nk * 32;
     const int slot = blockIdx.x;
     const int k = slot % Gp < G ? (slot / Gp) * G + slot % Gp : K;     // K: a padded slot
     const int chunk = slot / (NT * 16), kk = slot % (NT * 16);
-    const int c = 4 * (kk / 64) + (kk % 4), i = (kk % 64) / 4;
+    // column i of tile c: 4 consecutive slots per lane and block of 64, or (lane_major) NT
+    // consecutive slots per lane -- see lognorm_epilogue_lane_major
+    const int c = lane_major ? kk % NT : 4 * (kk / 64) + (kk % 4);
+    const int i = lane_major ? kk / NT : (kk % 64) / 4;
     if (slot == 0)
         for (int s = threadIdx.x; s < (nk + 1) * 8; s += blockDim.x) {
             // padding slabs read the zero columns behind the constants of a frame row
@@ -561,7 +564,19 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
         return;
     }
     if constexpr (LNO) {
-        // (jw == 4 by construction of the dispatch; gl = lanes per group, uniform)
+        // (jw == 4 by construction of the dispatch; gl = lanes per group, uniform; 0: the
+        // image is lane-major, a group is G <= 16 registers of one lane)
+        if constexpr (NT == 16 && GQ == 1) {
+            if (gl == 0) {
+                if (G == 4)
+                    lognorm_epilogue_lane_major<NT, MT, 4>(acc, fb, nframes, kbase, S, i, g, lane, log_norm, llh_sum, c0[0]);
+                else if (G == 8)
+                    lognorm_epilogue_lane_major<NT, MT, 8>(acc, fb, nframes, kbase, S, i, g, lane, log_norm, llh_sum, c0[0]);
+                else
+                    lognorm_epilogue_lane_major<NT, MT, 16>(acc, fb, nframes, kbase, S, i, g, lane, log_norm, llh_sum, c0[0]);
+                return;
+            }
+        }
 #define BEER_LN(GL_) lognorm_epilogue<NT, MT, GQ, GL_>(acc, fb, nframes, kbase, S, G, i, g, lane, \
                                                        log_norm, llh_sum, c0[0])
         switch (gl) {
@@ -1947,9 +1962,12 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
     w += up256((size_t)(nk + 1) * 8 * sizeof(int));
     float* c0 = reinterpret_cast<float*>(w);
     hipLaunchKernelGGL(const_max_kernel, dim3(1), dim3(256), 0, s, cov, D, Kreal, expT, logw, c0);
+    // log-normalisers only, groups of 4 / 8 / 16: the image is dealt out lane-major and the
+    // log-sum-exp of a state stays inside a lane (lognorm_epilogue_lane_major)
+    const bool lane_major = S > 1 && !resps && !packed && NT == 16 && (G == 4 || G == 8 || G == 16);
     hipLaunchKernelGGL(packx_kernel, dim3(kpad), dim3(256),
                        (size_t)stats_dim(cov, D) * sizeof(float), s, cov, D, Kreal, NT, expT, logw,
-                       reinterpret_cast<unsigned short*>(P), tab, Greal, G, c0);
+                       reinterpret_cast<unsigned short*>(P), tab, Greal, G, c0, lane_major ? 1 : 0);
     BEER_LAUNCH_CHECK();
     const bool full = cov == BEER_FULL;
 #define BEER_LLHX(NT_, MT_, GQ_, PK_, LNO_, ...)                                                  \
@@ -1988,7 +2006,7 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
         BEER_LLHX(16, 2, 4, false, false);
     }
     const int jw = G < 4 ? G : 4;
-    const int gl = G < 4 ? 1 : (G < 64 ? G / 4 : 16);
+    const int gl = lane_major ? 0 : (G < 4 ? 1 : (G < 64 ? G / 4 : 16));
     const int gq = G <= 64 ? 1 : G / 64;
     if (packed) {
         // the responsibilities within each state's mixture as the accumulation's LDS tiles
@@ -2217,7 +2235,7 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
     hipLaunchKernelGGL(const_max_kernel, dim3(1), dim3(256), 0, s, cov, D, Kreal, expT, logw, c0);
     hipLaunchKernelGGL(packx_kernel, dim3(kpad), dim3(256),
                        (size_t)stats_dim(cov, D) * sizeof(float), s, cov, D, Kreal, NTC, expT, logw,
-                       reinterpret_cast<unsigned short*>(P), tab, Greal, G, c0);
+                       reinterpret_cast<unsigned short*>(P), tab, Greal, G, c0, 0);
     BEER_LAUNCH_CHECK();
     // The states of every 64-component chunk fit a block of 4 consecutive ones?
     // (groups are padded to a multiple of 4: a lane's 4 components share their state)

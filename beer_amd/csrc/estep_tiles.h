@@ -562,4 +562,60 @@ __device__ __forceinline__ void lognorm_epilogue(
     }
 }
 
+// ... and for groups that live INSIDE a lane.  With NT = 16 column tiles a lane holds 16
+// logits per frame row; when the packed image deals the components out lane-major (lane
+// column i: component slots 16 i .. 16 i + 15 of the chunk, slot 16 i + c in tile c --
+// packx_kernel's `lane_major`) a state's G <= 16 Gaussians are 16 / G runs of G registers
+// of ONE lane: the log-sum-exp needs no cross-lane step at all (the layout above spends
+// two DPP stages with their wait states per group and row, and a predicated store per
+// group), the maxima come three at a time (v_max3), and the change of base folds into the
+// subtraction: 2^(a L + nm) with nm = fl(-mx L) is 2^((a - mx) L) times 2^d, d = mx L + nm
+// the EXACT rounding error of nm (one fma), taken out of the logarithm again.  Per logit:
+// fma, exp, add (+ half a max) instead of max, sub, mul, exp, add and the shuffles.
+template <int NT, int MT, int G>
+__device__ __forceinline__ void lognorm_epilogue_lane_major(
+    f32x4 (&acc)[MT][NT], int64_t fb, int64_t nframes, int kbase, int S, int i, int g, int lane,
+    float* __restrict__ log_norm, double* __restrict__ llh_sum, float shift) {
+    static_assert(NT == 16 && (G == 4 || G == 8 || G == 16), "16 logits per lane and row, whole groups");
+    constexpr int NG = NT / G;
+    constexpr float L2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+    const int s0 = (kbase + NT * i) / G;                 // the lane's first state
+    double llh_local = 0.0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            __builtin_amdgcn_sched_barrier(0);           // (one row at a time: registers)
+            const int64_t f = fb + m * 16 + 4 * g + r;
+            const bool ok = f < nframes;
+            float* row = log_norm + (ok ? f : 0) * S + s0;
+            float rowsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                float mx = acc[m][q * G][r];
+#pragma unroll
+                for (int c = 1; c + 1 < G; c += 2)
+                    mx = __builtin_fmaxf(__builtin_fmaxf(mx, acc[m][q * G + c][r]), acc[m][q * G + c + 1][r]);
+                mx = __builtin_fmaxf(mx, acc[m][q * G + G - 1][r]);
+                const float nm = -mx * L2E;
+                const float d = __builtin_fmaf(mx, L2E, nm);
+                float sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < G; ++c)
+                    sum += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[m][q * G + c][r], L2E, nm));
+                const float lse = __builtin_fmaf(__builtin_amdgcn_logf(sum) - d, LN2, mx) + shift;
+                if (ok && s0 + q < S) {
+                    if (log_norm) row[q] = lse;
+                    rowsum += lse;
+                }
+            }
+            llh_local += (double)rowsum;
+        }
+    }
+    if (llh_sum) {
+        llh_local = wave_sum(llh_local);
+        if (lane == 0) atomicAdd(llh_sum, llh_local);
+    }
+}
+
 }  // namespace beer_mfma
