@@ -28,7 +28,15 @@ class HipUnavailable(RuntimeError):
 
 
 class HipError(RuntimeError):
-    pass
+    'A call into libbeer_hip.so failed; `rc` is its status (-(hipError_t) for launch errors).'
+    rc = None
+
+
+class HipInvalid(HipError):
+    '''BEER_EINVAL: the library refused the arguments (a shape this entry point does not
+    take) before launching anything.  The only failure a caller may answer by trying
+    another entry point; launch errors are plain `HipError`s and must propagate.'''
+    rc = EINVAL
 
 
 _lib = None
@@ -44,7 +52,41 @@ def lib():
                 '(beer_amd has no CPU fallback)')
         _lib = ctypes.CDLL(LIB_PATH)
         _declare(_lib)
+        _options_from_env(_lib)
     return _lib
+
+
+# BEER_OPT_* of include/beer_hip.h and the environment variables that preset them
+OPTIONS = {'ax_max_frames': (0, 'BEER_AX_MAXFRAMES'), 'accf_rounds': (1, 'BEER_ACCF_ROUNDS'),
+           'k1_wide': (2, 'BEER_K1_WIDE')}
+
+
+def _options_from_env(l):
+    for name, (code, env) in OPTIONS.items():
+        text = os.environ.get(env)
+        if text is None:
+            continue
+        try:
+            value = int(text)
+        except ValueError:
+            raise ValueError(f'{env}={text!r}: expected an integer') from None
+        if l.beer_hip_set_option(code, value) != 0:
+            raise ValueError(f'{env}={value}: outside the range of option {name!r} '
+                             '(include/beer_hip.h)')
+
+
+def set_option(name, value):
+    '''Set a launch-tuning option of the library (`OPTIONS`; include/beer_hip.h
+    BEER_OPT_*); returns the previous value.  Out-of-range values raise.'''
+    code = OPTIONS[name][0]
+    old = lib().beer_hip_get_option(code)
+    if lib().beer_hip_set_option(code, int(value)) != 0:
+        raise ValueError(f'option {name!r}: value {value} out of range')
+    return old
+
+
+def get_option(name):
+    return lib().beer_hip_get_option(OPTIONS[name][0])
 
 
 c_p, c_i, c_l, c_d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
@@ -103,6 +145,8 @@ _gam = [c_i, c_i, c_p, c_p, c_p, c_p]
 SIGNATURES = {
     'beer_hip_version': [],
     'beer_hip_device_count': [],
+    'beer_hip_set_option': [c_i, c_i],
+    'beer_hip_get_option': [c_i],
     'beer_mixtureset_packed_supported': [c_i, c_i, c_i, c_i],
     'beer_nw_expected_stats': _four, 'beer_nw_log_norm': _four, 'beer_nw_natural': _four,
     'beer_nw_from_natural': _from,
@@ -250,9 +294,12 @@ def stream():
 def call(name, *args):
     'Call an entry point on the current torch stream and check its status.'
     rc = getattr(lib(), name)(*args, stream())
+    if rc == EINVAL:
+        raise HipInvalid(f'{name} failed: invalid argument')
     if rc != 0:
-        what = 'invalid argument' if rc == EINVAL else f'hipError {-rc}'
-        raise HipError(f'{name} failed: {what}')
+        err = HipError(f'{name} failed: hipError {-rc}')
+        err.rc = rc
+        raise err
 
 
 EXACT = 0x10                # BEER_EXACT of include/beer_hip.h: `dtype | EXACT`
@@ -307,7 +354,7 @@ def call_host(name, *args):
     'Call a host-side entry point (no stream, works without a GPU).'
     rc = getattr(lib(), name)(*args)
     if rc != 0:
-        raise HipError(f'{name} failed: invalid argument')
+        raise HipInvalid(f'{name} failed: invalid argument')
 
 
 _workspaces = {}

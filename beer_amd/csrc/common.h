@@ -33,6 +33,16 @@ static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
 namespace beer {
 
+// current value of a BEER_OPT_* tuning option (util.hip)
+int option(int key);
+constexpr int kAxMaxFramesDefault = 4096;   // BEER_OPT_AX_MAXFRAMES (estep_bf16.hip: accx_kernel)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the KERNEL, not of a
+// launch: every launch site sets it to the same value (a CU's whole LDS), so host
+// threads that share a kernel cannot lower each other's limit between the attribute
+// call and the launch.
+constexpr int kMaxDynLds = 160 * 1024;
+
 constexpr double kLog2Pi = 1.8378770664093453;
 constexpr double kLog2 = 0.6931471805599453;
 constexpr double kLogPi = 1.1447298858494002;

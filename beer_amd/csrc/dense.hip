@@ -586,7 +586,7 @@ int suffstats_backward_launch(int cov, int64_t T_, int ns, int D, const void* X,
         const size_t lds = 4 * ((size_t)D * (D + 1) + 2 * D) * sizeof(T);
         const int64_t wgs = (T_ + 3) / 4;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(suffstats_backward_full_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);
         hipLaunchKernelGGL(suffstats_backward_full_kernel<T>,
                            dim3((unsigned)(wgs > 65536 ? 65536 : wgs)), dim3(256), lds,
                            as_stream(stream), T_, ns, D, (const T*)X, (const T*)gs, (T*)gx);

@@ -614,7 +614,7 @@ int launch_llhx(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int
     const int cg = xcd_chunk_group(nchunks, (size_t)nku * NT * kBlockU4 * 16);
     (void)hipFuncSetAttribute(
         reinterpret_cast<const void*>(llhx_kernel<NT, MT, GQ, PACKED, SQ, LNO, IMG>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);
     hipLaunchKernelGGL((llhx_kernel<NT, MT, GQ, PACKED, SQ, LNO, IMG>),
                        dim3(nchunks > 1 ? xcd_grid(blocks, nchunks, cg) : (unsigned)blocks),
                        dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nk, X,
@@ -635,7 +635,7 @@ int launch_llhx(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int
 // tiles (256 accumulators): A fragments = three ds_read_b128 per component tile,
 // loaded once per k-step and reused by the 8 statistic tiles; B fragments =
 // products of two X^T rows over the lane's 8 frames, split on the fly, reused by
-// the 8 component tiles.  A workgroup sums at most kAxMaxFrames frames in fp32 --
+// the 8 component tiles.  A workgroup sums at most BEER_OPT_AX_MAXFRAMES frames in fp32 --
 // one rounding per 32-frame MFMA -- and adds its partial sums to the fp64 image
 // with atomics.
 // SR (mixture sets): the tiles hold the responsibilities WITHIN each state's
@@ -659,7 +659,7 @@ constexpr int kAxXS = kAxFT + 4;      // X^T row stride (floats), 16-byte aligne
 // 1024 frames, -3.3e-7 with 4096, -1.5e-6 with 16384.  4096 it is; the partial sums of the
 // workgroups are added in fp64 (the flush costs 0.1 ms per 1 M frames and 2048 frames of
 // chain at K = 256).
-constexpr int kAxMaxFrames = 4096;
+// (the chain length: BEER_OPT_AX_MAXFRAMES, default beer::kAxMaxFramesDefault = 4096)
 constexpr int kPiece = 4096;          // granule of the X^T image (bytes)
 constexpr int kAxMC = 8, kAxNQ = 8, kAxWaves = 4;
 
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(256) void pack_resps_kernel(int64_t nframes, int K,
 // frame tiles it walks (fp32, <= 4096 frames), then adds it to the fp64 image.
 // ---------------------------------------------------------------------------
 constexpr int kAfXS = 36;                 // row stride (floats) of the transposed frame tile
-constexpr int kAfMaxFramesPerWave = 1024; // MFMA accumulations per sum: 32 (see kAxMaxFrames)
+constexpr int kAfMaxFramesPerWave = 1024; // MFMA accumulations per sum: 32 (see BEER_OPT_AX_MAXFRAMES)
 
 // BLK: the states of a 64-component chunk are at most 4 consecutive ones (G >= 16): a
 // lane fetches the 4 normalisers or posteriors of one frame row in one go, ONE TILE
@@ -1954,6 +1954,11 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
     const int K = S * G;
     const int NT = ntx_for(S, K), nchunks = nchunksx_for(S, K), nk = nk16_of(cov, D);
     const int kpad = nchunks * NT * 16;
+    // a frame fragment image: mixture sets, log-normalisers only, groups of >= 4 (refused
+    // here, before anything is launched)
+    if (image && (S == 1 || packed || resps || G < 4 || cov == BEER_FULL ||
+                  !supported_frame_image(cov, D)))
+        return BEER_EINVAL;
     g_cov_of_launch = cov;
     char* w = reinterpret_cast<char*>(ws);
     void* P = w;
@@ -1997,7 +2002,7 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
             // 2.3 ms for 64 x 256 per wave with one wave per SIMD (BEER_K1_WIDE=1), whose
             // hand-placed main loop runs at 90 % of the MFMA rate but whose epilogue, 0.4 ms,
             // nothing covers.
-            static const bool wide = [] { const char* e = getenv("BEER_K1_WIDE"); return e && atoi(e); }();
+            const bool wide = beer::option(BEER_OPT_K1_WIDE) != 0;
             if (wide) BEER_LLHX(16, 4, 4, true, false, xt, xtf);
             BEER_LLHX(16, 2, 4, true, false, xt, xtf);
         }
@@ -2010,7 +2015,7 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
     const int gq = G <= 64 ? 1 : G / 64;
     if (packed) {
         // the responsibilities within each state's mixture as the accumulation's LDS tiles
-        static const bool wide = [] { const char* e = getenv("BEER_K1_WIDE"); return e && atoi(e); }();
+        const bool wide = beer::option(BEER_OPT_K1_WIDE) != 0;
         if (wide) {
             switch (gq) {
                 case 1: BEER_LLHX(16, 4, 1, true, false);
@@ -2022,7 +2027,6 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
             default: BEER_LLHX(16, 2, 2, true, false);
         }
     }
-    if (image && (resps || jw != 4 || full || !supported_frame_image(cov, D))) return BEER_EINVAL;
     if (image) {
         // ... with the A fragments from the caller's frame fragment image
 #define BEER_LNI(GQ_)                                                                            \
@@ -2125,8 +2129,8 @@ int acc_bf16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, co
     const int gx = (ntiles + kAxNQ * kAxWaves - 1) / (kAxNQ * kAxWaves);
     const int gy = (K + 16 * kAxMC - 1) / (16 * kAxMC);
     // one workgroup per CU (120 KB of LDS, 512 registers per lane): whole rounds of 256
-    // workgroups, at most kAxMaxFrames frames each
-    static const int chain = [] { const char* e = getenv("BEER_AX_MAXFRAMES"); return e ? atoi(e) : kAxMaxFrames; }();
+    // workgroups, at most BEER_OPT_AX_MAXFRAMES frames each
+    const int chain = beer::option(BEER_OPT_AX_MAXFRAMES);
     const int64_t max_z = (nframes + 511) / 512, min_z = (nframes + chain - 1) / chain;
     const int64_t rounds = ((int64_t)gx * gy * min_z + 255) / 256;
     int64_t gz = rounds * 256 / ((int64_t)gx * gy);
@@ -2143,7 +2147,7 @@ int acc_bf16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, co
 #define BEER_ACCX(SR_)                                                                           \
     do {                                                                                         \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(accx_kernel<SR_>),               \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);         \
         hipLaunchKernelGGL((accx_kernel<SR_>), grid, dim3(64 * kAxWaves), lds, s, nframes, D, K, \
                            nslab, NX, Xt, reinterpret_cast<const unsigned*>(Rimg), tab, fpb, Sp, \
                            gx, gy, (int)gz, Gt, lgG);                                            \
@@ -2249,7 +2253,7 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
     const int waves = (NTC == 4 && NQT == 6) ? 8 : 4;
     // frames per workgroup: <= kAfMaxFramesPerWave per wave, about one workgroup of
     // 8 waves (two of 4) per CU and round
-    static const int rounds = [] { const char* e = getenv("BEER_ACCF_ROUNDS"); return e ? atoi(e) : 6; }();
+    const int rounds = beer::option(BEER_OPT_ACCF_ROUNDS);
     int64_t gz = ((waves == 8 ? 256 : 512) * rounds + nchunks - 1) / nchunks;
     gz = (gz + 7) / 8 * 8;                       // whole rows of the XCD-aware grid
     const int64_t min_z = (nframes + (int64_t)waves * kAfMaxFramesPerWave - 1) /
@@ -2274,7 +2278,7 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
 #define BEER_ACCFI(NKU_)                                                                         \
     do {                                                                                         \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(accfi_kernel<NKU_>),             \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);       \
         hipLaunchKernelGGL((accfi_kernel<NKU_>), grid, dim3(512), lds_f, s, nframes, K, S, G,     \
                            Greal, nk, nslab, reinterpret_cast<const u4*>(image),                 \
                            reinterpret_cast<const u4*>(P), log_norm, sr, fpb, Sp, c0);           \
@@ -2293,7 +2297,7 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
         constexpr int XP_ = NQT_ == 6 ? 5 : 8;      /* D <= 40 <=> C4 <= 10 <=> nq <= 96 */       \
         (void)hipFuncSetAttribute(                                                               \
             reinterpret_cast<const void*>(accf_kernel<NTC_, NQT_, true, W_, XP_, BLK_>),         \
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+            hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);                               \
         hipLaunchKernelGGL((accf_kernel<NTC_, NQT_, true, W_, XP_, BLK_>), grid, dim3(64 * W_),  \
                            lds, s, nframes, D, K, S, G, Greal, nk, nslab, X,                     \
                            reinterpret_cast<const u4*>(P), tab, log_norm, sr, fpb, Sp, c0);      \

@@ -496,7 +496,7 @@ int acc_impl(int cov, int64_t nframes, int D, int S, int G, const T* X, const T*
 #define BEER_ACC(NQ_, SR_)                                                                      \
     do {                                                                                        \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(acc_kernel<T, NQ_, SR_>),       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);        \
         hipLaunchKernelGGL((acc_kernel<T, NQ_, SR_>), grid, dim3(kThreads), lds, s, nframes, D, \
                            K, G, S, nslab, X, R, SR, tab, fpb, Sp);                             \
     } while (0)

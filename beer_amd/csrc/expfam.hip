@@ -517,18 +517,18 @@ int nw_launch(int which, int K, int D, const void* mean, const void* scale,
     hipStream_t s = as_stream(stream);
     if (which == 0) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nw_expected_stats_kernel<T>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);
         hipLaunchKernelGGL(nw_expected_stats_kernel<T>, dim3(K), dim3(nw_threads(K, D)), lds, s, D,
                            (const T*)mean, (const T*)scale, (const T*)W, (const T*)dof, (T*)out,
                            (T*)lnorm);
     } else if (which == 1) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nw_log_norm_kernel<T>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);
         hipLaunchKernelGGL(nw_log_norm_kernel<T>, dim3(K), dim3(nw_threads(K, D)), lds, s, D,
                            (const T*)scale, (const T*)W, (const T*)dof, (T*)out);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nw_natural_kernel<T>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);
         hipLaunchKernelGGL(nw_natural_kernel<T>, dim3(K), dim3(nw_threads(K, D)), lds, s, D,
                            (const T*)mean, (const T*)scale, (const T*)W, (const T*)dof, (T*)out);
     }
@@ -543,7 +543,7 @@ int nw_from_natural_launch(int K, int D, const void* eta, void* mean, void* scal
     if (K == 0) return BEER_OK;
     const size_t lds = ((size_t)D * D + 4 * D + 16) * sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nw_from_natural_kernel<T>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);
     hipLaunchKernelGGL(nw_from_natural_kernel<T>, dim3(K), dim3(nw_threads(K, D)), lds,
                        as_stream(stream), D, (const T*)eta, (T*)mean, (T*)scale, (T*)W, (T*)dof);
     BEER_LAUNCH_CHECK();
@@ -558,7 +558,7 @@ int nw_update_launch(int K, int D, const void* eta, void* mean, void* scale, voi
     BEER_REQUIRE(eta && mean && scale && W && dof && out && lnorm);
     const size_t lds = ((size_t)D * D + 4 * D + 16) * sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nw_update_kernel<T>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);
     hipLaunchKernelGGL(nw_update_kernel<T>, dim3(K), dim3(nw_threads(K, D)), lds,
                        as_stream(stream), D, (const T*)eta, (T*)mean, (T*)scale, (T*)W, (T*)dof,
                        (T*)out, (T*)lnorm, (T*)moments);

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(kLdThreads) void fb_lowdeg_kernel(
     T* __restrict__ gamma, double* __restrict__ xi_sum, double* __restrict__ gamma0_sum,
     double* __restrict__ hub_flow, T* __restrict__ lognorm_mean) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int u = blockIdx.x, tid = threadIdx.x, nt_ = blockDim.x, lane = tid & 63;
+    const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const beer_graph g = b.graphs[b.graph_id[u]];
     const beer_graph_lowdeg L = *g.lowdeg;
@@ -1859,7 +1859,7 @@ int beer_hmm_forward_backward(int dtype, const beer_batch* b, const void* pc_llh
 #define BEER_FB(T_, BIG_, LDS_, GRID_)                                                           \
     do {                                                                                         \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fb_kernel<T_, BIG_>),            \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_));      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);      \
         hipLaunchKernelGGL((fb_kernel<T_, BIG_>), dim3(GRID_), dim3(kFbThreads), LDS_, s, *b,    \
                            (const T_*)pc_llhs, alpha_ws, (T_*)gamma, xi_sum, gamma0_sum,         \
                            (T_*)lognorm_mean, hub_ws);                                           \
@@ -1923,12 +1923,12 @@ int beer_hmm_viterbi(int dtype, const beer_batch* b, const void* pc_llhs, int32_
     const int vthreads = 4 * b->max_states <= kViterbiThreads ? kViterbiThreads : kHmmThreads;
     if (dtype == BEER_F32) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(viterbi_kernel<float>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);
         hipLaunchKernelGGL(viterbi_kernel<float>, dim3(b->nutt), dim3(vthreads), lds, s, *b,
                            (const float*)pc_llhs, bt_ws, path, map_pdf, arcs_in_lds);
     } else if (dtype == BEER_F64) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(viterbi_kernel<double>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);
         hipLaunchKernelGGL(viterbi_kernel<double>, dim3(b->nutt), dim3(vthreads), lds, s, *b,
                            (const double*)pc_llhs, bt_ws, path, map_pdf, arcs_in_lds);
     } else {

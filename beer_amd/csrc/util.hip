@@ -1,6 +1,23 @@
 // Small device utilities of the host layer.
 
+#include <atomic>
+
 #include "common.h"
+
+namespace beer {
+// Tuning options (beer_hip_set_option): process-wide, read at launch time by the host
+// code of the kernels they tune.  The defaults are what the parity suite validates.
+namespace {
+struct OptSpec { int def, lo, hi; };
+constexpr OptSpec kOptSpec[BEER_OPT_COUNT] = {
+    {kAxMaxFramesDefault, 64, 1 << 20},      // BEER_OPT_AX_MAXFRAMES
+    {6, 1, 64},               // BEER_OPT_ACCF_ROUNDS
+    {0, 0, 1},                // BEER_OPT_K1_WIDE
+};
+std::atomic<int> g_opt[BEER_OPT_COUNT] = {{kOptSpec[0].def}, {kOptSpec[1].def}, {kOptSpec[2].def}};
+}  // namespace
+int option(int key) { return g_opt[key].load(std::memory_order_relaxed); }
+}  // namespace beer
 
 namespace {
 
@@ -13,6 +30,19 @@ __global__ void copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ d
 }  // namespace
 
 extern "C" {
+
+int beer_hip_set_option(int option, int value) {
+    if (option < 0 || option >= BEER_OPT_COUNT) return BEER_EINVAL;
+    const auto& sp = beer::kOptSpec[option];
+    if (value < sp.lo || value > sp.hi) return BEER_EINVAL;
+    beer::g_opt[option].store(value, std::memory_order_relaxed);
+    return BEER_OK;
+}
+
+int beer_hip_get_option(int option) {
+    if (option < 0 || option >= BEER_OPT_COUNT) return BEER_EINVAL;
+    return beer::option(option);
+}
 
 int beer_copy_pinned(void* dst_device, const void* src_pinned_host, size_t nbytes, void* stream) {
     if (nbytes == 0) return BEER_OK;

@@ -90,8 +90,8 @@ def mixtureset_estep(stats, exp_stats, log_weights, S, G, cov_type, labels=None,
                           _hip.ptr(X), _hip.ptr(E), _hip.ptr(lw), _hip.ptr(img),
                           _hip.ptr(log_norm), _hip.ptr(llh_sum), _hip.ptr(ws), ws_bytes)
                 return log_norm, None
-            except _hip.HipError:
-                pass                                   # (a shape the image kernels do not take)
+            except _hip.HipInvalid:
+                pass          # a shape the image kernels do not take (refused before any launch)
 
     def launch(resps):
         _hip.call('beer_mixtureset_estep', _hip.dtype_code(X.dtype, exact),
@@ -100,7 +100,7 @@ def mixtureset_estep(stats, exp_stats, log_weights, S, G, cov_type, labels=None,
                   _hip.ptr(llh_sum), _hip.ptr(ws), ws_bytes)
     try:
         launch(resps)
-    except _hip.HipError:
+    except _hip.HipInvalid:
         # `on_matrix_cores` above restates the library's own dispatch; should the two
         # ever disagree, the library refuses a G > 1 call without a responsibilities
         # buffer (the generic kernels normalise in it): give it one

@@ -255,10 +255,37 @@ def cpu_baseline_gmm(frames_target=1 << 20, chunk=8192, budget_s=15.):
     tp.gmm_update(post, prior, w, w, acc_n * (n / done), acc_w * (n / done), D)
     dt = time.perf_counter() - t0
     return {'value': done / dt, 'unit': 'frames/s', 'cores': int(torch.get_num_threads()),
-            'kind': 'port',
+            **host_cores(), 'kind': 'port',
             'sample': f'{done} frames of the config-2 workload (K=256 full-cov, D=40, fp32) in '
                       f'{chunk}-frame utterances + 1 M-step, torch-CPU replay of the '
                       f'reference op sequence, {dt:.1f} s'}
+
+
+def host_cores():
+    '''The host the CPU baseline ran on: hardware threads, physical cores and sockets
+    (/proc/cpuinfo); `cores` of a cpu_baseline is the number of threads the baseline
+    actually used (the best of the thread counts probed), these say out of how many.'''
+    out = {'host_threads': os.cpu_count() or 1}
+    try:
+        phys, sockets = set(), set()
+        pid = cid = None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                pid = line.split(':')[1].strip()
+                sockets.add(pid)
+            elif line.startswith('core id'):
+                cid = line.split(':')[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+        if phys:
+            out['host_cores'] = len(phys)
+            out['host_sockets'] = len(sockets)
+            out['host_cores_per_socket'] = len(phys) // max(1, len(sockets))
+    except OSError:
+        pass
+    return out
 
 
 def cpu_baseline_features(signals, conf=None):
@@ -286,8 +313,11 @@ def cpu_baseline_graph_compile(sequences, units, graph_cls):
 
 def gmm_parity_check(model, X, n=65536, chunk=8192):
     '''The kernels the timed loop runs (packed hand-over: n >= 16384 frames) against
-    the fp64 numpy oracle on the same frames: relative error of the ELBO and of the
-    accumulated statistics.'''
+    the fp64 numpy oracle on the same frames, in BOTH float32 arithmetics: relative error of
+    the ELBO and of the accumulated statistics -- the whole array and per block (counts,
+    first moments, second moments, each against its own largest entry) plus the mean
+    relative bias of the counts (the matrix core's truncating accumulate shows there
+    first).  Returns {mode: {...}}.'''
     from oracle import beer_oracle as orc
     p0, p1 = list(model.bayesian_parameters())
 
@@ -303,10 +333,25 @@ def gmm_parity_check(model, X, n=65536, chunk=8192):
         per_frame += r['per_frame'].sum()
         acc_n, kl = acc_n + r['acc_normal'], r['kl']
     truth = per_frame - kl
-    elbo = beer.accumulate_elbo(model, (X[:n], [n]), datasize=n)
-    got_acc = elbo._acc_stats[p0].cpu().numpy().astype(np.float64)
-    return (abs(float(elbo) - truth) / abs(truth),
-            float(np.abs(got_acc - acc_n).max() / np.abs(acc_n).max()))
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / np.abs(b).max())
+    out = {}
+    for mode in ('bf16x3', 'exact'):
+        old = beer.get_f32_mode()
+        beer.set_f32_mode(mode)
+        try:
+            elbo = beer.accumulate_elbo(model, (X[:n], [n]), datasize=n)
+        finally:
+            beer.set_f32_mode(old)
+        got = elbo._acc_stats[p0].cpu().numpy().astype(np.float64)
+        out[mode] = {'elbo_rel_err': abs(float(elbo) - truth) / abs(truth),
+                     'stats_rel_err': rel(got, acc_n),
+                     'first_moments_rel_err': rel(got[:, :D], acc_n[:, :D]),
+                     'second_moments_rel_err': rel(got[:, D:-2], acc_n[:, D:-2]),
+                     'counts_rel_err': rel(got[:, -2:], acc_n[:, -2:]),
+                     'counts_mean_rel_bias': float(((got[:, -2] - acc_n[:, -2]) / acc_n[:, -2]).mean())}
+    return out
 
 
 def run_gmm(args, rank, world, device, backend):
@@ -324,9 +369,12 @@ def run_gmm(args, rank, world, device, backend):
     # thread next to the capture)
     optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.,
                                       graph=not args.no_mstep_graph and world == 1)
-    elbo_err = stats_err = None
+    parity = {}
     if rank == 0 and not args.no_check:
-        elbo_err, stats_err = gmm_parity_check(model, X, n=min(65536, frames))
+        parity = gmm_parity_check(model, X, n=min(65536, frames))
+    mode_now = beer.get_f32_mode()
+    elbo_err = parity.get(mode_now, {}).get('elbo_rel_err')
+    stats_err = parity.get(mode_now, {}).get('stats_rel_err')
     phases = PhaseTimer()
 
     def step():
@@ -380,14 +428,22 @@ def run_gmm(args, rank, world, device, backend):
             e_elapsed, e_kt, _ = timed_loop(e_steps, 1)
             e_kern = kernel_table(e_kt, e_steps)
         e_dom = max(e_kern, key=lambda nm: e_kern[nm]['ms'] * e_kern[nm]['launches'])
+        # what the exact kernels execute: the D(D+1)/2 + D + 1 distinct products of a frame's
+        # statistics in slabs of 4 (231 slabs = 924 of the Q = 1642 entries), not SURVEY 8d's
+        # dense 2*K*Q -- `frac` is priced in those executed multiply-adds, so it cannot exceed 1
+        q_exec = 4 * (D // 4 * (D // 4 + 1) // 2 * 4 + D // 4 + 1)
         exact = {'ms_per_step': 1e3 * e_elapsed / e_steps,
                  'value': datasize * e_steps / e_elapsed, 'kernel': e_dom,
-                 'achieved': e_kern[e_dom]['tflops'], 'peak': PEAK_TFLOPS['f32'],
-                 'frac': e_kern[e_dom]['tflops'] / PEAK_TFLOPS['f32'],
+                 'achieved': e_kern[e_dom]['tflops'] * q_exec / Q, 'peak': PEAK_TFLOPS['f32'],
+                 'frac': e_kern[e_dom]['tflops'] * q_exec / Q / PEAK_TFLOPS['f32'],
+                 'achieved_algorithmic': e_kern[e_dom]['tflops'],
                  'avg_launch_ms': e_kern[e_dom]['ms'],
                  'traffic': pmc_traffic('acc_kernel' if 'accumulate' in e_dom else 'llh_kernel'),
-                 'note': 'v_mfma_f32_16x16x4_f32, bitwise an fmaf chain; the kernels contract only '
-                         'the D(D+1)/2 symmetric products, so frac can exceed 1'}
+                 **{k_: v_ for k_, v_ in parity.get('exact', {}).items()},
+                 'note': 'v_mfma_f32_16x16x4_f32, bitwise an fmaf chain.  achieved / frac count '
+                         f'the multiply-adds the kernels execute (2*K*{q_exec} per frame: the '
+                         'distinct products of the symmetric statistics); achieved_algorithmic is '
+                         f'SURVEY 8d\'s 2*K*Q = 2*K*{Q} per frame over the same time'}
     if rank != 0:
         return None
     ms_per_step = 1e3 * elapsed / args.steps
@@ -423,8 +479,10 @@ def run_gmm(args, rank, world, device, backend):
                    'components': K, 'dim': D},
         **census,
         'elbo_rel_err_vs_cpu_fp64': elbo_err, 'stats_rel_err_vs_cpu_fp64': stats_err,
+        'parity_vs_cpu_fp64': parity,
         'parity_check': 'first 65536 frames through the timed kernels (packed hand-over) vs the '
-                        'fp64 numpy oracle',
+                        'fp64 numpy oracle, in both float32 arithmetics; statistics per block '
+                        '(counts / first / second moments against their own largest entry)',
         'elbo_per_frame': float(elbo) / (len(lengths) * world * datasize),
         'f32_mode': mode,
         'f32_arithmetic': 'bf16x3: every fp32 operand exactly as three bf16 pieces, six partial '
@@ -547,10 +605,14 @@ def cpu_baseline_hmm(budget_s=20.):
         utts += 1
     dt = time.perf_counter() - t0
     return {'value': frames / dt, 'unit': 'frames/s', 'cores': int(torch.get_num_threads()),
-            'kind': 'port',
+            **host_cores(), 'kind': 'port',
             'sample': f'{utts} utterances ({frames} frames) of the config-3 workload (phone loop '
-                      f'40x3 states, 16 diagonal Gaussians per state, D=40, fp32), E-step only, '
-                      f'torch-CPU replay of the reference op sequence, {dt:.1f} s'}
+                      f'40x3 states, 16 diagonal Gaussians per state, D=40, fp32): the per-utterance '
+                      f'evidence_lower_bound calls of accumulate.py:39-59 (E-step, forward-backward, '
+                      f'statistics, KL), torch-CPU replay of the reference op sequence, {dt:.1f} s; '
+                      f'the once-per-iteration update of update.py:41-62 (1920 diagonal posteriors, '
+                      f'< 1 ms on the host against {1e7 / (frames / dt):.0f} s of accumulation for '
+                      f'the 10 M frames) is not in the sample'}
 
 
 def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, steps=None,

@@ -51,6 +51,23 @@ extern "C" {
 int beer_hip_version(void);
 int beer_hip_device_count(void);
 
+/* Tuning options (no reference counterpart): process-wide launch parameters of the
+ * matrix-core kernels, for measurements and for the tests that pin the defaults.
+ * They change how the work is cut into launches and chains, never what is computed;
+ * the defaults are what the parity suite validates.  A value outside the range is
+ * refused with BEER_EINVAL and leaves the option as it was. */
+#define BEER_OPT_AX_MAXFRAMES 0  /* frames a workgroup of beer_normal_accumulate_packed sums in
+                                  * float32 before its partial sums meet in fp64 (the matrix
+                                  * core truncates its accumulator: bias ~ 8e-11 per frame of
+                                  * chain on same-sign sums).  Default 4096, range 64 .. 2^20. */
+#define BEER_OPT_ACCF_ROUNDS 1   /* workgroup rounds per CU of beer_mixtureset_accumulate_fused.
+                                  * Default 6, range 1 .. 64. */
+#define BEER_OPT_K1_WIDE 2       /* 1: the packed E-step runs its 64 x 256-per-wave form.
+                                  * Default 0. */
+#define BEER_OPT_COUNT 3
+int beer_hip_set_option(int option, int value);
+int beer_hip_get_option(int option);   /* the value, or BEER_EINVAL for an unknown option */
+
 /* How float32 models multiply on the matrix cores is chosen PER CALL (float64
  * models always use the exact fp64 MFMA): the `dtype` argument of
  * beer_mixtureset_estep is BEER_F32 for the default arithmetic, "bf16x3" -- every

@@ -608,6 +608,14 @@ def g13_fp64():
     for utt in sorted(feats.files):
         free += beer.evidence_lower_bound(ploop, torch.from_numpy(feats[utt]).double(), datasize=N)
     out = {'free_elbo': np.asarray(float(free))}
+    # ... and the forced-alignment accumulation of the same replay (accumulate.py:39-59 with
+    # --alis), before the update
+    alis = np.load(os.path.join(HERE, 'ref_alis.npz'), allow_pickle=True)
+    ali = beer.evidence_lower_bound(datasize=N)
+    for utt in sorted(feats.files):
+        ali += beer.evidence_lower_bound(ploop, torch.from_numpy(feats[utt]).double(),
+                                         inference_graph=alis[utt][0], datasize=N)
+    out['ali_elbo'] = np.asarray(float(ali))
     free.backward()
     optim.step()
     dump_params(out, 'updated', ploop)

@@ -7,6 +7,8 @@ decode) run with the REFERENCE's own command line on a synthetic 20-utterance co
 writes  g17_corpus.npz    the corpus: int16 audio per utterance, transcriptions, units
         g17_workflow.npz  what the reference produced: features, initial models, per-epoch
                           ELBO, final posteriors, decoded phone strings
+        g17_workflow_fp64.npz  the same training run by the reference in float64 (model and
+                          features cast to double): per-epoch ELBO and final posteriors
 Only data is stored.  tests/test_workflow.py replays the same commands through bin/beer.
 """
 import os
@@ -50,6 +52,39 @@ def params_of(model):
         post = param.posterior
         for n in STD_NAMES[type(post).__name__]:
             out[f'p{i}.{n}'] = getattr(post.params, n).detach().cpu().numpy()
+    return out
+
+
+def fp64_run(beer, mdl0, paths, uttids):
+    '''The same EPOCHS of aligned training run by the REFERENCE in float64 -- initial model,
+    features cast to double, the alignment graphs as `mkaligraph` wrote them --
+    through the loop of accumulate.py:39-59 / update.py:41-62 (one shard: the sum over
+    utterances does not depend on how they are dealt to jobs): the fp64 truth of the same
+    float32 inputs for tests/test_workflow.py, so that the test does not take it from
+    the build's own fp64 path (as g13_cli_reference_run_fp64 does for the CLI replay).'''
+    import torch
+    model = pickle.load(open(mdl0, 'rb')).double()
+    dataset = pickle.load(open(paths['dataset'], 'rb'))
+    alis = np.load(paths['alis'], allow_pickle=True)
+    optim = beer.VBConjugateOptimizer(model.conjugate_bayesian_parameters(keepgroups=True), 1.)
+    logged = []
+    for _ in range(EPOCHS):
+        optim.init_step()
+        elbo = beer.evidence_lower_bound(datasize=dataset.size)
+        count = 0
+        for uttid in uttids:
+            utt = dataset[uttid]
+            elbo += beer.evidence_lower_bound(model, utt.features.double(),
+                                              inference_graph=alis[uttid][0],
+                                              datasize=dataset.size, scale=1.)
+            count += 1
+        logged.append(float(elbo) / (count * dataset.size))
+        elbo.backward()
+        optim.step()
+    out = {'logged_elbo': np.asarray(logged)}
+    for k, v in params_of(model).items():
+        out['final.' + k] = v
+    print('fp64 logged ELBO per epoch:', logged)
     return out
 
 
@@ -118,6 +153,8 @@ def main():
         out['decode_init'] = np.asarray(sorted(l for l in dec0.strip().split('\n') if l))
         out['phonelist'] = np.asarray(ref(['hmm', 'phonelist', paths['hmms']]).split())
         np.savez_compressed(os.path.join(HERE, 'g17_workflow.npz'), **out)
+        np.savez_compressed(os.path.join(HERE, 'g17_workflow_fp64.npz'),
+                            **fp64_run(beer, os.path.join(tmp, '0.mdl'), paths, uttids))
         print('logged ELBO per epoch:', logged)
         print('\n'.join(out['decode'][:4]))
     finally:

@@ -63,6 +63,33 @@ def assert_close(a, b, tol, what=''):
     assert err <= tol, f'{what}: rel err {err:.3e} > {tol:.1e}'
 
 
+def stat_blocks(Q, D):
+    '''Column blocks of accumulated Normal statistics [.., Q] in the reference's
+    layout [sum g x | -1/2 second moments | -1/2 N, +1/2 N]
+    (beer/dists/normalwishart.py:30-38, normalgamma.py:20-27, isonormalgamma.py:21-30).'''
+    return (('first moments', slice(0, D)), ('second moments', slice(D, Q - 2)),
+            ('counts', slice(Q - 2, Q)))
+
+
+def assert_stats_close(got, truth, D, tol, what='', ref32=None, slack=1.):
+    '''Accumulated statistics [K, Q] held PER BLOCK: the counts, the first and the
+    second moments each against their own largest entry.  A max-norm over the whole
+    array would let the counts and first moments be off by (largest second moment /
+    their size) x tol.  With `ref32` every block gets assert_within_f32_band's band.'''
+    got, truth = np.asarray(got, dtype=np.float64), np.asarray(truth, dtype=np.float64)
+    assert got.shape == truth.shape, f'{what}: shape {got.shape} != {truth.shape}'
+    errs = {}
+    for name, sl in stat_blocks(truth.shape[-1], D):
+        if ref32 is None:
+            assert_close(got[..., sl], truth[..., sl], tol, f'{what} [{name}]')
+            errs[name] = rel_err(got[..., sl], truth[..., sl])
+        else:
+            errs[name], _ = assert_within_f32_band(got[..., sl], truth[..., sl],
+                                                   np.asarray(ref32)[..., sl],
+                                                   f'{what} [{name}]', tol=tol, slack=slack)
+    return errs
+
+
 def assert_within_f32_band(got, truth, ref32, what='', tol=1e-5, slack=1.):
     '''float32 results against the fp64 truth of the same float32 inputs: within
     north_star's 1e-5, or -- where float32 arithmetic itself cannot do that --

@@ -147,7 +147,11 @@ def test_cli_accumulate_update_decode_reproduce_the_reference_run(tmp_path):
          str(tmp_path / 'elbo_ali.pkl')], stdin=uttids)
     elbo, count = pickle.load(open(tmp_path / 'elbo_ali.pkl', 'rb'))
     assert count == 3
-    assert_close(float(elbo), g['ali_elbo'], 2e-5)       # fp32 model: reference's own band
+    # fp32 model: within 1e-5 of the REFERENCE's float64 run of the same inputs (golden
+    # g13_cli_reference_run_fp64), or within the error of its own float32 run
+    from helpers import assert_within_f32_band
+    g64 = load_golden('g13_cli_reference_run_fp64')
+    assert_within_f32_band(float(elbo), float(g64['ali_elbo']), g['ali_elbo'], 'aligned ELBO')
     # free phone loop in two shards, reduced by `update`
     run(['hmm', 'accumulate', mdl, str(tmp_path / 'ds.pkl'), str(tmp_path / 'e1.pkl')],
         stdin='utt0\nutt2\n')
@@ -158,14 +162,11 @@ def test_cli_accumulate_update_decode_reproduce_the_reference_run(tmp_path):
     e1, c1 = pickle.load(open(tmp_path / 'e1.pkl', 'rb'))
     e2, c2 = pickle.load(open(tmp_path / 'e2.pkl', 'rb'))
     assert (c1, c2) == (2, 1)
-    assert_close(float(e1 + e2), g['free_elbo'], 2e-5)
     new = pickle.load(open(tmp_path / '1.mdl', 'rb'))
     # fp64 truth of the same float32 inputs: the same iteration run by the REFERENCE with
     # the model and the features cast to float64 (golden g13_cli_reference_run_fp64,
     # make_golden.py:g13_fp64).  The float32 CLI run must be within 1e-5 of it, or within
     # the error of the reference's own float32 run where float32 cannot do that.
-    from helpers import assert_within_f32_band
-    g64 = load_golden('g13_cli_reference_run_fp64')
     assert_within_f32_band(float(e1 + e2), float(g64['free_elbo']), g['free_elbo'], 'free-loop ELBO')
     for i, p in enumerate(new.bayesian_parameters()):
         for name, ref, truth in zip(p.posterior._std_params_def,

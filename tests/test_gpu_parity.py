@@ -6,8 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (COV_OF, assert_close, assert_within_f32_band, dist_cls, load_golden, orc,
-                     std_params)
+from helpers import (COV_OF, assert_close, assert_stats_close, assert_within_f32_band, dist_cls,
+                     load_golden, orc, std_params)
 
 pytestmark = pytest.mark.gpu
 
@@ -471,7 +471,7 @@ def test_c2_shape_one_step_vs_oracle(dtype, tol, tol_post):
     elbo = beer.evidence_lower_bound(model, X.to(DEV))
     assert_close(float(elbo), truth['value'], tol, 'elbo')
     acc = npy(elbo._acc_stats[p0]).astype(np.float64)
-    assert_close(acc, truth['acc_normal'], tol, 'acc')
+    assert_stats_close(acc, truth['acc_normal'], D, tol, 'acc')
     # properties: counts sum to T; second-moment block symmetric
     assert abs(-2 * acc[:, -2].sum() - T) <= 1e-6 * T
     S2 = acc[:, D:D + D * D].reshape(K, D, D)
@@ -546,7 +546,7 @@ def test_bench_kernel_variant_vs_oracle(cov, K):
     assert beer.get_f32_mode() == 'bf16x3'
     assert_close(float(elbo), truth['value'], 1e-5, 'elbo')
     acc = npy(elbo._acc_stats[p0]).astype(np.float64)
-    assert_within_f32_band(acc, truth['acc_normal'], ref32['acc_normal'], 'acc normal')
+    assert_stats_close(acc, truth['acc_normal'], D, 1e-5, 'acc normal', ref32=ref32['acc_normal'])
     assert_within_f32_band(npy(elbo._acc_stats[p1]).astype(np.float64), truth['acc_weights'],
                            ref32['acc_weights'], 'acc weights')
     elbo.backward()
@@ -573,8 +573,8 @@ def test_bench_kernel_variant_vs_oracle(cov, K):
     with _hip.exact_f32():
         e_elbo = beer.accumulate_elbo(exact_model, (X.to(DEV), [T]), datasize=T)
     assert_close(float(e_elbo), truth['value'], 1e-5, 'elbo (exact)')
-    assert_within_f32_band(npy(e_elbo._acc_stats[q0]).astype(np.float64), truth['acc_normal'],
-                           ref32['acc_normal'], 'acc normal (exact)')
+    assert_stats_close(npy(e_elbo._acc_stats[q0]), truth['acc_normal'], D, 1e-5,
+                       'acc normal (exact)', ref32=ref32['acc_normal'])
 
 
 def test_full_size_properties_linearity_and_monotone_elbo():
@@ -760,7 +760,8 @@ def test_c3_shape_batched_phone_loop_vs_oracle(cov, dtype, tol, tol_stats):
     elbo = beer.accumulate_elbo(ploop, [tt(x) for x in utts], datasize=N)
     assert_close(float(elbo), value, tol, 'elbo')
     ms = ploop.modelset.original_modelset.modelsets[0]
-    assert_close(npy(elbo._acc_stats[ms.modelset.means_precisions]), acc_n, tol_stats, 'acc normal')
+    assert_stats_close(npy(elbo._acc_stats[ms.modelset.means_precisions]), acc_n, D, tol_stats,
+                       'acc normal')
     assert_close(npy(elbo._acc_stats[ms.categoricalset.weights]), acc_w, tol_stats, 'acc weights')
     assert_close(npy(elbo._acc_stats[cat]), counts, tol_stats, 'phone counts')
 
@@ -801,6 +802,21 @@ def _oracle_phone_loop_shard(ploop, utts, N, with_counts=True, dtype=np.float64)
                           ('diagonal', torch.float32, 56, 1e-5, 1e-5),
                           ('full', torch.float32, 56, 1e-5, 1e-5)])
 def test_c3_real_dimensions_phone_loop_vs_oracle(cov, dtype, nutt, tol, tol_stats):
+    # float32 posteriors after the M-step: the band is the error of the reference's own
+    # float32 run, ONE realisation of rounding noise amplified by an ill-conditioned inverse
+    # (components that saw less than a frame).  The small float32 cases therefore run over
+    # three corpora and compare MEAN errors (no slack factor); the others hold every
+    # quantity inside the band of their single corpus.
+    seeds = (12, 13, 14) if dtype == torch.float32 and nutt == 4 else (12,)
+    runs = [_c3_real_dimensions(cov, dtype, nutt, tol, tol_stats, seed) for seed in seeds]
+    for what in runs[0]:
+        err = float(np.mean([r[what][0] for r in runs]))
+        ref = float(np.mean([r[what][1] for r in runs]))
+        assert err <= max(1e-5, ref), f'{what}: mean rel err {err:.3e} > band {max(1e-5, ref):.3e} ' \
+                                      f'over corpora {seeds}'
+
+
+def _c3_real_dimensions(cov, dtype, nutt, tol, tol_stats, seed):
     '''BASELINE config 3 at its real dimensions -- 40 phones x 3 states (S = 120,
     a 40-phone hub), G = 16 Gaussians per state (K = 1920: 8 component chunks),
     D = 40 -- utterances of ~300 frames through the batched E-step vs the oracle's
@@ -812,7 +828,7 @@ def test_c3_real_dimensions_phone_loop_vs_oracle(cov, dtype, nutt, tol, tol_stat
     float32 kernels.'''
     P, G, D = 40, 16, 40
     ploop = _phone_loop(P, G, D, cov, dtype, seed=33)
-    rng = np.random.RandomState(12)
+    rng = np.random.RandomState(seed)
     lens = [int(n) for n in rng.randint(250, 350, nutt)]
     npdt = np.float32 if dtype == torch.float32 else np.float64
     # frames drawn around the model's own component means: responsibilities and
@@ -837,13 +853,16 @@ def test_c3_real_dimensions_phone_loop_vs_oracle(cov, dtype, nutt, tol, tol_stat
         _, acc_n32, acc_w32, _ = _oracle_phone_loop_shard(ploop, utts, N, with_counts=False,
                                                           dtype=np.float32)
 
+    banded = {}
+
     def check(got, truth, ref32, what):
         got = np.asarray(got, dtype=np.float64).reshape(np.shape(truth))
         if f32 and ref32 is not None:
             # (posteriors of components that saw less than a frame: the inverse amplifies
             # float32 rounding a thousandfold -- for the reference as for anybody)
-            assert_within_f32_band(got, np.asarray(truth), np.asarray(ref32, dtype=np.float64), what,
-                                   slack=2.)
+            from helpers import rel_err
+            banded[what] = (rel_err(got, np.asarray(truth)),
+                            rel_err(np.asarray(ref32, dtype=np.float64), np.asarray(truth)))
         else:
             assert_close(got, truth, tol_stats, what)
     optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.)
@@ -852,7 +871,8 @@ def test_c3_real_dimensions_phone_loop_vs_oracle(cov, dtype, nutt, tol, tol_stat
     assert_close(float(elbo), value, tol, 'elbo')
     ms = ploop.modelset.original_modelset.modelsets[0]
     cat = ploop.categorical.weights
-    assert_close(npy(elbo._acc_stats[ms.modelset.means_precisions]), acc_n, tol_stats, 'acc normal')
+    assert_stats_close(npy(elbo._acc_stats[ms.modelset.means_precisions]), acc_n, D, tol_stats,
+                       'acc normal')
     assert_close(npy(elbo._acc_stats[ms.categoricalset.weights]), acc_w, tol_stats, 'acc weights')
     assert_close(npy(elbo._acc_stats[cat]), counts, tol_stats, 'phone counts')
     # the M-step on these statistics (scale N / frames, objectives.py:98)
@@ -873,6 +893,7 @@ def test_c3_real_dimensions_phone_loop_vs_oracle(cov, dtype, nutt, tol, tol_stat
               'posterior ' + n)
     check(npy(ms.categoricalset.weights.posterior.params.concentrations), new['w_post'],
           new32['w_post'] if new32 else None, 'posterior weights')
+    return banded
 
 
 @pytest.mark.parametrize('cov', ['diagonal', 'isotropic', 'full'])
@@ -898,7 +919,7 @@ def test_gmm_matrix_core_path_all_cov_types_vs_oracle(cov, dtype, tol, tol_stats
     truth = orc.gmm_elbo_step(Xn.astype(np.float64), cov, post, prior, w_post, w_prior)
     elbo = beer.evidence_lower_bound(model, X.to(DEV))
     assert_close(float(elbo), truth['value'], tol, 'elbo')
-    assert_close(npy(elbo._acc_stats[p0]), truth['acc_normal'], tol_stats, 'acc normal')
+    assert_stats_close(npy(elbo._acc_stats[p0]), truth['acc_normal'], D, tol_stats, 'acc normal')
     assert_close(npy(elbo._acc_stats[p1]), truth['acc_weights'], tol_stats, 'acc weights')
 
 
@@ -944,8 +965,8 @@ def test_gmm_with_more_than_256_components_on_the_matrix_cores(cov, K, D, split)
     assert len(taken) == 2
     for e in (elbo, batched):
         assert_close(float(e), truth['value'], 1e-5, 'elbo')
-        assert_within_f32_band(npy(e._acc_stats[p0]).astype(np.float64), truth['acc_normal'],
-                               ref32['acc_normal'], 'acc normal')
+        assert_stats_close(npy(e._acc_stats[p0]), truth['acc_normal'], D, 1e-5, 'acc normal',
+                           ref32=ref32['acc_normal'])
         assert_within_f32_band(npy(e._acc_stats[p1]).astype(np.float64), truth['acc_weights'],
                                ref32['acc_weights'], 'acc weights')
     # the factored responsibilities as a matrix
@@ -954,7 +975,7 @@ def test_gmm_with_more_than_256_components_on_the_matrix_cores(cov, K, D, split)
                                        cov, split)
     r = npy(wr.dense()).astype(np.float64)
     assert np.abs(r.sum(1) - 1).max() < 5e-5
-    assert np.abs(r - truth['resps']).max() < 2e-4
+    assert_within_f32_band(r, truth['resps'], ref32['resps'].astype(np.float64), 'responsibilities')
 
 
 @pytest.mark.parametrize('cov,K,D', [('full', 64, 80), ('diagonal', 200, 96), ('full', 32, 72)])
@@ -996,8 +1017,8 @@ def test_matrix_core_paths_beyond_64_dimensions(cov, K, D):
     assert 'beer_mixture_estep_packed' in calls and 'beer_normal_accumulate_packed' in calls
     assert 'beer_mixtureset_estep' not in calls and 'beer_normal_accumulate' not in calls
     assert_close(float(elbo), truth['value'], 1e-5, 'elbo')
-    assert_within_f32_band(npy(elbo._acc_stats[p0]).astype(np.float64), truth['acc_normal'],
-                           ref32['acc_normal'], 'acc normal')
+    assert_stats_close(npy(elbo._acc_stats[p0]), truth['acc_normal'], D, 1e-5, 'acc normal',
+                       ref32=ref32['acc_normal'])
     assert_within_f32_band(npy(elbo._acc_stats[p1]).astype(np.float64), truth['acc_weights'],
                            ref32['acc_weights'], 'acc weights')
 
@@ -1066,7 +1087,7 @@ def test_forward_backward_kernels_agree_with_oracle_on_long_chains(n_states):
                                   orc.best_path(llhs, init, final, trans))
 
 
-@pytest.mark.parametrize('n_states,dtype,tol', [(100, torch.float64, 1e-9), (100, torch.float32, 2e-5),
+@pytest.mark.parametrize('n_states,dtype,tol', [(100, torch.float64, 1e-9), (100, torch.float32, 1e-5),
                                                (180, torch.float64, 1e-9)])
 def test_forward_backward_on_dense_graphs_beyond_lds(n_states, dtype, tol):
     '''An ergodic HMM with every transition present: 10 000 / 32 400 arcs, more than a
@@ -1087,19 +1108,33 @@ def test_forward_backward_on_dense_graphs_beyond_lds(n_states, dtype, tol):
     packed = torch.cat([tt(l).reshape(-1) for l in llhs])
     g, x, g0, ln, flow = hk.forward_backward(batch, packed, want_xi=True, want_lognorm=True)
     g = npy(g).astype(np.float64)
+    f32 = dtype == torch.float32
+
+    def check(got, truth, ref32, what):
+        # float32: 1e-5, or the error of the reference's own float32 op sequence
+        if f32:
+            assert_within_f32_band(got, truth, ref32, what, tol=tol)
+        else:
+            assert_close(got, truth, tol, what)
     xi_sum, gam0, off = 0., 0., 0
+    xi_sum32, gam032 = 0., 0.
     for T, l in zip(lens, llhs):
         gam, xi, lnm = orc.posteriors(l.astype(np.float64), init.astype(np.float64),
                                       final.astype(np.float64), trans.astype(np.float64), True)
-        assert_close(g[off:off + T * n_states].reshape(T, -1), gam, tol, 'gamma')
+        gam32, xi32 = gam, xi
+        if f32:
+            gam32, xi32, _ = orc.posteriors(l, init, final, trans, True)
+            xi_sum32, gam032 = xi_sum32 + xi32.sum(0).astype(np.float64), gam032 + gam32[0].astype(np.float64)
+        check(g[off:off + T * n_states].reshape(T, -1), gam, gam32, 'gamma')
         xi_sum, gam0, off = xi_sum + xi.sum(0), gam0 + gam[0], off + T * n_states
-    assert_close(npy(x), xi_sum, tol, 'xi')
-    assert_close(npy(g0), gam0, tol, 'gamma0')
+    check(npy(x), xi_sum, xi_sum32, 'xi')
+    check(npy(g0), gam0, gam032, 'gamma0')
     # the model-level entry point: HMM-style posteriors of one utterance
     post = graph.posteriors(tt(llhs[0]))[0]
     gam, _, _ = orc.posteriors(llhs[0].astype(np.float64), init.astype(np.float64),
                                final.astype(np.float64), trans.astype(np.float64), True)
-    assert_close(npy(post).astype(np.float64), gam, tol, 'CompiledGraph.posteriors')
+    gam32 = orc.posteriors(llhs[0], init, final, trans, True)[0] if f32 else gam
+    check(npy(post).astype(np.float64), gam, gam32, 'CompiledGraph.posteriors')
 
 
 def test_hmm_batch_with_one_frame_utterances():
@@ -1195,8 +1230,50 @@ def test_f32_modes_agree_with_fp64(cov, K, D):
     # same operands, same fp32 accumulation: the two arithmetics differ by rounding
     # noise only (the MFMA chains are of different lengths), never by a factor
     for e_exact, e_fast in zip(err['exact'], err['bf16x3']):
-        assert e_fast <= 4. * e_exact + 1e-7, (err['exact'], err['bf16x3'])
+        assert e_fast <= 2. * e_exact + 1e-7, (err['exact'], err['bf16x3'])
     assert err['bf16x3'][1] <= 2e-6 and err['bf16x3'][3] <= 2e-6, err['bf16x3']
+
+
+def test_chain_length_rule_of_the_packed_accumulation():
+    '''The matrix core truncates its accumulator: a float32 chain over
+    same-sign products drifts low in proportion to its length.  One million frames,
+    K = 256 full covariance, D = 40, the fp64 responsibilities given to the bf16x3
+    accumulation (beer_normal_accumulate_packed): at the DEFAULT chain length
+    (BEER_OPT_AX_MAXFRAMES = 4096 frames per workgroup, partial sums meet in fp64) the
+    mean relative bias of the counts N_k stays below 5e-7 and every block of the
+    statistics within 1e-6 of the fp64 kernels; chains 16 times as long are what the
+    rule forbids -- their bias is several times larger and negative.  Reference:
+    beer/dists/normalwishart.py:30-38, beer/models/normalset.py:117-123.'''
+    from beer_amd import _hip, kernels
+    K, D, T = 256, 40, 1 << 20
+    rng = np.random.RandomState(3)
+    means = rng.randn(K, D) * 2
+    X = torch.from_numpy((means[rng.randint(0, K, T)] + rng.randn(T, D)).astype(np.float32)).to(DEV)
+    torch.manual_seed(7)
+    ns = beer.NormalSet.create(X.mean(0).cpu(), torch.diag(X.var(0).cpu()), size=K,
+                               prior_strength=1., noise_std=1., cov_type='full')
+    model = beer.Mixture.create(ns, prior_strength=1.).to(DEV)
+    E, lw = ns.means_precisions.natural_form(), model._log_weights().view(1, K)
+    st64, st32 = beer.FrameStats(X.double(), 'full'), beer.FrameStats(X, 'full')
+    _, r64 = kernels.mixtureset_estep(st64, E.double(), lw.double(), 1, K, 'full')
+    acc64 = npy(kernels.normal_accumulate(st64, r64, None, 1, K, 'full'))
+    packed = kernels.pack_resps(st32, r64.float(), None, 1, K)
+    del r64
+    assert _hip.get_option('ax_max_frames') == 4096
+    bias = {}
+    try:
+        for chain in (1024, 4096, 65536):
+            _hip.set_option('ax_max_frames', chain)
+            acc = npy(kernels.normal_accumulate(st32, packed, None, 1, K, 'full')).astype(np.float64)
+            bias[chain] = float(((acc[:, -2] - acc64[:, -2]) / acc64[:, -2]).mean())
+            if chain == 4096:
+                assert_stats_close(acc, acc64, D, 1e-6, 'default chain')
+    finally:
+        _hip.set_option('ax_max_frames', 4096)
+    assert abs(bias[4096]) <= 5e-7 and abs(bias[1024]) <= 2.5e-7, bias
+    assert bias[65536] < 0 and abs(bias[65536]) >= 3. * abs(bias[4096]), bias
+    with pytest.raises(ValueError):
+        _hip.set_option('ax_max_frames', 0)          # (refused: it is a divisor)
 
 
 def test_fast_path_takes_outliers_and_any_range():
@@ -1238,12 +1315,12 @@ def test_fast_path_takes_outliers_and_any_range():
     # per-frame log-normalisers: relative to each frame's own magnitude (the outlier
     # frame's is ~1e10)
     rel = lambda ln: float(((ln.double() - ln64).abs() / (1. + ln64.abs())).max())   # noqa: E731
-    assert rel(ln_f) <= 4. * rel(ln_e) + 1e-6, (rel(ln_f), rel(ln_e))
+    assert rel(ln_f) <= 2. * rel(ln_e) + 1e-6, (rel(ln_f), rel(ln_e))
     # statistics: per column (the columns' magnitudes span 24 orders)
     col = acc64.abs().amax(0, keepdim=True) + 1e-300
     e_f = float(((acc_f - acc64).abs() / col).max())
     e_e = float(((acc_e - acc64).abs() / col).max())
-    assert e_f <= 4. * e_e + 2e-6, (e_f, e_e)
+    assert e_f <= 2. * e_e + 2e-6, (e_f, e_e)
 
 
 @pytest.mark.parametrize('cov,S,G,D', [('diagonal', 30, 16, 40), ('full', 12, 16, 20),
@@ -1280,7 +1357,7 @@ def test_fast_path_mixture_sets(cov, S, G, D):
                      float((r.double() - r64).abs().max()),
                      float((acc - acc64).abs().max() / acc64.abs().max()))
     for e_exact, e_fast in zip(err['exact'], err['bf16x3']):
-        assert e_fast <= 4. * e_exact + 1e-7, err
+        assert e_fast <= 2. * e_exact + 1e-7, err
     assert err['bf16x3'][2] <= 2e-6, err
 
 
@@ -1331,10 +1408,10 @@ def test_packed_responsibilities_match_the_two_call_path(cov, K, D, T):
     scale = float(acc64.abs().max())
     e_exact = float((acc_e - acc64).abs().max()) / scale
     e_packed = float((acc_p - acc64).abs().max()) / scale
-    assert e_packed <= 4. * e_exact + 2e-6, (e_packed, e_exact)
+    assert e_packed <= 2. * e_exact + 2e-6, (e_packed, e_exact)
     ln_scale = float(ln64.abs().max())
     assert float((ln_p.double() - ln64).abs().max()) <= \
-        4. * float((ln_e.double() - ln64).abs().max()) + 1e-6 * ln_scale
+        2. * float((ln_e.double() - ln64).abs().max()) + 1e-6 * ln_scale
 
 
 class _no_packed:

@@ -38,6 +38,24 @@ def test_library_exports_every_declared_symbol():
     assert lib.beer_hip_version() >= 100
 
 
+def test_tuning_options_are_clamped():
+    '''beer_hip_set_option refuses values outside an option's range (the chain length is a
+    divisor; round 3 read it with atoi from the environment) and unknown options.'''
+    lib = _hip.lib()
+    code = _hip.OPTIONS['ax_max_frames'][0]
+    assert lib.beer_hip_get_option(code) == 4096
+    assert lib.beer_hip_set_option(code, 0) == _hip.EINVAL
+    assert lib.beer_hip_set_option(code, -5) == _hip.EINVAL
+    assert lib.beer_hip_set_option(99, 1) == _hip.EINVAL
+    assert lib.beer_hip_get_option(99) == _hip.EINVAL
+    assert lib.beer_hip_get_option(code) == 4096
+    assert _hip.set_option('ax_max_frames', 2048) == 4096
+    assert _hip.get_option('ax_max_frames') == 2048
+    _hip.set_option('ax_max_frames', 4096)
+    with pytest.raises(ValueError):
+        _hip.set_option('accf_rounds', 0)
+
+
 def test_struct_layouts_match_header():
     # 4 int32 + 14 pointers; 6 int32 + 6 pointers (LP64)
     assert ctypes.sizeof(_hip.Graph) == 16 + 15 * 8
