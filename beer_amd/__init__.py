@@ -21,7 +21,7 @@ from . import graph
 from . import nnet
 from . import utils
 from . import vbi
-from .stats import FrameStats, reference_layout
+from .stats import FrameImages, FrameStats, reference_layout
 from ._hip import get_f32_mode, set_f32_mode
 
 __version__ = '0.1.0'

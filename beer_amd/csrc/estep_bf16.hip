@@ -46,6 +46,15 @@
 #ifndef BEER_AFI_ABL
 #define BEER_AFI_ABL 0     // accfi_kernel, bits: 1 one B fragment load per tile, 2 no flush, 4 one A fragment load per tile
 #endif
+#ifndef BEER_LNFI_ABL
+#define BEER_LNFI_ABL 0     // lnfi_kernel, bits: 1 no epilogue, 2 no MFMAs, 4 no LDS reads of B, 8 no A loads
+#endif
+#ifndef BEER_LNFI_SLEEP
+#define BEER_LNFI_SLEEP 0   // lnfi_kernel: s_sleep count (x 64 cycles) of the second wave of every SIMD at its start
+#endif
+#ifndef BEER_ACCFI_SLEEP
+#define BEER_ACCFI_SLEEP 0  // accfi_kernel: the same
+#endif
 #ifndef BEER_K1_FENCE
 #define BEER_K1_FENCE 0    // K1: scheduling fence every n MFMAs of the hand-placed stream (0 = none)
 #endif
@@ -1586,13 +1595,13 @@ __global__ __launch_bounds__(256) void frame_image_kernel(int64_t nframes, int D
     }
 }
 
-template <int NKU>
-__global__ __launch_bounds__(512, 2) void accfi_kernel(
+template <int NKU, int WAVES = 8>
+__global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
     int64_t nframes, int K, int S, int G, int Greal, int nk, int nslab,
     const u4* __restrict__ img, const u4* __restrict__ Pall, const float* __restrict__ log_norm,
     const float* __restrict__ sr, int64_t frames_per_block, double* __restrict__ Sp,
     const float* __restrict__ c0p) {
-    constexpr int NTC = 4, NQT = 6, MT = 2, FW = 32, WAVES = 8, NTHREADS = 64 * WAVES;
+    constexpr int NTC = 4, NQT = 6, MT = 2, FW = 32, NTHREADS = 64 * WAVES;
     constexpr int kTileU4 = (NKU * NP * MT + NQT * NP) * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int64_t bx;
@@ -1615,6 +1624,11 @@ __global__ __launch_bounds__(512, 2) void accfi_kernel(
         for (int idx = tid; idx < p_u4; idx += NTHREADS) Ps[idx] = src[idx];
     }
     __syncthreads();
+    if (BEER_ACCFI_SLEEP > 0 && (WAVES == 8 ? wave >= 4 : (blockIdx.x >> 3) & 1)) {
+#pragma unroll
+        for (int n = 0; n < (BEER_ACCFI_SLEEP + 126) / 127; ++n)
+            __builtin_amdgcn_s_sleep(BEER_ACCFI_SLEEP < 127 ? BEER_ACCFI_SLEEP : 127);
+    }
     const int kbase = by * (16 * NTC);
     const float c0 = c0p[0];
     const int64_t tb = bx * frames_per_block;
@@ -1685,11 +1699,16 @@ __global__ __launch_bounds__(512, 2) void accfi_kernel(
 #pragma unroll
                 for (int m = 0; m < MT; ++m) af[0][q][m] = ti[(q * MT + m) * 64];
         }
-        // the first two B fragments of the statistics
+        // the first B fragment of the statistics (the second when the logits are done: the
+        // exponentials cover its latency, and the logits phase has no registers to spare)
 #pragma unroll
-        for (int uu = 0; uu < 2; ++uu)
+        for (int q = 0; q < NP; ++q) bq[0][q] = ti[(NKU * NP * MT + q) * 64];
+        // (B fragments of the logits: the three planes of component tile c + 1 are read from
+        // LDS at the START of tile c's 12 MFMAs -- see lnfi_kernel)
+        u4 bp[2][NP];
 #pragma unroll
-            for (int q = 0; q < NP; ++q) bq[uu][q] = ti[(NKU * NP * MT + uu * NP + q) * 64];
+        for (int pq = 0; pq < NP; ++pq) bp[0][pq] = Pl[64 * pq];
+        __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
 #pragma unroll
         for (int s = 0; s < NKU; ++s) {
             if (s + 1 < NKU) {
@@ -1700,26 +1719,30 @@ __global__ __launch_bounds__(512, 2) void accfi_kernel(
                         af[(s + 1) & 1][q][m] = (BEER_AFI_ABL & 4) ? af[s & 1][q][m] :
                                                 ti[(((s + 1) * NP + q) * MT + m) * 64];
             }
+            // the loads of this k-step first (the counts must match what is issued here, or
+            // hipcc moves other loads in to fill the group)
+            if (s == 0) __builtin_amdgcn_sched_group_barrier(0x020, NKU > 1 ? 9 : 3, 0);
+            else if (s + 1 < NKU) __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
 #pragma unroll
             for (int c = 0; c < NTC; ++c) {
-                u4 bp[NP];
+                constexpr int kLast = NKU * NTC - 1;
+                const int gi = s * NTC + c, gn = gi < kLast ? gi + 1 : kLast;
 #pragma unroll
-                for (int pq = 0; pq < NP; ++pq) bp[pq] = Pl[(s * NTC + c) * kBlockU4 + 64 * pq];
+                for (int pq = 0; pq < NP; ++pq) bp[(gi + 1) & 1][pq] = Pl[gn * kBlockU4 + 64 * pq];
                 // (the products in the order of llhx_kernel: same roundings)
 #pragma unroll
                 for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        acc[m][c] = mfma_bf16(af[s & 1][kProdA[pr]][m], bp[kProdB[pr]], acc[m][c]);
+                        acc[m][c] = mfma_bf16(af[s & 1][kProdA[pr]][m], bp[gi & 1][kProdB[pr]], acc[m][c]);
+                __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT, 0);
             }
-            // the loads of this k-step first (the counts must match what is issued here, or
-            // hipcc moves other loads in to fill the group)
-            if (s == 0) __builtin_amdgcn_sched_group_barrier(0x020, NKU > 1 ? 12 : 6, 0);
-            else if (s + 1 < NKU) __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT * NTC, 0);
         }
 
         // ---- r sr = exp(l - log_norm) sr, split into the A fragments of the statistics ----
+#pragma unroll
+        for (int q = 0; q < NP; ++q) bq[1][q] = ti[(NKU * NP * MT + NP + q) * 64];
         u4 ar[NTC][NP];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -1733,8 +1756,7 @@ __global__ __launch_bounds__(512, 2) void accfi_kernel(
                 const float wg = (sr ? lsw[(FW + row) * 4 + sidx] : 1.f) * (ok ? 1.f : 0.f);
 #pragma unroll
                 for (int nt = 0; nt < NTC; ++nt)
-                    acc[m][nt][r] = __builtin_amdgcn_exp2f((acc[m][nt][r] + nl2) *
-                                                           1.44269504088896340736f) * wg;
+                    acc[m][nt][r] = exp2_valu((acc[m][nt][r] + nl2) * 1.44269504088896340736f) * wg;
             }
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt)
@@ -1820,6 +1842,139 @@ __global__ __launch_bounds__(512, 2) void accfi_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Log-normalisers of a mixture set from a frame fragment image (pass 1 of the config-3
+// iteration; replaces llhx_kernel<.., LNO, IMG> where the packed image is lane-major).
+// That kernel gave every wave ONE 32-frame tile and streamed the chunk's packed
+// parameters (3 k-steps x 16 tiles x 3 KiB = 144 KiB at D = 40) from L2 for each of
+// them, one batch of two tiles ahead: 80 s_waitcnt per 384 MFMAs in its loop, the
+// vector-memory path of a CU more than half busy with re-reading the same 144 KiB, 58 %
+// MFMA busy.  Here a workgroup of 8 waves (two per SIMD) keeps the WHOLE chunk in LDS --
+// 144 KiB of the CU's 160 -- and walks a block of frames: B fragments are ds_read_b128
+// with LDS latency, the only global loads left are the 18 A fragments per tile (from the
+// image, a k-step ahead; the next tile's first k-step during the epilogue).  Same
+// products in the same order as llhx_kernel and accfi_kernel: bit-identical logits.
+// ---------------------------------------------------------------------------
+template <int NKU, int G>
+__global__ __launch_bounds__(512, 2) void lnfi_kernel(
+    int64_t nframes, int K, int S, int nk, const u4* __restrict__ img,
+    const u4* __restrict__ Pall, float* __restrict__ log_norm, double* __restrict__ llh_sum,
+    int64_t frames_per_block, const float* __restrict__ c0p) {
+    constexpr int NT = 16, MT = 2, FW = 32, WAVES = 8, NTHREADS = 64 * WAVES;
+    constexpr int kTileU4 = (NKU * NP * MT + 6 * NP) * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int64_t bx;
+    int by;
+    {
+        const int nch = (K + 16 * NT - 1) / (16 * NT);
+        if (!xcd_block((nframes + frames_per_block - 1) / frames_per_block, nch, nch, bx, by))
+            return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    constexpr int p_u4 = NKU * NT * kBlockU4;
+    u4* Ps = reinterpret_cast<u4*>(smem);
+    {
+        const u4* src = Pall + (size_t)by * nk * NT * kBlockU4;
+#pragma unroll 2
+        for (int idx = tid; idx < p_u4; idx += NTHREADS) Ps[idx] = src[idx];
+    }
+    __syncthreads();
+    if (BEER_LNFI_SLEEP > 0 && wave >= WAVES / 2) {
+#pragma unroll
+        for (int n = 0; n < (BEER_LNFI_SLEEP + 126) / 127; ++n)
+            __builtin_amdgcn_s_sleep(BEER_LNFI_SLEEP < 127 ? BEER_LNFI_SLEEP : 127);
+    }
+    const int kbase = by * (16 * NT);
+    const float c0 = c0p[0];
+    const int64_t tb = bx * frames_per_block;
+    const int64_t te = tb + frames_per_block < nframes ? tb + frames_per_block : nframes;
+    const u4* Pl = Ps + lane;
+    u4 af[2][NP][MT];
+    const int64_t fb0 = tb + (int64_t)wave * FW;
+    if (fb0 < te) {
+        const u4* t0 = img + (fb0 / FW) * (int64_t)kTileU4 + lane;
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) af[0][q][m] = t0[(q * MT + m) * 64];
+    }
+    for (int64_t fb = fb0; fb < te; fb += WAVES * FW) {
+        const u4* ti = img + (fb / FW) * (int64_t)kTileU4 + lane;
+        const bool has_next = fb + WAVES * FW < te;
+        const u4* tn = ti + (has_next ? (int64_t)WAVES * kTileU4 : 0);
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[m][c] = f32x4{0, 0, 0, 0};
+        // B fragments: the three planes of component tile c + 1 are read from LDS at the START of
+        // tile c's 12 MFMAs (hipcc otherwise places the reads behind them and waits for the
+        // last one's full LDS latency before every tile: 48 stalls per wave-tile)
+        u4 bp[2][NP];
+#pragma unroll
+        for (int pq = 0; pq < NP; ++pq) bp[0][pq] = Pl[64 * pq];
+        __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
+#pragma unroll
+        for (int s = 0; s < NKU; ++s) {
+            // the A fragments of the next k-step (of the next tile's first one: this tile's
+            // again when there is none)
+            {
+                const u4* src = s + 1 < NKU ? ti + (size_t)(s + 1) * NP * MT * 64 : tn;
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        af[(s + 1) & 1][q][m] = (BEER_LNFI_ABL & 8) ? af[s & 1][q][m] : src[(q * MT + m) * 64];
+            }
+            if (!(BEER_LNFI_ABL & 8)) __builtin_amdgcn_sched_group_barrier(0x020, NP * MT, 0);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                constexpr int kLast = NKU * NT - 1;
+                const int gi = s * NT + c, gn = gi < kLast ? gi + 1 : kLast;
+#pragma unroll
+                for (int pq = 0; pq < NP; ++pq)
+                    bp[(gi + 1) & 1][pq] = (BEER_LNFI_ABL & 4) ? bp[gi & 1][pq] : Pl[gn * kBlockU4 + 64 * pq];
+                if (BEER_LNFI_ABL & 2) continue;
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m][c] = mfma_bf16(af[s & 1][kProdA[pr]][m], bp[gi & 1][kProdB[pr]], acc[m][c]);
+                if (!(BEER_LNFI_ABL & 4)) __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT, 0);
+            }
+        }
+        if (BEER_LNFI_ABL & 1) {
+            float t = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int c = 0; c < NT; ++c) t += acc[m][c][0] + acc[m][c][1] + acc[m][c][2] + acc[m][c][3];
+            if (t == 1.2345f) log_norm[0] = t;
+        } else {
+            if (BEER_LNFI_ABL & 2) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int c = 0; c < NT; ++c)
+                        acc[m][c] = f32x4{(float)(c + lane), (float)(m - c), (float)lane, bp[0][0][0] * 1e-30f};
+            }
+            lognorm_epilogue_lane_major<NT, MT, G>(acc, fb, nframes, kbase, S, i, g, lane, log_norm,
+                                                   llh_sum, c0);
+        }
+        if constexpr (NKU % 2 == 0) {
+            // (even number of k-steps: the prefetched fragments sit in af[0] already)
+        } else {
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[0][q][m] = af[1][q][m];
+        }
+    }
+}
+
 // component tiles per wave: 4 (64 components).  With at most 96 statistic columns
 // (D <= 40) a wave's tile leaves room for two waves per SIMD: one wave's epilogue and
 // fragment arithmetic run under the other's MFMAs.
@@ -1871,7 +2026,9 @@ template __global__ void accx_kernel<false>(int64_t, int, int, int, int, const f
 template __global__ void accx_kernel<true>(int64_t, int, int, int, int, const float*, const unsigned*,
                                            const int*, int64_t, double*, int, int, int,
                                            const float*, int);
-template __global__ void accfi_kernel<3>(int64_t, int, int, int, int, int, int, const u4*, const u4*,
+template __global__ void lnfi_kernel<3, 16>(int64_t, int, int, int, const u4*, const u4*, float*, double*,
+                                            int64_t, const float*);
+template __global__ void accfi_kernel<3, 8>(int64_t, int, int, int, int, int, int, const u4*, const u4*,
                                          const float*, const float*, int64_t, double*, const float*);
 template __global__ void accf_kernel<4, 6, true, 8, 5, true>(int64_t, int, int, int, int, int, int, int,
                                                        const float*, const u4*, const int*,
@@ -2026,6 +2183,39 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
             case 1: BEER_LLHX(16, 2, 1, true, false);
             default: BEER_LLHX(16, 2, 2, true, false);
         }
+    }
+    if (image && lane_major && (nslab_of(cov, D) + 7) / 8 <= 3 && beer::option(BEER_OPT_LNFI)) {
+        // lane-major groups over a frame image: the chunk's parameters in LDS, a workgroup
+        // walks a block of frames (lnfi_kernel)
+        const int nku = (nslab_of(cov, D) + 7) / 8;
+        // frames per workgroup: whole rounds of its 8 waves (256 frames); the block length
+        // that minimises rounds of 256 workgroups x (block + the LDS fill, worth ~128 frames)
+        int64_t best_fpb = 256, best_cost = -1;
+        for (int64_t fpb = 256; fpb <= 8192; fpb += 256) {
+            const int64_t wgs = (nframes + fpb - 1) / fpb * nchunks;
+            const int64_t cost = (wgs + 255) / 256 * (fpb + 128);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_fpb = fpb; }
+        }
+        const int64_t gz = (nframes + best_fpb - 1) / best_fpb;
+        const size_t lds = (size_t)nku * 16 * kBlockU4 * 16;
+        const dim3 grid(xcd_grid(gz, nchunks, nchunks));
+#define BEER_LNFI(NKU_, G_)                                                                      \
+    do {                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lnfi_kernel<NKU_, G_>),          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds); \
+        hipLaunchKernelGGL((lnfi_kernel<NKU_, G_>), grid, dim3(512), lds, s, nframes, K, S, nk,  \
+                           reinterpret_cast<const u4*>(image), reinterpret_cast<const u4*>(P),   \
+                           log_norm, llh_sum, best_fpb, c0);                                     \
+    } while (0)
+#define BEER_LNFI_G(NKU_)                                                                        \
+    do {                                                                                         \
+        if (G == 4) BEER_LNFI(NKU_, 4); else if (G == 8) BEER_LNFI(NKU_, 8); else BEER_LNFI(NKU_, 16); \
+    } while (0)
+        if (nku == 1) BEER_LNFI_G(1); else if (nku == 2) BEER_LNFI_G(2); else BEER_LNFI_G(3);
+#undef BEER_LNFI_G
+#undef BEER_LNFI
+        BEER_LAUNCH_CHECK();
+        return BEER_OK;
     }
     if (image) {
         // ... with the A fragments from the caller's frame fragment image
@@ -2250,7 +2440,8 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
     }
     const int nk_used = (nslab + 7) / 8;
     // waves per workgroup: 8 (two per SIMD) with 64-component chunks, 4 with 128
-    const int waves = (NTC == 4 && NQT == 6) ? 8 : 4;
+    const bool use_image = image && blk && NTC == 4 && NQT == 6 && supported_frame_image(cov, D);
+    const int waves = (NTC == 4 && NQT == 6) ? (use_image ? beer::option(BEER_OPT_ACCFI_WAVES) : 8) : 4;
     // frames per workgroup: <= kAfMaxFramesPerWave per wave, about one workgroup of
     // 8 waves (two of 4) per CU and round
     const int rounds = beer::option(BEER_OPT_ACCF_ROUNDS);
@@ -2270,20 +2461,24 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
                        (size_t)waves * (32 * ld16_of(D) + (D + 2) * kAfXS + (blk ? 256 : 0)) *
                            sizeof(float);
     const dim3 grid(xcd_grid(gz, nchunks, nchunks));
-    if (image && blk && waves == 8 && supported_frame_image(cov, D)) {
+    if (use_image) {
         // every fragment that depends on the frames only comes from the caller's image
         const size_t lds_i = (size_t)nk_used * NTC * kBlockU4 * 16 + (size_t)waves * 256 * sizeof(float);
         const size_t lds_red = (size_t)waves * 16 * 64 * sizeof(float);
         const size_t lds_f = lds_i > lds_red ? lds_i : lds_red;
-#define BEER_ACCFI(NKU_)                                                                         \
+#define BEER_ACCFI(NKU_, W_)                                                                     \
     do {                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(accfi_kernel<NKU_>),             \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);       \
-        hipLaunchKernelGGL((accfi_kernel<NKU_>), grid, dim3(512), lds_f, s, nframes, K, S, G,     \
-                           Greal, nk, nslab, reinterpret_cast<const u4*>(image),                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(accfi_kernel<NKU_, W_>),         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds); \
+        hipLaunchKernelGGL((accfi_kernel<NKU_, W_>), grid, dim3(64 * W_), lds_f, s, nframes, K,  \
+                           S, G, Greal, nk, nslab, reinterpret_cast<const u4*>(image),           \
                            reinterpret_cast<const u4*>(P), log_norm, sr, fpb, Sp, c0);           \
     } while (0)
-        if (nk_used == 1) BEER_ACCFI(1); else if (nk_used == 2) BEER_ACCFI(2); else BEER_ACCFI(3);
+        if (waves == 8) {
+            if (nk_used == 1) BEER_ACCFI(1, 8); else if (nk_used == 2) BEER_ACCFI(2, 8); else BEER_ACCFI(3, 8);
+        } else {
+            if (nk_used == 1) BEER_ACCFI(1, 4); else if (nk_used == 2) BEER_ACCFI(2, 4); else BEER_ACCFI(3, 4);
+        }
 #undef BEER_ACCFI
         BEER_LAUNCH_CHECK();
         const int64_t total_i = (int64_t)Kreal * stats_dim(cov, D);

@@ -15,6 +15,39 @@ using namespace beer;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
+// 2^y, y <~ 0, on the plain vector ALU.  v_exp_f32 runs at a quarter of the vector rate AND
+// keeps the matrix pipe of its SIMD from issuing meanwhile -- measured
+// (tools/probes/coissue.hip): a wave of fma + add + exp triples beside a wave of MFMAs on the
+// same SIMD takes the SUM of their times (65.6 k cycles against 35.4 k + 35 k), where plain
+// fmas vanish behind the MFMAs (37 k); in the epilogues below that was 16 cycles of matrix
+// pipe per exponential.  y = n + f, n = rint(y) by the 1.5 * 2^23 trick, 2^f on [-1/2, 1/2] by a
+// degree-6 polynomial (max relative error 7.9e-8 evaluated in float32: a float32 ulp, like
+// v_exp_f32), 2^n added into the exponent field.  Arguments below -125 (padded components,
+// rows past the end) give 2^-125; NaN arguments give 2^-125 too (the log-normaliser of the
+// frame is NaN regardless: its maximum is).  11 full-rate instructions.
+#ifndef BEER_EXP_VALU
+#define BEER_EXP_VALU 0
+#endif
+#ifndef BEER_LNFI_TRANS_EVERY
+#define BEER_LNFI_TRANS_EVERY 0     // lane-major log-normaliser epilogue: every n-th exponential on v_exp_f32 (0: none)
+#endif
+__device__ __forceinline__ float exp2_valu(float y) {
+    if (!BEER_EXP_VALU) return __builtin_amdgcn_exp2f(y);
+    y = __builtin_fmaxf(y, -125.f);
+    const float magic = 12582912.f;
+    const float t = y + magic;
+    const float f = y - (t - magic);
+    float p = 0.00015345810970757157f;
+    p = __builtin_fmaf(p, f, 0.0013399930903688073f);
+    p = __builtin_fmaf(p, f, 0.009618489071726799f);
+    p = __builtin_fmaf(p, f, 0.05550328642129898f);
+    p = __builtin_fmaf(p, f, 0.24022646248340607f);
+    p = __builtin_fmaf(p, f, 0.6931471824645996f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, p) +
+                                         (int)((unsigned)__builtin_bit_cast(int, t) << 23));
+}
+
 template <typename T> struct Mma;
 template <> struct Mma<float> {
     using acc_t = f32x4;
@@ -602,7 +635,9 @@ __device__ __forceinline__ void lognorm_epilogue_lane_major(
                 float sum = 0.f;
 #pragma unroll
                 for (int c = 0; c < G; ++c)
-                    sum += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[m][q * G + c][r], L2E, nm));
+                    sum += (BEER_LNFI_TRANS_EVERY > 0 && c % BEER_LNFI_TRANS_EVERY == 0)
+                               ? __builtin_amdgcn_exp2f(__builtin_fmaf(acc[m][q * G + c][r], L2E, nm))
+                               : exp2_valu(__builtin_fmaf(acc[m][q * G + c][r], L2E, nm));
                 const float lse = __builtin_fmaf(__builtin_amdgcn_logf(sum) - d, LN2, mx) + shift;
                 if (ok && s0 + q < S) {
                     if (log_norm) row[q] = lse;

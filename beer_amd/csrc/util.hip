@@ -13,8 +13,11 @@ constexpr OptSpec kOptSpec[BEER_OPT_COUNT] = {
     {kAxMaxFramesDefault, 64, 1 << 20},      // BEER_OPT_AX_MAXFRAMES
     {6, 1, 64},               // BEER_OPT_ACCF_ROUNDS
     {0, 0, 1},                // BEER_OPT_K1_WIDE
+    {4, 4, 8},                // BEER_OPT_ACCFI_WAVES (4 or 8)
+    {1, 0, 1},                // BEER_OPT_LNFI
 };
-std::atomic<int> g_opt[BEER_OPT_COUNT] = {{kOptSpec[0].def}, {kOptSpec[1].def}, {kOptSpec[2].def}};
+std::atomic<int> g_opt[BEER_OPT_COUNT] = {{kOptSpec[0].def}, {kOptSpec[1].def}, {kOptSpec[2].def},
+                                          {kOptSpec[3].def}, {kOptSpec[4].def}};
 }  // namespace
 int option(int key) { return g_opt[key].load(std::memory_order_relaxed); }
 }  // namespace beer
@@ -35,6 +38,7 @@ int beer_hip_set_option(int option, int value) {
     if (option < 0 || option >= BEER_OPT_COUNT) return BEER_EINVAL;
     const auto& sp = beer::kOptSpec[option];
     if (value < sp.lo || value > sp.hi) return BEER_EINVAL;
+    if (option == BEER_OPT_ACCFI_WAVES && value != 4 && value != 8) return BEER_EINVAL;
     beer::g_opt[option].store(value, std::memory_order_relaxed);
     return BEER_OK;
 }

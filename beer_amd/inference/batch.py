@@ -249,7 +249,7 @@ def _emission_estep(groups, stats, dtype, for_accumulate=False):
     for grp, S, G in groups:
         ns = _normalset(grp)
         lw = grp._log_weights() if isinstance(grp, MixtureSet) else None
-        gstats = FrameStats(stats.data, ns.cov_type)
+        gstats = stats.as_cov(ns.cov_type)
         fused = for_accumulate and G > 1 and \
             kernels.fused_accumulate_ok(gstats, S, G, ns.cov_type)
         if for_accumulate and G > 1 and not fused and \
@@ -261,7 +261,7 @@ def _emission_estep(groups, stats, dtype, for_accumulate=False):
             comps.append(packed)
             continue
         log_norm, resps = kernels.mixtureset_estep(
-            stats, ns.means_precisions.natural_form(), lw, S, G, ns.cov_type,
+            gstats, ns.means_precisions.natural_form(), lw, S, G, ns.cov_type,
             want_resps=for_accumulate and G > 1 and not fused)
         cols.append(log_norm)
         comps.append(('fused', log_norm, lw) if fused else resps)
@@ -269,7 +269,8 @@ def _emission_estep(groups, stats, dtype, for_accumulate=False):
     return pc_all, comps
 
 
-def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths, max_frames):
+def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths, max_frames,
+               frame_images=None):
     emissions = model._emissions()
     groups = _groups(emissions)
     S_total = sum(S for _, S, _ in groups)
@@ -294,13 +295,18 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
     K_scratch = sum(S * G for grp, S, G in groups if G > 1 and not kernels.fused_accumulate_ok(
         FrameStats(X, _normalset(grp).cov_type), S, G, _normalset(grp).cov_type))
     bpf = (K_scratch + 2 * S_total) * X.element_size() + max_S * (3 * X.element_size() + 8)
+    if frame_images is None or not frame_images.covers(X):
+        # frame fragment images built per sub-batch and freed with it (the caller keeps none)
+        bpf += max((_hip.lib().beer_frame_image_bytes(
+            _hip.COV_CODE[_normalset(grp).cov_type], 1 << 20, X.shape[1]) >> 20)
+            for grp, _, _ in groups) if X.dtype == torch.float32 else 0
     for run in _sub_batches(lengths, bpf, max_frames):
         done = _throttle()
         f0, f1 = int(off[run[0]]), int(off[run[-1] + 1])
         run_lengths = [lengths[u] for u in run]
         # the emission E-step is queued first: building the batch descriptor (host
         # work + one asynchronous copy from pinned memory) overlaps with it
-        stats = FrameStats(X[f0:f1], _normalset(groups[0][0]).cov_type)
+        stats = FrameStats(X[f0:f1], _normalset(groups[0][0]).cov_type, images=frame_images)
         pc_all, comps = _emission_estep(groups, stats, dtype, for_accumulate=True)
         if free_loop:
             batch = _cached_batch(model.graph, run_lengths, dtype)
@@ -348,7 +354,7 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
             ns = _normalset(grp)
             sr_g = sr if len(groups) == 1 else sr[:, first:first + S].contiguous()
             first += S
-            gstats = FrameStats(X[f0:f1], ns.cov_type)
+            gstats = stats.as_cov(ns.cov_type)
             if G == 1:
                 kernels.normal_accumulate(gstats, sr_g, None, S, 1, ns.cov_type, acc=acc)
             elif isinstance(comp, tuple):
@@ -405,7 +411,7 @@ def _vae_batch(model, X, lengths, datasize, nsamples, llh_weight, kl_weight):
 
 def accumulate_elbo(model, utterances, datasize=-1, inference_graphs=None, scale=1.,
                     viterbi=False, state_paths=None, labels=None, max_frames=1 << 22,
-                    nsamples=1, llh_weight=1., kl_weight=1.):
+                    nsamples=1, llh_weight=1., kl_weight=1., frame_images=None):
     '''ELBO + accumulated statistics of a shard of utterances, identical to the
     sum of per-utterance `evidence_lower_bound(model, utt, datasize=datasize,
     inference_graph=..., scale=..., viterbi=...)` calls.
@@ -422,6 +428,9 @@ def accumulate_elbo(model, utterances, datasize=-1, inference_graphs=None, scale
         nsamples, llh_weight, kl_weight: `VAE.expected_log_likelihood`
             arguments (VAE only; the batch is one minibatch, its value keeps
             the autograd graph of the networks).
+        frame_images: optional `FrameImages` of the packed frames (HMM only; the
+            caller's, kept across iterations over the same shard).  Without it the
+            images of a sub-batch live for this call only.
     '''
     X, lengths = pack_utterances(utterances)
     if any(T <= 0 for T in lengths):
@@ -436,7 +445,7 @@ def accumulate_elbo(model, utterances, datasize=-1, inference_graphs=None, scale
         value_terms, acc = _mixture_batch(model, X, lengths, datasize, labels, max_frames)
     elif isinstance(model, HMM):
         value_terms, acc = _hmm_batch(model, X, lengths, datasize, inference_graphs, scale,
-                                      viterbi, state_paths, max_frames)
+                                      viterbi, state_paths, max_frames, frame_images)
     elif isinstance(model, VAE):
         value_terms, acc = _vae_batch(model, X, lengths, datasize, nsamples, llh_weight,
                                       kl_weight)

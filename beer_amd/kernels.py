@@ -4,7 +4,6 @@ Shapes and argument checks only: the arithmetic is in beer_amd/csrc.  All
 returned tensors live on the GPU.
 """
 
-import collections
 import os
 
 import torch
@@ -13,7 +12,7 @@ from . import _hip
 from .stats import FrameStats
 
 __all__ = ['normal_llh', 'mixtureset_estep', 'normal_accumulate', 'weights_from_acc',
-           'frame_image', 'clear_frame_images', 'is_dense', 'dense_llh', 'dense_softmax', 'dense_accumulate', 'rowdot',
+           'is_dense', 'dense_llh', 'dense_softmax', 'dense_accumulate', 'rowdot',
            'attach_stats_grad', 'differentiable_stats']
 
 LOG_2PI = 1.8378770664093453
@@ -83,7 +82,7 @@ def mixtureset_estep(stats, exp_stats, log_weights, S, G, cov_type, labels=None,
             X.dtype == torch.float32 and _hip.f32_fast_ok(X):
         # log-normalisers only, on the bf16x3 path: the logits' A fragments from the frame
         # fragment image where the frames have one (the fused accumulation uses the same)
-        img = frame_image(X, cov_type)
+        img = st.frame_image(cov_type)
         if img is not None:
             try:
                 _hip.call('beer_mixtureset_lognorm_image', _hip.COV_CODE[cov_type], T, D, S, G,
@@ -405,64 +404,11 @@ def mixtureset_accumulate_fused(stats, exp_stats, log_weights, log_norm, state_r
     ws = _hip._workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = _hip._workspaces[key] = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
-    img = frame_image(X, cov_type)
+    img = st.frame_image(cov_type)
     _hip.call('beer_mixtureset_accumulate_fused', code, T, D, S, G, _hip.ptr(X), _hip.ptr(E),
               _hip.ptr(lw), _hip.ptr(ln), _hip.ptr(sr), _hip.ptr(img), _hip.ptr(acc), _hip.ptr(ws),
               nbytes)
     return acc
-
-
-# Frame fragment images (include/beer_hip.h: beer_frame_image): a function of the frames
-# only, kept per block of frames for as long as the frames are (a training loop walks the
-# same sub-batches of the same resident tensor every iteration).  Keyed by storage
-# address, shape and torch's version counter (any in-place write makes a new image);
-# least recently used blocks are dropped beyond the budget -- min(BEER_FRAME_IMAGE_GB or
-# 64 GB, a quarter of the device memory); BEER_FRAME_IMAGE=0 disables them.
-_frame_images = collections.OrderedDict()
-_frame_image_stats = {'builds': 0, 'hits': 0, 'build_ms': 0.0, 'bytes': 0}
-
-
-def _frame_image_budget(device):
-    gb = os.environ.get('BEER_FRAME_IMAGE_GB')
-    total = torch.cuda.get_device_properties(device).total_memory
-    return int(min(float(gb) * 2 ** 30 if gb else 64 * 2 ** 30, total / 4))
-
-
-def clear_frame_images():
-    'Drop every cached frame image (and the references to the frames they were built from).'
-    _frame_images.clear()
-    _frame_image_stats['bytes'] = 0
-
-
-def frame_image(X, cov_type):
-    'The image of the float32 frames X for the fused accumulation, or None.'
-    if os.environ.get('BEER_FRAME_IMAGE', '1') == '0' or X.dtype != torch.float32:
-        return None
-    T, D = X.shape
-    code = _hip.COV_CODE[cov_type]
-    nbytes = _hip.lib().beer_frame_image_bytes(code, T, D)
-    if nbytes == 0 or T < _hip.FAST_MIN_FRAMES:
-        return None
-    key = (X.data_ptr(), T, D, code, X._version, X.device)
-    hit = _frame_images.get(key)
-    if hit is not None:
-        _frame_images.move_to_end(key)
-        _frame_image_stats['hits'] += 1
-        return hit[0]
-    budget = _frame_image_budget(X.device)
-    if nbytes > budget:
-        return None
-    while _frame_images and _frame_image_stats['bytes'] + nbytes > budget:
-        _, old = _frame_images.popitem(last=False)
-        _frame_image_stats['bytes'] -= old[0].numel()
-    img = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
-    _hip.call('beer_frame_image', code, T, D, _hip.ptr(X), _hip.ptr(img), nbytes)
-    # (the entry holds the frames too: their address cannot be given to another tensor
-    # while an image is filed under it)
-    _frame_images[key] = (img, X)
-    _frame_image_stats['builds'] += 1
-    _frame_image_stats['bytes'] += nbytes
-    return img
 
 
 def weights_from_acc(acc, S, G):

@@ -632,11 +632,15 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
     optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.,
                                       graph=not args.no_mstep_graph and world == 1)
     phases = PhaseTimer()
+    # the frames stay resident over the iterations, and so do their fragment images: the
+    # caller (this script) owns both
+    images = beer.FrameImages(X) if cov != 'full' and not os.environ.get('BEER_BENCH_NO_IMAGES') \
+        else None
 
     def step():
         optim.init_step()
         elbo = beer.accumulate_elbo(ploop, (X, lengths), datasize=datasize,
-                                    max_frames=args.max_frames)
+                                    max_frames=args.max_frames, frame_images=images)
         with phases.span('all_reduce'):
             elbo, _ = all_reduce_elbo(elbo, ploop, len(lengths))
         with phases.span('m_step'):
@@ -744,30 +748,31 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
     }
     if with_cpu_baseline and not args.no_cpu_baseline and world == 1 and cov == 'diagonal':
         out['cpu_baseline'] = cpu_baseline_hmm()
-    fi = frame_image_report(cov, X) if cov != 'full' else None
+    fi = frame_image_report(images)
     if fi:
         out['frame_image'] = fi
     return out
 
 
-def frame_image_report(cov, X):
-    '''What the fused accumulation's frame images cost (diagonal emissions): bytes held,
-    builds / hits during this run, and the time of one build (they are built in the
-    warm-up iteration, once per block of frames, and reused for as long as the frames
-    stay where they are -- like the frames themselves they are input layout, not model
-    state; BEER_FRAME_IMAGE=0 runs without them).'''
-    from beer_amd import kernels
-    st = dict(kernels._frame_image_stats)
-    if not st['builds']:
+def frame_image_report(images):
+    '''What the caller-owned frame images (beer_amd.FrameImages: diagonal emissions) hold and
+    cost: bytes of images and of the frames the object keeps alive, builds / hits during
+    this run, and the time of one build (built in the warm-up iteration, once per block of
+    frames, reused for as long as the frames stay where they are -- like the frames
+    themselves they are input layout, not model state; BEER_FRAME_IMAGE=0 runs without).'''
+    if images is None or not images.builds:
         return None
+    X = images.X
     n = min(len(X), 1 << 20)
-    probe = X[:n].clone()
+    probe = beer.FrameStats(X[:n].clone(), 'diagonal')
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record()
-    kernels.frame_image(probe, cov)
+    probe.frame_image()
     t1.record()
     torch.cuda.synchronize()
-    return {'bytes_held': st['bytes'], 'builds': st['builds'], 'hits': st['hits'],
+    return {'owner': 'beer_amd.FrameImages(X), passed to accumulate_elbo(frame_images=...)',
+            'bytes_held': images.bytes_held, 'frames_bytes': images.frames_bytes,
+            'budget_bytes': images.budget, 'builds': images.builds, 'hits': images.hits,
             'build_ms_per_million_frames': t0.elapsed_time(t1) * 1e6 / n,
             'note': 'bf16x3 fragments of phi(x) per 32-frame tile, a function of the frames only: '
                     'built in the warm-up iteration, reused by every timed one'}

@@ -64,7 +64,13 @@ int beer_hip_device_count(void);
                                   * Default 6, range 1 .. 64. */
 #define BEER_OPT_K1_WIDE 2       /* 1: the packed E-step runs its 64 x 256-per-wave form.
                                   * Default 0. */
-#define BEER_OPT_COUNT 3
+#define BEER_OPT_ACCFI_WAVES 3   /* waves per workgroup of the fused accumulation over a frame
+                                  * image: 4 (two workgroups per CU: one flushes its partial
+                                  * sums while the other multiplies) or 8.  Default 4. */
+#define BEER_OPT_LNFI 4          /* 1: beer_mixtureset_lognorm_image keeps a chunk's packed
+                                  * parameters in LDS and walks blocks of frames (lnfi_kernel);
+                                  * 0: one tile per wave, parameters streamed from L2.  Default 1. */
+#define BEER_OPT_COUNT 5
 int beer_hip_set_option(int option, int value);
 int beer_hip_get_option(int option);   /* the value, or BEER_EINVAL for an unknown option */
 
