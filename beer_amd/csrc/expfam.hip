@@ -742,11 +742,60 @@ __global__ void sb_log_weights_kernel(int P, const T* __restrict__ conc,
     }
 }
 
+// ... and for truncations beyond what a workgroup's static LDS arrays hold (the reference
+// takes any truncation, beer/models/categorical.py:84-86): the same arithmetic in the same
+// order on the global arrays themselves -- `ordering` (an output) is the stick -> category
+// table of the second phase, ranks and the sticks' E[ln(1 - v)] are recomputed where they are
+// needed.  O(P^2 / 1024) per thread: a few ms at P = 10 000, nobody's hot path.
+template <typename T>
+__global__ void sb_transform_big_kernel(int P, const T* __restrict__ counts,
+                                        int64_t* __restrict__ ordering, T* __restrict__ stats) {
+    for (int i = threadIdx.x; i < P; i += blockDim.x) ordering[sb_rank(counts, P, i)] = i;
+    __syncthreads();                                  // (one workgroup: its global writes are visible)
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const int rank = sb_rank(counts, P, i);
+        double tail = 0.0;
+        for (int r = P - 1; r > rank; --r) tail += (double)counts[ordering[r]];
+        stats[2 * i] = counts[i];
+        stats[2 * i + 1] = (T)(tail + (double)counts[i]);
+    }
+}
+
+template <typename T>
+__global__ void sb_log_weights_big_kernel(int P, const T* __restrict__ conc,
+                                          const int64_t* __restrict__ ordering,
+                                          T* __restrict__ log_w, T* __restrict__ log_1_v_sum) {
+    auto l1v = [&](int q) {
+        const int i = (int)ordering[q];
+        const double a = (double)conc[2 * i], b = (double)conc[2 * i + 1];
+        return digamma(b) - digamma(a + b);
+    };
+    double mine = 0.0;
+    for (int r = threadIdx.x; r < P; r += blockDim.x) {
+        const int i = (int)ordering[r];
+        const double a = (double)conc[2 * i], b = (double)conc[2 * i + 1];
+        double acc = digamma(a) - digamma(a + b);
+        for (int q = 0; q < r; ++q) acc += l1v(q);
+        log_w[i] = (T)acc;
+    }
+    if (log_1_v_sum) {
+        // (the sticks in order, as the small kernel adds them: thread 0 alone)
+        if (threadIdx.x == 0) {
+            for (int r = 0; r < P; ++r) mine += l1v(r);
+            *log_1_v_sum = (T)mine;
+        }
+    }
+}
+
 template <typename T>
 int sb_transform_launch(int P, const void* counts, int64_t* ordering, void* stats, void* stream) {
-    BEER_REQUIRE(P >= 1 && P <= kSbMax && counts && ordering && stats);
-    hipLaunchKernelGGL(sb_transform_kernel<T>, dim3(1), dim3(256), 0, as_stream(stream), P,
-                       (const T*)counts, ordering, (T*)stats);
+    BEER_REQUIRE(P >= 1 && counts && ordering && stats);
+    if (P <= kSbMax)
+        hipLaunchKernelGGL(sb_transform_kernel<T>, dim3(1), dim3(256), 0, as_stream(stream), P,
+                           (const T*)counts, ordering, (T*)stats);
+    else
+        hipLaunchKernelGGL(sb_transform_big_kernel<T>, dim3(1), dim3(1024), 0, as_stream(stream), P,
+                           (const T*)counts, ordering, (T*)stats);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }
@@ -754,9 +803,13 @@ int sb_transform_launch(int P, const void* counts, int64_t* ordering, void* stat
 template <typename T>
 int sb_log_weights_launch(int P, const void* conc, const int64_t* ordering, void* log_w,
                           void* log_1_v_sum, void* stream) {
-    BEER_REQUIRE(P >= 1 && P <= kSbMax && conc && ordering && log_w);
-    hipLaunchKernelGGL(sb_log_weights_kernel<T>, dim3(1), dim3(256), 0, as_stream(stream), P,
-                       (const T*)conc, ordering, (T*)log_w, (T*)log_1_v_sum);
+    BEER_REQUIRE(P >= 1 && conc && ordering && log_w);
+    if (P <= kSbMax)
+        hipLaunchKernelGGL(sb_log_weights_kernel<T>, dim3(1), dim3(256), 0, as_stream(stream), P,
+                           (const T*)conc, ordering, (T*)log_w, (T*)log_1_v_sum);
+    else
+        hipLaunchKernelGGL(sb_log_weights_big_kernel<T>, dim3(1), dim3(1024), 0, as_stream(stream),
+                           P, (const T*)conc, ordering, (T*)log_w, (T*)log_1_v_sum);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }

@@ -508,7 +508,19 @@ class CompiledGraph(torch.nn.Module):
     def weights_rewritten(self):
         '''Tell the graph that `trans_log_probs` was rewritten in place on the
         same sparsity pattern (finite entries stay finite): its device image
-        is then refreshed on the device instead of being rebuilt.'''
+        is refreshed on the device instead of being rebuilt -- right here when
+        the matrix lives on the GPU (index kernels on the current stream: part of
+        a captured M-step when one is being recorded), at the next inference
+        otherwise.'''
+        memo = self.__dict__.get('_device_memo')
+        tensors = (self.init_log_probs, self.final_log_probs, self.trans_log_probs)
+        if memo is not None and self.trans_log_probs.is_cuda and \
+                all(a is b for a, b in zip(memo[1], tensors)) and \
+                memo[2][:2] == tuple(t._version for t in tensors[:2]):
+            memo[3].refresh(self.trans_log_probs)
+            self.__dict__['_device_memo'] = (memo[0], tensors,
+                                             tuple(t._version for t in tensors), memo[3])
+            return
         self.__dict__['_weights_rewritten'] = True
 
     def __repr__(self):

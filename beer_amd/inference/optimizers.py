@@ -75,10 +75,16 @@ class VBConjugateOptimizer:
     # is put back to what the capture produced (same tensors, new contents) and everything
     # computed lazily since (KL terms, log-weights ...) is dropped.
     @staticmethod
+    def _signature(members):
+        'Identity and version of every tensor of the members\' posteriors and priors.'
+        return tuple((id(t), t._version) for p in members
+                     for t in tuple(p.posterior._tensors()) + tuple(p.prior._tensors()))
+
+    @staticmethod
     def _capturable(members):
         for p in members:
-            if getattr(p, '_callbacks', None):
-                return False                      # callbacks run Python (and host copies)
+            if getattr(p, '_callbacks', None) and not p.callbacks_device_only():
+                return False                      # callbacks that run host code / host copies
             tensors = tuple(p.posterior._tensors()) + tuple(p.prior._tensors()) + (p.stats,)
             if not all(t.is_cuda for t in tensors):
                 return False
@@ -89,8 +95,12 @@ class VBConjugateOptimizer:
         entry = self._captured.get(key)
         if entry is False:
             return False
-        if entry is not None and entry[4] != self.lrate:
-            entry = None                          # a new learning rate: capture again
+        if entry is not None and (entry[4] != self.lrate or entry[5] != self._signature(members)):
+            # a new learning rate, or the posterior was touched from outside since the
+            # capture (a state-dict load, another optimizer, a re-initialisation: its tensors
+            # were replaced or written in place -- a replay itself leaves torch's version
+            # counters alone): the graph's private eta is stale, capture again
+            entry = None
         if entry is None:
             if not self._capturable(members):
                 self._captured[key] = False
@@ -106,18 +116,30 @@ class VBConjugateOptimizer:
                     for p, st, eta in zip(members, statics, etas):
                         p.stats = st
                         eta.copy_(p.natural_grad_update(self.lrate, eta_q=eta))
-            except Exception:                     # (a step of this family cannot be captured)
+            except Exception:
+                # a step of this family cannot be captured (or the runtime refused the
+                # capture, e.g. next to a collective's watchdog): nothing ran on the device
+                # -- a capture records, it does not execute --, so the eager update below
+                # starts from the same posterior; only the host-side memos the recording
+                # wrote have to go
                 self._captured[key] = False
-                raise
+                for p, st in zip(members, statics):
+                    p.stats = st
+                    p.posterior.__dict__.pop('_memo', None)
+                    p.__dict__.pop('_kl_memo', None)
+                if os.environ.get('BEER_MSTEP_GRAPH_STRICT') == '1':
+                    raise
+                return False
             memos = [dict(p.posterior.__dict__.get('_memo', {})) for p in members]
-            entry = self._captured[key] = (graph, statics, etas, memos, self.lrate)
+            entry = self._captured[key] = (graph, statics, etas, memos, self.lrate,
+                                           self._signature(members))
         else:
-            graph, statics, etas, memos, _ = entry
+            graph, statics, etas, memos = entry[:4]
             for p, st in zip(members, statics):
                 if p.stats is not st:
                     st.copy_(p.stats)
                     p.stats = st
-        graph, statics, etas, memos, _ = entry
+        graph, statics, etas, memos = entry[:4]
         graph.replay()
         for p, memo in zip(members, memos):
             p.posterior.__dict__['_memo'] = dict(memo)

@@ -77,7 +77,27 @@ class BayesianParameter(torch.nn.Module):
                 callback()
 
     def register_callback(self, callback, notify_before_update=False):
+        '''`callback()` runs before / after every update of this parameter
+        (beer/models/parameters.py:49-57).  A callback whose work is launches on
+        device tensors only may carry the attribute `device_only = True`
+        (a function returning a bool: asked each time): the update of its
+        group can then be captured and replayed as a HIP graph (optimizers.py).'''
         self._callbacks.add((callback, notify_before_update))
+
+    def callbacks_device_only(self):
+        'True when every registered callback declares itself capturable.'
+        for callback, _ in self._callbacks:
+            flag = getattr(callback, 'device_only', None)
+            if flag is None and hasattr(callback, '__func__'):
+                flag = getattr(callback.__func__, 'device_only', None)
+            if flag is None:
+                return False
+            if callable(flag):
+                owner = getattr(callback, '__self__', None)
+                flag = flag(owner) if owner is not None else flag()
+            if not flag:
+                return False
+        return True
 
     def value(self):
         return self.posterior.expected_value()

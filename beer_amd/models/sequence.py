@@ -194,6 +194,11 @@ class PhoneLoop(HMM):
         if len(set(end_idxs)) == len(end_idxs) and len(set(start_idxs)) == len(start_idxs):
             self.graph.set_hub(end_idxs, residuals, start_idxs, log_weights)
 
+    # the callback is index arithmetic on device tensors when the graph lives on the GPU
+    # (no host copy, no synchronisation): the update of the weights' group may then be
+    # captured as a HIP graph (parameters.py: register_callback)
+    _on_weights_update.device_only = lambda self: self.graph.trans_log_probs.is_cuda
+
     def mean_field_factorization(self):
         from .mixtures import _merge_groups
         return _merge_groups(self.modelset.mean_field_factorization(),

@@ -110,15 +110,12 @@ class SBCategorical(Model):
     def create(cls, truncation, prior_strength=1.):
         return cls(cls._sticks(truncation, prior_strength))
 
-    MAX_TRUNCATION = 1024       # kSbMax of csrc/expfam.hip: one workgroup ranks the sticks
-
     def __init__(self, stickbreaking):
         super().__init__()
         self.stickbreaking = stickbreaking
         conc = stickbreaking.posterior.params.concentrations
-        if conc.shape[0] > self.MAX_TRUNCATION:
-            raise ValueError(f'stick-breaking truncation {conc.shape[0]}: beer_sb_transform_stats / '
-                             f'beer_sb_log_weights take at most {self.MAX_TRUNCATION} sticks')
+        # (any truncation, like the reference: up to 1024 sticks the kernels rank them in
+        # LDS, beyond that on the global arrays -- csrc/expfam.hip)
         self.ordering = torch.arange(conc.shape[0], device=conc.device)
         stickbreaking.register_callback(self._transform_stats, notify_before_update=True)
 

@@ -365,10 +365,11 @@ def run_gmm(args, rank, world, device, backend):
     datasize = args.frames * world if args.scaling == 'weak' else args.frames
     census = rank_census(world, device, backend, frames)
     model = make_gmm(device)             # identical on every rank
-    # (the captured M-step only where it could be validated: one process, no RCCL watchdog
-    # thread next to the capture)
+    # (the captured M-step at any world size: the capture is thread-local -- a collective's
+    # watchdog thread keeps calling into the runtime -- and a refused capture falls back to
+    # the eager update, optimizers.py)
     optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.,
-                                      graph=not args.no_mstep_graph and world == 1)
+                                      graph=not args.no_mstep_graph)
     parity = {}
     if rank == 0 and not args.no_check:
         parity = gmm_parity_check(model, X, n=min(65536, frames))
@@ -512,8 +513,11 @@ N_PHONES, N_COMP = 40, 16
 TOPO = [(0, 1, 1.), (1, 1, .75), (1, 2, .25), (2, 2, .75), (2, 3, .25), (3, 3, .75), (3, 4, .25)]
 
 
-def make_phone_loop(cov, device):
-    'beer hmm mkphones / mkphoneloopgraph / mkphoneloop in memory (recipes/aud/conf/hmm.yml topology).'
+def make_phone_loop(cov, device, dim=None, n_comp=None):
+    '''beer hmm mkphones / mkphoneloopgraph / mkphoneloop in memory (recipes/aud/conf/hmm.yml
+    topology).  `n_comp` = 1: one Gaussian per state (the prior of config 4's HMM-VAE, over
+    its `dim`-dimensional latent variable).'''
+    dim, n_comp = dim or D, n_comp or N_COMP
     units, pdf = {}, 0
     for p in range(N_PHONES):
         g = beer.graph.Graph()
@@ -539,9 +543,10 @@ def make_phone_loop(cov, device):
     graph.normalize()
     torch.manual_seed(3)
     S = 3 * N_PHONES
-    ns = beer.NormalSet.create(torch.zeros(D), torch.ones(D), size=S * N_COMP, prior_strength=1.,
+    ns = beer.NormalSet.create(torch.zeros(dim), torch.ones(dim), size=S * n_comp, prior_strength=1.,
                                noise_std=1., cov_type=cov)
-    emissions = beer.JointModelSet([beer.MixtureSet.create(S, ns, prior_strength=1.)])
+    emissions = ns if n_comp == 1 else \
+        beer.JointModelSet([beer.MixtureSet.create(S, ns, prior_strength=1.)])
     ploop = beer.PhoneLoop.create(graph.compile(), {p: 3 * p for p in units},
                                   {p: 3 * p + 2 for p in units}, emissions)
     return ploop.float().to(device)
@@ -630,7 +635,7 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
     ploop = make_phone_loop(cov, device)                     # identical on every rank
     census = rank_census(world, device, backend, n_local)
     optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.,
-                                      graph=not args.no_mstep_graph and world == 1)
+                                      graph=not args.no_mstep_graph)
     phases = PhaseTimer()
     # the frames stay resident over the iterations, and so do their fragment images: the
     # caller (this script) owns both
@@ -754,6 +759,119 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
     return out
 
 
+# --------------------------------------------------------------------------------------------
+# config 4: HMM-VAE (the prior's "statistics-in" hot path)
+# --------------------------------------------------------------------------------------------
+
+LATENT = 64
+
+
+def run_vae(args, device, frames=1_000_000, steps=3, warmup=1):
+    '''BASELINE config 4 (`configs[3]`): HMM-VAE, D = 40 frames, residual feed-forward
+    encoder / decoder (2 blocks x 128, beer/nnet), 64-dimensional Normal latent, phone-loop
+    HMM prior (40 phones x 3 states, one Gaussian per state), one minibatch of 1 M frames in
+    utterances of 200-400 frames out of the 5 M-frame corpus (datasize).  Per covariance type
+    of the prior: the whole VAE step (ELBO + backward to the networks + statistics +
+    natural-gradient / Adam update) and the prior's hot path alone -- statistics of the latent
+    samples -> per-state log-likelihoods -> forward-backward -> gradient w.r.t. the
+    statistics and the samples -> accumulation (beer/models/vae.py:63-89, hmm.py:73-100) --
+    with the HIP-event time of every C-ABI call and the roofline of the dominant one.
+    Rank 0 of a one-process run only: the minibatch does not shard.'''
+    lengths = hmm_corpus(frames)
+    total = sum(lengths)
+    g = torch.Generator(device=device).manual_seed(4)
+    X = torch.randn(total, D, generator=g, device=device)
+    names = ('beer_suffstats_mean', 'beer_dense_llh', 'beer_hmm_posteriors_fused',
+             'beer_hmm_forward_backward', 'beer_hmm_gather', 'beer_hmm_scatter',
+             'beer_dense_llh_backward', 'beer_suffstats_backward', 'beer_dense_accumulate',
+             'beer_softmax_groups', 'beer_rowdot')
+    out = {'workload': f'configs[3]: HMM-VAE, D={D}, latent {LATENT}, residual encoder/decoder '
+                       f'2x128, phone-loop prior {N_PHONES}x3 states (1 Gaussian per state), one '
+                       f'minibatch of {total} fp32 frames in {len(lengths)} utterances of the '
+                       '5 M-frame corpus, 1 sample per frame',
+           'unit': 'frames/s', 'steps': steps, 'warmup': warmup}
+    S = 3 * N_PHONES
+    for cov in ('diagonal', 'full'):
+        Qz = {'diagonal': 2 * LATENT + 2, 'full': LATENT * LATENT + LATENT + 2}[cov]
+        torch.manual_seed(4)
+        prior = make_phone_loop(cov, device, dim=LATENT, n_comp=1)
+        vae = beer.VAE(prior, beer.nnet.ResidualFeedForwardNet(D, 2, 128),
+                       beer.nnet.ResidualFeedForwardNet(LATENT, 2, 128)).to(device)
+        cjg = beer.VBConjugateOptimizer(vae.mean_field_factorization(), lrate=.1)
+        optim = beer.VBOptimizer(cjg, torch.optim.Adam(vae.parameters(), lr=1e-3))
+
+        def vae_step():
+            optim.init_step()
+            elbo = beer.accumulate_elbo(vae, (X, lengths), datasize=5_000_000)
+            elbo.backward()
+            optim.step()
+            return elbo
+
+        Z = torch.randn(total, LATENT, generator=g, device=device)
+
+        def prior_path():
+            z = Z.clone().requires_grad_(True)
+            stats = beer.kernels.differentiable_stats(z, cov, 1)
+            exp_llh = prior.expected_log_likelihood(stats, utt_lengths=lengths)
+            exp_llh.sum().backward()
+            acc = prior.accumulate(stats.detach())
+            prior.clear_cache()
+            return acc
+
+        sub = {}
+        for key, fn in (('vae_step', vae_step), ('prior_hot_path', prior_path)):
+            for _ in range(warmup):
+                fn()
+            torch.cuda.synchronize()
+            with KernelTimer(names) as kt:
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    res = fn()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+            kern = {}
+            for nm in names:
+                ms, n = kt.mean_ms(nm)
+                if n:
+                    kern[nm] = {'ms': ms, 'launches_per_step': n / steps}
+                    if nm in ('beer_dense_llh', 'beer_dense_llh_backward', 'beer_dense_accumulate'):
+                        # one [T, Q] x [Q, S] (or its transpose) product: 2 T Q S flop
+                        kern[nm]['tflops'] = 2. * total * Qz * S / (ms * 1e-3) / 1e12
+            sub[key] = {'value': total / dt, 'ms_per_step': 1e3 * dt, 'kernels': kern}
+            if key == 'vae_step':
+                sub[key]['elbo_per_frame'] = float(res) / (5_000_000 * len(lengths))
+        kern = sub['prior_hot_path']['kernels']
+        dom = max(kern, key=lambda nm: kern[nm]['ms'] * kern[nm]['launches_per_step'])
+        if 'tflops' in kern[dom]:
+            # float32 [T, Q] products on the bf16 matrix pipes, three pieces per operand
+            # (gemm3_kernel, csrc/dense.hip): priced like config 2 against the dense bf16 peak
+            roof = {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'],
+                    'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s',
+                    'frac': kern[dom]['tflops'] / PEAK_TFLOPS['bf16'], 'traffic': None,
+                    'avg_launch_ms': kern[dom]['ms'],
+                    'note': f'achieved = 2*T*Q*S algorithmic flop of one [T, Q={Qz}] x [Q, S={S}] '
+                            'product / HIP-event time; six bf16 MFMAs per float32 product'}
+        else:
+            # the dominant call streams [T, Q] / [T, S] arrays: HBM bound; algorithmic bytes =
+            # the latent samples in (and their gradient out) + the posteriors
+            byts = {'beer_suffstats_mean': 4. * total * (LATENT + Qz),
+                    'beer_suffstats_backward': 4. * total * (LATENT + Qz),
+                    'beer_hmm_posteriors_fused': 4. * total * S * 2,
+                    'beer_hmm_forward_backward': 4. * total * S * 2}.get(dom, 4. * total * Qz)
+            roof = {'bound': 'hbm', 'kernel': dom, 'achieved': byts / (kern[dom]['ms'] * 1e-3) / 1e9,
+                    'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'frac': byts / (kern[dom]['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 'traffic': None,
+                    'avg_launch_ms': kern[dom]['ms'],
+                    'note': 'achieved = algorithmic bytes of the dominant call (its [T, .] arrays '
+                            'once) / HIP-event time'}
+        sub['roofline'] = roof
+        out[cov] = sub
+        del vae, prior, optim, cjg, Z
+        torch.cuda.empty_cache()
+    out['value'] = out['diagonal']['vae_step']['value']
+    return out
+
+
 def frame_image_report(images):
     '''What the caller-owned frame images (beer_amd.FrameImages: diagonal emissions) hold and
     cost: bytes of images and of the frames the object keeps alive, builds / hits during
@@ -810,6 +928,9 @@ def worker(args):
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if args.config4_only:
+        print(json.dumps(run_vae(args, device)), flush=True)
+        return
     run = run_gmm if args.config == 2 else run_hmm
     out = run(args, rank, world, device, backend)
     if args.config == 2 and not args.no_config3:
@@ -818,13 +939,16 @@ def worker(args):
         # sharded over them)
         torch.cuda.empty_cache()
         c3 = run_hmm(args, rank, world, device, backend, cov='diagonal', total_frames=10_000_000,
-                     steps=3, warmup=1)
+                     steps=6, warmup=2)
         torch.cuda.empty_cache()
         c3f = run_hmm(args, rank, world, device, backend, cov='full', total_frames=2_000_000,
-                      steps=3, warmup=1, with_cpu_baseline=False)
+                      steps=6, warmup=2, with_cpu_baseline=False)
         if rank == 0:
             out['config3'] = config3_subobject(c3)
             out['config3_full'] = config3_subobject(c3f)
+        if rank == 0 and world == 1 and not args.no_config4:
+            torch.cuda.empty_cache()
+            out['config4'] = run_vae(args, device)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -859,6 +983,10 @@ def main():
                     help='launch the M-step kernel by kernel instead of replaying its captured HIP graph')
     ap.add_argument('--no-config3', action='store_true',
                     help='default line: skip the config3 / config3_full sub-objects')
+    ap.add_argument('--no-config4', action='store_true',
+                    help='default line: skip the config4 sub-object (HMM-VAE, one process)')
+    ap.add_argument('--config4-only', action='store_true',
+                    help='print the config4 sub-object alone (no config 2 / 3 runs)')
     ap.add_argument('--scaling', default='weak', choices=('weak', 'strong'),
                     help='config 2: 1 M frames per GPU (weak, default) or --frames in total (strong)')
     args = ap.parse_args()

@@ -170,7 +170,8 @@ int beer_dirichlet_natural(int dtype, int S, int G, const void* conc,
                            void* out, void* stream);
 int beer_dirichlet_from_natural(int dtype, int S, int G, const void* eta,
                                 void* conc, void* stream);
-/* Truncated stick-breaking categorical (P <= 1024 sticks; device, one workgroup).
+/* Truncated stick-breaking categorical (any truncation P; device, one workgroup: up to
+ * 1024 sticks ranked in LDS, beyond that on the global arrays).
  * beer_sb_transform_stats: SBCategorical._transform_stats
  * (beer/models/categorical.py:106-118) -- the sticks are ordered by decreasing
  * count (stable), `ordering[r]` = category of stick r, and the counts [P] become

@@ -1795,3 +1795,124 @@ def test_m_step_as_a_captured_graph_matches_the_eager_m_step(cov):
     assert v0 == v1
     for a, b in zip(p0, p1):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_m_step_of_a_phone_loop_as_a_captured_graph():
+    '''The group of a phone loop's unigram weights has a callback -- the phone-exit
+    transitions are rewritten with E[ln w] after every update (beer/models/phoneloop.py:53-65)
+    -- which round 3 ran on the host, so that group stayed eager.  On the GPU the callback is
+    index kernels on device tensors (and refreshes the graph's device image right away): the
+    group is captured like the others.  Four VB iterations of a small phone loop, captured
+    against eager: the same ELBOs, posteriors and transition matrix, bit for bit.'''
+    rng = np.random.RandomState(3)
+    utts = [tt((rng.randn(T, 6) * 1.3).astype(np.float32)) for T in (90, 140, 75, 110)]
+
+    def run(graph):
+        ploop = _phone_loop(4, 2, 6, 'diagonal', torch.float32, seed=9)
+        groups = ploop.mean_field_factorization()
+        optim = beer.VBConjugateOptimizer(groups, 1., graph=graph)
+        values = []
+        for _ in range(2 * len(optim.groups)):
+            optim.init_step()
+            elbo = beer.accumulate_elbo(ploop, utts, datasize=1000)
+            elbo.backward()
+            optim.step()
+            values.append(float(elbo))
+        params = [getattr(p.posterior.params, n).clone() for p in ploop.bayesian_parameters()
+                  for n in p.posterior._std_params_def]
+        return values, params, ploop.graph.trans_log_probs.clone(), optim
+
+    v0, p0, t0, _ = run(False)
+    v1, p1, t1, optim = run(True)
+    captured = [e not in (None, False) for e in optim._captured.values()]
+    assert len(captured) == len(optim.groups) and all(captured), optim._captured
+    assert v0 == v1
+    assert torch.equal(t0, t1)
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('P,dtype', [(2000, torch.float64), (1500, torch.float32), (1024, torch.float64)])
+def test_stick_breaking_with_any_truncation(P, dtype):
+    '''The reference's SBCategorical takes any truncation (beer/models/categorical.py:84-86);
+    round 3 raised beyond 1024 sticks.  2000 / 1500 sticks with tied and zero counts: the
+    ordering (stable, decreasing counts: bit-exact), the sticks' statistics, E[ln pi] after
+    the update and the mixture weights against the oracle (categorical.py:106-131, 157-159).'''
+    rng = np.random.RandomState(P)
+    counts = rng.gamma(.3, 40., P).round()            # many ties, many zeros
+    counts[rng.randint(0, P, P // 10)] = 0.
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    tol = 1e-10 if dtype == torch.float64 else 1e-5
+    sb = beer.SBCategorical.create(P, prior_strength=2.)
+    sb = (sb.double() if dtype == torch.float64 else sb.float()).to(DEV)
+    param = sb.stickbreaking
+    prior_c = npy(param.prior.params.concentrations).astype(np.float64)
+    param.stats = tt(counts.astype(npdt))
+    param.natural_grad_update(1.)                      # callback: counts -> ordered stick statistics
+    ordering, pairs = orc.sb_transform_stats(counts.astype(np.float64))
+    np.testing.assert_array_equal(npy(sb.ordering), ordering)
+    post_c = prior_c + pairs                           # Dirichlet update at lrate 1 (natural = c - 1)
+    assert_close(npy(param.posterior.params.concentrations), post_c, tol, 'stick concentrations')
+    want = orc.sb_log_weights(post_c, ordering)
+    assert_close(npy(sb.log_weights()), want, tol, 'E[ln pi]')
+    got_mean = npy(sb.mean).astype(np.float64)
+    assert got_mean.shape == (P,) and abs(got_mean.sum() - 1.) < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cov,K,dtype,tol', [('full', 24, torch.float64, 1e-9), ('full', 24, torch.float32, 1e-5),
+                                             ('diagonal', 40, torch.float32, 1e-5),
+                                             ('isotropic', 16, torch.float64, 1e-9)])
+def test_dimension_128_takes_the_generic_kernels_and_matches_the_oracle(cov, K, dtype, tol):
+    '''The reference's statistics are defined for any D (beer/dists/normalwishart.py:30-38).
+    The matrix-core kernels stop at D = 96 (float32) / 64 (float64); beyond that the generic
+    kernels of csrc/estep.hip run -- round 3 had no GPU test of them at D > 96.  A mixture at
+    D = 128 (a wav2vec-sized feature vector): ELBO, statistics per block and the posterior
+    after the M-step against the oracle; and the same model as emissions of an HMM.'''
+    from beer_amd import _hip
+    D, T = 128, 2500
+    assert D > _hip.MAX_DIM_F32
+    rng = np.random.RandomState(K + D)
+    means = rng.randn(K, D)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    Xn = (means[rng.randint(0, K, T)] + rng.randn(T, D) * (.5 + rng.rand(D))).astype(npdt)
+    X = torch.from_numpy(Xn)
+    torch.manual_seed(5)
+    var = X.var(0) if cov != 'full' else torch.diag(X.var(0))
+    ns = beer.NormalSet.create(X.mean(0), var, size=K, prior_strength=1., noise_std=1., cov_type=cov)
+    model = beer.Mixture.create(ns).to(DEV)
+    p0, p1 = params_of(model)
+    as64 = lambda d: [npy(getattr(d.params, n)).astype(np.float64) for n in d._std_params_def]
+    post, prior = as64(p0.posterior), as64(p0.prior)
+    (w_post,), (w_prior,) = as64(p1.posterior), as64(p1.prior)
+    truth = orc.gmm_elbo_step(Xn.astype(np.float64), cov, post, prior, w_post, w_prior)
+    optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), 1.)
+    optim.init_step()
+    elbo = beer.evidence_lower_bound(model, X.to(DEV))
+    assert_close(float(elbo), truth['value'], tol, 'elbo')
+    if dtype == torch.float32:
+        f32 = lambda arrs: [a.astype(np.float32) for a in arrs]
+        ref32 = orc.gmm_elbo_step(Xn, cov, f32(post), f32(prior), w_post.astype(np.float32),
+                                  w_prior.astype(np.float32))
+        assert_stats_close(npy(elbo._acc_stats[p0]), truth['acc_normal'], D, tol, 'acc normal',
+                           ref32=ref32['acc_normal'])
+    else:
+        assert_stats_close(npy(elbo._acc_stats[p0]), truth['acc_normal'], D, tol, 'acc normal')
+    assert_close(npy(elbo._acc_stats[p1]), truth['acc_weights'], tol, 'acc weights')
+    # the batched entry point == the reference's loop over utterances (accumulate.py:39-59)
+    Xd = X.to(DEV)
+    loop = beer.evidence_lower_bound(datasize=T)
+    for x in (Xd[:T - 1000], Xd[T - 1000:]):
+        loop += beer.evidence_lower_bound(model, x, datasize=T)
+    batched = beer.accumulate_elbo(model, (Xd, [T - 1000, 1000]), datasize=T)
+    assert_close(float(batched), float(loop), 1e-10 if dtype == torch.float64 else 1e-6, 'batched')
+    if dtype == torch.float64:
+        elbo.backward()
+        optim.step()
+        new_post, _ = orc.gmm_mstep(cov, post, prior, w_post, w_prior, truth['acc_normal'],
+                                    truth['acc_weights'])
+        for n, ref in zip(p0.posterior._std_params_def, new_post):
+            got = npy(getattr(p0.posterior.params, n)).astype(np.float64)
+            assert_close(got.reshape(ref.shape), ref, 1e-7, 'posterior ' + n)
