@@ -2196,8 +2196,8 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
             const int64_t cost = (wgs + 255) / 256 * (fpb + 128);
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_fpb = fpb; }
         }
-        const int64_t gz = (nframes + best_fpb - 1) / best_fpb;
         const size_t lds = (size_t)nku * 16 * kBlockU4 * 16;
+        const int64_t gz = (nframes + best_fpb - 1) / best_fpb;
         const dim3 grid(xcd_grid(gz, nchunks, nchunks));
 #define BEER_LNFI(NKU_, G_)                                                                      \
     do {                                                                                         \

@@ -699,7 +699,7 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
              'beer_mixtureset_estep_packed': 'llhx_kernel',
              'beer_mixtureset_accumulate_packed': 'accx_kernel',
              'beer_mixtureset_estep': 'llhx_kernel',
-             'beer_mixtureset_lognorm_image': 'llhx_kernel',
+             'beer_mixtureset_lognorm_image': 'lnfi_kernel',
              'beer_hmm_posteriors_fused': 'fb_wave_kernel'}.get(dom, dom)
     pmc_key = ('c3full_' if cov == 'full' else 'c3_') + kname
     pmc = pmc_entry(pmc_key)
