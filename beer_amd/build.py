@@ -21,6 +21,13 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall',
          '-Wno-unused-function', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
 
 
+# Per-file flags.  estep_bf16.hip: no SLP vectorisation -- hipcc pairs adjacent float32
+# adds / multiplies of the fragment arithmetic into v_pk_* instructions, which beside MFMAs cost
+# more than the two plain instructions they replace (MI355X_MICROARCH.md, price of a filler;
+# measured: fused accumulation of config 3 10.6 -> 10.3 ms per 3.33 M frames).
+FILE_FLAGS = {'estep_bf16.hip': ['-fno-slp-vectorize']}
+
+
 def _sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
@@ -50,7 +57,7 @@ def build(force=False, verbose=True):
                                             [src] + glob.glob(os.path.join(CSRC, '*.h')) +
                                             glob.glob(os.path.join(ROOT, 'include', '*.h'))):
             continue
-        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

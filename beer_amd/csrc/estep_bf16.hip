@@ -125,6 +125,14 @@ __device__ __forceinline__ void mfma_drain() {
 __host__ __device__ inline size_t frame_image_tile_u4(int nk_used, int nqt) {
     return (size_t)(nk_used * NP * 2 + nqt * NP) * 64;
 }
+// Statistic tiles of a frame image: the DATA slabs of a diagonal / isotropic model only
+// (squares and linear terms: 2 D4 <= 20 slabs = 5 tiles of 16 columns at D <= 40), in the
+// table's order without its constant slabs -- data slab j is slab j + j / 7 (every eighth
+// slab closes a k-step with a constant, estep_tiles.h: diag_walk).  The counts N_k, the only
+// statistic a constant slab carries, are summed on the vector ALU (accfi_kernel): a sixth
+// tile for one useful column in sixteen cost 24 of a wave-tile's 288 MFMAs.
+constexpr int kImgNQT = 5;
+__host__ __device__ inline int stat_slab(int j) { return j + j / 7; }
 // k-steps (8 slabs each), padded to an even count: the K1 loop is unrolled by two
 __host__ __device__ inline int nk16_of(int cov, int D) {
     return ((nslab_of(cov, D) + 7) / 8 + 1) / 2 * 2;
@@ -536,7 +544,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
     // statistics' fragments, which this kernel does not use
     const u4* ti = nullptr;
     if constexpr (IMG)
-        ti = img + (fb / FW) * (int64_t)frame_image_tile_u4(nku, 6) + lane;
+        ti = img + (fb / FW) * (int64_t)frame_image_tile_u4(nku, kImgNQT) + lane;
     auto load_a = [&](int s, AFrag& f) {
 #pragma unroll
         for (int q = 0; q < NP; ++q)
@@ -1567,8 +1575,9 @@ __global__ __launch_bounds__(256) void frame_image_kernel(int64_t nframes, int D
             for (int m = 0; m < MT; ++m) out[((s * NP + q) * MT + m) * 64] = w[q][m];
     }
     out += (size_t)nk_used * NP * MT * 64;
+    const int ndata = 2 * D4;                              // data slabs: squares and linear terms
     for (int uu = 0; uu < nqt; ++uu) {
-        const int col = 16 * uu + i, slab = col >> 2;
+        const int col = 16 * uu + i, slab = (col >> 2) < ndata ? stat_slab(col >> 2) : nslab;
         int a = Dp + 2, b = Dp + 2;
         if (slab < nslab) {
             const int t = tabs[slab];
@@ -1601,7 +1610,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
     const u4* __restrict__ img, const u4* __restrict__ Pall, const float* __restrict__ log_norm,
     const float* __restrict__ sr, int64_t frames_per_block, double* __restrict__ Sp,
     const float* __restrict__ c0p) {
-    constexpr int NTC = 4, NQT = 6, MT = 2, FW = 32, NTHREADS = 64 * WAVES;
+    constexpr int NTC = 4, NQT = kImgNQT, MT = 2, FW = 32, NTHREADS = 64 * WAVES;
     constexpr int kTileU4 = (NKU * NP * MT + NQT * NP) * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int64_t bx;
@@ -1646,6 +1655,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
     for (int c = 0; c < NTC; ++c)
 #pragma unroll
         for (int uu = 0; uu < NQT; ++uu) sacc[c][uu] = f32x4{0, 0, 0, 0};
+    // counts N_k = sum_t r sr of the lane's component (tile c, column i) over the frames of
+    // its row group: plain float32 additions of the weights the statistics are multiplied with
+    float cnt[NTC];
+#pragma unroll
+    for (int c = 0; c < NTC; ++c) cnt[c] = 0.f;
 
     const int lr = lane & 31, lh = lane >> 5;
     f32x4 lsv = f32x4{0, 0, 0, 0};
@@ -1760,6 +1774,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
             }
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt)
+            cnt[nt] += ((acc[0][nt][0] + acc[0][nt][1]) + (acc[0][nt][2] + acc[0][nt][3])) +
+                       ((acc[1][nt][0] + acc[1][nt][1]) + (acc[1][nt][2] + acc[1][nt][3]));
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1810,6 +1828,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
     }
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);          // [WAVES][16 = c * 4 + r][64 lanes]
+    const int ndata = nslab - 1 - (nslab - 1) / 8;         // squares and linear terms (no constants)
     constexpr int EPT = 16 * 64 / NTHREADS;
     int64_t dst_row[EPT];
     int dst_i[EPT];
@@ -1835,10 +1854,31 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
             double t = 0.0;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) t += (double)red[w * 1024 + el];
-            const int q = 16 * uu + dst_i[e];
-            if (dst_row[e] >= 0 && q < nq) atomicAdd(Sp + dst_row[e] + q, t);
+            // statistic column of (tile uu, column i): data slab (16 uu + i) / 4 of the table
+            const int dslab = (16 * uu + dst_i[e]) >> 2;
+            const int q = stat_slab(dslab) * 4 + (dst_i[e] & 3);
+            if (dst_row[e] >= 0 && dslab < ndata) atomicAdd(Sp + dst_row[e] + q, t);
         }
         __syncthreads();
+    }
+    // the counts: over the lane's 4 row groups (lanes i, i + 16, i + 32, i + 48), then over the
+    // waves in fp64, into entry 0 of the final constant slab (what unpack_kernel reads)
+#pragma unroll
+    for (int c = 0; c < NTC; ++c) {
+        float v = cnt[c];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16) red[(wave * NTC + c) * 16 + lane] = v;
+    }
+    __syncthreads();
+    if (tid < 16 * NTC) {
+        const int c = tid >> 4, ii = tid & 15;
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) t += (double)red[(w * NTC + c) * 16 + ii];
+        const int slot = kbase + 4 * ii + c, gi = slot % G;
+        if (slot < K && gi < Greal)
+            atomicAdd(Sp + (int64_t)((slot / G) * Greal + gi) * nq + (nslab - 1) * 4, t);
     }
 }
 
@@ -1861,7 +1901,7 @@ __global__ __launch_bounds__(512, 2) void lnfi_kernel(
     const u4* __restrict__ Pall, float* __restrict__ log_norm, double* __restrict__ llh_sum,
     int64_t frames_per_block, const float* __restrict__ c0p) {
     constexpr int NT = 16, MT = 2, FW = 32, WAVES = 8, NTHREADS = 64 * WAVES;
-    constexpr int kTileU4 = (NKU * NP * MT + 6 * NP) * 64;
+    constexpr int kTileU4 = (NKU * NP * MT + kImgNQT * NP) * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int64_t bx;
     int by;
@@ -2380,7 +2420,7 @@ size_t frame_image_bytes(int cov, int64_t nframes, int D) {
     if (!supported_frame_image(cov, D) || nframes < 0) return 0;
     const int nk = nk16_of(cov, D), nk_used = (nslab_of(cov, D) + 7) / 8;
     const int64_t tiles = (nframes + 31) / 32;
-    return (size_t)tiles * frame_image_tile_u4(nk_used, 6) * 16 + up256((size_t)(nk + 1) * 8 * sizeof(int));
+    return (size_t)tiles * frame_image_tile_u4(nk_used, kImgNQT) * 16 + up256((size_t)(nk + 1) * 8 * sizeof(int));
 }
 __global__ void tabx_kernel(int cov, int D, int nk, int* __restrict__ tab) {
     const int Dp = 4 * d4_of(D);
@@ -2393,12 +2433,12 @@ int frame_image(int cov, int64_t nframes, int D, const float* X, void* image, hi
     const int nk = nk16_of(cov, D), nslab = nslab_of(cov, D), nk_used = (nslab + 7) / 8;
     const int64_t tiles = (nframes + 31) / 32;
     int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(image) +
-                                      (size_t)tiles * frame_image_tile_u4(nk_used, 6) * 16);
+                                      (size_t)tiles * frame_image_tile_u4(nk_used, kImgNQT) * 16);
     hipLaunchKernelGGL(tabx_kernel, dim3(1), dim3(256), 0, s, cov, D, nk, tab);
     const size_t lds = (size_t)(nk + 1) * 8 * sizeof(int) +
                        (size_t)4 * (32 * ld16_of(D) + (D + 2) * kAfXS) * sizeof(float);
     hipLaunchKernelGGL(frame_image_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), lds, s,
-                       nframes, D, nk, nslab, 6, X, tab, reinterpret_cast<u4*>(image));
+                       nframes, D, nk, nslab, kImgNQT, X, tab, reinterpret_cast<u4*>(image));
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }

@@ -769,6 +769,9 @@ constexpr int kWvWaves = BEER_FB_WAVES; // utterances (waves) per workgroup
 #define BEER_FB_PF 4
 #endif
 constexpr int kWvPF = BEER_FB_PF;      // steps of look-ahead of the global loads
+#ifndef BEER_FB_OCC
+#define BEER_FB_OCC 4                  // waves per SIMD the linear-domain kernel is compiled for
+#endif
 
 template <typename T> struct Lin;
 template <> struct Lin<float> {
@@ -799,7 +802,7 @@ __device__ __forceinline__ int expo_field(double v) {
 }
 
 template <typename T, int SPL, int DEG, bool FUSED, bool XI>
-__global__ __launch_bounds__(64 * kWvWaves) void fb_wave_kernel(
+__global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_wave_kernel(
     beer_batch b, const T* __restrict__ pc, int S_total, T scale, double* __restrict__ alpha_ws,
     double* __restrict__ hubf_ws, T* __restrict__ out, T resp_scale, int atomic_out,
     double* __restrict__ xi_sum, double* __restrict__ gamma0_sum, double* __restrict__ hub_flow,

@@ -1681,7 +1681,7 @@ def test_elbo_round_trip_through_the_flat_device_buffer():
 @pytest.mark.gpu
 @pytest.mark.parametrize('cov,T,D,S,G', [('diagonal', 40000, 40, 24, 16), ('diagonal', 33001, 20, 9, 16),
                                          ('isotropic', 20011, 12, 6, 32), ('diagonal', 17000, 8, 40, 8)])
-def test_fused_accumulation_with_frame_image_is_bit_identical(monkeypatch, cov, T, D, S, G):
+def test_fused_accumulation_with_frame_image_matches_the_plain_kernel(monkeypatch, cov, T, D, S, G):
     '''beer_frame_image + beer_mixtureset_accumulate_fused(frame_image=...) -- the frames'
     fragments built once and loaded -- against the same call that rebuilds them per
     component chunk: the same numbers (fp64 sums of the same float32 partial sums; the
@@ -1736,7 +1736,13 @@ def test_fused_accumulation_with_frame_image_is_bit_identical(monkeypatch, cov, 
     assert torch.equal(ln_img, ln_plain)
     without = kernels.mixtureset_accumulate_fused(st, E, lw, ln, sr, S, G, cov)
     scale = float(without.abs().max())
-    assert float((with_img - without).abs().max()) <= 1e-12 * scale
+    # the moments: the same float32 partial sums (fp64 sums of them in another order); the
+    # counts (last two columns, -N/2 and N/2 or D N/2): the image kernel adds the weights on the
+    # vector ALU, the other one multiplies them with a column of ones on the matrix cores --
+    # float32 rounding apart
+    assert float((with_img - without)[:, :-2].abs().max()) <= 1e-12 * scale
+    cscale = float(without[:, -2:].abs().max())
+    assert float((with_img - without)[:, -2:].abs().max()) <= 5e-7 * cscale
     assert float((again - with_img).abs().max()) <= 1e-12 * scale
     monkeypatch.delenv('BEER_FRAME_IMAGE')
     X.add_(0.)                                             # an in-place write: a new image

@@ -16,7 +16,8 @@ if len(sys.argv) > 1 and sys.argv[1].endswith('.hip'):      # another source of 
 cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-mllvm',
        '-pragma-unroll-threshold=262144', '-Wno-unused-function', '-DBEER_KERNEL_PROBE',
        '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.dirname(SRC), '-S',
-       '--cuda-device-only', SRC, '-o', OUT] + sys.argv[1:]
+       '--cuda-device-only', SRC, '-o', OUT] + \
+    (['-fno-slp-vectorize'] if SRC.endswith('estep_bf16.hip') else []) + sys.argv[1:]
 subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 s = open(OUT).read()
 for f in re.split(r'\n\t\.globl\t', s)[1:]:
