@@ -923,8 +923,13 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
                         else if (n == 4) xb[1] = *reinterpret_cast<const f32x4*>(pb + 16);
                         else if (n >= 12 && n < 20) {
                             const int e = n - 12;
-                            pp[e] = xa[e >> 2][e & 3] * xb[e >> 2][e & 3];
-                            pin(pp[e]);
+                            if (BEER_ASM_STEPS) {
+                                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(pp[e])
+                                             : "v"(xa[e >> 2][e & 3]), "v"(xb[e >> 2][e & 3]));
+                            } else {
+                                pp[e] = xa[e >> 2][e & 3] * xb[e >> 2][e & 3];
+                                pin(pp[e]);
+                            }
                         } else if (n >= 20) {
                             const int e = (n - 20) / 7;
                             split3_step((n - 20) % 7, pp[2 * e], pp[2 * e + 1], st[e]);

@@ -336,8 +336,36 @@ __device__ __forceinline__ void split3(float a, float b, unsigned (&p)[3]) {
 template <typename V>
 __device__ __forceinline__ void pin(V& v) { asm volatile("" : "+v"(v)); }
 struct Split3Steps { unsigned w0, w1, w2; float r0, r1; };
+// BEER_ASM_STEPS: every step is a volatile asm statement (one or two instructions).  Pinning
+// the RESULT of a C++ step (pin()) keeps it from sinking to its first use, but the machine
+// scheduler still slides the instruction itself along the stream and gathers the steps into
+// runs of four or five behind every second MFMA -- and an in-order wave that meets
+// `M M v v v v` waits for the matrix pipe in front of the second M with nothing to issue
+// (21.5 cycles per MFMA against 17.3 for `M v v M v v`, tools/probes/coissue.hip).  Volatile asm
+// statements keep their program order among themselves: the steps stay where they are written.
+#ifndef BEER_ASM_STEPS
+#define BEER_ASM_STEPS 1
+#endif
 __device__ __forceinline__ void split3_step(int k, float a, float b, Split3Steps& t) {
 #pragma clang fp contract(off)
+    if (BEER_ASM_STEPS) {
+        unsigned tmp;
+        switch (k) {
+            case 0: asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(t.w0) : "v"(a), "v"(b)); break;
+            case 1: asm volatile("v_lshlrev_b32 %0, 16, %1\n\tv_sub_f32 %0, %2, %0"
+                                 : "=&v"(t.r0) : "v"(t.w0), "v"(a)); break;
+            case 2: asm volatile("v_and_b32 %0, 0xffff0000, %1\n\tv_sub_f32 %0, %2, %0"
+                                 : "=&v"(t.r1) : "v"(t.w0), "v"(b)); break;
+            case 3: asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(t.w1) : "v"(t.r0), "v"(t.r1)); break;
+            case 4: asm volatile("v_lshlrev_b32 %0, 16, %2\n\tv_sub_f32 %1, %1, %0"
+                                 : "=&v"(tmp), "+v"(t.r0) : "v"(t.w1)); break;
+            case 5: asm volatile("v_and_b32 %0, 0xffff0000, %2\n\tv_sub_f32 %1, %1, %0"
+                                 : "=&v"(tmp), "+v"(t.r1) : "v"(t.w1)); break;
+            case 6: asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(t.w2) : "v"(t.r0), "v"(t.r1)); break;
+            default: break;
+        }
+        return;
+    }
     switch (k) {
         case 0: t.w0 = cvt_pk_bf16(a, b); pin(t.w0); break;
         case 1: t.r0 = a - __builtin_bit_cast(float, t.w0 << 16); pin(t.r0); break;
