@@ -931,8 +931,17 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
                                 pin(pp[e]);
                             }
                         } else if (n >= 20) {
-                            const int e = (n - 20) / 7;
-                            split3_step((n - 20) % 7, pp[2 * e], pp[2 * e + 1], st[e]);
+                            // two pairs at a time, their seven steps alternating: a step and the
+                            // one that consumes its result are two MFMAs apart (back to back --
+                            // one MFMA apart -- hipcc pads the dependence with an s_nop: 612 of
+                            // them per tile pair)
+#ifndef BEER_K2_CHAINS
+#define BEER_K2_CHAINS 2
+#endif
+                            constexpr int NCH = BEER_K2_CHAINS;
+                            const int m = n - 20, grp = m / (7 * NCH), mm = m % (7 * NCH);
+                            const int e = NCH * grp + mm % NCH;
+                            split3_step(mm / NCH, pp[2 * e], pp[2 * e + 1], st[e]);
                         }
                     }
                     if (build) {
