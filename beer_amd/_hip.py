@@ -315,7 +315,9 @@ def set_f32_mode(mode):
     bitwise an fmaf chain) or 'bf16x3' (default: every operand exactly as three
     bf16 pieces, the six leading partial products of each multiplication on the
     bf16 MFMA, fp32 accumulation -- fp32's own operands and accumulation, product
-    error <= 2^-23, at 2.7x the fp32 pipe's rate).'''
+    error <= 2^-23, at 2.7x the fp32 pipe's rate).  The mode governs the kernels that
+    take FRAMES (E-step, accumulation); the statistics-in products of a VAE's prior
+    (`beer_dense_*`: large float32 shapes) are bf16x3 in either mode.'''
     if mode not in F32_MODES:
         raise ValueError(f'f32 mode {mode!r}: expected one of {F32_MODES}')
     _f32_mode[0] = mode

@@ -601,7 +601,10 @@ int beer_segment_sum(int dtype, int32_t nutt, const int64_t* frame_off,
  * the matrix cores in the E-step's bf16x3 arithmetic (float32 operands held
  * exactly as three bf16 pieces, float32 accumulation; sums over frames in chains
  * of 4096 frames, fp64 between workgroups); everything else, and fp64, on an
- * LDS-tiled kernel that accumulates in fp64.  No library underneath. */
+ * LDS-tiled kernel that accumulates in fp64.  No library underneath.  These entry
+ * points take BEER_F32 / BEER_F64 only: BEER_EXACT (the fp32 MFMA of the frame
+ * kernels) has no counterpart here -- large float32 shapes are bf16x3, as
+ * accurate as a float32 product, in either mode of the host layer. */
 
 /* out[t,k] = sum_q stats[t,q] * exp_stats[k,q] + base   -> [T, K]
  * (ConjugateLikelihood.__call__, beer/dists/normalgamma.py:55-59; base is the
