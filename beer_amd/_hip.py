@@ -59,7 +59,7 @@ def lib():
 # BEER_OPT_* of include/beer_hip.h and the environment variables that preset them
 OPTIONS = {'ax_max_frames': (0, 'BEER_AX_MAXFRAMES'), 'accf_rounds': (1, 'BEER_ACCF_ROUNDS'),
            'k1_wide': (2, 'BEER_K1_WIDE'), 'accfi_waves': (3, 'BEER_ACCFI_WAVES'),
-           'lnfi': (4, 'BEER_LNFI'), 'accfi_pipe': (5, 'BEER_ACCFI_PIPE')}
+           'lnfi': (4, 'BEER_LNFI')}
 
 
 def _options_from_env(l):

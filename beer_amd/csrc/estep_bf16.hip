@@ -120,21 +120,6 @@ __device__ __forceinline__ void mfma_drain() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// the first MFMA of an accumulation chain: C = 0 (no zeroing of the AGPR quad)
-__device__ __forceinline__ void mfma_bf16_first(f32x4& acc, const u4& a, const u4& b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
-}
-// one-instruction steps of a hand-placed stream (volatile: they stay where they are written)
-__device__ __forceinline__ void step_acc_read(float& dst, const float& src) {
-    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(dst) : "a"(src));
-}
-__device__ __forceinline__ void step_fma(float& x, float a, float b) {        // x = x * a + b
-    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void step_exp2(float& x) { asm volatile("v_exp_f32 %0, %0" : "+v"(x)); }
-__device__ __forceinline__ void step_mul(float& x, float a) { asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(a)); }
-__device__ __forceinline__ void step_add(float& x, float a) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(a)); }
-
 // u4 per 32-frame tile of a frame fragment image (frame_image_kernel): A fragments of
 // nk_used k-steps (3 pieces x 2 frame tiles), then B fragments of nqt statistic tiles
 __host__ __device__ inline size_t frame_image_tile_u4(int nk_used, int nqt) {
@@ -2044,358 +2029,6 @@ __global__ __launch_bounds__(512, 2) void lnfi_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------
-// The fused accumulation over a frame image as ONE hand-placed stream per SIMD, software
-// pipelined over the wave's tiles (dense state posteriors: no tile is skipped).
-// accfi_kernel alternates, in every wave, a phase of 144 logit MFMAs, a phase of ~280 vector
-// instructions (exponentials, weights, three-way splits) and a phase of 120 statistic MFMAs;
-// phases ADD unless the partner wave of the SIMD happens to be in the other one
-// (tools/probes/coissue.hip, mode 3), and it ran at 71-75 % MFMA busy.  Here iteration n of a
-// wave issues
-//     MFMAs:    statistics of tile n-1   (A = ar[1-p], the responsibilities split last time)
-//               logits of tile n+1       (into lacc[1-p])
-//     between:  one step per MFMA of X(n): read logit of tile n from lacc[p] (AGPR), fma, exp2,
-//               weight, count, three-way split -> ar[p]
-// with p = n & 1: the vector work of a tile stands BETWEEN the MFMAs of its neighbours (two
-// plain instructions per MFMA are free; volatile asm keeps every step where it is written).
-// Accumulators live in AGPRs ("+a"): 80 for the statistics, 2 x 32 for the logits.
-// Same products in the same order as accfi_kernel per tile; what differs is the order in
-// which the tiles' float32 partial sums meet (none: a wave's chain is the same tiles in the
-// same order) -- results equal accfi_kernel's up to the fp64 sums' order.
-// ---------------------------------------------------------------------------
-template <int NKU>
-__global__ __launch_bounds__(256, 1) void accfp_kernel(
-    int64_t nframes, int K, int S, int G, int Greal, int nk, int nslab,
-    const u4* __restrict__ img, const u4* __restrict__ Pall, const float* __restrict__ log_norm,
-    const float* __restrict__ sr, int64_t frames_per_block, double* __restrict__ Sp,
-    const float* __restrict__ c0p) {
-    constexpr int NTC = 4, NQT = kImgNQT, MT = 2, FW = 32, WAVES = 4, NTHREADS = 64 * WAVES;
-    constexpr int kTileU4 = (NKU * NP * MT + NQT * NP) * 64;
-    constexpr float L2E = 1.44269504088896340736f;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int64_t bx;
-    int by;
-    {
-        const int nch = (K + 16 * NTC - 1) / (16 * NTC);
-        if (!xcd_block((nframes + frames_per_block - 1) / frames_per_block, nch, nch, bx, by))
-            return;
-    }
-    const int nq = nslab * 4;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 15, g = lane >> 4;
-    constexpr int p_u4 = NKU * NTC * kBlockU4;
-    u4* Ps = reinterpret_cast<u4*>(smem);
-    // per wave: two buffers (tile parity) of [2 = normalisers / posteriors][FW rows][4 states]
-    float* lsw = reinterpret_cast<float*>(Ps + p_u4) + wave * (2 * 2 * FW * 4);
-    {
-        const u4* src = Pall + (size_t)by * nk * NTC * kBlockU4;
-        for (int idx = tid; idx < p_u4; idx += NTHREADS) Ps[idx] = src[idx];
-    }
-    __syncthreads();
-    const int kbase = by * (16 * NTC);
-    const float c0 = c0p[0];
-    const int64_t tb = bx * frames_per_block;
-    const int64_t te = tb + frames_per_block < nframes ? tb + frames_per_block : nframes;
-    const u4* Pl = Ps + lane;
-    int sidx, st0c;
-    {
-        const int s0 = (kbase + 4 * i) / G, st = s0 < S ? s0 : S - 1;
-        const int st0 = kbase / G < S ? kbase / G : S - 1;
-        st0c = st0 < S - 4 ? st0 : S - 4;
-        sidx = st - st0c;
-    }
-    const int64_t fb0 = tb + (int64_t)wave * FW;
-    const int ntiles = fb0 < te ? (int)((te - fb0 + WAVES * FW - 1) / (WAVES * FW)) : 0;
-
-    f32x4 sacc[NTC][NQT];          // statistics (AGPR)
-    f32x4 lacc[2][MT][NTC];        // logits of two tiles (AGPR)
-#pragma unroll
-    for (int c = 0; c < NTC; ++c)
-#pragma unroll
-        for (int uu = 0; uu < NQT; ++uu) sacc[c][uu] = f32x4{0, 0, 0, 0};
-    float cnt[NTC];
-#pragma unroll
-    for (int c = 0; c < NTC; ++c) cnt[c] = 0.f;
-    u4 ar[2][NTC][NP];             // responsibilities x posteriors as statistics A fragments
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int c = 0; c < NTC; ++c)
-#pragma unroll
-            for (int q = 0; q < NP; ++q) ar[b][c][q] = u4{0, 0, 0, 0};
-
-    auto tile_fb = [&](int n) { return fb0 + (int64_t)(n < ntiles ? (n < 0 ? 0 : n) : ntiles - 1) * WAVES * FW; };
-    auto tile_img = [&](int n) { return img + (tile_fb(n) / FW) * (int64_t)kTileU4 + lane; };
-
-    const int lr = lane & 31, lh = lane >> 5;
-    f32x4 lsv = f32x4{0, 0, 0, 0};
-    auto issue_ls = [&](int n) {         // normalisers / posteriors of tile n's rows (a tile past the end: the last)
-        const int64_t fbn = tile_fb(n);
-        const int rows_n = (int)(te - fbn < FW ? te - fbn : FW);
-        const int64_t rown = fbn + (lr < rows_n ? lr : rows_n - 1);
-        const float* src = ((lh && sr) ? sr : log_norm) + rown * S + st0c;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lsv[j] = src[j];
-    };
-    u4 af[2][NP][MT];
-    u4 bp[2][NP];
-    u4 bq[3][NP];
-
-    // logits of tile n (MFMAs only) into lacc[b]: the first product of every chain takes C = 0
-    auto logits_only = [&](int n, auto bsel) {
-        constexpr int b = decltype(bsel)::value;
-        const u4* ti = tile_img(n);
-#pragma unroll
-        for (int q = 0; q < NP; ++q)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) af[0][q][m] = ti[(q * MT + m) * 64];
-#pragma unroll
-        for (int pq = 0; pq < NP; ++pq) bp[0][pq] = Pl[64 * pq];
-        static_for<NKU>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            if constexpr (s + 1 < NKU) {
-#pragma unroll
-                for (int q = 0; q < NP; ++q)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) af[(s + 1) & 1][q][m] = ti[(((s + 1) * NP + q) * MT + m) * 64];
-            }
-            static_for<NTC>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-                constexpr int gi = s * NTC + c, gn = gi < NKU * NTC - 1 ? gi + 1 : NKU * NTC - 1;
-#pragma unroll
-                for (int pq = 0; pq < NP; ++pq) bp[(gi + 1) & 1][pq] = Pl[gn * kBlockU4 + 64 * pq];
-                static_for<6>([&](auto prc) {
-                    constexpr int pr = decltype(prc)::value;
-                    static_for<MT>([&](auto mc) {
-                        constexpr int m = decltype(mc)::value;
-                        if constexpr (s == 0 && pr == 0)
-                            mfma_bf16_first(lacc[b][m][c], af[s & 1][kProdA[pr]][m], bp[gi & 1][kProdB[pr]]);
-                        else
-                            mfma_bf16_pinned<false>(lacc[b][m][c], af[s & 1][kProdA[pr]][m],
-                                                    bp[gi & 1][kProdB[pr]]);
-                    });
-                });
-            });
-        });
-    };
-
-    // ---- the steps of X(n): logits of tile n (lacc[p]) -> ar[p], cnt ----
-    // per lane 8 rows (m, r): nlL = ((row exists ? c0 : -1e30) - log_norm) * log2(e), wg = posterior
-    float nlL[MT][4], wg[MT][4], wv[4];
-    Split3Steps st[2];
-    // steps 0 .. 15: the 16 row constants; then per (m, nt) group 34 steps
-    constexpr int kRowSteps = 2 * MT * 4, kGrpSteps = 4 * 5 + 2 * 7, kXSteps = kRowSteps + MT * NTC * kGrpSteps;
-    constexpr int kNMFMA = NQT * 6 * NTC + NKU * NTC * 6 * MT;       // 120 + 144
-    auto xstep = [&](auto kc, auto pc, const float* lsb, int rows) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value, p = decltype(pc)::value;
-        if constexpr (k < kRowSteps) {
-            constexpr int h = k / (MT * 4), m = (k / 4) % MT, r = k % 4;
-            const int row = 16 * m + 4 * g + r;
-            const bool ok = row < rows;
-            if constexpr (h == 0) {
-                const float v = ((ok ? c0 : -1.0e30f) - lsb[row * 4 + sidx]) * L2E;
-                nlL[m][r] = v;
-                pin(nlL[m][r]);
-            } else {
-                const float v = (sr ? lsb[(FW + row) * 4 + sidx] : 1.f) * (ok ? 1.f : 0.f);
-                wg[m][r] = v;
-                pin(wg[m][r]);
-            }
-        } else {
-            constexpr int kk = k - kRowSteps, grp = kk / kGrpSteps, q = kk % kGrpSteps;
-            constexpr int m = grp / NTC, nt = grp % NTC;
-            // op-major over the group's four values, then the count additions between the
-            // split steps of the two pairs: a step and the one that consumes its result are at
-            // least two MFMAs apart (one apart, hipcc pads the dependence with an s_nop)
-            auto split = [&](auto ec, auto skc) {
-                constexpr int e = decltype(ec)::value, sk = decltype(skc)::value;
-                split3_step(sk, wv[2 * e], wv[2 * e + 1], st[e]);
-                if constexpr (sk == 6) {
-                    ar[p][nt][0][2 * m + e] = st[e].w0;
-                    ar[p][nt][1][2 * m + e] = st[e].w1;
-                    ar[p][nt][2][2 * m + e] = st[e].w2;
-                }
-            };
-            if constexpr (q < 16) {
-                constexpr int op = q / 4, r = q % 4;
-                if constexpr (op == 0) {
-                    // (one v_accvgpr_read_b32; an asm operand "a"(element) makes hipcc carry the
-                    // element through a VGPR into a scratch AGPR first: three moves)
-                    wv[r] = lacc[p][m][nt][r];
-                    pin(wv[r]);
-                }
-                else if constexpr (op == 1) step_fma(wv[r], L2E, nlL[m][r]);
-                else if constexpr (op == 2) step_exp2(wv[r]);
-                else step_mul(wv[r], wg[m][r]);
-            } else if constexpr (q < 28) {
-                // add r, split step r of pair 0, split step r of pair 1   (r = 0 .. 3)
-                constexpr int r = (q - 16) / 3, w = (q - 16) % 3;
-                if constexpr (w == 0) step_add(cnt[nt], wv[r]);
-                else split(ic<w - 1>{}, ic<r>{});
-            } else {
-                constexpr int sk = 4 + (q - 28) / 2, e = (q - 28) % 2;
-                split(ic<e>{}, ic<sk>{});
-            }
-        }
-    };
-
-    // One pipeline iteration (tile n, parity p): S(n-1) and L(n+1) as MFMAs, X(n) between them.
-    auto iteration = [&](int n, auto pc) __attribute__((always_inline)) {
-        constexpr int p = decltype(pc)::value;
-        const int64_t fbx = tile_fb(n);
-        const int rows = n < ntiles ? (int)(te - fbx < FW ? te - fbx : FW) : 0;     // X(n): rows that exist
-        float* lsb = lsw + p * (2 * FW * 4);
-        // park the normalisers / posteriors of tile n (loaded an iteration ago), fetch those of n + 1
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-        *reinterpret_cast<f32x4*>(lsb + (lh * FW + lr) * 4) = lsv;
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");
-        issue_ls(n + 1);
-        const u4* tprev = tile_img(n - 1);        // statistics B fragments of tile n - 1
-        const u4* tcur = tile_img(n);             // ... of tile n (the next iteration's)
-        const u4* tnext = tile_img(n + 1);        // logits A fragments of tile n + 1
-        // Global loads are issued ~100 MFMAs (1700 cycles) before their first use: a single
-        // wave per SIMD has nobody to cover an L2 round trip.  The three ring slots of the
-        // statistics' B fragments were filled during the logits of the iteration before
-        // (the first iteration: here), A fragments of k-steps 0 and 1 at the start.
-        if (n == 0) {
-#pragma unroll
-            for (int uu = 0; uu < 3; ++uu)
-#pragma unroll
-                for (int q = 0; q < NP; ++q) bq[uu][q] = tprev[(NKU * NP * MT + uu * NP + q) * 64];
-        }
-#pragma unroll
-        for (int q = 0; q < NP; ++q)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) af[0][q][m] = tnext[(q * MT + m) * 64];
-        if constexpr (NKU > 1) {
-#pragma unroll
-            for (int q = 0; q < NP; ++q)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) af[1][q][m] = tnext[((NP + q) * MT + m) * 64];
-        }
-        static_for<kNMFMA>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if constexpr (j < NQT * 6 * NTC) {
-                // ---- statistics of tile n - 1 ----
-                constexpr int uu = j / (6 * NTC), pr = (j / NTC) % 6, c = j % NTC;
-                if constexpr (pr == 0 && c == 0) {
-                    // slot (uu - 1) % 3 is free again: the fragment of tile uu + 2 goes there
-                    if constexpr (uu >= 1 && uu + 2 < NQT) {
-#pragma unroll
-                        for (int q = 0; q < NP; ++q)
-                            bq[(uu + 2) % 3][q] = tprev[(NKU * NP * MT + (uu + 2) * NP + q) * 64];
-                    }
-                    if constexpr (uu == NQT - 1) {
-#pragma unroll
-                        for (int pq = 0; pq < NP; ++pq) bp[0][pq] = Pl[64 * pq];
-                    }
-                }
-                mfma_bf16_pinned<false>(sacc[c][uu], ar[1 - p][c][kProdA[pr]], bq[uu % 3][kProdB[pr]]);
-            } else {
-                // ---- logits of tile n + 1 into lacc[1 - p] ----
-                constexpr int jj = j - NQT * 6 * NTC;
-                constexpr int s = jj / (NTC * 6 * MT), c = (jj / (6 * MT)) % NTC, pr = (jj / MT) % 6, m = jj % MT;
-                constexpr int gi = s * NTC + c, gn = gi < NKU * NTC - 1 ? gi + 1 : NKU * NTC - 1;
-                if constexpr (pr == 0 && m == 0) {
-                    // k-step s + 1's A fragments: k-step 1 is here already; k-step 2 goes into
-                    // the slot k-step 0 leaves when k-step 1 starts
-                    if constexpr (c == 0 && s >= 1 && s + 1 < NKU) {
-#pragma unroll
-                        for (int q = 0; q < NP; ++q)
-#pragma unroll
-                            for (int mm = 0; mm < MT; ++mm)
-                                af[(s + 1) & 1][q][mm] = tnext[(((s + 1) * NP + q) * MT + mm) * 64];
-                    }
-                    // the statistics' B fragments of the NEXT iteration (tile n) into the ring
-                    if constexpr (s == 0 && c < 3) {
-#pragma unroll
-                        for (int q = 0; q < NP; ++q) bq[c][q] = tcur[(NKU * NP * MT + c * NP + q) * 64];
-                    }
-#pragma unroll
-                    for (int pq = 0; pq < NP; ++pq) bp[(gi + 1) & 1][pq] = Pl[gn * kBlockU4 + 64 * pq];
-                }
-                if constexpr (s == 0 && pr == 0)
-                    mfma_bf16_first(lacc[1 - p][m][c], af[s & 1][kProdA[pr]][m], bp[gi & 1][kProdB[pr]]);
-                else
-                    mfma_bf16_pinned<false>(lacc[1 - p][m][c], af[s & 1][kProdA[pr]][m],
-                                            bp[gi & 1][kProdB[pr]]);
-            }
-            // ---- the steps of X(n) that stand behind MFMA j ----
-            constexpr int k0 = (int)((long long)j * kXSteps / kNMFMA);
-            constexpr int k1 = (int)((long long)(j + 1) * kXSteps / kNMFMA);
-            static_for<k1 - k0>([&](auto dc) {
-                xstep(ic<k0 + decltype(dc)::value>{}, pc, lsb, rows);
-            });
-        });
-    };
-
-    if (ntiles > 0) {
-        issue_ls(0);
-        logits_only(0, ic<0>{});
-        for (int n = 0; n <= ntiles; n += 2) {
-            iteration(n, ic<0>{});
-            if (n + 1 <= ntiles) iteration(n + 1, ic<1>{});
-        }
-    }
-    mfma_drain();
-
-    // ---- flush (as accfi_kernel): the waves' partial sums through LDS (fp64), one atomic per element ----
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);          // [WAVES][16 = c * 4 + r][64 lanes]
-    const int ndata = nslab - 1 - (nslab - 1) / 8;
-    constexpr int EPT = 16 * 64 / NTHREADS;
-    int64_t dst_row[EPT];
-    int dst_i[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int el = tid + e * NTHREADS, j = el >> 6, ln = el & 63;
-        const int c = j >> 2, r = j & 3, gg = ln >> 4;
-        const int slot = kbase + 64 * (c >> 2) + 4 * (4 * gg + r) + (c & 3);
-        const int gi = slot % G;
-        dst_row[e] = slot < K && gi < Greal ? (int64_t)((slot / G) * Greal + gi) * nq : -1;
-        dst_i[e] = ln & 15;
-    }
-#pragma unroll
-    for (int uu = 0; uu < NQT; ++uu) {
-#pragma unroll
-        for (int c = 0; c < NTC; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[(wave * 16 + c * 4 + r) * 64 + lane] = sacc[c][uu][r];
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int el = tid + e * NTHREADS;
-            double t = 0.0;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) t += (double)red[w * 1024 + el];
-            const int dslab = (16 * uu + dst_i[e]) >> 2;
-            const int q = stat_slab(dslab) * 4 + (dst_i[e] & 3);
-            if (dst_row[e] >= 0 && dslab < ndata) atomicAdd(Sp + dst_row[e] + q, t);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int c = 0; c < NTC; ++c) {
-        float v = cnt[c];
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (lane < 16) red[(wave * NTC + c) * 16 + lane] = v;
-    }
-    __syncthreads();
-    if (tid < 16 * NTC) {
-        const int c = tid >> 4, ii = tid & 15;
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) t += (double)red[(w * NTC + c) * 16 + ii];
-        const int slot = kbase + 4 * ii + c, gi = slot % G;
-        if (slot < K && gi < Greal)
-            atomicAdd(Sp + (int64_t)((slot / G) * Greal + gi) * nq + (nslab - 1) * 4, t);
-    }
-}
-
 // component tiles per wave: 4 (64 components).  With at most 96 statistic columns
 // (D <= 40) a wave's tile leaves room for two waves per SIMD: one wave's epilogue and
 // fragment arithmetic run under the other's MFMAs.
@@ -2449,8 +2082,6 @@ template __global__ void accx_kernel<true>(int64_t, int, int, int, int, const fl
                                            const float*, int);
 template __global__ void lnfi_kernel<3, 16>(int64_t, int, int, int, const u4*, const u4*, float*, double*,
                                             int64_t, const float*);
-template __global__ void accfp_kernel<3>(int64_t, int, int, int, int, int, int, const u4*, const u4*,
-                                         const float*, const float*, int64_t, double*, const float*);
 template __global__ void accfi_kernel<3, 8>(int64_t, int, int, int, int, int, int, const u4*, const u4*,
                                          const float*, const float*, int64_t, double*, const float*);
 template __global__ void accf_kernel<4, 6, true, 8, 5, true>(int64_t, int, int, int, int, int, int, int,
@@ -2884,41 +2515,6 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
                        (size_t)waves * (32 * ld16_of(D) + (D + 2) * kAfXS + (blk ? 256 : 0)) *
                            sizeof(float);
     const dim3 grid(xcd_grid(gz, nchunks, nchunks));
-    if (use_image && beer::option(BEER_OPT_ACCFI_PIPE)) {
-        // one hand-placed stream per SIMD, software pipelined over the wave's tiles
-        // (accfp_kernel; no tile is skipped: for dense state posteriors)
-        const int wv = 4;
-        int64_t fpb_p = 32 * wv;
-        {
-            int64_t cost_p = -1;
-            for (int64_t f = 32 * wv; f <= (int64_t)wv * kAfMaxFramesPerWave; f += 32 * wv) {
-                const int64_t wgs = (nframes + f - 1) / f * nchunks;
-                const int64_t cost = (wgs + 255) / 256 * (f + 2 * 32 * wv + 64);   // + pipeline fill, flush
-                if (cost_p < 0 || cost < cost_p) { cost_p = cost; fpb_p = f; }
-            }
-        }
-        const int64_t gzp = (nframes + fpb_p - 1) / fpb_p;
-        const size_t lds_p = (size_t)nk_used * NTC * kBlockU4 * 16 + (size_t)wv * 2 * 2 * 32 * 4 * sizeof(float);
-        const size_t lds_r = (size_t)wv * 16 * 64 * sizeof(float);
-        const size_t lds_pf = lds_p > lds_r ? lds_p : lds_r;
-        const dim3 gridp(xcd_grid(gzp, nchunks, nchunks));
-#define BEER_ACCFP(NKU_)                                                                         \
-    do {                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(accfp_kernel<NKU_>),             \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds); \
-        hipLaunchKernelGGL((accfp_kernel<NKU_>), gridp, dim3(256), lds_pf, s, nframes, K, S, G,  \
-                           Greal, nk, nslab, reinterpret_cast<const u4*>(image),                 \
-                           reinterpret_cast<const u4*>(P), log_norm, sr, fpb_p, Sp, c0);         \
-    } while (0)
-        if (nk_used == 1) BEER_ACCFP(1); else if (nk_used == 2) BEER_ACCFP(2); else BEER_ACCFP(3);
-#undef BEER_ACCFP
-        BEER_LAUNCH_CHECK();
-        const int64_t total_p = (int64_t)Kreal * stats_dim(cov, D);
-        hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((total_p + 255) / 256)), dim3(256), 0, s,
-                           cov, D, Kreal, Sp, acc);
-        BEER_LAUNCH_CHECK();
-        return BEER_OK;
-    }
     if (use_image) {
         // every fragment that depends on the frames only comes from the caller's image
         const size_t lds_i = (size_t)nk_used * NTC * kBlockU4 * 16 + (size_t)waves * 256 * sizeof(float);

@@ -70,11 +70,7 @@ int beer_hip_device_count(void);
 #define BEER_OPT_LNFI 4          /* 1: beer_mixtureset_lognorm_image keeps a chunk's packed
                                   * parameters in LDS and walks blocks of frames (lnfi_kernel);
                                   * 0: one tile per wave, parameters streamed from L2.  Default 1. */
-#define BEER_OPT_ACCFI_PIPE 5    /* 1: the fused accumulation over a frame image runs as one
-                                  * software-pipelined stream per SIMD (accfp_kernel: the vector
-                                  * work of a tile between the MFMAs of its neighbours; no tile
-                                  * is skipped -- for dense state posteriors).  Default 0. */
-#define BEER_OPT_COUNT 6
+#define BEER_OPT_COUNT 5
 int beer_hip_set_option(int option, int value);
 int beer_hip_get_option(int option);   /* the value, or BEER_EINVAL for an unknown option */
 
