@@ -8,6 +8,7 @@ fallback -- without the library or without a GPU the calls raise.
 
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -360,6 +361,9 @@ def call_host(name, *args):
         raise HipInvalid(f'{name} failed: invalid argument')
 
 
+# Scratch buffers are filed per (query, shape, device, STREAM): two host threads on two streams
+# get buffers of their own; two threads sharing ONE stream would share them, which the stream's
+# order makes safe (a kernel that uses a workspace is queued before the next one that does).
 _workspaces = {}
 
 
@@ -397,20 +401,21 @@ def packed_workspace(cov, T, D, K, device, sets=None):
     return buf, nbytes
 
 
-_staging_ring = []          # [(pinned buffer, event)], reused round-robin
-_staging_next = [0]
+_staging = threading.local()    # per host thread: .ring [(pinned buffer, event)], .next
 
 
-def _staging(nbytes):
+def _staging_buffer(nbytes):
     '''A pinned staging buffer of at least `nbytes` from a small ring that is
     allocated once and grown rarely: `hipHostMalloc` takes tens of ms and
     synchronises the device, so it must not happen per batch.'''
-    if not _staging_ring:
+    ring = _staging.__dict__.setdefault('ring', [])
+    if not ring:
         for _ in range(4):
-            _staging_ring.append([torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True),
-                                  torch.cuda.Event()])
-    slot = _staging_ring[_staging_next[0] % len(_staging_ring)]
-    _staging_next[0] += 1
+            ring.append([torch.empty(1 << 20, dtype=torch.uint8, pin_memory=True),
+                         torch.cuda.Event()])
+    nxt = _staging.__dict__.get('next', 0)
+    slot = ring[nxt % len(ring)]
+    _staging.next = nxt + 1
     slot[1].synchronize()                      # the copy that last used it has run
     if slot[0].numel() < nbytes:
         slot[0] = torch.empty(max(nbytes, 2 * slot[0].numel()), dtype=torch.uint8,
@@ -430,7 +435,7 @@ def upload(tensors, device):
         names.append(name)
         metas.append((t, total, nbytes))
         total = (total + nbytes + 15) // 16 * 16
-    host, done = _staging(max(total, 16))
+    host, done = _staging_buffer(max(total, 16))
     for t, off, nbytes in metas:
         if nbytes:
             host[off:off + nbytes] = t.reshape(-1).view(torch.uint8)

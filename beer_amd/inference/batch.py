@@ -18,6 +18,7 @@ once.  Sufficient statistics are accumulated in fp64 across the whole shard.
 """
 
 import os
+import threading
 
 import torch
 
@@ -108,7 +109,9 @@ def _sub_batches(lengths, bytes_per_frame, max_frames):
     return runs
 
 
-_in_flight = []
+# Per host thread (a thread drives its own stream of sub-batches: two training loops in two
+# threads must not pop each other's events) -- the throttle's queue and the KL side streams.
+_local = threading.local()
 
 
 def _throttle(depth=2):
@@ -117,10 +120,11 @@ def _throttle(depth=2):
     likelihoods); a host that queues many of them before the first has run
     makes the caching allocator hipMalloc new blocks instead of recycling --
     tens of ms each, and the stream waits for them.'''
-    while len(_in_flight) >= depth:
-        _in_flight.pop(0).synchronize()
+    in_flight = _local.__dict__.setdefault('in_flight', [])
+    while len(in_flight) >= depth:
+        in_flight.pop(0).synchronize()
     ev = torch.cuda.Event()
-    _in_flight.append(ev)
+    in_flight.append(ev)
     return ev
 
 
@@ -145,7 +149,6 @@ def _cached_batch(graph, run_lengths, dtype):
     return batch
 
 
-_side_streams = {}
 _KL_BESIDE = os.environ.get('BEER_KL_SIDE_STREAM', '1') != '0'
 
 
@@ -172,9 +175,10 @@ def _kl_beside_the_estep(model, device):
                 dist.expected_sufficient_statistics()
                 dist.log_norm()
                 dist.natural_parameters()
-    side = _side_streams.get(device)
+    side_streams = _local.__dict__.setdefault('side_streams', {})
+    side = side_streams.get(device)
     if side is None:
-        side = _side_streams[device] = torch.cuda.Stream(device)
+        side = side_streams[device] = torch.cuda.Stream(device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         kl = torch.as_tensor(model.kl_div_posterior_prior())

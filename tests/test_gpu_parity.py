@@ -1922,3 +1922,43 @@ def test_dimension_128_takes_the_generic_kernels_and_matches_the_oracle(cov, K, 
         for n, ref in zip(p0.posterior._std_params_def, new_post):
             got = npy(getattr(p0.posterior.params, n)).astype(np.float64)
             assert_close(got.reshape(ref.shape), ref, 1e-7, 'posterior ' + n)
+
+
+@pytest.mark.gpu
+def test_two_host_threads_on_their_own_streams():
+    '''The host layer's per-call state (the sub-batch throttle, the KL side stream, the pinned
+    staging ring) is per thread, scratch buffers per stream: two threads that each drive their
+    own stream through accumulate_elbo get what one thread gets (round 3 kept that state in
+    module globals).'''
+    import threading
+    torch.manual_seed(3)
+    T, D, K = 40000, 10, 32
+    X = (torch.randn(K, D)[torch.randint(0, K, (T,))] * 2 + torch.randn(T, D)).to(DEV)
+    lengths = [10000] * 4
+
+    def make():
+        torch.manual_seed(9)
+        ns = beer.NormalSet.create(X.mean(0).cpu(), X.var(0).cpu(), size=K, prior_strength=1.,
+                                   noise_std=1., cov_type='diagonal')
+        return beer.Mixture.create(ns).to(DEV)
+
+    def run(model, out, key, own_stream):
+        stream = torch.cuda.Stream() if own_stream else torch.cuda.current_stream()
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                elbo = beer.accumulate_elbo(model, (X, lengths), datasize=T, max_frames=10000)
+            p0 = params_of(model)[0]
+            out[key] = (float(elbo), npy(elbo._acc_stats[p0]).copy())
+
+    torch.cuda.synchronize()
+    out = {}
+    run(make(), out, 'ref', False)
+    models = [make(), make()]
+    threads = [threading.Thread(target=run, args=(m, out, i, True)) for i, m in enumerate(models)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(2):
+        assert out[i][0] == out['ref'][0]
+        np.testing.assert_array_equal(out[i][1], out['ref'][1])
