@@ -1859,7 +1859,8 @@ def test_stick_breaking_with_any_truncation(P, dtype):
     param.natural_grad_update(1.)                      # callback: counts -> ordered stick statistics
     ordering, pairs = orc.sb_transform_stats(counts.astype(np.float64))
     np.testing.assert_array_equal(npy(sb.ordering), ordering)
-    post_c = prior_c + pairs                           # Dirichlet update at lrate 1 (natural = c - 1)
+    # the update at lrate 1 in natural parameters (dirichlet.py:71-81, 144-159; parameters.py:134-141)
+    post_c = orc.dir_from_natural(orc.dir_natural(prior_c) + pairs)
     assert_close(npy(param.posterior.params.concentrations), post_c, tol, 'stick concentrations')
     want = orc.sb_log_weights(post_c, ordering)
     assert_close(npy(sb.log_weights()), want, tol, 'E[ln pi]')
