@@ -53,4 +53,3 @@ def run(cov, K, D, T, seed=3):
         print(f'          stats with the fp64 responsibilities given: {blocks(accr)}')
 run('full', 256, 40, 65536)
 run('diagonal', 256, 40, 65536)
-run('diagonal', 512, 40, 17000, seed=552)
