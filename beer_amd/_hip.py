@@ -332,7 +332,8 @@ def get_f32_mode():
 # microseconds there, and the bf16x3 path has per-call set-up (the packed
 # parameter image, the tile images of the hand-over)
 FAST_MIN_FRAMES = 16384
-MAX_DIM_F32 = 96              # kMaxDimF32 of csrc/estep_mfma.h
+MAX_DIM_F32 = 96              # kMaxDimF32 of csrc/estep_mfma.h: the exact fp32 MFMA kernels
+MAX_DIM_FAST = 128            # kMaxDimX: the bf16x3 kernels
 
 
 def f32_fast_ok(X):
@@ -340,7 +341,7 @@ def f32_fast_ok(X):
     is on and there are enough frames.  No look at the data is needed -- three
     bf16 pieces hold any float32 value exactly -- so the answer costs nothing.'''
     return X.dtype == torch.float32 and get_f32_mode() == 'bf16x3' and \
-        X.shape[0] >= FAST_MIN_FRAMES and X.shape[1] <= MAX_DIM_F32
+        X.shape[0] >= FAST_MIN_FRAMES and X.shape[1] <= MAX_DIM_FAST
 
 
 class exact_f32:

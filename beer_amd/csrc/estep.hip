@@ -331,12 +331,16 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
     void* w_buf = comp_resps;
     // group-aligned shapes on every arithmetic; any G on the split path when only the
     // log-normalisers are wanted (groups padded to a power of two)
+    // (the exact kernels take D <= 96 / 64, the bf16x3 kernels D <= 128)
     const bool aligned = beer_mfma::supported_llh(D, S, G, sizeof(T)) &&
                          ws_bytes >= beer_mfma::estep_workspace_bytes(sizeof(T), cov, D, S, G);
-    const bool padded = sizeof(T) == 4 && !exact && !comp_resps &&
-                        beer_mfma::supported_llh_split(D, S, G) &&
-                        ws_bytes >= beer_mfma::estepx_workspace_bytes(cov, D, S, G);
-    const bool mfma_ok = !labels && !pc_llh && stat_scale == 1.0 && ws && (aligned || padded) &&
+    const bool split_ws = sizeof(T) == 4 && !exact &&
+                          ws_bytes >= beer_mfma::estepx_workspace_bytes(cov, D, S, G) &&
+                          beer_mfma::estepx_workspace_bytes(cov, D, S, G) > 0;
+    const bool aligned_x = split_ws && beer_mfma::supported_llh_x(D, S, G);
+    const bool padded = split_ws && !comp_resps && beer_mfma::supported_llh_split(D, S, G);
+    const bool use_x = aligned_x || padded;
+    const bool mfma_ok = !labels && !pc_llh && stat_scale == 1.0 && ws && (aligned || use_x) &&
                          (log_norm || comp_resps || llh_sum);
     if (need_norm && !w_buf && !mfma_ok) {
         // G == 1: log_norm == w; let pass 1 write into log_norm directly (the
@@ -352,9 +356,7 @@ int estep_launch(int cov, int64_t nframes, int D, int S, int G, const void* X, c
 
     if (mfma_ok) {
         // gfx950 matrix-core path: GEMM + (grouped) softmax fused, one kernel
-        if (sizeof(T) == 4 && !exact &&
-            ws_bytes >= beer_mfma::estepx_workspace_bytes(cov, D, S, G) &&
-            (padded || beer_mfma::supported_llh(D, S, G, sizeof(T))))
+        if (use_x)
             return beer_mfma::estep_bf16x3(cov, nframes, D, S, G, (const float*)X,
                                            (const float*)expT, (const float*)logw,
                                            (float*)comp_resps, (float*)log_norm, llh_sum, ws,
@@ -509,7 +511,7 @@ int beer_mixture_estep_packed(int cov, int64_t T, int D, int K, const float* X,
                               size_t workspace_bytes, void* stream) {
     BEER_REQUIRE(T >= 0 && D >= 1 && K >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(X && exp_stats && log_weights && packed_resps && workspace);
-    BEER_REQUIRE(beer_mfma::supported_llh(D, 1, K));
+    BEER_REQUIRE(beer_mfma::supported_llh_x(D, 1, K));
     BEER_REQUIRE(workspace_bytes >= beer_mfma::estepx_workspace_bytes(cov, D, 1, K));
     if (T == 0) return BEER_OK;
     return beer_mfma::estep_bf16x3(cov, T, D, 1, K, X, exp_stats, log_weights,
@@ -522,7 +524,7 @@ int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float*
                                   size_t workspace_bytes, void* stream) {
     BEER_REQUIRE(T >= 0 && D >= 1 && K >= 1 && cov >= 0 && cov <= 2);
     BEER_REQUIRE(X && packed_resps && acc && workspace);
-    BEER_REQUIRE(beer_mfma::supported_acc(D, K));
+    BEER_REQUIRE(beer_mfma::supported_acc_x(D, K));
     BEER_REQUIRE(workspace_bytes >= beer_mfma::accx_workspace_bytes(cov, T, D, K));
     if (T == 0) return BEER_OK;
     return beer_mfma::acc_bf16x3_packed(cov, T, D, K, X, packed_resps, acc, workspace,
@@ -530,7 +532,7 @@ int beer_normal_accumulate_packed(int cov, int64_t T, int D, int K, const float*
 }
 
 int beer_mixtureset_packed_supported(int cov, int D, int S, int G) {
-    return cov >= 0 && cov <= 2 && D >= 1 && D <= beer_mfma::kMaxDimF32 && S >= 1 && G >= 1 &&
+    return cov >= 0 && cov <= 2 && D >= 1 && D <= beer_mfma::kMaxDimX && S >= 1 && G >= 1 &&
            beer_mfma::supported_llh_packed_sets(cov, D, S, G) &&
            beer_mfma::supported_acc_sets(cov, D, S, G);
 }
@@ -613,7 +615,7 @@ int beer_mixtureset_accumulate_fused(int cov, int64_t T, int D, int S, int G, co
 }
 
 size_t beer_packed_resps_bytes(int64_t T, int D, int K) {
-    return T < 0 || D < 1 || D > beer_mfma::kMaxDimF32 || K < 1 ? 0 : beer_mfma::packed_resps_bytes(T, D, K);
+    return T < 0 || D < 1 || D > beer_mfma::kMaxDimX || K < 1 ? 0 : beer_mfma::packed_resps_bytes(T, D, K);
 }
 
 size_t beer_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int K) {
@@ -623,7 +625,7 @@ size_t beer_accumulate_packed_workspace_bytes(int cov, int64_t T, int D, int K) 
 
 int beer_pack_resps(int64_t T, int D, int S, int G, const float* X, const float* comp_resps,
                     const float* state_resps, void* packed_resps, void* stream) {
-    BEER_REQUIRE(T >= 0 && D >= 1 && D <= beer_mfma::kMaxDimF32 && S >= 1 && G >= 1 && (S * G) % 4 == 0);
+    BEER_REQUIRE(T >= 0 && D >= 1 && D <= beer_mfma::kMaxDimX && S >= 1 && G >= 1 && (S * G) % 4 == 0);
     BEER_REQUIRE(T == 0 || (X && comp_resps && packed_resps));
     return beer_mfma::pack_resps(T, D, S, G, X, comp_resps, state_resps, packed_resps,
                                  as_stream(stream));

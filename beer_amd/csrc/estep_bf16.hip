@@ -300,7 +300,7 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ X, int64_t 
                                            float* __restrict__ xw) {
     const int Dp = 4 * d4_of(D);
     if ((D & 3) == 0) {
-        constexpr int LPR = 64 / FW, NPC = kMaxDimF32 / 4 / LPR;   // pieces per lane
+        constexpr int LPR = 64 / FW, NPC = kMaxDimX / 4 / LPR;     // pieces per lane
         const int C4 = D >> 2, r = lane & (FW - 1), h = lane / FW;
         const int64_t f = fb + r;
         const bool valid = f < nframes;
@@ -688,7 +688,7 @@ inline int xt_pieces(int D) { return (xt_rows(D) * kAxXS * 4 + kPiece - 1) / kPi
 __global__ __launch_bounds__(256) void xt_image_kernel(int64_t nframes, int D, int NX,
                                                        const float* __restrict__ X,
                                                        float* __restrict__ Xt) {
-    constexpr int LD = kMaxDimF32 + 1;            // odd: the transposed reads spread over the banks
+    constexpr int LD = kMaxDimX + 1;              // odd: the transposed reads spread over the banks
     __shared__ float tile[kAxFT * LD];
     const int64_t tau = blockIdx.x, t0 = tau * kAxFT;
     const int rows = (int)(nframes - t0 < kAxFT ? nframes - t0 : kAxFT);
@@ -712,13 +712,20 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
     int64_t nframes, int D, int K, int nslab, int NX, const float* __restrict__ Xt,
     const unsigned* __restrict__ Rimg, const int* __restrict__ tab,
     int64_t frames_per_block, double* __restrict__ Sp, int gx, int gy, int gz,
-    const float* __restrict__ Gt, int lgG) {
+    const float* __restrict__ Gt, int lgG, int sx) {
     constexpr int MC = kAxMC, NQ = kAxNQ, WAVES = kAxWaves, NB = 2;
     static_assert(16 * MC == kPackedComps && kAxFT == kPackedFrames, "the packed image is this kernel's LDS tile");
     constexpr int plane = kPackedPlaneWords * 4;                  // bytes of one piece plane
-    // NX = 4 KiB pieces of the transposed frame tile (1 .. 7: D <= 96)
+    // NX = 4 KiB pieces of the transposed frame tile (1 .. 9: D <= 128).  Two buffers of
+    // [X^T | three planes of R] -- or, `sx` (D > 112: two of them do not fit a CU's 160 KiB),
+    // ONE X^T tile in front of two buffers of R planes; the next tile's X^T is then fetched
+    // only when every wave is done with this one (an exposed DMA round trip per tile: the
+    // price of the shapes beyond 112 dimensions, still an order of magnitude ahead of the
+    // generic kernels).
     const int r_off = NX * kPiece, buf_bytes = r_off + NP * plane;
-    const int g_base = NB * buf_bytes;                            // SR: NB x 4 KiB of gamma^T
+    const int xstride = sx ? 0 : buf_bytes;                       // X^T of buffer b at b * xstride
+    const int rstride = sx ? NP * plane : buf_bytes;              // R planes of buffer b at r_off + b * rstride
+    const int g_base = sx ? r_off + NB * NP * plane : NB * buf_bytes;   // SR: NB x 4 KiB of gamma^T
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -766,7 +773,7 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
     int a_off[kAxFT / 32];
 #pragma unroll
     for (int ks = 0; ks < kAxFT / 32; ++ks)
-        a_off[ks] = r_off + (i * kPackedFrames + (((4 * ks + g) ^ (i & 7)) << 3)) * 2;
+        a_off[ks] = r_off + (i * kPackedFrames + (((4 * ks + g) ^ (i & 7)) << 3)) * 2;   // (+ b * rstride)
 
     f32x4 acc[MC][NQ];
 #pragma unroll
@@ -787,24 +794,31 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
     const char* xsrc = reinterpret_cast<const char*>(Xt) + wave * 1024 + lane * 16;
     const char* rsrc = reinterpret_cast<const char*>(Rimg) + wave * 1024 + lane * 16;
     const char* gsrc = SR ? reinterpret_cast<const char*>(Gt) + wave * 1024 + lane * 16 : nullptr;
-    auto stage = [&](int tile, int buf) {
-        const int64_t tau = tau0 + tile;
-        typedef __attribute__((address_space(3))) void* lds_ptr;
-        const char* xs = xsrc + tau * (size_t)(NX * kPiece);
-        const char* rs = rsrc + (tau * nblk + by) * (size_t)(NP * plane);
-        char* dst = smem + buf * buf_bytes + wave * 1024;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto stage_x = [&](int tile, int buf) {
+        const char* xs = xsrc + (tau0 + tile) * (size_t)(NX * kPiece);
+        char* dst = smem + buf * xstride + wave * 1024;
 #pragma unroll 1
         for (int n = 0; n < NX * (kPiece / 1024) / WAVES; ++n)
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const u4*>(xs + n * (WAVES * 1024)),
                                              (lds_ptr)(dst + n * (WAVES * 1024)), 16, 0, 0);
+    };
+    auto stage_r = [&](int tile, int buf) {
+        const int64_t tau = tau0 + tile;
+        const char* rs = rsrc + (tau * nblk + by) * (size_t)(NP * plane);
+        char* dst = smem + r_off + buf * rstride + wave * 1024;
 #pragma unroll
         for (int n = 0; n < NP * plane / 1024 / WAVES; ++n)
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const u4*>(rs + n * (WAVES * 1024)),
-                                             (lds_ptr)(dst + r_off + n * (WAVES * 1024)), 16, 0, 0);
+                                             (lds_ptr)(dst + n * (WAVES * 1024)), 16, 0, 0);
         if (SR && wave < gkb)
             __builtin_amdgcn_global_load_lds(
                 reinterpret_cast<const u4*>(gsrc + (tau * nblk + by) * (size_t)gbytes),
                 (lds_ptr)(smem + g_base + buf * 4096 + wave * 1024), 16, 0, 0);
+    };
+    auto stage = [&](int tile, int buf) {
+        if (!sx) stage_x(tile, buf);
+        stage_r(tile, buf);
     };
     // SR: this thread's share of the R image in `buf`: 4 chunks of 8 frames (row c,
     // chunk position pos holds frames 8 (pos ^ (c & 7)) ..), all three planes, times
@@ -814,7 +828,7 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
 #pragma unroll 1
         for (int n = 0; n < 16 * MC * 8 / (64 * WAVES); ++n) {
             const int p = tid + 64 * WAVES * n, c = p >> 3, pos = p & 7, ch = pos ^ (c & 7);
-            char* ph = smem + buf * buf_bytes + r_off + c * (kPackedFrames * 2) + pos * 16;
+            char* ph = smem + buf * rstride + r_off + c * (kPackedFrames * 2) + pos * 16;
             const u4 w0 = *reinterpret_cast<const u4*>(ph);
             const u4 w1 = *reinterpret_cast<const u4*>(ph + plane);
             const u4 w2 = *reinterpret_cast<const u4*>(ph + 2 * plane);
@@ -843,7 +857,10 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
             *reinterpret_cast<u4*>(ph + 2 * plane) = o2;
         }
     };
-    if (ntiles > 0) stage(0, 0);
+    if (ntiles > 0) {
+        stage_x(0, 0);
+        stage_r(0, 0);
+    }
     __syncthreads();
     if (SR && ntiles > 0) {
         fold(0);
@@ -859,7 +876,7 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
     // the six products with the pieces of A in ascending order: (A, B) =
     constexpr int kPA[6] = {0, 0, 0, 1, 1, 2}, kPB[6] = {0, 1, 2, 0, 1, 0};
     auto a_ptr = [&](int b, int ks, int c) {
-        return smem + a_off[ks] + (b * buf_bytes + c * 16 * kPackedFrames * 2);
+        return smem + a_off[ks] + (b * rstride + c * 16 * kPackedFrames * 2);
     };
     auto load_a = [&](int b, int ks) {
 #pragma unroll
@@ -869,8 +886,8 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
                 af[c][q] = *reinterpret_cast<const u4*>(a_ptr(b, ks, c) + q * plane);
     };
     auto gen_b = [&](int b, int ks, int uu, u4 (&out)[NP]) {
-        const char* pa = smem + xa_off[uu] + (b * buf_bytes + 128 * ks);
-        const char* pb = smem + xb_off[uu] + (b * buf_bytes + 128 * ks);
+        const char* pa = smem + xa_off[uu] + (b * xstride + 128 * ks);
+        const char* pb = smem + xb_off[uu] + (b * xstride + 128 * ks);
         const f32x4 xa0 = *reinterpret_cast<const f32x4*>(pa);
         const f32x4 xa1 = *reinterpret_cast<const f32x4*>(pa + 16);
         const f32x4 xb0 = *reinterpret_cast<const f32x4*>(pb);
@@ -907,8 +924,8 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
                     // 4 x 7 steps of the three-way split.
                     const bool build = BEER_K2_ABL < 1 && (uu + 1 < NQ || ks == 0);
                     const int nks = uu + 1 < NQ ? ks : 1, nuu = uu + 1 < NQ ? uu + 1 : 0;
-                    const char* pa = smem + xa_off[nuu] + (buf * buf_bytes + 128 * nks);
-                    const char* pb = smem + xb_off[nuu] + (buf * buf_bytes + 128 * nks);
+                    const char* pa = smem + xa_off[nuu] + (buf * xstride + 128 * nks);
+                    const char* pb = smem + xb_off[nuu] + (buf * xstride + 128 * nks);
                     f32x4 xa[2], xb[2];
                     float pp[8];
                     Split3Steps st[4];
@@ -959,6 +976,10 @@ __global__ __launch_bounds__(64 * kAxWaves, 1) void accx_kernel(
             }
         }
         __syncthreads();
+        if (sx && tile + 1 < ntiles) {
+            stage_x(tile + 1, 0);              // every wave is done with this tile's X^T
+            __syncthreads();
+        }
         if (SR) {
             if (fold_next) fold(next);
             __syncthreads();
@@ -2048,7 +2069,7 @@ inline int group_pad(int G) {
 // the fused accumulation needs a multiple of 4 only (no group reductions)
 inline int accf_group_pad(int S, int G) { return (G + 3) / 4 * 4; }
 inline bool supported_llh_padded(int D, int S, int G) {
-    return supported_llh(D, S, S > 1 ? group_pad(G) : G);
+    return supported_llh_x(D, S, S > 1 ? group_pad(G) : G);
 }
 
 inline int ntx_for(int S, int K) { return S > 1 ? 16 : (K <= 64 ? 4 : (K <= 128 ? 8 : 16)); }
@@ -2076,10 +2097,10 @@ template __global__ void llhx_kernel<16, 2, 1, false, true, true, true>(
     double*, float*, int, int, int, const float*, const u4*);
 template __global__ void accx_kernel<false>(int64_t, int, int, int, int, const float*, const unsigned*,
                                             const int*, int64_t, double*, int, int, int,
-                                            const float*, int);
+                                            const float*, int, int);
 template __global__ void accx_kernel<true>(int64_t, int, int, int, int, const float*, const unsigned*,
                                            const int*, int64_t, double*, int, int, int,
-                                           const float*, int);
+                                           const float*, int, int);
 template __global__ void lnfi_kernel<3, 16>(int64_t, int, int, int, const u4*, const u4*, float*, double*,
                                             int64_t, const float*);
 template __global__ void accfi_kernel<3, 8>(int64_t, int, int, int, int, int, int, const u4*, const u4*,
@@ -2095,7 +2116,7 @@ bool supported_llh_split(int D, int S, int G) { return supported_llh_padded(D, S
 // covariance, groups of 4 .. 128 components, a power of two
 bool supported_llh_packed_sets(int cov, int D, int S, int G) {
     return cov == BEER_FULL && S > 1 && G >= 4 && G <= 128 && (G & (G - 1)) == 0 &&
-           supported_llh_padded(D, S, G) && supported_acc(D, S * G);
+           supported_llh_padded(D, S, G) && supported_acc_x(D, S * G);
 }
 
 // 129 .. 256 components of ONE mixture: the E-step kernel also leaves the
@@ -2115,7 +2136,7 @@ size_t packed_resps_bytes(int64_t nframes, int D, int K) {
 int pack_resps(int64_t nframes, int D, int S, int G, const float* X, const float* R,
                const float* SR, void* packed, hipStream_t s) {
     const int K = S * G;
-    if ((K & 3) || D < 1 || D > kMaxDimF32) return BEER_EINVAL;
+    if ((K & 3) || D < 1 || D > kMaxDimX) return BEER_EINVAL;
     if (nframes == 0) return BEER_OK;
     unsigned* tiles = reinterpret_cast<unsigned*>(packed);
     const int64_t ntile = (nframes + kPackedFrames - 1) / kPackedFrames;
@@ -2301,7 +2322,7 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
 }
 
 size_t accx_base_workspace_bytes(int cov, int D, int K) {
-    if (!supported_acc(D, K)) return 0;
+    if (!supported_acc_x(D, K)) return 0;
     const int nslab = nslab_of(cov, D);
     return up256((size_t)K * nslab * 4 * sizeof(double)) + up256((size_t)nslab * sizeof(int)) + 1024;
 }
@@ -2316,7 +2337,7 @@ size_t accx_workspace_bytes(int cov, int64_t nframes, int D, int K) {
 // ... with state posteriors multiplied in by the accumulation kernel: S states of G
 // components (a power of two, 8 .. 128)
 bool supported_acc_sets(int cov, int D, int S, int G) {
-    return S >= 1 && G >= 8 && G <= 128 && (G & (G - 1)) == 0 && supported_acc(D, S * G);
+    return S >= 1 && G >= 8 && G <= 128 && (G & (G - 1)) == 0 && supported_acc_x(D, S * G);
 }
 inline int acc_sets_spad(int S, int G) {
     return (S * G + kPackedComps - 1) / kPackedComps * (kPackedComps / G);
@@ -2331,7 +2352,7 @@ size_t accxs_workspace_bytes(int cov, int64_t nframes, int D, int S, int G) {
 int acc_bf16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, const void* Rimg,
                       double* acc, void* ws, size_t ws_bytes, hipStream_t s, int S, int G,
                       const float* SR) {
-    if (!supported_acc(D, K) || ws_bytes < accx_workspace_bytes(cov, nframes, D, K))
+    if (!supported_acc_x(D, K) || ws_bytes < accx_workspace_bytes(cov, nframes, D, K))
         return BEER_EINVAL;
     if (SR && (S * G != K || !supported_acc_sets(cov, D, S, G) ||
                ws_bytes < accxs_workspace_bytes(cov, nframes, D, S, G)))
@@ -2384,8 +2405,10 @@ int acc_bf16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, co
     int64_t fpb = (nframes + gz - 1) / gz;
     fpb = (fpb + kAxFT - 1) / kAxFT * kAxFT;
     gz = (nframes + fpb - 1) / fpb;
-    const size_t lds = 2 * ((size_t)NX * kPiece + (size_t)NP * kPackedPlaneWords * 4) +
-                       (SR ? 2 * 4096 : 0);
+    size_t lds = 2 * ((size_t)NX * kPiece + (size_t)NP * kPackedPlaneWords * 4) +
+                 (SR ? 2 * 4096 : 0);
+    const int sx = lds > (size_t)beer::kMaxDynLds ? 1 : 0;       // one X^T tile, two R buffers
+    if (sx) lds = (size_t)NX * kPiece + 2 * (size_t)NP * kPackedPlaneWords * 4 + (SR ? 2 * 4096 : 0);
     const int64_t nyz = ((int64_t)gy * gz + 7) / 8 * 8;
     const dim3 grid((unsigned)(nyz * gx));
 #define BEER_ACCX(SR_)                                                                           \
@@ -2394,7 +2417,7 @@ int acc_bf16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, co
                                   hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);         \
         hipLaunchKernelGGL((accx_kernel<SR_>), grid, dim3(64 * kAxWaves), lds, s, nframes, D, K, \
                            nslab, NX, Xt, reinterpret_cast<const unsigned*>(Rimg), tab, fpb, Sp, \
-                           gx, gy, (int)gz, Gt, lgG);                                            \
+                           gx, gy, (int)gz, Gt, lgG, sx);                                        \
     } while (0)
     if (SR) BEER_ACCX(true);
     else BEER_ACCX(false);

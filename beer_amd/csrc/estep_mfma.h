@@ -9,13 +9,18 @@
 
 namespace beer_mfma {
 
-// Largest feature dimension of the matrix-core paths: float32 96 (the accumulation kernels
-// keep two tiles of transposed frames + responsibilities in a CU's 160 KiB of LDS),
+// Largest feature dimension of the exact matrix-core paths: float32 96 (the accumulation
+// kernels keep two tiles of transposed frames + responsibilities in a CU's 160 KiB of LDS),
 // float64 64.  Beyond: the generic kernels of estep.hip.
 constexpr int kMaxDimF32 = 96, kMaxDimF64 = 64;
+// ... and of the bf16x3 kernels (estep_bf16.hip): 128 -- beyond 112 dimensions the packed
+// accumulation keeps ONE tile of transposed frames in LDS instead of two (accx_kernel: sx).
+constexpr int kMaxDimX = 128;
 inline int max_dim(size_t elem) { return elem == 8 ? kMaxDimF64 : kMaxDimF32; }
 bool supported_llh(int D, int S, int G, size_t elem = 4);
 bool supported_acc(int D, int K, size_t elem = 4);
+bool supported_llh_x(int D, int S, int G);           // the same shapes with D <= kMaxDimX
+bool supported_acc_x(int D, int K);
 size_t estep_workspace_bytes(size_t elem, int cov, int D, int S, int G);
 size_t acc_workspace_bytes(int cov, int D, int K, size_t elem = 4);
 

@@ -520,20 +520,23 @@ int acc_impl(int cov, int64_t nframes, int D, int S, int G, const T* X, const T*
 
 }  // namespace
 
-bool supported_llh(int D, int S, int G, size_t elem) {
+static bool supported_llh_dim(int D, int S, int G, int max_d) {
     // 8-bit slab-table fields: Dp + 4 <= 255.  GMM (S = 1): any K in [16, 256]
     // (a whole softmax row inside one wave's accumulators, padded to 64 / 128 /
     // 256 columns).  Mixture set (S > 1): G a power of two <= 256 so that the
     // groups align with lanes / column tiles; K is cut into chunks of 256.
-    if (D < 1 || D > max_dim(elem) || S < 1 || G < 1) return false;
+    if (D < 1 || D > max_d || S < 1 || G < 1) return false;
     const int K = S * G;
     if (S == 1) return K >= 16 && K <= 256;
     return K >= 16 && G <= 256 && (G & (G - 1)) == 0;
 }
+bool supported_llh(int D, int S, int G, size_t elem) { return supported_llh_dim(D, S, G, max_dim(elem)); }
+bool supported_llh_x(int D, int S, int G) { return supported_llh_dim(D, S, G, kMaxDimX); }
 
 bool supported_acc(int D, int K, size_t elem) {
     return D >= 1 && D <= max_dim(elem) && K >= 16 && K % 4 == 0;
 }
+bool supported_acc_x(int D, int K) { return D >= 1 && D <= kMaxDimX && K >= 16 && K % 4 == 0; }
 
 size_t estep_workspace_bytes(size_t elem, int cov, int D, int S, int G) {
     if (!supported_llh(D, S, G, elem)) return 0;

@@ -138,8 +138,9 @@ def packed_path_ok(stats, K, cov_type):
         return False
     code, D = _hip.COV_CODE[cov_type], X.shape[1]
     lib, dt = _hip.lib(), _hip.dtype_code(X.dtype)
+    # (the packed kernels' own queries: they take D <= 128, the exact ones D <= 96)
     return lib.beer_estep_workspace_bytes(dt, code, D, 1, K) > 0 and \
-        lib.beer_accumulate_workspace_bytes(dt, code, D, 1, K) > 0
+        lib.beer_accumulate_packed_workspace_bytes(code, X.shape[0], D, K) > 0
 
 
 def mixture_estep_packed(stats, exp_stats, log_weights, K, cov_type, llh_sum=None):
@@ -300,8 +301,8 @@ def _repack_pays(stats, K, cov_type):
     if cov_type != 'full' or stats.shape[1] <= 512 or K % 4 or stats.scale != 1.0 or \
             not _hip.f32_fast_ok(X):
         return False
-    return _hip.lib().beer_accumulate_workspace_bytes(
-        _hip.dtype_code(X.dtype), _hip.COV_CODE[cov_type], X.shape[1], 1, K) > 0
+    return _hip.lib().beer_accumulate_packed_workspace_bytes(
+        _hip.COV_CODE[cov_type], X.shape[0], X.shape[1], K) > 0
 
 
 def normal_accumulate(stats, comp_resps, state_resps, S, G, cov_type, acc=None):

@@ -982,11 +982,14 @@ def test_gmm_with_more_than_256_components_on_the_matrix_cores(cov, K, D, split)
                            slack=1.5)
 
 
-@pytest.mark.parametrize('cov,K,D', [('full', 64, 80), ('diagonal', 200, 96), ('full', 32, 72)])
+@pytest.mark.parametrize('cov,K,D', [('full', 64, 80), ('diagonal', 200, 96), ('full', 32, 72),
+                                     ('full', 32, 128), ('diagonal', 160, 128), ('full', 48, 112),
+                                     ('full', 20, 100)])
 def test_matrix_core_paths_beyond_64_dimensions(cov, K, D):
-    '''Round 2 sent D > 64 to the generic VALU kernels; the float32 matrix-core kernels now
-    take D <= 96 (the reference has no such limit: beer/dists/normalwishart.py:30-38).
-    A mixture at D = 72 / 80 / 96 through accumulate_elbo: the packed E-step and the
+    '''Round 2 sent D > 64 to the generic VALU kernels; the float32 bf16x3 kernels take
+    D <= 128 since round 4 (the reference has no limit: beer/dists/normalwishart.py:30-38;
+    beyond 112 dimensions the accumulation keeps one tile of transposed frames in LDS).
+    A mixture at D = 72 ... 128 through accumulate_elbo: the packed E-step and the
     packed accumulation are the calls that run (spied), and the results are the
     oracle's.'''
     from beer_amd import kernels

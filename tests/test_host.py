@@ -346,7 +346,7 @@ def test_fast_f32_path_needs_no_look_at_the_data():
         assert _hip.f32_fast_ok(a) and _hip.f32_fast_ok(a[8:])
         assert not _hip.f32_fast_ok(a[:100])                         # small: exact kernels
         assert not _hip.f32_fast_ok(a.double())
-        assert not _hip.f32_fast_ok(torch.zeros(_hip.FAST_MIN_FRAMES, _hip.MAX_DIM_F32 + 1))
+        assert not _hip.f32_fast_ok(torch.zeros(_hip.FAST_MIN_FRAMES, _hip.MAX_DIM_FAST + 1))
         huge = a.clone()
         huge[0, 0] = 3e38                                            # any float32 value will do
         huge[1, 1] = 1e-30
