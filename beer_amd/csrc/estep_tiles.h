@@ -663,7 +663,7 @@ __device__ __forceinline__ void lognorm_epilogue_lane_major(
                 float sum = 0.f;
 #pragma unroll
                 for (int c = 0; c < G; ++c)
-                    sum += (BEER_LNFI_TRANS_EVERY > 0 && c % BEER_LNFI_TRANS_EVERY == 0)
+                    sum += (BEER_LNFI_TRANS_EVERY > 0 && c % (BEER_LNFI_TRANS_EVERY > 0 ? BEER_LNFI_TRANS_EVERY : 1) == 0)
                                ? __builtin_amdgcn_exp2f(__builtin_fmaf(acc[m][q * G + c][r], L2E, nm))
                                : exp2_valu(__builtin_fmaf(acc[m][q * G + c][r], L2E, nm));
                 const float lse = __builtin_fmaf(__builtin_amdgcn_logf(sum) - d, LN2, mx) + shift;
