@@ -1550,7 +1550,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void accf_kernel(
 // frame_image_kernel builds them once per frame tile, in exactly the registers' layout:
 //   img[tile of 32 frames][ k-step s ][ piece q ][ frame tile m ][ 64 lanes ] u4   (A)
 //   img[tile            ][ NKU*6 +  statistic tile uu * 3 + piece q ][ 64 lanes ] u4   (B)
-// (1152 B per frame at D = 40: 3.8 GB per 3.33 M frames, read by the 30 chunk blocks of
+// (1056 B per frame at D = 40: 3.5 GB per 3.33 M frames, read by the 30 chunk blocks of
 // a frame block that xcd_block() puts on one XCD next to each other.)  accfi_kernel is
 // accf_kernel with every fragment a 16-byte load.
 // ---------------------------------------------------------------------------

@@ -67,7 +67,7 @@ class FrameImages:
     The fused E-step / accumulation of a mixture set with diagonal or isotropic Gaussians
     reads phi(x) = [x^2, x, 1] of every 32-frame tile as bf16x3 register fragments -- a
     function of the frames only, the same for every component chunk and every VB
-    iteration (1152 B per frame at D = 40, 7.2x the frames).  A training loop that walks
+    iteration (1056 B per frame at D = 40, 6.6x the frames).  A training loop that walks
     the same shard again and again builds them once:
 
         X, lengths = beer_amd.pack_utterances(utterances)

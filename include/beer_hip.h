@@ -368,7 +368,8 @@ int beer_mixtureset_accumulate_fused(int cov, int64_t T, int D, int S, int G,
 /* `frame_image` above (nullable): the operands of that kernel that depend on the
  * frames only -- phi(x_t) = [x^2, x, 1] of every 32-frame tile as bf16x3 pieces, once in
  * the layout of the logits' A fragments and once in that of the statistics' B
- * fragments, 1152 bytes per frame at D = 40.  The kernel is bound by vector
+ * fragments, 1056 bytes per frame at D = 40 (the statistics' data columns: the counts are
+ * summed on the vector ALU).  The kernel is bound by vector
  * instruction issue and two thirds of its vector instructions rebuild these for each
  * of the K / 64 component chunks; the frames do not change between the VB iterations
  * of a training run, so a caller that keeps X resident builds the image once per block
