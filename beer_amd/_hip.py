@@ -211,6 +211,7 @@ SIGNATURES = {
     'beer_copy_pinned': [c_p, c_p, c_z, c_p],
     'beer_suffstats_mean': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p],
     'beer_suffstats_backward': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
+    'beer_frames_llh_backward': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_z, c_p],
 }
 
 
@@ -238,6 +239,7 @@ SIZE_QUERIES = {
     'beer_accumulate_packed_workspace_bytes': [c_i, c_l, c_i, c_i],
     'beer_mixtureset_accumulate_packed_workspace_bytes': [c_i, c_l, c_i, c_i, c_i],
     'beer_hmm_fb_scratch_doubles': [c_i, c_p, c_i],
+    'beer_frames_llh_backward_workspace_bytes': [c_i, c_i, c_l, c_i, c_i],
 }
 
 

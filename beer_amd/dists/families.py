@@ -141,12 +141,12 @@ class NormalLikelihood(ConjugateLikelihood):
 
     def __call__(self, pdfvecs, stats):
         'stats @ pdfvecs^T - D/2 ln 2pi -> [T, K] (normalwishart.py:88-92).'
-        from ..kernels import dense_llh_autograd, is_dense, normal_llh
+        from ..kernels import dense_llh_autograd, is_dense, normal_llh_autograd
         if pdfvecs.dim() == 1:
             pdfvecs = pdfvecs.view(1, -1)
         if is_dense(stats):
             return dense_llh_autograd(stats, pdfvecs, self.dim)
-        return normal_llh(stats, pdfvecs, self.cov_type)
+        return normal_llh_autograd(stats, pdfvecs, self.cov_type)
 
 
 class NormalDiagonalLikelihood(NormalLikelihood):

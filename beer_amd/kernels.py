@@ -13,7 +13,8 @@ from .stats import FrameStats
 
 __all__ = ['normal_llh', 'mixtureset_estep', 'normal_accumulate', 'weights_from_acc',
            'is_dense', 'dense_llh', 'dense_softmax', 'dense_accumulate', 'rowdot',
-           'attach_stats_grad', 'differentiable_stats']
+           'attach_stats_grad', 'differentiable_stats', 'sample_stats', 'attach_frame_grad',
+           'frames_llh_backward', 'normal_llh_autograd']
 
 LOG_2PI = 1.8378770664093453
 
@@ -573,3 +574,105 @@ def differentiable_stats(data, cov_type, nsamples=1):
     if data.dim() != 2 or data.shape[0] % nsamples:
         raise ValueError('expected [n_frames * nsamples, dim] samples')
     return _SuffStats.apply(data, cov_type, int(nsamples))
+
+
+# ---- one sample per frame: the prior of a VAE on the frame kernels --------------
+# With nsamples = 1 the statistics a VAE hands its prior (vae.py:73-74) are phi(z_t) of the
+# samples themselves: the prior runs its frame kernels on them -- no [T, Q] tensor -- and the
+# gradient w.r.t. the samples is one product (csrc/sample_grad.hip).
+
+def sample_stats(data, cov_type):
+    """Lazy statistics of frames that carry an autograd graph: a `FrameStats` of their
+    values whose `source` is the differentiable tensor.  Models that find a `source` give
+    their expected log-likelihood its gradient w.r.t. it (`attach_frame_grad`)."""
+    if data.dim() != 2:
+        raise ValueError('expected [n_frames, dim] samples')
+    st = FrameStats(data.detach(), cov_type)
+    if torch.is_grad_enabled() and data.requires_grad:
+        st.source = data
+    return st
+
+
+def has_source(stats):
+    return isinstance(stats, FrameStats) and stats.source is not None and \
+        torch.is_grad_enabled() and stats.source.requires_grad
+
+
+def frames_llh_backward(stats, weights, grad, exp_stats):
+    """grad[t] * sum_k weights[t,k] * d l_k(x_t) / d x_t -> [T, D]
+    (`beer_frames_llh_backward`; `grad` None = 1)."""
+    st = _frames(stats)
+    X = st.data
+    T, D = X.shape
+    w = _hip.on_device(weights, X.dtype)
+    E = _hip.on_device(exp_stats, X.dtype)
+    g = None if grad is None else _hip.on_device(grad, X.dtype)
+    K = E.shape[0]
+    if tuple(w.shape) != (T, K) or E.shape[1] != st.shape[1]:
+        raise ValueError(f'weights {tuple(w.shape)} / parameters {tuple(E.shape)} for '
+                         f'{T} frames of dimension {D}')
+    out = torch.empty_like(X)
+    code, cov = _hip.dtype_code(X.dtype), _hip.COV_CODE[st.cov_type]
+    nbytes = _hip.lib().beer_frames_llh_backward_workspace_bytes(code, cov, T, D, K)
+    ws = None
+    if nbytes:
+        key = ('sgrad', cov, D, K, X.device, torch.cuda.current_stream().cuda_stream)
+        ws = _hip._workspaces.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = _hip._workspaces[key] = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+    _hip.call('beer_frames_llh_backward', code, cov, T, D, K, _hip.ptr(X), _hip.ptr(w),
+              _hip.ptr(g), _hip.ptr(E), _hip.ptr(out), _hip.ptr(ws), nbytes)
+    if st.scale != 1.0:
+        out *= st.scale
+    return out
+
+
+class _FrameGrad(torch.autograd.Function):
+    """`_StatsGrad` for statistics that are phi(x_t) of differentiable frames: value[t] =
+    sum_k weights[t,k] llh[t,k] (+ terms without gradient) differentiated w.r.t. the
+    frames, the chain statistics -> frames included."""
+
+    @staticmethod
+    def forward(ctx, source, value, weights, exp_stats, stats):
+        ctx.save_for_backward(weights, exp_stats)
+        ctx.stats = stats
+        ctx.home = (source.device, source.dtype)
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, grad):
+        weights, exp_stats = ctx.saved_tensors
+        out = frames_llh_backward(ctx.stats, weights, grad.contiguous(), exp_stats)
+        return out.to(device=ctx.home[0], dtype=ctx.home[1]), None, None, None, None
+
+
+def attach_frame_grad(stats, value, weights, exp_stats):
+    'Give `value` [T] its gradient w.r.t. the source of `stats` (no-op without one).'
+    if not has_source(stats):
+        return value
+    return _FrameGrad.apply(stats.source, value, weights.detach(), exp_stats.detach(),
+                            stats.detach())
+
+
+class _FrameLlh(torch.autograd.Function):
+    'Differentiable l[t,k] = phi(x_t) . E[T]_k + base -> [T, K] w.r.t. the frames.'
+
+    @staticmethod
+    def forward(ctx, source, exp_stats, stats):
+        ctx.save_for_backward(exp_stats)
+        ctx.stats = stats
+        ctx.home = (source.device, source.dtype)
+        return normal_llh(stats, exp_stats, stats.cov_type)
+
+    @staticmethod
+    def backward(ctx, grad):
+        exp_stats, = ctx.saved_tensors
+        out = frames_llh_backward(ctx.stats, grad.contiguous(), None, exp_stats)
+        return out.to(device=ctx.home[0], dtype=ctx.home[1]), None, None
+
+
+def normal_llh_autograd(stats, exp_stats, cov_type):
+    '`normal_llh`, differentiable w.r.t. the source of `stats` when it has one.'
+    if has_source(stats):
+        return _FrameLlh.apply(stats.source, exp_stats.detach(), stats.detach())
+    return normal_llh(stats, exp_stats, cov_type)

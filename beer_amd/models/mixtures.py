@@ -87,7 +87,14 @@ class Mixture(DiscreteLatentModel):
                 stats, ns.means_precisions.natural_form(), self._log_weights().view(1, K),
                 1, K, ns.cov_type, labels=labels)
         self.cache['resps'] = resps
-        return log_norm.view(-1)
+        value = log_norm.view(-1)
+        if kernels.has_source(stats):
+            # differentiable frames (one sample per frame of a VAE): the gradient flows
+            # through sum_k r_k l_k only, as in the statistics-in variant below
+            value = kernels.attach_frame_grad(
+                stats, value, resps.dense() if wide else resps,
+                ns.means_precisions.natural_form())
+        return value
 
     def _dense_expected_log_likelihood(self, stats, labels):
         '''Statistics-in variant (prior of a VAE): same value, and the gradient

@@ -73,7 +73,8 @@ class HMM(DiscreteLatentModel):
         graph = self.graph if inference_graph is None else inference_graph
         dense = kernels.is_dense(stats)
         emissions = self._emissions()
-        pc_all = emissions.expected_log_likelihood(stats.detach() if dense else stats)
+        # (no gradient through the posteriors: detached statistics, hmm.py:81-87)
+        pc_all = emissions.expected_log_likelihood(stats.detach())
         self.modelset.cache['order'] = graph.pdf_id_mapping
         T, S_total = pc_all.shape
         if utt_lengths is None:
@@ -109,6 +110,11 @@ class HMM(DiscreteLatentModel):
             # statistics-in (prior of a VAE): d exp_llh / d stats through
             # sum_s gamma_ts * scale * l_ts with detached posteriors (hmm.py:81-87)
             exp_llh = kernels.attach_stats_grad(
+                stats, exp_llh, state_resps, emissions.means_precisions.natural_form())
+        elif isinstance(emissions, NormalSet) and kernels.has_source(stats):
+            # the same for statistics that are phi(z_t) of differentiable frames (a VAE with
+            # one sample per frame): the frame kernels above, the gradient w.r.t. the frames
+            exp_llh = kernels.attach_frame_grad(
                 stats, exp_llh, state_resps, emissions.means_precisions.natural_form())
         return exp_llh
 

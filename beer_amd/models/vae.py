@@ -2,11 +2,14 @@
 
 API mirror of beer/models/vae.py:28-89.  The encoder / decoder are torch.nn
 modules trained by autograd; the prior (Normal, Mixture, HMM ...) is the hot
-path: it receives the sample-averaged sufficient statistics of the latent
-variable as a dense [T, Q] tensor ("statistics-in") and runs
-`beer_dense_llh` / `beer_softmax_groups` / forward-backward /
-`beer_dense_accumulate`, with `beer_dense_llh_backward` and
-`beer_suffstats_backward` carrying the gradient back to the encoder.
+path.  With one sample per frame (the default) the statistics it receives are
+phi(z_t) of the samples: the prior runs its FRAME kernels on them (E-step,
+forward-backward, accumulation -- no [T, Q] tensor) and `beer_frames_llh_backward`
+carries the gradient back to the encoder.  With several samples per frame it
+receives their sample-averaged statistics as a dense [T, Q] tensor
+("statistics-in") and runs `beer_dense_llh` / `beer_softmax_groups` /
+forward-backward / `beer_dense_accumulate`, with `beer_dense_llh_backward` and
+`beer_suffstats_backward` on the way back (`dense_statistics=True`: always).
 
 Quirk Q7 (kept behind a switch): the reference subtracts a [T] vector from a
 [T, 1] one (vae.py:84-86) and returns a [T, T] matrix whose sum is T times
@@ -14,6 +17,8 @@ the intended value -- and T^2 memory.  `reference_broadcast=True` returns
 T * (llh - kl) per frame, which has the same sum and gradient without the
 matrix; the default returns the intended per-frame value.
 """
+
+import os
 
 import torch
 
@@ -40,12 +45,16 @@ class MeanLogDiagCov(torch.nn.Module):
 
 class VAE(Model):
 
-    def __init__(self, prior, encoder, decoder, reference_broadcast=False):
+    def __init__(self, prior, encoder, decoder, reference_broadcast=False,
+                 dense_statistics=None):
         super().__init__()
         self.prior = prior
         self.encoder = encoder
         self.decoder = decoder
         self.reference_broadcast = reference_broadcast
+        # True: the prior always gets dense [T, Q] statistics, also with one sample per frame
+        self.dense_statistics = (os.environ.get('BEER_VAE_DENSE') == '1') \
+            if dense_statistics is None else bool(dense_statistics)
         self.enc_mean_layer = torch.nn.Linear(encoder.dim_out, decoder.dim_in)
         self.enc_var_layer = torch.nn.Linear(encoder.dim_out, decoder.dim_in)
         self.dec_mean_layer = torch.nn.Linear(decoder.dim_out, encoder.dim_in)
@@ -89,13 +98,19 @@ class VAE(Model):
         ent = -posts(posts.sufficient_statistics(samples).mean(dim=1), pdfwise=True)
         flat = samples.reshape(-1, samples.shape[-1])
         cov_type = self._prior_cov_type()
-        if cov_type is not None:
+        if cov_type is not None and nsamples == 1 and \
+                not getattr(self, 'dense_statistics', False):
+            # one sample per frame: the statistics are phi(z_t) -- the prior runs its frame
+            # kernels on the samples and differentiates w.r.t. them (kernels.sample_stats)
+            prior_stats = kernels.sample_stats(flat, cov_type)
+        elif cov_type is not None:
             # sample-averaged statistics [T, Q] in one kernel (no [T*ns, Q] tensor)
             prior_stats = kernels.differentiable_stats(flat, cov_type, nsamples)
         else:
             prior_stats = self.prior.sufficient_statistics(flat)
             prior_stats = prior_stats.reshape(T, nsamples, -1).mean(dim=1)
-        self.cache['prior_stats'] = prior_stats
+        # (the accumulation needs the values only: no autograd graph kept in the cache)
+        self.cache['prior_stats'] = prior_stats.detach()
         # extra keyword arguments reach the prior (`utt_lengths` of an HMM prior
         # over a batch of utterances); the reference passes none
         xent = -self.prior.expected_log_likelihood(prior_stats, **kwargs).reshape(-1)

@@ -162,6 +162,9 @@ class FrameStats:
         self.scale = float(scale)
         self.images = images
         self._image = {}                      # this handle's own images, by covariance type
+        # the tensor these frames are the values of, when they carry an autograd graph
+        # (one sample per frame of a VAE's latent variable): `kernels.sample_stats`
+        self.source = None
 
     def frame_image(self, cov_type=None):
         '''The frame fragment image of these frames for `cov_type` (default: this
@@ -186,6 +189,15 @@ class FrameStats:
         if cov_type == self.cov_type:
             return self
         out = FrameStats(self.data, cov_type, self.scale, self.images)
+        out._image = self._image
+        out.source = self.source
+        return out
+
+    def detach(self):
+        'The same frames without the autograd graph of their source (images shared).'
+        if self.source is None:
+            return self
+        out = FrameStats(self.data, self.cov_type, self.scale, self.images)
         out._image = self._image
         return out
 
@@ -213,6 +225,7 @@ class FrameStats:
     def __mul__(self, scale):
         out = FrameStats(self.data, self.cov_type, self.scale * float(scale), self.images)
         out._image = self._image
+        out.source = self.source
         return out
 
     __rmul__ = __mul__

@@ -656,6 +656,29 @@ int beer_suffstats_backward(int dtype, int cov, int64_t T, int ns, int D,
                             const void* X, const void* grad_stats,
                             void* grad_X, void* stream);
 
+/* ---- one sample per frame: the prior of a VAE on the frame kernels -----------
+ * With ONE sample z_t per frame (vae.py:63-86, nsamples = 1) the statistics the
+ * prior receives are phi(z_t): its E-step and accumulation are the frame entry
+ * points above (beer_mixtureset_estep, beer_normal_accumulate ...) on the samples,
+ * and the gradient the reference's autograd carries from `(pc_llhs * resps).sum(-1)`
+ * through the statistics to the samples (mixture.py:79,92; hmm.py:81-87;
+ * normalwishart.py:30-38) is one product, with no [T, Q] tensor in between:
+ *
+ *   out[t,:] = grad[t] * sum_k weights[t,k] * d(phi(x_t) . exp_stats[k]) / d x_t  -> [T, D]
+ *
+ * = beer_suffstats_backward(beer_dense_llh_backward(weights, grad, exp_stats)) at
+ * ns = 1.  `grad` nullable (= 1); `weights` [T, K]; `exp_stats` [K, Q] as for
+ * beer_dense_llh.  BEER_F32 / BEER_F64.  Full covariance, float32, 8 <= D <= 64,
+ * T >= 4096 with a workspace of beer_frames_llh_backward_workspace_bytes (> 0 for
+ * exactly those shapes; the parameters as bf16x3 MFMA fragments): matrix cores,
+ * bf16x3 arithmetic, float32 accumulation over the components.  Everything else
+ * (workspace may be NULL): one thread per output, float64 accumulation. */
+size_t beer_frames_llh_backward_workspace_bytes(int dtype, int cov, int64_t T, int D, int K);
+int beer_frames_llh_backward(int dtype, int cov, int64_t T, int D, int K, const void* X,
+                             const void* weights, const void* grad, const void* exp_stats,
+                             void* out, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 /* ---- feature front-end (beer/features.py, `beer features extract`) ----------
  * Ragged batch of utterances: `signal` holds the samples of all utterances
  * back to back, utterance u owns samples [sample_off[u], sample_off[u+1]) and

@@ -730,6 +730,87 @@ def g14_hmm_vae():
     save('g14_hmm_vae_step', out)
 
 
+def g18_vae_one_sample():
+    """ONE sample per frame (vae.py:63-89 with nsamples = 1): the statistics the prior
+    receives are phi(z_t) of the samples.  Priors alone (value, gradient w.r.t. the samples,
+    accumulated statistics) and whole VAE steps with a full-covariance HMM / GMM prior and
+    the noise of the reparameterisation recorded."""
+    rng = np.random.RandomState(18)
+    T, Dz = 70, 5
+    z0 = torch.from_numpy(rng.randn(T, 1, Dz) * 1.5)
+    cvec = torch.from_numpy(rng.rand(T) + .5)
+
+    def prior_case(name, prior, **kwargs):
+        prior = prior.double()
+        z = z0.clone().requires_grad_(True)
+        stats = prior.sufficient_statistics(z.view(-1, Dz)).reshape(T, 1, -1).mean(dim=1)
+        exp_llh = prior.expected_log_likelihood(stats, **kwargs)
+        (cvec * exp_llh).sum().backward()
+        out = {'z': npy(z0), 'c': npy(cvec), 'exp_llh': npy(exp_llh), 'grad_z': npy(z.grad)}
+        dump_params(out, 'init', prior)
+        dump_acc(out, 'acc', prior, prior.accumulate(stats.detach()))
+        if hasattr(prior, 'graph'):
+            dump_graph(out, 'graph', prior.graph)
+        save(name, out)
+
+    for cov in ('full', 'diagonal', 'isotropic'):
+        torch.manual_seed(180)
+        nset = beer.NormalSet.create(torch.zeros(Dz), torch.ones(Dz) * 2., size=4,
+                                     prior_strength=1., noise_std=1., cov_type=cov)
+        prior_case(f'g18_onesample_gmm_{cov}', beer.Mixture.create(nset))
+        torch.manual_seed(181)
+        nset = beer.NormalSet.create(torch.zeros(Dz), torch.ones(Dz) * 2., size=3,
+                                     prior_strength=1., noise_std=1., cov_type=cov)
+        prior_case(f'g18_onesample_hmm_{cov}', beer.HMM.create(notebook_graph(), nset))
+    torch.manual_seed(182)
+    prior_case('g18_onesample_normal_full',
+               beer.Normal.create(torch.zeros(Dz), torch.ones(Dz), cov_type='full'))
+
+    def vae_step(name, make_prior, Dx, Dz2, T2, width, seed):
+        torch.manual_seed(seed)
+        X = torch.from_numpy(rng.randn(T2, Dx)).double()
+        enc = beer.nnet.ResidualFeedForwardNet(dim_in=Dx, nblocks=2, block_width=width)
+        dec = beer.nnet.ResidualFeedForwardNet(dim_in=Dz2, nblocks=2, block_width=width)
+        vae = beer.VAE(make_prior(Dz2), enc, dec).double()
+        noise = []
+        real_randn = torch.randn
+
+        def recording_randn(*a, **k):
+            t = real_randn(*a, **k)
+            noise.append(t)
+            return t
+        torch.randn = recording_randn
+        try:
+            elbo = beer.evidence_lower_bound(vae, X, nsamples=1, datasize=10 * T2)
+        finally:
+            torch.randn = real_randn
+        assert len(noise) == 1
+        elbo.backward()
+        out = {'X': npy(X), 'noise': npy(noise[0]), 'nsamples': np.array(1),
+               'datasize': np.array(10 * T2), 'elbo': np.asarray(float(elbo))}
+        for pname, p in vae.named_parameters():
+            out['nn.' + pname] = npy(p)
+            out['nngrad.' + pname] = npy(p.grad)
+        dump_params(out, 'init', vae)
+        dump_acc(out, 'acc', vae, elbo._acc_stats)
+        if hasattr(vae.prior, 'graph'):
+            dump_graph(out, 'graph', vae.prior.graph)
+        save(name, out)
+
+    def hmm_prior(Dz2):
+        nset = beer.NormalSet.create(torch.zeros(Dz2), torch.ones(Dz2), size=3,
+                                     prior_strength=1., noise_std=.5, cov_type='full')
+        return beer.HMM.create(notebook_graph(), nset)
+
+    def gmm_prior(Dz2):
+        nset = beer.NormalSet.create(torch.zeros(Dz2), torch.ones(Dz2), size=4,
+                                     prior_strength=1., noise_std=.5, cov_type='full')
+        return beer.Mixture.create(nset)
+
+    vae_step('g18_hmm_vae_step_full', hmm_prior, Dx=12, Dz2=8, T2=48, width=16, seed=183)
+    vae_step('g18_gmm_vae_step_full', gmm_prior, Dx=6, Dz2=3, T2=40, width=8, seed=184)
+
+
 def g15_features():
     """Feature front-end: outputs of beer/features.py functions and of the
     `beer features extract` operation sequence (extract.py:107-161) on the
@@ -824,6 +905,7 @@ if __name__ == '__main__':
     g_pickles()
     g14_vae()
     g14_hmm_vae()
+    g18_vae_one_sample()
     g13_fp64()
     g15_features()
     g16_notebooks()

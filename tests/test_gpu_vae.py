@@ -284,3 +284,166 @@ def test_statistics_gradient_against_autograd(cov, D, ns, dtype, tol):
     (stats * up.to(dtype)).sum().backward()
     torch.testing.assert_close(data.grad.double(), xr.grad, rtol=0,
                                atol=tol * float(xr.grad.abs().max()))
+
+
+# ---- one sample per frame: the prior on the frame kernels (csrc/sample_grad.hip) ----------
+
+def _no_dense_statistics(monkeypatch):
+    'The [T, Q] tensor must not be formed on this route.'
+    from beer_amd import kernels
+
+    def refuse(*a, **k):
+        raise AssertionError('dense [T, Q] statistics formed on the one-sample route')
+    monkeypatch.setattr(kernels, 'differentiable_stats', refuse)
+    monkeypatch.setattr(kernels, 'dense_llh', refuse)
+    monkeypatch.setattr(kernels, 'dense_accumulate', refuse)
+
+
+@pytest.mark.parametrize('name,kind', [
+    ('g18_onesample_gmm_full', 'gmm'), ('g18_onesample_gmm_diagonal', 'gmm'),
+    ('g18_onesample_gmm_isotropic', 'gmm'), ('g18_onesample_hmm_full', 'hmm'),
+    ('g18_onesample_hmm_diagonal', 'hmm'), ('g18_onesample_hmm_isotropic', 'hmm'),
+    ('g18_onesample_normal_full', 'normal')])
+def test_one_sample_prior_against_reference(name, kind, monkeypatch):
+    '''A prior over statistics that are phi(z_t) of differentiable samples (vae.py:63-86 with
+    one sample per frame): value, gradient w.r.t. the samples and accumulated statistics of
+    the reference, from the frame kernels + `beer_frames_llh_backward`.'''
+    from beer_amd import kernels
+    from gpu_helpers import npy, params_of, tt
+    g = load_golden(name)
+    prior = _prior(g, kind)
+    _no_dense_statistics(monkeypatch)
+    z = tt(g['z']).requires_grad_(True)
+    T, ns, Dz = z.shape
+    assert ns == 1
+    c = tt(g['c'])
+    stats = kernels.sample_stats(z.view(-1, Dz), name.rsplit('_', 1)[1])
+    assert stats.source is not None and stats.detach().source is None
+    exp_llh = prior.expected_log_likelihood(stats)
+    assert_close(npy(exp_llh).reshape(g['exp_llh'].shape), g['exp_llh'], TOL, 'exp_llh')
+    (c * exp_llh.reshape(g['exp_llh'].shape)).sum().backward()
+    assert_close(npy(z.grad), g['grad_z'], TOL, 'd/dz')
+    acc = prior.accumulate(stats.detach())
+    for i, p in enumerate(params_of(prior)):
+        assert_close(npy(acc[p]).reshape(g[f'acc.p{i}'].shape), g[f'acc.p{i}'], TOL, f'acc p{i}')
+
+
+@pytest.mark.parametrize('name,kind,width', [('g18_hmm_vae_step_full', 'hmm', 16),
+                                             ('g18_gmm_vae_step_full', 'gmm', 8)])
+def test_vae_step_with_one_sample_against_reference(name, kind, width, monkeypatch):
+    '''One ELBO + backward of a VAE with a full-covariance HMM / GMM prior and ONE sample per
+    frame, the reference's weights and noise: value, gradient of every network weight,
+    accumulated statistics -- without the [T, Q] statistics.'''
+    import beer_amd as beer
+    from beer_amd.dists import normaldiag
+    from gpu_helpers import build_hmm, build_mixture, npy, params_of, tt
+    g = load_golden(name)
+    X = tt(g['X'])
+    Dx, Dz = X.shape[1], g['noise'].shape[-1]
+    enc = beer.nnet.ResidualFeedForwardNet(dim_in=Dx, nblocks=2, block_width=width)
+    dec = beer.nnet.ResidualFeedForwardNet(dim_in=Dz, nblocks=2, block_width=width)
+    prior = build_hmm(g) if kind == 'hmm' else build_mixture(g)
+    vae = beer.VAE(prior, enc, dec, reference_broadcast=True).double().to('cuda')
+    assert not vae.dense_statistics
+    with torch.no_grad():
+        for pname, p in vae.named_parameters():
+            p.copy_(tt(g['nn.' + pname]))
+    monkeypatch.setattr(normaldiag, '_randn', lambda *a, **k: tt(g['noise']))
+    _no_dense_statistics(monkeypatch)
+    elbo = beer.evidence_lower_bound(vae, X, nsamples=1, datasize=int(g['datasize']))
+    assert abs(float(elbo) - float(g['elbo'])) <= 1e-9 * abs(float(g['elbo']))
+    elbo.backward()
+    for pname, p in vae.named_parameters():
+        assert_close(npy(p.grad), g['nngrad.' + pname], 1e-7, 'grad ' + pname)
+    for i, p in enumerate(params_of(vae)):
+        assert_close(npy(elbo._acc_stats[p]).reshape(g[f'acc.p{i}'].shape), g[f'acc.p{i}'],
+                     1e-9, f'acc p{i}')
+
+
+@pytest.mark.parametrize('cov,T,D,K,dtype,tol', [
+    ('full', 20001, 64, 120, torch.float32, 2e-6), ('full', 9000, 40, 7, torch.float32, 2e-6),
+    ('full', 4096, 24, 33, torch.float32, 2e-6), ('full', 5000, 13, 4, torch.float32, 2e-6),
+    ('full', 700, 64, 9, torch.float32, 2e-6), ('full', 5000, 72, 5, torch.float32, 2e-6),
+    ('diagonal', 6000, 64, 120, torch.float32, 2e-6), ('isotropic', 6000, 40, 12, torch.float32, 2e-6),
+    ('full', 3000, 33, 6, torch.float64, 1e-12), ('diagonal', 3000, 40, 6, torch.float64, 1e-12),
+    ('isotropic', 300, 5, 3, torch.float64, 1e-12)])
+def test_frames_gradient_against_autograd(cov, T, D, K, dtype, tol):
+    '''`beer_frames_llh_backward` (matrix cores for float32 / full covariance / D <= 64 / large
+    T, the generic kernel otherwise) against torch autograd in fp64 on the dense construction
+    g_t sum_k w_tk phi(x_t) . E_k, with and without the per-frame factor.'''
+    from beer_amd import _hip, kernels
+    from gpu_helpers import DEV
+    torch.manual_seed(11)
+    x64 = torch.randn(T, D, dtype=torch.float64, device=DEV)
+    Q = {'full': D * D + D + 2, 'diagonal': 2 * D + 2, 'isotropic': D + 3}[cov]
+    E = torch.randn(K, Q, dtype=torch.float64, device=DEV) / D ** .5
+    w = torch.rand(T, K, dtype=torch.float64, device=DEV)
+    g = torch.rand(T, dtype=torch.float64, device=DEV) + .5
+    fast = _hip.lib().beer_frames_llh_backward_workspace_bytes(
+        _hip.dtype_code(dtype), _hip.COV_CODE[cov], T, D, K) > 0
+    assert fast == (dtype == torch.float32 and cov == 'full' and 8 <= D <= 64 and T >= 4096)
+    for grad in (g, None):
+        xr = x64.clone().requires_grad_(True)
+        ones = torch.ones(T, 1, dtype=torch.float64, device=DEV)
+        if cov == 'full':
+            quad = -.5 * (xr[:, :, None] * xr[:, None, :]).reshape(T, D * D)
+        elif cov == 'diagonal':
+            quad = -.5 * xr ** 2
+        else:
+            quad = -.5 * (xr ** 2).sum(1, keepdim=True)
+        dense = torch.cat([xr, quad, -.5 * ones, .5 * ones], dim=1)
+        value = ((dense @ E.t()) * w).sum(1)
+        (value if grad is None else value * grad).sum().backward()
+        stats = kernels.sample_stats(x64.to(dtype), cov)
+        out = kernels.frames_llh_backward(stats, w.to(dtype), None if grad is None else grad.to(dtype),
+                                          E.to(dtype))
+        assert out.dtype == dtype and tuple(out.shape) == (T, D)
+        torch.testing.assert_close(out.double(), xr.grad, rtol=0,
+                                   atol=tol * float(xr.grad.abs().max()))
+
+
+def test_hmm_vae_routes_agree_on_a_large_minibatch(monkeypatch):
+    '''An HMM-VAE with a full-covariance prior at config 4's latent dimension on 20 k float32
+    frames in utterances: the one-sample route (frame kernels on the matrix cores,
+    `sgrad_kernel`) and the dense-statistics route give the same ELBO, network gradients
+    and accumulated statistics to float32 accuracy.'''
+    import beer_amd as beer
+    from beer_amd.dists import normaldiag
+    from gpu_helpers import npy
+    torch.manual_seed(3)
+    Dx, Dz, S = 20, 64, 12
+    lengths = [400] * 50
+    T = sum(lengths)
+    X = torch.randn(T, Dx, device='cuda')
+    noise = torch.randn(T, 1, Dz, device='cuda')
+    graph = beer.graph.Graph()
+    s0, s1 = graph.add_state(), graph.add_state()
+    graph.start_state, graph.end_state = s0, s1
+    st = [graph.add_state(pdf_id=i) for i in range(S)]
+    graph.add_arc(s0, st[0])
+    for i, s in enumerate(st):
+        graph.add_arc(s, s)
+        graph.add_arc(s, st[(i + 1) % S])
+    graph.add_arc(st[-1], s1)
+    graph.normalize()
+    ns = beer.NormalSet.create(torch.zeros(Dz), torch.ones(Dz), size=S, cov_type='full',
+                               noise_std=.5)
+    vae = beer.VAE(beer.HMM.create(graph.compile(), ns),
+                   beer.nnet.ResidualFeedForwardNet(Dx, 1, 32),
+                   beer.nnet.ResidualFeedForwardNet(Dz, 1, 32)).to('cuda')
+    monkeypatch.setattr(normaldiag, '_randn', lambda *a, **k: noise)
+    results = []
+    for dense in (True, False):
+        vae.dense_statistics = dense
+        vae.zero_grad()
+        elbo = beer.accumulate_elbo(vae, (X, lengths), datasize=10 * T)
+        elbo.backward()
+        results.append((float(elbo), {n: p.grad.clone() for n, p in vae.named_parameters()},
+                        {p: v.clone() for p, v in elbo._acc_stats.items()}))
+    (e_d, g_d, a_d), (e_s, g_s, a_s) = results
+    assert abs(e_s - e_d) <= 2e-6 * abs(e_d)
+    for n in g_d:
+        torch.testing.assert_close(g_s[n], g_d[n], rtol=0,
+                                   atol=2e-5 * float(g_d[n].abs().max()) + 1e-12)
+    for p in a_d:
+        assert_close(npy(a_s[p]), npy(a_d[p]), 2e-5, 'acc')
