@@ -24,8 +24,9 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall',
 # Per-file flags.  estep_bf16.hip: no SLP vectorisation -- hipcc pairs adjacent float32
 # adds / multiplies of the fragment arithmetic into v_pk_* instructions, which beside MFMAs cost
 # more than the two plain instructions they replace (MI355X_MICROARCH.md, price of a filler;
-# measured: fused accumulation of config 3 10.6 -> 10.3 ms per 3.33 M frames).
-FILE_FLAGS = {'estep_bf16.hip': ['-fno-slp-vectorize']}
+# measured: fused accumulation of config 3 10.6 -> 10.3 ms per 3.33 M frames; the gradient
+# w.r.t. the samples of config 4 4.21 -> 4.07 ms per 1 M frames).
+FILE_FLAGS = {'estep_bf16.hip': ['-fno-slp-vectorize'], 'sample_grad.hip': ['-fno-slp-vectorize']}
 
 
 def _sources():

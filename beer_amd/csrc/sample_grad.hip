@@ -25,8 +25,10 @@
 // fragments and copied global -> LDS by the DMA path, component k + 1 in flight while k is
 // multiplied.  Algorithmic work: 2 T K D (D + 1) flop (983 GFLOP per million frames at
 // K = 120, D = 64), six bf16 MFMAs per float32 product.
-// Everything else (float64, diagonal / isotropic, D > 64, small inputs): `sgrad_generic_kernel`,
-// a thread per output, float64 accumulation.
+// Everything else (float64, diagonal / isotropic, D > 64): the two steps of dense.hip's route --
+// beer_dense_llh_backward, then beer_suffstats_backward -- over chunks of frames whose [frames, Q]
+// gradient fits a bounded workspace (256 MiB); small inputs, or no workspace:
+// `sgrad_generic_kernel`, a thread per output, float64 accumulation.
 
 #include "common.h"
 #include "estep_tiles.h"
@@ -39,8 +41,18 @@ typedef unsigned int sgu4 __attribute__((ext_vector_type(4)));
 typedef __bf16 sgbf8 __attribute__((ext_vector_type(8)));
 using beer_mfma::f32x4;
 
-constexpr int kSgWaves = 8;            // waves per workgroup (two per SIMD)
-constexpr int kSgWM = 3;               // 16-frame tiles per wave
+#ifndef BEER_SG_WAVES
+#define BEER_SG_WAVES 8
+#endif
+#ifndef BEER_SG_WM
+#define BEER_SG_WM 4
+#endif
+#ifndef BEER_SG_KPS
+#define BEER_SG_KPS 1                  // components per stage (one barrier per stage)
+#endif
+constexpr int kSgWaves = BEER_SG_WAVES;   // waves per workgroup (two per SIMD)
+constexpr int kSgWM = BEER_SG_WM;         // 16-frame tiles per wave
+constexpr int kSgKps = BEER_SG_KPS;
 constexpr int kSgFrames = kSgWaves * kSgWM * 16;
 constexpr int64_t kSgMinFrames = 4096; // below: the generic kernel
 
@@ -97,7 +109,8 @@ __global__ __launch_bounds__(kSgWaves * 64) void sgrad_kernel(
     int64_t T_, int D, int K, const float* __restrict__ X, const float* __restrict__ W,
     const float* __restrict__ g, const char* __restrict__ img, float* __restrict__ out) {
     constexpr int NJ = 2 * NKB, NCH = sg_chunks(NKB), WM = kSgWM;
-    __shared__ __attribute__((aligned(16))) char smem[2 * NCH * 1024];
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 stages
+    static_assert(4 % kSgKps == 0, "stages of 1, 2 or 4 components");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
     const int64_t t0 = (int64_t)blockIdx.x * kSgFrames + wave * (WM * 16);
@@ -130,13 +143,15 @@ __global__ __launch_bounds__(kSgWaves * 64) void sgrad_kernel(
     }
 
     typedef __attribute__((address_space(3))) void* lds_ptr;
+    // components k .. k + kSgKps - 1 (those below K) into buffer `buf`
     auto stage = [&](int k, int buf) {
         const char* src = img + (size_t)k * (NCH * 1024) + lane * 16;
-        char* dst = smem + buf * (NCH * 1024);
+        char* dst = smem + buf * (kSgKps * NCH * 1024);
+        const int nch = (K - k < kSgKps ? K - k : kSgKps) * NCH;
 #pragma unroll
-        for (int c = 0; c < (NCH + kSgWaves - 1) / kSgWaves; ++c) {
+        for (int c = 0; c < (kSgKps * NCH + kSgWaves - 1) / kSgWaves; ++c) {
             const int ch = wave + c * kSgWaves;
-            if (ch < NCH)
+            if (ch < nch)
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const sgu4*>(src + ch * 1024),
                                                  (lds_ptr)(dst + ch * 1024), 16, 0, 0);
         }
@@ -166,13 +181,16 @@ __global__ __launch_bounds__(kSgWaves * 64) void sgrad_kernel(
         for (int c = 0; c < 4; ++c) {
             const int k = k0 + c;
             if (k >= K) break;
-            // component k has landed (this wave's share; the barrier: everybody's), and
-            // everybody is done with component k - 1, whose buffer k + 1 goes into
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (k + 1 < K) stage(k + 1, (k + 1) & 1);
+            if (c % kSgKps == 0) {
+                // this stage has landed (this wave's share; the barrier: everybody's), and
+                // everybody is done with the previous one, whose buffer the next goes into
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (k + kSgKps < K) stage(k + kSgKps, (k / kSgKps + 1) & 1);
+            }
             if (c == 0) load_w(k0 + 4, wnext);
-            const char* buf = smem + (k & 1) * (NCH * 1024);
+            const char* buf = smem + ((k / kSgKps) & 1) * (kSgKps * NCH * 1024) +
+                              (c % kSgKps) * (NCH * 1024);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 sgu4 bfr[NKB][3];
@@ -274,6 +292,19 @@ inline size_t sg_image_bytes(int D, int K) {
     return (size_t)K * sg_chunks(sg_blocks(D)) * 1024;
 }
 
+// the chunked two-step route: frames per chunk, bytes of its [frames, Q] gradient
+constexpr size_t kSgChunkBytes = (size_t)256 << 20;
+inline int64_t sg_chunk_frames(int dtype, int cov, int64_t T_, int D) {
+    const size_t row = (size_t)stats_dim(cov, D) * (dtype == BEER_F64 ? 8 : 4);
+    int64_t n = (int64_t)(kSgChunkBytes / row);
+    if (n < 1024) n = 1024;
+    return n < T_ ? n : T_;
+}
+inline size_t sg_chunk_bytes(int dtype, int cov, int64_t T_, int D) {
+    return (size_t)sg_chunk_frames(dtype, cov, T_, D) * stats_dim(cov, D) *
+           (dtype == BEER_F64 ? 8 : 4);
+}
+
 template <typename T>
 int sgrad_generic_launch(int cov, int64_t T_, int D, int K, const void* X, const void* W,
                          const void* g, const void* E, void* out, void* stream) {
@@ -292,8 +323,11 @@ int sgrad_fast_launch(int64_t T_, int D, int K, const float* X, const float* W, 
     hipLaunchKernelGGL(sgrad_image_kernel<NKB>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0,
                        s, K, D, E, img);
     BEER_LAUNCH_CHECK();
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sgrad_kernel<NKB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);
     hipLaunchKernelGGL(sgrad_kernel<NKB>, dim3((unsigned)((T_ + kSgFrames - 1) / kSgFrames)),
-                       dim3(kSgWaves * 64), 0, s, T_, D, K, X, W, g, img, out);
+                       dim3(kSgWaves * 64), 2 * kSgKps * sg_chunks(NKB) * 1024, s, T_, D, K, X, W, g,
+                       img, out);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }
@@ -303,7 +337,9 @@ int sgrad_fast_launch(int64_t T_, int D, int K, const float* X, const float* W, 
 extern "C" {
 
 size_t beer_frames_llh_backward_workspace_bytes(int dtype, int cov, int64_t T, int D, int K) {
-    return sg_fast(dtype, cov, T, D, K) ? sg_image_bytes(D, K) : 0;
+    if (T < kSgMinFrames || D < 1 || K < 1 || cov < 0 || cov > 2) return 0;
+    if (dtype != BEER_F32 && dtype != BEER_F64) return 0;
+    return sg_fast(dtype, cov, T, D, K) ? sg_image_bytes(D, K) : sg_chunk_bytes(dtype, cov, T, D);
 }
 
 int beer_frames_llh_backward(int dtype, int cov, int64_t T, int D, int K, const void* X,
@@ -321,6 +357,22 @@ int beer_frames_llh_backward(int dtype, int cov, int64_t T, int D, int K, const 
         return sgrad_fast_launch<2>(T, D, K, (const float*)X, (const float*)weights,
                                     (const float*)grad, (const float*)exp_stats, (float*)out,
                                     (char*)workspace, as_stream(stream));
+    }
+    if (T >= kSgMinFrames && workspace && workspace_bytes >= sg_chunk_bytes(dtype, cov, T, D)) {
+        const int64_t chunk = sg_chunk_frames(dtype, cov, T, D);
+        const size_t elem = dtype == BEER_F64 ? 8 : 4;
+        const int Q = stats_dim(cov, D);
+        for (int64_t c0 = 0; c0 < T; c0 += chunk) {
+            const int64_t n = T - c0 < chunk ? T - c0 : chunk;
+            int rc = beer_dense_llh_backward(
+                dtype, n, K, Q, (const char*)weights + (size_t)c0 * K * elem,
+                grad ? (const char*)grad + (size_t)c0 * elem : nullptr, exp_stats, workspace, stream);
+            if (rc != BEER_OK) return rc;
+            rc = beer_suffstats_backward(dtype, cov, n, 1, D, (const char*)X + (size_t)c0 * D * elem,
+                                         workspace, (char*)out + (size_t)c0 * D * elem, stream);
+            if (rc != BEER_OK) return rc;
+        }
+        return BEER_OK;
     }
     BEER_DISPATCH(dtype, sgrad_generic_launch, cov, T, D, K, X, weights, grad, exp_stats, out,
                   stream);

@@ -44,6 +44,10 @@ def normal_llh(stats, exp_stats, cov_type):
     T, D = X.shape
     E = _hip.on_device(exp_stats, X.dtype)
     K = E.shape[0]
+    if st.scale == 1.0:
+        # K mixtures of one component: the log-normalisers ARE the log-likelihoods, and that
+        # form of the call runs on the matrix cores (the per-component output does not)
+        return mixtureset_estep(st, E, None, K, 1, cov_type, want_resps=False)[0]
     out = torch.empty(T, K, dtype=X.dtype, device=X.device)
     _hip.call('beer_mixtureset_estep', _hip.dtype_code(X.dtype), _hip.COV_CODE[cov_type],
               T, D, K, 1, _hip.ptr(X), _hip.ptr(E), None, None, st.scale,

@@ -781,14 +781,22 @@ def run_vae(args, device, frames=1_000_000, steps=3, warmup=1):
     total = sum(lengths)
     g = torch.Generator(device=device).manual_seed(4)
     X = torch.randn(total, D, generator=g, device=device)
-    names = ('beer_suffstats_mean', 'beer_dense_llh', 'beer_hmm_posteriors_fused',
-             'beer_hmm_forward_backward', 'beer_hmm_gather', 'beer_hmm_scatter',
-             'beer_dense_llh_backward', 'beer_suffstats_backward', 'beer_dense_accumulate',
-             'beer_softmax_groups', 'beer_rowdot')
+    names = ('beer_mixtureset_estep', 'beer_hmm_posteriors_fused', 'beer_hmm_forward_backward',
+             'beer_hmm_gather', 'beer_hmm_scatter', 'beer_frames_llh_backward', 'beer_pack_resps',
+             'beer_normal_accumulate_packed', 'beer_normal_accumulate',
+             # the dense-statistics route (several samples per frame; `dense_route` below)
+             'beer_suffstats_mean', 'beer_dense_llh', 'beer_dense_llh_backward',
+             'beer_suffstats_backward', 'beer_dense_accumulate', 'beer_softmax_groups',
+             'beer_rowdot')
+    products = ('beer_mixtureset_estep', 'beer_frames_llh_backward', 'beer_normal_accumulate_packed',
+                'beer_normal_accumulate', 'beer_dense_llh', 'beer_dense_llh_backward',
+                'beer_dense_accumulate')
     out = {'workload': f'configs[3]: HMM-VAE, D={D}, latent {LATENT}, residual encoder/decoder '
                        f'2x128, phone-loop prior {N_PHONES}x3 states (1 Gaussian per state), one '
                        f'minibatch of {total} fp32 frames in {len(lengths)} utterances of the '
-                       '5 M-frame corpus, 1 sample per frame',
+                       '5 M-frame corpus, 1 sample per frame (the prior runs its frame kernels on '
+                       'the samples; `dense_route`: the [T, Q] statistics route that several '
+                       'samples per frame take, same minibatch)',
            'unit': 'frames/s', 'steps': steps, 'warmup': warmup}
     S = 3 * N_PHONES
     for cov in ('diagonal', 'full'):
@@ -809,9 +817,10 @@ def run_vae(args, device, frames=1_000_000, steps=3, warmup=1):
 
         Z = torch.randn(total, LATENT, generator=g, device=device)
 
-        def prior_path():
+        def prior_path(dense=False):
             z = Z.clone().requires_grad_(True)
-            stats = beer.kernels.differentiable_stats(z, cov, 1)
+            stats = beer.kernels.differentiable_stats(z, cov, 1) if dense else \
+                beer.kernels.sample_stats(z, cov)
             exp_llh = prior.expected_log_likelihood(stats, utt_lengths=lengths)
             exp_llh.sum().backward()
             acc = prior.accumulate(stats.detach())
@@ -819,7 +828,8 @@ def run_vae(args, device, frames=1_000_000, steps=3, warmup=1):
             return acc
 
         sub = {}
-        for key, fn in (('vae_step', vae_step), ('prior_hot_path', prior_path)):
+        for key, fn in (('vae_step', vae_step), ('prior_hot_path', prior_path),
+                        ('dense_route', lambda: prior_path(dense=True))):
             for _ in range(warmup):
                 fn()
             torch.cuda.synchronize()
@@ -834,8 +844,9 @@ def run_vae(args, device, frames=1_000_000, steps=3, warmup=1):
                 ms, n = kt.mean_ms(nm)
                 if n:
                     kern[nm] = {'ms': ms, 'launches_per_step': n / steps}
-                    if nm in ('beer_dense_llh', 'beer_dense_llh_backward', 'beer_dense_accumulate'):
-                        # one [T, Q] x [Q, S] (or its transpose) product: 2 T Q S flop
+                    if nm in products:
+                        # one [T, Q] x [Q, S] (or its transpose) product, on either route: 2 T Q S
+                        # flop (the gradient w.r.t. the samples: 2 T S D (D + 1), the same count)
                         kern[nm]['tflops'] = 2. * total * Qz * S / (ms * 1e-3) / 1e12
             sub[key] = {'value': total / dt, 'ms_per_step': 1e3 * dt, 'kernels': kern}
             if key == 'vae_step':
@@ -850,7 +861,8 @@ def run_vae(args, device, frames=1_000_000, steps=3, warmup=1):
                     'frac': kern[dom]['tflops'] / PEAK_TFLOPS['bf16'], 'traffic': None,
                     'avg_launch_ms': kern[dom]['ms'],
                     'note': f'achieved = 2*T*Q*S algorithmic flop of one [T, Q={Qz}] x [Q, S={S}] '
-                            'product / HIP-event time; six bf16 MFMAs per float32 product'}
+                            'product (no symmetry discount) / HIP-event time; six bf16 MFMAs per '
+                            'float32 product'}
         else:
             # the dominant call streams [T, Q] / [T, S] arrays: HBM bound; algorithmic bytes =
             # the latent samples in (and their gradient out) + the posteriors

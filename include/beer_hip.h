@@ -669,10 +669,12 @@ int beer_suffstats_backward(int dtype, int cov, int64_t T, int ns, int D,
  * = beer_suffstats_backward(beer_dense_llh_backward(weights, grad, exp_stats)) at
  * ns = 1.  `grad` nullable (= 1); `weights` [T, K]; `exp_stats` [K, Q] as for
  * beer_dense_llh.  BEER_F32 / BEER_F64.  Full covariance, float32, 8 <= D <= 64,
- * T >= 4096 with a workspace of beer_frames_llh_backward_workspace_bytes (> 0 for
- * exactly those shapes; the parameters as bf16x3 MFMA fragments): matrix cores,
- * bf16x3 arithmetic, float32 accumulation over the components.  Everything else
- * (workspace may be NULL): one thread per output, float64 accumulation. */
+ * T >= 4096 with a workspace of beer_frames_llh_backward_workspace_bytes (the
+ * parameters as bf16x3 MFMA fragments): matrix cores, bf16x3 arithmetic, float32
+ * accumulation over the components.  Other shapes with T >= 4096 and that
+ * workspace (<= 256 MiB): the two calls above over chunks of frames whose
+ * [frames, Q] gradient fits it.  T < 4096 (the query returns 0), or workspace
+ * NULL: one thread per output, float64 accumulation. */
 size_t beer_frames_llh_backward_workspace_bytes(int dtype, int cov, int64_t T, int D, int K);
 int beer_frames_llh_backward(int dtype, int cov, int64_t T, int D, int K, const void* X,
                              const void* weights, const void* grad, const void* exp_stats,

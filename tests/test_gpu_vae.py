@@ -379,9 +379,18 @@ def test_frames_gradient_against_autograd(cov, T, D, K, dtype, tol):
     E = torch.randn(K, Q, dtype=torch.float64, device=DEV) / D ** .5
     w = torch.rand(T, K, dtype=torch.float64, device=DEV)
     g = torch.rand(T, dtype=torch.float64, device=DEV) + .5
-    fast = _hip.lib().beer_frames_llh_backward_workspace_bytes(
-        _hip.dtype_code(dtype), _hip.COV_CODE[cov], T, D, K) > 0
-    assert fast == (dtype == torch.float32 and cov == 'full' and 8 <= D <= 64 and T >= 4096)
+    # the workspace says which route a shape takes: none below 4096 frames (a thread per
+    # output), the parameters' fragment image (25 / 7 KiB per component) on the matrix cores,
+    # a chunk of [frames, Q] gradients for the two-step route
+    nbytes = _hip.lib().beer_frames_llh_backward_workspace_bytes(
+        _hip.dtype_code(dtype), _hip.COV_CODE[cov], T, D, K)
+    if T < 4096:
+        assert nbytes == 0
+    elif dtype == torch.float32 and cov == 'full' and 8 <= D <= 64:
+        assert nbytes == K * (25 if D > 32 else 7) * 1024
+    else:
+        assert nbytes == min(T, max(1024, (256 << 20) // (Q * x64.to(dtype).element_size()))) * \
+            Q * x64.to(dtype).element_size()
     for grad in (g, None):
         xr = x64.clone().requires_grad_(True)
         ones = torch.ones(T, 1, dtype=torch.float64, device=DEV)

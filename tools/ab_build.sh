@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 NAME=$1; FILE=$2; DEFS=$3
 # (per-file flags of beer_amd/build.py)
-if [ "$FILE" == "estep_bf16" ] && [[ "$DEFS" != *-fslp-vectorize* ]]; then DEFS="$DEFS -fno-slp-vectorize"; fi
+if { [ "$FILE" == "estep_bf16" ] || [ "$FILE" == "sample_grad" ]; } && [[ "$DEFS" != *-fslp-vectorize* ]]; then DEFS="$DEFS -fno-slp-vectorize"; fi
 mkdir -p build_ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -mllvm -pragma-unroll-threshold=262144 \
   -Wno-unused-function -Iinclude -Ibeer_amd/csrc $DEFS -c beer_amd/csrc/$FILE.hip -o build_ab/${FILE}_$NAME.o
