@@ -2184,7 +2184,12 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
     if (S > 1) G = group_pad(G);
     if (G != Greal && resps) return BEER_EINVAL;
     const int K = S * G;
-    const int NT = ntx_for(S, K), nchunks = nchunksx_for(S, K), nk = nk16_of(cov, D);
+    // a set of at most 128 single Gaussians (the per-state log-likelihoods of an HMM with one
+    // Gaussian per state: 120 states at config 4) is one chunk of 8 / 4 component tiles, not
+    // of 16 half of which would be padding
+    const bool narrow = S > 1 && Greal == 1 && K <= 128 && !packed && !image;
+    const int NT = narrow ? (K <= 64 ? 4 : 8) : ntx_for(S, K);
+    const int nchunks = nchunksx_for(S, K), nk = nk16_of(cov, D);
     const int kpad = nchunks * NT * 16;
     // a frame fragment image: mixture sets, log-normalisers only, groups of >= 4 (refused
     // here, before anything is launched)
@@ -2245,6 +2250,10 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
     const int jw = G < 4 ? G : 4;
     const int gl = lane_major ? 0 : (G < 4 ? 1 : (G < 64 ? G / 4 : 16));
     const int gq = G <= 64 ? 1 : G / 64;
+    if (narrow) {
+        if (NT == 4) BEER_LLHX(4, 2, 1, false, false);
+        BEER_LLHX(8, 2, 1, false, false);
+    }
     if (packed) {
         // the responsibilities within each state's mixture as the accumulation's LDS tiles
         const bool wide = beer::option(BEER_OPT_K1_WIDE) != 0;

@@ -456,3 +456,27 @@ def test_hmm_vae_routes_agree_on_a_large_minibatch(monkeypatch):
                                    atol=2e-5 * float(g_d[n].abs().max()) + 1e-12)
     for p in a_d:
         assert_close(npy(a_s[p]), npy(a_d[p]), 2e-5, 'acc')
+
+
+@pytest.mark.parametrize('cov,D,K', [('full', 64, 120), ('full', 40, 48), ('diagonal', 64, 120),
+                                     ('full', 24, 128), ('isotropic', 40, 3), ('full', 64, 130)])
+def test_per_state_log_likelihoods_on_the_matrix_cores(cov, D, K):
+    '''`NormalSet.expected_log_likelihood` of float32 frames -- the per-state log-likelihoods of
+    an HMM with one Gaussian per state, K mixtures of ONE component to the E-step kernel (a
+    chunk of 4 / 8 component tiles up to 128 Gaussians, of 16 beyond) -- against the float64
+    kernels on the same frames, to float32 accuracy.'''
+    import beer_amd as beer
+    from gpu_helpers import DEV
+    torch.manual_seed(21)
+    T = 20000
+    X = torch.randn(T, D, dtype=torch.float64, device=DEV) * 1.5 + .3
+    ns = beer.NormalSet.create(torch.zeros(D, dtype=torch.float64), torch.ones(D, dtype=torch.float64),
+                               size=K, cov_type=cov, noise_std=1.).to(DEV)
+    l64 = ns.expected_log_likelihood(ns.sufficient_statistics(X))
+    ns32 = ns.float()
+    l32 = ns32.expected_log_likelihood(ns32.sufficient_statistics(X.float()))
+    assert l32.dtype == torch.float32 and tuple(l32.shape) == (T, K)
+    # (the float32 model's parameters are the float64 ones rounded: the band of that
+    # rounding, a few 1e-7 of the largest term of a logit, plus the arithmetic's)
+    scale = float((X.abs().max() ** 2) * D)
+    torch.testing.assert_close(l32.double(), l64, rtol=2e-6, atol=2e-6 * scale)

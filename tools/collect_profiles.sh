@@ -9,6 +9,9 @@ rm -f profiles/${R}_pmc.json
 python tools/pmc_summary.py $R "--command=python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-config3 --no-config4" $O/c2_pmc1 $O/c2_pmc2 $O/c2_pmc3
 python tools/pmc_summary.py $R "--command=python bench.py --config 3 --steps 3 --warmup 2 --no-cpu-baseline" --tag=c3 $O/c3_pmc1 $O/c3_pmc2 $O/c3_pmc3
 python tools/pmc_summary.py $R "--command=python bench.py --config 3 --cov full --frames 2000000 --steps 3 --warmup 2 --no-cpu-baseline" --tag=c3full $O/c3full_pmc1 $O/c3full_pmc2 $O/c3full_pmc3
+python tools/pmc_summary.py $R "--command=python tools/probes/c4_prior_path.py full 4" --tag=c4 $O/c4_pmc1 $O/c4_pmc2 $O/c4_pmc3
+cp $(ls -t $O/c4_stats/*/*kernel_stats.csv | head -1) profiles/${R}_config4_prior_path_kernel_stats.csv
+cp $(ls -t $O/c4bench_stats/*/*kernel_stats.csv | head -1) profiles/${R}_bench_config4_kernel_stats.csv
 cp $(ls -t $O/c2_stats/*/*kernel_stats.csv | head -1) profiles/${R}_bench_kernel_stats.csv
 cp $(ls -t $O/c3_stats/*/*kernel_stats.csv | head -1) profiles/${R}_bench_config3_kernel_stats.csv
 cp $(ls -t $O/c3full_stats/*/*kernel_stats.csv | head -1) profiles/${R}_bench_config3_full_kernel_stats.csv

@@ -10,7 +10,8 @@ C2="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-config3 --no-con
 C3="python bench.py --config 3 --steps 3 --warmup 2 --no-cpu-baseline"
 C3F="python bench.py --config 3 --cov full --frames 2000000 --steps 3 --warmup 2 --no-cpu-baseline"
 P1="SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-KEEP="Kernel_Name|llhx_kernel|lnfi_kernel|accx_kernel|accf_kernel|accfi_kernel|frame_image_kernel|fb_wave_kernel|llh_kernel|acc_kernel|gt_image|xt_image"
+C4="python tools/probes/c4_prior_path.py full 4"
+KEEP="Kernel_Name|llhx_kernel|lnfi_kernel|accx_kernel|accf_kernel|accfi_kernel|frame_image_kernel|fb_wave_kernel|llh_kernel|acc_kernel|gt_image|xt_image|sgrad_kernel"
 run() {  # name, command
   $T rocprofv3 --kernel-trace --stats -f csv -d $O/$1_stats -- $2 > $O/$1_stats.log 2>&1
   $T rocprofv3 --kernel-trace --pmc $P1 -f csv -d $O/$1_pmc1 -- $2 > $O/$1_pmc1.log 2>&1
@@ -26,6 +27,9 @@ run() {  # name, command
 run c2 "$C2"
 run c3 "$C3"
 run c3full "$C3F"
+run c4 "$C4"          # the prior hot path of config 4 (full covariance, one-sample route) alone
+$T rocprofv3 --kernel-trace --stats -f csv -d $O/c4bench_stats -- python bench.py --config4-only > $O/c4bench_stats.log 2>&1
+find $O/c4bench_stats -name '*kernel_trace.csv' -delete
 du -sh $O
 # the driver's line (cpu baselines, config-3 and config-4 sub-objects), and the lines alone
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2>>$O/err.log
