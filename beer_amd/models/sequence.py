@@ -104,6 +104,10 @@ class HMM(DiscreteLatentModel):
             # loop) are summed over their sources in 'hub_flow' [S] instead
             self.cache['trans_resps'] = xi
             self.cache['hub_flow'] = flow
+            # posteriors of the FIRST frame, summed over the utterances of a ragged batch
+            # (`utt_lengths`): what a phone loop counts besides the flows (phoneloop.py:88-95,
+            # once per utterance in the reference's loop)
+            self.cache['first_resps'] = g0
         self.cache['scaled_pdf_resps'] = state_resps
         self.cache['scale'] = scale
         if dense and isinstance(emissions, NormalSet):
@@ -229,7 +233,9 @@ class PhoneLoop(HMM):
         wparam = self.categorical.mean_field_factorization()[0][0]
         ref = wparam.stats
         if 'trans_resps' in self.cache:
-            counts = self.phone_counts(self.cache['trans_resps'], self.cache['resps'][0],
+            first = self.cache.get('first_resps')
+            counts = self.phone_counts(self.cache['trans_resps'],
+                                       self.cache['resps'][0] if first is None else first,
                                        self.cache.get('hub_flow'))
             counts = counts.to(dtype=ref.dtype, device=ref.device)
             resps_stats = self.categorical.sufficient_statistics(counts.view(1, -1))

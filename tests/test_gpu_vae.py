@@ -480,3 +480,79 @@ def test_per_state_log_likelihoods_on_the_matrix_cores(cov, D, K):
     # rounding, a few 1e-7 of the largest term of a logit, plus the arithmetic's)
     scale = float((X.abs().max() ** 2) * D)
     torch.testing.assert_close(l32.double(), l64, rtol=2e-6, atol=2e-6 * scale)
+
+
+def _small_phone_loop(n_phones, dim, cov, dtype):
+    'beer hmm mkphones / mkphoneloopgraph / mkphoneloop in memory: 3 emitting states per phone.'
+    import beer_amd as beer
+    units, pdf = {}, 0
+    for p in range(n_phones):
+        g = beer.graph.Graph()
+        for sid in range(5):
+            g.add_state(pdf_id=None if sid in (0, 4) else pdf + sid - 1)
+        g.start_state, g.end_state = 0, 4
+        for arc in ((0, 1), (1, 1), (1, 2), (2, 2), (2, 3), (3, 3), (3, 4)):
+            g.add_arc(*arc)
+        g.normalize()
+        units[p] = g
+        pdf += 3
+    graph = beer.graph.Graph()
+    graph.start_state, graph.end_state = graph.add_state(), graph.add_state()
+    pivot = graph.add_state()
+    u2s = {p: graph.add_state() for p in units}
+    graph.add_arc(graph.start_state, pivot)
+    graph.add_arc(pivot, graph.end_state)
+    for p in units:
+        graph.add_arc(pivot, u2s[p])
+        graph.add_arc(u2s[p], pivot)
+    graph.normalize()
+    for p, hmm in units.items():
+        graph.replace_state(u2s[p], hmm)
+    graph.normalize()
+    ns = beer.NormalSet.create(torch.zeros(dim, dtype=dtype), torch.ones(dim, dtype=dtype),
+                               size=3 * n_phones, cov_type=cov, noise_std=1.)
+    return beer.PhoneLoop.create(graph.compile(), {p: 3 * p for p in units},
+                                 {p: 3 * p + 2 for p in units}, ns)
+
+
+@pytest.mark.parametrize('nsamp', [1, 2])
+def test_phone_loop_vae_batch_equals_per_utterance_loop(nsamp, monkeypatch):
+    '''A VAE whose prior is a phone loop (config 4's model): accumulate_elbo on a minibatch of
+    utterances == the reference's loop of per-utterance calls -- value, network gradients, the
+    Gaussians' statistics AND the phone counts, which take the first frame of EVERY utterance
+    (phoneloop.py:88-95).  One sample per frame (frame kernels) and two (dense statistics).'''
+    import beer_amd as beer
+    from beer_amd.dists import normaldiag
+    from gpu_helpers import npy
+    torch.manual_seed(6)
+    Dx, Dz = 5, 4
+    lengths = [30, 17, 44, 25]
+    X = torch.randn(sum(lengths), Dx, dtype=torch.float64, device='cuda')
+    master = torch.randn(sum(lengths), nsamp, Dz, dtype=torch.float64, device='cuda')
+    prior = _small_phone_loop(3, Dz, 'full', torch.float64)
+    vae = beer.VAE(prior, beer.nnet.ResidualFeedForwardNet(Dx, 1, 8),
+                   beer.nnet.ResidualFeedForwardNet(Dz, 1, 8)).double().to('cuda')
+    cursor = [0]
+
+    def fake_randn(n, *rest, **conf):
+        out = master[cursor[0]:cursor[0] + n]
+        cursor[0] += n
+        return out
+    monkeypatch.setattr(normaldiag, '_randn', fake_randn)
+    N = 1000
+    loop = beer.evidence_lower_bound(datasize=N)
+    for u in torch.split(X, lengths):
+        loop += beer.evidence_lower_bound(vae, u, datasize=N, nsamples=nsamp)
+    loop.backward()
+    grads = {n: p.grad.clone() for n, p in vae.named_parameters()}
+    vae.zero_grad()
+    cursor[0] = 0
+    batch = beer.accumulate_elbo(vae, (X, lengths), datasize=N, nsamples=nsamp)
+    assert abs(float(batch) - float(loop)) <= 1e-10 * abs(float(loop))
+    batch.backward()
+    for n, p in vae.named_parameters():
+        assert_close(npy(p.grad), npy(grads[n]), 1e-8, 'grad ' + n)
+    params = list(vae.bayesian_parameters())
+    assert len(params) == 2                      # the Gaussians and the phone weights
+    for p in params:
+        assert_close(npy(batch._acc_stats[p]), npy(loop._acc_stats[p]), 1e-9, 'acc')
