@@ -84,8 +84,29 @@ class HMM(DiscreteLatentModel):
             if sum(lengths) != T:
                 raise ValueError('utt_lengths do not add up to the number of frames')
             batch = hk.HmmBatch([graph], [0] * len(lengths), lengths, pc_all.dtype)
+        flow = g0 = None
+        # a ragged batch (`utt_lengths`, not in the reference) on graphs the one-wave kernel
+        # takes: gather + forward-backward + scatter in ONE launch, as `accumulate_elbo` runs
+        # an HMM shard (the per-state posteriors [T, n_states] are not kept then -- a phone
+        # loop counts from the first-frame posteriors and hub flows the kernel sums)
+        fused = utt_lengths is not None and not viterbi and state_path is None and \
+            hk.fused_ok(batch)
+        need_counts = trans_posts and hasattr(self, 'start_pdf')
+        if fused and need_counts:
+            fused = getattr(getattr(batch.dgraphs[0], 'lowdeg', None), 'n_hubs', 0) >= 1
+        if fused:
+            state_resps, g0, flow = hk.posteriors_fused(batch, pc_all, scale,
+                                                        want_counts=need_counts)
+            exp_llh = kernels.rowdot(state_resps, pc_all)
+            self.cache.pop('resps', None)
+            if trans_posts:
+                self.cache['trans_resps'] = None
+                self.cache['hub_flow'] = flow
+                self.cache['first_resps'] = g0
+            self.cache['scaled_pdf_resps'] = state_resps
+            self.cache['scale'] = scale
+            return self._with_gradient(stats, exp_llh, state_resps, emissions, dense)
         pc_llhs = hk.gather(batch, pc_all, scale)
-        flow = None
         if viterbi or state_path is not None:
             path = hk.viterbi(batch, pc_llhs) if state_path is None else state_path
             gamma, xi, g0 = hk.path_posteriors(batch, path, want_xi=trans_posts)
@@ -110,6 +131,11 @@ class HMM(DiscreteLatentModel):
             self.cache['first_resps'] = g0
         self.cache['scaled_pdf_resps'] = state_resps
         self.cache['scale'] = scale
+        return self._with_gradient(stats, exp_llh, state_resps, emissions, dense)
+
+    @staticmethod
+    def _with_gradient(stats, exp_llh, state_resps, emissions, dense):
+        'The value with its gradient w.r.t. differentiable statistics / frames (a VAE\'s prior).'
         if dense and isinstance(emissions, NormalSet):
             # statistics-in (prior of a VAE): d exp_llh / d stats through
             # sum_s gamma_ts * scale * l_ts with detached posteriors (hmm.py:81-87)

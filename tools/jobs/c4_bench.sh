@@ -6,9 +6,10 @@ R=$GRAFT_REPO_ROOT
 cd $R
 timeout 600 python bench.py --config4-only > gpurun_out/c4/bench_c4.json 2> gpurun_out/c4/bench_c4.err
 tail -c 600 gpurun_out/c4/bench_c4.err
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/c4/prof -o c4 -- python bench.py --config4-only > gpurun_out/c4/prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/c4/prof -- python bench.py --config4-only > gpurun_out/c4/prof.log 2>&1
 f=$(find gpurun_out/c4/prof -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && head -25 "$f" > gpurun_out/c4/kernel_stats_head.csv
+[ -n "$f" ] && python tools/kstats_head.py "$f" 45 > gpurun_out/c4/kernel_stats_head.txt
+find gpurun_out/c4/prof -name "*kernel_trace.csv" -delete
 find gpurun_out/c4/prof -name "*.csv" ! -name "*kernel_stats.csv" -delete
 find gpurun_out/c4/prof -name "*.db" -delete
 python - <<'PY'
