@@ -25,7 +25,9 @@
 // fragments and copied global -> LDS by the DMA path, component k + 1 in flight while k is
 // multiplied.  Algorithmic work: 2 T K D (D + 1) flop (983 GFLOP per million frames at
 // K = 120, D = 64), six bf16 MFMAs per float32 product.
-// Everything else (float64, diagonal / isotropic, D > 64): the two steps of dense.hip's route --
+// Diagonal / isotropic, float32, D <= 128: `sgrad_diag_kernel` below (one [T, K] x [K, 2 D] product
+// on the matrix cores, HBM-bound).
+// Everything else (float64, full covariance beyond 64 dimensions): the two steps of dense.hip's route --
 // beer_dense_llh_backward, then beer_suffstats_backward -- over chunks of frames whose [frames, Q]
 // gradient fits a bounded workspace (256 MiB); small inputs, or no workspace:
 // `sgrad_generic_kernel`, a thread per output, float64 accumulation.
@@ -247,6 +249,161 @@ __global__ __launch_bounds__(kSgWaves * 64) void sgrad_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Diagonal / isotropic covariance, float32, D <= 128 (`sgrad_diag_kernel`):
+//     out[t, d] = grad[t] * (S1[t, d] - x[t, d] S2[t, d]),   [S1 | S2] = w [T, K] x [E1 | E2] [K, 2 D]
+// one product on the matrix cores in the same bf16x3 arithmetic -- the posteriors as the frame-side
+// operand, split on the fly (8 values per lane and 32 components), [E1 | E2] prepared once per
+// call as MFMA fragments (`sgrad_diag_image_kernel`; isotropic: E2_k repeated over the
+// dimensions) and staged through LDS 32 components at a time -- and the combination with the
+// frame in the epilogue: the lane that holds S1[t, d] also holds S2[t, d].  The call streams
+// w, x and out once (4 (K + 2 D) bytes per frame): HBM-bound.
+// ---------------------------------------------------------------------------
+constexpr int kSdWaves = 8, kSdWM = 2, kSdFrames = kSdWaves * kSdWM * 16;
+
+inline int sd_tiles(int D) { return D <= 32 ? 2 : (D <= 48 ? 3 : (D <= 64 ? 4 : 8)); }   // of 16 dims
+
+template <int NJ2>
+__global__ __launch_bounds__(256) void sgrad_diag_image_kernel(int cov, int K, int D,
+                                                               const float* __restrict__ E,
+                                                               char* __restrict__ img) {
+    constexpr int NJ = 2 * NJ2, DP = NJ2 * 16;
+    const int Q = stats_dim(cov, D), KB = (K + 31) / 32;
+    const int64_t total = (int64_t)KB * NJ * 3 * 64;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(idx & 63);
+        const int ch = (int)(idx >> 6), q = ch % 3, j = (ch / 3) % NJ, kb = ch / (3 * NJ);
+        const int fi = lane & 15, fg = lane >> 4, n = j * 16 + fi;
+        const int d = n < DP ? n : n - DP;
+        unsigned w[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            unsigned short h[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int k = kb * 32 + fg * 8 + 2 * p + s2;
+                float v = 0.f;
+                if (k < K && d < D)
+                    v = n < DP ? E[(size_t)k * Q + d]
+                               : E[(size_t)k * Q + D + (cov == BEER_DIAG ? d : 0)];
+                unsigned short pc[3];
+                beer_mfma::split3_scalar(v, pc);
+                h[s2] = pc[q];
+            }
+            w[p] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+        }
+        *reinterpret_cast<sgu4*>(img + (size_t)ch * 1024 + lane * 16) = sgu4{w[0], w[1], w[2], w[3]};
+    }
+}
+
+template <int NJ2>
+__global__ __launch_bounds__(kSdWaves * 64) void sgrad_diag_kernel(
+    int64_t T_, int D, int K, const float* __restrict__ X, const float* __restrict__ W,
+    const float* __restrict__ g, const char* __restrict__ img, float* __restrict__ out) {
+    constexpr int NJ = 2 * NJ2, WM = kSdWM, STAGE = NJ * 3 * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 stages
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fg = lane >> 4, KB = (K + 31) / 32;
+    const int64_t t0 = (int64_t)blockIdx.x * kSdFrames + wave * (WM * 16);
+    const float* wrow[WM];
+    bool live[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int64_t t = t0 + i * 16 + fi;
+        live[i] = t < T_;
+        wrow[i] = W + (live[i] ? t : T_ - 1) * K;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto stage = [&](int kb, int buf) {
+        const char* src = img + (size_t)kb * STAGE + lane * 16;
+        char* dst = smem + buf * STAGE;
+#pragma unroll
+        for (int c = 0; c < (NJ * 3 + kSdWaves - 1) / kSdWaves; ++c) {
+            const int ch = wave + c * kSdWaves;
+            if (ch < NJ * 3)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const sgu4*>(src + ch * 1024),
+                                                 (lds_ptr)(dst + ch * 1024), 16, 0, 0);
+        }
+    };
+    auto load_w = [&](int kb, float (&dst)[WM][8]) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = kb * 32 + fg * 8 + e;
+                dst[i][e] = (k < K && live[i]) ? wrow[i][k] : 0.f;
+            }
+    };
+    f32x4 acc[WM][NJ];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float wnext[WM][8];
+    stage(0, 0);
+    load_w(0, wnext);
+    for (int kb = 0; kb < KB; ++kb) {
+        sgu4 af[WM][3];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                unsigned pc[3];
+                beer_mfma::split3(wnext[i][2 * p], wnext[i][2 * p + 1], pc);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) af[i][q][p] = pc[q];
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kb + 1 < KB) {
+            stage(kb + 1, (kb + 1) & 1);
+            load_w(kb + 1, wnext);
+        }
+        const char* buf = smem + (kb & 1) * STAGE;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            sgu4 bfr[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                bfr[q] = *reinterpret_cast<const sgu4*>(buf + (j * 3 + q) * 1024 + lane * 16);
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(sgbf8, bfr[PB[pr]]), __builtin_bit_cast(sgbf8, af[i][PA[pr]]),
+                        acc[i][j], 0, 0, 0);
+        }
+    }
+    // a lane holds [S1 | S2][frame fi][column 16 j + 4 fg + e]: S1 in tiles j < NJ2, S2 of the
+    // same dimensions in tiles j + NJ2
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int64_t t = t0 + i * 16 + fi;
+        if (t >= T_) continue;
+        const float sc = g ? g[t] : 1.f;
+#pragma unroll
+        for (int j = 0; j < NJ2; ++j) {
+            const int d0 = j * 16 + fg * 4;
+            if (d0 + 3 < D && (D & 3) == 0) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(X + t * D + d0);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = sc * (acc[i][j][e] - x[e] * acc[i][j + NJ2][e]);
+                *reinterpret_cast<f32x4*>(out + t * D + d0) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (d0 + e < D)
+                        out[t * D + d0 + e] =
+                            sc * (acc[i][j][e] - X[t * D + d0 + e] * acc[i][j + NJ2][e]);
+            }
+        }
+    }
+}
+
 // any dtype / covariance type / dimension: a thread per output, float64 accumulation
 template <typename T>
 __global__ __launch_bounds__(256) void sgrad_generic_kernel(
@@ -292,6 +449,14 @@ inline size_t sg_image_bytes(int D, int K) {
     return (size_t)K * sg_chunks(sg_blocks(D)) * 1024;
 }
 
+inline bool sd_fast(int dtype, int cov, int64_t T_, int D, int K) {
+    return dtype == BEER_F32 && (cov == BEER_DIAG || cov == BEER_ISO) && D >= 1 && D <= 128 &&
+           K >= 1 && T_ >= kSgMinFrames;
+}
+inline size_t sd_image_bytes(int D, int K) {
+    return (size_t)((K + 31) / 32) * 2 * sd_tiles(D) * 3 * 1024;
+}
+
 // the chunked two-step route: frames per chunk, bytes of its [frames, Q] gradient
 constexpr size_t kSgChunkBytes = (size_t)256 << 20;
 inline int64_t sg_chunk_frames(int dtype, int cov, int64_t T_, int D) {
@@ -312,6 +477,21 @@ int sgrad_generic_launch(int cov, int64_t T_, int D, int K, const void* X, const
     const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
     hipLaunchKernelGGL(sgrad_generic_kernel<T>, dim3(blocks), dim3(256), 0, as_stream(stream), cov,
                        T_, D, K, (const T*)X, (const T*)W, (const T*)g, (const T*)E, (T*)out);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+template <int NJ2>
+int sgrad_diag_launch(int cov, int64_t T_, int D, int K, const float* X, const float* W,
+                      const float* g, const float* E, float* out, char* img, hipStream_t s) {
+    const int64_t items = (int64_t)((K + 31) / 32) * 2 * NJ2 * 3 * 64;
+    hipLaunchKernelGGL(sgrad_diag_image_kernel<NJ2>, dim3((unsigned)((items + 255) / 256)),
+                       dim3(256), 0, s, cov, K, D, E, img);
+    BEER_LAUNCH_CHECK();
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sgrad_diag_kernel<NJ2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);
+    hipLaunchKernelGGL(sgrad_diag_kernel<NJ2>, dim3((unsigned)((T_ + kSdFrames - 1) / kSdFrames)),
+                       dim3(kSdWaves * 64), 2 * 2 * NJ2 * 3 * 1024, s, T_, D, K, X, W, g, img, out);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }
@@ -339,7 +519,9 @@ extern "C" {
 size_t beer_frames_llh_backward_workspace_bytes(int dtype, int cov, int64_t T, int D, int K) {
     if (T < kSgMinFrames || D < 1 || K < 1 || cov < 0 || cov > 2) return 0;
     if (dtype != BEER_F32 && dtype != BEER_F64) return 0;
-    return sg_fast(dtype, cov, T, D, K) ? sg_image_bytes(D, K) : sg_chunk_bytes(dtype, cov, T, D);
+    if (sg_fast(dtype, cov, T, D, K)) return sg_image_bytes(D, K);
+    if (sd_fast(dtype, cov, T, D, K)) return sd_image_bytes(D, K);
+    return sg_chunk_bytes(dtype, cov, T, D);
 }
 
 int beer_frames_llh_backward(int dtype, int cov, int64_t T, int D, int K, const void* X,
@@ -357,6 +539,19 @@ int beer_frames_llh_backward(int dtype, int cov, int64_t T, int D, int K, const 
         return sgrad_fast_launch<2>(T, D, K, (const float*)X, (const float*)weights,
                                     (const float*)grad, (const float*)exp_stats, (float*)out,
                                     (char*)workspace, as_stream(stream));
+    }
+    if (sd_fast(dtype, cov, T, D, K) && workspace && workspace_bytes >= sd_image_bytes(D, K)) {
+#define BEER_SD(NJ2_)                                                                            \
+    return sgrad_diag_launch<NJ2_>(cov, T, D, K, (const float*)X, (const float*)weights,         \
+                                   (const float*)grad, (const float*)exp_stats, (float*)out,     \
+                                   (char*)workspace, as_stream(stream))
+        switch (sd_tiles(D)) {
+            case 2: BEER_SD(2);
+            case 3: BEER_SD(3);
+            case 4: BEER_SD(4);
+            default: BEER_SD(8);
+        }
+#undef BEER_SD
     }
     if (T >= kSgMinFrames && workspace && workspace_bytes >= sg_chunk_bytes(dtype, cov, T, D)) {
         const int64_t chunk = sg_chunk_frames(dtype, cov, T, D);

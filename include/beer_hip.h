@@ -671,9 +671,11 @@ int beer_suffstats_backward(int dtype, int cov, int64_t T, int ns, int D,
  * beer_dense_llh.  BEER_F32 / BEER_F64.  Full covariance, float32, 8 <= D <= 64,
  * T >= 4096 with a workspace of beer_frames_llh_backward_workspace_bytes (the
  * parameters as bf16x3 MFMA fragments): matrix cores, bf16x3 arithmetic, float32
- * accumulation over the components.  Other shapes with T >= 4096 and that
- * workspace (<= 256 MiB): the two calls above over chunks of frames whose
- * [frames, Q] gradient fits it.  T < 4096 (the query returns 0), or workspace
+ * accumulation over the components; diagonal / isotropic, float32, D <= 128: one
+ * [T, K] x [K, 2 D] product in the same arithmetic, combined with the frames in
+ * its epilogue (HBM-bound).  Other shapes with T >= 4096 and that workspace
+ * (<= 256 MiB): the two calls above over chunks of frames whose [frames, Q]
+ * gradient fits it.  T < 4096 (the query returns 0), or workspace
  * NULL: one thread per output, float64 accumulation. */
 size_t beer_frames_llh_backward_workspace_bytes(int dtype, int cov, int64_t T, int D, int K);
 int beer_frames_llh_backward(int dtype, int cov, int64_t T, int D, int K, const void* X,

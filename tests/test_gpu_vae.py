@@ -365,11 +365,15 @@ def test_vae_step_with_one_sample_against_reference(name, kind, width, monkeypat
     ('full', 4096, 24, 33, torch.float32, 2e-6), ('full', 5000, 13, 4, torch.float32, 2e-6),
     ('full', 700, 64, 9, torch.float32, 2e-6), ('full', 5000, 72, 5, torch.float32, 2e-6),
     ('diagonal', 6000, 64, 120, torch.float32, 2e-6), ('isotropic', 6000, 40, 12, torch.float32, 2e-6),
+    ('diagonal', 20001, 40, 33, torch.float32, 2e-6), ('diagonal', 4100, 13, 7, torch.float32, 2e-6),
+    ('diagonal', 5000, 100, 64, torch.float32, 2e-6), ('isotropic', 5000, 128, 5, torch.float32, 2e-6),
+    ('diagonal', 5000, 130, 5, torch.float32, 2e-6), ('diagonal', 900, 64, 12, torch.float32, 2e-6),
     ('full', 3000, 33, 6, torch.float64, 1e-12), ('diagonal', 3000, 40, 6, torch.float64, 1e-12),
     ('isotropic', 300, 5, 3, torch.float64, 1e-12)])
 def test_frames_gradient_against_autograd(cov, T, D, K, dtype, tol):
-    '''`beer_frames_llh_backward` (matrix cores for float32 / full covariance / D <= 64 / large
-    T, the generic kernel otherwise) against torch autograd in fp64 on the dense construction
+    '''`beer_frames_llh_backward` (matrix cores for float32 and large T -- full covariance up to
+    64 dimensions, diagonal / isotropic up to 128 --, the two dense steps over chunks or the
+    generic kernel otherwise) against torch autograd in fp64 on the dense construction
     g_t sum_k w_tk phi(x_t) . E_k, with and without the per-frame factor.'''
     from beer_amd import _hip, kernels
     from gpu_helpers import DEV
@@ -381,13 +385,17 @@ def test_frames_gradient_against_autograd(cov, T, D, K, dtype, tol):
     g = torch.rand(T, dtype=torch.float64, device=DEV) + .5
     # the workspace says which route a shape takes: none below 4096 frames (a thread per
     # output), the parameters' fragment image (25 / 7 KiB per component) on the matrix cores,
-    # a chunk of [frames, Q] gradients for the two-step route
+    # the same for [E1 | E2] of diagonal / isotropic Gaussians, a chunk of [frames, Q] gradients
+    # for the two-step route
     nbytes = _hip.lib().beer_frames_llh_backward_workspace_bytes(
         _hip.dtype_code(dtype), _hip.COV_CODE[cov], T, D, K)
     if T < 4096:
         assert nbytes == 0
     elif dtype == torch.float32 and cov == 'full' and 8 <= D <= 64:
         assert nbytes == K * (25 if D > 32 else 7) * 1024
+    elif dtype == torch.float32 and cov != 'full' and D <= 128:
+        tiles = 2 if D <= 32 else 3 if D <= 48 else 4 if D <= 64 else 8
+        assert nbytes == -(-K // 32) * 2 * tiles * 3 * 1024
     else:
         assert nbytes == min(T, max(1024, (256 << 20) // (Q * x64.to(dtype).element_size()))) * \
             Q * x64.to(dtype).element_size()
