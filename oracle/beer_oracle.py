@@ -656,6 +656,51 @@ def hmm_elbo_step(X, groups, graph, datasize=-1, scale=1., viterbi=False,
     return r
 
 
+# ---------------------------------------------------------------------------
+# The prior of a VAE (beer/models/vae.py:63-86): value and gradient w.r.t. the samples
+# ---------------------------------------------------------------------------
+
+def suffstats_backward(cov_type, X, grad_stats):
+    """What autograd gives the reference for `sufficient_statistics` (normalwishart.py:30-38,
+    normalgamma.py:20-27, isonormalgamma.py:21-30): J_phi(x_t)^T grad_stats[t] -> [T, D]."""
+    T, D = X.shape
+    out = grad_stats[:, :D].copy()
+    if cov_type == 'full':
+        G = grad_stats[:, D:D + D * D].reshape(T, D, D)
+        out -= .5 * (np.einsum('tij,tj->ti', G, X) + np.einsum('tji,tj->ti', G, X))
+    elif cov_type == 'diagonal':
+        out -= grad_stats[:, D:2 * D] * X
+    else:
+        out -= grad_stats[:, D:D + 1] * X
+    return out
+
+
+def prior_gradient_wrt_samples(cov_type, Z, weights, exp_T, upstream=None):
+    """d/dZ of sum_t upstream[t] * sum_k weights[t,k] * (phi(z_t) . exp_T[k]) with `weights`
+    detached: the reference's autograd through `(pc_llhs * resps).sum(-1)` (mixture.py:79,92;
+    hmm.py:81-87), `stats @ exp_T^T` (normalwishart.py:88-92) and `sufficient_statistics`,
+    for ONE sample per frame (vae.py:73-74: the mean over one sample is the sample's phi)."""
+    w = weights if upstream is None else weights * upstream[:, None]
+    return suffstats_backward(cov_type, Z, w @ exp_T)
+
+
+def vae_gmm_prior(cov_type, Z, post, w_post):
+    """`Mixture.expected_log_likelihood(phi(Z))` as a VAE's prior with one sample per frame
+    (mixture.py:70-93): (per-frame value [T], responsibilities [T, K], E[T] [K, Q])."""
+    exp_T = FAMILIES[cov_type]['exp'](*post)
+    value, resps = mixture_estep(SUFFSTATS[cov_type](Z), exp_T, Z.shape[1], log_weights(w_post))
+    return value, resps, exp_T
+
+
+def vae_hmm_prior(cov_type, Z, post, graph):
+    """`HMM.expected_log_likelihood(phi(Z))` likewise (hmm.py:73-92): (per-frame value [T],
+    state posteriors scattered to the pdf ids [T, S_total], E[T])."""
+    exp_T = FAMILIES[cov_type]['exp'](*post)
+    pc_all = normal_llh(SUFFSTATS[cov_type](Z), exp_T, Z.shape[1])
+    r = hmm_estep(pc_all, graph['order'], graph['init'], graph['final'], graph['trans'])
+    return r['exp_llh'], scatter_states(r['resps'], graph['order'], pc_all.shape[1]), exp_T
+
+
 def emissions_mstep(groups, acc, scale, lrate=1.):
     """backward + step on every emission parameter (objectives.py:98-105,
     parameters.py:134-141).  Returns new groups."""

@@ -564,3 +564,36 @@ def test_phone_loop_vae_batch_equals_per_utterance_loop(nsamp, monkeypatch):
     assert len(params) == 2                      # the Gaussians and the phone weights
     for p in params:
         assert_close(npy(batch._acc_stats[p]), npy(loop._acc_stats[p]), 1e-9, 'acc')
+
+
+@pytest.mark.parametrize('cov,T,D,K,dtype,tol', [('full', 6000, 24, 12, torch.float32, 1e-5),
+                                                 ('diagonal', 6000, 40, 33, torch.float32, 1e-5),
+                                                 ('full', 500, 9, 5, torch.float64, 1e-9),
+                                                 ('isotropic', 500, 9, 5, torch.float64, 1e-9)])
+def test_one_sample_gmm_prior_against_the_oracle(cov, T, D, K, dtype, tol):
+    '''A GMM prior over phi(z_t) of seeded samples: value, gradient w.r.t. the samples and
+    accumulated statistics of the HIP path against the CPU oracle (oracle/beer_oracle.py:
+    vae_gmm_prior, prior_gradient_wrt_samples -- pinned on the reference's G18 goldens).'''
+    import beer_amd as beer
+    from beer_amd import kernels
+    from gpu_helpers import DEV, npy, params_of
+    from helpers import orc
+    torch.manual_seed(31)
+    Z = (torch.randn(T, D, dtype=torch.float64) * 1.3 + .2).to(dtype)
+    c = torch.rand(T, dtype=torch.float64).to(dtype) + .5
+    ns = beer.NormalSet.create(torch.zeros(D, dtype=dtype), torch.ones(D, dtype=dtype), size=K,
+                               cov_type=cov, noise_std=1.)
+    prior = beer.Mixture.create(ns).to(DEV)
+    p0, p1 = params_of(prior)
+    as64 = lambda d: [npy(getattr(d.params, n)).astype(np.float64) for n in d._std_params_def]
+    Zn = Z.numpy().astype(np.float64)
+    value, resps, exp_T = orc.vae_gmm_prior(cov, Zn, as64(p0.posterior), as64(p1.posterior)[0])
+    grad = orc.prior_gradient_wrt_samples(cov, Zn, resps, exp_T, c.numpy().astype(np.float64))
+    z = Z.to(DEV).requires_grad_(True)
+    stats = kernels.sample_stats(z, cov)
+    got = prior.expected_log_likelihood(stats)
+    assert_close(npy(got), value, tol, 'value')
+    (c.to(DEV) * got).sum().backward()
+    assert_close(npy(z.grad), grad, 10 * tol, 'd/dz')
+    acc = prior.accumulate(stats.detach())[p0]
+    assert_close(npy(acc), resps.T @ orc.SUFFSTATS[cov](Zn), 10 * tol, 'acc')

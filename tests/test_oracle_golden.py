@@ -172,6 +172,28 @@ def test_g4_hmm(cov, suffix, tol):
         assert_close(post, g['posteriors'], 1e-6)
 
 
+# --- G18: the prior of a VAE with one sample per frame --------------------------
+
+@pytest.mark.parametrize('cov', ['full', 'diagonal', 'isotropic'])
+@pytest.mark.parametrize('kind', ['gmm', 'hmm'])
+def test_g18_prior_value_and_gradient_wrt_samples(kind, cov):
+    """The reference's value, autograd gradient w.r.t. the samples and accumulated statistics of
+    a GMM / HMM prior over phi(z_t) (vae.py:63-86 with nsamples = 1)."""
+    g = load_golden(f'g18_onesample_{kind}_{cov}')
+    Z, c = g['z'][:, 0, :], g['c']
+    post = std_params(g, 'init.p0.posterior')
+    if kind == 'gmm':
+        (w_post,) = std_params(g, 'init.p1.posterior')
+        value, weights, exp_T = orc.vae_gmm_prior(cov, Z, post, w_post)
+    else:
+        value, weights, exp_T = orc.vae_hmm_prior(cov, Z, post, _graph(g, 'graph'))
+    assert_close(value, g['exp_llh'].reshape(-1), TOL64, 'exp_llh')
+    grad = orc.prior_gradient_wrt_samples(cov, Z, weights, exp_T, c)
+    assert_close(grad, g['grad_z'][:, 0, :], 1e-9, 'd/dz')
+    acc = weights.T @ orc.SUFFSTATS[cov](Z)
+    assert_close(acc, g['acc.p0'].reshape(acc.shape), 1e-9, 'acc')
+
+
 def test_g7_viterbi_ties():
     g = load_golden('g07_viterbi_ties')
     graph = _graph(g, 'graph')
