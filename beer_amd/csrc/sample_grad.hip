@@ -52,6 +52,9 @@ using beer_mfma::f32x4;
 #ifndef BEER_SG_KPS
 #define BEER_SG_KPS 1                  // components per stage (one barrier per stage)
 #endif
+#ifndef BEER_SG_ABL
+#define BEER_SG_ABL 0    // timing experiments (wrong results), bits: 1 no barrier / re-staging after
+#endif                   // the first component, 2 B fragments read from LDS once per component
 constexpr int kSgWaves = BEER_SG_WAVES;   // waves per workgroup (two per SIMD)
 constexpr int kSgWM = BEER_SG_WM;         // 16-frame tiles per wave
 constexpr int kSgKps = BEER_SG_KPS;
@@ -173,6 +176,11 @@ __global__ __launch_bounds__(kSgWaves * 64) void sgrad_kernel(
 
     float wcur[WM][4], wnext[WM][4];
     stage(0, 0);
+    if ((BEER_SG_ABL & 1) && K > kSgKps) {
+        stage(kSgKps, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     load_w(0, wnext);
     for (int k0 = 0; k0 < K; k0 += 4) {
 #pragma unroll
@@ -183,7 +191,11 @@ __global__ __launch_bounds__(kSgWaves * 64) void sgrad_kernel(
         for (int c = 0; c < 4; ++c) {
             const int k = k0 + c;
             if (k >= K) break;
-            if (c % kSgKps == 0) {
+            if ((BEER_SG_ABL & 1) && k > 0) {
+                // (no barrier, no staging -- but the same fence for the compiler)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (c % kSgKps == 0) {
                 // this stage has landed (this wave's share; the barrier: everybody's), and
                 // everybody is done with the previous one, whose buffer the next goes into
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(kSgWaves * 64) void sgrad_kernel(
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
                         bfr[kb][q] = *reinterpret_cast<const sgu4*>(
-                            buf + ((j * NKB + kb) * 3 + q) * 1024 + lane * 16);
+                            buf + ((((BEER_SG_ABL & 2) ? 0 : j) * NKB + kb) * 3 + q) * 1024 + lane * 16);
                 // C = E1_k: a lane holds y[dimension 16 j + 4 fg + e][frame fi]
                 const f32x4 c0 = *reinterpret_cast<const f32x4*>(
                     buf + (NCH - 1) * 1024 + (j * 16 + fg * 4) * 4);
