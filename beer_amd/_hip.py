@@ -320,7 +320,9 @@ def set_f32_mode(mode):
     bf16 MFMA, fp32 accumulation -- fp32's own operands and accumulation, product
     error <= 2^-23, at 2.7x the fp32 pipe's rate).  The mode governs the kernels that
     take FRAMES (E-step, accumulation); the statistics-in products of a VAE's prior
-    (`beer_dense_*`: large float32 shapes) are bf16x3 in either mode.'''
+    (`beer_dense_*`: large float32 shapes) are bf16x3 in either mode, and the gradient
+    w.r.t. the samples of a one-sample VAE (`beer_frames_llh_backward`) leaves the matrix
+    cores for a float64-accumulating kernel in 'exact' mode.'''
     if mode not in F32_MODES:
         raise ValueError(f'f32 mode {mode!r}: expected one of {F32_MODES}')
     _f32_mode[0] = mode

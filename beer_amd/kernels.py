@@ -618,6 +618,10 @@ def frames_llh_backward(stats, weights, grad, exp_stats):
     out = torch.empty_like(X)
     code, cov = _hip.dtype_code(X.dtype), _hip.COV_CODE[st.cov_type]
     nbytes = _hip.lib().beer_frames_llh_backward_workspace_bytes(code, cov, T, D, K)
+    if X.dtype == torch.float32 and _hip.get_f32_mode() == 'exact':
+        # the matrix-core kernels of this call are bf16x3; without a workspace the library
+        # runs its thread-per-output kernel (float64 accumulation): exact, and slow
+        nbytes = 0
     ws = None
     if nbytes:
         key = ('sgrad', cov, D, K, X.device, torch.cuda.current_stream().cuda_stream)

@@ -597,3 +597,26 @@ def test_one_sample_gmm_prior_against_the_oracle(cov, T, D, K, dtype, tol):
     assert_close(npy(z.grad), grad, 10 * tol, 'd/dz')
     acc = prior.accumulate(stats.detach())[p0]
     assert_close(npy(acc), resps.T @ orc.SUFFSTATS[cov](Zn), 10 * tol, 'acc')
+
+
+def test_exact_mode_keeps_the_sample_gradient_off_the_bf16_kernels():
+    '''`set_f32_mode('exact')`: the gradient w.r.t. the samples comes from the float64-accumulating
+    kernel (no workspace handed over) -- equal to the fp64 result to float32 rounding of the
+    output, and different in the last bits from the bf16x3 kernel's.'''
+    from beer_amd import _hip, kernels
+    from gpu_helpers import DEV
+    torch.manual_seed(12)
+    T, D, K = 5000, 16, 6
+    X = torch.randn(T, D, device=DEV)
+    E = torch.randn(K, D * D + D + 2, device=DEV) / D ** .5
+    w = torch.rand(T, K, device=DEV)
+    st = kernels.sample_stats(X, 'full')
+    fast = kernels.frames_llh_backward(st, w, None, E)
+    with _hip.exact_f32():
+        exact = kernels.frames_llh_backward(st, w, None, E)
+    ref = kernels.frames_llh_backward(kernels.sample_stats(X.double(), 'full'), w.double(), None,
+                                      E.double())
+    scale = float(ref.abs().max())
+    assert float((exact.double() - ref).abs().max()) <= 1e-7 * scale
+    assert float((fast.double() - ref).abs().max()) <= 2e-6 * scale
+    assert not torch.equal(fast, exact)
