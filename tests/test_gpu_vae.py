@@ -620,3 +620,38 @@ def test_exact_mode_keeps_the_sample_gradient_off_the_bf16_kernels():
     assert float((exact.double() - ref).abs().max()) <= 1e-7 * scale
     assert float((fast.double() - ref).abs().max()) <= 2e-6 * scale
     assert not torch.equal(fast, exact)
+
+
+@pytest.mark.parametrize('cov', ['full', 'diagonal'])
+def test_sample_gradient_at_config4_size(cov):
+    '''`beer_frames_llh_backward` at BASELINE config 4's own size (1 M samples of a 64-dimensional
+    latent variable, 120 states) through size-independent properties: it is linear in the
+    posteriors and in the per-frame factor, rows depend on their own frame only (any slice
+    of the batch reproduces its rows bit for bit on the same route), and sampled rows agree
+    with the float64 kernel.'''
+    from beer_amd import kernels
+    from gpu_helpers import DEV
+    torch.manual_seed(44)
+    T, D, K = 1_000_000, 64, 120
+    Q = D * D + D + 2 if cov == 'full' else 2 * D + 2
+    X = torch.randn(T, D, device=DEV)
+    E = torch.randn(K, Q, device=DEV) / D ** .5
+    w1 = torch.rand(T, K, device=DEV)
+    w2 = torch.rand(T, K, device=DEV)
+    g = torch.rand(T, device=DEV) + .5
+    st = kernels.sample_stats(X, cov)
+    a = kernels.frames_llh_backward(st, w1, None, E)
+    b = kernels.frames_llh_backward(st, w2, None, E)
+    ab = kernels.frames_llh_backward(st, w1 + w2, None, E)
+    scale = float(ab.abs().max())
+    assert float((ab - (a + b)).abs().max()) <= 4e-6 * scale           # linear in the posteriors
+    ag = kernels.frames_llh_backward(st, w1, g, E)
+    assert float((ag - g[:, None] * a).abs().max()) <= 1e-6 * scale    # ... and in the factor
+    lo, n = 123_456, 65_536 + 17
+    part = kernels.frames_llh_backward(kernels.sample_stats(X[lo:lo + n], cov), w1[lo:lo + n],
+                                       None, E)
+    assert torch.equal(part, a[lo:lo + n])                             # rows are independent
+    idx = torch.randint(0, T, (3000,), device=DEV)
+    ref = kernels.frames_llh_backward(kernels.sample_stats(X[idx].double(), cov), w1[idx].double(),
+                                      None, E.double())
+    assert float((a[idx].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
