@@ -52,9 +52,6 @@ using beer_mfma::f32x4;
 #ifndef BEER_SG_KPS
 #define BEER_SG_KPS 1                  // components per stage (one barrier per stage)
 #endif
-#ifndef BEER_SG_M32
-#define BEER_SG_M32 0                  // 1: sgrad32_kernel (v_mfma_f32_32x32x16_bf16) instead of sgrad_kernel
-#endif
 #ifndef BEER_SG_ABL
 #define BEER_SG_ABL 0    // timing experiments (wrong results), bits: 1 no barrier / re-staging after
 #endif                   // the first component, 2 B fragments read from LDS once per component
@@ -91,15 +88,9 @@ __global__ __launch_bounds__(256) void sgrad_image_kernel(int K, int D, const fl
             *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
             continue;
         }
-        const int q = ch % 3;
-        // 16x16x32 fragments: chunk (j, kb, q), lane (fi, fg): rows d' = 32 kb + 8 fg .., column
-        // d = 16 j + fi.  32x32x16 fragments (BEER_SG_M32): chunk (j32, kb16, q) with
-        // j32 = c / (2 NKB), kb16 = c % (2 NKB), lane (r = lane % 32, h = lane / 32): rows
-        // d' = 16 kb16 + 8 h .., column d = 32 j32 + r
-        const int c = ch / 3;
-        const int d = BEER_SG_M32 ? (c / (2 * NKB)) * 32 + (lane & 31) : (c / NKB) * 16 + (lane & 15);
-        const int dp0 = BEER_SG_M32 ? (c % (2 * NKB)) * 16 + (lane >> 5) * 8
-                                    : (c % NKB) * 32 + (lane >> 4) * 8;
+        const int q = ch % 3, kb = (ch / 3) % NKB, j = ch / (3 * NKB);
+        const int fi = lane & 15, fg = lane >> 4, d = j * 16 + fi;
+        const int dp0 = kb * 32 + fg * 8;
         unsigned w[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -268,145 +259,6 @@ __global__ __launch_bounds__(kSgWaves * 64) void sgrad_kernel(
                     if (d0 + e < D) out[t * D + d0 + e] = sc * acc[i][j][e];
             }
         }
-    }
-}
-
-// The same on v_mfma_f32_32x32x16_bf16 (BEER_SG_M32): a wave's 64 frames are two tiles of 32, a
-// component's B_k is NJ32 x (2 NKB) fragments of 32 dimensions x 16; a lane holds
-// y[dimension 32 j32 + 8 (e / 4) + 4 (lane / 32) + e % 4][frame lane % 32], e = 0 .. 15.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-template <int NKB>
-__global__ __launch_bounds__(kSgWaves * 64) void sgrad32_kernel(
-    int64_t T_, int D, int K, const float* __restrict__ X, const float* __restrict__ W,
-    const float* __restrict__ g, const char* __restrict__ img, float* __restrict__ out) {
-    constexpr int NJ = NKB, NK16 = 2 * NKB, NCH = sg_chunks(NKB), WM = 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 stages
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 31, fh = lane >> 5;
-    const int64_t t0 = (int64_t)blockIdx.x * (kSgWaves * 64) + wave * 64;
-    sgu4 zf[WM][NK16][3];
-    const float* wrow[WM];
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-        const int64_t t = t0 + i * 32 + fr;
-        const int64_t tc = t < T_ ? t : T_ - 1;
-        wrow[i] = W + tc * K;
-#pragma unroll
-        for (int kb = 0; kb < NK16; ++kb) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int dp = kb * 16 + fh * 8 + e;
-                v[e] = (t < T_ && dp < D) ? X[tc * D + dp] : 0.f;
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                unsigned pc[3];
-                beer_mfma::split3(v[2 * p], v[2 * p + 1], pc);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) zf[i][kb][q][p] = pc[q];
-            }
-        }
-    }
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    auto stage = [&](int k, int buf) {
-        const char* src = img + (size_t)k * (NCH * 1024) + lane * 16;
-        char* dst = smem + buf * (NCH * 1024);
-#pragma unroll
-        for (int c = 0; c < (NCH + kSgWaves - 1) / kSgWaves; ++c) {
-            const int ch = wave + c * kSgWaves;
-            if (ch < NCH)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const sgu4*>(src + ch * 1024),
-                                                 (lds_ptr)(dst + ch * 1024), 16, 0, 0);
-        }
-    };
-    auto load_w = [&](int k0, float (&dst)[WM][4]) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) dst[i][c] = k0 + c < K ? wrow[i][k0 + c] : 0.f;
-    };
-    f32x16 acc[WM][NJ];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    float wcur[WM][4], wnext[WM][4];
-    stage(0, 0);
-    load_w(0, wnext);
-    for (int k0 = 0; k0 < K; k0 += 4) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) wcur[i][c] = wnext[i][c];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int k = k0 + c;
-            if (k >= K) break;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (k + 1 < K) stage(k + 1, (k + 1) & 1);
-            if (c == 0) load_w(k0 + 4, wnext);
-            const char* buf = smem + (k & 1) * (NCH * 1024);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                // C = E1_k at the lane's 16 dimensions
-                f32x16 y[WM];
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(
-                        buf + (NCH - 1) * 1024 + (j * 32 + gq * 8 + fh * 4) * 4);
-#pragma unroll
-                    for (int i = 0; i < WM; ++i)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[i][gq * 4 + e] = c0[e];
-                }
-                constexpr int PZ[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-                for (int kb = 0; kb < NK16; ++kb) {
-                    sgu4 bfr[3];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        bfr[q] = *reinterpret_cast<const sgu4*>(
-                            buf + ((j * NK16 + kb) * 3 + q) * 1024 + lane * 16);
-#pragma unroll
-                    for (int pr = 0; pr < 6; ++pr)
-#pragma unroll
-                        for (int i = 0; i < WM; ++i)
-                            y[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(sgbf8, bfr[PB[pr]]),
-                                __builtin_bit_cast(sgbf8, zf[i][kb][PZ[pr]]), y[i], 0, 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        acc[i][j][e] = __builtin_fmaf(wcur[i][c], y[i][e], acc[i][j][e]);
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-        const int64_t t = t0 + i * 32 + fr;
-        if (t >= T_) continue;
-        const float sc = g ? g[t] : 1.f;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int d0 = j * 32 + gq * 8 + fh * 4;
-                if (d0 + 3 < D && (D & 3) == 0) {
-                    *reinterpret_cast<f32x4*>(out + t * D + d0) =
-                        f32x4{sc * acc[i][j][gq * 4], sc * acc[i][j][gq * 4 + 1],
-                              sc * acc[i][j][gq * 4 + 2], sc * acc[i][j][gq * 4 + 3]};
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (d0 + e < D) out[t * D + d0 + e] = sc * acc[i][j][gq * 4 + e];
-                }
-            }
     }
 }
 
@@ -666,16 +518,6 @@ int sgrad_fast_launch(int64_t T_, int D, int K, const float* X, const float* W, 
     BEER_LAUNCH_CHECK();
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sgrad_kernel<NKB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);
-    if (BEER_SG_M32) {
-        constexpr int frames = kSgWaves * 64;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sgrad32_kernel<NKB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);
-        hipLaunchKernelGGL(sgrad32_kernel<NKB>, dim3((unsigned)((T_ + frames - 1) / frames)),
-                           dim3(kSgWaves * 64), 2 * sg_chunks(NKB) * 1024, s, T_, D, K, X, W, g, img,
-                           out);
-        BEER_LAUNCH_CHECK();
-        return BEER_OK;
-    }
     hipLaunchKernelGGL(sgrad_kernel<NKB>, dim3((unsigned)((T_ + kSgFrames - 1) / kSgFrames)),
                        dim3(kSgWaves * 64), 2 * kSgKps * sg_chunks(NKB) * 1024, s, T_, D, K, X, W, g,
                        img, out);
