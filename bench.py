@@ -856,9 +856,15 @@ def run_vae(args, device, frames=1_000_000, steps=3, warmup=1):
         if 'tflops' in kern[dom]:
             # float32 [T, Q] products on the bf16 matrix pipes, three pieces per operand
             # (gemm3_kernel, csrc/dense.hip): priced like config 2 against the dense bf16 peak
+            # (HBM bytes per launch of the call's main kernel from the committed PMC passes of the
+            # prior path alone, profiles/r*_pmc.json keys c4_*; None for calls without one)
+            pmc_key = {'beer_frames_llh_backward': 'c4_sgrad_kernel',
+                       'beer_mixtureset_estep': 'c4_llhx_kernel',
+                       'beer_normal_accumulate_packed': 'c4_accx_kernel'}.get(dom)
             roof = {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'],
                     'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s',
-                    'frac': kern[dom]['tflops'] / PEAK_TFLOPS['bf16'], 'traffic': None,
+                    'frac': kern[dom]['tflops'] / PEAK_TFLOPS['bf16'],
+                    'traffic': pmc_traffic(pmc_key) if pmc_key and cov == 'full' else None,
                     'avg_launch_ms': kern[dom]['ms'],
                     'note': f'achieved = 2*T*Q*S algorithmic flop of one [T, Q={Qz}] x [Q, S={S}] '
                             'product (no symmetry discount) / HIP-event time; six bf16 MFMAs per '
