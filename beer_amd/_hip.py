@@ -60,7 +60,7 @@ def lib():
 # BEER_OPT_* of include/beer_hip.h and the environment variables that preset them
 OPTIONS = {'ax_max_frames': (0, 'BEER_AX_MAXFRAMES'), 'accf_rounds': (1, 'BEER_ACCF_ROUNDS'),
            'k1_wide': (2, 'BEER_K1_WIDE'), 'accfi_waves': (3, 'BEER_ACCFI_WAVES'),
-           'lnfi': (4, 'BEER_LNFI')}
+           'lnfi': (4, 'BEER_LNFI'), 'fb_log': (5, 'BEER_FB_LOG')}
 
 
 def _options_from_env(l):
@@ -192,6 +192,7 @@ SIGNATURES = {
     'beer_hmm_forward_backward': [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     'beer_hmm_posteriors_fused': [c_i, c_p, c_i, c_p, c_d, c_p, c_p, c_p, c_i, c_p, c_p, c_p,
                                   c_p],
+    'beer_hmm_fb_log_count': [c_p, c_p, c_p, c_p],
     'beer_hmm_viterbi': [c_i, c_p, c_p, c_p, c_p, c_i, c_p],
     'beer_hmm_trans_posteriors': [c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     'beer_hmm_path_posteriors': [c_i, c_p, c_p, c_p, c_p, c_p, c_p],

@@ -1335,9 +1335,11 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
     }
     // ---- forward ----
     T ll_next[SPL];
+    bool bad = false;                                     // a NaN log-likelihood (below)
 #pragma unroll
     for (int p = 0; p < SPL; ++p) {
         const double a = st[p] ? (double)load_ll(0, p) + (double)init[lane + 64 * p] : NINF;
+        bad |= a != a;
         lds(own[p]) = a;
         if (st[p]) alpha[a_off[p]] = a;
         ll_next[p] = load_ll(T_ > 1 ? 1 : 0, p);
@@ -1348,6 +1350,7 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
 #pragma unroll
         for (int p = 0; p < SPL; ++p) {
             ll[p] = ll_next[p];
+            bad |= ll[p] != ll[p];
             ll_next[p] = load_ll(t + 1 < T_ ? t + 1 : t, p);
         }
         double hub = NINF;
@@ -1370,6 +1373,36 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
             if (st[p]) alpha[t * S + a_off[p]] = a[p];
         }
         BEER_WAVE_ORDER();
+    }
+
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+        // A NaN log-likelihood anywhere in the utterance.  The reference adds it to EVERY
+        // entry of its dense transition matrix (NaN + -inf = NaN: graph.py:274-277,
+        // 283-286), so every forward value after the frame and every backward value before
+        // it is NaN: all state posteriors of the utterance are NaN, its transition
+        // posteriors 0 (NaN -> 0, graph.py:319-321), its log-normaliser NaN.  The sparse
+        // recursion would let the NaN travel along arcs only; say what the reference says.
+        const T nan_t = (T)__builtin_nan("");
+        for (int64_t t = 0; t < T_; ++t)
+#pragma unroll
+            for (int p = 0; p < SPL; ++p) {
+                if (!st[p]) continue;
+                if (FUSED) {
+                    T* dst = out + (f0 + t) * (int64_t)S_total + ll_off[p];
+                    if (atomic_out) atomicAdd(dst, nan_t);
+                    else *dst = nan_t;
+                } else {
+                    out[b.llh_off[u] + t * S + a_off[p]] = nan_t;
+                }
+            }
+#pragma unroll
+        for (int p = 0; p < SPL; ++p)
+            if (st[p] && gamma0_sum) atomicAdd(gamma0_sum + a_off[p], __builtin_nan(""));
+        if (lane == 0) {
+            if (lognorm_mean) lognorm_mean[u] = nan_t;
+            if (FUSED && utt_llh) atomicAdd(utt_llh + u, __builtin_nan(""));
+        }
+        return;
     }
 
     // ---- backward + posteriors ----
@@ -1731,6 +1764,29 @@ int scatter_launch(const beer_batch* b, int S_total, const void* pc, const void*
     return BEER_OK;
 }
 
+// The log-space flag of an utterance is the slot behind its hub values (hub_ws[first
+// frame + T - 1]; the recursions write slots 0 .. T-2 only).  BEER_OPT_FB_LOG sets it
+// for every utterance instead of running the linear-domain kernel;
+// beer_hmm_fb_log_count reads the flags back.
+__global__ void fb_flag_all_kernel(beer_batch b, double* __restrict__ hubf_ws) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= b.nutt) return;
+    const int64_t f1 = b.frame_off[u + 1];
+    if (f1 > b.frame_off[u]) hubf_ws[f1 - 1] = 1.0;
+}
+__global__ void fb_flag_count_kernel(beer_batch b, const double* __restrict__ hubf_ws,
+                                     int64_t* __restrict__ count) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    bool flagged = false;
+    if (u < b.nutt) {
+        const int64_t f1 = b.frame_off[u + 1];
+        flagged = f1 > b.frame_off[u] && hubf_ws[f1 - 1] != 0.0;
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(flagged);
+    if ((threadIdx.x & 63) == 0 && m)
+        atomicAdd(reinterpret_cast<unsigned long long*>(count), (unsigned long long)__builtin_popcountll(m));
+}
+
 // graphs the one-wave-per-utterance kernel takes: low-degree images with at most one
 // hub of at most 64 members a side, <= 4 states per lane (the host layer fills the
 // batch's max_degree / max_hubs / max_hub_members; 0 = unknown: not taken)
@@ -1750,12 +1806,18 @@ int wave_fb_launch(const beer_batch* b, const T* pc, int S_total, T scale, doubl
     const int spl = b->max_states <= 64 ? 1 : (b->max_states <= 128 ? 2 : 4);
     const int deg = b->max_degree <= 2 ? 2 : (b->max_degree <= 4 ? 4 : 8);
     const size_t lds = (size_t)kWvWaves * 2 * 64 * spl * sizeof(double);
+    const bool all_log = beer::option(BEER_OPT_FB_LOG) != 0;
     // the linear-domain kernel, then the log-space one for the utterances it flagged
 #define BEER_WV(SPL_, DEG_, XI_)                                                                \
     do {                                                                                        \
-        hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_>), grid, block, lds, s,   \
-                           *b, pc, S_total, scale, alpha_ws, hub_ws, out, resp_scale,          \
-                           atomic_out, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean);   \
+        if (all_log)                                                                            \
+            hipLaunchKernelGGL(fb_flag_all_kernel, dim3((unsigned)((b->nutt + 255) / 256)),     \
+                               dim3(256), 0, s, *b, hub_ws);                                    \
+        else                                                                                    \
+            hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_>), grid, block, lds,  \
+                               s, *b, pc, S_total, scale, alpha_ws, hub_ws, out, resp_scale,   \
+                               atomic_out, xi_sum, gamma0_sum, hub_flow, utt_llh,              \
+                               lognorm_mean);                                                   \
         hipLaunchKernelGGL((fb_wave_log_kernel<T, SPL_, DEG_, FUSED, XI_>), grid, block, lds,  \
                            s, *b, pc, S_total, scale, alpha_ws, hub_ws, out, resp_scale,       \
                            atomic_out, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean);   \
@@ -1880,6 +1942,18 @@ int beer_hmm_forward_backward(int dtype, const beer_batch* b, const void* pc_llh
         else BEER_FB(double, true, lds_big, grid);
     }
 #undef BEER_FB
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
+
+int beer_hmm_fb_log_count(const beer_batch* b, const double* hub_ws, int64_t* count,
+                          void* stream) {
+    BEER_REQUIRE(b && b->nutt >= 0 && count);
+    BEER_REQUIRE(wave_fb_ok(b));
+    if (b->nutt == 0) return BEER_OK;
+    BEER_REQUIRE(hub_ws);
+    hipLaunchKernelGGL(fb_flag_count_kernel, dim3((unsigned)((b->nutt + 255) / 256)), dim3(256),
+                       0, as_stream(stream), *b, hub_ws, count);
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }

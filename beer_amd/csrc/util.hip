@@ -15,6 +15,7 @@ constexpr OptSpec kOptSpec[BEER_OPT_COUNT] = {
     {0, 0, 1},                // BEER_OPT_K1_WIDE
     {4, 4, 8},                // BEER_OPT_ACCFI_WAVES (4 or 8)
     {1, 0, 1},                // BEER_OPT_LNFI
+    {0, 0, 1},                // BEER_OPT_FB_LOG
 };
 std::atomic<int> g_opt[BEER_OPT_COUNT] = {{kOptSpec[0].def}, {kOptSpec[1].def}, {kOptSpec[2].def},
                                           {kOptSpec[3].def}, {kOptSpec[4].def}};

@@ -2,6 +2,7 @@
 descriptors, pdf-id gather / scatter, forward-backward, Viterbi."""
 
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -10,7 +11,7 @@ from . import _hip
 
 __all__ = ['HmmBatch', 'gather', 'forward_backward', 'viterbi', 'path_posteriors',
            'scatter', 'gather_columns', 'scatter_columns', 'segment_sum', 'fused_ok',
-           'posteriors_fused', 'trans_posteriors_dense']
+           'posteriors_fused', 'trans_posteriors_dense', 'counting_log_space']
 
 
 class HmmBatch:
@@ -135,19 +136,10 @@ def forward_backward(batch, pc_llhs, want_xi=False, want_lognorm=False, dense_xi
     `hub_flow`; `dense_xi=True` forces the general kernel and a complete
     [S, S] matrix.'''
     dt, dev = batch.dtype, batch.device
-    if dense_xi and batch.struct.all_lowdeg:
-        # the general kernel: a complete [S, S] matrix, and log-space forward values in
-        # `alpha` (what `trans_posteriors_dense` reads; the one-wave kernel keeps scaled
-        # probabilities there)
-        batch.struct.all_lowdeg = 0
+    st = batch.struct
+    lowdeg_flag = st.all_lowdeg
     gamma = torch.empty(batch.n_elems, dtype=dt, device=dev)
     alpha = torch.empty(batch.n_elems, dtype=torch.float64, device=dev)
-    # hub values per frame, or -- graphs too dense for the arc lists to sit in LDS --
-    # the general kernel's per-arc scratch
-    n_ws = max(_hip.MAX_HUBS * batch.n_frames,
-               _hip.lib().beer_hmm_fb_scratch_doubles(_hip.dtype_code(dt), batch.ref(),
-                                                      int(want_xi)))
-    hub_ws = torch.empty(n_ws, dtype=torch.float64, device=dev)
     xi = g0 = ln = flow = None
     if want_xi:
         if not batch.shared_graph:
@@ -159,11 +151,25 @@ def forward_backward(batch, pc_llhs, want_xi=False, want_lognorm=False, dense_xi
     if want_lognorm:
         ln = torch.empty(batch.nutt, dtype=dt, device=dev)
     try:
+        if dense_xi:
+            # the general kernel: a complete [S, S] matrix, and log-space forward values in
+            # `alpha` (what `trans_posteriors_dense` reads; the one-wave kernel keeps scaled
+            # probabilities there).  The descriptor is shared with later calls on the same
+            # batch: the flag is put back below.
+            st.all_lowdeg = 0
+        # hub values per frame, or -- graphs too dense for the arc lists to sit in LDS --
+        # the general kernel's per-arc scratch
+        n_ws = max(_hip.MAX_HUBS * batch.n_frames,
+                   _hip.lib().beer_hmm_fb_scratch_doubles(_hip.dtype_code(dt), batch.ref(),
+                                                          int(want_xi)))
+        hub_ws = torch.empty(n_ws, dtype=torch.float64, device=dev)
+        # which kernel family the C entry point picks (wave_fb_ok of csrc/hmm.hip): the
+        # one-wave kernel leaves SCALED PROBABILITIES in `alpha`, the others logarithms
+        alpha_is_log = not fused_ok(batch)
         _hip.call('beer_hmm_forward_backward', _hip.dtype_code(dt), batch.ref(),
                   _hip.ptr(pc_llhs), _hip.ptr(alpha), _hip.ptr(hub_ws), _hip.ptr(gamma),
                   _hip.ptr(xi), _hip.ptr(g0), _hip.ptr(flow), _hip.ptr(ln))
     except _hip.HipError as err:
-        st = batch.struct
         if 'invalid argument' in str(err) and not st.all_lowdeg:
             raise _hip.HipError(
                 f'forward-backward: a graph of the batch has {st.max_states} states; the general '
@@ -171,7 +177,12 @@ def forward_backward(batch, pc_llhs, want_xi=False, want_lognorm=False, dense_xi
                 'Graphs with at most 8 arcs per state besides a declared hub '
                 '(CompiledGraph.set_hub) run at any size') from err
         raise
+    finally:
+        st.all_lowdeg = lowdeg_flag
     batch.last_alpha = alpha              # (for `trans_posteriors_dense`)
+    batch.last_alpha_is_log = alpha_is_log
+    if not alpha_is_log:
+        counting_log_space.note(batch, hub_ws)
     return gamma, xi, g0, ln, flow
 
 
@@ -181,6 +192,9 @@ def trans_posteriors_dense(batch, pc_llhs, gamma, trans_log_probs):
     reference's layout, graph.py:308-323.'''
     if batch.nutt != 1:
         raise ValueError('per-frame transition posteriors: one utterance at a time')
+    if not getattr(batch, 'last_alpha_is_log', False):
+        raise ValueError('per-frame transition posteriors read log-space forward values: run '
+                         'forward_backward(..., dense_xi=True) on this batch first')
     S, T = batch.n_states[0], batch.n_frames
     trans = _hip.on_device(trans_log_probs, batch.dtype)
     xi = torch.zeros(max(T - 1, 0), S, S, dtype=batch.dtype, device=batch.device)
@@ -188,6 +202,35 @@ def trans_posteriors_dense(batch, pc_llhs, gamma, trans_log_probs):
               _hip.ptr(batch.last_alpha), _hip.ptr(pc_llhs), _hip.ptr(gamma), _hip.ptr(trans),
               _hip.ptr(xi))
     return xi
+
+
+class counting_log_space:
+    '''Context manager (per host thread): while active, every one-wave forward-backward
+    launch adds the number of utterances it ran in LOG SPACE to `.count` (0-dim int64
+    device tensor; `beer_hmm_fb_log_count`).  The one-wave kernels work on scaled
+    probabilities and hand an utterance over to their log-space twin when a column or a
+    frame's normaliser leaves fp64's range or a log-likelihood is NaN (the reference is
+    log-space throughout, graph.py:270-326); `.launches` counts the launches seen.'''
+    _tls = threading.local()
+
+    def __enter__(self):
+        self.count = torch.zeros((), dtype=torch.int64, device=_hip.require_device())
+        self.launches = 0
+        self._outer = getattr(self._tls, 'active', None)
+        self._tls.active = self
+        return self
+
+    def __exit__(self, *exc):
+        self._tls.active = self._outer
+        return False
+
+    @classmethod
+    def note(cls, batch, hub_ws):
+        self = getattr(cls._tls, 'active', None)
+        if self is not None and fused_ok(batch):
+            _hip.call('beer_hmm_fb_log_count', batch.ref(), _hip.ptr(hub_ws),
+                      _hip.ptr(self.count))
+            self.launches += 1
 
 
 FUSED_MAX_STATES = 256      # kWvMaxStates of csrc/hmm.hip
@@ -226,6 +269,7 @@ def posteriors_fused(batch, pc_all, scale=1., want_counts=False, utt_llh=None):
     _hip.call('beer_hmm_posteriors_fused', _hip.dtype_code(dt), batch.ref(), S_total,
               _hip.ptr(pc_all), float(scale), _hip.ptr(alpha), _hip.ptr(hub_ws), _hip.ptr(sr),
               1 if repeats else 0, _hip.ptr(g0), _hip.ptr(flow), _hip.ptr(utt_llh))
+    counting_log_space.note(batch, hub_ws)
     return sr, g0, flow
 
 

@@ -14,8 +14,11 @@ optimizer states carry).
 
 import os
 import pickle
+import warnings
 
 import torch
+
+from .. import _hip
 
 __all__ = ['VBConjugateOptimizer', 'VBOptimizer']
 
@@ -25,13 +28,18 @@ _STATE = ('lrate', 'update_count')
 class VBConjugateOptimizer:
     'Round-robin coordinate ascent over mean-field groups of conjugate parameters.'
 
+    _warned = False                               # (one warning per process about a refused capture)
+
     def __init__(self, groups, lrate=1., graph=None):
         # a model may hand its groups over as generators: materialise them once
         self.groups = [list(members) for members in groups]
         self.lrate, self.update_count = lrate, 0
-        # graph=True (or BEER_MSTEP_GRAPH=1): the update of a group is captured once as a
-        # HIP graph and replayed -- one launch instead of ~20 per parameter
-        self.graph = (os.environ.get('BEER_MSTEP_GRAPH') == '1') if graph is None else bool(graph)
+        # The update of a group is captured once as a HIP graph and replayed -- one launch
+        # instead of ~20 per parameter -- whenever the group can be captured (device tensors,
+        # device-only callbacks: `_capturable`); other groups, and every group with
+        # graph=False or BEER_MSTEP_GRAPH=0, take the eager update.
+        self.graph = (os.environ.get('BEER_MSTEP_GRAPH', '1') != '0') if graph is None \
+            else bool(graph)
         self._captured = {}
 
     def __getstate__(self):
@@ -116,19 +124,29 @@ class VBConjugateOptimizer:
                     for p, st, eta in zip(members, statics, etas):
                         p.stats = st
                         eta.copy_(p.natural_grad_update(self.lrate, eta_q=eta))
-            except Exception:
-                # a step of this family cannot be captured (or the runtime refused the
-                # capture, e.g. next to a collective's watchdog): nothing ran on the device
-                # -- a capture records, it does not execute --, so the eager update below
-                # starts from the same posterior; only the host-side memos the recording
-                # wrote have to go
-                self._captured[key] = False
+            except RuntimeError as err:
+                # Only a REFUSED capture is answered by the eager update: torch's own
+                # RuntimeError (an operation that cannot be recorded, a capture next to a
+                # collective's watchdog), BEER_EINVAL (`HipInvalid`) or one of HIP's
+                # stream-capture status codes (900 .. 908) out of the library.  Anything else
+                # from the library is a launch error and propagates (`_hip.HipError`).
+                refused = not isinstance(err, _hip.HipError) or isinstance(err, _hip.HipInvalid) \
+                    or 900 <= -(err.rc or 0) <= 908
+                # Nothing ran on the device -- a capture records, it does not execute --, so
+                # the eager update starts from the same posterior; the host-side memos the
+                # recording wrote have to go.
                 for p, st in zip(members, statics):
                     p.stats = st
                     p.posterior.__dict__.pop('_memo', None)
                     p.__dict__.pop('_kl_memo', None)
-                if os.environ.get('BEER_MSTEP_GRAPH_STRICT') == '1':
+                if not refused or os.environ.get('BEER_MSTEP_GRAPH_STRICT') == '1':
                     raise
+                self._captured[key] = False
+                if not VBConjugateOptimizer._warned:
+                    VBConjugateOptimizer._warned = True
+                    warnings.warn(f'VBConjugateOptimizer: the M-step of group {key} could not be '
+                                  f'captured as a HIP graph ({type(err).__name__}: {err}); this '
+                                  'group takes the eager update from here on', RuntimeWarning)
                 return False
             memos = [dict(p.posterior.__dict__.get('_memo', {})) for p in members]
             entry = self._captured[key] = (graph, statics, etas, memos, self.lrate,

@@ -112,8 +112,10 @@ class HMM(DiscreteLatentModel):
             gamma, xi, g0 = hk.path_posteriors(batch, path, want_xi=trans_posts)
         else:
             per_frame = trans_posts and reference_layout_enabled() and utt_lengths is None
+            # (per frame: the general kernel -- log-space forward values, hub arcs in the matrix)
             gamma, xi, g0, _, flow = hk.forward_backward(batch, pc_llhs,
-                                                         want_xi=trans_posts and not per_frame)
+                                                         want_xi=trans_posts and not per_frame,
+                                                         dense_xi=per_frame)
             if per_frame:
                 # the reference's [T-1, S, S] tensor, hub arcs included: no separate flows
                 xi = hk.trans_posteriors_dense(batch, pc_llhs, gamma, graph.trans_log_probs)

@@ -70,7 +70,12 @@ int beer_hip_device_count(void);
 #define BEER_OPT_LNFI 4          /* 1: beer_mixtureset_lognorm_image keeps a chunk's packed
                                   * parameters in LDS and walks blocks of frames (lnfi_kernel);
                                   * 0: one tile per wave, parameters streamed from L2.  Default 1. */
-#define BEER_OPT_COUNT 5
+#define BEER_OPT_FB_LOG 5        /* 1: the one-wave-per-utterance forward-backward runs EVERY
+                                  * utterance in log space (the kernel that otherwise only
+                                  * redoes utterances whose dynamic range exceeds the
+                                  * scaled-probability recursion; beer/graph.py:270-326 is
+                                  * log-space throughout).  Default 0. */
+#define BEER_OPT_COUNT 6
 int beer_hip_set_option(int option, int value);
 int beer_hip_get_option(int option);   /* the value, or BEER_EINVAL for an unknown option */
 
@@ -517,6 +522,16 @@ int beer_hmm_forward_backward(int dtype, const beer_batch* batch_h,
                               const void* pc_llhs, double* alpha_ws, double* hub_ws,
                               void* gamma, double* xi_sum, double* gamma0_sum,
                               double* hub_flow, void* lognorm_mean, void* stream);
+/* How many utterances of the batch the last beer_hmm_forward_backward /
+ * beer_hmm_posteriors_fused call on `hub_ws` ran in LOG SPACE (no reference counterpart:
+ * beer/graph.py:270-326 is log-space throughout; the one-wave kernels run on scaled
+ * probabilities and hand an utterance over to their log-space twin when a column or a
+ * frame's normaliser falls below 2^-800 of its scale, or a log-likelihood is NaN).
+ * `count` (device, int64) += that number.  EINVAL unless the batch is of the kind the
+ * one-wave kernels take (other kernels are log-space: nothing to count). */
+int beer_hmm_fb_log_count(const beer_batch* batch_h, const double* hub_ws, int64_t* count,
+                          void* stream);
+
 /* Doubles `hub_ws` of beer_hmm_forward_backward must hold BESIDES the hub values
  * (BEER_MAX_HUBS per frame) for this batch: 0 while the arc lists of its largest
  * graph fit a CU's LDS (about 4000 arcs with transition posteriors in float32);

@@ -21,6 +21,8 @@ import zipfile
 
 import numpy as np
 
+sys.dont_write_bytecode = True     # (the reference tree is read-only: no __pycache__ into it)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 from workflow_conf import (EPOCHS, FEA_CONF, HMM_CONF, PHONES, SEED, UNITS,   # noqa: E402
@@ -30,7 +32,8 @@ REF = [sys.executable, os.path.join(HERE, 'run_reference_cli.py')]
 
 
 def ref(args, stdin=None, cwd=None):
-    p = subprocess.run(REF + args, input=stdin, capture_output=True, text=True, cwd=cwd)
+    p = subprocess.run(REF + args, input=stdin, capture_output=True, text=True, cwd=cwd,
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
     if p.returncode != 0:
         raise RuntimeError(f'reference beer {args}: {p.stderr[-2000:]}')
     return p.stdout

@@ -1,0 +1,401 @@
+"""The forward-backward pass outside the comfortable range.
+
+The one-wave kernels of csrc/hmm.hip run on SCALED PROBABILITIES (fp64) and hand an
+utterance over to their log-space twin (`fb_wave_log_kernel`) when a column or a frame's
+normaliser falls below 2^-800 of its scale or a log-likelihood is NaN; the reference is
+log-space throughout (beer/graph.py:270-326, NaN -> 0 at 319-321).  Every case here forces
+that hand-over -- asserted through `beer_hmm_fb_log_count` -- and holds the result against
+the numpy oracle (oracle/beer_oracle.py: `posteriors`, `hmm_estep`, `vae_hmm_prior`)."""
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, assert_stats_close, load_golden, orc
+
+pytestmark = pytest.mark.gpu
+
+import beer_amd as beer                                             # noqa: E402
+from beer_amd import _hip, hmm_kernels as hk                        # noqa: E402
+from gpu_helpers import DEV, build_hmm, npy, tt                     # noqa: E402
+
+
+def _strict_chain(n_states, rng, dtype):
+    'Left-to-right alignment chain: self-loop + next state only (what mkaligraph builds).'
+    trans = np.full((n_states, n_states), -np.inf)
+    for i in range(n_states):
+        if i + 1 < n_states:
+            p = rng.uniform(.3, .8)
+            trans[i, i], trans[i, i + 1] = np.log(p), np.log(1 - p)
+        else:
+            trans[i, i] = np.log(.6)                   # (the rest of the mass leaves the graph)
+    init = np.full(n_states, -np.inf)
+    init[0] = 0.
+    final = np.full(n_states, -np.inf)
+    final[-1] = np.log(.4)
+    return init.astype(dtype), final.astype(dtype), trans.astype(dtype)
+
+
+def _two_branches(dtype, n=5):
+    '''start state 0 -> branch A (states 1..n) or branch B (n+1..2n) -> end state 2n+1; no
+    way across: evidence early for A and late for B must be weighed over the whole utterance.'''
+    S = 2 * n + 2
+    trans = np.full((S, S), -np.inf)
+    trans[0, 0], trans[0, 1], trans[0, n + 1] = np.log([.5, .25, .25])
+    for base in (1, n + 1):
+        for k in range(n):
+            i = base + k
+            nxt = i + 1 if k + 1 < n else S - 1
+            trans[i, i], trans[i, nxt] = np.log([.7, .3])
+    trans[S - 1, S - 1] = np.log(.5)
+    init = np.full(S, -np.inf)
+    init[0] = 0.
+    final = np.full(S, -np.inf)
+    final[S - 1] = np.log(.5)
+    return init.astype(dtype), final.astype(dtype), trans.astype(dtype)
+
+
+def _run(graph_arrays, llhs_list, dtype, want_xi=True):
+    'forward_backward of a ragged batch on ONE graph: (gammas, xi_sum, gamma0, lognorms, #log-space).'
+    init, final, trans = graph_arrays
+    S = len(init)
+    graph = beer.graph.CompiledGraph(tt(init), tt(final), tt(trans), list(range(S)))
+    lens = [len(l) for l in llhs_list]
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    batch = hk.HmmBatch([graph], [0] * len(lens), lens, tdt)
+    assert hk.fused_ok(batch), 'these graphs must take the one-wave kernels'
+    flat = torch.cat([tt(l.astype(dtype)).reshape(-1) for l in llhs_list])
+    with hk.counting_log_space() as c:
+        g, x, g0, ln, flow = hk.forward_backward(batch, flat, want_xi=want_xi, want_lognorm=True)
+    assert c.launches == 1
+    g = npy(g)
+    off = np.concatenate([[0], np.cumsum([n * S for n in lens])])
+    gammas = [g[off[i]:off[i + 1]].reshape(lens[i], S) for i in range(len(lens))]
+    return gammas, (npy(x) if want_xi else None), (npy(g0) if want_xi else None), npy(ln), int(c.count)
+
+
+def _oracle(graph_arrays, llhs, dtype=np.float64):
+    init, final, trans = [a.astype(dtype) for a in graph_arrays]
+    with np.errstate(invalid='ignore', divide='ignore'):
+        return orc.posteriors(llhs.astype(dtype), init, final, trans, True)
+
+
+def _band(got, truth, f32_ref, what, floor=1e-5):
+    'fp32: inside the error of the oracle\'s own float32 run (the reference\'s op sequence) or 1e-5.'
+    scale = max(np.abs(truth).max(), 1e-300)
+    err = np.abs(np.asarray(got, dtype=np.float64) - truth).max() / scale
+    ref = np.abs(np.asarray(f32_ref, dtype=np.float64) - truth).max() / scale
+    assert err <= max(floor, 1.5 * ref), f'{what}: rel err {err:.3e} > band {max(floor, 1.5 * ref):.3e}'
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_alignment_pins_states_1500_nats_below_the_frames_best(dtype):
+    '''(a) A strict alignment chain leaves, at frame t, only a band of states reachable; for
+    a few frames those states sit 1500 nats below unreachable ones.  exp(-1500) is 0 in
+    fp64: the scaled column vanishes, the utterance must be redone in log space.'''
+    rng = np.random.RandomState(3)
+    S, T = 30, 45
+    graph = _strict_chain(S, rng, np.float64)
+    llhs = rng.randn(T, S) * 3
+    for t in (10, 11, 12, 30):
+        lo, hi = max(0, S - T + t), min(S - 1, t)
+        llhs[t, lo:hi + 1] -= 1500.
+    llhs = llhs.astype(dtype).astype(np.float64)         # (the same numbers for both runs)
+    calm = rng.randn(T + 7, S) * 3                       # a neighbour that stays linear
+    gam, xi, lnm = _oracle(graph, llhs)
+    gam_c, xi_c, _ = _oracle(graph, calm.astype(dtype).astype(np.float64))
+    gammas, x, g0, ln, count = _run(graph, [llhs, calm], dtype)
+    assert count == 1, f'{count} utterances in log space, expected exactly the pinned one'
+    if dtype == np.float64:
+        assert_close(gammas[0], gam, 1e-9, 'gamma (log space)')
+        assert_close(gammas[1], gam_c, 1e-9, 'gamma (linear neighbour)')
+        assert_close(x, xi.sum(0) + xi_c.sum(0), 1e-9, 'sum xi, each utterance once')
+        assert_close(g0, gam[0] + gam_c[0], 1e-9, 'gamma_0 sum')
+        assert_close(float(ln[0]), lnm, 1e-11, 'lognorm mean')
+    else:
+        g32, x32, _ = _oracle(graph, llhs, np.float32)
+        gc32, xc32, _ = _oracle(graph, calm.astype(np.float32), np.float32)
+        _band(gammas[0], gam, g32, 'gamma (log space, fp32)')
+        _band(gammas[1], gam_c, gc32, 'gamma (linear neighbour, fp32)')
+        _band(x, xi.sum(0) + xi_c.sum(0), x32.sum(0) + xc32.sum(0), 'sum xi (fp32)')
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_evidence_before_and_after_a_frame_contradicting_by_more_than_800_binades(dtype):
+    '''(b) Two branches without a way across.  The first half of the utterance favours branch
+    A by 900 nats in total, the second half branch B by 1800: at the frames in between the
+    forward column holds B at e^-900 of A (0 in a scaled fp64 column) and the backward
+    column A at e^-1800 of B -- the posterior belongs to B, and only log space sees it.'''
+    S_branch = 5
+    graph = _two_branches(np.float64, S_branch)
+    S = len(graph[0])
+    T = 64
+    rng = np.random.RandomState(5)
+    llhs = rng.randn(T, S)
+    A, B = slice(1, 1 + S_branch), slice(1 + S_branch, 1 + 2 * S_branch)
+    llhs[4:24, A] += 45.                                 # 20 frames x 45 = 900 nats for A
+    llhs[30:50, B] += 90.                                # 20 frames x 90 = 1800 nats for B
+    llhs = llhs.astype(dtype).astype(np.float64)
+    gam, xi, lnm = _oracle(graph, llhs)
+    assert gam[26, B].sum() > 1 - 1e-12                  # the oracle: branch B holds frame 26
+    gammas, x, g0, ln, count = _run(graph, [llhs], dtype)
+    assert count == 1
+    if dtype == np.float64:
+        assert_close(gammas[0], gam, 1e-9, 'gamma')
+        assert_close(x, xi.sum(0), 1e-9, 'sum xi')
+        assert_close(float(ln[0]), lnm, 1e-11, 'lognorm mean')
+    else:
+        g32, x32, _ = _oracle(graph, llhs, np.float32)
+        _band(gammas[0], gam, g32, 'gamma (fp32)')
+        _band(x, xi.sum(0), x32.sum(0), 'sum xi (fp32)')
+    # the same utterance with the contradiction inside fp64's reach stays linear
+    mild = rng.randn(T, S)
+    mild[4:24, A] += 10.
+    mild[30:50, B] += 20.
+    gm, xm, _ = _oracle(graph, mild.astype(dtype).astype(np.float64))
+    gammas, x, _, _, count = _run(graph, [mild], dtype)
+    assert count == 0
+    assert_close(gammas[0], gm, 1e-9 if dtype == np.float64 else 1e-5, 'gamma (200 / 400 nats: linear)')
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_a_nan_log_likelihood_in_one_utterance_of_a_ragged_batch(dtype):
+    '''(c) The reference adds a NaN log-likelihood to every entry of its dense transition
+    matrix: all state posteriors of THAT utterance are NaN, its transition posteriors 0
+    (NaN -> 0, graph.py:319-321), its log-normaliser NaN; the other utterances of the
+    batch do not see it.'''
+    rng = np.random.RandomState(9)
+    S = 12
+    graph = _strict_chain(S, rng, np.float64)
+    utts = [rng.randn(T, S) * 2 for T in (20, 33, 27, 64)]
+    utts = [u.astype(dtype).astype(np.float64) for u in utts]
+    utts[1][7, 3] = np.nan
+    utts[3][63, S - 1] = np.nan                          # (last frame, last state)
+    truth = [_oracle(graph, u) for u in utts]
+    assert np.isnan(truth[1][0]).all() and truth[1][1].sum() == 0. and np.isnan(truth[1][2])
+    gammas, x, g0, ln, count = _run(graph, utts, dtype)
+    assert count == 2
+    tol = 1e-9 if dtype == np.float64 else 1e-5
+    for i in (0, 2):
+        assert_close(gammas[i], truth[i][0], tol, f'gamma of neighbour {i}')
+        assert_close(float(ln[i]), truth[i][2], tol, f'lognorm of neighbour {i}')
+    for i in (1, 3):
+        assert np.isnan(gammas[i]).all(), 'every posterior of the utterance is NaN (reference)'
+        assert np.isnan(ln[i])
+    assert_close(x, truth[0][1].sum(0) + truth[2][1].sum(0), tol, 'sum xi: the NaN utterances add 0')
+    assert np.isnan(g0).all()                            # gamma_0 of a NaN utterance is NaN
+
+
+def _extreme_phone_loop_corpus(ploop, rng, nutt, P, G, D, npdt, far):
+    ns = ploop.modelset.original_modelset.modelsets[0].modelset
+    mu = npy(ns.means_precisions.posterior.params.mean).astype(np.float64)
+    utts, kinds = [], []
+    for i in range(nutt):
+        T = int(rng.randint(60, 110))
+        seq = np.repeat(rng.randint(0, P, T // 20 + 1), 20)[:T]
+        comp = G * (3 * seq + rng.randint(0, 3, T)) + rng.randint(0, G, T)
+        x = mu[comp] + rng.randn(T, D) * 1.2
+        extreme = i % 3 == 1
+        if extreme:
+            x = x * far                                   # far from every Gaussian: log-likelihoods
+        utts.append(x.astype(npdt))                       # thousands of nats apart between states
+        kinds.append(extreme)
+    return utts, kinds
+
+
+@pytest.mark.parametrize('cov', ['diagonal', 'full'])
+def test_mixed_batch_statistics_counts_and_xi_added_exactly_once(cov):
+    '''(d) A phone-loop shard (fp64) in which every third utterance lies 25x farther out than
+    the model's Gaussians: those utterances are redone in log space, the others are not,
+    and the shard's ELBO, Gaussian statistics, mixture-weight statistics and phone counts
+    (first-frame posteriors + hub flows) equal the oracle's per-utterance sums -- every
+    utterance added exactly once.'''
+    from test_gpu_parity import _oracle_phone_loop_shard, _phone_loop
+    P, G, D = 6, 4, 10
+    ploop = _phone_loop(P, G, D, cov, torch.float64, seed=17)
+    rng = np.random.RandomState(23)
+    utts, kinds = _extreme_phone_loop_corpus(ploop, rng, 9, P, G, D, np.float64, far=25.)
+    N = 50_000
+    with np.errstate(invalid='ignore', divide='ignore', over='ignore'):
+        value, acc_n, acc_w, counts = _oracle_phone_loop_shard(ploop, utts, N)
+    with hk.counting_log_space() as c:
+        elbo = beer.accumulate_elbo(ploop, [tt(x) for x in utts], datasize=N)
+    n_log = int(c.count)
+    assert c.launches >= 1
+    assert 0 < n_log < len(utts), f'{n_log} of {len(utts)} utterances in log space: not a mixed batch'
+    assert n_log >= sum(kinds) - 1
+    assert_close(float(elbo), value, 1e-8, 'elbo')
+    ms = ploop.modelset.original_modelset.modelsets[0]
+    assert_stats_close(npy(elbo._acc_stats[ms.modelset.means_precisions]), acc_n, D, 1e-7, 'acc normal')
+    assert_close(npy(elbo._acc_stats[ms.categoricalset.weights]), acc_w, 1e-7, 'acc weights')
+    assert_close(npy(elbo._acc_stats[ploop.categorical.weights]), counts, 1e-7, 'phone counts')
+    # the same shard, every utterance in log space (BEER_OPT_FB_LOG): the same numbers
+    old = _hip.set_option('fb_log', 1)
+    try:
+        with hk.counting_log_space() as c2:
+            elbo2 = beer.accumulate_elbo(ploop, [tt(x) for x in utts], datasize=N)
+        assert int(c2.count) == len(utts)
+    finally:
+        _hip.set_option('fb_log', old)
+    assert_close(float(elbo2), value, 1e-8, 'elbo, all in log space')
+    assert_close(npy(elbo2._acc_stats[ploop.categorical.weights]), counts, 1e-7, 'phone counts')
+
+
+def test_mixed_batch_with_alignment_graphs_and_repeated_pdf_ids():
+    '''(d') Per-utterance alignment graphs (`inference_graph`; pdf ids repeat when a phone
+    occurs twice: the posteriors go back by atomic adds, and the log-space kernel first
+    clears what the linear one had added for the utterance) with far-out utterances in
+    between: shard statistics against the oracle's per-utterance loop.'''
+    from test_gpu_parity import _oracle_groups, _phone_loop
+    P, G, D = 5, 4, 8
+    ploop = _phone_loop(P, G, D, 'diagonal', torch.float64, seed=4)
+    rng = np.random.RandomState(31)
+    utts, kinds = _extreme_phone_loop_corpus(ploop, rng, 6, P, G, D, np.float64, far=30.)
+    # alignment graph of utterance i: phones p, q, p (a repeated phone: repeated pdf ids)
+    alis, graphs = [], []
+    for i in range(len(utts)):
+        p, q = int(rng.randint(0, P)), int(rng.randint(0, P))
+        phones = [p, q, p]
+        order = [3 * ph + k for ph in phones for k in range(3)]
+        S = len(order)
+        init, final, trans = _strict_chain(S, rng, np.float64)
+        graphs.append(dict(init=init, final=final, trans=trans, order=np.asarray(order)))
+        alis.append(beer.graph.CompiledGraph(tt(init), tt(final), tt(trans), order))
+    N = 10_000
+    groups = _oracle_groups(ploop)
+    cat = ploop.categorical.weights
+    extra_kl = orc.dir_kl(npy(cat.posterior.params.concentrations).astype(np.float64),
+                          npy(cat.prior.params.concentrations).astype(np.float64)).sum()
+    value, acc_n, acc_w = 0., 0., 0.
+    with np.errstate(invalid='ignore', divide='ignore', over='ignore'):
+        for x, g in zip(utts, graphs):
+            r = orc.hmm_elbo_step(x, groups, g, datasize=N, extra_kl=extra_kl)
+            value += r['value']
+            acc_n, acc_w = acc_n + r['acc'][0][0], acc_w + r['acc'][0][1]
+    with hk.counting_log_space() as c:
+        elbo = beer.accumulate_elbo(ploop, [tt(x) for x in utts], datasize=N,
+                                    inference_graphs=alis)
+    assert 0 < int(c.count) < len(utts)
+    assert_close(float(elbo), value, 1e-8, 'elbo')
+    ms = ploop.modelset.original_modelset.modelsets[0]
+    assert_stats_close(npy(elbo._acc_stats[ms.modelset.means_precisions]), acc_n, D, 1e-7, 'acc normal')
+    assert_close(npy(elbo._acc_stats[ms.categoricalset.weights]), acc_w, 1e-7, 'acc weights')
+
+
+@pytest.mark.parametrize('cov', ['diagonal', 'full'])
+def test_vae_prior_launch_with_far_out_samples(cov):
+    '''(e) The fused launch of a VAE's HMM prior (gather + forward-backward + scatter of a
+    ragged minibatch, one sample per frame) with some utterances' samples 30x farther out
+    than the prior's Gaussians: per-frame value, scattered state posteriors and the
+    gradient w.r.t. the samples against `orc.vae_hmm_prior` / `prior_gradient_wrt_samples`
+    per utterance (vae.py:63-86, hmm.py:73-92).'''
+    from beer_amd import kernels
+    torch.manual_seed(8)
+    rng = np.random.RandomState(8)
+    D, S = 12, 9
+    graph = beer.graph.Graph()
+    s0, s1 = graph.add_state(), graph.add_state()
+    graph.start_state, graph.end_state = s0, s1
+    st = [graph.add_state(pdf_id=i) for i in range(S)]
+    graph.add_arc(s0, st[0])
+    for i, s in enumerate(st):
+        graph.add_arc(s, s)
+        graph.add_arc(s, st[(i + 1) % S])
+    graph.add_arc(st[-1], s1)
+    graph.normalize()
+    cg = graph.compile()
+    ns = beer.NormalSet.create(torch.zeros(D, dtype=torch.float64), torch.ones(D, dtype=torch.float64),
+                               size=S, cov_type=cov, noise_std=1.)
+    prior = beer.HMM.create(cg, ns).to(DEV)
+    lengths = [40, 55, 31, 62, 48]
+    far = [False, True, False, True, False]
+    Z = np.concatenate([rng.randn(T, D) * (30. if f else 1.2) for T, f in zip(lengths, far)])
+    c_up = rng.rand(len(Z)) + .5
+    p0 = list(prior.bayesian_parameters())[0]
+    post = [npy(getattr(p0.posterior.params, n)).astype(np.float64) for n in p0.posterior._std_params_def]
+    og = dict(init=npy(cg.init_log_probs).astype(np.float64), final=npy(cg.final_log_probs).astype(np.float64),
+              trans=npy(cg.trans_log_probs).astype(np.float64), order=np.asarray(cg.pdf_id_mapping))
+    vals, resps, off = [], [], 0
+    with np.errstate(invalid='ignore', divide='ignore', over='ignore'):
+        for T in lengths:
+            v, r, exp_T = orc.vae_hmm_prior(cov, Z[off:off + T], post, og)
+            vals.append(v)
+            resps.append(r)
+            off += T
+    value, resps = np.concatenate(vals), np.concatenate(resps)
+    grad = orc.prior_gradient_wrt_samples(cov, Z, resps, exp_T, c_up)
+    z = tt(Z).requires_grad_(True)
+    stats = kernels.sample_stats(z, cov)
+    with hk.counting_log_space() as c:
+        got = prior.expected_log_likelihood(stats, utt_lengths=lengths)
+    assert c.launches == 1 and 0 < int(c.count) < len(lengths)
+    assert_close(npy(got), value, 1e-9, 'per-frame value')
+    assert_close(npy(prior.cache['scaled_pdf_resps']), resps, 1e-9, 'state posteriors at the pdf ids')
+    (tt(c_up) * got).sum().backward()
+    assert_close(npy(z.grad), grad, 1e-9, 'd/dz')
+
+
+@pytest.mark.parametrize('cov', ['full', 'diagonal', 'isotropic'])
+def test_goldens_with_every_utterance_in_log_space(cov):
+    '''The reference's own G4 numbers (gamma, sum_t xi, log-normaliser: graph.py:289-326)
+    from the log-space twin alone (BEER_OPT_FB_LOG = 1), and from the default pair of
+    kernels: both are the reference's result.'''
+    g = load_golden(f'g04_hmm_{cov}')
+    hmm = build_hmm(g)
+    for force in (0, 1):
+        old = _hip.set_option('fb_log', force)
+        try:
+            with hk.counting_log_space() as c:
+                (gamma, xi_sum), lognorm = hmm.graph.posteriors(tt(g['pc_llhs']), trans_posteriors=True)
+                pc = tt(g['pc_llhs'])
+                batch = hk.HmmBatch([hmm.graph], [0], [len(pc)], pc.dtype)
+                gam2, xi2, _, ln2, _ = hk.forward_backward(batch, pc.reshape(-1), want_xi=True,
+                                                           want_lognorm=True)
+        finally:
+            _hip.set_option('fb_log', old)
+        assert int(c.count) == (c.launches if force else 0)
+        assert_close(npy(gamma), g['gamma'], 1e-9, 'gamma (general kernel)')
+        assert_close(npy(gam2).reshape(g['gamma'].shape), g['gamma'], 1e-9, f'gamma, fb_log={force}')
+        assert_close(npy(xi2), g['xi_sum'], 1e-9, f'xi_sum, fb_log={force}')
+        assert_close(float(ln2[0]), g['lognorm_mean'], 1e-10, f'lognorm, fb_log={force}')
+
+
+@pytest.mark.parametrize('kind', ['dirichlet', 'dirichlet_process'])
+def test_phone_loop_golden_with_every_utterance_in_log_space(kind):
+    'G5 (phone loop: hub flows, phone counts, weight update) with the log-space twin alone.'
+    import test_gpu_parity as tp
+    old = _hip.set_option('fb_log', 1)
+    try:
+        with hk.counting_log_space() as c:
+            tp.test_g5_phoneloop(kind)
+        assert c.launches >= 1 and int(c.count) >= c.launches
+    finally:
+        _hip.set_option('fb_log', old)
+
+
+@pytest.mark.parametrize('cov', ['full', 'diagonal'])
+def test_per_frame_transition_posteriors_through_the_model_protocol(cov):
+    '''`reference_layout()`: `hmm.cache['trans_resps']` after `evidence_lower_bound` is the
+    reference's [T-1, S, S] tensor (hmm.py:60-62, graph.py:308-323) -- held against the
+    golden's first three frames and its sum over time (the per-frame branch
+    read scaled probabilities as logarithms).'''
+    g = load_golden(f'g04_hmm_{cov}')
+    hmm = build_hmm(g)
+    X = tt(g['X'])
+    with beer.reference_layout():
+        beer.evidence_lower_bound(hmm, X)
+        xi = hmm.cache['trans_resps']
+    T, S = g['gamma'].shape
+    assert tuple(xi.shape) == (T - 1, S, S)
+    assert_close(npy(xi[:3]), g['xi_first'], 1e-9, 'xi[:3]')
+    assert_close(npy(xi.sum(0)), g['xi_sum'], 1e-9, 'sum_t xi')
+    assert_close(npy(hmm.cache['resps']), g['gamma'], 1e-9, 'gamma')
+    # a batch that ran the one-wave kernel refuses to hand its scaled columns over as logs
+    pc = tt(g['pc_llhs'])
+    batch = hk.HmmBatch([hmm.graph], [0], [T], pc.dtype)
+    gamma = hk.forward_backward(batch, pc.reshape(-1))[0]
+    with pytest.raises(ValueError):
+        hk.trans_posteriors_dense(batch, pc.reshape(-1), gamma, hmm.graph.trans_log_probs)
+    assert batch.struct.all_lowdeg == 1
+    hk.forward_backward(batch, pc.reshape(-1), dense_xi=True)
+    assert batch.struct.all_lowdeg == 1                  # (the shared descriptor is put back)

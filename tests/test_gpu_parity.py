@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from helpers import (COV_OF, assert_close, assert_stats_close, assert_within_f32_band, dist_cls,
-                     load_golden, orc, std_params)
+                     load_golden, orc, stat_blocks, std_params)
 
 pytestmark = pytest.mark.gpu
 
@@ -1052,8 +1052,12 @@ def test_m_step_in_one_launch():
     ref = NormalWishart.from_std_parameters(*[t.clone() for t in post._tensors()])
     torch.testing.assert_close(E, ref.expected_sufficient_statistics(), rtol=2e-6, atol=1e-5)
     torch.testing.assert_close(post.log_norm(), ref.log_norm(), rtol=1e-6, atol=1e-4)
-    torch.testing.assert_close(post.natural_parameters(), ref.natural_parameters(), rtol=1e-4,
-                               atol=1e-4)
+    # natural parameters: eta_2 = -(W^-1 + kappa m m^T) / 2 re-derived by inverting the float32
+    # scale matrix the update stored -- held per block against the block's largest entry
+    eta, eta_ref = post.natural_parameters().double(), ref.natural_parameters().double()
+    for name, sl in stat_blocks(eta.shape[-1], D):
+        err = float((eta[..., sl] - eta_ref[..., sl]).abs().max()) / float(eta_ref[..., sl].abs().max())
+        assert err <= 1e-5, (name, err)
 
 
 def _chain_graph(n_states, rng, dtype):
@@ -1500,6 +1504,7 @@ def test_packed_hand_over_random_shapes():
     import random
     from beer_amd import _hip, kernels
     rnd = random.Random(7)
+    failures = []
     for case in range(14):
         cov = rnd.choice(['full', 'diagonal', 'isotropic'])
         D = rnd.choice([1, 2, 3, 4, 5, 7, 8, 12, 13, 16, 20, 24, 31, 32, 39, 40, 48, 63, 64])
@@ -1522,16 +1527,21 @@ def test_packed_hand_over_random_shapes():
             acc_e = kernels.normal_accumulate(st32, r_e, None, 1, K, cov)
         ln_p, packed = kernels.mixture_estep_packed(st32, E64.float(), lw64.float(), K, cov)
         acc_p = kernels.normal_accumulate(st32, packed, None, 1, K, cov)
-        scale = float(acc64.abs().max())
-        e_e = float((acc_e - acc64).abs().max()) / scale
-        e_p = float((acc_p - acc64).abs().max()) / scale
         l_e = float((ln_e.double() - ln64).abs().max())
         l_p = float((ln_p.double() - ln64).abs().max())
-        what = (cov, D, K, T, e_p, e_e, l_p, l_e)
-        assert bool(torch.isfinite(acc_p).all()), what
-        assert e_p <= 4. * e_e + 2e-6, what
-        assert l_p <= 4. * l_e + 1e-6 * float(ln64.abs().max()), what
-        assert float((packed.unpack().double() - r64).abs().max()) < 1e-4, what
+        assert bool(torch.isfinite(acc_p).all()), (cov, D, K, T)
+        # per block of the statistics (counts, first, second moments: each against its own
+        # largest entry), bf16x3 within 2 x the exact fp32 kernels' error + 1e-6
+        for name, sl in stat_blocks(acc64.shape[-1], D):
+            scale = float(acc64[..., sl].abs().max())
+            e_e = float((acc_e[..., sl] - acc64[..., sl]).abs().max()) / scale
+            e_p = float((acc_p[..., sl] - acc64[..., sl]).abs().max()) / scale
+            if not e_p <= 2. * e_e + 1e-6:
+                failures.append((case, cov, D, K, T, name, e_p, e_e))
+        if not l_p <= 2. * l_e + 1e-6 * float(ln64.abs().max()):
+            failures.append((case, cov, D, K, T, 'log-normalisers', l_p, l_e))
+        assert float((packed.unpack().double() - r64).abs().max()) < 1e-4, (cov, D, K, T)
+    assert not failures, failures
 
 
 @pytest.mark.parametrize('cov,S,G,D,T', [('diagonal', 120, 16, 40, 20011), ('diagonal', 7, 4, 13, 17000),

@@ -704,3 +704,87 @@ def test_vae_with_mixture_states_routes_agree(cov, monkeypatch):
     assert len(a_d) == 2
     for p in a_d:
         assert_close(npy(a_s[p]), npy(a_d[p]), 1e-9, 'acc')
+
+
+@pytest.mark.parametrize('cov,S,D,nutt', [('full', 120, 64, 56), ('diagonal', 120, 64, 56)])
+def test_one_sample_hmm_prior_at_config4_shape_against_the_oracle(cov, S, D, nutt):
+    '''the float32 one-sample route of an HMM prior at BASELINE
+    config 4's shape -- a 40-phone x 3-state loop (S = 120 single Gaussians), 64-d latent,
+    > 16 384 float32 samples in ragged utterances, so `llhx_kernel`, the fused
+    forward-backward launch and `sgrad_kernel` / `sgrad_diag_kernel` (bf16x3 on the matrix
+    cores) are what runs -- against the CPU oracle's fp64 restatement of the reference's
+    chain (oracle/beer_oracle.py: `vae_hmm_prior`, `prior_gradient_wrt_samples`, pinned on
+    the reference's G18 goldens; vae.py:63-86, hmm.py:73-92, normalwishart.py:88-92): per-frame
+    value, state posteriors at the pdf ids, gradient w.r.t. the samples and accumulated
+    statistics, float32 at 1e-5 (posteriors: inside the band of the oracle's own float32 run).'''
+    import beer_amd as beer
+    from beer_amd import _hip, kernels
+    from gpu_helpers import DEV, npy
+    from helpers import assert_stats_close, orc, rel_err
+    torch.manual_seed(5)
+    rng = np.random.RandomState(5)
+    P = S // 3
+    graph = beer.graph.Graph()
+    s0, s1 = graph.add_state(), graph.add_state()
+    graph.start_state, graph.end_state = s0, s1
+    pivot = graph.add_state()
+    graph.add_arc(s0, pivot)
+    graph.add_arc(pivot, s1)
+    for p in range(P):
+        st = [graph.add_state(pdf_id=3 * p + k) for k in range(3)]
+        graph.add_arc(pivot, st[0])
+        for k in range(3):
+            graph.add_arc(st[k], st[k], .75)
+            graph.add_arc(st[k], st[k + 1] if k < 2 else pivot, .25)
+    graph.normalize()
+    cg = graph.compile()
+    ns = beer.NormalSet.create(torch.zeros(D), torch.ones(D), size=S, cov_type=cov, noise_std=1.)
+    prior = beer.HMM.create(cg, ns).to(DEV)
+    p0 = list(prior.bayesian_parameters())[0]
+    mu = npy(p0.posterior.params.mean).astype(np.float64)
+    lengths = [int(n) for n in rng.randint(250, 350, nutt)]
+    T = sum(lengths)
+    assert T >= _hip.FAST_MIN_FRAMES
+    parts = []
+    for n in lengths:
+        seq = np.repeat(rng.randint(0, P, n // 25 + 1), 25)[:n]
+        parts.append(mu[3 * seq + rng.randint(0, 3, n)] + rng.randn(n, D) * 1.2)
+    Z32 = np.concatenate(parts).astype(np.float32)
+    Zn = Z32.astype(np.float64)
+    c_up = (rng.rand(T) + .5).astype(np.float32)
+    post = [npy(getattr(p0.posterior.params, n)).astype(np.float64) for n in p0.posterior._std_params_def]
+    og = dict(init=npy(cg.init_log_probs).astype(np.float64), final=npy(cg.final_log_probs).astype(np.float64),
+              trans=npy(cg.trans_log_probs).astype(np.float64), order=np.asarray(cg.pdf_id_mapping))
+
+    def oracle(dtype):
+        vals, resps, off = [], [], 0
+        og_t = {k: (v.astype(dtype) if k != 'order' else v) for k, v in og.items()}
+        with np.errstate(invalid='ignore', divide='ignore'):
+            for n in lengths:
+                v, r, e = orc.vae_hmm_prior(cov, Zn[off:off + n].astype(dtype),
+                                            [a.astype(dtype) for a in post], og_t)
+                vals.append(v)
+                resps.append(r)
+                off += n
+        return np.concatenate(vals), np.concatenate(resps), e
+    value, resps, exp_T = oracle(np.float64)
+    value32, resps32, _ = oracle(np.float32)
+    grad = orc.prior_gradient_wrt_samples(cov, Zn, resps, exp_T, c_up.astype(np.float64))
+    z = torch.from_numpy(Z32).to(DEV).requires_grad_(True)
+    stats = kernels.sample_stats(z, cov)
+    got = prior.expected_log_likelihood(stats, utt_lengths=lengths)
+    band = lambda ref32, truth: max(1e-5, 1.5 * rel_err(ref32.astype(np.float64), truth))   # noqa: E731
+    assert rel_err(npy(got).astype(np.float64), value) <= band(value32, value), 'per-frame value'
+    sr = npy(prior.cache['scaled_pdf_resps']).astype(np.float64)
+    assert rel_err(sr, resps) <= band(resps32, resps), 'state posteriors'
+    assert abs(float(got.double().sum()) - value.sum()) <= 1e-5 * abs(value.sum())
+    (torch.from_numpy(c_up).to(DEV) * got).sum().backward()
+    # the gradient of the HIP path multiplies ITS posteriors: hold it against the oracle's
+    # gradient at 1e-5 of the largest entry plus what the posteriors' own float32 band moves
+    g_band = max(1e-5, 1.5 * rel_err(orc.prior_gradient_wrt_samples(
+        cov, Zn, resps32.astype(np.float64), exp_T, c_up.astype(np.float64)), grad))
+    assert rel_err(npy(z.grad).astype(np.float64), grad) <= g_band, 'd/dz'
+    acc = prior.accumulate(stats.detach())[p0]
+    acc_band = max(1e-5, 1.5 * rel_err(resps32.astype(np.float64).T @ orc.SUFFSTATS[cov](Zn),
+                                       resps.T @ orc.SUFFSTATS[cov](Zn)))
+    assert_stats_close(npy(acc), resps.T @ orc.SUFFSTATS[cov](Zn), D, acc_band, 'acc')

@@ -25,6 +25,8 @@ import os
 import sys
 import time
 
+sys.dont_write_bytecode = True     # (importing the reference must not drop __pycache__ into it)
+
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
