@@ -434,6 +434,11 @@ def upload(tensors, device):
     transfer from pinned memory; returns {name: device view}.  Dozens of
     pageable `tensor.to(device)` copies each make the host wait for the stream
     (and were seen to stall it for tens of ms inside an iteration).'''
+    if torch.cuda.is_current_stream_capturing():
+        # a captured copy kernel would re-read the pinned staging slot at every replay, long
+        # after the ring has handed it to somebody else
+        raise HipInvalid('host -> device upload while a HIP graph is being captured: the '
+                         'data of a captured iteration must be resident on the device')
     names, metas, total = [], [], 0
     for name, t in tensors.items():
         t = t.detach().contiguous()

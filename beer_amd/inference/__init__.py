@@ -1,3 +1,4 @@
 from .objectives import *
 from .optimizers import *
 from .batch import *
+from .captured import *

@@ -1,0 +1,147 @@
+"""A whole VB iteration as ONE submission.
+
+The reference's training loop on a resident minibatch (examples/Mixture Model.ipynb cell 9;
+beer/inference/objectives.py:119-190, optimizers.py:22-31) is
+
+    optim.init_step()
+    elbo = beer.evidence_lower_bound(model, X, datasize=N)
+    elbo.backward()
+    optim.step()
+
+-- some forty small launches for a mixture of a few Gaussians, each a few microseconds
+of GPU time behind tens of microseconds of host time: at BASELINE config 1 (K = 8, D = 2,
+1000 frames) the iteration is bound by the host, not by the device.  `CapturedIteration`
+records that sequence once as a HIP graph (`torch.cuda.CUDAGraph`: torch as the stream /
+graph container) and replays it: one launch per iteration.
+
+What makes the recorded sequence a fixed point.  The eager update REPLACES the posterior's
+tensors (as the reference does, parameters.py:134-141); a recorded E-step would go on
+reading the tensors it was recorded with.  The capture therefore ends with device copies
+of the new posterior back into the tensors the E-step read, and the model keeps those
+tensors: every replay reads the previous replay's result.  Everything derived from the
+posterior (E[T], log-normalisers, log-weights, KL) is recomputed INSIDE the recording --
+the memos are dropped before it and after every replay.  One graph per mean-field group in
+turn (optimizers.py:29-31: round robin).
+"""
+
+import warnings
+
+import torch
+
+from .. import _hip
+from .objectives import evidence_lower_bound
+from .optimizers import VBConjugateOptimizer
+
+__all__ = ['CapturedIteration']
+
+
+def _drop_memos(params):
+    for p in params:
+        p.posterior.__dict__['_memo'] = {}
+        p.__dict__.pop('_kl_memo', None)
+
+
+class CapturedIteration:
+    '''`it = CapturedIteration(model, optim, X, datasize=N, **kwargs)`; every `it()` is one
+    VB iteration on the resident minibatch `X` and returns the ELBO value (0-dim float64
+    device tensor, overwritten by the next call).  The first call of a mean-field group
+    runs eagerly (it settles the allocations and the constants), the second records,
+    later ones replay.  `mode` says what the last call did: 'eager', 'captured' or
+    'replayed'; a sequence that cannot be recorded (host callbacks, a host -> device
+    copy inside the E-step) stays eager, with one warning.'''
+
+    def __init__(self, model, optim, data, datasize=-1, **kwargs):
+        if not isinstance(optim, VBConjugateOptimizer):
+            raise TypeError('CapturedIteration drives a VBConjugateOptimizer')
+        self.model, self.optim = model, optim
+        self.data = _hip.on_device(data)
+        self.datasize, self.kwargs = datasize, kwargs
+        self._entries = {}                 # turn -> None (warmed up) | False (eager) | entry
+        self.mode = None
+
+    # -- the reference's loop body ------------------------------------------------------
+    def _iteration(self):
+        self.optim.init_step()
+        elbo = evidence_lower_bound(self.model, self.data, datasize=self.datasize, **self.kwargs)
+        elbo.backward()
+        self.optim.step()
+        return elbo
+
+    def _eager(self):
+        self.mode = 'eager'
+        value = self._iteration().value
+        return value if isinstance(value, torch.Tensor) else torch.as_tensor(value)
+
+    def _signature(self, members):
+        return (self.optim.lrate, self.data.data_ptr(), tuple(self.data.shape),
+                tuple(id(t) for p in members for t in p.posterior._tensors()))
+
+    def __call__(self):
+        optim = self.optim
+        if not optim.groups:
+            return self._eager()
+        turn = optim.update_count % len(optim.groups)
+        members = optim.groups[turn]
+        entry = self._entries.get(turn, 'new')
+        if entry == 'new':
+            self._entries[turn] = None
+            return self._eager()
+        if entry is False:
+            return self._eager()
+        if entry is not None and entry['signature'] != self._signature(members):
+            entry = None                   # posterior replaced from outside, new learning rate
+        if entry is None:
+            entry = self._capture(turn, members)
+            if entry is None:
+                return self._eager()
+            self.mode = 'captured'
+        else:
+            self.mode = 'replayed'
+        entry['graph'].replay()
+        optim.update_count += 1
+        every = [p for group in optim.groups for p in group]
+        _drop_memos(every)
+        for p, st in zip(members, entry['stats']):
+            p.stats = st
+        return entry['value']
+
+    def _capture(self, turn, members):
+        optim = self.optim
+        every = [p for group in optim.groups for p in group]
+        if not VBConjugateOptimizer._capturable(members) or \
+                not all(t.is_cuda for p in every for t in p.posterior._tensors()):
+            self._entries[turn] = False
+            return None
+        homes = [p.posterior.params for p in members]
+        home_tensors = [tuple(p.posterior._tensors()) for p in members]
+        count, use_graph = optim.update_count, optim.graph
+        _drop_memos(every)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            optim.graph = False            # (the M-step is part of THIS recording)
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                elbo = self._iteration()
+                value = elbo.value
+                for p, old in zip(members, home_tensors):
+                    for dst, src in zip(old, p.posterior._tensors()):
+                        dst.copy_(src)
+        except RuntimeError as err:
+            refused = not isinstance(err, _hip.HipError) or isinstance(err, _hip.HipInvalid) \
+                or 900 <= -(err.rc or 0) <= 908
+            if not refused:
+                raise
+            self._entries[turn] = False
+            warnings.warn(f'CapturedIteration: the iteration could not be recorded as a HIP graph '
+                          f'({type(err).__name__}: {err}); it runs eagerly', RuntimeWarning)
+            return None
+        finally:
+            optim.graph, optim.update_count = use_graph, count
+            # nothing has run: the model is the one the recording started from
+            for p, params in zip(members, homes):
+                p.posterior.params = params
+            _drop_memos(every)
+        entry = {'graph': graph, 'value': value, 'stats': [p.stats for p in members],
+                 'signature': self._signature(members)}
+        self._entries[turn] = entry
+        return entry

@@ -8,6 +8,8 @@ scales the summed statistics by datasize / sum(minibatch sizes) and stores
 (overwrites) them in the parameters (Q2).
 """
 
+import threading
+
 import torch
 
 from .. import _hip
@@ -76,11 +78,27 @@ class EvidenceLowerBoundInstance:
         self._model_parameters = set(model.bayesian_parameters())
 
 
+_span_lock = threading.Lock()
+_spans = {}                 # (device, n) -> int64 device tensor [0, n]: constants, made once
+
+
+def _span(n, device):
+    key = (device, n)
+    with _span_lock:
+        off = _spans.get(key)
+        if off is None:
+            if len(_spans) >= 64:
+                _spans.clear()
+            # (a host -> device copy: not while a HIP graph is being captured -- the warm-up
+            # iteration in front of every capture has made the entry by then)
+            off = _spans[key] = torch.tensor([0, n], dtype=torch.int64, device=device)
+    return off
+
+
 def frame_sum(values):
     'Sum of a per-frame tensor in fp64 on the device (beer_segment_sum).'
     values = _hip.on_device(values).reshape(-1)
-    off = torch.tensor([0, values.numel()], dtype=torch.int64, device=values.device)
-    return segment_sum(values, off, 1)[0]
+    return segment_sum(values, _span(values.numel(), values.device), 1)[0]
 
 
 def evidence_lower_bound(model=None, minibatch_data=None, datasize=-1, **kwargs):

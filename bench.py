@@ -155,13 +155,14 @@ def rank_census(world, device, backend, n_local):
     '''Evidence for an N > 1 line: the number of ranks the collective really spans (an
     all-reduce of ones) and the frames per rank (max / mean).'''
     if world == 1:
-        return {'rccl_ranks': 1, 'frames_per_rank': {'max': n_local, 'mean': float(n_local)}}
+        return {'ranks': 1, 'backend': None,
+                'frames_per_rank': {'max': n_local, 'mean': float(n_local)}}
     dev = device if backend == 'nccl' else 'cpu'
     t = torch.tensor([1., float(n_local)], dtype=torch.float64, device=dev)
     m = torch.tensor([float(n_local)], dtype=torch.float64, device=dev)
     dist.all_reduce(t)
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
-    return {'rccl_ranks': int(t[0].item()), 'backend': backend,
+    return {'ranks': int(t[0].item()), 'backend': 'rccl' if backend == 'nccl' else backend,
             'frames_per_rank': {'max': int(m.item()), 'mean': float(t[1].item()) / world}}
 
 
@@ -369,7 +370,7 @@ def run_gmm(args, rank, world, device, backend):
     # watchdog thread keeps calling into the runtime -- and a refused capture falls back to
     # the eager update, optimizers.py)
     optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.,
-                                      graph=not args.no_mstep_graph)
+                                      graph=False if args.no_mstep_graph else None)
     parity = {}
     if rank == 0 and not args.no_check:
         parity = gmm_parity_check(model, X, n=min(65536, frames))
@@ -621,13 +622,19 @@ def cpu_baseline_hmm(budget_s=20.):
 
 
 def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, steps=None,
-            warmup=None, with_cpu_baseline=True):
+            warmup=None, with_cpu_baseline=True, shard_of=None):
+    '''`shard_of` = N (one process): this GPU takes the part of the corpus that rank 0 of an
+    N-way split would take (`shard_utterances`: balanced by frame count) -- the per-rank work
+    of an N-GPU run measured on one GPU; no collective runs.'''
     cov = cov or args.cov
     total_frames = total_frames or args.frames
     steps, warmup = steps or args.steps, args.warmup if warmup is None else warmup
     lengths_all = hmm_corpus(total_frames)
     datasize = sum(lengths_all)
-    mine = shard_utterances(lengths_all, world, rank)        # balanced by frame count
+    if shard_of:
+        mine = shard_utterances(lengths_all, shard_of, 0)
+    else:
+        mine = shard_utterances(lengths_all, world, rank)    # balanced by frame count
     lengths = [lengths_all[u] for u in mine]
     n_local = sum(lengths)
     g = torch.Generator(device=device).manual_seed(2 + rank)
@@ -635,7 +642,7 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
     ploop = make_phone_loop(cov, device)                     # identical on every rank
     census = rank_census(world, device, backend, n_local)
     optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.,
-                                      graph=not args.no_mstep_graph)
+                                      graph=False if args.no_mstep_graph else None)
     phases = PhaseTimer()
     # the frames stay resident over the iterations, and so do their fragment images: the
     # caller (this script) owns both
@@ -681,7 +688,8 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
     # whole (all-reduced, datasize-scaled) job must add up to the number of frames
     counts = [v for p, v in elbo._acc_stats.items() if v.dim() == 2 and v.shape[-1] == N_COMP]
     # (a row of the statistics is (N_1 .. N_G-1, N_1 + .. + N_G): beer/dists/dirichlet.py:18-21)
-    conservation = abs(float(counts[0].double()[:, -1].sum()) - datasize) / datasize \
+    expect = n_local if shard_of else datasize
+    conservation = abs(float(counts[0].double()[:, -1].sum()) - expect) / expect \
         if counts else None
     Kc = 3 * N_PHONES * N_COMP
     Qd = {'diagonal': 2 * D + 2, 'full': D * D + D + 2, 'isotropic': D + 3}[cov]
@@ -751,6 +759,15 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
         'roofline': roof,
         'kernels': kern,
     }
+    # what an iteration costs besides its big calls (small kernels, the M-step, host gaps)
+    out['kernels_ms_per_step'] = sum(k['ms'] * k['launches'] for k in kern.values()) / steps
+    out['fixed_ms_per_step'] = out['ms_per_step'] - out['kernels_ms_per_step']
+    if shard_of:
+        out['shard'] = {'of': shard_of, 'frames': n_local, 'utterances': len(lengths),
+                        'note': f'rank 0\'s shard of a {shard_of}-way split of the {datasize}-frame '
+                                'corpus on ONE GPU, no collective: value = frames of the shard / '
+                                'time; x N is the projection for N GPUs'}
+        out['value'] = n_local * steps / elapsed
     if with_cpu_baseline and not args.no_cpu_baseline and world == 1 and cov == 'diagonal':
         out['cpu_baseline'] = cpu_baseline_hmm()
     fi = frame_image_report(images)
@@ -890,6 +907,99 @@ def run_vae(args, device, frames=1_000_000, steps=3, warmup=1):
     return out
 
 
+# --------------------------------------------------------------------------------------------
+# config 1: diagonal GMM K = 8, D = 2, 1000 frames -- the latency of ONE iteration
+# --------------------------------------------------------------------------------------------
+
+def run_config1(args, device, iters=400):
+    """BASELINE config 1 (`configs[0]`: examples/Mixture Model.ipynb): diagonal-covariance
+    mixture, K = 8, D = 2, 1000 fp64 frames, the notebook's loop body (init_step,
+    evidence_lower_bound, backward, step) as it stands -- an iteration here is launch-bound,
+    so the figure is MICROSECONDS PER ITERATION: eager (every kernel launched by the host),
+    the library's default (the M-step of a group replayed from its captured graph), and the
+    whole iteration as one captured HIP graph (`beer.CapturedIteration`); pipelined (the host
+    never waits) and with the ELBO read back after every iteration, as the notebook does."""
+    from oracle import torch_port as tp
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(1000, 2, dtype=torch.float64, generator=g)
+
+    def make():
+        torch.manual_seed(0)
+        ns = beer.NormalSet.create(X.mean(0), X.var(0), size=8, prior_strength=1., noise_std=1.,
+                                   cov_type='diagonal')
+        return beer.Mixture.create(ns, prior_strength=1.).double().to(device)
+    Xd = X.to(device)
+
+    def loop_body(model, optim):
+        def body():
+            optim.init_step()
+            elbo = beer.evidence_lower_bound(model, Xd)
+            elbo.backward()
+            optim.step()
+            return elbo.value
+        return body
+
+    def measure(fn):
+        for _ in range(10):
+            v = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            v = fn()
+        torch.cuda.synchronize()
+        piped = (time.perf_counter() - t0) / iters
+        t0 = time.perf_counter()
+        for _ in range(iters // 4):
+            v = float(fn())
+        synced = (time.perf_counter() - t0) / (iters // 4)
+        return {'us_per_iteration': 1e6 * piped, 'us_per_iteration_elbo_read_back': 1e6 * synced,
+                'frames_per_s': 1000 / piped, 'last_elbo': float(v)}
+    out = {'workload': 'configs[0]: diagonal GMM K=8, D=2, 1000 fp64 frames, one call of '
+                       'evidence_lower_bound + backward + step per iteration (examples/Mixture '
+                       'Model.ipynb cell 9)', 'iterations_timed': iters}
+    m = make()
+    out['eager'] = measure(loop_body(m, beer.VBConjugateOptimizer(m.mean_field_factorization(), 1.,
+                                                                  graph=False)))
+    m = make()
+    out['default'] = measure(loop_body(m, beer.VBConjugateOptimizer(m.mean_field_factorization(), 1.)))
+    m = make()
+    it = beer.CapturedIteration(m, beer.VBConjugateOptimizer(m.mean_field_factorization(), 1.), Xd)
+    out['captured'] = measure(it)
+    out['captured']['mode'] = it.mode
+    out['value'] = out['captured']['frames_per_s']
+    out['unit'] = 'frames/s (1000-frame iterations; see us_per_iteration)'
+    if not args.no_cpu_baseline:
+        # the port of the reference's op sequence for this model (oracle/torch_port.py:
+        # gmm_diag_iteration, pinned on the reference's golden G1) on the host, fp64
+        as64 = lambda d: tuple(getattr(d.params, n).detach().cpu().double().clone()       # noqa: E731
+                               for n in d._std_params_def)
+        m = make()
+        p0, p1 = list(m.bayesian_parameters())
+        post, prior = as64(p0.posterior), as64(p0.prior)
+        w_post, w_prior = as64(p1.posterior)[0], as64(p1.prior)[0]
+        nt = torch.get_num_threads()
+        torch.set_num_threads(1)
+        for _ in range(3):
+            tp.gmm_diag_iteration(X, post, prior, w_post, w_prior)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 2.:
+            _, post, w_post = tp.gmm_diag_iteration(X, post, prior, w_post, w_prior)
+            n += 1
+        dt = (time.perf_counter() - t0) / n
+        torch.set_num_threads(nt)
+        out['cpu_baseline'] = {'value': 1000 / dt, 'unit': 'frames/s', 'us_per_iteration': 1e6 * dt,
+                               'cores': 1, **host_cores(), 'kind': 'port',
+                               'sample': f'{n} iterations of the config-1 workload, torch-CPU replay '
+                                         'of the reference op sequence (oracle/torch_port.py: '
+                                         'gmm_diag_iteration), one thread',
+                               'reference_calibration': 'the imported reference itself needs 0.160 s '
+                                                        'per iteration on the survey container '
+                                                        '(BASELINE.md section 2: overhead-bound -- '
+                                                        'Python objects, not arithmetic)'}
+    return out
+
+
 def frame_image_report(images):
     '''What the caller-owned frame images (beer_amd.FrameImages: diagonal emissions) hold and
     cost: bytes of images and of the frames the object keeps alive, builds / hits during
@@ -918,10 +1028,51 @@ def config3_subobject(line):
     'The keys of a config-3 line that go into the default line as a sub-object.'
     keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'f32_mode', 'kernels',
             'roofline', 'cpu_baseline', 'frame_image', 'count_conservation_rel_err', 'elbo_per_frame',
-            'all_reduce_ms', 'm_step_ms', 'm_step', 'frames_per_rank', 'rccl_ranks')
+            'all_reduce_ms', 'm_step_ms', 'm_step', 'frames_per_rank', 'ranks', 'backend',
+            'fixed_ms_per_step', 'kernels_ms_per_step', 'shard')
     sub = {k: line[k] for k in keep if k in line}
     sub['workload'] = line['config']['workload']
     return sub
+
+
+def shard_projection(full, shard, n):
+    """What the one-GPU measurement of a rank's shard says about an N-GPU run of the same
+    corpus: the shard's time against a perfect split of the one-GPU time (the all-reduce
+    of the statistics -- 1.3 MB over xGMI -- is not in it)."""
+    ideal = full['ms_per_step'] / n
+    return {'gpus': n, 'one_gpu_ms_per_step': full['ms_per_step'], 'ideal_ms_per_step': ideal,
+            'shard_ms_per_step': shard['ms_per_step'], 'ratio_to_ideal': shard['ms_per_step'] / ideal,
+            'speedup': full['ms_per_step'] / shard['ms_per_step'],
+            'frames_per_s': full['config']['frames_total'] / (shard['ms_per_step'] * 1e-3)}
+
+
+def summary(out):
+    'The numbers of the line in one short object (its last key).'
+    s = {'config2_frames_per_s': round(out['value']), 'config2_ms_per_step': round(out['ms_per_step'], 3)}
+    roof = out.get('roofline') or {}
+    if roof.get('frac') is not None:
+        s['config2_roofline_frac'] = round(roof['frac'], 4)
+    for key in ('config3', 'config3_full', 'config3_shard'):
+        if key in out:
+            s[key + '_frames_per_s'] = round(out[key]['value'])
+            s[key + '_ms_per_step'] = round(out[key]['ms_per_step'], 3)
+    if 'config3_shard' in out:
+        s['config3_projected_8gpu_speedup'] = round(out['config3_shard']['projected_8gpu']['speedup'], 2)
+    c4 = out.get('config4')
+    if c4:
+        for cov in ('diagonal', 'full'):
+            if cov in c4:
+                s[f'config4_prior_{cov}_frames_per_s'] = round(c4[cov]['prior_hot_path']['value'])
+                s[f'config4_step_{cov}_frames_per_s'] = round(c4[cov]['vae_step']['value'])
+    c1 = out.get('config1')
+    if c1:
+        s['config1_us_per_iteration'] = {k: round(c1[k]['us_per_iteration'], 1)
+                                         for k in ('eager', 'default', 'captured') if k in c1}
+    c5 = out.get('config5')
+    if c5:
+        s['config5_frames_per_s'] = round(c5['value'])
+        s['config5_wall_s'] = round(c5['wall_s'], 3)
+    return s
 
 
 # --------------------------------------------------------------------------------------------
@@ -961,13 +1112,27 @@ def worker(args):
         torch.cuda.empty_cache()
         c3f = run_hmm(args, rank, world, device, backend, cov='full', total_frames=2_000_000,
                       steps=6, warmup=2, with_cpu_baseline=False)
+        c3s = None
+        if world == 1:
+            # one rank's share of an 8-GPU run of config 3, on this one GPU
+            torch.cuda.empty_cache()
+            c3s = run_hmm(args, rank, world, device, backend, cov='diagonal',
+                          total_frames=10_000_000, steps=20, warmup=3, with_cpu_baseline=False,
+                          shard_of=8)
         if rank == 0:
             out['config3'] = config3_subobject(c3)
             out['config3_full'] = config3_subobject(c3f)
+            if c3s:
+                out['config3_shard'] = config3_subobject(c3s)
+                out['config3_shard']['projected_8gpu'] = shard_projection(c3, c3s, 8)
         if rank == 0 and world == 1 and not args.no_config4:
             torch.cuda.empty_cache()
             out['config4'] = run_vae(args, device)
+        if rank == 0 and world == 1 and not args.no_config1:
+            out['config1'] = run_config1(args, device)
     if rank == 0:
+        if args.config == 2:
+            out['summary'] = summary(out)      # (last key: the tail of the line shows it)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -1003,6 +1168,8 @@ def main():
                     help='default line: skip the config3 / config3_full sub-objects')
     ap.add_argument('--no-config4', action='store_true',
                     help='default line: skip the config4 sub-object (HMM-VAE, one process)')
+    ap.add_argument('--no-config1', action='store_true',
+                    help='default line: skip the config1 sub-object (latency of one small iteration)')
     ap.add_argument('--config4-only', action='store_true',
                     help='print the config4 sub-object alone (no config 2 / 3 runs)')
     ap.add_argument('--scaling', default='weak', choices=('weak', 'strong'),

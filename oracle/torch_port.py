@@ -175,6 +175,58 @@ def ng_natural(mean, scale, shape, rates):
                      dim=-1)
 
 
+def ng_from_natural(eta, D):
+    'normalgamma.py:77-94.'
+    scale = -2 * eta[:, 2 * D:2 * D + 1]
+    shape = eta[:, 2 * D + 1:] + .5
+    mean = eta[:, :D] / scale
+    rates = -eta[:, D:2 * D] - .5 * scale * mean ** 2
+    return mean, scale, shape, rates
+
+
+def gmm_diag_elbo(X, post, prior, w_post, w_prior, datasize):
+    '''One `evidence_lower_bound(Mixture, X)` call with diagonal covariances (BASELINE
+    config 1: examples/Mixture Model.ipynb): phi(X) with mul + cat (normalgamma.py:20-27),
+    E[T] (118-146), stats @ E[T]^T (55-59), mixture.py:70-102, KL per call
+    (basedist.py:243-263, normalgamma.py:151-157).'''
+    T, D = X.shape
+    one = torch.ones(T, 1, dtype=X.dtype)
+    stats = torch.cat([X, -.5 * X ** 2, -.5 * one, .5 * one], dim=-1)
+    exp_T = ng_exp_stats(*post)
+    pc = stats @ exp_T.t() - .5 * D * LOG2PI
+    eye = torch.eye(len(w_post), dtype=X.dtype)
+    eye[:, -1] = eye.sum(-1)
+    lw = eye @ dir_exp_stats(w_post)
+    w = pc + lw[None]
+    lnorm = torch.logsumexp(w, dim=1).view(-1, 1)
+    log_r = w - lnorm
+    resps = log_r.exp()
+    local_kl = torch.sum(log_r.exp() * (log_r - lw[None]), dim=-1)
+    per_frame = (pc * resps).sum(-1) - local_kl
+    kl = (ng_log_norm(*prior) - ng_log_norm(*post)
+          - torch.sum(exp_T * (ng_natural(*prior) - ng_natural(*post)), dim=-1)).sum()
+    kl = kl + dir_log_norm(w_prior) - dir_log_norm(w_post) \
+        - torch.sum(dir_exp_stats(w_post) * (dir_natural(w_prior) - dir_natural(w_post)))
+    value = (datasize / float(T)) * per_frame.sum() - kl
+    rs = resps.clone()
+    rs[:, -1] = rs.sum(-1)
+    return value, resps.t() @ stats, rs.sum(0)
+
+
+def gmm_diag_iteration(X, post, prior, w_post, w_prior):
+    '''The loop body of examples/Mixture Model.ipynb cell 9 (init_step, evidence_lower_bound,
+    backward, step): (ELBO value, new posterior, new weight concentrations).'''
+    N, D = X.shape
+    value, acc_n, acc_w = gmm_diag_elbo(X, post, prior, w_post, w_prior, N)
+    eta = ng_natural(*post)
+    eta = eta + (ng_natural(*prior) + acc_n - eta)
+    eta_w = dir_natural(w_post)
+    eta_w = eta_w + (dir_natural(w_prior) + acc_w - eta_w)
+    c = eta_w + 1
+    c[-1] = eta_w[-1] - eta_w[:-1].sum() + 1
+    return float(value), ng_from_natural(eta, D), c
+
+
 def dirset_exp_stats(c):
     'Rows of Dirichlet concentrations [S, G] -> E[T] [S, G] (dirichlet.py:106-128).'
     out = torch.zeros_like(c)

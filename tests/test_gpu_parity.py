@@ -1995,3 +1995,31 @@ def test_two_host_threads_on_their_own_streams():
     for i in range(2):
         assert out[i][0] == out['ref'][0]
         np.testing.assert_array_equal(out[i][1], out['ref'][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['g01_gmm_diag_c1', 'g02_gmm_full'])
+def test_whole_iteration_as_a_captured_graph_matches_the_reference(name):
+    '''`beer.CapturedIteration`: the loop body of examples/Mixture Model.ipynb cell 9
+    (init_step, evidence_lower_bound, backward, step) recorded as ONE HIP graph -- first call
+    eager, second records, later ones replay -- against the reference's own iterations (G1 is
+    BASELINE config 1: K = 8, D = 2, T = 1000): ELBO and posteriors after every iteration.'''
+    g = load_golden(name)
+    X = tt(g['X'])
+    model = build_mixture(g)
+    optim = beer.VBConjugateOptimizer(model.mean_field_factorization(), lrate=1.)
+    it = beer.CapturedIteration(model, optim, X)
+    modes = []
+    for k in range(int(g['niter'])):
+        value = it()
+        modes.append(it.mode)
+        assert_close(float(value), g['elbos'][k], T64, f'elbo {k} ({it.mode})')
+        p0, p1 = params_of(model)
+        check_posterior(p0, g, f'it{k}.p0.posterior', 1e-7, assert_close)
+        check_posterior(p1, g, f'it{k}.p1.posterior', 1e-8, assert_close)
+    assert modes == (['eager', 'captured'] + ['replayed'] * len(modes))[:len(modes)], modes
+    assert optim.update_count == int(g['niter'])
+    # what the model holds after a replay is what an eager call computes from
+    eager = beer.evidence_lower_bound(model, X)
+    again = beer.evidence_lower_bound(build_mixture(g, f'it{int(g["niter"]) - 1}'), X)
+    assert_close(float(eager), float(again), 1e-8, 'ELBO of the replayed posterior')

@@ -372,6 +372,25 @@ def test_torch_port_matches_oracle():
     assert_close(new_w.numpy(), g['it0.p1.posterior.concentrations'], 1e-10)
 
 
+def test_torch_port_diag_gmm_matches_the_reference_golden():
+    """bench.py's config-1 cpu_baseline (oracle/torch_port.py: gmm_diag_iteration) over the five
+    iterations of the reference's own run of BASELINE config 1 (G1: K = 8, D = 2, T = 1000)."""
+    import torch
+    from oracle import torch_port as tp
+    g = load_golden('g01_gmm_diag_c1')
+    X = torch.from_numpy(g['X'])
+    tt = lambda arrs: tuple(torch.from_numpy(a.copy()) for a in arrs)       # noqa: E731
+    post, prior = tt(std_params(g, 'init.p0.posterior')), tt(std_params(g, 'init.p0.prior'))
+    w_post = torch.from_numpy(std_params(g, 'init.p1.posterior')[0].copy())
+    w_prior = torch.from_numpy(std_params(g, 'init.p1.prior')[0].copy())
+    for it in range(int(g['niter'])):
+        value, post, w_post = tp.gmm_diag_iteration(X, post, prior, w_post, w_prior)
+        assert_close(value, g['elbos'][it], 1e-10, f'elbo {it}')
+        for arr, ref in zip(post, std_params(g, f'it{it}.p0.posterior')):
+            assert_close(arr.numpy().reshape(ref.shape), ref, 1e-8, f'posterior {it}')
+        assert_close(w_post.numpy(), g[f'it{it}.p1.posterior.concentrations'], 1e-10)
+
+
 def test_torch_port_hmm_matches_oracle():
     '''bench.py's config-3 cpu_baseline (oracle/torch_port.py: hmm_elbo, the
     reference's op sequence on torch CPU tensors) against the numpy oracle, which
