@@ -235,7 +235,14 @@ class PhoneLoop(HMM):
     # the callback is index arithmetic on device tensors when the graph lives on the GPU
     # (no host copy, no synchronisation): the update of the weights' group may then be
     # captured as a HIP graph (parameters.py: register_callback)
-    _on_weights_update.device_only = lambda self: self.graph.trans_log_probs.is_cuda
+    def _weights_update_capturable(self):
+        if not self.graph.trans_log_probs.is_cuda:
+            return False
+        # (the index tensors are made NOW: their host -> device copy cannot be recorded)
+        self._index_tensors(self.graph.trans_log_probs.device)
+        return True
+
+    _on_weights_update.device_only = _weights_update_capturable
 
     def mean_field_factorization(self):
         from .mixtures import _merge_groups

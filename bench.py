@@ -908,6 +908,206 @@ def run_vae(args, device, frames=1_000_000, steps=3, warmup=1):
 
 
 # --------------------------------------------------------------------------------------------
+# config 5: the recipe end to end -- features -> training with alignments -> Viterbi align
+# --------------------------------------------------------------------------------------------
+
+def run_config5(args, device, hours=None, epochs=5, n_comp=4, cpu_sample=6):
+    """BASELINE config 5 (`configs[4]`; flow of recipes/aud/steps/monophone.sh:62-146 and
+    recipes/timit_v2/steps/train_hmm.sh:99-143, in memory): synthetic 16 kHz audio ->
+    `beer features extract` (MFCC + energy + deltas, 42 dimensions; features/extract.py:60-176)
+    -> dataset statistics (cli/dataset.py:38-80) -> monophone model, 40 phones x 3 states x 4
+    diagonal Gaussians (recipes/aud/conf/hmm.yml speech units) -> alignment graphs of every
+    transcription (hmm/mkaligraph.py:18-39) -> `epochs` x (accumulate with the alignment
+    graphs + update; accumulate.py:39-63, update.py:41-62) -> Viterbi alignment of every
+    utterance (hmm/decode.py).  Wall-clock per stage with the audio already on the device;
+    `value` = frames of the corpus / total wall time."""
+    hours = hours or float(os.environ.get('BEER_BENCH_C5_HOURS', 3.))
+    rng = np.random.RandomState(5)
+    srate, phones = 16000, N_PHONES
+    lens, total_s = [], 0.
+    while total_s < hours * 3600.:
+        n = int(rng.uniform(2., 4.) * srate)
+        lens.append(n)
+        total_s += n / srate
+    # band-limited noise with a slowly varying envelope, int16 like a wav file's samples
+    g = torch.Generator(device=device).manual_seed(5)
+    walls = {}
+    t_all = time.perf_counter()
+
+    def stage(name, t0):
+        torch.cuda.synchronize()
+        walls[name] = time.perf_counter() - t0
+
+    signals = []
+    for n in lens:
+        x = torch.randn(n, generator=g, device=device)
+        env = 1. + .8 * torch.sin(torch.arange(n, device=device) * (2 * np.pi * 3. / srate))
+        signals.append((x * env * 3000.).to(torch.int16))
+    torch.cuda.synchronize()
+    audio_bytes = 2 * sum(lens)
+    # -- features
+    t0 = time.perf_counter()
+    feats = beer.features.extract(signals, as_numpy=False)          # [T_u, 42] float64, device
+    stage('features', t0)
+    # -- dataset: float32 frames (cli/dataset.py:33 `.float()`), global mean / variance
+    t0 = time.perf_counter()
+    lengths = [len(f) for f in feats]
+    X = torch.cat(feats).float()
+    del feats
+    mean, var = X.mean(0), X.var(0)
+    stage('dataset', t0)
+    total, dim = len(X), X.shape[1]
+    # -- model (mkphones / mkphoneloopgraph / mkdecodegraph / mkphoneloop)
+    t0 = time.perf_counter()
+    units, pdf = {}, 0
+    for p in range(phones):
+        u = beer.graph.Graph()
+        for sid in range(5):
+            u.add_state(pdf_id=None if sid in (0, 4) else pdf + sid - 1)
+        u.start_state, u.end_state = 0, 4
+        for arc in TOPO:
+            u.add_arc(*arc)
+        units[p] = u
+        pdf += 3
+    graph = beer.graph.Graph()
+    graph.start_state, graph.end_state = graph.add_state(), graph.add_state()
+    pivot = graph.add_state()
+    u2s = {p: graph.add_state() for p in units}
+    graph.add_arc(graph.start_state, pivot)
+    graph.add_arc(pivot, graph.end_state)
+    for p in units:
+        graph.add_arc(pivot, u2s[p])
+        graph.add_arc(u2s[p], pivot)
+    graph.normalize()
+    for p, hmm in units.items():
+        graph.replace_state(u2s[p], hmm)
+    graph.normalize()
+    torch.manual_seed(5)
+    S = 3 * phones
+    ns = beer.NormalSet.create(mean.cpu(), var.cpu(), size=S * n_comp, prior_strength=1.,
+                               noise_std=.1, cov_type='diagonal')
+    emissions = beer.JointModelSet([beer.MixtureSet.create(S, ns, prior_strength=1.)])
+    ploop = beer.PhoneLoop.create(graph.compile(), {p: 3 * p for p in units},
+                                  {p: 3 * p + 2 for p in units}, emissions).float().to(device)
+    stage('model', t0)
+    # -- alignment graphs: a transcription of about one phone per ten frames
+    seqs = [[int(v) for v in rng.randint(0, phones, max(2, T // 10))] for T in lengths]
+    t0 = time.perf_counter()
+    gset = beer.graph.compile_alignments(seqs, units)
+    graphs = list(gset)
+    gset.device_image(torch.float32)
+    stage('alignment_graphs', t0)
+    # -- training
+    optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.)
+    names = ('beer_mixtureset_estep', 'beer_mixtureset_lognorm_image', 'beer_hmm_posteriors_fused',
+             'beer_hmm_forward_backward', 'beer_mixtureset_accumulate_fused',
+             'beer_normal_accumulate', 'beer_hmm_viterbi', 'beer_hmm_gather')
+    elbos = []
+    with KernelTimer(names) as kt:
+        t0 = time.perf_counter()
+        epoch_s = []
+        for _ in range(epochs):
+            te = time.perf_counter()
+            optim.init_step()
+            elbo = beer.accumulate_elbo(ploop, (X, lengths), datasize=total, inference_graphs=graphs)
+            elbo.backward()
+            optim.step()
+            elbos.append(elbo.value)
+            torch.cuda.synchronize()
+            epoch_s.append(time.perf_counter() - te)
+        stage('training', t0)
+        # -- Viterbi alignment
+        t0 = time.perf_counter()
+        paths = beer.decode_batch(ploop, (X, lengths), inference_graphs=graphs)
+        stage('viterbi_align', t0)
+    wall = time.perf_counter() - t_all
+    stage_sum = sum(walls.values())
+    elbos = [float(v) / (len(lengths) * total) for v in elbos]
+    kern = {}
+    for nm in names:
+        ms, n = kt.mean_ms(nm)
+        if n:
+            kern[nm] = {'ms': ms, 'launches': n}
+    out = {'workload': f'configs[4]: {total_s / 3600.:.2f} h of synthetic 16 kHz audio in {len(lens)} '
+                       f'utterances -> {dim}-dimensional MFCC+E+deltas ({total} frames) -> monophone '
+                       f'HMM {phones} phones x 3 states x {n_comp} diagonal Gaussians trained for '
+                       f'{epochs} epochs with alignment graphs (~{np.mean([len(q) for q in seqs]):.0f} '
+                       'phones per utterance) -> Viterbi alignment; in memory, audio resident on the '
+                       'device',
+           'unit': 'frames/s', 'value': total / stage_sum, 'wall_s': stage_sum,
+           'wall_s_with_synthesis': wall, 'stages_s': walls, 'epoch_s': epoch_s, 'epochs': epochs, 'frames': total,
+           'utterances': len(lens), 'audio_bytes': audio_bytes,
+           'training_frames_per_s': total * epochs / walls['training'],
+           'features_frames_per_s': total / walls['features'],
+           'viterbi_frames_per_s': total / walls['viterbi_align'],
+           'elbo_per_frame_by_epoch': elbos, 'elbo_monotone': bool(all(b >= a - 1e-7 * abs(a) for a, b in zip(elbos, elbos[1:]))),
+           'aligned_frames': int(sum(len(p) for p in paths)),
+           'pcie_note': f'the {audio_bytes / 1e6:.0f} MB of int16 samples would add '
+                        f'{audio_bytes / 63e9 * 1e3:.1f} ms over PCIe (63 GB/s) when they start on the host',
+           'kernels': kern}
+    if not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline_config5(signals, seqs, units, ploop, mean, var, epochs,
+                                                   n_comp, total, cpu_sample)
+    return out
+
+
+def cpu_baseline_config5(signals, seqs, units, ploop, mean, var, epochs, n_comp, total, m):
+    """The same stages on the host for a sample of `m` utterances, with the CPU restatements of
+    the reference (oracle/features_oracle.py, graph_oracle.py, torch_port.hmm_elbo with the
+    alignment graph's pdf ids, beer_oracle.best_path), projected to the corpus: stage time x
+    (utterances / m) (x epochs for training)."""
+    from oracle import beer_oracle as orc, features_oracle as fo, graph_oracle as go, torch_port as tp
+    S = 3 * N_PHONES
+    nutt = len(signals)
+    pick = list(range(0, nutt, max(1, nutt // m)))[:m]
+    t = {}
+    t0 = time.perf_counter()
+    sig_h = [signals[u].cpu().numpy() for u in pick]
+    feats = [fo.extract(sg) for sg in sig_h]
+    t['features'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cgs = [go.compile_graph(go.alignment_graph(seqs[u], units, beer.graph.Graph)) for u in pick]
+    t['alignment_graphs'] = time.perf_counter() - t0
+    D = feats[0].shape[1]
+    KK = S * n_comp
+    gen = torch.Generator().manual_seed(5)
+    prior = (mean.cpu().float().repeat(KK, 1), torch.ones(KK, 1), torch.ones(KK, 1),
+             var.cpu().float().repeat(KK, 1))
+    post = (prior[0] + .1 * torch.randn(KK, D, generator=gen) * var.cpu().float().sqrt(),) + prior[1:]
+    w = torch.ones(S, n_comp)
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    for f, cg in zip(feats, cgs):
+        Xh = torch.from_numpy(f).float()
+        with np.errstate(divide='ignore'):
+            init, fin, trans = [torch.from_numpy(np.log(np.asarray(a, dtype=np.float32))) for a in cg[:3]]
+        tp.hmm_elbo(Xh, post, prior, w, w, init, fin, trans, total, trans_posteriors=False,
+                    order=list(cg[3]))
+    t['training_one_epoch'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for f, cg in zip(feats, cgs):
+        with np.errstate(divide='ignore'):
+            init, fin, trans = [np.log(np.asarray(a, dtype=np.float64)) for a in cg[:3]]
+        pc = np.random.RandomState(0).randn(len(f), len(init))
+        orc.best_path(pc, init, fin, trans)
+    t['viterbi_align'] = time.perf_counter() - t0
+    torch.set_num_threads(nt)
+    scale = nutt / float(len(pick))
+    proj = {'features': t['features'] * scale, 'alignment_graphs': t['alignment_graphs'] * scale,
+            'training': t['training_one_epoch'] * scale * epochs, 'viterbi_align': t['viterbi_align'] * scale}
+    wall = sum(proj.values())
+    return {'value': total / wall, 'unit': 'frames/s', 'cores': int(min(16, os.cpu_count() or 1)),
+            **host_cores(), 'kind': 'port', 'projected_wall_s': wall, 'projected_stages_s': proj,
+            'sample_stages_s': t,
+            'sample': f'{len(pick)} of the {nutt} utterances through the CPU restatements of the '
+                      'reference stage by stage (features: numpy, one core; alignment graphs: the '
+                      'reference\'s pure-Python builder + compile; training: torch replay of '
+                      'evidence_lower_bound with the alignment graph, one epoch; Viterbi: numpy '
+                      'best_path on the graph\'s states), projected to the corpus and the epochs'}
+
+
+# --------------------------------------------------------------------------------------------
 # config 1: diagonal GMM K = 8, D = 2, 1000 frames -- the latency of ONE iteration
 # --------------------------------------------------------------------------------------------
 
@@ -1100,6 +1300,9 @@ def worker(args):
     if args.config4_only:
         print(json.dumps(run_vae(args, device)), flush=True)
         return
+    if args.config5_only:
+        print(json.dumps(run_config5(args, device)), flush=True)
+        return
     run = run_gmm if args.config == 2 else run_hmm
     out = run(args, rank, world, device, backend)
     if args.config == 2 and not args.no_config3:
@@ -1130,6 +1333,9 @@ def worker(args):
             out['config4'] = run_vae(args, device)
         if rank == 0 and world == 1 and not args.no_config1:
             out['config1'] = run_config1(args, device)
+        if rank == 0 and world == 1 and not args.no_config5:
+            torch.cuda.empty_cache()
+            out['config5'] = run_config5(args, device)
     if rank == 0:
         if args.config == 2:
             out['summary'] = summary(out)      # (last key: the tail of the line shows it)
@@ -1170,6 +1376,10 @@ def main():
                     help='default line: skip the config4 sub-object (HMM-VAE, one process)')
     ap.add_argument('--no-config1', action='store_true',
                     help='default line: skip the config1 sub-object (latency of one small iteration)')
+    ap.add_argument('--no-config5', action='store_true',
+                    help='default line: skip the config5 sub-object (recipe end to end)')
+    ap.add_argument('--config5-only', action='store_true',
+                    help='print the config5 sub-object alone')
     ap.add_argument('--config4-only', action='store_true',
                     help='print the config4 sub-object alone (no config 2 / 3 runs)')
     ap.add_argument('--scaling', default='weak', choices=('weak', 'strong'),

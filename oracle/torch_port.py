@@ -268,11 +268,15 @@ def hmm_forward_backward(llhs, init_lp, final_lp, trans_lp):
 
 
 def hmm_elbo(X, post, prior, w_post, w_prior, init_lp, final_lp, trans_lp, datasize,
-             trans_posteriors=True):
+             trans_posteriors=True, order=None):
     '''One utterance through a phone-loop HMM whose S states each have a G-component
     diagonal mixture (pdf ids = states).  post / prior: Normal-Gamma std params of
     the S*G Gaussians; w_post / w_prior [S, G].  Returns (value, Gaussian stats
-    [S*G, 2D+2], weight stats [S, G], summed transition posteriors [S, S]).'''
+    [S*G, 2D+2], weight stats [S, G], summed transition posteriors [S, S]).
+    `order` (an inference graph's `pdf_id_mapping`, e.g. an alignment graph: `beer hmm
+    accumulate --alis`): the graph's states read the per-pdf log-likelihoods through it
+    (modelset.py:140-146) and their posteriors are added back column by column in a Python
+    loop (modelset.py:148-154), as the reference does.'''
     T, D = X.shape
     S, G = w_post.shape
     one = torch.ones(T, 1, dtype=X.dtype)
@@ -285,8 +289,17 @@ def hmm_elbo(X, post, prior, w_post, w_prior, init_lp, final_lp, trans_lp, datas
     w = pc + lw[None]
     log_norm = torch.logsumexp(w, dim=-1)
     comp = torch.exp(w - log_norm[:, :, None])
-    gamma, xi = hmm_forward_backward(log_norm, init_lp, final_lp, trans_lp)
-    exp_llh = (log_norm * gamma).sum(-1)
+    if order is None:
+        gamma, xi = hmm_forward_backward(log_norm, init_lp, final_lp, trans_lp)
+        exp_llh = (log_norm * gamma).sum(-1)
+    else:
+        idx = torch.as_tensor(order, dtype=torch.long)
+        pc_llhs = log_norm[:, idx]
+        g_u, xi = hmm_forward_backward(pc_llhs, init_lp, final_lp, trans_lp)
+        exp_llh = (pc_llhs * g_u).sum(-1)
+        gamma = torch.zeros_like(log_norm)
+        for i, pdf_id in enumerate(order):
+            gamma[:, pdf_id] += g_u[:, i]
     kl = (ng_log_norm(*prior) - ng_log_norm(*post)
           - torch.sum(exp_T * (ng_natural(*prior) - ng_natural(*post)), dim=-1)).sum()
     kl = kl + (dirset_log_norm(w_prior) - dirset_log_norm(w_post)

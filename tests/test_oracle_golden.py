@@ -422,4 +422,21 @@ def test_torch_port_hmm_matches_oracle():
     assert_close(float(value), ref['value'], 1e-12, 'value')
     assert_close(acc.numpy(), ref['acc'][0][0], 1e-12, 'Gaussian statistics')
     assert_close(wstats.numpy(), ref['acc'][0][1], 1e-12, 'weight statistics')
+    # ... and through an alignment graph whose pdf ids repeat (phones 1, 0, 1)
+    order = np.asarray([3, 4, 5, 0, 1, 2, 3, 4, 5])
+    Sa = len(order)
+    ta = np.full((Sa, Sa), -np.inf)
+    for s_ in range(Sa):
+        ta[s_, s_] = np.log(.75)
+        if s_ + 1 < Sa:
+            ta[s_, s_ + 1] = np.log(.25)
+    ia = np.where(np.arange(Sa) == 0, 0., -np.inf)
+    fa = np.where(np.arange(Sa) == Sa - 1, np.log(.25), -np.inf)
+    ref_a = orc.hmm_elbo_step(X, groups, dict(init=ia, final=fa, trans=ta, order=order), datasize=1000)
+    value, acc, wstats, _ = tp.hmm_elbo(t(X), tuple(map(t, post)), tuple(map(t, prior)), t(wp), t(w0),
+                                        t(ia), t(fa), t(ta), 1000, trans_posteriors=False,
+                                        order=order.tolist())
+    assert_close(float(value), ref_a['value'], 1e-12, 'value (alignment graph)')
+    assert_close(acc.numpy(), ref_a['acc'][0][0], 1e-12, 'Gaussian statistics (alignment graph)')
+    assert_close(wstats.numpy(), ref_a['acc'][0][1], 1e-12, 'weight statistics (alignment graph)')
     assert_close(xi.numpy(), ref['trans_resps'].sum(0), 1e-12, 'transition posteriors')
