@@ -11,11 +11,12 @@ receives their sample-averaged statistics as a dense [T, Q] tensor
 forward-backward / `beer_dense_accumulate`, with `beer_dense_llh_backward` and
 `beer_suffstats_backward` on the way back (`dense_statistics=True`: always).
 
-Quirk Q7 (kept behind a switch): the reference subtracts a [T] vector from a
-[T, 1] one (vae.py:84-86) and returns a [T, T] matrix whose sum is T times
-the intended value -- and T^2 memory.  `reference_broadcast=True` returns
-T * (llh - kl) per frame, which has the same sum and gradient without the
-matrix; the default returns the intended per-frame value.
+Quirk Q7 (the DEFAULT, because it is the reference's result): the reference subtracts a
+[T] vector from a [T, 1] one (vae.py:84-86) and returns a [T, T] matrix whose sum is T
+times the per-frame value -- and T^2 memory.  `VAE(...)` returns T * (llh - kl) per frame:
+the same sum, the same gradient scale, the same ELBO as the reference, without the
+matrix.  `VAE(..., reference_broadcast=False)` returns the per-frame value the code
+evidently meant (a deviation from the reference: ELBO and gradients are T times smaller).
 """
 
 import os
@@ -45,8 +46,10 @@ class MeanLogDiagCov(torch.nn.Module):
 
 class VAE(Model):
 
-    def __init__(self, prior, encoder, decoder, reference_broadcast=False,
+    def __init__(self, prior, encoder, decoder, reference_broadcast=True,
                  dense_statistics=None):
+        # reference_broadcast=True (default): T x the per-frame value, the reference's own
+        # result (its [T, 1] - [T] broadcast, vae.py:84-86); False: the per-frame value
         super().__init__()
         self.prior = prior
         self.encoder = encoder
@@ -86,7 +89,10 @@ class VAE(Model):
         return self.prior.mean_field_factorization()
 
     def sufficient_statistics(self, data):
-        return _hip.on_device(data)
+        # The frames go where the NETWORKS are (plain torch.nn, out of the hot path's scope):
+        # a notebook that leaves its model on the host (examples/HMM-VAE.ipynb) runs them
+        # there; the prior's kernels get the latent samples on the GPU either way.
+        return data.to(self.enc_mean_layer.weight.device)
 
     def expected_log_likelihood(self, data, nsamples=1, llh_weight=1., kl_weight=1.,
                                 **kwargs):
@@ -96,7 +102,9 @@ class VAE(Model):
         # local KL divergence by sampling, so that any prior can be plugged in
         samples = posts.sample(nsamples)                          # [T, ns, Dz]
         ent = -posts(posts.sufficient_statistics(samples).mean(dim=1), pdfwise=True)
-        flat = samples.reshape(-1, samples.shape[-1])
+        flat_nn = samples.reshape(-1, samples.shape[-1])     # where the networks are
+        # (the prior's kernels run on the GPU; `.to` is differentiable: gradients flow back)
+        flat = flat_nn if flat_nn.is_cuda else flat_nn.to(_hip.require_device())
         cov_type = self._prior_cov_type()
         if cov_type is not None and nsamples == 1 and \
                 not getattr(self, 'dense_statistics', False):
@@ -117,7 +125,7 @@ class VAE(Model):
         local_kl_div = xent.to(ent.device) - ent
 
         # expected log-likelihood with the reparameterisation trick
-        pdfs = self.pdfs(flat)
+        pdfs = self.pdfs(flat_nn)
         r_data = data[:, None, :].expand(-1, nsamples, -1).reshape(-1, data.shape[-1])
         llh = pdfs(pdfs.sufficient_statistics(r_data), pdfwise=True)
         llh = llh.reshape(T, nsamples).mean(dim=1)

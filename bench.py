@@ -132,6 +132,46 @@ def pmc_traffic(kernel_key):
     return None
 
 
+def kernel_times_entry(kernel_key):
+    """The committed profile of a kernel's launches (profiles/r*_kernel_times.json, written by
+    tools/trace_stats.py from `rocprofv3 --kernel-trace` of the same command at the bench's own
+    step counts, warm-up launches dropped), newest round first; ({}, None) if absent."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_times.json')), reverse=True):
+        try:
+            return json.load(open(path))['kernels'][kernel_key], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return {}, None
+
+
+def profiled(kernel_key, roof, per_launch_scale=1.):
+    """What the committed profiles say about the roofline's kernel: `traffic` (HBM bytes per
+    launch from the PMC passes, `traffic_source`), and the same fraction priced on the PROFILED
+    average launch time (`frac_profiled`, `profiled_avg_launch_ms`, `profiled_clock_ghz`): the
+    line's own `frac` uses the HIP events of this run."""
+    out = {'traffic': None, 'traffic_source': None}
+    if not kernel_key:
+        return out
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')), reverse=True):
+        try:
+            json.load(open(path))['kernels'][kernel_key]
+        except Exception:
+            continue
+        t = pmc_traffic(kernel_key)
+        if t:
+            out['traffic'], out['traffic_source'] = t * per_launch_scale, os.path.relpath(path, ROOT)
+        out['profiled_clock_ghz'] = pmc_entry(kernel_key).get('clock_ghz')
+        break
+    kt, src = kernel_times_entry(kernel_key)
+    if kt.get('avg_ms') and roof.get('avg_launch_ms') and roof.get('frac') is not None:
+        out['profiled_avg_launch_ms'] = kt['avg_ms'] * per_launch_scale
+        out['frac_profiled'] = roof['frac'] * roof['avg_launch_ms'] / (kt['avg_ms'] * per_launch_scale)
+        out['profiled_source'] = src
+    return out
+
+
 def pmc_entry(kernel_key):
     'The committed PMC summary of a kernel (profiles/r*_pmc.json), newest round first; {} if absent.'
     import glob
@@ -495,10 +535,10 @@ def run_gmm(args, rank, world, device, backend):
         'm_step': m_step_mode(optim),
         'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'],
                      'peak': peak, 'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / peak,
-                     'traffic': pmc_traffic(pmc_key), 'avg_launch_ms': kern[dom]['ms'],
-                     'note': note},
+                     'avg_launch_ms': kern[dom]['ms'], 'note': note},
         'kernels': kern,
     }
+    out['roofline'].update(profiled(pmc_key, out['roofline']))
     if exact:
         out['f32_exact'] = exact
     if not args.no_cpu_baseline and world == 1:
@@ -725,10 +765,12 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
     fpl = kern[dom]['frames_per_launch']
     roof = {'bound': bound, 'kernel': dom, 'achieved': achieved, 'peak': peak,
             'unit': 'GB/s' if bound == 'hbm' else 'TFLOP/s', 'frac': achieved / peak,
-            'traffic': pmc_traffic(pmc_key), 'avg_launch_ms': kern[dom]['ms'],
+            'avg_launch_ms': kern[dom]['ms'],
             'frac_of_bf16_mfma_peak': None if bound == 'hbm' else achieved / PEAK_TFLOPS['bf16'],
-            'valu_wave_insts_per_frame': (pmc['SQ_INSTS_VALU'] / fpl) if 'SQ_INSTS_VALU' in pmc else None,
-            'counter_bytes_per_frame': (pmc_traffic(pmc_key) / fpl) if pmc_traffic(pmc_key) else None,
+            'valu_wave_insts_per_frame': (pmc['SQ_INSTS_VALU'] / fpl)
+            if 'SQ_INSTS_VALU' in pmc and not shard_of else None,
+            'counter_bytes_per_frame': (pmc_traffic(pmc_key) / fpl)
+            if pmc_traffic(pmc_key) and not shard_of else None,
             'algorithmic_bytes_per_frame': 4 * D,
             'note': 'achieved = algorithmic flops of the dominant call (2*K*Q per frame: one of '
                     'the two products of the iteration; the fused accumulation also recomputes '
@@ -737,6 +779,8 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
                     'products on the bf16 MFMA with three pieces per operand (6 MFMAs per '
                     f'product), see frac_of_bf16_mfma_peak.  Iteration: 4*K*Q = {4 * Kc * Qd} '
                     'flop per frame, 160 B of frames per frame.'}
+    # (a shard's launches are smaller than the profiled full-size ones: no profiled fraction)
+    roof.update(profiled(None if shard_of else pmc_key, roof))
     out = {
         'metric': 'frames/sec per VB iteration (E+M)', 'value': datasize * steps / elapsed,
         'unit': 'frames/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
@@ -783,21 +827,68 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
 LATENT = 64
 
 
-def run_vae(args, device, frames=1_000_000, steps=3, warmup=1):
+def cpu_baseline_vae_prior(cov, budget_s=8.):
+    """The prior hot path of config 4 on the host: per utterance phi(z), stats @ E[T]^T, the Python
+    forward-backward loop over the dense 120 x 120 matrix, autograd back to the samples,
+    gamma^T @ stats (oracle/torch_port.py: vae_hmm_prior_path, the reference's op sequence,
+    vae.py:63-86 / hmm.py:73-100) on a bounded sample of utterances."""
+    from oracle import torch_port as tp
+    g = torch.Generator().manual_seed(6)
+    S, Dz = 3 * N_PHONES, LATENT
+    if cov == 'full':
+        post = (torch.randn(S, Dz, generator=g), torch.ones(S, 1),
+                torch.eye(Dz).repeat(S, 1, 1) / Dz, torch.full((S, 1), float(Dz)))
+    else:
+        post = (torch.randn(S, Dz, generator=g), torch.ones(S, 1), torch.ones(S, 1), torch.ones(S, Dz))
+    trans = torch.full((S, S), -float('inf'))
+    for st in range(S):
+        trans[st, st] = np.log(.75)
+        if st % 3 < 2:
+            trans[st, st + 1] = np.log(.25)
+        else:
+            trans[st, ::3] = np.log(.25 / N_PHONES)
+    init = torch.where(torch.arange(S) % 3 == 0, torch.tensor(np.log(1. / N_PHONES)),
+                       torch.tensor(-float('inf'))).float()
+    fin = torch.where(torch.arange(S) % 3 == 2, torch.tensor(np.log(.25)),
+                      torch.tensor(-float('inf'))).float()
+    rng = np.random.RandomState(4)
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    tp.vae_hmm_prior_path(torch.randn(50, Dz, generator=g), cov, post, init, fin, trans)
+    t0 = time.perf_counter()
+    frames = utts = 0
+    while time.perf_counter() - t0 < budget_s:
+        T = int(rng.randint(200, 401))
+        tp.vae_hmm_prior_path(torch.randn(T, Dz, generator=g), cov, post, init, fin, trans)
+        frames += T
+        utts += 1
+    dt = time.perf_counter() - t0
+    cores = int(torch.get_num_threads())
+    torch.set_num_threads(nt)
+    return {'value': frames / dt, 'unit': 'frames/s', 'cores': cores, **host_cores(), 'kind': 'port',
+            'sample': f'{utts} utterances ({frames} latent samples) through the prior hot path of '
+                      f'config 4 ({cov} Gaussians, 64-d latent, 120 states): torch-CPU replay of the '
+                      f'reference op sequence incl. autograd, {dt:.1f} s'}
+
+
+def run_vae(args, device, frames=5_000_000, n_minibatches=5, warmup=1):
     '''BASELINE config 4 (`configs[3]`): HMM-VAE, D = 40 frames, residual feed-forward
     encoder / decoder (2 blocks x 128, beer/nnet), 64-dimensional Normal latent, phone-loop
-    HMM prior (40 phones x 3 states, one Gaussian per state), one minibatch of 1 M frames in
-    utterances of 200-400 frames out of the 5 M-frame corpus (datasize).  Per covariance type
+    HMM prior (40 phones x 3 states, one Gaussian per state), ONE EPOCH over the 5 M-frame corpus
+    in five minibatches of ~1 M frames (utterances of 200-400 frames).  Per covariance type
     of the prior: the whole VAE step (ELBO + backward to the networks + statistics +
     natural-gradient / Adam update) and the prior's hot path alone -- statistics of the latent
     samples -> per-state log-likelihoods -> forward-backward -> gradient w.r.t. the
     statistics and the samples -> accumulation (beer/models/vae.py:63-89, hmm.py:73-100) --
     with the HIP-event time of every C-ABI call and the roofline of the dominant one.
-    Rank 0 of a one-process run only: the minibatch does not shard.'''
-    lengths = hmm_corpus(frames)
-    total = sum(lengths)
+    Rank 0 of a one-process run only: a minibatch does not shard.'''
+    lengths_all = hmm_corpus(frames)
+    per = -(-len(lengths_all) // n_minibatches)
+    batches = [lengths_all[i:i + per] for i in range(0, len(lengths_all), per)]
+    total = sum(lengths_all)
     g = torch.Generator(device=device).manual_seed(4)
     X = torch.randn(total, D, generator=g, device=device)
+    Xs = torch.split(X, [sum(b) for b in batches])
     names = ('beer_mixtureset_estep', 'beer_hmm_posteriors_fused', 'beer_hmm_forward_backward',
              'beer_hmm_gather', 'beer_hmm_scatter', 'beer_frames_llh_backward', 'beer_pack_resps',
              'beer_normal_accumulate_packed', 'beer_normal_accumulate',
@@ -809,12 +900,13 @@ def run_vae(args, device, frames=1_000_000, steps=3, warmup=1):
                 'beer_normal_accumulate', 'beer_dense_llh', 'beer_dense_llh_backward',
                 'beer_dense_accumulate')
     out = {'workload': f'configs[3]: HMM-VAE, D={D}, latent {LATENT}, residual encoder/decoder '
-                       f'2x128, phone-loop prior {N_PHONES}x3 states (1 Gaussian per state), one '
-                       f'minibatch of {total} fp32 frames in {len(lengths)} utterances of the '
-                       '5 M-frame corpus, 1 sample per frame (the prior runs its frame kernels on '
-                       'the samples; `dense_route`: the [T, Q] statistics route that several '
-                       'samples per frame take, same minibatch)',
-           'unit': 'frames/s', 'steps': steps, 'warmup': warmup}
+                       f'2x128, phone-loop prior {N_PHONES}x3 states (1 Gaussian per state), one EPOCH '
+                       f'over the {total}-frame corpus in {len(batches)} minibatches of '
+                       f'~{total // len(batches)} fp32 frames ({len(lengths_all)} utterances), 1 sample '
+                       'per frame (the prior runs its frame kernels on the samples; `dense_route`: '
+                       'the [T, Q] statistics route that several samples per frame take, ONE '
+                       'minibatch)',
+           'unit': 'frames/s', 'minibatches': len(batches), 'warmup_minibatches': warmup}
     S = 3 * N_PHONES
     for cov in ('diagonal', 'full'):
         Qz = {'diagonal': 2 * LATENT + 2, 'full': LATENT * LATENT + LATENT + 2}[cov]
@@ -825,83 +917,89 @@ def run_vae(args, device, frames=1_000_000, steps=3, warmup=1):
         cjg = beer.VBConjugateOptimizer(vae.mean_field_factorization(), lrate=.1)
         optim = beer.VBOptimizer(cjg, torch.optim.Adam(vae.parameters(), lr=1e-3))
 
-        def vae_step():
+        def vae_step(b):
             optim.init_step()
-            elbo = beer.accumulate_elbo(vae, (X, lengths), datasize=5_000_000)
+            elbo = beer.accumulate_elbo(vae, (Xs[b], batches[b]), datasize=total)
             elbo.backward()
             optim.step()
             return elbo
 
         Z = torch.randn(total, LATENT, generator=g, device=device)
+        Zs = torch.split(Z, [sum(b) for b in batches])
 
-        def prior_path(dense=False):
-            z = Z.clone().requires_grad_(True)
+        def prior_path(b, dense=False):
+            z = Zs[b].clone().requires_grad_(True)
             stats = beer.kernels.differentiable_stats(z, cov, 1) if dense else \
                 beer.kernels.sample_stats(z, cov)
-            exp_llh = prior.expected_log_likelihood(stats, utt_lengths=lengths)
+            exp_llh = prior.expected_log_likelihood(stats, utt_lengths=batches[b])
             exp_llh.sum().backward()
             acc = prior.accumulate(stats.detach())
             prior.clear_cache()
             return acc
 
         sub = {}
-        for key, fn in (('vae_step', vae_step), ('prior_hot_path', prior_path),
-                        ('dense_route', lambda: prior_path(dense=True))):
-            for _ in range(warmup):
-                fn()
+        for key, fn, nb in (('vae_step', vae_step, len(batches)),
+                            ('prior_hot_path', prior_path, len(batches)),
+                            ('dense_route', lambda b: prior_path(b, dense=True), 1)):
+            for b in range(warmup):
+                fn(b)
             torch.cuda.synchronize()
             with KernelTimer(names) as kt:
                 t0 = time.perf_counter()
-                for _ in range(steps):
-                    res = fn()
+                for b in range(nb):
+                    res = fn(b)
                 torch.cuda.synchronize()
-                dt = (time.perf_counter() - t0) / steps
+                dt = time.perf_counter() - t0
+            nfr = sum(sum(batches[b]) for b in range(nb))
             kern = {}
             for nm in names:
                 ms, n = kt.mean_ms(nm)
                 if n:
-                    kern[nm] = {'ms': ms, 'launches_per_step': n / steps}
+                    kern[nm] = {'ms': ms, 'launches_per_minibatch': n / nb}
                     if nm in products:
                         # one [T, Q] x [Q, S] (or its transpose) product, on either route: 2 T Q S
                         # flop (the gradient w.r.t. the samples: 2 T S D (D + 1), the same count)
-                        kern[nm]['tflops'] = 2. * total * Qz * S / (ms * 1e-3) / 1e12
-            sub[key] = {'value': total / dt, 'ms_per_step': 1e3 * dt, 'kernels': kern}
+                        kern[nm]['tflops'] = 2. * (nfr / nb) * Qz * S / (ms * 1e-3) / 1e12
+            sub[key] = {'value': nfr / dt, 'frames': nfr, 'minibatches': nb,
+                        'ms_per_minibatch': 1e3 * dt / nb, 'kernels': kern}
             if key == 'vae_step':
-                sub[key]['elbo_per_frame'] = float(res) / (5_000_000 * len(lengths))
+                sub[key]['ms_per_epoch'] = 1e3 * dt
+                sub[key]['elbo_per_frame_last_minibatch'] = float(res) / (total * len(batches[nb - 1]))
         kern = sub['prior_hot_path']['kernels']
-        dom = max(kern, key=lambda nm: kern[nm]['ms'] * kern[nm]['launches_per_step'])
+        dom = max(kern, key=lambda nm: kern[nm]['ms'] * kern[nm]['launches_per_minibatch'])
+        mb_frames = total / len(batches)
+        pmc_key = {'beer_frames_llh_backward': 'c4_sgrad_kernel', 'beer_mixtureset_estep': 'c4_llhx_kernel',
+                   'beer_normal_accumulate_packed': 'c4_accx_kernel',
+                   'beer_hmm_posteriors_fused': 'c4_fb_wave_kernel',
+                   'beer_hmm_forward_backward': 'c4_fb_wave_kernel'}.get(dom)
         if 'tflops' in kern[dom]:
-            # float32 [T, Q] products on the bf16 matrix pipes, three pieces per operand
-            # (gemm3_kernel, csrc/dense.hip): priced like config 2 against the dense bf16 peak
-            # (HBM bytes per launch of the call's main kernel from the committed PMC passes of the
-            # prior path alone, profiles/r*_pmc.json keys c4_*; None for calls without one)
-            pmc_key = {'beer_frames_llh_backward': 'c4_sgrad_kernel',
-                       'beer_mixtureset_estep': 'c4_llhx_kernel',
-                       'beer_normal_accumulate_packed': 'c4_accx_kernel'}.get(dom)
+            # float32 [T, Q] products on the bf16 matrix pipes, three pieces per operand: priced
+            # like config 2 against the dense bf16 peak
             roof = {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'],
                     'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s',
                     'frac': kern[dom]['tflops'] / PEAK_TFLOPS['bf16'],
-                    'traffic': pmc_traffic(pmc_key) if pmc_key and cov == 'full' else None,
                     'avg_launch_ms': kern[dom]['ms'],
                     'note': f'achieved = 2*T*Q*S algorithmic flop of one [T, Q={Qz}] x [Q, S={S}] '
                             'product (no symmetry discount) / HIP-event time; six bf16 MFMAs per '
                             'float32 product'}
         else:
-            # the dominant call streams [T, Q] / [T, S] arrays: HBM bound; algorithmic bytes =
-            # the latent samples in (and their gradient out) + the posteriors
-            byts = {'beer_suffstats_mean': 4. * total * (LATENT + Qz),
-                    'beer_suffstats_backward': 4. * total * (LATENT + Qz),
-                    'beer_hmm_posteriors_fused': 4. * total * S * 2,
-                    'beer_hmm_forward_backward': 4. * total * S * 2}.get(dom, 4. * total * Qz)
+            # the dominant call streams [T, S] arrays: HBM bound; algorithmic bytes = the per-state
+            # log-likelihoods in and the posteriors out, once
+            byts = {'beer_hmm_posteriors_fused': 4. * mb_frames * S * 2,
+                    'beer_hmm_forward_backward': 4. * mb_frames * S * 2}.get(dom, 4. * mb_frames * Qz)
             roof = {'bound': 'hbm', 'kernel': dom, 'achieved': byts / (kern[dom]['ms'] * 1e-3) / 1e9,
                     'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                    'frac': byts / (kern[dom]['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 'traffic': None,
+                    'frac': byts / (kern[dom]['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS,
                     'avg_launch_ms': kern[dom]['ms'],
-                    'note': 'achieved = algorithmic bytes of the dominant call (its [T, .] arrays '
-                            'once) / HIP-event time'}
+                    'note': 'achieved = algorithmic bytes of the dominant call (its [T, S] arrays '
+                            'once) / HIP-event time; the kernel also keeps its forward columns '
+                            '(fp64) in HBM between the two passes: `traffic`'}
+        roof.update(profiled(pmc_key, roof, per_launch_scale=1.))
         sub['roofline'] = roof
+        if not args.no_cpu_baseline:
+            sub['cpu_baseline'] = cpu_baseline_vae_prior(cov)
         out[cov] = sub
-        del vae, prior, optim, cjg, Z
+        del vae, prior, optim, cjg, Z, Zs
         torch.cuda.empty_cache()
     out['value'] = out['diagonal']['vae_step']['value']
     return out

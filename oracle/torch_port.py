@@ -312,3 +312,36 @@ def hmm_elbo(X, post, prior, w_post, w_prior, init_lp, final_lp, trans_lp, datas
     wstats = wstats.reshape(T, S, G).sum(0)
     acc = joint.reshape(T, S * G).t() @ stats
     return value, acc, wstats, (xi.sum(0) if trans_posteriors else None)
+
+
+# ---------------------------------------------------------------------------
+# The prior of an HMM-VAE (BASELINE config 4): what `VAE.expected_log_likelihood` asks of its
+# HMM prior for one utterance with one sample per frame (vae.py:63-86, hmm.py:73-100) --
+#     phi(z) with mul + cat                      normalgamma.py:20-27 / normalwishart.py:30-38
+#     stats @ E[T]^T                             normalset.py:117-119
+#     the Python forward-backward loop           graph.py:270-326   (on detached values, hmm.py:80)
+#     sum_s gamma l, autograd back to z          hmm.py:87, torch.autograd
+#     gamma^T @ stats                            normalset.py:121-123
+# Pinned on the numpy oracle's `vae_hmm_prior` / `prior_gradient_wrt_samples`
+# (tests/test_oracle_golden.py::test_torch_port_vae_prior_matches_oracle), which are pinned on
+# the reference's G18 goldens.
+# ---------------------------------------------------------------------------
+
+def vae_hmm_prior_path(z, cov_type, post, init_lp, final_lp, trans_lp):
+    """(per-frame value [T], d sum(value) / dz [T, D], accumulated statistics [S, Q]) of an HMM
+    prior with ONE Gaussian per state over the latent samples `z` [T, D]."""
+    z = z.detach().clone().requires_grad_(True)
+    T, D = z.shape
+    one = torch.ones(T, 1, dtype=z.dtype)
+    if cov_type == 'full':
+        quad = (z[:, :, None] * z[:, None, :]).reshape(T, -1)
+        exp_T = nw_exp_stats(*post)
+    else:
+        quad = z ** 2
+        exp_T = ng_exp_stats(*post)
+    stats = torch.cat([z, -.5 * quad, -.5 * one, .5 * one], dim=-1)
+    pc = stats @ exp_T.t() - .5 * D * LOG2PI
+    gamma, _ = hmm_forward_backward(pc.detach(), init_lp, final_lp, trans_lp)
+    value = (pc * gamma).sum(-1)
+    value.sum().backward()
+    return value.detach(), z.grad, gamma.t() @ stats.detach()

@@ -885,6 +885,38 @@ def g16_notebooks():
     save('g16_notebooks', out)
 
 
+def g19_hmm_vae_notebook():
+    '''examples/HMM-VAE.ipynb cells 2-5 and 7-9 (tests/golden/notebook_cells.py: hmm_vae) run on
+    the reference, epochs cut to 8 (HMM alone: 5), the prior's learning rate switched on after
+    3 epochs; the noise of every `posts.sample(5)` and the seeded initial network weights
+    are recorded so that the replay starts from the same numbers.'''
+    import contextlib
+    sys.path.insert(0, HERE)
+    import notebook_cells as nb
+    data, states = nb.hmm_vae_data()
+    noise = []
+    real_randn = torch.randn
+
+    @contextlib.contextmanager
+    def recording():
+        def rec(*a, **k):
+            t = real_randn(*a, **k)
+            noise.append(npy(t))
+            return t
+        torch.randn = rec
+        try:
+            yield
+        finally:
+            torch.randn = real_randn
+    out = {'data': data, 'states': states}
+    for key, val in nb.hmm_vae(beer, data, hmm_epochs=5, epochs=8, update_prior_after_epoch=3,
+                               randomness=recording()).items():
+        out[key] = val
+    assert len(noise) == 8
+    out['noise'] = np.stack(noise)
+    save('g19_hmm_vae_notebook', out)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'notebooks':
         g16_notebooks()
@@ -909,3 +941,4 @@ if __name__ == '__main__':
     g13_fp64()
     g15_features()
     g16_notebooks()
+    g19_hmm_vae_notebook()

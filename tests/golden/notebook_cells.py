@@ -195,3 +195,79 @@ def hmm_align(beer, data, epochs, seed=5):
     return {'loop.elbos': np.asarray(elbos['loop']), 'align.elbos': np.asarray(elbos['align']),
             'loop.posts': _np(models['loop'].posteriors(X)),
             'align.posts': _np(models['align'].posteriors(X, ali_graph))}
+
+
+def hmm_vae_data(seed=7, nsamples=120):
+    'HMM-VAE.ipynb cell 1: the three-state chain of HMM.ipynb with its own means.'
+    rng = np.random.RandomState(seed)
+    trans = np.array([[.5, .5, 0], [0, .5, .5], [.5, 0, .5]])
+    means = [np.array([-1.5, 4.]) * 2, np.array([5., 5.]) * 2, np.array([1., -2.]) * 2]
+    covs = [np.array([[.75, -.5], [-.5, 2.]]), np.array([[2., 1.], [1., .75]]), np.eye(2)]
+    states = np.zeros(nsamples, dtype=int)
+    data = np.zeros((nsamples, 2))
+    data[0] = rng.multivariate_normal(means[0], covs[0])
+    for n in range(1, nsamples):
+        states[n] = rng.choice(3, p=trans[states[n - 1]])
+        data[n] = rng.multivariate_normal(means[states[n]], covs[states[n]])
+    return data, states
+
+
+def hmm_vae(beer, data, hmm_epochs, epochs, update_prior_after_epoch, randomness, nn_init=None,
+            seed=8):
+    '''HMM-VAE.ipynb cells 2-5 (the full-covariance HMM, trained alone first) and 7-9 (a VAE
+    around it: residual encoder / decoder of width 2, `VBOptimizer(VBConjugateOptimizer(lrate=0),
+    Adam)`, `evidence_lower_bound(vae, X, nsamples=5)`, the prior's learning rate switched on
+    after `update_prior_after_epoch` epochs).  `randomness` is the caller's context manager
+    around the epochs: the reference side records the noise `posts.sample` draws, the
+    replay feeds it back.  `nn_init` (name -> array): initial network weights to load (the
+    replay takes the reference's; None: keep the seeded initialisation and report it).'''
+    cgraph = _loop_graph(beer).compile()
+    data_mean = torch.from_numpy(data.mean(axis=0)).float()
+    data_var = torch.from_numpy(np.cov(data.T)).float()
+    torch.manual_seed(seed)
+    modelset = beer.NormalSet.create(data_mean, data_var, size=3, prior_strength=1., noise_std=0,
+                                     cov_type='full')
+    hmm_full = beer.HMM.create(cgraph, modelset).double()
+    X = torch.from_numpy(data)
+    optim = beer.VBConjugateOptimizer(hmm_full.mean_field_factorization(), 1.)
+    hmm_elbos = []
+    for _ in range(hmm_epochs):
+        optim.init_step()
+        elbo = beer.evidence_lower_bound(hmm_full, X, datasize=len(X), viterbi=False)
+        elbo.backward()
+        hmm_elbos.append(float(elbo) / len(X))
+        optim.step()
+    # cell 7
+    encoder = beer.nnet.ResidualFeedForwardNet(dim_in=2, nblocks=2, block_width=2).double()
+    decoder = beer.nnet.ResidualFeedForwardNet(dim_in=2, nblocks=2, block_width=2).double()
+    vae = beer.VAE(hmm_full, encoder, decoder).double()
+    out = {'hmm.elbos': np.asarray(hmm_elbos)}
+    if nn_init is not None:
+        with torch.no_grad():
+            for name, p in vae.named_parameters():
+                p.copy_(torch.from_numpy(np.asarray(nn_init[name])).to(p.device))
+    else:
+        for name, p in vae.named_parameters():
+            out['nn_init.' + name] = _np(p)
+    # cell 8
+    prior_lrate = 1.
+    cjg_optim = beer.VBConjugateOptimizer(vae.mean_field_factorization(), lrate=0)
+    std_optim = torch.optim.Adam(vae.parameters(), lr=1e-3)
+    optim = beer.VBOptimizer(cjg_optim, std_optim)
+    # cell 9
+    elbos = []
+    with randomness:
+        for e in range(epochs):
+            optim.init_step()
+            elbo = beer.evidence_lower_bound(vae, X, nsamples=5)
+            elbo.backward()
+            optim.step()
+            if e >= update_prior_after_epoch:
+                cjg_optim.lrate = prior_lrate
+            elbos.append(float(elbo) / len(X))
+    out['elbos'] = np.asarray(elbos)
+    for name, p in vae.named_parameters():
+        out['nn_final.' + name] = _np(p)
+    post = hmm_full.modelset.original_modelset.means_precisions.posterior
+    out['prior.mean'], out['prior.scale_matrix'] = _np(post.params.mean), _np(post.params.scale_matrix)
+    return out

@@ -52,3 +52,31 @@ def test_hmm_align_notebook():
     got = nb.hmm_align(beer, g['align.data'], epochs=6)
     for key, val in got.items():
         assert_close(val, g[f'align.{key}'], 1e-7, key)
+
+
+def test_hmm_vae_notebook(monkeypatch):
+    '''examples/HMM-VAE.ipynb cells 2-5 and 7-9 (`notebook_cells.hmm_vae`) with
+    `import beer_amd as beer`: the HMM trained alone, then a VAE around it --
+    `VBOptimizer(VBConjugateOptimizer(lrate=0), Adam)`, `evidence_lower_bound(vae, X, nsamples=5)`
+    for 8 epochs, the prior's learning rate switched on after 3 -- from the reference's
+    initial network weights and the noise its `posts.sample(5)` drew (g19_hmm_vae_notebook.npz,
+    make_golden.py: g19_hmm_vae_notebook).  The reference's ELBO is its [T, 1] - [T] broadcast
+    (vae.py:84-86): T times the per-frame sum, which `beer_amd.VAE` returns by default.'''
+    import contextlib
+    import torch
+    from beer_amd.dists import normaldiag
+    g = load_golden('g19_hmm_vae_notebook')
+    nn_init = {k[len('nn_init.'):]: g[k] for k in g if k.startswith('nn_init.')}
+    draws = iter(g['noise'])
+
+    def replay(*shape, **conf):
+        t = torch.from_numpy(next(draws).copy())
+        return t.to(dtype=conf.get('dtype', t.dtype), device=conf.get('device', 'cpu'))
+    monkeypatch.setattr(normaldiag, '_randn', replay)
+    got = nb.hmm_vae(beer, g['data'], hmm_epochs=5, epochs=8, update_prior_after_epoch=3,
+                     randomness=contextlib.nullcontext(), nn_init=nn_init)
+    assert_close(got['hmm.elbos'], g['hmm.elbos'], TOL, 'HMM alone')
+    assert_close(got['elbos'], g['elbos'], 1e-7, 'VAE ELBO per epoch')
+    for key in got:
+        if key.startswith('nn_final.') or key.startswith('prior.'):
+            assert_close(got[key], g[key], 1e-6, key)

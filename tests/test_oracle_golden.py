@@ -440,3 +440,35 @@ def test_torch_port_hmm_matches_oracle():
     assert_close(acc.numpy(), ref_a['acc'][0][0], 1e-12, 'Gaussian statistics (alignment graph)')
     assert_close(wstats.numpy(), ref_a['acc'][0][1], 1e-12, 'weight statistics (alignment graph)')
     assert_close(xi.numpy(), ref['trans_resps'].sum(0), 1e-12, 'transition posteriors')
+
+
+@pytest.mark.parametrize('cov', ['diagonal', 'full'])
+def test_torch_port_vae_prior_matches_oracle(cov):
+    """bench.py's config-4 cpu_baseline (oracle/torch_port.py: vae_hmm_prior_path -- the
+    reference's op sequence incl. torch autograd) against the numpy oracle's `vae_hmm_prior`
+    and `prior_gradient_wrt_samples`, which the CPU suite pins on the reference's G18 goldens."""
+    import torch
+    from oracle import torch_port as tp
+    rng = np.random.RandomState(3)
+    S, D, T = 6, 5, 37
+    if cov == 'full':
+        A = rng.randn(S, D, D) * .3
+        W = np.einsum('sij,skj->sik', A, A) + np.eye(D) * .5
+        post = (rng.randn(S, D), 1 + rng.rand(S, 1), W, D + 1 + rng.rand(S, 1))
+    else:
+        post = (rng.randn(S, D), 1 + rng.rand(S, 1), 2 + rng.rand(S, 1), 1 + rng.rand(S, D))
+    trans = np.full((S, S), -np.inf)
+    for s_ in range(S):
+        trans[s_, s_] = np.log(.6)
+        trans[s_, (s_ + 1) % S] = np.log(.4)
+    init = np.where(np.arange(S) == 0, 0., -np.inf)
+    fin = np.where(np.arange(S) >= S - 2, np.log(.5), -np.inf)
+    Z = rng.randn(T, D) * 1.3
+    value, resps, exp_T = orc.vae_hmm_prior(cov, Z, post, dict(init=init, final=fin, trans=trans,
+                                                                order=np.arange(S)))
+    grad = orc.prior_gradient_wrt_samples(cov, Z, resps, exp_T)
+    t = lambda a: torch.from_numpy(np.asarray(a))          # noqa: E731
+    v, g, acc = tp.vae_hmm_prior_path(t(Z), cov, tuple(map(t, post)), t(init), t(fin), t(trans))
+    assert_close(v.numpy(), value, 1e-12, 'per-frame value')
+    assert_close(g.numpy(), grad, 1e-11, 'gradient w.r.t. the samples')
+    assert_close(acc.numpy(), resps.T @ orc.SUFFSTATS[cov](Z), 1e-12, 'accumulated statistics')

@@ -37,6 +37,11 @@ def main():
     tag = ''
     if dirs and dirs[0].startswith('--tag='):
         tag, dirs = dirs[0][len('--tag='):] + '_', dirs[1:]
+    # --skip=W/N: the first W of every N full-size launches of a kernel are warm-up steps
+    skip = (0, 1)
+    if dirs and dirs[0].startswith('--skip='):
+        a, b = dirs[0][len('--skip='):].split('/')
+        skip, dirs = (int(a), int(b)), dirs[1:]
     out = collections.defaultdict(dict)
     for i, d in enumerate(dirs, start=1):
         # (gpurun merges a new run's files into the local directory: take the newest)
@@ -51,11 +56,14 @@ def main():
                 continue
             keep.append(r)
             dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
-            per[key][r['Counter_Name']].append((float(r['Counter_Value']), dur))
+            per[key][r['Counter_Name']].append((int(r['Start_Timestamp']), float(r['Counter_Value']), dur))
         for key, counters in per.items():
             for name, vals in counters.items():
+                vals = [(v, t) for _, v, t in sorted(vals)]
                 big = max(v for v, _ in vals)
                 full = [(v, t) for v, t in vals if v > .5 * big] or vals     # full-size launches
+                drop = int(round(len(full) * skip[0] / float(skip[1])))
+                full = full[drop:] or full                                   # (warm-up steps dropped)
                 out[key][name] = sum(v for v, _ in full) / len(full)
                 out[key][name + '_ms'] = sum(t for _, t in full) / len(full)
         with open(os.path.join(ROOT, 'profiles', f'{rnd}_pmc_{tag}pass{i}.csv'), 'w', newline='') as g:
