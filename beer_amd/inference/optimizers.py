@@ -93,8 +93,11 @@ class VBConjugateOptimizer:
         for p in members:
             if getattr(p, '_callbacks', None) and not p.callbacks_device_only():
                 return False                      # callbacks that run host code / host copies
-            tensors = tuple(p.posterior._tensors()) + tuple(p.prior._tensors()) + (p.stats,)
-            if not all(t.is_cuda for t in tensors):
+            try:
+                tensors = tuple(p.posterior._tensors()) + tuple(p.prior._tensors()) + (p.stats,)
+            except AttributeError:
+                return False                      # (not a ConjugateBayesianParameter: eager)
+            if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in tensors):
                 return False
         return True
 
