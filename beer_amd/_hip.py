@@ -124,7 +124,8 @@ class Batch(ctypes.Structure):
                 ('frame_off', c_p), ('llh_off', c_p), ('graph_id', c_p),
                 ('graphs', c_p), ('pdf_off', c_p), ('pdf_ids', c_p),
                 ('max_degree', ctypes.c_int32), ('max_hubs', ctypes.c_int32),
-                ('max_hub_members', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('max_hub_members', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('order', c_p)]
 
 
 class FeaConf(ctypes.Structure):

@@ -769,9 +769,16 @@ constexpr int kWvWaves = BEER_FB_WAVES; // utterances (waves) per workgroup
 #define BEER_FB_PF 4
 #endif
 constexpr int kWvPF = BEER_FB_PF;      // steps of look-ahead of the global loads
+#ifndef BEER_FB_RESCALE
+#define BEER_FB_RESCALE 2
+#endif
+constexpr int kWvRescale = BEER_FB_RESCALE;   // a column is rescaled every kWvRescale-th frame (divides kWvPF)
+static_assert(kWvPF % kWvRescale == 0, "the rescaled frames are fixed positions of the unrolled loop");
 #ifndef BEER_FB_OCC
 #define BEER_FB_OCC 4                  // waves per SIMD the linear-domain kernel is compiled for
 #endif
+
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));     // a 64-bit buffer word
 
 template <typename T> struct Lin;
 template <> struct Lin<float> {
@@ -787,8 +794,11 @@ template <> struct Lin<float> {
     // sum over the wave of non-negative terms <= ~1
     static __device__ __forceinline__ double wsum(double v) {
         const float s = wave_sum((float)v);
-        // (uniform; the float sum has lost nothing that matters unless it is tiny)
-        if (__builtin_amdgcn_readfirstlane(s > 1.0e-30f) != 0) return (double)s;
+        // (uniform; the float sum has lost nothing that matters unless it is tiny.  The test
+        // is the scalar unit's: for a non-negative float, s > 1e-30f is an integer comparison
+        // of the bit patterns; a NaN passes and is returned as it is)
+        const int bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s));
+        if (bits > 0x0DA24260) return (double)s;
         return wave_sum(v);
     }
 };
@@ -796,29 +806,51 @@ template <> struct Lin<double> {
     static __device__ __forceinline__ double ex(double d) { return exp(d); }
     static __device__ __forceinline__ double wsum(double v) { return wave_sum(v); }
 };
+// a wave-uniform 64-bit value, moved to SGPRs
+template <typename V>
+__device__ __forceinline__ V uniform64(V v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(V, ((unsigned long long)hi << 32) | lo);
+}
+// maximum of a float over the wave (NaN if any lane holds one): on the order-preserving
+// integer image of the floats, one v_max_i32 with a DPP operand per step instead of a move
+// and two quieting operations around every v_max_f32
+__device__ __forceinline__ float wave_fmax(float v) {
+    int i = __builtin_bit_cast(int, v);
+    i ^= (i >> 31) & 0x7fffffff;
+    i = wave_max(i);
+    i ^= (i >> 31) & 0x7fffffff;
+    return __builtin_bit_cast(float, i);
+}
 // biased exponent of a non-negative double (0: zero or denormal)
 __device__ __forceinline__ int expo_field(double v) {
     return (int)((__builtin_bit_cast(unsigned long long, v) >> 52) & 0x7ffull);
 }
 
-template <typename T, int SPL, int DEG, bool FUSED, bool XI>
+template <typename T, int SPL, int DEG, bool FUSED, bool XI, bool ATOMIC>
 __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_wave_kernel(
     beer_batch b, const T* __restrict__ pc, int S_total, T scale, double* __restrict__ alpha_ws,
-    double* __restrict__ hubf_ws, T* __restrict__ out, T resp_scale, int atomic_out,
+    double* __restrict__ hubf_ws, T* __restrict__ out, T resp_scale,
     double* __restrict__ xi_sum, double* __restrict__ gamma0_sum, double* __restrict__ hub_flow,
     double* __restrict__ utt_llh, T* __restrict__ lognorm_mean) {
     typedef Lin<T> R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int u = blockIdx.x * kWvWaves + wave;
-    if (u >= b.nutt) return;                              // (no workgroup barrier below)
+    const int slot = blockIdx.x * kWvWaves + wave;
+    if (slot >= b.nutt) return;                           // (no workgroup barrier below)
+    const int u = b.order ? __builtin_amdgcn_readfirstlane(b.order[slot]) : slot;
     const int gid = b.graph_id[u];
     const beer_graph g = b.graphs[gid];
     const beer_graph_lowdeg L = *g.lowdeg;
     const int S = g.n_states;
     const bool has_hub = L.n_hubs > 0;
-    const int64_t f0 = b.frame_off[u], T_ = b.frame_off[u + 1] - f0;
+    // (wave-uniform by construction: in SGPRs, so that the frame loops and the row pointers
+    // are the scalar unit's work)
+    const int64_t f0 = uniform64(b.frame_off[u]);
+    const int T_ = __builtin_amdgcn_readfirstlane((int)(b.frame_off[u + 1] - f0));
     if (T_ <= 0) return;
     constexpr int NS = 64 * SPL;                          // LDS slots per column
     // byte addresses in LDS: cur[NS] (a_{t-1}), lb[NS] (b_{t+1} beta_{t+1})
@@ -888,6 +920,25 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
 
     const T* llh = FUSED ? pc + f0 * (int64_t)S_total : pc + b.llh_off[u];
     const int64_t ll_stride = FUSED ? S_total : S;
+    // Every global access of the recursions goes through a buffer descriptor of ONE ROW
+    // (frame) of its array -- a uniform base the scalar unit advances per frame, a 32-bit
+    // lane offset that never changes, and the hardware's range check instead of a branch:
+    // lanes without a state carry an offset past the row, their loads return 0 and their
+    // stores are dropped (the loop had a saveexec / branch pair around every store and two
+    // 64-bit address computations per access).
+    constexpr int kOob = 0x7fffffff;
+    auto row_of = [&](const void* base, int64_t elems, int elem_bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0,
+                                                 (int)(elems * elem_bytes), 0x00020000);
+    };
+    int vo_ll[SPL], vo_a[SPL], vo_out[SPL];
+#pragma unroll
+    for (int p = 0; p < SPL; ++p) {
+        vo_ll[p] = (int)(ll_off[p] * (int64_t)sizeof(T));          // (lanes without a state: element 0)
+        vo_a[p] = st[p] ? (int)(a_off[p] * 8) : kOob;
+        vo_out[p] = st[p] ? (int)((FUSED ? ll_off[p] : a_off[p]) * (int64_t)sizeof(T)) : kOob;
+    }
+    const int vo_lane0 = lane == 0 ? 0 : kOob;
     // (kept in fp64 also for float models: a float column loses a state below 2^-126 of
     // the frame's best -- 87 nats, which evidence after the frame does make up for on real
     // utterances: the real-dimension parity test failed with float columns.  Measured: 6 %
@@ -895,10 +946,31 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
     // normaliser test pays the log-space kernel on top)
     typedef double A_t;
     A_t* alpha = reinterpret_cast<A_t*>(alpha_ws + b.llh_off[u]);   // scaled forward columns
+    auto al_row = [&](int64_t t) { return row_of(alpha + t * S, S, 8); };
     constexpr double kMinNorm = 0x1p-800;
     double* hubf = hubf_ws + f0;                          // forward hub value per frame
+    const __amdgpu_buffer_rsrc_t hub_rs = row_of(hubf, T_, 8);
+    auto load_word = [&](__amdgpu_buffer_rsrc_t r, int vo) -> T {
+        if constexpr (sizeof(T) == 4)
+            return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, vo, 0, 0));
+        else
+            return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, vo, 0, 0));
+    };
+    auto store_word = [&](T v, __amdgpu_buffer_rsrc_t r, int vo) {
+        if constexpr (sizeof(T) == 4)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vo, 0, 0);
+        else
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, v), r, vo, 0, 0);
+    };
+    auto load_f64 = [&](__amdgpu_buffer_rsrc_t r, int vo) -> double {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, vo, 0, 0));
+    };
+    auto store_f64 = [&](double v, __amdgpu_buffer_rsrc_t r, int vo) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, v), r, vo, 0, 0);
+    };
+    auto ll_row = [&](int64_t t) { return row_of(llh + t * ll_stride, ll_stride, sizeof(T)); };
     auto load_ll = [&](int64_t t, int p) -> T {
-        const T v = llh[t * ll_stride + ll_off[p]];       // (lanes without a state: element 0)
+        const T v = load_word(ll_row(t), vo_ll[p]);
         return FUSED ? scale * v : v;
     };
     // the shift of a block of NF frames: the float maximum over their states (a frame
@@ -915,9 +987,9 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
                 m = __builtin_fmaxf(m, (float)ll[k][p]);  // (lanes without a state read state 0's)
                 bad |= ll[k][p] != ll[k][p];
             }
-        m = wave_max(m);
+        m = wave_fmax(m);
         gave_up |= __builtin_amdgcn_ballot_w64(bad) != 0;
-        return m > -INFINITY && m < INFINITY ? (double)m : 0.0;
+        return uniform64(m > -INFINITY && m < INFINITY ? (double)m : 0.0);
     };
     // Giving up.  fp64 holds a state's mass down to 2^-1022 of the column's largest; what
     // falls below is lost, and harmless unless the OTHER pass weights exactly those
@@ -962,7 +1034,7 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
             bad0 |= l0[p] != l0[p];
         }
         gave_up |= __builtin_amdgcn_ballot_w64(bad0) != 0;
-        m = wave_max(m);
+        m = wave_fmax(m);
         const double m0 = m > -INFINITY && m < INFINITY ? (double)m : 0.0;
 #pragma unroll
         for (int p = 0; p < SPL; ++p) a[p] = st[p] ? R::ex(l0[p] - m0) : 0.0;
@@ -972,7 +1044,7 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
 #pragma unroll
         for (int p = 0; p < SPL; ++p) {
             lds(own[p]) = a[p];
-            if (st[p]) alpha[a_off[p]] = (A_t)a[p];
+            store_f64(a[p], al_row(0), vo_a[p]);
         }
 #pragma unroll
         for (int k = 0; k < PF; ++k)
@@ -980,11 +1052,11 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
             for (int p = 0; p < SPL; ++p) ll_ring[k][p] = load_ll(1 + k < T_ ? 1 + k : T_ - 1, p);
     }
     BEER_WAVE_ORDER();
-    auto forward_step = [&](int64_t t, const T (&ll)[SPL], double mt) {
+    auto forward_step = [&](int64_t t, const T (&ll)[SPL], double mt, bool scale_now) {
         double hub = 0.0;
         if (has_hub) {
             hub = R::wsum(lds(hm_src) * hw_src);
-            if (lane == 0) hubf[t - 1] = hub;             // H(t-1): flows of the arcs t-1 -> t
+            store_f64(hub, hub_rs, vo_lane0 == 0 ? (int)(8 * (t - 1)) : kOob);   // H(t-1): flows t-1 -> t
         }
         double a[SPL];
 #pragma unroll
@@ -994,22 +1066,28 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
             for (int k = 0; k < DEG; ++k) pred = __builtin_fma(lds(isrc[p][k]), iw[p][k], pred);
             a[p] = R::ex((double)ll[p] - mt) * pred;       // (lanes without a state: weights 0)
         }
-        const int sh = rescale(a);
+        // (the column is brought back to [1/2, 1) on every kWvRescale-th frame: between two
+        // rescalings it can only shrink, by what the frames' likelihoods differ from their
+        // block's maximum -- a column that runs out of fp64's range on the way is all zero
+        // at the next rescaling and flags the utterance)
         m_sum += mt;
-        sh_sum += (double)sh;
+        if (scale_now) sh_sum += (double)rescale(a);
         BEER_WAVE_ORDER();                                // every read of the column is done
+        {
+            const __amdgpu_buffer_rsrc_t ar = al_row(t);
 #pragma unroll
-        for (int p = 0; p < SPL; ++p) {
-            lds(own[p]) = a[p];
-            if (st[p]) alpha[t * S + a_off[p]] = (A_t)a[p];
+            for (int p = 0; p < SPL; ++p) {
+                lds(own[p]) = a[p];
+                store_f64(a[p], ar, vo_a[p]);
+            }
         }
         BEER_WAVE_ORDER();
     };
-    for (int64_t t0 = 1; t0 < T_; t0 += PF) {
+    for (int t0 = 1; t0 < T_; t0 += PF) {
         const double mt = frames_max(ll_ring, PF);        // (frames past the end: the last one again)
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
-            const int64_t t = t0 + k;
+            const int t = t0 + k;
             if (t >= T_) break;
             T ll[SPL];
 #pragma unroll
@@ -1017,14 +1095,14 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
                 ll[p] = ll_ring[k][p];
                 ll_ring[k][p] = load_ll(t + PF < T_ ? t + PF : T_ - 1, p);
             }
-            forward_step(t, ll, mt);
+            forward_step(t, ll, mt, (k % kWvRescale) == kWvRescale - 1);
         }
     }
 
     // ---- backward + posteriors ----
     // frame T-1 first (beta = final, nothing to recurse), then the loop
     double llh_acc = 0.0, log_px = 0.0;
-    double lb_own[SPL];
+    double lb_own[SPL], g0v[SPL];                  // (g0v: the posteriors of the frame done last, 0)
     A_t a_ring[PF][SPL];                           // frames t - 1 - k
     T lt_ring[PF][SPL];
     double hf_ring[PF];
@@ -1032,7 +1110,7 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
     // then lb_t = b_t beta_t for frame t - 1
     auto finish_frame = [&](int64_t t, const double (&a_cur)[SPL], const T (&lt_cur)[SPL],
                             double (&beta)[SPL], const double (&lbd)[SPL][DEG], double hf_cur,
-                            bool inner, double mt) {
+                            bool inner, double mt, bool scale_now) {
         double gq[SPL], gsum = 0.0;
 #pragma unroll
         for (int p = 0; p < SPL; ++p) {
@@ -1043,38 +1121,47 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
         if (t == T_ - 1) log_px = norm;
         const bool ok = norm >= kMinNorm && norm < __builtin_huge_val();
         gave_up |= !ok;
+        // (a frame that fails the test flags the utterance: whatever it adds to the
+        // accumulators below is never flushed, so nothing here needs to look at `ok`)
         // 1 / norm: the hardware's estimate and two Newton steps (a flagged frame's value
         // is not used)
         double inv = __builtin_amdgcn_rcp(norm);
         inv = __builtin_fma(__builtin_fma(-norm, inv, 1.0), inv, inv);
         inv = __builtin_fma(__builtin_fma(-norm, inv, 1.0), inv, inv);
+        const __amdgpu_buffer_rsrc_t orow = FUSED
+            ? row_of(out + (f0 + t) * (int64_t)S_total, S_total, sizeof(T))
+            : row_of(out + b.llh_off[u] + t * S, S, sizeof(T));
+        const double hfi = hf_cur * inv;
 #pragma unroll
         for (int p = 0; p < SPL; ++p) {
             const double gv = gq[p] * inv;
-            if (st[p]) {
-                if (FUSED) {
-                    const T gT = (T)gv;
-                    T* dst = out + (f0 + t) * (int64_t)S_total + ll_off[p];
-                    if (atomic_out) atomicAdd(dst, resp_scale * gT);
-                    else *dst = resp_scale * gT;
-                    llh_acc += (double)(lt_cur[p] * gT);
+            g0v[p] = gv;
+            if (FUSED) {
+                const T gT = (T)gv;
+                if constexpr (ATOMIC) {
+                    // (repeated pdf ids: added, not stored -- the rare case keeps its branch)
+                    if (st[p]) atomicAdd(out + (f0 + t) * (int64_t)S_total + ll_off[p], resp_scale * gT);
                 } else {
-                    out[b.llh_off[u] + t * S + a_off[p]] = (T)gv;
+                    store_word(resp_scale * gT, orow, vo_out[p]);
                 }
-                if (t == 0 && gamma0_sum && !gave_up) atomicAdd(gamma0_sum + a_off[p], gv);
+                // (lanes without a state read state 0's log-likelihood: not theirs to add)
+                const T prod = lt_cur[p] * gT;
+                llh_acc += (double)(st[p] ? prod : (T)0);
+            } else {
+                store_word((T)gv, orow, vo_out[p]);
             }
-            if (inner && ok) {
+            if (inner) {
                 if (XI) {
                     const double ai = a_cur[p] * inv;
 #pragma unroll
                     for (int k = 0; k < DEG; ++k) xi_r[p][k] = __builtin_fma(ai * ow[p][k], lbd[p][k], xi_r[p][k]);
                 }
                 if (has_hub && hub_flow)
-                    flow_r[p] = __builtin_fma(hf_cur * inv * hd_w[p], lb_own[p], flow_r[p]);
+                    flow_r[p] = __builtin_fma(hfi * hd_w[p], lb_own[p], flow_r[p]);
             }
         }
         if (t > 0) {
-            (void)rescale(beta);
+            if (scale_now) (void)rescale(beta);
 #pragma unroll
             for (int p = 0; p < SPL; ++p)
                 lb_own[p] = R::ex((double)lt_cur[p] - mt) * beta[p];     // for frame t - 1
@@ -1086,12 +1173,13 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
     };
     auto load_back = [&](int64_t tq, A_t (&av)[SPL], T (&lv)[SPL], double& hv) {
         const int64_t tc = tq > 0 ? tq : 0;                // (clamped: loaded, never used)
+        const __amdgpu_buffer_rsrc_t ar = al_row(tc);
 #pragma unroll
         for (int p = 0; p < SPL; ++p) {
-            av[p] = alpha[tc * S + (st[p] ? a_off[p] : 0)];
+            av[p] = load_f64(ar, vo_a[p]);                  // (lanes without a state: 0)
             lv[p] = load_ll(tc, p);
         }
-        hv = has_hub ? hubf[tc] : 0.0;
+        hv = has_hub ? load_f64(hub_rs, (int)(8 * tc)) : 0.0;
     };
     {
         const int64_t t = T_ - 1;
@@ -1099,7 +1187,7 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
         T lt_cur[SPL];
 #pragma unroll
         for (int p = 0; p < SPL; ++p) {
-            a_cur[p] = st[p] ? (double)alpha[t * S + a_off[p]] : 0.0;
+            a_cur[p] = load_f64(al_row(t), vo_a[p]);
             lt_cur[p] = load_ll(t, p);
             beta[p] = fin_w[p];
             lb_own[p] = 0.0;
@@ -1111,16 +1199,16 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
         T one[1][SPL];
 #pragma unroll
         for (int p = 0; p < SPL; ++p) one[0][p] = lt_cur[p];
-        finish_frame(t, a_cur, lt_cur, beta, lbd, 0.0, false, frames_max(one, 1));
+        finish_frame(t, a_cur, lt_cur, beta, lbd, 0.0, false, frames_max(one, 1), true);
     }
     auto backward_step = [&](int64_t t, const A_t (&a_t)[SPL], const T (&lt_cur)[SPL], double hf_cur,
-                             double mt) {
+                             double mt, bool scale_now) {
         double a_cur[SPL], beta[SPL], lbd[SPL][DEG];
         double hub = 0.0;
         if (has_hub) hub = R::wsum(lds(hm_dst) * hw_dst);
 #pragma unroll
         for (int p = 0; p < SPL; ++p) {
-            a_cur[p] = st[p] ? (double)a_t[p] : 0.0;
+            a_cur[p] = (double)a_t[p];
             double acc = hub * hs_w[p];
 #pragma unroll
             for (int k = 0; k < DEG; ++k) {
@@ -1129,13 +1217,13 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
             }
             beta[p] = acc;
         }
-        finish_frame(t, a_cur, lt_cur, beta, lbd, hf_cur, true, mt);
+        finish_frame(t, a_cur, lt_cur, beta, lbd, hf_cur, true, mt, scale_now);
     };
-    for (int64_t t0 = T_ - 2; t0 >= 0; t0 -= PF) {
+    for (int t0 = T_ - 2; t0 >= 0; t0 -= PF) {
         const double mt = frames_max(lt_ring, PF);        // (frames before the start: frame 0 again)
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
-            const int64_t t = t0 - k;
+            const int t = t0 - k;
             if (t < 0) break;
             A_t a_t[SPL];
             T lt_cur[SPL];
@@ -1143,12 +1231,18 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
             for (int p = 0; p < SPL; ++p) { a_t[p] = a_ring[k][p]; lt_cur[p] = lt_ring[k][p]; }
             const double hf_cur = hf_ring[k];              // H(t)
             load_back(t - PF, a_ring[k], lt_ring[k], hf_ring[k]);
-            backward_step(t, a_t, lt_cur, hf_cur, mt);
+            backward_step(t, a_t, lt_cur, hf_cur, mt, (k % kWvRescale) == kWvRescale - 1);
         }
     }
 #undef BEER_WAVE_ORDER
     if (lane == 0) hubf[T_ - 1] = gave_up ? 1.0 : 0.0;     // (hub values: slots 0 .. T-2)
     if (gave_up) return;
+    if (gamma0_sum) {
+        // the posteriors of frame 0 (the frame the backward pass finished with)
+#pragma unroll
+        for (int p = 0; p < SPL; ++p)
+            if (st[p]) atomicAdd(gamma0_sum + a_off[p], g0v[p]);
+    }
     // log p(X): every frame's log-normaliser (graph.py:304-326 averages T equal numbers)
     if (lognorm_mean && lane == 0)
         lognorm_mean[u] = (T)(m_sum - sh_sum * 0.69314718055994530942 + log(log_px));
@@ -1225,8 +1319,9 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int u = blockIdx.x * kWvWaves + wave;
-    if (u >= b.nutt) return;                              // (no workgroup barrier below)
+    const int slot = blockIdx.x * kWvWaves + wave;
+    if (slot >= b.nutt) return;                           // (no workgroup barrier below)
+    const int u = b.order ? __builtin_amdgcn_readfirstlane(b.order[slot]) : slot;
     const int gid = b.graph_id[u];
     const beer_graph g = b.graphs[gid];
     const beer_graph_lowdeg L = *g.lowdeg;
@@ -1813,11 +1908,14 @@ int wave_fb_launch(const beer_batch* b, const T* pc, int S_total, T scale, doubl
         if (all_log)                                                                            \
             hipLaunchKernelGGL(fb_flag_all_kernel, dim3((unsigned)((b->nutt + 255) / 256)),     \
                                dim3(256), 0, s, *b, hub_ws);                                    \
+        else if (FUSED && atomic_out)                                                           \
+            hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_, FUSED>), grid, block, \
+                               lds, s, *b, pc, S_total, scale, alpha_ws, hub_ws, out,           \
+                               resp_scale, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean); \
         else                                                                                    \
-            hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_>), grid, block, lds,  \
-                               s, *b, pc, S_total, scale, alpha_ws, hub_ws, out, resp_scale,   \
-                               atomic_out, xi_sum, gamma0_sum, hub_flow, utt_llh,              \
-                               lognorm_mean);                                                   \
+            hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_, false>), grid, block, \
+                               lds, s, *b, pc, S_total, scale, alpha_ws, hub_ws, out,           \
+                               resp_scale, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean); \
         hipLaunchKernelGGL((fb_wave_log_kernel<T, SPL_, DEG_, FUSED, XI_>), grid, block, lds,  \
                            s, *b, pc, S_total, scale, alpha_ws, hub_ws, out, resp_scale,       \
                            atomic_out, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean);   \

@@ -82,8 +82,13 @@ class HmmBatch:
         self.frame_off_h, self.llh_off_h = frame_off, llh_off
         self.n_states = n_states
         self.graph_ids = list(graph_ids)
+        # longest utterance first: the waves of a workgroup of the one-wave kernels then
+        # finish together, and a launch ends with its shortest utterances
+        order = torch.argsort(lengths_t, descending=True, stable=True).to(torch.int32) \
+            if self.nutt else torch.zeros(0, dtype=torch.int32)
         self.bufs = _hip.upload(dict(
             frame_off=frame_off, llh_off=llh_off[:-1], graph_id=gid_t.to(torch.int32),
+            order=order,
             graphs=graph_bytes,
             pdf_off=torch.as_tensor(np.asarray(pdf_off), dtype=torch.int32),
             pdf_ids=torch.as_tensor(pdf_ids, dtype=torch.int32)), dev)
@@ -93,7 +98,7 @@ class HmmBatch:
             1 if (lowdeg and all_lowdeg) else 0, len(graphs),
             b['frame_off'].data_ptr(), b['llh_off'].data_ptr(), b['graph_id'].data_ptr(),
             b['graphs'].data_ptr(), b['pdf_off'].data_ptr(), b['pdf_ids'].data_ptr(),
-            *(ld_info if all_lowdeg else (0, 0, 0)), 0)
+            *(ld_info if all_lowdeg else (0, 0, 0)), 0, b['order'].data_ptr())
         self.shared_graph = len(graphs) == 1
         self._pdf_ids_h, self._pdf_off_h = np.asarray(pdf_ids), np.asarray(pdf_off)
         self._profile = {}

@@ -493,6 +493,12 @@ typedef struct {
     int32_t max_hubs;          /* largest n_hubs */
     int32_t max_hub_members;   /* largest number of sources / destinations of a hub */
     int32_t reserved;
+    /* (nullable) [nutt]: the order in which the one-wave-per-utterance kernels hand the
+     * utterances to their waves -- longest first, so that the four waves of a workgroup
+     * finish together and the launch ends with its shortest utterances (the reference
+     * loops over utterances in file order, accumulate.py:39-59; the sums do not care).
+     * NULL: 0, 1, 2, ... */
+    const int32_t* order;
 } beer_batch;
 
 /* pc_llhs[u][t,s] = scale * pc_all[frame_off[u]+t, pdf_id[s]]: the gather of

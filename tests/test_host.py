@@ -60,7 +60,7 @@ def test_struct_layouts_match_header():
     # 4 int32 + 14 pointers; 6 int32 + 6 pointers (LP64)
     assert ctypes.sizeof(_hip.Graph) == 16 + 15 * 8
     assert ctypes.sizeof(_hip.GraphLowDeg) == 8 + 14 * 8
-    assert ctypes.sizeof(_hip.Batch) == 24 + 6 * 8 + 16
+    assert ctypes.sizeof(_hip.Batch) == 24 + 6 * 8 + 16 + 8          # (+ `order`, round 5)
     assert ctypes.sizeof(_hip.FeaConf) == 8 * 4 + 3 * 8 + 6 * 8
 
 
