@@ -780,32 +780,6 @@ static_assert(kWvPF % kWvRescale == 0, "the rescaled frames are fixed positions 
 
 typedef unsigned v2u_t __attribute__((ext_vector_type(2)));     // a 64-bit buffer word
 
-template <typename T> struct Lin;
-template <> struct Lin<float> {
-    // exp(d) in fp64 range, relative error ~1e-7; d = -inf -> 0 (and NaN -> 0: the
-    // kernel flags utterances with NaN log-likelihoods, see `gave_up`)
-    static __device__ __forceinline__ double ex(double d) {
-        const double y = d * 1.4426950408889634074;
-        const double yc = __builtin_fmax(y, -1100.0);
-        const double n = __builtin_rint(yc);
-        const double r = (double)__builtin_amdgcn_exp2f((float)(yc - n));
-        return __builtin_amdgcn_ldexp(r, (int)n);
-    }
-    // sum over the wave of non-negative terms <= ~1
-    static __device__ __forceinline__ double wsum(double v) {
-        const float s = wave_sum((float)v);
-        // (uniform; the float sum has lost nothing that matters unless it is tiny.  The test
-        // is the scalar unit's: for a non-negative float, s > 1e-30f is an integer comparison
-        // of the bit patterns; a NaN passes and is returned as it is)
-        const int bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s));
-        if (bits > 0x0DA24260) return (double)s;
-        return wave_sum(v);
-    }
-};
-template <> struct Lin<double> {
-    static __device__ __forceinline__ double ex(double d) { return exp(d); }
-    static __device__ __forceinline__ double wsum(double v) { return wave_sum(v); }
-};
 // a wave-uniform 64-bit value, moved to SGPRs
 template <typename V>
 __device__ __forceinline__ V uniform64(V v) {
@@ -814,16 +788,68 @@ __device__ __forceinline__ V uniform64(V v) {
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
     return __builtin_bit_cast(V, ((unsigned long long)hi << 32) | lo);
 }
+// Sum / maximum over the wave INTO AN SGPR: six DPP steps -- four inside the rows of 16 lanes,
+// then row_bcast:15 and row_bcast:31 carry the rows' totals up to row 3 -- and one readlane
+// of lane 63.  The generic all-reduce (common.h) spends a move, a lane swap and the
+// operation on each of its two cross-row steps and leaves the result in every lane, where
+// these kernels then had to fetch it for the scalar unit again: 12 vector instructions per
+// reduction against 7, four reductions per frame.  Written as one asm block: hipcc does not
+// fuse a row_bcast with row_mask into the operation (it emits v_mov_b32_dpp + the
+// operation); the two wait states a DPP read needs after the VALU write of its source are
+// the s_nops (the assembler does not add them inside inline asm).  All lanes take part.
+#define BEER_DPP_CHAIN(OP)                                                                       \
+    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"     \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                     \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+__device__ __forceinline__ float wave_sum_scalar(float v) {
+    asm volatile(BEER_DPP_CHAIN("v_add_f32_dpp") : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int wave_max_scalar(int v) {
+    asm volatile(BEER_DPP_CHAIN("v_max_i32_dpp") : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+#undef BEER_DPP_CHAIN
 // maximum of a float over the wave (NaN if any lane holds one): on the order-preserving
 // integer image of the floats, one v_max_i32 with a DPP operand per step instead of a move
 // and two quieting operations around every v_max_f32
 __device__ __forceinline__ float wave_fmax(float v) {
     int i = __builtin_bit_cast(int, v);
     i ^= (i >> 31) & 0x7fffffff;
-    i = wave_max(i);
+    i = wave_max_scalar(i);
     i ^= (i >> 31) & 0x7fffffff;
     return __builtin_bit_cast(float, i);
 }
+
+template <typename T> struct Lin;
+template <> struct Lin<float> {
+    // exp(d) in fp64 range, relative error ~1e-7; d = -inf -> 0 (and NaN -> 0: the
+    // kernel flags utterances with NaN log-likelihoods, see `gave_up`)
+    static __device__ __forceinline__ double ex(double d) {
+        const double y = d * 1.4426950408889634074;
+        // (-inf and anything below 2^-1100 alike: 0 after the ldexp)
+        const double yc = __builtin_fmax(y, -1100.0);
+        const double n = __builtin_rint(yc);
+        const double r = (double)__builtin_amdgcn_exp2f((float)(yc - n));
+        return __builtin_amdgcn_ldexp(r, (int)n);
+    }
+    // sum over the wave of non-negative terms <= ~1
+    static __device__ __forceinline__ double wsum(double v) {
+        const float s = wave_sum_scalar((float)v);
+        // (uniform; the float sum has lost nothing that matters unless it is tiny.  The test
+        // is the scalar unit's: for a non-negative float, s > 1e-30f is an integer comparison
+        // of the bit patterns; a NaN passes and is returned as it is)
+        if (__builtin_bit_cast(int, s) > 0x0DA24260) return (double)s;
+        return wave_sum(v);
+    }
+};
+template <> struct Lin<double> {
+    static __device__ __forceinline__ double ex(double d) { return exp(d); }
+    static __device__ __forceinline__ double wsum(double v) { return wave_sum(v); }
+};
 // biased exponent of a non-negative double (0: zero or denormal)
 __device__ __forceinline__ int expo_field(double v) {
     return (int)((__builtin_bit_cast(unsigned long long, v) >> 52) & 0x7ffull);
@@ -1006,7 +1032,7 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
         int e = 0;
 #pragma unroll
         for (int p = 0; p < SPL; ++p) { const int ep = expo_field(v[p]); e = ep > e ? ep : e; }
-        e = wave_max(e);
+        e = wave_max_scalar(e);
         gave_up |= e < 1023 - 800 || e >= 0x7ff;
         const int sh = (e > 0 && e < 0x7ff) ? 1022 - e : 0;
 #pragma unroll
@@ -1070,8 +1096,11 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
         // rescalings it can only shrink, by what the frames' likelihoods differ from their
         // block's maximum -- a column that runs out of fp64's range on the way is all zero
         // at the next rescaling and flags the utterance)
-        m_sum += mt;
-        if (scale_now) sh_sum += (double)rescale(a);
+        if (scale_now) {
+            const int sh = rescale(a);
+            if constexpr (!FUSED) sh_sum += (double)sh;        // (the fused launch reports no log p(X))
+        }
+        if constexpr (!FUSED) m_sum += mt;
         BEER_WAVE_ORDER();                                // every read of the column is done
         {
             const __amdgpu_buffer_rsrc_t ar = al_row(t);
