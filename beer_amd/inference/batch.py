@@ -32,13 +32,14 @@ from ..models.weights import SBCategorical
 from ..stats import FrameStats
 from .objectives import EvidenceLowerBoundInstance
 
-__all__ = ['accumulate_elbo', 'pack_utterances', 'decode_batch']
+__all__ = ['accumulate_elbo', 'pack_utterances', 'decode_batch', 'ShardStatics']
 
 # Scratch of one sub-batch (responsibilities, per-state likelihoods, trellis): up to
 # three sub-batches are in flight, so a sub-batch may take an eighth of what is free on
-# the device when the first batch is cut, at most 24 GB (a 288 GB MI355X to itself:
-# 24 GB; a smaller or shared device: less).  BEER_SCRATCH_GB overrides.
-_SCRATCH_CAP = 24 << 30
+# the device when the first batch is cut, at most 48 GB (a 288 GB MI355X to itself:
+# 36 GB -- the 10 M frames of BASELINE config 3 are then ONE launch of every kernel, 29 GB
+# of scratch; a smaller or shared device: less).  BEER_SCRATCH_GB overrides.
+_SCRATCH_CAP = 48 << 30
 _scratch_bytes = [int(os.environ['BEER_SCRATCH_GB']) << 30 if 'BEER_SCRATCH_GB' in os.environ
                   else None]
 
@@ -51,6 +52,31 @@ def _scratch_budget():
         except Exception:                                   # no device: the caller raises later
             _scratch_bytes[0] = _SCRATCH_CAP
     return _scratch_bytes[0]
+
+
+class ShardStatics:
+    '''What `accumulate_elbo` derives from the utterance LENGTHS and the data-set size alone
+    -- offsets, the per-utterance weights datasize / T_u on the device, the cut into
+    sub-batches -- kept by the caller across the iterations over one shard (like
+    `FrameImages` for the frames: nothing is cached behind the caller's back).  One object
+    per (utterances, datasize) pair; a call whose lengths do not match what the object was
+    filled with refills it.  Without one these are rebuilt per call: a 33 k-element host
+    loop and two small uploads per iteration, and -- uploads cannot be recorded -- no
+    capture of the iteration as a HIP graph (`CapturedIteration`).'''
+
+    def __init__(self):
+        self.key, self.items = None, {}
+
+    def entry(self, key, name, make):
+        if self.key != key:
+            self.key, self.items = key, {}
+        if name not in self.items:
+            self.items[name] = make()
+        return self.items[name]
+
+
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
 def pack_utterances(utterances):
@@ -120,6 +146,8 @@ def _throttle(depth=2):
     likelihoods); a host that queues many of them before the first has run
     makes the caching allocator hipMalloc new blocks instead of recycling --
     tens of ms each, and the stream waits for them.'''
+    if _capturing():
+        return torch.cuda.Event()             # (a recording does not run: nothing to wait for)
     in_flight = _local.__dict__.setdefault('in_flight', [])
     while len(in_flight) >= depth:
         in_flight.pop(0).synchronize()
@@ -160,7 +188,7 @@ def _kl_beside_the_estep(model, device):
     caller makes its stream wait for the event before it uses `kl`.  The side stream
     starts behind everything queued so far (the previous M-step), and the next call
     starts behind this one's consumers: tensors it allocates are not recycled early.'''
-    if not _KL_BESIDE or isinstance(model, VAE) or device.type != 'cuda':
+    if not _KL_BESIDE or isinstance(model, VAE) or device.type != 'cuda' or _capturing():
         return torch.as_tensor(model.kl_div_posterior_prior()), None
     main = torch.cuda.current_stream(device)
     # Everything the distributions memoise -- expected statistics (which the E-step
@@ -196,7 +224,7 @@ def _like(param, t):
     return t.to(dtype=param.stats.dtype, device=param.stats.device)
 
 
-def _mixture_batch(model, X, lengths, datasize, labels, max_frames):
+def _mixture_batch(model, X, lengths, datasize, labels, max_frames, statics=None):
     ns = model.modelset
     K, cov = len(ns), ns.cov_type
     dev, dtype = X.device, X.dtype
@@ -205,15 +233,20 @@ def _mixture_batch(model, X, lengths, datasize, labels, max_frames):
     Q = FrameStats(X[:1], cov).shape[1]
     acc = torch.zeros(K, Q, dtype=torch.float64, device=dev)
     utt_llh = torch.zeros(len(lengths), dtype=torch.float64, device=dev)
-    off = torch.zeros(len(lengths) + 1, dtype=torch.int64)
-    off[1:] = torch.cumsum(torch.as_tensor(lengths, dtype=torch.int64), 0)
-    # every host -> device copy happens here, BEFORE the first big kernel: a copy
-    # from pageable memory makes the host wait for the stream, and one issued
-    # after the E-step kernels would keep the host from queueing the M-step
-    # launches while those kernels run
-    up = _hip.upload({'off': off, 'scales': torch.as_tensor(
-        [datasize / float(T) for T in lengths], dtype=torch.float64)}, dev)
-    off_dev, scales = up['off'], up['scales']
+
+    def offsets_and_scales():
+        off = torch.zeros(len(lengths) + 1, dtype=torch.int64)
+        off[1:] = torch.cumsum(torch.as_tensor(lengths, dtype=torch.int64), 0)
+        # every host -> device copy happens here, BEFORE the first big kernel: a copy
+        # from pageable memory makes the host wait for the stream, and one issued
+        # after the E-step kernels would keep the host from queueing the M-step
+        # launches while those kernels run
+        up = _hip.upload({'off': off, 'scales': torch.as_tensor(
+            [datasize / float(T) for T in lengths], dtype=torch.float64)}, dev)
+        return off, up['off'], up['scales']
+    statics = statics if statics is not None else ShardStatics()
+    skey = ('mixture', len(lengths), sum(lengths), lengths[0], lengths[-1], float(datasize), str(dev))
+    off, off_dev, scales = statics.entry(skey, 'offsets', offsets_and_scales)
     lab_dev = None if labels is None else \
         _hip.on_device(torch.as_tensor(labels)).to(torch.int64).contiguous()
     for run in _sub_batches(lengths, K * X.element_size(), max_frames):
@@ -274,7 +307,7 @@ def _emission_estep(groups, stats, dtype, for_accumulate=False):
 
 
 def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths, max_frames,
-               frame_images=None):
+               frame_images=None, statics=None):
     emissions = model._emissions()
     groups = _groups(emissions)
     S_total = sum(S for _, S, _ in groups)
@@ -288,10 +321,15 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
         accs.append(torch.zeros(S * G, Q, dtype=torch.float64, device=dev))
     nutt = len(lengths)
     utt_llh = torch.zeros(nutt, dtype=torch.float64, device=dev)
-    off = torch.zeros(nutt + 1, dtype=torch.int64)
-    off[1:] = torch.cumsum(torch.as_tensor(lengths, dtype=torch.int64), 0)
-    scales = _hip.to_device(torch.as_tensor([datasize / float(T) for T in lengths],
-                                            dtype=torch.float64), dev)
+
+    def offsets_and_scales():
+        off = torch.zeros(nutt + 1, dtype=torch.int64)
+        off[1:] = torch.cumsum(torch.as_tensor(lengths, dtype=torch.int64), 0)
+        return off, _hip.to_device(torch.as_tensor([datasize / float(T) for T in lengths],
+                                                   dtype=torch.float64), dev)
+    statics = statics if statics is not None else ShardStatics()
+    skey = ('hmm', nutt, sum(lengths), lengths[0], lengths[-1], float(datasize), str(dev))
+    off, scales = statics.entry(skey, 'offsets', offsets_and_scales)
     xi_tot = g0_tot = flow_tot = None
     max_S = model.graph.n_states if free_loop else max(g.n_states for g in graphs)
     # scratch per frame: the responsibilities of the groups whose accumulation does
@@ -304,10 +342,11 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
         bpf += max((_hip.lib().beer_frame_image_bytes(
             _hip.COV_CODE[_normalset(grp).cov_type], 1 << 20, X.shape[1]) >> 20)
             for grp, _, _ in groups) if X.dtype == torch.float32 else 0
-    for run in _sub_batches(lengths, bpf, max_frames):
+    runs = statics.entry(skey, ('runs', bpf, max_frames), lambda: [
+        (run, int(off[run[0]]), int(off[run[-1] + 1]), [lengths[u] for u in run])
+        for run in _sub_batches(lengths, bpf, max_frames)])
+    for run, f0, f1, run_lengths in runs:
         done = _throttle()
-        f0, f1 = int(off[run[0]]), int(off[run[-1] + 1])
-        run_lengths = [lengths[u] for u in run]
         # the emission E-step is queued first: building the batch descriptor (host
         # work + one asynchronous copy from pinned memory) overlaps with it
         stats = FrameStats(X[f0:f1], _normalset(groups[0][0]).cov_type, images=frame_images)
@@ -414,8 +453,8 @@ def _vae_batch(model, X, lengths, datasize, nsamples, llh_weight, kl_weight):
 
 
 def accumulate_elbo(model, utterances, datasize=-1, inference_graphs=None, scale=1.,
-                    viterbi=False, state_paths=None, labels=None, max_frames=1 << 22,
-                    nsamples=1, llh_weight=1., kl_weight=1., frame_images=None):
+                    viterbi=False, state_paths=None, labels=None, max_frames=1 << 24,
+                    nsamples=1, llh_weight=1., kl_weight=1., frame_images=None, statics=None):
     '''ELBO + accumulated statistics of a shard of utterances, identical to the
     sum of per-utterance `evidence_lower_bound(model, utt, datasize=datasize,
     inference_graph=..., scale=..., viterbi=...)` calls.
@@ -435,6 +474,8 @@ def accumulate_elbo(model, utterances, datasize=-1, inference_graphs=None, scale
         frame_images: optional `FrameImages` of the packed frames (HMM only; the
             caller's, kept across iterations over the same shard).  Without it the
             images of a sub-batch live for this call only.
+        statics: optional `ShardStatics` (Mixture, HMM): what depends on the utterance
+            lengths and `datasize` only, kept by the caller across iterations.
     '''
     X, lengths = pack_utterances(utterances)
     if any(T <= 0 for T in lengths):
@@ -446,10 +487,10 @@ def accumulate_elbo(model, utterances, datasize=-1, inference_graphs=None, scale
         return EvidenceLowerBoundInstance(0., {}, [], 0, datasize)
     kl, kl_done = _kl_beside_the_estep(model, X.device)
     if isinstance(model, Mixture):
-        value_terms, acc = _mixture_batch(model, X, lengths, datasize, labels, max_frames)
+        value_terms, acc = _mixture_batch(model, X, lengths, datasize, labels, max_frames, statics)
     elif isinstance(model, HMM):
         value_terms, acc = _hmm_batch(model, X, lengths, datasize, inference_graphs, scale,
-                                      viterbi, state_paths, max_frames, frame_images)
+                                      viterbi, state_paths, max_frames, frame_images, statics)
     elif isinstance(model, VAE):
         value_terms, acc = _vae_batch(model, X, lengths, datasize, nsamples, llh_weight,
                                       kl_weight)

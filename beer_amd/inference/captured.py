@@ -54,7 +54,21 @@ class CapturedIteration:
         if not isinstance(optim, VBConjugateOptimizer):
             raise TypeError('CapturedIteration drives a VBConjugateOptimizer')
         self.model, self.optim = model, optim
-        self.data = _hip.on_device(data)
+        # `data`: one resident minibatch [T, D] (-> evidence_lower_bound), or a shard of
+        # utterances as `(X_packed, lengths)` (-> accumulate_elbo: the batched E-step of
+        # `beer hmm accumulate` + `update`, accumulate.py:39-63, update.py:41-62).  The shard
+        # form keeps what depends on the lengths only (`ShardStatics`) and, for diagonal
+        # emissions, the frame fragment images (`FrameImages`) for as long as this object lives.
+        self.lengths = None
+        if isinstance(data, tuple) and len(data) == 2 and isinstance(data[0], torch.Tensor):
+            from ..stats import FrameImages
+            from .batch import ShardStatics
+            self.data, self.lengths = _hip.on_device(data[0]), [int(n) for n in data[1]]
+            kwargs.setdefault('statics', ShardStatics())
+            if 'frame_images' not in kwargs and self.data.dtype == torch.float32:
+                kwargs['frame_images'] = FrameImages(self.data)
+        else:
+            self.data = _hip.on_device(data)
         self.datasize, self.kwargs = datasize, kwargs
         self._entries = {}                 # turn -> None (warmed up) | False (eager) | entry
         self.mode = None
@@ -62,7 +76,13 @@ class CapturedIteration:
     # -- the reference's loop body ------------------------------------------------------
     def _iteration(self):
         self.optim.init_step()
-        elbo = evidence_lower_bound(self.model, self.data, datasize=self.datasize, **self.kwargs)
+        if self.lengths is None:
+            elbo = evidence_lower_bound(self.model, self.data, datasize=self.datasize,
+                                        **self.kwargs)
+        else:
+            from .batch import accumulate_elbo
+            elbo = accumulate_elbo(self.model, (self.data, self.lengths), datasize=self.datasize,
+                                   **self.kwargs)
         elbo.backward()
         self.optim.step()
         return elbo

@@ -1461,7 +1461,7 @@ def main():
                          'corpus (10,000,000)')
     ap.add_argument('--chunk', type=int, default=8192, help='config 2: frames per "utterance"')
     ap.add_argument('--cov', default='diagonal', help='config 3: covariance type of the emissions')
-    ap.add_argument('--max-frames', type=int, default=1 << 22,
+    ap.add_argument('--max-frames', type=int, default=1 << 24,
                     help='config 3: frames per launch of the batched E-step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-exact', action='store_true', help='config 2: skip the f32_exact leg')

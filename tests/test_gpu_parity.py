@@ -2023,3 +2023,42 @@ def test_whole_iteration_as_a_captured_graph_matches_the_reference(name):
     eager = beer.evidence_lower_bound(model, X)
     again = beer.evidence_lower_bound(build_mixture(g, f'it{int(g["niter"]) - 1}'), X)
     assert_close(float(eager), float(again), 1e-8, 'ELBO of the replayed posterior')
+
+
+@pytest.mark.gpu
+def test_captured_iteration_over_a_shard_of_utterances_equals_the_eager_loop():
+    '''`beer.CapturedIteration(model, optim, (X, lengths), datasize=N)`: the batched iteration
+    of `beer hmm accumulate` + `update` (accumulate.py:39-63, update.py:41-62) over a resident
+    shard -- emission E-step, forward-backward, statistics, phone counts, the update of the
+    group in turn and the phone loop's weight rewrite -- recorded as HIP graphs (one per
+    mean-field group) and replayed, against the same iterations launched call by call.'''
+    P, G, D = 6, 4, 10
+    rng = np.random.RandomState(3)
+    lens = [int(n) for n in rng.randint(40, 90, 24)]
+    X = tt(rng.randn(sum(lens), D).astype(np.float32))
+    N = 10 * sum(lens)
+
+    def run(captured):
+        ploop = _phone_loop(P, G, D, 'diagonal', torch.float32, seed=9)
+        optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.)
+        values, modes = [], []
+        it = beer.CapturedIteration(ploop, optim, (X, lens), datasize=N) if captured else None
+        for _ in range(7):
+            if captured:
+                values.append(float(it()))
+                modes.append(it.mode)
+            else:
+                optim.init_step()
+                elbo = beer.accumulate_elbo(ploop, (X, lens), datasize=N)
+                elbo.backward()
+                optim.step()
+                values.append(float(elbo))
+        return values, modes, [npy(t) for p in ploop.bayesian_parameters() for t in p.posterior._tensors()], \
+            npy(ploop.graph.trans_log_probs)
+    ev, _, ep, et = run(False)
+    cv, modes, cp, ct = run(True)
+    assert 'replayed' in modes and modes[0] == 'eager', modes
+    assert_close(np.asarray(cv), np.asarray(ev), 1e-6, 'ELBO per iteration')
+    for a, b in zip(cp, ep):
+        assert_close(a, b, 1e-5, 'posterior after 7 iterations')
+    assert_close(np.exp(ct), np.exp(et), 1e-6, 'phone-loop transitions')
