@@ -419,9 +419,11 @@ def run_gmm(args, rank, world, device, backend):
     stats_err = parity.get(mode_now, {}).get('stats_rel_err')
     phases = PhaseTimer()
 
+    statics = beer.ShardStatics()        # offsets / weights of the shard's utterances: the caller's
+
     def step():
         optim.init_step()
-        elbo = beer.accumulate_elbo(model, (X, lengths), datasize=datasize)
+        elbo = beer.accumulate_elbo(model, (X, lengths), datasize=datasize, statics=statics)
         with phases.span('all_reduce'):
             elbo, _ = all_reduce_elbo(elbo, model, len(lengths))
         with phases.span('m_step'):
@@ -689,10 +691,13 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
     images = beer.FrameImages(X) if cov != 'full' and not os.environ.get('BEER_BENCH_NO_IMAGES') \
         else None
 
+    statics = beer.ShardStatics()        # offsets / weights of the shard's utterances: the caller's
+
     def step():
         optim.init_step()
         elbo = beer.accumulate_elbo(ploop, (X, lengths), datasize=datasize,
-                                    max_frames=args.max_frames, frame_images=images)
+                                    max_frames=args.max_frames, frame_images=images,
+                                    statics=statics)
         with phases.span('all_reduce'):
             elbo, _ = all_reduce_elbo(elbo, ploop, len(lengths))
         with phases.span('m_step'):
@@ -812,6 +817,21 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
                                 'corpus on ONE GPU, no collective: value = frames of the shard / '
                                 'time; x N is the projection for N GPUs'}
         out['value'] = n_local * steps / elapsed
+        # the same iterations recorded as HIP graphs (beer.CapturedIteration: E-step, statistics,
+        # update and the phone loop's weight rewrite as ONE submission per iteration)
+        ploop_c = make_phone_loop(cov, device)
+        it = beer.CapturedIteration(ploop_c, beer.VBConjugateOptimizer(
+            ploop_c.mean_field_factorization(), 1.), (X, lengths), datasize=datasize,
+            frame_images=images)
+        for _ in range(4):
+            it()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            it()
+        torch.cuda.synchronize()
+        out['shard']['captured_ms_per_step'] = 1e3 * (time.perf_counter() - t0) / steps
+        out['shard']['captured_mode'] = it.mode
     if with_cpu_baseline and not args.no_cpu_baseline and world == 1 and cov == 'diagonal':
         out['cpu_baseline'] = cpu_baseline_hmm()
     fi = frame_image_report(images)
