@@ -277,12 +277,14 @@ def cpu_baseline_gmm(frames_target=1 << 20, chunk=8192, budget_s=15.):
     # thrash).  The baseline is then timed at that setting.
     ncpu = os.cpu_count() or 1
     best = (0., torch.get_num_threads())
+    probe = {}
     for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
         torch.set_num_threads(nt)
         tp.gmm_elbo(X[:chunk], post, prior, w, w, n)                   # warm-up
         t = time.perf_counter()
         tp.gmm_elbo(X[chunk:2 * chunk], post, prior, w, w, n)
         rate = chunk / (time.perf_counter() - t)
+        probe[str(nt)] = rate
         if rate > best[0]:
             best = (rate, nt)
     torch.set_num_threads(best[1])
@@ -297,6 +299,10 @@ def cpu_baseline_gmm(frames_target=1 << 20, chunk=8192, budget_s=15.):
     dt = time.perf_counter() - t0
     return {'value': done / dt, 'unit': 'frames/s', 'cores': int(torch.get_num_threads()),
             **host_cores(), 'kind': 'port',
+            'frames_per_s_by_threads': probe,
+            'threads_note': '`cores` = the thread count that served the reference\'s op mix best '
+                            '(one 8192-frame utterance per count, `frames_per_s_by_threads`: also '
+                            'one whole socket, 64 threads); `value` is timed at that count',
             'sample': f'{done} frames of the config-2 workload (K=256 full-cov, D=40, fp32) in '
                       f'{chunk}-frame utterances + 1 M-step, torch-CPU replay of the '
                       f'reference op sequence, {dt:.1f} s'}
@@ -1014,6 +1020,9 @@ def run_vae(args, device, frames=5_000_000, n_minibatches=5, warmup=1):
                     'note': 'achieved = algorithmic bytes of the dominant call (its [T, S] arrays '
                             'once) / HIP-event time; the kernel also keeps its forward columns '
                             '(fp64) in HBM between the two passes: `traffic`'}
+        # (the diagonal prior's path has its own passes, keys c4d_*; older rounds: c4_* only)
+        if cov == 'diagonal' and pmc_key and pmc_entry('c4d_' + pmc_key[3:]):
+            pmc_key = 'c4d_' + pmc_key[3:]
         roof.update(profiled(pmc_key, roof, per_launch_scale=1.))
         sub['roofline'] = roof
         if not args.no_cpu_baseline:
