@@ -91,8 +91,14 @@ class FrameImages:
         if budget is None:
             import os
             gb = os.environ.get('BEER_FRAME_IMAGE_GB')
+            if gb is not None:
+                try:
+                    gb = float(gb)
+                except ValueError:
+                    raise ValueError(f'BEER_FRAME_IMAGE_GB={gb!r}: expected a number of '
+                                     'gigabytes') from None
             total = torch.cuda.get_device_properties(X.device).total_memory
-            budget = int(min(float(gb) * 2 ** 30 if gb else 64 * 2 ** 30, total / 4))
+            budget = int(min(gb * 2 ** 30 if gb is not None else 64 * 2 ** 30, total / 4))
         self.budget = int(budget)
         self._version = X._version
         self._images = {}
@@ -176,12 +182,15 @@ class FrameStats:
         if os.environ.get('BEER_FRAME_IMAGE', '1') == '0' or X.dtype != torch.float32 or \
                 X.shape[0] < _hip.FAST_MIN_FRAMES or _image_bytes(cov_type, *X.shape) == 0:
             return None
-        img = self._image.get(cov_type)
+        # (filed with the version of the frames it was built from: a handle reused after an
+        # in-place write to its frames builds a new image)
+        hit = self._image.get(cov_type)
+        img = hit[1] if hit is not None and hit[0] == X._version else None
         if img is None and self.images is not None:
             img = self.images.get(X, cov_type)
         if img is None:
             img = _build_image(X, cov_type)
-        self._image[cov_type] = img
+        self._image[cov_type] = (X._version, img)
         return img
 
     def as_cov(self, cov_type):
