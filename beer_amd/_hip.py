@@ -60,7 +60,8 @@ def lib():
 # BEER_OPT_* of include/beer_hip.h and the environment variables that preset them
 OPTIONS = {'ax_max_frames': (0, 'BEER_AX_MAXFRAMES'), 'accf_rounds': (1, 'BEER_ACCF_ROUNDS'),
            'k1_wide': (2, 'BEER_K1_WIDE'), 'accfi_waves': (3, 'BEER_ACCFI_WAVES'),
-           'lnfi': (4, 'BEER_LNFI'), 'fb_log': (5, 'BEER_FB_LOG')}
+           'lnfi': (4, 'BEER_LNFI'), 'fb_log': (5, 'BEER_FB_LOG'),
+           'k1_lds': (6, 'BEER_K1_LDS')}
 
 
 def _options_from_env(l):

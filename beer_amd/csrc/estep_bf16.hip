@@ -353,7 +353,15 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ X, int64_t 
 // IMG: the A fragments come from the caller's frame fragment image (frame_image_kernel
 // further down: they depend on the frames only), 16-byte loads instead of the staging of
 // the frames and the fragment arithmetic.
-template <int NT, int MT, int GQ, bool PACKED, bool SQ, bool LNO, bool IMG = false>
+// BL: the B fragments of a k-step go through LDS ONCE PER WORKGROUP -- half a k-step (8 tiles,
+// 24 KiB) at a time, copied global -> LDS by the DMA path into a ring of two buffers -- instead
+// of once per wave from L2: every wave used to stream the chunk's whole packed image (1.4 MB at
+// D = 40) for its 32 frames, 43 GB per launch of config 2 through the L2s, and the kernel ran
+// at 1.69 GHz where the accumulation holds 1.91 (r05_pmc.json).  Two synchronisation points per
+// k-step (in front of the batches whose look-ahead reads cross into the other buffer): wait
+// for the own DMA, barrier, refill the buffer that has just been read out.  A wave that waits
+// at the barrier leaves the matrix pipe to the wave of the other workgroup on its SIMD.
+template <int NT, int MT, int GQ, bool PACKED, bool SQ, bool LNO, bool IMG = false, bool BL = false>
 __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
     int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nk,
     const float* __restrict__ X, const u4* __restrict__ Pall, const int* __restrict__ tab,
@@ -361,6 +369,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
     float* __restrict__ xt_out, int xt_floats, int nku, int cg, const float* __restrict__ c0,
     const u4* __restrict__ img = nullptr) {
     static_assert(!IMG || (MT == 2 && !PACKED && LNO), "the image holds 32-frame tiles");
+    static_assert(!BL || (NT == 16 && MT == 2 && !IMG), "half k-steps of 8 tiles, hipcc-scheduled form");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LD = ld16_of(D);                                // 16-byte aligned rows
     const int tid = threadIdx.x, lane = tid & 63;
@@ -370,6 +379,10 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
     constexpr bool PIN = MT * NT > 32;                        // 256 accumulators: see mfma_bf16_pinned
     float* xw = reinterpret_cast<float*>(smem) + wave * (FW * LD);
     int* tabs = reinterpret_cast<int*>(reinterpret_cast<float*>(smem) + NW * FW * LD);
+    // (BL) the ring of two half-k-step buffers behind the slab table, 1 KiB aligned
+    constexpr int kHalfBytes = 8 * kBlockU4 * 16;             // 8 tiles x 3 KiB
+    char* ring = smem + (((size_t)NW * FW * LD * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int)
+                          + 1023) & ~(size_t)1023);
     int64_t bx = blockIdx.x;
     int by = 0;
     {
@@ -455,7 +468,34 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
 #pragma unroll
         for (int c = 0; c < BT; ++c)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) b.p[c][q] = Pl[(size_t)(blk + c) * kBlockU4 + 64 * q];
+            for (int q = 0; q < NP; ++q) {
+                if constexpr (BL) {
+                    // block blk + c sits in buffer ((blk + c) / 8) & 1 at position (blk + c) & 7
+                    const int bb = (int)(blk + c);
+                    b.p[c][q] = *reinterpret_cast<const u4*>(
+                        ring + ((bb >> 3) & 1) * kHalfBytes + (bb & 7) * (kBlockU4 * 16) + q * 1024 +
+                        lane * 16);
+                } else {
+                    b.p[c][q] = Pl[(size_t)(blk + c) * kBlockU4 + 64 * q];
+                }
+            }
+    };
+    // (BL) DMA of half k-step `hs` (blocks 8 hs .. 8 hs + 7 of the chunk's image) into buffer
+    // hs & 1: 24 pieces of 1 KiB, six per wave
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const char* bsrc = reinterpret_cast<const char*>(Pall + (size_t)by * nk * NT * kBlockU4) +
+                       wave * 1024 + lane * 16;
+    auto stage_half = [&](int hs) {
+        const char* src = bsrc + (size_t)hs * kHalfBytes;
+        char* dst = ring + (hs & 1) * kHalfBytes + wave * 1024;
+#pragma unroll
+        for (int n = 0; n < kHalfBytes / 1024 / NW; ++n)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const u4*>(src + n * (NW * 1024)),
+                                             (lds_ptr)(dst + n * (NW * 1024)), 16, 0, 0);
+    };
+    auto publish = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     };
     auto batch = [&](int s, int bi, const AFrag& cur, AFrag& nxt, const BFrag& b, BFrag& bn) {
         if constexpr (PIN) {
@@ -518,6 +558,17 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
             }
             return;
         }
+        if constexpr (BL) {
+            // in front of the batches whose look-ahead read crosses into the other buffer:
+            // batch 3 (reads tile 8 of this k-step; buffer 0 has been read out: refill it with
+            // the first half of the next k-step), batch 7 (reads tile 0 of the next k-step;
+            // buffer 1 is free for its second half)
+            if (bi == NBATCH / 2 - 1 || bi == NBATCH - 1) {
+                publish();
+                const int hs = 2 * (s + 1) + (bi == NBATCH - 1 ? 1 : 0);
+                if (hs < 2 * nku) stage_half(hs);
+            }
+        }
         // P is padded by one batch (bi + 1 = NBATCH: first batch of the next k-step)
         load_b((int64_t)s * NT + (bi + 1) * BT, bn);
         // slices of the next A: MT * 2 halves over the NBATCH batches
@@ -535,7 +586,10 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
                 for (int m = 0; m < MT; ++m)
                     acc[m][bi * BT + c] = mfma_bf16(cur.w[kProdA[pr]][m], b.p[c][kProdB[pr]],
                                                     acc[m][bi * BT + c]);
-        __builtin_amdgcn_sched_group_barrier(0x020, NP * BT, 0);         // VMEM reads
+        if constexpr (BL)
+            __builtin_amdgcn_sched_group_barrier(0x100, NP * BT, 0);     // DS reads (B fragments)
+        else
+            __builtin_amdgcn_sched_group_barrier(0x020, NP * BT, 0);     // VMEM reads
         if constexpr (!IMG)
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * ((MT * 2 + NBATCH - 1) / NBATCH), 0);   // DS reads
         __builtin_amdgcn_sched_group_barrier(0x008, 6 * MT * BT, 0);     // MFMA
@@ -568,6 +622,11 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
     } else {
 #pragma unroll
         for (int hh = 0; hh < MT * 2; ++hh) make_half(0, hh % MT, hh / MT, f0);
+    }
+    if constexpr (BL) {
+        stage_half(0);
+        if (nku > 0) stage_half(1);
+        publish();
     }
     load_b(0, b0);
     // (the image is padded to an even number of k-steps; only those that hold slabs run)
@@ -611,12 +670,19 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
     }
 }
 
+// Two workgroups of the LDS-staged form (BL) fit a CU: frame tiles + slab table + the ring
+inline bool k1_lds_fits(int D, int nk) {
+    size_t lds = (size_t)32 * (kThreads / 64) * ld16_of(D) * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int);
+    lds = ((lds + 1023) & ~(size_t)1023) + 2 * (size_t)(8 * kBlockU4 * 16);
+    return 2 * lds <= (size_t)beer::kMaxDynLds;
+}
+
 // covariance type of the E-step being launched (the launch helpers below take the
 // shape, not the type; SQ = false kernels are full covariance by construction)
 thread_local int g_cov_of_launch = BEER_FULL;
 
 template <int NT, int MT, int GQ, bool PACKED = false, bool SQ = true, bool LNO = false,
-          bool IMG = false>
+          bool IMG = false, bool BL = false>
 int launch_llhx(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int nchunks, int nk,
                 const float* X, const void* P, const int* tab, const float* c0, float* resps,
                 float* log_norm, double* llh_sum, hipStream_t s, float* xt_out = nullptr,
@@ -625,14 +691,15 @@ int launch_llhx(int64_t nframes, int D, int K, int S, int G, int gl, int jw, int
     // k-steps that hold slabs: the slab count is the table's (full: SQ = false)
     const int nku = (nslab_of(SQ ? g_cov_of_launch : BEER_FULL, D) + 7) / 8;
     constexpr int FB = 16 * MT * (kThreads / 64);
-    const size_t lds = (size_t)FB * LD * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int);
+    size_t lds = (size_t)FB * LD * sizeof(float) + (size_t)(nk + 1) * 8 * sizeof(int);
+    if (BL) lds = ((lds + 1023) & ~(size_t)1023) + 2 * (size_t)(8 * kBlockU4 * 16);
     const int64_t blocks = (nframes + FB - 1) / FB;
     if (nchunks != (K + 16 * NT - 1) / (16 * NT)) return BEER_EINVAL;
     const int cg = xcd_chunk_group(nchunks, (size_t)nku * NT * kBlockU4 * 16);
     (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(llhx_kernel<NT, MT, GQ, PACKED, SQ, LNO, IMG>),
+        reinterpret_cast<const void*>(llhx_kernel<NT, MT, GQ, PACKED, SQ, LNO, IMG, BL>),
         hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds);
-    hipLaunchKernelGGL((llhx_kernel<NT, MT, GQ, PACKED, SQ, LNO, IMG>),
+    hipLaunchKernelGGL((llhx_kernel<NT, MT, GQ, PACKED, SQ, LNO, IMG, BL>),
                        dim3(nchunks > 1 ? xcd_grid(blocks, nchunks, cg) : (unsigned)blocks),
                        dim3(kThreads), lds, s, nframes, D, K, S, G, gl, jw, nk, X,
                        reinterpret_cast<const u4*>(P), tab, resps, log_norm, llh_sum, xt_out,
@@ -2241,6 +2308,10 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
             // nothing covers.
             const bool wide = beer::option(BEER_OPT_K1_WIDE) != 0;
             if (wide) BEER_LLHX(16, 4, 4, true, false, xt, xtf);
+            if (full && k1_lds_fits(D, nk) && beer::option(BEER_OPT_K1_LDS))
+                return launch_llhx<16, 2, 4, true, false, false, false, true>(
+                    nframes, D, K, S, G, gl, jw, nchunks, nk, X, P, tab, c0, resps, log_norm,
+                    llh_sum, s, xt, xtf);
             BEER_LLHX(16, 2, 4, true, false, xt, xtf);
         }
         if (NT == 4) BEER_LLHX(4, 2, 1, false, false);
@@ -2262,6 +2333,15 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
                 case 1: BEER_LLHX(16, 4, 1, true, false);
                 default: BEER_LLHX(16, 4, 2, true, false);
             }
+        }
+        if (full && k1_lds_fits(D, nk) && beer::option(BEER_OPT_K1_LDS)) {
+            if (gq == 1)
+                return launch_llhx<16, 2, 1, true, false, false, false, true>(
+                    nframes, D, K, S, G, gl, jw, nchunks, nk, X, P, tab, c0, resps, log_norm,
+                    llh_sum, s);
+            return launch_llhx<16, 2, 2, true, false, false, false, true>(
+                nframes, D, K, S, G, gl, jw, nchunks, nk, X, P, tab, c0, resps, log_norm, llh_sum,
+                s);
         }
         switch (gq) {
             case 1: BEER_LLHX(16, 2, 1, true, false);

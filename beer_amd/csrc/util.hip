@@ -16,6 +16,7 @@ constexpr OptSpec kOptSpec[BEER_OPT_COUNT] = {
     {4, 4, 8},                // BEER_OPT_ACCFI_WAVES (4 or 8)
     {1, 0, 1},                // BEER_OPT_LNFI
     {0, 0, 1},                // BEER_OPT_FB_LOG
+    {1, 0, 1},                // BEER_OPT_K1_LDS
 };
 std::atomic<int> g_opt[BEER_OPT_COUNT] = {{kOptSpec[0].def}, {kOptSpec[1].def}, {kOptSpec[2].def},
                                           {kOptSpec[3].def}, {kOptSpec[4].def}};

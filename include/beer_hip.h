@@ -75,7 +75,12 @@ int beer_hip_device_count(void);
                                   * redoes utterances whose dynamic range exceeds the
                                   * scaled-probability recursion; beer/graph.py:270-326 is
                                   * log-space throughout).  Default 0. */
-#define BEER_OPT_COUNT 6
+#define BEER_OPT_K1_LDS 6        /* 1: the packed full-covariance E-step stages the packed
+                                  * parameters of a k-step through LDS once per workgroup (DMA,
+                                  * ring of two half k-steps) instead of streaming them from L2
+                                  * per wave; 0: per wave.  Same products in the same order:
+                                  * bit-identical results.  Default 1. */
+#define BEER_OPT_COUNT 7
 int beer_hip_set_option(int option, int value);
 int beer_hip_get_option(int option);   /* the value, or BEER_EINVAL for an unknown option */
 
