@@ -345,7 +345,7 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
     runs = statics.entry(skey, ('runs', bpf, max_frames), lambda: [
         (run, int(off[run[0]]), int(off[run[-1] + 1]), [lengths[u] for u in run])
         for run in _sub_batches(lengths, bpf, max_frames)])
-    for run, f0, f1, run_lengths in runs:
+    for run_index, (run, f0, f1, run_lengths) in enumerate(runs):
         done = _throttle()
         # the emission E-step is queued first: building the batch descriptor (host
         # work + one asynchronous copy from pinned memory) overlaps with it
@@ -354,14 +354,19 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
         if free_loop:
             batch = _cached_batch(model.graph, run_lengths, dtype)
         else:
-            uniq, ids, seen = [], [], {}
-            for u in run:
-                g = graphs[u]
-                if id(g) not in seen:
-                    seen[id(g)] = len(uniq)
-                    uniq.append(g)
-                ids.append(seen[id(g)])
-            batch = hk.HmmBatch(uniq, ids, run_lengths, dtype)
+            def make_batch():
+                uniq, ids, seen = [], [], {}
+                for u in run:
+                    g = graphs[u]
+                    if id(g) not in seen:
+                        seen[id(g)] = len(uniq)
+                        uniq.append(g)
+                    ids.append(seen[id(g)])
+                return hk.HmmBatch(uniq, ids, run_lengths, dtype), graphs
+            # (the descriptor of a run's alignment graphs -- thousands of graph structs, one
+            # upload -- is the caller's to keep with the shard: the same list of graphs gives
+            # the same descriptor; the list itself is held so that its identity stays unique)
+            batch, _ = statics.entry(skey, ('batch', run_index, id(graphs), str(dtype)), make_batch)
         hard = viterbi or state_paths is not None
         # phone counts come from the flows through the loop's hub (the eliminated
         # pivot); a loop whose end -> start arcs stayed ordinary arcs needs xi
