@@ -2062,3 +2062,38 @@ def test_captured_iteration_over_a_shard_of_utterances_equals_the_eager_loop():
     for a, b in zip(cp, ep):
         assert_close(a, b, 1e-5, 'posterior after 7 iterations')
     assert_close(np.exp(ct), np.exp(et), 1e-6, 'phone-loop transitions')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('K,G,D,T', [(256, None, 40, 33000), (96, 16, 24, 20011), (512, 128, 32, 17000)])
+def test_parameters_staged_through_lds_give_the_same_bits(K, G, D, T):
+    '''`BEER_OPT_K1_LDS`: the packed full-covariance E-step with a k-step's packed parameters
+    copied global -> LDS once per workgroup (DMA ring of half k-steps) against every wave
+    streaming them from L2 -- the same products in the same order: log-normalisers and packed
+    responsibilities equal bit for bit, for a mixture (one softmax over K) and for mixture sets
+    (S = K / G states of G Gaussians).'''
+    from beer_amd import _hip, kernels
+    torch.manual_seed(K + D)
+    X = torch.randn(T, D, device=DEV) * 1.5 + .3
+    ns = beer.NormalSet.create(torch.zeros(D), torch.eye(D), size=K, prior_strength=1., noise_std=1.,
+                               cov_type='full')
+    st = beer.FrameStats(X, 'full')
+    outs = []
+    for mode in (0, 1):
+        old = _hip.set_option('k1_lds', mode)
+        try:
+            if G is None:
+                mix = beer.Mixture.create(ns).to(DEV)
+                ln, packed = kernels.mixture_estep_packed(
+                    st, ns.means_precisions.natural_form(), mix._log_weights().view(1, K), K, 'full')
+            else:
+                ms = beer.MixtureSet.create(K // G, ns).to(DEV)
+                assert kernels.packed_sets_ok(st, K // G, G, 'full')
+                ln, packed = kernels.mixtureset_estep_packed(
+                    st, ns.means_precisions.natural_form(), ms._log_weights(), K // G, G, 'full')
+        finally:
+            _hip.set_option('k1_lds', old)
+        outs.append((ln.clone(), packed.unpack().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]), 'log-normalisers'
+    assert torch.equal(outs[0][1], outs[1][1]), 'responsibilities'
+    assert bool(torch.isfinite(outs[0][0]).all())
