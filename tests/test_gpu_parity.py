@@ -2097,3 +2097,27 @@ def test_parameters_staged_through_lds_give_the_same_bits(K, G, D, T):
     assert torch.equal(outs[0][0], outs[1][0]), 'log-normalisers'
     assert torch.equal(outs[0][1], outs[1][1]), 'responsibilities'
     assert bool(torch.isfinite(outs[0][0]).all())
+
+
+@pytest.mark.gpu
+def test_shard_statics_follow_the_shard_they_are_given():
+    '''`ShardStatics` keeps what depends on the utterance lengths and the data-set size only;
+    handing the same object a different shard (other lengths, other datasize, other alignment
+    graphs) must refill it, not reuse offsets or batch descriptors of the first one: every call
+    equals the call without statics.'''
+    P, G, D = 5, 4, 8
+    rng = np.random.RandomState(12)
+    ploop = _phone_loop(P, G, D, 'diagonal', torch.float64, seed=2)
+    statics = beer.ShardStatics()
+
+    def shard(n, lo, hi):
+        lens = [int(v) for v in rng.randint(lo, hi, n)]
+        return tt(rng.randn(sum(lens), D)), lens
+    shards = [shard(7, 30, 60), shard(7, 30, 60), shard(11, 20, 40)]
+    for X, lens in shards + shards[:1]:
+        for N in (5000, 9000):
+            a = beer.accumulate_elbo(ploop, (X, lens), datasize=N, statics=statics)
+            b = beer.accumulate_elbo(ploop, (X, lens), datasize=N)
+            assert_close(float(a), float(b), 1e-12, 'elbo with / without statics')
+            for p in b._acc_stats:
+                assert_close(npy(a._acc_stats[p]), npy(b._acc_stats[p]), 1e-12, 'statistics')
