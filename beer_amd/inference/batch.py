@@ -65,7 +65,15 @@ class ShardStatics:
     capture of the iteration as a HIP graph (`CapturedIteration`).'''
 
     def __init__(self):
-        self.key, self.items = None, {}
+        self.key, self.items, self.lengths = None, {}, None
+
+    def bind(self, lengths):
+        '''The shard these statics belong to: the same list object (the usual case: O(1)) or
+        an equal one keeps them, anything else empties them.'''
+        if self.lengths is not lengths:
+            if self.lengths != lengths:
+                self.key, self.items = None, {}
+            self.lengths = lengths
 
     def entry(self, key, name, make):
         if self.key != key:
@@ -85,7 +93,11 @@ def pack_utterances(utterances):
     if isinstance(utterances, tuple) and len(utterances) == 2 and \
             isinstance(utterances[0], torch.Tensor):
         X, lengths = utterances
-        return _hip.on_device(X), [int(n) for n in lengths]
+        # (a list of Python ints is handed through as it is: `ShardStatics` recognises the
+        # caller's list by identity)
+        if not (isinstance(lengths, list) and all(type(n) is int for n in lengths[:4])):
+            lengths = [int(n) for n in lengths]
+        return _hip.on_device(X), lengths
     utterances = list(utterances)
     lengths = [len(u) for u in utterances]
     dev = _hip.require_device()
@@ -245,7 +257,8 @@ def _mixture_batch(model, X, lengths, datasize, labels, max_frames, statics=None
             [datasize / float(T) for T in lengths], dtype=torch.float64)}, dev)
         return off, up['off'], up['scales']
     statics = statics if statics is not None else ShardStatics()
-    skey = ('mixture', len(lengths), sum(lengths), lengths[0], lengths[-1], float(datasize), str(dev))
+    statics.bind(lengths)
+    skey = ('mixture', len(lengths), float(datasize), str(dev))
     off, off_dev, scales = statics.entry(skey, 'offsets', offsets_and_scales)
     lab_dev = None if labels is None else \
         _hip.on_device(torch.as_tensor(labels)).to(torch.int64).contiguous()
@@ -328,7 +341,8 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
         return off, _hip.to_device(torch.as_tensor([datasize / float(T) for T in lengths],
                                                    dtype=torch.float64), dev)
     statics = statics if statics is not None else ShardStatics()
-    skey = ('hmm', nutt, sum(lengths), lengths[0], lengths[-1], float(datasize), str(dev))
+    statics.bind(lengths)
+    skey = ('hmm', nutt, float(datasize), str(dev))
     off, scales = statics.entry(skey, 'offsets', offsets_and_scales)
     xi_tot = g0_tot = flow_tot = None
     max_S = model.graph.n_states if free_loop else max(g.n_states for g in graphs)
