@@ -2618,8 +2618,11 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
     const int rounds = beer::option(BEER_OPT_ACCF_ROUNDS);
     int64_t gz = ((waves == 8 ? 256 : 512) * rounds + nchunks - 1) / nchunks;
     gz = (gz + 7) / 8 * 8;                       // whole rows of the XCD-aware grid
-    const int64_t min_z = (nframes + (int64_t)waves * kAfMaxFramesPerWave - 1) /
-                          ((int64_t)waves * kAfMaxFramesPerWave);
+    // (the full chain where the launch is long enough for its last round of workgroups not
+    // to matter -- 70 rounds per XCD at 10 M frames --, half of it below 4 M frames: a shard
+    // of 1.25 M frames is 9 rounds per XCD with 2048-frame chains and lost 17 % to the tail)
+    const int64_t chain = nframes >= ((int64_t)4 << 20) ? kAfMaxFramesPerWave : kAfMaxFramesPerWave / 2;
+    const int64_t min_z = (nframes + (int64_t)waves * chain - 1) / ((int64_t)waves * chain);
     const int64_t max_z = (nframes + 32 * waves - 1) / (32 * waves);
     if (gz > max_z) gz = max_z;
     if (gz < min_z) gz = min_z;
