@@ -777,7 +777,7 @@ def test_one_sample_hmm_prior_at_config4_shape_against_the_oracle(cov, S, D, nut
     assert rel_err(npy(got).astype(np.float64), value) <= band(value32, value), 'per-frame value'
     sr = npy(prior.cache['scaled_pdf_resps']).astype(np.float64)
     assert rel_err(sr, resps) <= band(resps32, resps), 'state posteriors'
-    assert abs(float(got.double().sum()) - value.sum()) <= 1e-5 * abs(value.sum())
+    assert abs(float(got.detach().double().sum()) - value.sum()) <= 1e-5 * abs(value.sum())
     (torch.from_numpy(c_up).to(DEV) * got).sum().backward()
     # the gradient of the HIP path multiplies ITS posteriors: hold it against the oracle's
     # gradient at 1e-5 of the largest entry plus what the posteriors' own float32 band moves
