@@ -2065,7 +2065,9 @@ def test_captured_iteration_over_a_shard_of_utterances_equals_the_eager_loop():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('K,G,D,T', [(256, None, 40, 33000), (96, 16, 24, 20011), (512, 128, 32, 17000)])
+@pytest.mark.parametrize('K,G,D,T', [(256, None, 40, 33000), (96, 16, 24, 20011), (512, 128, 32, 17000),
+                                     (256, None, 44, 17000), (128, None, 48, 16999), (256, 64, 52, 18000),
+                                     (64, None, 64, 16500)])
 def test_parameters_staged_through_lds_give_the_same_bits(K, G, D, T):
     '''`BEER_OPT_K1_LDS`: the packed full-covariance E-step with a k-step's packed parameters
     copied global -> LDS once per workgroup (DMA ring of half k-steps) against every wave
