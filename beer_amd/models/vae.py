@@ -24,6 +24,7 @@ import os
 import torch
 
 from .. import _hip, kernels
+from ..nnet.linear import Linear
 from ..dists.normaldiag import NormalDiagonalCovariance
 from .basemodel import Model
 from .gaussians import Normal, NormalSet
@@ -58,10 +59,10 @@ class VAE(Model):
         # True: the prior always gets dense [T, Q] statistics, also with one sample per frame
         self.dense_statistics = (os.environ.get('BEER_VAE_DENSE') == '1') \
             if dense_statistics is None else bool(dense_statistics)
-        self.enc_mean_layer = torch.nn.Linear(encoder.dim_out, decoder.dim_in)
-        self.enc_var_layer = torch.nn.Linear(encoder.dim_out, decoder.dim_in)
-        self.dec_mean_layer = torch.nn.Linear(decoder.dim_out, encoder.dim_in)
-        self.dec_var_layer = torch.nn.Linear(decoder.dim_out, encoder.dim_in)
+        self.enc_mean_layer = Linear(encoder.dim_out, decoder.dim_in)
+        self.enc_var_layer = Linear(encoder.dim_out, decoder.dim_in)
+        self.dec_mean_layer = Linear(decoder.dim_out, encoder.dim_in)
+        self.dec_var_layer = Linear(decoder.dim_out, encoder.dim_in)
 
     def posteriors(self, X):
         'Variational posteriors of the latent variable given the frames.'

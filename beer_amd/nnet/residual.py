@@ -1,7 +1,7 @@
 """Residual feed-forward encoder / decoder trunk of the VAE examples.
 
-torch.nn modules (they run on PyTorch-ROCm as they are: SURVEY.md marks beer/nnet
-as context of the hot path, not part of it).  Interface of
+torch.nn modules (SURVEY.md marks beer/nnet as context of the hot path, not part of it;
+the layers are `linear.Linear`: nn.Linear with a weight gradient that fills the chip).  Interface of
 beer/nnet/residual.py:5-51: `ResidualFeedForwardNet(dim_in, nblocks, block_width)`
 with `dim_in` / `dim_out`; the block class keeps the reference's spelling
 (`ResidualFeedFowardBlock`) and sub-module names (`layer1`, `layer2`,
@@ -11,6 +11,8 @@ with `dim_in` / `dim_out`; the block class keeps the reference's spelling
 import torch
 from torch import nn
 
+from .linear import Linear
+
 __all__ = ['ResidualFeedForwardNet']
 
 
@@ -19,7 +21,7 @@ class ResidualFeedFowardBlock(nn.Module):
 
     def __init__(self, dim_in, width, activation_fn=nn.Tanh):
         super().__init__()
-        self.layer1, self.layer2 = nn.Linear(dim_in, width), nn.Linear(width, dim_in)
+        self.layer1, self.layer2 = Linear(dim_in, width), Linear(width, dim_in)
         self.activation_fn = activation_fn()
 
     def forward(self, x):

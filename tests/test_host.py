@@ -359,3 +359,31 @@ def test_fast_f32_path_needs_no_look_at_the_data():
     assert calls == []
     lib = ctypes.CDLL(_hip.LIB_PATH)
     assert not hasattr(lib, 'beer_f32_split_hazard') and not hasattr(lib, 'beer_frame_scales')
+
+
+@pytest.mark.parametrize('T', [64, 70, 333])
+def test_row_split_weight_gradient_of_the_vae_layers_is_nn_linears(T, monkeypatch):
+    '''`beer_amd.nnet.Linear` (the layers of the residual nets and the VAE's heads): above
+    `ROW_SPLIT_MIN` rows the weight gradient is a batched product over blocks of rows plus a tail;
+    forward, input gradient and bias gradient are nn.Linear's, the weight gradient equals it to
+    float64 rounding, state dict and pickle keep nn.Linear's names.'''
+    from beer_amd.nnet import linear
+    monkeypatch.setattr(linear, 'ROW_SPLIT_MIN', 64)
+    monkeypatch.setattr(linear, 'ROW_BLOCK', 16)
+    torch.manual_seed(T)
+    lin = beer.nnet.Linear(7, 5).double()
+    ref = torch.nn.Linear(7, 5).double()
+    ref.load_state_dict(lin.state_dict())
+    x = torch.randn(T, 7, dtype=torch.float64, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    y, y2 = lin(x), ref(x2)
+    assert y.grad_fn.name().startswith('_RowSplitLinear') and torch.equal(y, y2)
+    y.tanh().sum().backward()
+    y2.tanh().sum().backward()
+    assert torch.equal(x.grad, x2.grad) and torch.equal(lin.bias.grad, ref.bias.grad)
+    assert_close(lin.weight.grad.numpy(), ref.weight.grad.numpy(), 1e-13, 'weight gradient')
+    with torch.no_grad():
+        assert lin(x).grad_fn is None
+    net = pickle.loads(pickle.dumps(beer.nnet.ResidualFeedForwardNet(4, 1, 3)))
+    assert sorted(net.state_dict()) == ['blocks.0.layer1.bias', 'blocks.0.layer1.weight',
+                                        'blocks.0.layer2.bias', 'blocks.0.layer2.weight']
