@@ -22,6 +22,6 @@ from . import nnet
 from . import utils
 from . import vbi
 from .stats import FrameImages, FrameStats, reference_layout
-from ._hip import get_f32_mode, set_f32_mode
+from ._hip import exact_f32, get_f32_mode, set_f32_mode
 
 __version__ = '0.1.0'

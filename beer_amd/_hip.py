@@ -236,6 +236,7 @@ HOST_SIGNATURES = {
 SIZE_QUERIES = {
     'beer_estep_workspace_bytes': [c_i, c_i, c_i, c_i, c_i],
     'beer_accumulate_workspace_bytes': [c_i, c_i, c_i, c_i, c_i],
+    'beer_accumulate_frames_workspace_bytes': [c_i, c_i, c_l, c_i, c_i, c_i],
     'beer_packed_resps_bytes': [c_l, c_i, c_i],
     'beer_accumulate_fused_workspace_bytes': [c_i, c_i, c_i, c_i],
     'beer_frame_image_bytes': [c_i, c_l, c_i],
@@ -383,6 +384,20 @@ def workspace(query, dtype, cov, D, S, G, device):
     if nbytes == 0:
         return None, 0
     key = (query, dtype, cov, D, S, G, device, torch.cuda.current_stream().cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf, nbytes
+
+
+def frames_workspace(dtype, exact, cov, T, D, S, G, device):
+    """(tensor, nbytes) scratch of `beer_normal_accumulate` over T frames (for some shapes it
+    holds per-chain partial sums, hence T); one buffer per (shape, stream), grown on demand."""
+    nbytes = lib().beer_accumulate_frames_workspace_bytes(dtype_code(dtype, exact), cov, T, D, S, G)
+    if nbytes == 0:
+        return None, 0
+    key = ('frames', dtype, cov, D, S, G, device, torch.cuda.current_stream().cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)

@@ -442,7 +442,13 @@ int accumulate_launch(int cov, int64_t nframes, int D, int S, int G, const void*
     // (float32 responsibilities [T, K] in memory: the exact fp32 / fp64 MFMA kernels;
     // the bf16x3 accumulation takes packed tiles -- beer_pack_resps +
     // beer_normal_accumulate_packed -- whose size depends on T)
-    (void)exact;
+    // ... except diagonal / isotropic Gaussians without state posteriors (a set of single
+    // Gaussians under an HMM: the prior of a VAE): few statistics per Gaussian, the float32
+    // weights are split inside the kernel (acc_diag.hip)
+    if (sizeof(T) == 4 && !exact && cr && !sr &&
+        beer_mfma::supported_acc_diag(cov, nframes, D, S * G))
+        return beer_mfma::acc_diag_bf16x3(cov, nframes, D, S * G, (const float*)X,
+                                          (const float*)cr, acc, ws, ws_bytes, s);
     if (cr && ws && beer_mfma::supported_acc(D, S * G, sizeof(T)) &&
         ws_bytes >= beer_mfma::acc_workspace_bytes(cov, D, S * G, sizeof(T))) {
         return sizeof(T) == 4
@@ -495,6 +501,13 @@ size_t beer_estep_workspace_bytes(int dtype, int cov, int D, int S, int G) {
 size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G) {
     if (cov < 0 || cov > 2) return 0;
     return beer_mfma::acc_workspace_bytes(cov, D, S * G, (dtype & ~BEER_EXACT) == BEER_F64 ? 8 : 4);
+}
+
+size_t beer_accumulate_frames_workspace_bytes(int dtype, int cov, int64_t T, int D, int S, int G) {
+    const size_t base = beer_accumulate_workspace_bytes(dtype, cov, D, S, G);
+    if (dtype != BEER_F32 || T < 0 || S < 1 || G < 1) return base;
+    const size_t rows = beer_mfma::acc_diag_workspace_bytes(cov, T, D, S * G);
+    return rows > base ? rows : base;
 }
 
 int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G, const void* X,

@@ -72,6 +72,14 @@ int acc_fused_bf16x3(int cov, int64_t T, int D, int S, int G, const float* X, co
 size_t frame_image_bytes(int cov, int64_t T, int D);
 int frame_image(int cov, int64_t T, int D, const float* X, void* image, hipStream_t s);
 
+// Diagonal / isotropic Gaussians, float32 weights [T, K] in memory (acc_diag.hip: accd_kernel):
+// acc += W^T phi(X) in the bf16x3 arithmetic.  Workspace (optional): the partial sums of every
+// chain of frames, added up by a second small kernel; without it fp64 atomics.
+bool supported_acc_diag(int cov, int64_t T, int D, int K);
+size_t acc_diag_workspace_bytes(int cov, int64_t T, int D, int K);
+int acc_diag_bf16x3(int cov, int64_t T, int D, int K, const float* X, const float* W, double* acc,
+                    void* ws, size_t ws_bytes, hipStream_t s);
+
 int estep_f32(int cov, int64_t T, int D, int S, int G, const float* X, const float* expT,
               const float* logw, float* resps, float* log_norm, double* llh_sum, void* ws,
               size_t ws_bytes, hipStream_t s);

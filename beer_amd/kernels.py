@@ -364,8 +364,8 @@ def normal_accumulate(stats, comp_resps, state_resps, S, G, cov_type, acc=None):
                                  cov_type, acc=acc)
     cr = None if comp_resps is None else _hip.on_device(comp_resps, X.dtype)
     sr = None if state_resps is None else _hip.on_device(state_resps, X.dtype)
-    ws, ws_bytes = _hip.workspace('beer_accumulate_workspace_bytes', X.dtype,
-                                  _hip.COV_CODE[cov_type], D, S, G, X.device)
+    ws, ws_bytes = _hip.frames_workspace(X.dtype, _exact(X), _hip.COV_CODE[cov_type], T, D, S, G,
+                                         X.device)
     _hip.call('beer_normal_accumulate', _hip.dtype_code(X.dtype, _exact(X)),
               _hip.COV_CODE[cov_type], T, D, S, G, _hip.ptr(X), _hip.ptr(cr), _hip.ptr(sr),
               _hip.ptr(acc), _hip.ptr(ws), ws_bytes)

@@ -271,6 +271,11 @@ int beer_mixtureset_estep(int dtype, int cov, int64_t T, int D, int S, int G,
  * (BEER_EXACT). */
 size_t beer_estep_workspace_bytes(int dtype, int cov, int D, int S, int G);
 size_t beer_accumulate_workspace_bytes(int dtype, int cov, int D, int S, int G);
+/* ... the same for a call over T frames: never smaller; for float32 diagonal / isotropic
+ * Gaussians accumulated without state posteriors (T >= 16384, D <= 64: acc_diag.hip) it also
+ * holds the partial sums of every 2048-frame chain, which a second small kernel adds up in
+ * fp64 -- with the smaller workspace that call adds them with fp64 atomics (same sums). */
+size_t beer_accumulate_frames_workspace_bytes(int dtype, int cov, int64_t T, int D, int S, int G);
 
 /* gamma-weighted sufficient statistics (N_k, sum r x, sum r xx^T) packed as
  * the reference packs them, [K,Q] = resps^T @ phi(X), accumulated (+=) in

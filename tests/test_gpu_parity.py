@@ -2123,3 +2123,42 @@ def test_shard_statics_follow_the_shard_they_are_given():
             assert_close(float(a), float(b), 1e-12, 'elbo with / without statics')
             for p in b._acc_stats:
                 assert_close(npy(a._acc_stats[p]), npy(b._acc_stats[p]), 1e-12, 'statistics')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cov,D,K,T', [('diagonal', 64, 120, 40_003), ('diagonal', 40, 256, 33_000),
+                                       ('isotropic', 24, 48, 33_333), ('diagonal', 7, 300, 20_000),
+                                       ('isotropic', 64, 17, 16_384), ('diagonal', 33, 64, 18_433),
+                                       ('diagonal', 16, 16, 16_385)])
+def test_weights_in_memory_times_diagonal_statistics_against_the_oracle(cov, D, K, T):
+    '''`beer_normal_accumulate`, float32, diagonal / isotropic Gaussians, weights [T, K] in memory
+    and no state posteriors (normalset.py:121-123 as an HMM over single Gaussians calls it:
+    the prior of a VAE) -- `accd_kernel` (acc_diag.hip): bf16x3 products, 512-frame sums on the
+    matrix cores, 2048-frame chains in float32, fp64 beyond.  Against the oracle's fp64
+    `resps^T @ stats` on the same float32 inputs: every statistic to 5e-7 of its column's scale,
+    the counts to 2e-7; frames with an offset and one badly scaled dimension; the partial-sum
+    workspace and the atomic flush (no workspace) give the same sums; `acc` is added to.'''
+    from beer_amd import _hip, kernels
+    torch.manual_seed(D * K)
+    X = torch.randn(T, D, device=DEV) * 1.7 + 3.
+    X[:, 0] *= 100.
+    W = torch.softmax(torch.randn(T, K, device=DEV) * 3, dim=1)
+    W[::7] = 0.                                          # frames no component takes
+    st = beer.FrameStats(X, cov)
+    before = torch.full((K, st.shape[1]), 2.5, dtype=torch.float64, device=DEV)
+    got = npy(kernels.normal_accumulate(st, W, None, K, 1, cov, acc=before.clone())) - 2.5
+    phi = orc.SUFFSTATS[cov](npy(X).astype(np.float64))
+    _, want = orc.mixture_accumulate(phi, npy(W).astype(np.float64))
+    scale = np.abs(npy(W).astype(np.float64)).T @ np.abs(phi)            # per entry: sum |w phi|
+    assert np.max(np.abs(got - want) / scale) <= 5e-7
+    assert_close(-2 * got[:, -2], npy(W).astype(np.float64).sum(0), 2e-7, 'counts')
+    # the flush with fp64 atomics (a caller without the larger workspace)
+    code = _hip.COV_CODE[cov]
+    acc2 = torch.zeros(K, st.shape[1], dtype=torch.float64, device=DEV)
+    _hip.call('beer_normal_accumulate', _hip.F32, code, T, D, K, 1, _hip.ptr(X), _hip.ptr(W), None,
+              _hip.ptr(acc2), None, 0)
+    np.testing.assert_allclose(npy(acc2), got, rtol=0, atol=1e-9 * np.abs(want).max())
+    # the exact float32 kernels on the same call (BEER_EXACT): the same statistics to 1e-6
+    with beer.exact_f32():
+        ex = npy(kernels.normal_accumulate(st, W, None, K, 1, cov))
+    assert np.max(np.abs(ex - want) / scale) <= 1e-6
