@@ -996,7 +996,7 @@ def run_vae(args, device, frames=5_000_000, n_minibatches=5, warmup=1):
         mb_frames = total / len(batches)
         pmc_key = {'beer_frames_llh_backward': 'c4_sgrad_kernel', 'beer_mixtureset_estep': 'c4_llhx_kernel',
                    'beer_normal_accumulate_packed': 'c4_accx_kernel',
-                   'beer_normal_accumulate': 'c4_acc_kernel',
+                   'beer_normal_accumulate': 'c4_accd_kernel',
                    'beer_hmm_posteriors_fused': 'c4_fb_wave_kernel',
                    'beer_hmm_forward_backward': 'c4_fb_wave_kernel'}.get(dom)
         if 'tflops' in kern[dom]:

@@ -13,7 +13,7 @@ C3F="python bench.py --config 3 --cov full --frames 2000000 --steps 6 --warmup 2
 C4="python tools/probes/c4_prior_path.py full 5"
 C4D="python tools/probes/c4_prior_path.py diagonal 5"
 P1="SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-KEEP="Kernel_Name|llhx_kernel|lnfi_kernel|accx_kernel|accf_kernel|accfi_kernel|frame_image_kernel|fb_wave_kernel|llh_kernel|acc_kernel|gt_image|xt_image|sgrad_kernel"
+KEEP="Kernel_Name|llhx_kernel|lnfi_kernel|accx_kernel|accf_kernel|accfi_kernel|frame_image_kernel|fb_wave_kernel|llh_kernel|acc_kernel|accd_kernel|gt_image|xt_image|sgrad_kernel"
 run() {  # name, steps, warmup, command
   $T rocprofv3 --kernel-trace --stats -f csv -d $O/$1_stats -- $4 > $O/$1_stats.log 2>&1
   python tools/trace_stats.py $O/$1_stats $O/$1_timed_stats.csv $O/kernel_times.json --tag=$5 --steps=$2 --warmup=$3 "--command=$4" > $O/$1_timed.txt 2>&1

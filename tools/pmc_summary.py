@@ -21,11 +21,13 @@ import sys
 
 KERNELS = {'llhx_kernel': 'llhx_kernel', 'lnfi_kernel': 'lnfi_kernel', 'accx_kernel': 'accx_kernel',
            'accfi_kernel': 'accf_kernel', 'accf_kernel': 'accf_kernel', 'fb_wave_kernel': 'fb_wave_kernel',
-           'llh_kernel<': 'llh_kernel', 'acc_kernel<': 'acc_kernel', 'sgrad_kernel': 'sgrad_kernel'}
+           'llh_kernel<': 'llh_kernel', 'acc_kernel<': 'acc_kernel', 'sgrad_kernel': 'sgrad_kernel',
+           'accd_kernel': 'accd_kernel'}
 # kernels whose streaming reads are 16 B per lane: FETCH_SIZE counts half their bytes on
 # gfx950 (MI355X_MICROARCH.md, HBM section); bench.py doubles the read figure for these
 WIDE_LOADS = {'llhx_kernel': True, 'lnfi_kernel': True, 'accx_kernel': True, 'accf_kernel': True,
-              'fb_wave_kernel': False, 'llh_kernel': True, 'acc_kernel': True, 'sgrad_kernel': False}
+              'fb_wave_kernel': False, 'llh_kernel': True, 'acc_kernel': True, 'sgrad_kernel': False,
+              'accd_kernel': False}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

@@ -16,7 +16,8 @@ import collections, csv, glob, json, os, re, sys
 
 KERNELS = {'llhx_kernel': 'llhx_kernel', 'lnfi_kernel': 'lnfi_kernel', 'accx_kernel': 'accx_kernel',
            'accfi_kernel': 'accf_kernel', 'accf_kernel': 'accf_kernel', 'fb_wave_kernel': 'fb_wave_kernel',
-           'llh_kernel<': 'llh_kernel', 'acc_kernel<': 'acc_kernel', 'sgrad_kernel': 'sgrad_kernel'}
+           'llh_kernel<': 'llh_kernel', 'acc_kernel<': 'acc_kernel', 'sgrad_kernel': 'sgrad_kernel',
+           'accd_kernel': 'accd_kernel'}
 
 
 def main():
