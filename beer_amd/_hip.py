@@ -193,7 +193,7 @@ SIGNATURES = {
     'beer_hmm_gather': [c_i, c_p, c_i, c_p, c_d, c_p, c_p],
     'beer_hmm_forward_backward': [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     'beer_hmm_posteriors_fused': [c_i, c_p, c_i, c_p, c_d, c_p, c_p, c_p, c_i, c_p, c_p, c_p,
-                                  c_p],
+                                  c_p, c_p],
     'beer_hmm_fb_log_count': [c_p, c_p, c_p, c_p],
     'beer_hmm_viterbi': [c_i, c_p, c_p, c_p, c_p, c_i, c_p],
     'beer_hmm_trans_posteriors': [c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p],

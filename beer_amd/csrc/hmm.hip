@@ -860,7 +860,7 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
     beer_batch b, const T* __restrict__ pc, int S_total, T scale, double* __restrict__ alpha_ws,
     double* __restrict__ hubf_ws, T* __restrict__ out, T resp_scale,
     double* __restrict__ xi_sum, double* __restrict__ gamma0_sum, double* __restrict__ hub_flow,
-    double* __restrict__ utt_llh, T* __restrict__ lognorm_mean) {
+    double* __restrict__ utt_llh, T* __restrict__ lognorm_mean, T* __restrict__ frame_llh) {
     typedef Lin<T> R;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -995,6 +995,9 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, v), r, vo, 0, 0);
     };
     auto ll_row = [&](int64_t t) { return row_of(llh + t * ll_stride, ll_stride, sizeof(T)); };
+    // (the utterance's slice of the per-frame values; no buffer: every store out of range)
+    const __amdgpu_buffer_rsrc_t frame_rs =
+        row_of(frame_llh ? frame_llh + f0 : nullptr, frame_llh ? T_ : 0, sizeof(T));
     auto load_ll = [&](int64_t t, int p) -> T {
         const T v = load_word(ll_row(t), vo_ll[p]);
         return FUSED ? scale * v : v;
@@ -1161,6 +1164,7 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
             ? row_of(out + (f0 + t) * (int64_t)S_total, S_total, sizeof(T))
             : row_of(out + b.llh_off[u] + t * S, S, sizeof(T));
         const double hfi = hf_cur * inv;
+        T fval = 0;                                        // this lane's share of sum_s gamma l
 #pragma unroll
         for (int p = 0; p < SPL; ++p) {
             const double gv = gq[p] * inv;
@@ -1174,8 +1178,9 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
                     store_word(resp_scale * gT, orow, vo_out[p]);
                 }
                 // (lanes without a state read state 0's log-likelihood: not theirs to add)
-                const T prod = lt_cur[p] * gT;
-                llh_acc += (double)(st[p] ? prod : (T)0);
+                const T prod = st[p] ? lt_cur[p] * gT : (T)0;
+                llh_acc += (double)prod;
+                fval += prod;
             } else {
                 store_word((T)gv, orow, vo_out[p]);
             }
@@ -1188,6 +1193,14 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
                 if (has_hub && hub_flow)
                     flow_r[p] = __builtin_fma(hfi * hd_w[p], lb_own[p], flow_r[p]);
             }
+        }
+        if (FUSED && frame_llh) {
+            // the frame's expected log-likelihood sum_s gamma_ts l_ts (hmm.py:87) while both
+            // factors are in registers: one wave reduction instead of a pass over two [T, S] arrays
+            T fsum;
+            if constexpr (sizeof(T) == 4) fsum = wave_sum_scalar(fval);
+            else fsum = wave_sum(fval);
+            store_word(fsum, frame_rs, lane == 0 ? (int)(t * (int64_t)sizeof(T)) : kOob);
         }
         if (t > 0) {
             if (scale_now) (void)rescale(beta);
@@ -1342,7 +1355,7 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
     beer_batch b, const T* __restrict__ pc, int S_total, T scale, double* __restrict__ alpha_ws,
     double* __restrict__ hubf_ws, T* __restrict__ out, T resp_scale, int atomic_out,
     double* __restrict__ xi_sum, double* __restrict__ gamma0_sum, double* __restrict__ hub_flow,
-    double* __restrict__ utt_llh, T* __restrict__ lognorm_mean) {
+    double* __restrict__ utt_llh, T* __restrict__ lognorm_mean, T* __restrict__ frame_llh) {
     typedef Rel<T> R;
     typedef typename R::r_t r_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1522,6 +1535,8 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
 #pragma unroll
         for (int p = 0; p < SPL; ++p)
             if (st[p] && gamma0_sum) atomicAdd(gamma0_sum + a_off[p], __builtin_nan(""));
+        if (FUSED && frame_llh)
+            for (int64_t t = lane; t < T_; t += 64) frame_llh[f0 + t] = nan_t;
         if (lane == 0) {
             if (lognorm_mean) lognorm_mean[u] = nan_t;
             if (FUSED && utt_llh) atomicAdd(utt_llh + u, __builtin_nan(""));
@@ -1552,6 +1567,7 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
         const double lognorm = mb + R::lg(wave_sum(sm));   // per frame (graph.py:304-307)
         ln_acc += lognorm;
         const bool ok = lognorm > NINF;
+        T fval = 0;
 #pragma unroll
         for (int p = 0; p < SPL; ++p) {
             // NaN when alpha + beta and lognorm are both -inf, as in the reference
@@ -1563,6 +1579,7 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
                     if (atomic_out) atomicAdd(dst, resp_scale * gT);
                     else *dst = resp_scale * gT;
                     llh_acc += (double)(lt_cur[p] * gT);
+                    fval += lt_cur[p] * gT;
                 } else {
                     out[b.llh_off[u] + t * S + a_off[p]] = (T)gv;
                 }
@@ -1582,6 +1599,10 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
                     flow_r[p] += (ok && val == val) ? val : 0.0;
                 }
             }
+        }
+        if (FUSED && frame_llh) {
+            const T fsum = wave_sum(fval);
+            if (lane == 0) frame_llh[f0 + t] = fsum;
         }
         BEER_WAVE_ORDER();                                 // lb fully read
 #pragma unroll
@@ -1924,7 +1945,7 @@ template <typename T, bool FUSED>
 int wave_fb_launch(const beer_batch* b, const T* pc, int S_total, T scale, double* alpha_ws,
                    double* hub_ws, T* out, T resp_scale, int atomic_out, double* xi_sum,
                    double* gamma0_sum, double* hub_flow, double* utt_llh, T* lognorm_mean,
-                   hipStream_t s) {
+                   T* frame_llh, hipStream_t s) {
     const dim3 grid((unsigned)((b->nutt + kWvWaves - 1) / kWvWaves)), block(64 * kWvWaves);
     const bool xi = !FUSED && xi_sum != nullptr;
     const int spl = b->max_states <= 64 ? 1 : (b->max_states <= 128 ? 2 : 4);
@@ -1940,14 +1961,17 @@ int wave_fb_launch(const beer_batch* b, const T* pc, int S_total, T scale, doubl
         else if (FUSED && atomic_out)                                                           \
             hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_, FUSED>), grid, block, \
                                lds, s, *b, pc, S_total, scale, alpha_ws, hub_ws, out,           \
-                               resp_scale, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean); \
+                               resp_scale, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean, \
+                               frame_llh);                                                     \
         else                                                                                    \
             hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_, false>), grid, block, \
                                lds, s, *b, pc, S_total, scale, alpha_ws, hub_ws, out,           \
-                               resp_scale, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean); \
+                               resp_scale, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean, \
+                               frame_llh);                                                     \
         hipLaunchKernelGGL((fb_wave_log_kernel<T, SPL_, DEG_, FUSED, XI_>), grid, block, lds,  \
                            s, *b, pc, S_total, scale, alpha_ws, hub_ws, out, resp_scale,       \
-                           atomic_out, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean);   \
+                           atomic_out, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean,    \
+                           frame_llh);                                                         \
     } while (0)
 #define BEER_WV_DEG(SPL_, XI_)                                                                  \
     do {                                                                                        \
@@ -1981,7 +2005,7 @@ extern "C" {
 int beer_hmm_posteriors_fused(int dtype, const beer_batch* b, int S_total, const void* pc_all,
                               double scale, double* alpha_ws, double* hub_ws, void* state_resps,
                               int atomic_out, double* gamma0_sum, double* hub_flow,
-                              double* utt_llh, void* stream) {
+                              double* utt_llh, void* frame_llh, void* stream) {
     BEER_REQUIRE(b && b->nutt >= 0 && b->max_states >= 1 && S_total >= 1);
     BEER_REQUIRE(dtype == BEER_F32 || dtype == BEER_F64);
     BEER_REQUIRE(wave_fb_ok(b));
@@ -1992,10 +2016,10 @@ int beer_hmm_posteriors_fused(int dtype, const beer_batch* b, int S_total, const
         return wave_fb_launch<float, true>(b, (const float*)pc_all, S_total, (float)scale,
                                            alpha_ws, hub_ws, (float*)state_resps, (float)scale,
                                            atomic_out, nullptr, gamma0_sum, hub_flow, utt_llh,
-                                           nullptr, s);
+                                           nullptr, (float*)frame_llh, s);
     return wave_fb_launch<double, true>(b, (const double*)pc_all, S_total, scale, alpha_ws,
                                         hub_ws, (double*)state_resps, scale, atomic_out, nullptr,
-                                        gamma0_sum, hub_flow, utt_llh, nullptr, s);
+                                        gamma0_sum, hub_flow, utt_llh, nullptr, (double*)frame_llh, s);
 }
 
 int beer_hmm_gather(int dtype, const beer_batch* batch_h, int S_total, const void* pc_all,
@@ -2024,11 +2048,11 @@ int beer_hmm_forward_backward(int dtype, const beer_batch* b, const void* pc_llh
             return wave_fb_launch<float, false>(b, (const float*)pc_llhs, b->max_states, 1.f,
                                                 alpha_ws, hub_ws, (float*)gamma, 1.f, 0, xi_sum,
                                                 gamma0_sum, hub_flow, nullptr,
-                                                (float*)lognorm_mean, s);
+                                                (float*)lognorm_mean, nullptr, s);
         return wave_fb_launch<double, false>(b, (const double*)pc_llhs, b->max_states, 1.0,
                                              alpha_ws, hub_ws, (double*)gamma, 1.0, 0, xi_sum,
                                              gamma0_sum, hub_flow, nullptr,
-                                             (double*)lognorm_mean, s);
+                                             (double*)lognorm_mean, nullptr, s);
     }
     if (b->all_lowdeg && b->max_states <= kLdThreads && (!xi_sum || hub_flow)) {
         // factorised low-degree recursion: one thread per state

@@ -249,11 +249,12 @@ def fused_ok(batch):
         1 <= st.max_degree <= _hip.SEG and st.max_hubs <= 1 and st.max_hub_members <= 64
 
 
-def posteriors_fused(batch, pc_all, scale=1., want_counts=False, utt_llh=None):
+def posteriors_fused(batch, pc_all, scale=1., want_counts=False, utt_llh=None, frame_llh=None):
     '''Gather + forward-backward + scatter of a shard in one launch
     (`beer_hmm_posteriors_fused`): (state_resps [n_frames, S_total] = scale *
     gamma at the pdf ids, gamma0_sum [S] or None, hub_flow [S] or None);
-    `utt_llh` [nutt] fp64 += sum_t sum_s gamma * scale * pc.  `want_counts`
+    `utt_llh` [nutt] fp64 += sum_t sum_s gamma * scale * pc; `frame_llh` [n_frames]
+    (the batch's dtype) receives that sum per frame (hmm.py:87).  `want_counts`
     (one graph for the whole batch): the posteriors of the first frame and the
     flows through the graph's hub -- what PhoneLoop counts (phoneloop.py:88-95).'''
     dt, dev = batch.dtype, batch.device
@@ -271,9 +272,13 @@ def posteriors_fused(batch, pc_all, scale=1., want_counts=False, utt_llh=None):
         S = batch.n_states[0]
         g0 = torch.zeros(S, dtype=torch.float64, device=dev)
         flow = torch.zeros(S, dtype=torch.float64, device=dev)
+    if frame_llh is not None and (frame_llh.dtype != dt or frame_llh.numel() != batch.n_frames or
+                                  not frame_llh.is_contiguous() or frame_llh.device != sr.device):
+        raise ValueError('frame_llh: a contiguous [n_frames] tensor of the batch\'s dtype and device')
     _hip.call('beer_hmm_posteriors_fused', _hip.dtype_code(dt), batch.ref(), S_total,
               _hip.ptr(pc_all), float(scale), _hip.ptr(alpha), _hip.ptr(hub_ws), _hip.ptr(sr),
-              1 if repeats else 0, _hip.ptr(g0), _hip.ptr(flow), _hip.ptr(utt_llh))
+              1 if repeats else 0, _hip.ptr(g0), _hip.ptr(flow), _hip.ptr(utt_llh),
+              _hip.ptr(frame_llh))
     counting_log_space.note(batch, hub_ws)
     return sr, g0, flow
 

@@ -95,9 +95,10 @@ class HMM(DiscreteLatentModel):
         if fused and need_counts:
             fused = getattr(getattr(batch.dgraphs[0], 'lowdeg', None), 'n_hubs', 0) >= 1
         if fused:
+            # (the per-frame value sum_s gamma l comes out of the same launch)
+            exp_llh = torch.empty(T, dtype=pc_all.dtype, device=pc_all.device)
             state_resps, g0, flow = hk.posteriors_fused(batch, pc_all, scale,
-                                                        want_counts=need_counts)
-            exp_llh = kernels.rowdot(state_resps, pc_all)
+                                                        want_counts=need_counts, frame_llh=exp_llh)
             self.cache.pop('resps', None)
             if trans_posts:
                 self.cache['trans_resps'] = None

@@ -574,13 +574,17 @@ size_t beer_hmm_fb_scratch_doubles(int dtype, const beer_batch* batch_h, int wan
  *                added atomically into the zero-filled array (repeated ids).
  *   utt_llh      (nullable, [nutt] fp64, +=) sum_t sum_s gamma * scale * pc
  *                (hmm.py:87);  gamma0_sum, hub_flow: as above (graph 0 for all).
+ *   frame_llh    (nullable, [n_frames] of dtype, stored) the per-frame value
+ *                sum_s gamma_ts * scale * pc_ts that HMM.expected_log_likelihood returns
+ *                (hmm.py:87), reduced over the wave while both factors are in registers --
+ *                what beer_rowdot(state_resps, pc_all) computes from the two [T, S] arrays.
  *   alpha_ws     fp64 scratch, sum_u T_u * S_u;  hub_ws: fp64 scratch, n_frames.
  * EINVAL when the batch is not of that kind (use the three calls instead). */
 int beer_hmm_posteriors_fused(int dtype, const beer_batch* batch_h, int S_total,
                               const void* pc_all, double scale, double* alpha_ws,
                               double* hub_ws, void* state_resps, int atomic_out,
                               double* gamma0_sum, double* hub_flow, double* utt_llh,
-                              void* stream);
+                              void* frame_llh, void* stream);
 
 /* Per-frame transition posteriors in the reference's own layout, xi [T-1, S, S]
  * (beer/graph.py:308-323: normalised per frame, NaN -> 0), for ONE utterance,

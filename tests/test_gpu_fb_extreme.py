@@ -402,3 +402,66 @@ def test_per_frame_transition_posteriors_through_the_model_protocol(cov):
     assert batch.struct.all_lowdeg == 1
     hk.forward_backward(batch, pc.reshape(-1), dense_xi=True)
     assert batch.struct.all_lowdeg == 1                  # (the shared descriptor is put back)
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+@pytest.mark.parametrize('repeat_ids', [False, True])
+def test_per_frame_value_of_the_fused_launch_is_the_row_dot_product(dtype, repeat_ids):
+    '''`beer_hmm_posteriors_fused(..., frame_llh)`: the per-frame value sum_s gamma_ts scale l_ts
+    (hmm.py:87) reduced inside the forward-backward kernels against `beer_rowdot` of the two
+    [T, S] arrays the launch reads and writes -- acoustic scale 0.7, a ragged batch, with
+    distinct pdf ids (plain stores) and with two states sharing a pdf (atomic scatter); the
+    linear kernel alone, then EVERY utterance through the log-space twin (`BEER_OPT_FB_LOG`),
+    then with a NaN log-likelihood in one utterance: that utterance's values are NaN (its
+    posteriors are, graph.py:274-277), its neighbours' untouched.'''
+    from beer_amd import kernels
+    rng = np.random.RandomState(3 + repeat_ids)
+    S = 11
+    graph = beer.graph.Graph()
+    s0, s1 = graph.add_state(), graph.add_state()
+    graph.start_state, graph.end_state = s0, s1
+    ids = list(range(S))
+    if repeat_ids:
+        ids[7] = ids[2]
+    st = [graph.add_state(pdf_id=i) for i in ids]
+    graph.add_arc(s0, st[0])
+    for i, s in enumerate(st):
+        graph.add_arc(s, s)
+        graph.add_arc(s, st[(i + 1) % S])
+    graph.add_arc(st[-1], s1)
+    graph.normalize()
+    cg = graph.compile()
+    lengths = [33, 70, 12, 129, 64, 18]
+    T = sum(lengths)
+    pc = torch.from_numpy(rng.randn(T, S) * 4 - 30).to(dtype).to(DEV)
+    batch = hk.HmmBatch([cg], [0] * len(lengths), lengths, dtype)
+    assert hk.fused_ok(batch)
+    tol = 1e-12 if dtype == torch.float64 else 2e-6
+
+    def run(pc_in):
+        val = torch.full((T,), 7., dtype=dtype, device=DEV)
+        with hk.counting_log_space() as c:
+            sr, _, _ = hk.posteriors_fused(batch, pc_in, .7, frame_llh=val)
+        return val, kernels.rowdot(sr, pc_in), int(c.count)
+
+    val, want, n_log = run(pc)
+    assert n_log == 0
+    assert_close(npy(val), npy(want), tol, 'linear kernel')
+    old = _hip.set_option('fb_log', 1)
+    try:
+        val2, want2, n_log = run(pc)
+    finally:
+        _hip.set_option('fb_log', old)
+    assert n_log == len(lengths)
+    assert_close(npy(val2), npy(want2), tol, 'log-space twin')
+    assert_close(npy(val2), npy(val), 10 * tol, 'the two kernels')
+    bad = pc.clone()
+    off = sum(lengths[:3])
+    bad[off + 40, 5] = float('nan')
+    val3, want3, n_log = run(bad)
+    assert n_log == 1
+    got3, ref = npy(val3), npy(val)
+    assert np.isnan(got3[off:off + lengths[3]]).all()
+    keep = np.ones(T, bool)
+    keep[off:off + lengths[3]] = False
+    assert_close(got3[keep], ref[keep], 10 * tol, 'neighbours of the NaN utterance')
