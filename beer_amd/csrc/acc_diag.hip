@@ -45,6 +45,7 @@ constexpr int kAdChain = BEER_AD_CHAIN;   // frames a workgroup sums in float32 
 constexpr int kAdInner = BEER_AD_INNER;
 static_assert(kAdChain % kAdInner == 0 && kAdInner % kAdFT == 0, "whole tiles per inner chain");
 constexpr int64_t kAdMinFrames = 16384;   // below: the exact kernels (launch-bound there)
+constexpr size_t kAdMaxPartialBytes = (size_t)512 << 20;   // largest partial-sum workspace asked for
 
 template <int NJ2, int CT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void accd_kernel(
@@ -289,7 +290,8 @@ int launch_accd(int cov, int64_t T_, int D, int K, const float* X, const float* 
 namespace beer_mfma {
 
 bool supported_acc_diag(int cov, int64_t T_, int D, int K) {
-    return (cov == BEER_DIAG || cov == BEER_ISO) && D >= 1 && D <= 64 && K >= 16 &&
+    // (K: the chain's rows are addressed with 32-bit byte offsets, kAdChain K 4 < 2^31)
+    return (cov == BEER_DIAG || cov == BEER_ISO) && D >= 1 && D <= 64 && K >= 16 && K <= 65536 &&
            T_ >= kAdMinFrames;
 }
 
@@ -297,7 +299,10 @@ bool supported_acc_diag(int cov, int64_t T_, int D, int K) {
 size_t acc_diag_workspace_bytes(int cov, int64_t T_, int D, int K) {
     if (!supported_acc_diag(cov, T_, D, K)) return 0;
     const int DP = (D + 15) / 16 * 16;
-    return (size_t)ad_chains(T_) * ad_kp(K) * (2 * DP + 1) * sizeof(float) + 256;
+    const size_t bytes = (size_t)ad_chains(T_) * ad_kp(K) * (2 * DP + 1) * sizeof(float) + 256;
+    // (many components x many frames: the partial sums would outgrow what they save -- 32 MB
+    // at config 4 -- and the call flushes with atomics instead)
+    return bytes <= kAdMaxPartialBytes ? bytes : 0;
 }
 
 int acc_diag_bf16x3(int cov, int64_t T_, int D, int K, const float* X, const float* W, double* acc,

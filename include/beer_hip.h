@@ -282,7 +282,11 @@ size_t beer_accumulate_frames_workspace_bytes(int dtype, int cov, int64_t T, int
  * fp64:  acc[k,:] += sum_t comp_resps[t,k] * state_resps[t, k / G] * phi(x_t).
  * Replaces NormalSet.accumulate (beer/models/normalset.py:121-123) with the
  * joint responsibilities of MixtureSet.accumulate (mixtureset.py:100-112);
- * `state_resps` [T,S] nullable (= 1), `comp_resps` [T,K] nullable (= 1). */
+ * `state_resps` [T,S] nullable (= 1), `comp_resps` [T,K] nullable (= 1).
+ * float32 without BEER_EXACT, diagonal / isotropic, comp_resps given and no state_resps,
+ * T >= 16384, D <= 64, 16 <= K <= 65536: the bf16x3 arithmetic of the E-step (acc_diag.hip:
+ * three bf16 pieces per operand, six MFMAs per product, 512-frame sums on the matrix cores,
+ * float32 to 2048 frames, fp64 beyond); everything else float32: the exact fp32 kernels. */
 int beer_normal_accumulate(int dtype, int cov, int64_t T, int D, int S, int G,
                            const void* X, const void* comp_resps,
                            const void* state_resps, double* acc, void* workspace,

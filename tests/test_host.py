@@ -387,3 +387,22 @@ def test_row_split_weight_gradient_of_the_vae_layers_is_nn_linears(T, monkeypatc
     net = pickle.loads(pickle.dumps(beer.nnet.ResidualFeedForwardNet(4, 1, 3)))
     assert sorted(net.state_dict()) == ['blocks.0.layer1.bias', 'blocks.0.layer1.weight',
                                         'blocks.0.layer2.bias', 'blocks.0.layer2.weight']
+
+
+def test_frames_workspace_of_the_diagonal_accumulation_is_bounded():
+    '''`beer_accumulate_frames_workspace_bytes`: never below the shape's own query; for the
+    float32 diagonal accumulation over frames it holds per-chain partial sums (grows with T) --
+    but never more than 512 MiB (beyond, the call flushes with atomics), and not at all for
+    BEER_EXACT, float64, full covariance or fewer than 16384 frames.'''
+    lib = _hip.lib()
+    q, base = lib.beer_accumulate_frames_workspace_bytes, lib.beer_accumulate_workspace_bytes
+    F32, F64, FULL, DIAG, ISO = _hip.F32, _hip.F64, 0, 1, 2
+    b = base(F32, DIAG, 64, 120, 1)
+    small = q(F32, DIAG, 1_000_000, 64, 120, 1)
+    assert small > b and small == 489 * 128 * (128 + 1) * 4 + 256            # 32 MB at config 4
+    assert q(F32, ISO, 1_000_000, 24, 48, 1) == 489 * 64 * (2 * 32 + 1) * 4 + 256
+    assert q(F32, DIAG, 10_000_000, 64, 65536, 1) == base(F32, DIAG, 64, 65536, 1)  # would be 165 GB
+    assert q(F32, DIAG, 16_383, 64, 120, 1) == b
+    assert q(F32 | _hip.EXACT, DIAG, 1_000_000, 64, 120, 1) == base(F32 | _hip.EXACT, DIAG, 64, 120, 1)
+    assert q(F64, DIAG, 1_000_000, 64, 120, 1) == base(F64, DIAG, 64, 120, 1)
+    assert q(F32, FULL, 1_000_000, 40, 256, 1) == base(F32, FULL, 40, 256, 1)
