@@ -22,6 +22,9 @@ for n in c2:bench c3:bench_config3 c3full:bench_config3_full c4:config4_prior_pa
   [ -n "$f" ] && cp $f profiles/${R}_${b}_kernel_stats.csv
   [ -s $O/${a}_timed_stats.csv ] && cp $O/${a}_timed_stats.csv profiles/${R}_${b}_timed_stats.csv
 done
+# (--profiles-only: called by the job itself ON THE GPU BOX before it runs the bench lines, so that a
+#  line's frac_profiled / traffic are priced on the profile of the very box it runs on)
+[ "$3" = "--profiles-only" ] && exit 0
 cp $O/bench.json profiles/${R}_bench.json
 cp $O/bench_c3.json profiles/${R}_bench_config3.json
 cp $O/bench_c3full.json profiles/${R}_bench_config3_full.json

@@ -37,8 +37,10 @@ find $O/c5_stats -name '*kernel_trace.csv' -delete
 $T rocprofv3 --kernel-trace --stats -f csv -d $O/c4bench_stats -- python bench.py --config4-only --no-cpu-baseline > $O/c4bench_stats.log 2>&1
 find $O/c4bench_stats -name '*kernel_trace.csv' -delete
 du -sh $O
-# the lines: the driver's (needs the kernel times / PMC summary in profiles/ to price frac_profiled:
-# the collector writes them, the next run of the line reads them), and the workloads alone
+bash tools/collect_profiles.sh r05 gpurun_out/r5prof --profiles-only > $O/collect.log 2>&1
+# the lines: the driver's (prices frac_profiled / traffic on profiles/r05_kernel_times.json and
+# r05_pmc.json, which the collector call above has just written from THIS box's passes), and the
+# workloads alone
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2>>$O/err.log
 $T python bench.py --config 3 --steps 6 --warmup 2 > $O/bench_c3.json 2>>$O/err.log
 $T python bench.py --config 3 --cov full --frames 2000000 --no-cpu-baseline --steps 6 --warmup 2 > $O/bench_c3full.json 2>>$O/err.log
