@@ -2542,10 +2542,10 @@ size_t accf_workspace_bytes(int cov, int D, int S, int G) {
 }
 
 // Frame fragment images (frame_image_kernel): diagonal / isotropic statistics of at most
-// 96 columns in at most 3 k-steps, whole float4 rows
+// 96 columns in at most 3 k-steps (D <= 40; any D: the rows are staged with their padding, a
+// dimension beyond D is a zero column of the tile)
 bool supported_frame_image(int cov, int D) {
-    return cov != BEER_FULL && D >= 4 && (D & 3) == 0 && accf_nqt(cov, D) == 6 &&
-           (nslab_of(cov, D) + 7) / 8 <= 3;
+    return cov != BEER_FULL && D >= 1 && accf_nqt(cov, D) == 6 && (nslab_of(cov, D) + 7) / 8 <= 3;
 }
 size_t frame_image_bytes(int cov, int64_t nframes, int D) {
     if (!supported_frame_image(cov, D) || nframes < 0) return 0;

@@ -1712,7 +1712,10 @@ def test_elbo_round_trip_through_the_flat_device_buffer():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('cov,T,D,S,G', [('diagonal', 40000, 40, 24, 16), ('diagonal', 33001, 20, 9, 16),
-                                         ('isotropic', 20011, 12, 6, 32), ('diagonal', 17000, 8, 40, 8)])
+                                         ('isotropic', 20011, 12, 6, 32), ('diagonal', 17000, 8, 40, 8),
+                                         # dimensions that are not a multiple of four (39 = 13 MFCCs x 3)
+                                         ('diagonal', 30011, 39, 24, 16), ('diagonal', 20000, 13, 12, 4),
+                                         ('isotropic', 17001, 26, 5, 16), ('diagonal', 16500, 3, 7, 8)])
 def test_fused_accumulation_with_frame_image_matches_the_plain_kernel(monkeypatch, cov, T, D, S, G):
     '''beer_frame_image + beer_mixtureset_accumulate_fused(frame_image=...) -- the frames'
     fragments built once and loaded -- against the same call that rebuilds them per
