@@ -1,5 +1,6 @@
 """Config 4, diagonal prior: accumulation of the state posteriors over 1 M latent samples --
-the exact float32 kernel on [T, S] posteriors against packing them first and the bf16x3 kernel."""
+the default route (`accd_kernel` since round 5; the exact float32 kernel before) against packing the
+posteriors first and the packed bf16x3 kernel; then the default route against fp64 for several shapes."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -20,11 +21,11 @@ for cov in ('diagonal', 'isotropic'):
     a = kernels.normal_accumulate(st, W, None, S, 1, cov)
     b = kernels.normal_accumulate(st, kernels.pack_resps(st, W, None, S, 1), None, S, 1, cov)
     ref = torch.cat([W.double().t() @ Z.double(), -.5 * (W.double().t() @ (Z.double() ** 2))], 1) if cov == 'diagonal' else None
-    print(cov, 'exact vs packed: max rel', float(((a - b).abs() / (a.abs() + 1e-3)).max()))
+    print(cov, 'default route vs packed route: max rel', float(((a - b).abs() / (a.abs() + 1e-3)).max()))
     if ref is not None:
-        print('  vs fp64: exact', float(((a[:, :2 * D] - ref).abs() / (ref.abs() + 1e-3)).max()),
+        print('  vs fp64: default', float(((a[:, :2 * D] - ref).abs() / (ref.abs() + 1e-3)).max()),
               'packed', float(((b[:, :2 * D] - ref).abs() / (ref.abs() + 1e-3)).max()))
-    print('  exact   %.3f ms' % t(lambda: kernels.normal_accumulate(st, W, None, S, 1, cov)))
+    print('  default %.3f ms' % t(lambda: kernels.normal_accumulate(st, W, None, S, 1, cov)))
     print('  pack    %.3f ms' % t(lambda: kernels.pack_resps(st, W, None, S, 1)))
     p = kernels.pack_resps(st, W, None, S, 1)
     print('  packed  %.3f ms' % t(lambda: kernels.normal_accumulate(st, p, None, S, 1, cov)))
