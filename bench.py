@@ -33,9 +33,13 @@ import socket
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# (multi-process GPU work on this pool needs dmabuf IPC; set before the HIP runtime starts -- the
+#  driver exports it too, this covers a bare `torchrun bench.py`)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np                                        # noqa: E402
+import torch                                              # noqa: E402
+import torch.distributed as dist                          # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
