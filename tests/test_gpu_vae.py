@@ -788,3 +788,40 @@ def test_one_sample_hmm_prior_at_config4_shape_against_the_oracle(cov, S, D, nut
     acc_band = max(1e-5, 1.5 * rel_err(resps32.astype(np.float64).T @ orc.SUFFSTATS[cov](Zn),
                                        resps.T @ orc.SUFFSTATS[cov](Zn)))
     assert_stats_close(npy(acc), resps.T @ orc.SUFFSTATS[cov](Zn), D, acc_band, 'acc')
+
+
+@pytest.mark.gpu
+def test_row_split_layers_on_the_gpu_match_nn_linear():
+    '''`beer_amd.nnet.Linear` at a minibatch size where the split is taken (>= 65536 rows), on the
+    device: the same output and input gradient as nn.Linear, the weight gradient within float32
+    summation noise of the float64 result (and no farther from it than torch's own long-chain
+    product), through a residual block and the VAE's heads as the config-4 step uses them.'''
+    from beer_amd.nnet import linear
+    from gpu_helpers import DEV
+    import beer_amd as beer
+    torch.manual_seed(5)
+    T, fin, fout = 70_003, 40, 128
+    assert T >= linear.ROW_SPLIT_MIN
+    x = torch.randn(T, fin, device=DEV)
+    up = torch.randn(T, fout, device=DEV)
+    lin = beer.nnet.Linear(fin, fout).to(DEV)
+    ref = torch.nn.Linear(fin, fout).to(DEV)
+    ref.load_state_dict(lin.state_dict())
+    ref64 = torch.nn.Linear(fin, fout).to(DEV).double()
+    ref64.load_state_dict(lin.state_dict())
+    xs = [x.clone().requires_grad_(True), x.clone().requires_grad_(True), x.double().requires_grad_(True)]
+    ys = [lin(xs[0]), ref(xs[1]), ref64(xs[2])]
+    assert ys[0].grad_fn.name().startswith('_RowSplitLinear') and torch.equal(ys[0], ys[1])
+    for y, u in zip(ys, (up, up, up.double())):
+        (y.tanh() * u).sum().backward()
+    assert torch.equal(xs[0].grad, xs[1].grad)
+    truth = ref64.weight.grad
+    err_split = float((lin.weight.grad.double() - truth).abs().max() / truth.abs().max())
+    err_torch = float((ref.weight.grad.double() - truth).abs().max() / truth.abs().max())
+    assert err_split <= 2e-6 and err_split <= 2 * err_torch + 1e-7, (err_split, err_torch)
+    assert float((lin.bias.grad.double() - ref64.bias.grad).abs().max() / ref64.bias.grad.abs().max()) <= 2e-6
+    net = beer.nnet.ResidualFeedForwardNet(fin, 2, 64).to(DEV)
+    assert all(isinstance(b.layer1, linear.Linear) and isinstance(b.layer2, linear.Linear) for b in net.blocks)
+    out = net(x.requires_grad_(True))
+    out.sum().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
