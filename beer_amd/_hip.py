@@ -212,6 +212,7 @@ SIGNATURES = {
                              ctypes.c_int32, c_p, c_p, c_p],
     'beer_features_cmn': [ctypes.c_int32, c_p, ctypes.c_int32, ctypes.c_int32, c_p, c_p],
     'beer_copy_pinned': [c_p, c_p, c_z, c_p],
+    'beer_clock_probe': [c_p, c_i, c_p],
     'beer_suffstats_mean': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p],
     'beer_suffstats_backward': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
     'beer_frames_llh_backward': [c_i, c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_z, c_p],

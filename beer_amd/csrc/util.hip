@@ -18,8 +18,14 @@ constexpr OptSpec kOptSpec[BEER_OPT_COUNT] = {
     {0, 0, 1},                // BEER_OPT_FB_LOG
     {1, 0, 1},                // BEER_OPT_K1_LDS
 };
-std::atomic<int> g_opt[BEER_OPT_COUNT] = {{kOptSpec[0].def}, {kOptSpec[1].def}, {kOptSpec[2].def},
-                                          {kOptSpec[3].def}, {kOptSpec[4].def}};
+static_assert(sizeof(kOptSpec) / sizeof(kOptSpec[0]) == BEER_OPT_COUNT, "one OptSpec per option");
+// every option starts at its spec'd default: filled from the table, never listed by hand
+struct OptTable {
+    std::atomic<int> v[BEER_OPT_COUNT];
+    OptTable() { for (int i = 0; i < BEER_OPT_COUNT; ++i) v[i].store(kOptSpec[i].def, std::memory_order_relaxed); }
+};
+OptTable g_tab;
+std::atomic<int>* const g_opt = g_tab.v;
 }  // namespace
 int option(int key) { return g_opt[key].load(std::memory_order_relaxed); }
 }  // namespace beer
@@ -32,9 +38,29 @@ __global__ void copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ d
         dst[i] = src[i];
 }
 
+// One wave asleep between two readings of the shader clock and of the reference clock.
+__global__ void clock_probe_kernel(int64_t* __restrict__ out, int sleeps) {
+    const uint64_t t0 = __builtin_readcyclecounter();
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    const uint64_t t1 = __builtin_readcyclecounter();
+    const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[0] = (int64_t)(t1 - t0);
+        out[1] = (int64_t)(r1 - r0);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int beer_clock_probe(int64_t* ticks_out, int32_t sleeps, void* stream) {
+    if (!ticks_out || sleeps < 1 || sleeps > (1 << 22)) return BEER_EINVAL;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, as_stream(stream), ticks_out, sleeps);
+    BEER_LAUNCH_CHECK();
+    return BEER_OK;
+}
 
 int beer_hip_set_option(int option, int value) {
     if (option < 0 || option >= BEER_OPT_COUNT) return BEER_EINVAL;

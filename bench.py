@@ -23,7 +23,10 @@ One process per GPU, ONE RCCL all-reduce of the accumulated statistics per
 iteration, replicated M-step.  With --gpus N > 1 and no launcher in the
 environment (no WORLD_SIZE) the script spawns its own N ranks; under
 `python -m torch.distributed.run` it takes RANK / LOCAL_RANK / WORLD_SIZE from
-the environment.  Rank 0 prints ONE JSON line.
+the environment.  Rank 0 prints ONE compact JSON line on stdout (benchlib/format.py: the
+contract's keys, the headline's roofline and cpu_baseline, a `summary` of the other
+configurations; < 4 KB); the full objects -- per-kernel tables, the other configurations' own
+rooflines and baselines -- go to bench_detail.json and to stderr.
 """
 
 import argparse
@@ -48,143 +51,20 @@ import beer_amd as beer                                   # noqa: E402
 from beer_amd import _hip                                  # noqa: E402
 from beer_amd.distributed import all_reduce_elbo, shard_utterances   # noqa: E402
 
-K, D = 256, 40
-Q = D * D + D + 2
-# MI355X_MICROARCH.md: dense MFMA peaks (f32 operands; bf16 operands / f32 accumulate), the fp32
-# vector peak (= the f32 MFMA peak), HBM3E
-PEAK_TFLOPS = {'f32': 157.3, 'f64': 78.6, 'bf16': 2500.}
-PEAK_HBM_GBS = 8000.
+from benchlib.shapes import (D, K, LATENT, N_COMP, N_PHONES, PEAK_HBM_GBS, PEAK_TFLOPS, Q,   # noqa: E402,F401
+                             TOPO)
+from benchlib.timers import (ClockProbe, KernelTimer, PhaseTimer, kernel_times_entry, pmc_entry,            # noqa: E402,F401
+                             pmc_traffic, profiled)
+from benchlib.baselines import (cpu_baseline_config1, cpu_baseline_config5,                     # noqa: E402,F401
+                                cpu_baseline_features, cpu_baseline_gmm,
+                                cpu_baseline_graph_compile, cpu_baseline_hmm,
+                                cpu_baseline_vae_prior, gmm_parity_check, host_cores)
+from benchlib.format import emit, summary                 # noqa: E402,F401
 
 
 # --------------------------------------------------------------------------------------------
 # shared pieces
 # --------------------------------------------------------------------------------------------
-
-class KernelTimer:
-    'HIP-event timing of chosen C-ABI calls on the launching (current) stream.'
-
-    def __init__(self, names):
-        self.names, self.events = set(names), {n: [] for n in names}
-        self._orig = _hip.call
-
-    def __enter__(self):
-        def timed(name, *args):
-            if name not in self.names:
-                return self._orig(name, *args)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            self._orig(name, *args)
-            b.record()
-            self.events[name].append((a, b))
-        _hip.call = timed
-        return self
-
-    def __exit__(self, *exc):
-        _hip.call = self._orig
-
-    def mean_ms(self, name):
-        ev = self.events[name]
-        return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev)), len(ev)
-
-
-class PhaseTimer:
-    'HIP-event timing of named phases of a step (all-reduce, M-step) on the current stream.'
-
-    def __init__(self):
-        self.spans = {}
-
-    def span(self, name):
-        timer = self
-
-        class _Span:
-            def __enter__(self):
-                self.a = torch.cuda.Event(enable_timing=True)
-                self.b = torch.cuda.Event(enable_timing=True)
-                self.a.record()
-
-            def __exit__(self, *exc):
-                self.b.record()
-                timer.spans.setdefault(name, []).append((self.a, self.b))
-        return _Span()
-
-    def mean_ms(self, name):
-        ev = self.spans.get(name, [])
-        return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
-
-    def clear(self):
-        self.spans = {}
-
-
-def pmc_traffic(kernel_key):
-    '''HBM bytes per launch of a kernel from the committed PMC passes
-    (profiles/r*_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    passes, full-size launches of this same command).  Counters cannot be read
-    from inside the timed run, so this is the last profiled value; None if absent.'''
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')), reverse=True):
-        try:
-            k = json.load(open(path))['kernels'][kernel_key]
-            # FETCH_SIZE under-reports wide (16 B / lane) coalesced reads by 2x on gfx950
-            # (MI355X_MICROARCH.md): kernels that stream with 16-byte loads are corrected
-            read = k['hbm_read_bytes_raw'] * (2. if k.get('wide_loads', kernel_key.startswith('acc'))
-                                              else 1.)
-            if not read:
-                continue
-            return read + k['hbm_write_bytes']
-        except Exception:
-            continue
-    return None
-
-
-def kernel_times_entry(kernel_key):
-    """The committed profile of a kernel's launches (profiles/r*_kernel_times.json, written by
-    tools/trace_stats.py from `rocprofv3 --kernel-trace` of the same command at the bench's own
-    step counts, warm-up launches dropped), newest round first; ({}, None) if absent."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_times.json')), reverse=True):
-        try:
-            return json.load(open(path))['kernels'][kernel_key], os.path.relpath(path, ROOT)
-        except Exception:
-            continue
-    return {}, None
-
-
-def profiled(kernel_key, roof, per_launch_scale=1.):
-    """What the committed profiles say about the roofline's kernel: `traffic` (HBM bytes per
-    launch from the PMC passes, `traffic_source`), and the same fraction priced on the PROFILED
-    average launch time (`frac_profiled`, `profiled_avg_launch_ms`, `profiled_clock_ghz`): the
-    line's own `frac` uses the HIP events of this run."""
-    out = {'traffic': None, 'traffic_source': None}
-    if not kernel_key:
-        return out
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')), reverse=True):
-        try:
-            json.load(open(path))['kernels'][kernel_key]
-        except Exception:
-            continue
-        t = pmc_traffic(kernel_key)
-        if t:
-            out['traffic'], out['traffic_source'] = t * per_launch_scale, os.path.relpath(path, ROOT)
-        out['profiled_clock_ghz'] = pmc_entry(kernel_key).get('clock_ghz')
-        break
-    kt, src = kernel_times_entry(kernel_key)
-    if kt.get('avg_ms') and roof.get('avg_launch_ms') and roof.get('frac') is not None:
-        out['profiled_avg_launch_ms'] = kt['avg_ms'] * per_launch_scale
-        out['frac_profiled'] = roof['frac'] * roof['avg_launch_ms'] / (kt['avg_ms'] * per_launch_scale)
-        out['profiled_source'] = src
-    return out
-
-
-def pmc_entry(kernel_key):
-    'The committed PMC summary of a kernel (profiles/r*_pmc.json), newest round first; {} if absent.'
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')), reverse=True):
-        try:
-            return json.load(open(path))['kernels'][kernel_key]
-        except Exception:
-            continue
-    return {}
 
 
 def m_step_mode(optim):
@@ -262,149 +142,6 @@ def make_gmm(device):
     return beer.Mixture.create(ns, prior_strength=1.).to(device)
 
 
-def cpu_baseline_gmm(frames_target=1 << 20, chunk=8192, budget_s=15.):
-    '''beer's CPU path on the host cores: the reference's own op sequence replayed
-    with torch CPU ops (oracle/torch_port.py; numerically identical to the
-    reference) on a bounded sample of config 2.'''
-    from oracle import torch_port as tp
-    g = torch.Generator().manual_seed(3)
-    n = 16 * chunk
-    means = torch.randn(K, D, generator=g) * 2
-    X = means[torch.randint(0, K, (n,), generator=g)] + torch.randn(n, D, generator=g)
-    mean, cov = X.mean(0), torch.cov(X.t())
-    dof = torch.full((K, 1), float(D))
-    prior = (mean.repeat(K, 1), torch.ones(K, 1), (cov.inverse() / D).repeat(K, 1, 1), dof)
-    post = (prior[0] + torch.randn(K, D, generator=g) * cov.diag().sqrt(),) + prior[1:]
-    w = torch.full((K,), 1. / K)
-    # Pick the thread count that serves the reference's op mix best on this
-    # host (all hardware threads is usually NOT it: the element-wise passes
-    # thrash).  The baseline is then timed at that setting.
-    ncpu = os.cpu_count() or 1
-    best = (0., torch.get_num_threads())
-    probe = {}
-    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
-        torch.set_num_threads(nt)
-        tp.gmm_elbo(X[:chunk], post, prior, w, w, n)                   # warm-up
-        t = time.perf_counter()
-        tp.gmm_elbo(X[chunk:2 * chunk], post, prior, w, w, n)
-        rate = chunk / (time.perf_counter() - t)
-        probe[str(nt)] = rate
-        if rate > best[0]:
-            best = (rate, nt)
-    torch.set_num_threads(best[1])
-    t0 = time.perf_counter()
-    done, acc_n, acc_w = 0, 0., 0.
-    while done < frames_target and time.perf_counter() - t0 < budget_s:
-        lo = done % n
-        _, an, aw = tp.gmm_elbo(X[lo:lo + chunk], post, prior, w, w, n)
-        acc_n, acc_w = acc_n + an, acc_w + aw
-        done += chunk
-    tp.gmm_update(post, prior, w, w, acc_n * (n / done), acc_w * (n / done), D)
-    dt = time.perf_counter() - t0
-    return {'value': done / dt, 'unit': 'frames/s', 'cores': int(torch.get_num_threads()),
-            **host_cores(), 'kind': 'port',
-            'frames_per_s_by_threads': probe,
-            'threads_note': '`cores` = the thread count that served the reference\'s op mix best '
-                            '(one 8192-frame utterance per count, `frames_per_s_by_threads`: also '
-                            'one whole socket, 64 threads); `value` is timed at that count',
-            'sample': f'{done} frames of the config-2 workload (K=256 full-cov, D=40, fp32) in '
-                      f'{chunk}-frame utterances + 1 M-step, torch-CPU replay of the '
-                      f'reference op sequence, {dt:.1f} s'}
-
-
-def host_cores():
-    '''The host the CPU baseline ran on: hardware threads, physical cores and sockets
-    (/proc/cpuinfo); `cores` of a cpu_baseline is the number of threads the baseline
-    actually used (the best of the thread counts probed), these say out of how many.'''
-    out = {'host_threads': os.cpu_count() or 1}
-    try:
-        phys, sockets = set(), set()
-        pid = cid = None
-        for line in open('/proc/cpuinfo'):
-            if line.startswith('physical id'):
-                pid = line.split(':')[1].strip()
-                sockets.add(pid)
-            elif line.startswith('core id'):
-                cid = line.split(':')[1].strip()
-            elif not line.strip():
-                if pid is not None and cid is not None:
-                    phys.add((pid, cid))
-                pid = cid = None
-        if phys:
-            out['host_cores'] = len(phys)
-            out['host_sockets'] = len(sockets)
-            out['host_cores_per_socket'] = len(phys) // max(1, len(sockets))
-    except OSError:
-        pass
-    return out
-
-
-def cpu_baseline_features(signals, conf=None):
-    '''cpu_baseline leg of tools/bench_features.py: the numpy oracle of the
-    feature front-end on a bounded sample of utterances, one host core.
-    Returns (frames per second, list of feature matrices).'''
-    from oracle import features_oracle as fo
-    t0 = time.perf_counter()
-    feats = [fo.extract(sig, conf) for sig in signals]
-    dt = time.perf_counter() - t0
-    return sum(len(f) for f in feats) / dt, feats
-
-
-def cpu_baseline_graph_compile(sequences, units, graph_cls):
-    '''cpu_baseline leg of tools/bench_hmm.py: alignment graphs of a bounded
-    sample of transcriptions with the plain-Python restatement of the
-    reference's builder + Graph.compile (oracle/graph_oracle.py), one host
-    core.  Returns seconds per utterance.'''
-    from oracle import graph_oracle as go
-    t0 = time.perf_counter()
-    for seq in sequences:
-        go.compile_graph(go.alignment_graph(seq, units, graph_cls))
-    return (time.perf_counter() - t0) / max(1, len(sequences))
-
-
-def gmm_parity_check(model, X, n=65536, chunk=8192):
-    '''The kernels the timed loop runs (packed hand-over: n >= 16384 frames) against
-    the fp64 numpy oracle on the same frames, in BOTH float32 arithmetics: relative error of
-    the ELBO and of the accumulated statistics -- the whole array and per block (counts,
-    first moments, second moments, each against its own largest entry) plus the mean
-    relative bias of the counts (the matrix core's truncating accumulate shows there
-    first).  Returns {mode: {...}}.'''
-    from oracle import beer_oracle as orc
-    p0, p1 = list(model.bayesian_parameters())
-
-    def as64(d):
-        return [getattr(d.params, nm).cpu().numpy().astype(np.float64)
-                for nm in d._std_params_def]
-    post, prior, w_post, w_prior = as64(p0.posterior), as64(p0.prior), as64(p1.posterior)[0], \
-        as64(p1.prior)[0]
-    Xh = X[:n].cpu().numpy().astype(np.float64)
-    per_frame, acc_n, kl = 0., 0., None
-    for lo in range(0, n, chunk):
-        r = orc.gmm_elbo_step(Xh[lo:lo + chunk], 'full', post, prior, w_post, w_prior)
-        per_frame += r['per_frame'].sum()
-        acc_n, kl = acc_n + r['acc_normal'], r['kl']
-    truth = per_frame - kl
-
-    def rel(a, b):
-        return float(np.abs(a - b).max() / np.abs(b).max())
-    out = {}
-    for mode in ('bf16x3', 'exact'):
-        old = beer.get_f32_mode()
-        beer.set_f32_mode(mode)
-        try:
-            elbo = beer.accumulate_elbo(model, (X[:n], [n]), datasize=n)
-        finally:
-            beer.set_f32_mode(old)
-        got = elbo._acc_stats[p0].cpu().numpy().astype(np.float64)
-        out[mode] = {'elbo_rel_err': abs(float(elbo) - truth) / abs(truth),
-                     'stats_rel_err': rel(got, acc_n),
-                     'first_moments_rel_err': rel(got[:, :D], acc_n[:, :D]),
-                     'second_moments_rel_err': rel(got[:, D:-2], acc_n[:, D:-2]),
-                     'counts_rel_err': rel(got[:, -2:], acc_n[:, -2:]),
-                     'counts_mean_rel_bias': float(((got[:, -2] - acc_n[:, -2]) / acc_n[:, -2]).mean())}
-    return out
-
-
 def run_gmm(args, rank, world, device, backend):
     frames = args.frames
     if args.scaling == 'strong':              # a fixed corpus of args.frames, sharded
@@ -472,6 +209,9 @@ def run_gmm(args, rank, world, device, backend):
 
     elapsed, kt, elbo = timed_loop(args.steps, args.warmup)
     kern = kernel_table(kt, args.steps)
+    # the shader clock the iteration's kernels run at on THIS box (a sleeping wave on a side stream)
+    # (every rank: the step holds a collective)
+    clock = ClockProbe(device).measure(step, 1e3 * elapsed / args.steps)
     allreduce_ms, mstep_ms = phases.mean_ms('all_reduce'), phases.mean_ms('m_step')
     mode = beer.get_f32_mode()
     # secondary: the same iteration on the exact fp32 MFMA (every product an fmaf)
@@ -544,7 +284,7 @@ def run_gmm(args, rank, world, device, backend):
                           'accumulation (not narrower than fp32: 24-bit operands, product error '
                           '<= 2^-23)' if split else 'v_mfma_f32_16x16x4_f32',
         'all_reduce_ms': allreduce_ms, 'm_step_ms': mstep_ms,
-        'm_step': m_step_mode(optim),
+        'm_step': m_step_mode(optim), 'clock': clock,
         'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'],
                      'peak': peak, 'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / peak,
                      'avg_launch_ms': kern[dom]['ms'], 'note': note},
@@ -562,8 +302,6 @@ def run_gmm(args, rank, world, device, backend):
 # config 3: monophone phone-loop HMM
 # --------------------------------------------------------------------------------------------
 
-N_PHONES, N_COMP = 40, 16
-TOPO = [(0, 1, 1.), (1, 1, .75), (1, 2, .25), (2, 2, .75), (2, 3, .25), (3, 3, .75), (3, 4, .25)]
 
 
 def make_phone_loop(cov, device, dim=None, n_comp=None):
@@ -612,65 +350,6 @@ def hmm_corpus(total_frames):
     while sum(lengths) < total_frames:
         lengths.append(int(rng.randint(200, 401)))
     return lengths
-
-
-def cpu_baseline_hmm(budget_s=20.):
-    '''beer's CPU path for config 3 on the host cores: the reference's op sequence for one
-    `evidence_lower_bound(PhoneLoop, utterance)` per utterance -- phi(X), stats @ E[T]^T,
-    per-state logsumexp, a Python loop of dense [S, S] logsumexp per frame for forward
-    and backward, [T-1, S, S] transition posteriors, joint responsibilities^T @ stats,
-    KL of every parameter per utterance -- replayed with torch CPU ops
-    (oracle/torch_port.py: hmm_elbo) on a bounded sample of utterances.'''
-    from oracle import torch_port as tp
-    g = torch.Generator().manual_seed(5)
-    S, G = 3 * N_PHONES, N_COMP
-    KK = S * G
-    prior = (torch.zeros(KK, D), torch.ones(KK, 1), torch.ones(KK, 1), torch.ones(KK, D))
-    post = (torch.randn(KK, D, generator=g),) + prior[1:]
-    w = torch.ones(S, G)
-    trans = torch.full((S, S), -float('inf'))
-    for s in range(S):
-        trans[s, s] = np.log(.75)
-        if s % 3 < 2:
-            trans[s, s + 1] = np.log(.25)
-        else:
-            trans[s, ::3] = np.log(.25 / N_PHONES)
-    init = torch.where(torch.arange(S) % 3 == 0, torch.tensor(np.log(1. / N_PHONES)),
-                       torch.tensor(-float('inf'))).float()
-    fin = torch.where(torch.arange(S) % 3 == 2, torch.tensor(np.log(.25)),
-                      torch.tensor(-float('inf'))).float()
-    rng = np.random.RandomState(2)
-    ncpu = os.cpu_count() or 1
-    best = (0., torch.get_num_threads())
-    probe = torch.randn(300, D, generator=g)
-    for nt in sorted({min(ncpu, c) for c in (4, 8, 16)}):
-        torch.set_num_threads(nt)
-        t = time.perf_counter()
-        tp.hmm_elbo(probe, post, prior, w, w, init, fin, trans, 10_000_000)
-        rate = 300 / (time.perf_counter() - t)
-        if rate > best[0]:
-            best = (rate, nt)
-    torch.set_num_threads(best[1])
-    t0 = time.perf_counter()
-    frames = utts = 0
-    acc = 0.
-    while time.perf_counter() - t0 < budget_s:
-        T = int(rng.randint(200, 401))
-        X = torch.randn(T, D, generator=g)
-        _, a, _, _ = tp.hmm_elbo(X, post, prior, w, w, init, fin, trans, 10_000_000)
-        acc = acc + a
-        frames += T
-        utts += 1
-    dt = time.perf_counter() - t0
-    return {'value': frames / dt, 'unit': 'frames/s', 'cores': int(torch.get_num_threads()),
-            **host_cores(), 'kind': 'port',
-            'sample': f'{utts} utterances ({frames} frames) of the config-3 workload (phone loop '
-                      f'40x3 states, 16 diagonal Gaussians per state, D=40, fp32): the per-utterance '
-                      f'evidence_lower_bound calls of accumulate.py:39-59 (E-step, forward-backward, '
-                      f'statistics, KL), torch-CPU replay of the reference op sequence, {dt:.1f} s; '
-                      f'the once-per-iteration update of update.py:41-62 (1920 diagonal posteriors, '
-                      f'< 1 ms on the host against {1e7 / (frames / dt):.0f} s of accumulation for '
-                      f'the 10 M frames) is not in the sample'}
 
 
 def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, steps=None,
@@ -733,6 +412,7 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
         fence(world)
         elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, world, device, backend)
+    clock = ClockProbe(device).measure(step, 1e3 * elapsed / steps)    # (every rank: a collective)
     if os.environ.get('BEER_BENCH_NO_KT'):
         print('NO_KT ms/step', elapsed / steps * 1e3, file=sys.stderr)
         return None
@@ -814,7 +494,7 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
         'count_conservation_rel_err': conservation,
         'f32_mode': beer.get_f32_mode(),
         'all_reduce_ms': phases.mean_ms('all_reduce'), 'm_step_ms': phases.mean_ms('m_step'),
-        'm_step': m_step_mode(optim),
+        'm_step': m_step_mode(optim), 'clock': clock,
         'roofline': roof,
         'kernels': kern,
     }
@@ -854,51 +534,6 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
 # config 4: HMM-VAE (the prior's "statistics-in" hot path)
 # --------------------------------------------------------------------------------------------
 
-LATENT = 64
-
-
-def cpu_baseline_vae_prior(cov, budget_s=8.):
-    """The prior hot path of config 4 on the host: per utterance phi(z), stats @ E[T]^T, the Python
-    forward-backward loop over the dense 120 x 120 matrix, autograd back to the samples,
-    gamma^T @ stats (oracle/torch_port.py: vae_hmm_prior_path, the reference's op sequence,
-    vae.py:63-86 / hmm.py:73-100) on a bounded sample of utterances."""
-    from oracle import torch_port as tp
-    g = torch.Generator().manual_seed(6)
-    S, Dz = 3 * N_PHONES, LATENT
-    if cov == 'full':
-        post = (torch.randn(S, Dz, generator=g), torch.ones(S, 1),
-                torch.eye(Dz).repeat(S, 1, 1) / Dz, torch.full((S, 1), float(Dz)))
-    else:
-        post = (torch.randn(S, Dz, generator=g), torch.ones(S, 1), torch.ones(S, 1), torch.ones(S, Dz))
-    trans = torch.full((S, S), -float('inf'))
-    for st in range(S):
-        trans[st, st] = np.log(.75)
-        if st % 3 < 2:
-            trans[st, st + 1] = np.log(.25)
-        else:
-            trans[st, ::3] = np.log(.25 / N_PHONES)
-    init = torch.where(torch.arange(S) % 3 == 0, torch.tensor(np.log(1. / N_PHONES)),
-                       torch.tensor(-float('inf'))).float()
-    fin = torch.where(torch.arange(S) % 3 == 2, torch.tensor(np.log(.25)),
-                      torch.tensor(-float('inf'))).float()
-    rng = np.random.RandomState(4)
-    nt = torch.get_num_threads()
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    tp.vae_hmm_prior_path(torch.randn(50, Dz, generator=g), cov, post, init, fin, trans)
-    t0 = time.perf_counter()
-    frames = utts = 0
-    while time.perf_counter() - t0 < budget_s:
-        T = int(rng.randint(200, 401))
-        tp.vae_hmm_prior_path(torch.randn(T, Dz, generator=g), cov, post, init, fin, trans)
-        frames += T
-        utts += 1
-    dt = time.perf_counter() - t0
-    cores = int(torch.get_num_threads())
-    torch.set_num_threads(nt)
-    return {'value': frames / dt, 'unit': 'frames/s', 'cores': cores, **host_cores(), 'kind': 'port',
-            'sample': f'{utts} utterances ({frames} latent samples) through the prior hot path of '
-                      f'config 4 ({cov} Gaussians, 64-d latent, 120 states): torch-CPU replay of the '
-                      f'reference op sequence incl. autograd, {dt:.1f} s'}
 
 
 def run_vae(args, device, frames=5_000_000, n_minibatches=5, warmup=1):
@@ -1185,62 +820,6 @@ def run_config5(args, device, hours=None, epochs=5, n_comp=4, cpu_sample=6):
     return out
 
 
-def cpu_baseline_config5(signals, seqs, units, ploop, mean, var, epochs, n_comp, total, m):
-    """The same stages on the host for a sample of `m` utterances, with the CPU restatements of
-    the reference (oracle/features_oracle.py, graph_oracle.py, torch_port.hmm_elbo with the
-    alignment graph's pdf ids, beer_oracle.best_path), projected to the corpus: stage time x
-    (utterances / m) (x epochs for training)."""
-    from oracle import beer_oracle as orc, features_oracle as fo, graph_oracle as go, torch_port as tp
-    S = 3 * N_PHONES
-    nutt = len(signals)
-    pick = list(range(0, nutt, max(1, nutt // m)))[:m]
-    t = {}
-    t0 = time.perf_counter()
-    sig_h = [signals[u].cpu().numpy() for u in pick]
-    feats = [fo.extract(sg) for sg in sig_h]
-    t['features'] = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    cgs = [go.compile_graph(go.alignment_graph(seqs[u], units, beer.graph.Graph)) for u in pick]
-    t['alignment_graphs'] = time.perf_counter() - t0
-    D = feats[0].shape[1]
-    KK = S * n_comp
-    gen = torch.Generator().manual_seed(5)
-    prior = (mean.cpu().float().repeat(KK, 1), torch.ones(KK, 1), torch.ones(KK, 1),
-             var.cpu().float().repeat(KK, 1))
-    post = (prior[0] + .1 * torch.randn(KK, D, generator=gen) * var.cpu().float().sqrt(),) + prior[1:]
-    w = torch.ones(S, n_comp)
-    nt = torch.get_num_threads()
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    t0 = time.perf_counter()
-    for f, cg in zip(feats, cgs):
-        Xh = torch.from_numpy(f).float()
-        with np.errstate(divide='ignore'):
-            init, fin, trans = [torch.from_numpy(np.log(np.asarray(a, dtype=np.float32))) for a in cg[:3]]
-        tp.hmm_elbo(Xh, post, prior, w, w, init, fin, trans, total, trans_posteriors=False,
-                    order=list(cg[3]))
-    t['training_one_epoch'] = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    for f, cg in zip(feats, cgs):
-        with np.errstate(divide='ignore'):
-            init, fin, trans = [np.log(np.asarray(a, dtype=np.float64)) for a in cg[:3]]
-        pc = np.random.RandomState(0).randn(len(f), len(init))
-        orc.best_path(pc, init, fin, trans)
-    t['viterbi_align'] = time.perf_counter() - t0
-    torch.set_num_threads(nt)
-    scale = nutt / float(len(pick))
-    proj = {'features': t['features'] * scale, 'alignment_graphs': t['alignment_graphs'] * scale,
-            'training': t['training_one_epoch'] * scale * epochs, 'viterbi_align': t['viterbi_align'] * scale}
-    wall = sum(proj.values())
-    return {'value': total / wall, 'unit': 'frames/s', 'cores': int(min(16, os.cpu_count() or 1)),
-            **host_cores(), 'kind': 'port', 'projected_wall_s': wall, 'projected_stages_s': proj,
-            'sample_stages_s': t,
-            'sample': f'{len(pick)} of the {nutt} utterances through the CPU restatements of the '
-                      'reference stage by stage (features: numpy, one core; alignment graphs: the '
-                      'reference\'s pure-Python builder + compile; training: torch replay of '
-                      'evidence_lower_bound with the alignment graph, one epoch; Viterbi: numpy '
-                      'best_path on the graph\'s states), projected to the corpus and the epochs'}
-
-
 # --------------------------------------------------------------------------------------------
 # config 1: diagonal GMM K = 8, D = 2, 1000 frames -- the latency of ONE iteration
 # --------------------------------------------------------------------------------------------
@@ -1253,7 +832,6 @@ def run_config1(args, device, iters=400):
     the library's default (the M-step of a group replayed from its captured graph), and the
     whole iteration as one captured HIP graph (`beer.CapturedIteration`); pipelined (the host
     never waits) and with the ELBO read back after every iteration, as the notebook does."""
-    from oracle import torch_port as tp
     g = torch.Generator().manual_seed(0)
     X = torch.randn(1000, 2, dtype=torch.float64, generator=g)
 
@@ -1303,34 +881,7 @@ def run_config1(args, device, iters=400):
     out['value'] = out['captured']['frames_per_s']
     out['unit'] = 'frames/s (1000-frame iterations; see us_per_iteration)'
     if not args.no_cpu_baseline:
-        # the port of the reference's op sequence for this model (oracle/torch_port.py:
-        # gmm_diag_iteration, pinned on the reference's golden G1) on the host, fp64
-        as64 = lambda d: tuple(getattr(d.params, n).detach().cpu().double().clone()       # noqa: E731
-                               for n in d._std_params_def)
-        m = make()
-        p0, p1 = list(m.bayesian_parameters())
-        post, prior = as64(p0.posterior), as64(p0.prior)
-        w_post, w_prior = as64(p1.posterior)[0], as64(p1.prior)[0]
-        nt = torch.get_num_threads()
-        torch.set_num_threads(1)
-        for _ in range(3):
-            tp.gmm_diag_iteration(X, post, prior, w_post, w_prior)
-        t0 = time.perf_counter()
-        n = 0
-        while time.perf_counter() - t0 < 2.:
-            _, post, w_post = tp.gmm_diag_iteration(X, post, prior, w_post, w_prior)
-            n += 1
-        dt = (time.perf_counter() - t0) / n
-        torch.set_num_threads(nt)
-        out['cpu_baseline'] = {'value': 1000 / dt, 'unit': 'frames/s', 'us_per_iteration': 1e6 * dt,
-                               'cores': 1, **host_cores(), 'kind': 'port',
-                               'sample': f'{n} iterations of the config-1 workload, torch-CPU replay '
-                                         'of the reference op sequence (oracle/torch_port.py: '
-                                         'gmm_diag_iteration), one thread',
-                               'reference_calibration': 'the imported reference itself needs 0.160 s '
-                                                        'per iteration on the survey container '
-                                                        '(BASELINE.md section 2: overhead-bound -- '
-                                                        'Python objects, not arithmetic)'}
+        out['cpu_baseline'] = cpu_baseline_config1(X, make)
     return out
 
 
@@ -1363,7 +914,7 @@ def config3_subobject(line):
     keep = ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'scaling', 'f32_mode', 'kernels',
             'roofline', 'cpu_baseline', 'frame_image', 'count_conservation_rel_err', 'elbo_per_frame',
             'all_reduce_ms', 'm_step_ms', 'm_step', 'frames_per_rank', 'ranks', 'backend',
-            'fixed_ms_per_step', 'kernels_ms_per_step', 'shard')
+            'fixed_ms_per_step', 'kernels_ms_per_step', 'shard', 'clock')
     sub = {k: line[k] for k in keep if k in line}
     sub['workload'] = line['config']['workload']
     return sub
@@ -1378,35 +929,6 @@ def shard_projection(full, shard, n):
             'shard_ms_per_step': shard['ms_per_step'], 'ratio_to_ideal': shard['ms_per_step'] / ideal,
             'speedup': full['ms_per_step'] / shard['ms_per_step'],
             'frames_per_s': full['config']['frames_total'] / (shard['ms_per_step'] * 1e-3)}
-
-
-def summary(out):
-    'The numbers of the line in one short object (its last key).'
-    s = {'config2_frames_per_s': round(out['value']), 'config2_ms_per_step': round(out['ms_per_step'], 3)}
-    roof = out.get('roofline') or {}
-    if roof.get('frac') is not None:
-        s['config2_roofline_frac'] = round(roof['frac'], 4)
-    for key in ('config3', 'config3_full', 'config3_shard'):
-        if key in out:
-            s[key + '_frames_per_s'] = round(out[key]['value'])
-            s[key + '_ms_per_step'] = round(out[key]['ms_per_step'], 3)
-    if 'config3_shard' in out:
-        s['config3_projected_8gpu_speedup'] = round(out['config3_shard']['projected_8gpu']['speedup'], 2)
-    c4 = out.get('config4')
-    if c4:
-        for cov in ('diagonal', 'full'):
-            if cov in c4:
-                s[f'config4_prior_{cov}_frames_per_s'] = round(c4[cov]['prior_hot_path']['value'])
-                s[f'config4_step_{cov}_frames_per_s'] = round(c4[cov]['vae_step']['value'])
-    c1 = out.get('config1')
-    if c1:
-        s['config1_us_per_iteration'] = {k: round(c1[k]['us_per_iteration'], 1)
-                                         for k in ('eager', 'default', 'captured') if k in c1}
-    c5 = out.get('config5')
-    if c5:
-        s['config5_frames_per_s'] = round(c5['value'])
-        s['config5_wall_s'] = round(c5['wall_s'], 3)
-    return s
 
 
 # --------------------------------------------------------------------------------------------
@@ -1472,8 +994,14 @@ def worker(args):
             out['config5'] = run_config5(args, device)
     if rank == 0:
         if args.config == 2:
-            out['summary'] = summary(out)      # (last key: the tail of the line shows it)
-        print(json.dumps(out), flush=True)
+            out['summary'] = summary(out)
+        else:
+            out['summary'] = {'config3_frames_per_s': round(out['value']),
+                              'config3_ms_per_step': round(out['ms_per_step'], 3),
+                              'config3_roofline_frac': round(out['roofline']['frac'], 4)}
+        # stdout carries ONE compact line (< 4 KB: what the driver parses); the full objects go
+        # to bench_detail.json and, one JSON line per sub-object, to stderr
+        emit(out, ROOT)
     if world > 1:
         dist.destroy_process_group()
 

@@ -789,6 +789,14 @@ int beer_features_cmn(int32_t nutt, const int64_t* frame_off, int32_t D, int32_t
 int beer_copy_pinned(void* dst_device, const void* src_pinned_host, size_t nbytes,
                      void* stream);
 
+/* Measurement aid (bench.py's `clock`): one wave sleeps through `sleeps` x s_sleep 127 and
+ * writes the elapsed ticks of the shader clock (s_memtime) and of the fixed 100 MHz reference
+ * clock (s_memrealtime) to `ticks_out[0..1]` (device).  Launched on a side stream while the
+ * kernels of an iteration run, their ratio x 100 MHz is the clock those kernels really ran at
+ * -- what a roofline fraction measured on one box needs to be compared with another box's.
+ * Replaces nothing of the reference (beer has no device clock to read). */
+int beer_clock_probe(int64_t* ticks_out, int32_t sleeps, void* stream);
+
 /* ---- graph compilation (HOST functions: host pointers, no stream) -----------
  * Graph.compile (beer/graph.py:185-240) and create_graph_from_seq
  * (beer/cli/subcommands/hmm/mkaligraph.py:18-39) in O(states + arcs), for one

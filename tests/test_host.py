@@ -56,6 +56,39 @@ def test_tuning_options_are_clamped():
         _hip.set_option('accf_rounds', 0)
 
 
+def test_every_option_starts_at_its_documented_default():
+    """Each BEER_OPT_* of include/beer_hip.h documents "Default N": a FRESH load of the library
+    (its own process: no test has touched the options, no BEER_* preset in the environment)
+    must report exactly that for every option, and `_hip.OPTIONS` must name every one of them
+    (round 5 shipped BEER_OPT_K1_LDS documented 1, actual 0)."""
+    import re
+    import subprocess
+    import sys
+    text = open(os.path.join(ROOT, 'include', 'beer_hip.h')).read()
+    count = int(re.search(r'#define\s+BEER_OPT_COUNT\s+(\d+)', text).group(1))
+    documented = {}
+    for m in re.finditer(r'#define\s+(BEER_OPT_\w+)\s+(\d+)\s*/\*(.*?)\*/', text, re.S):
+        if m.group(1) == 'BEER_OPT_COUNT':
+            continue
+        d = re.search(r'Default\s+(\d+)', m.group(3))
+        assert d, f'{m.group(1)}: no "Default N" in its comment'
+        documented[int(m.group(2))] = int(d.group(1))
+    assert sorted(documented) == list(range(count))
+    assert sorted(code for code, _ in _hip.OPTIONS.values()) == list(range(count))
+    env = {k: v for k, v in os.environ.items() if not k.startswith('BEER_')}
+    out = subprocess.run(
+        [sys.executable, '-c',
+         'import ctypes, sys; l = ctypes.CDLL(sys.argv[1]); '
+         f'print([l.beer_hip_get_option(i) for i in range({count})])', _hip.LIB_PATH],
+        env=env, check=True, capture_output=True, text=True).stdout
+    assert eval(out) == [documented[i] for i in range(count)]
+    # and through the loader the package uses (the environment presets only when set)
+    if not any(env_name in os.environ for _, env_name in _hip.OPTIONS.values()):
+        for name, (code, _) in _hip.OPTIONS.items():
+            if name != 'ax_max_frames':          # (restored by the test above)
+                assert _hip.get_option(name) == documented[code], name
+
+
 def test_struct_layouts_match_header():
     # 4 int32 + 14 pointers; 6 int32 + 6 pointers (LP64)
     assert ctypes.sizeof(_hip.Graph) == 16 + 15 * 8
