@@ -1014,7 +1014,9 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
 #pragma unroll
             for (int p = 0; p < SPL; ++p) {
                 m = __builtin_fmaxf(m, (float)ll[k][p]);  // (lanes without a state read state 0's)
-                bad |= ll[k][p] != ll[k][p];
+                // (only the graph's own pdf columns count, as in the reference: the value a
+                //  state-less lane read belongs to another utterance's graph)
+                bad |= st[p] && ll[k][p] != ll[k][p];
             }
         m = wave_fmax(m);
         gave_up |= __builtin_amdgcn_ballot_w64(bad) != 0;
@@ -1487,7 +1489,7 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
 #pragma unroll
         for (int p = 0; p < SPL; ++p) {
             ll[p] = ll_next[p];
-            bad |= ll[p] != ll[p];
+            bad |= st[p] && ll[p] != ll[p];               // (the graph's own pdf columns only)
             ll_next[p] = load_ll(t + 1 < T_ ? t + 1 : t, p);
         }
         double hub = NINF;

@@ -65,15 +65,19 @@ class ShardStatics:
     capture of the iteration as a HIP graph (`CapturedIteration`).'''
 
     def __init__(self):
-        self.key, self.items, self.lengths = None, {}, None
+        self.key, self.items, self.lengths, self.mark = None, {}, None, None
 
     def bind(self, lengths):
         '''The shard these statics belong to: the same list object (the usual case: O(1)) or
         an equal one keeps them, anything else empties them.'''
-        if self.lengths is not lengths:
-            if self.lengths != lengths:
+        n = len(lengths)
+        mark = (n, lengths[0], lengths[n // 2], lengths[-1]) if n else (0,)
+        if self.lengths is not lengths or self.mark != mark:
+            # (the same list edited in place is caught where it is cheap to look: its length
+            #  and three of its entries)
+            if self.mark != mark or self.lengths != lengths:
                 self.key, self.items = None, {}
-            self.lengths = lengths
+            self.lengths, self.mark = lengths, mark
 
     def entry(self, key, name, make):
         if self.key != key:
@@ -95,7 +99,7 @@ def pack_utterances(utterances):
         X, lengths = utterances
         # (a list of Python ints is handed through as it is: `ShardStatics` recognises the
         # caller's list by identity)
-        if not (isinstance(lengths, list) and all(type(n) is int for n in lengths[:4])):
+        if not (isinstance(lengths, list) and set(map(type, lengths)) <= {int}):
             lengths = [int(n) for n in lengths]
         return _hip.on_device(X), lengths
     utterances = list(utterances)
@@ -368,6 +372,20 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
         if free_loop:
             batch = _cached_batch(model.graph, run_lengths, dtype)
         else:
+            def images_of(uniq):
+                """What a cached descriptor's struct pointers point into: one blob per GraphSet
+                (alignment graphs compiled together share it), the memoised device image of every
+                other graph (rebuilt -- a NEW object -- when its tensors are replaced or rewritten)."""
+                sets, out = {}, []
+                for g in uniq:
+                    owner = getattr(g, '_set', None)
+                    if owner is None:
+                        out.append(g.device_graph(dtype))
+                    elif id(owner) not in sets:
+                        sets[id(owner)] = True
+                        out.append(owner.device_image(dtype)[0])
+                return out
+
             def make_batch():
                 uniq, ids, seen = [], [], {}
                 for u in run:
@@ -376,11 +394,18 @@ def _hmm_batch(model, X, lengths, datasize, graphs, scale, viterbi, state_paths,
                         seen[id(g)] = len(uniq)
                         uniq.append(g)
                     ids.append(seen[id(g)])
-                return hk.HmmBatch(uniq, ids, run_lengths, dtype), graphs
+                return hk.HmmBatch(uniq, ids, run_lengths, dtype), graphs, uniq, images_of(uniq)
             # (the descriptor of a run's alignment graphs -- thousands of graph structs, one
-            # upload -- is the caller's to keep with the shard: the same list of graphs gives
-            # the same descriptor; the list itself is held so that its identity stays unique)
-            batch, _ = statics.entry(skey, ('batch', run_index, id(graphs), str(dtype)), make_batch)
+            # upload -- is the caller's to keep with the shard.  Its key names everything the cut
+            # into runs depends on (bytes per frame, max_frames) and the list of graphs (identity,
+            # length, the run's first and last graph); a hit is still checked against the device
+            # images its struct pointers were taken from)
+            bkey = ('batch', run_index, bpf, max_frames, id(graphs), len(graphs),
+                    id(graphs[run[0]]), id(graphs[run[-1]]), str(dtype))
+            batch, _, uniq, images = statics.entry(skey, bkey, make_batch)
+            if not all(a is b for a, b in zip(images, images_of(uniq))):
+                statics.items.pop(bkey)
+                batch, _, uniq, images = statics.entry(skey, bkey, make_batch)
         hard = viterbi or state_paths is not None
         # phone counts come from the flows through the loop's hub (the eliminated
         # pivot); a loop whose end -> start arcs stayed ordinary arcs needs xi

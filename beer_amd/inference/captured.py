@@ -70,7 +70,8 @@ class CapturedIteration:
         else:
             self.data = _hip.on_device(data)
         self.datasize, self.kwargs = datasize, kwargs
-        self._entries = {}                 # turn -> None (warmed up) | False (eager) | entry
+        self._entries = {}                 # turn -> None (warmed up) | entry
+        self._all_eager = False            # a group that cannot be recorded: every turn eager
         self.mode = None
 
     # -- the reference's loop body ------------------------------------------------------
@@ -92,9 +93,39 @@ class CapturedIteration:
         value = self._iteration().value
         return value if isinstance(value, torch.Tensor) else torch.as_tensor(value)
 
-    def _signature(self, members):
-        return (self.optim.lrate, self.data.data_ptr(), tuple(self.data.shape),
-                tuple(id(t) for p in members for t in p.posterior._tensors()))
+    def _device_images(self):
+        """The device images a recorded E-step reads besides the posteriors: the CSR copy of
+        every compiled graph the model (or the call's `inference_graphs`) holds.  A rebuilt image
+        is a new object; the recording would go on reading the old one."""
+        from ..graph import CompiledGraph
+
+        def image(g):
+            return vars(g).get('_device_memo', (None,) * 4)[3]
+        images = [image(g) for m in self.model.modules() for g in vars(m).values()
+                  if isinstance(g, CompiledGraph)]
+        extra = self.kwargs.get('inference_graphs')
+        if extra is not None and len(extra):
+            owners = {id(o): o for o in (getattr(extra[0], '_set', None), getattr(extra[-1], '_set', None))
+                      if o is not None}
+            if owners:                     # graphs of a GraphSet: one blob per set and dtype
+                images += [len(extra)] + [blob for o in owners.values() for blob, _ in o._images.values()]
+            else:
+                images += [image(g) for g in extra if isinstance(g, CompiledGraph)]
+        return tuple(images)
+
+    def _signature(self):
+        """What every recording of this object depends on: the learning rate, the data, the
+        posterior tensors of EVERY mean-field group (the E-step of one group's turn reads all of
+        them) and the graphs' device images.  The tuple holds the objects themselves -- compared by
+        identity, and kept alive so that no identity can be reused."""
+        every = [p for group in self.optim.groups for p in group]
+        return (self.optim.lrate, self.data.data_ptr(), tuple(self.data.shape)) + \
+            tuple(t for p in every for t in p.posterior._tensors()) + self._device_images()
+
+    @staticmethod
+    def _same(a, b):
+        return len(a) == len(b) and a[:3] == b[:3] and \
+            all(x is y or (isinstance(x, int) and x == y) for x, y in zip(a[3:], b[3:]))
 
     def __call__(self):
         optim = self.optim
@@ -103,13 +134,16 @@ class CapturedIteration:
         turn = optim.update_count % len(optim.groups)
         members = optim.groups[turn]
         entry = self._entries.get(turn, 'new')
+        if self._all_eager:
+            return self._eager()
         if entry == 'new':
             self._entries[turn] = None
             return self._eager()
-        if entry is False:
-            return self._eager()
-        if entry is not None and entry['signature'] != self._signature(members):
-            entry = None                   # posterior replaced from outside, new learning rate
+        if entry is not None and not self._same(entry['signature'], self._signature()):
+            # a posterior of ANY group replaced from outside (or by a group's eager warm-up turn),
+            # a rebuilt graph image, a new learning rate: every recording read the old objects
+            self._entries = {t: None for t in self._entries}
+            entry = None
         if entry is None:
             entry = self._capture(turn, members)
             if entry is None:
@@ -128,9 +162,12 @@ class CapturedIteration:
     def _capture(self, turn, members):
         optim = self.optim
         every = [p for group in optim.groups for p in group]
-        if not VBConjugateOptimizer._capturable(members) or \
+        # EVERY group has to be recordable: a group that stays eager (host callback, host graph
+        # tensors, non-conjugate parameter) replaces its posterior tensors each turn, and the other
+        # groups' recordings would go on reading the old -- possibly freed -- ones.
+        if not all(VBConjugateOptimizer._capturable(group) for group in optim.groups) or \
                 not all(t.is_cuda for p in every for t in p.posterior._tensors()):
-            self._entries[turn] = False
+            self._all_eager = True
             return None
         homes = [p.posterior.params for p in members]
         home_tensors = [tuple(p.posterior._tensors()) for p in members]
@@ -151,7 +188,7 @@ class CapturedIteration:
                 or 900 <= -(err.rc or 0) <= 908
             if not refused:
                 raise
-            self._entries[turn] = False
+            self._all_eager = True
             warnings.warn(f'CapturedIteration: the iteration could not be recorded as a HIP graph '
                           f'({type(err).__name__}: {err}); it runs eagerly', RuntimeWarning)
             return None
@@ -162,6 +199,6 @@ class CapturedIteration:
                 p.posterior.params = params
             _drop_memos(every)
         entry = {'graph': graph, 'value': value, 'stats': [p.stats for p in members],
-                 'signature': self._signature(members)}
+                 'signature': self._signature()}
         self._entries[turn] = entry
         return entry

@@ -38,6 +38,12 @@ class VBConjugateOptimizer:
         # instead of ~20 per parameter -- whenever the group can be captured (device tensors,
         # device-only callbacks: `_capturable`); other groups, and every group with
         # graph=False or BEER_MSTEP_GRAPH=0, take the eager update.
+        # IN-PLACE semantics of the replayed update: the reference replaces the posterior's
+        # tensors at every update (parameters.py:134-141); a replay rewrites the tensors of the
+        # capture instead.  Code that keeps references to a posterior's tensors across updates
+        # (a convergence check, a snapshot) sees them change: `.clone()` what has to stay, or
+        # construct with graph=False for the reference's replace-on-update behaviour.  The first
+        # update of every group synchronises the device once (the capture).
         self.graph = (os.environ.get('BEER_MSTEP_GRAPH', '1') != '0') if graph is None \
             else bool(graph)
         self._captured = {}

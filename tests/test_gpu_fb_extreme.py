@@ -465,3 +465,58 @@ def test_per_frame_value_of_the_fused_launch_is_the_row_dot_product(dtype, repea
     keep = np.ones(T, bool)
     keep[off:off + lengths[3]] = False
     assert_close(got3[keep], ref[keep], 10 * tol, 'neighbours of the NaN utterance')
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+@pytest.mark.parametrize('log_space', [False, True])
+def test_a_nan_in_a_pdf_column_the_graph_does_not_use_is_ignored(dtype, log_space):
+    '''The fused launch reads the per-pdf rows [T, S_total] through each graph's pdf ids; lanes
+    without a state read element 0 of the row.  A NaN in pdf 0's column must not flag an
+    utterance whose graph never emits pdf 0 (the reference only gathers the graph's own
+    columns: hmm.py:73-80) -- round-5 advisor finding (hmm.hip all-NaN path).'''
+    rng = np.random.RandomState(11)
+    S_total, S = 9, 5
+    graph = beer.graph.Graph()
+    s0, s1 = graph.add_state(), graph.add_state()
+    graph.start_state, graph.end_state = s0, s1
+    ids = [3, 4, 6, 7, 8][:S]                               # (pdf 0 is nobody's)
+    st = [graph.add_state(pdf_id=i) for i in ids]
+    graph.add_arc(s0, st[0])
+    for i, s in enumerate(st):
+        graph.add_arc(s, s)
+        if i + 1 < S:
+            graph.add_arc(s, st[i + 1])
+    graph.add_arc(st[-1], s1)
+    graph.normalize()
+    cg = graph.compile()
+    lengths = [40, 17, 64]
+    T = sum(lengths)
+    pc = torch.from_numpy(rng.randn(T, S_total) * 3 - 20).to(dtype).to(DEV)
+    batch = hk.HmmBatch([cg], [0] * len(lengths), lengths, dtype)
+    assert hk.fused_ok(batch)
+    bad = pc.clone()
+    bad[:, 0] = float('nan')
+    bad[45, 1] = float('nan')                               # (another column nobody uses)
+    old = _hip.set_option('fb_log', int(log_space))
+    try:
+        with hk.counting_log_space() as c:
+            want, _, _ = hk.posteriors_fused(batch, pc, 1.)
+            n_clean = int(c.count)
+        with hk.counting_log_space() as c:
+            got, _, _ = hk.posteriors_fused(batch, bad, 1.)
+            n_bad = int(c.count)
+    finally:
+        _hip.set_option('fb_log', old)
+    assert n_bad == n_clean == (len(lengths) if log_space else 0)
+    got, want = npy(got), npy(want)
+    assert not np.isnan(got[:, ids]).any()
+    np.testing.assert_array_equal(got[:, ids], want[:, ids])
+    # and against the oracle on the graph's own columns
+    init, fin, trans = [npy(t).astype(np.float64) for t in
+                        (cg.init_log_probs, cg.final_log_probs, cg.trans_log_probs)]
+    tol = 1e-12 if dtype == torch.float64 else 1e-5
+    off = 0
+    for n in lengths:
+        truth = orc.posteriors(npy(pc[off:off + n][:, ids]).astype(np.float64), init, fin, trans)
+        assert_close(got[off:off + n][:, ids], truth[0], tol, 'state posteriors')
+        off += n

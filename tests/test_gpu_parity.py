@@ -2068,6 +2068,62 @@ def test_captured_iteration_over_a_shard_of_utterances_equals_the_eager_loop():
 
 
 @pytest.mark.gpu
+def test_captured_iteration_notices_a_posterior_replaced_in_another_group():
+    """Round-5 advisor finding: the recorded E-step of one group's turn reads EVERY group's
+    posterior tensors.  Replacing the posterior of a group that is NOT in turn (a state-dict
+    load, a re-initialisation) must invalidate all recordings: the iterations after the
+    replacement equal the eager loop's, and the first of them is recorded anew."""
+    P, G, D = 5, 3, 8
+    rng = np.random.RandomState(5)
+    lens = [int(n) for n in rng.randint(40, 90, 16)]
+    X = tt(rng.randn(sum(lens), D).astype(np.float32))
+    N = 10 * sum(lens)
+
+    def disturb(ploop, optim):
+        # the group whose turn is NOT next gets new posterior tensors with new values
+        turn = optim.update_count % len(optim.groups)
+        other = optim.groups[(turn + 1) % len(optim.groups)]
+        for p in other:
+            # (a convex combination of two valid natural parameters is valid)
+            eta = .9 * p.posterior.natural_parameters().detach() + .1 * p.prior.natural_parameters().detach()
+            p.posterior.update_from_natural_parameters(eta.clone())
+            p.dispatch(before_update=False)
+
+    def run(captured):
+        ploop = _phone_loop(P, G, D, 'diagonal', torch.float32, seed=4)
+        optim = beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.)
+        n_groups = len(optim.groups)
+        values, modes = [], []
+        it = beer.CapturedIteration(ploop, optim, (X, lens), datasize=N) if captured else None
+
+        def one():
+            if captured:
+                values.append(float(it()))
+                modes.append(it.mode)
+            else:
+                optim.init_step()
+                elbo = beer.accumulate_elbo(ploop, (X, lens), datasize=N)
+                elbo.backward()
+                optim.step()
+                values.append(float(elbo))
+        for _ in range(3 * n_groups):
+            one()
+        disturb(ploop, optim)
+        for _ in range(2 * n_groups):
+            one()
+        return values, modes, n_groups, \
+            [npy(t) for p in ploop.bayesian_parameters() for t in p.posterior._tensors()]
+    ev, _, n_groups, ep = run(False)
+    cv, modes, _, cp = run(True)
+    assert modes[3 * n_groups - 1] == 'replayed', modes
+    assert modes[3 * n_groups] == 'captured', modes          # (the replacement was noticed)
+    assert modes[-1] == 'replayed', modes
+    assert_close(np.asarray(cv), np.asarray(ev), 1e-6, 'ELBO per iteration')
+    for a, b in zip(cp, ep):
+        assert_close(a, b, 1e-5, 'posteriors at the end')
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('K,G,D,T', [(256, None, 40, 33000), (96, 16, 24, 20011), (512, 128, 32, 17000),
                                      (256, None, 44, 17000), (128, None, 48, 16999), (256, 64, 52, 18000),
                                      (64, None, 64, 16500)])
