@@ -912,7 +912,9 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
             fin_w[p] = exp((double)fin[j]);
             if (FUSED) id = ids[j];
         }
-        ll_off[p] = st[p] ? (FUSED ? (int64_t)id : (int64_t)j) : 0;    // (always a valid element)
+        // (lanes without a state: the pdf of the graph's OWN state 0 -- always a valid element, and
+        //  never another graph's column, whose NaN is not this utterance's)
+        ll_off[p] = st[p] ? (FUSED ? (int64_t)id : (int64_t)j) : (FUSED ? (int64_t)ids[0] : 0);
         a_off[p] = j;
 #pragma unroll
         for (int k = 0; k < DEG; ++k) {
@@ -1409,7 +1411,9 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
             fin_w[p] = fin[j];
             if (FUSED) id = ids[j];
         }
-        ll_off[p] = st[p] ? (FUSED ? (int64_t)id : (int64_t)j) : 0;    // (always a valid element)
+        // (lanes without a state: the pdf of the graph's OWN state 0 -- always a valid element, and
+        //  never another graph's column, whose NaN is not this utterance's)
+        ll_off[p] = st[p] ? (FUSED ? (int64_t)id : (int64_t)j) : (FUSED ? (int64_t)ids[0] : 0);
         a_off[p] = j;
 #pragma unroll
         for (int k = 0; k < DEG; ++k) {

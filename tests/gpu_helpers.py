@@ -84,3 +84,28 @@ def check_posterior(param, g, prefix, tol, assert_close):
     for name, ref in zip(param.posterior._std_params_def, std_params(g, prefix)):
         got = npy(getattr(param.posterior.params, name)).reshape(ref.shape)
         assert_close(got, ref, tol, f'{prefix}.{name}')
+
+
+def oracle_mixtureset(X, cov, ns, weights_model, S, G, state_resps=None, dtype=np.float64):
+    """The numpy oracle's truth for what the mixture(-set) kernels compute from frames `X`, a
+    NormalSet `ns` of S * G components and the Dirichlet posterior of `weights_model`
+    (a Mixture: S = 1, or a MixtureSet): per-state log-normalisers [T, S], responsibilities
+    within each state's mixture [T, S * G], and -- with the state posteriors `state_resps`
+    [T, S] (None: ones) -- the accumulated statistics of the Gaussians [S * G, Q] and of the
+    weights [S, G].  beer/models/mixtureset.py:85-112 (mixture.py:70-102 for S = 1) through
+    oracle/beer_oracle.py, in `dtype` arithmetic (float32: the reference's own float32 run)."""
+    from helpers import orc
+    Xn = npy(X).astype(dtype) if hasattr(X, 'cpu') else np.asarray(X, dtype=dtype)
+    p = ns.means_precisions.posterior
+    post = [npy(getattr(p.params, n)).astype(dtype) for n in p._std_params_def]
+    cat = weights_model.categorical if hasattr(weights_model, 'categorical') \
+        else weights_model.categoricalset
+    conc = npy(cat.weights.posterior.params.concentrations).astype(dtype).reshape(S, G)
+    stats = orc.SUFFSTATS[cov](Xn)
+    exp_T = orc.FAMILIES[cov]['exp'](*post)
+    lw = orc.log_weights(conc[0])[None] if S == 1 else orc.log_weights_set(conc)
+    ln, cr = orc.mixtureset_estep(stats, exp_T, Xn.shape[1], lw.astype(dtype))
+    sr = np.ones((len(Xn), S), dtype=dtype) if state_resps is None else \
+        (npy(state_resps) if hasattr(state_resps, 'cpu') else np.asarray(state_resps)).astype(dtype)
+    wstats, acc = orc.mixtureset_accumulate(stats, cr, sr)
+    return dict(ln=ln, resps=cr.reshape(len(Xn), S * G), acc=acc, wstats=wstats)

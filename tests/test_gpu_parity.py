@@ -7,13 +7,14 @@ import pytest
 import torch
 
 from helpers import (COV_OF, assert_close, assert_stats_close, assert_within_f32_band, dist_cls,
-                     load_golden, orc, stat_blocks, std_params)
+                     load_golden, orc, rel_err, stat_blocks, std_params)
 
 pytestmark = pytest.mark.gpu
 
 import beer_amd as beer                       # noqa: E402
 from gpu_helpers import (DEV, build_dist, build_graph, build_hmm, build_mixture,   # noqa: E402
-                         build_param, build_phoneloop, check_posterior, npy, params_of, tt)
+                         build_param, build_phoneloop, check_posterior, npy, oracle_mixtureset,
+                         params_of, tt)
 
 # Tolerances (relative to the largest reference entry).  fp64 models: every
 # kernel computes in fp64.  fp32 models: north-star bound 1e-5 on ELBO and
@@ -1385,6 +1386,14 @@ def test_fast_path_mixture_sets(cov, S, G, D):
         assert err['bf16x3'][0] <= 2e-6 * ln_scale and err['bf16x3'][1] <= 2e-6 * ln_scale, \
             (err, ln_scale)
     assert err['bf16x3'][2] <= 2e-6, err
+    # ... and DIRECTLY against the numpy oracle (mixtureset.py:85-112): the log-normalisers and,
+    # with the oracle's own responsibilities x state posteriors, the statistics per block
+    truth = oracle_mixtureset(X.float(), cov, ns, mset, S, G, state_resps=sr64.float())
+    ln_b, r_b = kernels.mixtureset_estep(st32, E64.float(), lw64.float(), S, G, cov)
+    acc_b = kernels.normal_accumulate(st32, r_b, sr64.float(), S, G, cov)
+    assert_close(npy(ln_b), truth['ln'], 1e-5, 'log-normalisers vs oracle')
+    assert np.abs(npy(r_b).astype(np.float64) - truth['resps']).max() <= 1e-4
+    assert_stats_close(npy(acc_b), truth['acc'], D, 1e-5, 'statistics vs oracle')
     if cov == 'full' and kernels.packed_sets_ok(st32, S, G, cov):
         # the hand-over an HMM iteration uses: packed tiles of the responsibilities within each
         # state's mixture, the state posteriors folded in by the accumulation kernel
@@ -1393,6 +1402,8 @@ def test_fast_path_mixture_sets(cov, S, G, D):
         assert float((ln_p.double() - ln64).abs().max()) <= \
             max(2. * err['exact'][0] + 1e-7, 2e-6 * float(ln64.abs().max()))
         assert float((acc_p - acc64).abs().max() / acc64.abs().max()) <= 5e-6
+        assert_close(npy(ln_p), truth['ln'], 1e-5, 'packed log-normalisers vs oracle')
+        assert_stats_close(npy(acc_p), truth['acc'], D, 1e-5, 'packed statistics vs oracle')
 
 
 @pytest.mark.parametrize('cov,K,D,T', [('full', 256, 40, 40001), ('diagonal', 256, 40, 33000),
@@ -1446,6 +1457,11 @@ def test_packed_responsibilities_match_the_two_call_path(cov, K, D, T):
     ln_scale = float(ln64.abs().max())
     assert float((ln_p.double() - ln64).abs().max()) <= \
         2. * float((ln_e.double() - ln64).abs().max()) + 1e-6 * ln_scale
+    # directly against the numpy oracle (mixture.py:70-102)
+    truth = oracle_mixtureset(X.float(), cov, ns, mix, 1, K)
+    assert_close(npy(ln_p), truth['ln'], 1e-5, 'log-normalisers vs oracle')
+    assert np.abs(npy(packed.unpack()).astype(np.float64) - truth['resps']).max() <= 1e-4
+    assert_stats_close(npy(acc_p), truth['acc'], D, 1e-5, 'statistics vs oracle')
 
 
 class _no_packed:
@@ -1541,6 +1557,18 @@ def test_packed_hand_over_random_shapes():
         if not l_p <= 2. * l_e + 1e-6 * float(ln64.abs().max()):
             failures.append((case, cov, D, K, T, 'log-normalisers', l_p, l_e))
         assert float((packed.unpack().double() - r64).abs().max()) < 1e-4, (cov, D, K, T)
+        # directly against the numpy oracle
+        # (1e-5, or -- where float32 logits cannot do that -- the error of the oracle's own
+        # float32 run of the reference's op sequence: assert_within_f32_band's rule)
+        truth = oracle_mixtureset(X.float(), cov, ns, mix, 1, K)
+        ref32 = oracle_mixtureset(X.float(), cov, ns, mix, 1, K, dtype=np.float32)
+        if rel_err(npy(ln_p), truth['ln']) > max(1e-5, rel_err(ref32['ln'], truth['ln'])):
+            failures.append((case, cov, D, K, T, 'log-normalisers vs oracle', rel_err(npy(ln_p), truth['ln'])))
+        for name, sl in stat_blocks(acc64.shape[-1], D):
+            e = rel_err(npy(acc_p)[..., sl], truth['acc'][..., sl])
+            band = max(1e-5, rel_err(ref32['acc'][..., sl], truth['acc'][..., sl]))
+            if e > band:
+                failures.append((case, cov, D, K, T, name + ' vs oracle', f'{e:.2e} > {band:.2e}'))
     assert not failures, failures
 
 
@@ -1594,6 +1622,10 @@ def test_fused_accumulation_recomputes_the_responsibilities(cov, S, G, D, T):
         # values of magnitude ~100 carry up to 3.8e-6 of rounding, zero-mean per frame,
         # which scales a frame's responsibilities; the two-call path never stores them)
         assert err <= max(5e-6, 3. * err2), (cov, S, G, D, err, err2)
+        # directly against the numpy oracle (mixtureset.py:100-112), per block of the statistics
+        truth = oracle_mixtureset(X.float(), cov, ns, ms, S, G, state_resps=state)
+        assert_stats_close(npy(got), truth['acc'], D, 1e-5, 'fused statistics vs oracle')
+        assert_close(npy(ln32), truth['ln'], 1e-5, 'log-normalisers vs oracle')
     # += semantics
     again = kernels.mixtureset_accumulate_fused(st32, E64.float(), lw64.float(), ln32, None, S, G,
                                                 cov, acc=got.clone())
@@ -1623,6 +1655,10 @@ def test_pack_resps_and_repacked_accumulation(cov, S, G, D):
     packed = kernels.pack_resps(st32, r.float(), sr.float(), S, G)
     acc_p = kernels.normal_accumulate(st32, packed, None, S, G, cov)
     assert float((acc_p - acc64).abs().max() / acc64.abs().max()) <= 2e-6
+    # directly against numpy: joint responsibilities^T @ statistics (mixtureset.py:100-112)
+    joint = npy(r.float()).astype(np.float64) * np.repeat(npy(sr.float()).astype(np.float64), G, axis=1)
+    truth_acc = joint.T @ orc.SUFFSTATS[cov](npy(X.float()).astype(np.float64))
+    assert_stats_close(npy(acc_p), truth_acc, D, 1e-5, 'repacked statistics vs oracle')
     # what normal_accumulate itself does with float32 operands (repacks when it pays)
     acc32 = kernels.normal_accumulate(st32, r.float(), sr.float(), S, G, cov)
     assert float((acc32 - acc64).abs().max() / acc64.abs().max()) <= 2e-6
@@ -1668,6 +1704,11 @@ def test_packed_hand_over_of_a_mixture_set(S, G, D, T):
     err, err2 = float((got - acc64).abs().max()) / scale, float((two - acc64).abs().max()) / scale
     assert bool(torch.isfinite(got).all())
     assert err <= max(2e-6, 3. * err2), (S, G, D, err, err2)
+    # directly against the numpy oracle (mixtureset.py:85-112)
+    truth = oracle_mixtureset(X.float(), cov, ns, ms, S, G, state_resps=sr64.float())
+    assert_close(npy(ln32), truth['ln'], 1e-5, 'log-normalisers vs oracle')
+    assert np.abs(npy(packed.unpack()).astype(np.float64) - truth['resps']).max() <= 1e-4
+    assert_stats_close(npy(got), truth['acc'], D, 1e-5, 'statistics vs oracle')
     # the counts: sum_t r[t,k] gamma[t, state(k)] to 1e-6 of the largest
     n64 = (r64 * sr64.repeat_interleave(G, dim=1)).sum(0)
     Q = acc64.shape[1]
