@@ -131,7 +131,10 @@ __host__ __device__ inline size_t frame_image_tile_u4(int nk_used, int nqt) {
 // slab closes a k-step with a constant, estep_tiles.h: diag_walk).  The counts N_k, the only
 // statistic a constant slab carries, are summed on the vector ALU (accfi_kernel): a sixth
 // tile for one useful column in sixteen cost 24 of a wave-tile's 288 MFMAs.
-constexpr int kImgNQT = 5;
+// Up to 3 k-steps (D <= 40) the image carries 5 tiles; the 4-k-step format of D = 41 .. 48
+// (22 / 24 data slabs: the recipes' 13 MFCCs + energy with deltas are 42 dimensions) 6.
+__host__ __device__ constexpr int img_nqt(int nk_used) { return nk_used <= 3 ? 5 : 6; }
+constexpr int kImgMaxNK = 4;
 __host__ __device__ inline int stat_slab(int j) { return j + j / 7; }
 // k-steps (8 slabs each), padded to an even count: the K1 loop is unrolled by two
 __host__ __device__ inline int nk16_of(int cov, int D) {
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(kThreads, MT * NT <= 32 ? 2 : 1) void llhx_kernel(
     // statistics' fragments, which this kernel does not use
     const u4* ti = nullptr;
     if constexpr (IMG)
-        ti = img + (fb / FW) * (int64_t)frame_image_tile_u4(nku, kImgNQT) + lane;
+        ti = img + (fb / FW) * (int64_t)frame_image_tile_u4(nku, img_nqt(nku)) + lane;
     auto load_a = [&](int s, AFrag& f) {
 #pragma unroll
         for (int q = 0; q < NP; ++q)
@@ -1711,13 +1714,18 @@ __global__ __launch_bounds__(256) void frame_image_kernel(int64_t nframes, int D
     }
 }
 
-template <int NKU, int WAVES = 8>
+// NS: the states a 64-component chunk may reach into, a block of NS consecutive ones whose
+// normalisers / posteriors a wave stages per tile -- 4 (groups of >= 16 Gaussians: config 3) or 16
+// (groups of 4 .. 12: the recipes' 4 and 10 Gaussians per state).
+template <int NKU, int WAVES = 8, int NS = 4>
 __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
     int64_t nframes, int K, int S, int G, int Greal, int nk, int nslab,
     const u4* __restrict__ img, const u4* __restrict__ Pall, const float* __restrict__ log_norm,
     const float* __restrict__ sr, int64_t frames_per_block, double* __restrict__ Sp,
     const float* __restrict__ c0p) {
-    constexpr int NTC = 4, NQT = kImgNQT, MT = 2, FW = 32, NTHREADS = 64 * WAVES;
+    constexpr int NTC = 4, NQT = img_nqt(NKU), MT = 2, FW = 32, NTHREADS = 64 * WAVES;
+    // (the 6-tile format leaves no registers for a third B fragment in flight)
+    constexpr int NBQ = NQT > 5 ? 2 : 3;
     constexpr int kTileU4 = (NKU * NP * MT + NQT * NP) * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int64_t bx;
@@ -1734,7 +1742,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
     // LDS: the chunk's packed parameters, then per wave the normalisers / posteriors of a tile
     constexpr int p_u4 = NKU * NTC * kBlockU4;
     u4* Ps = reinterpret_cast<u4*>(smem);
-    float* lsw = reinterpret_cast<float*>(Ps + p_u4) + wave * (2 * FW * 4);
+    float* lsw = reinterpret_cast<float*>(Ps + p_u4) + wave * (2 * FW * NS);
     {
         const u4* src = Pall + (size_t)by * nk * NTC * kBlockU4;
         for (int idx = tid; idx < p_u4; idx += NTHREADS) Ps[idx] = src[idx];
@@ -1750,12 +1758,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
     const int64_t tb = bx * frames_per_block;
     const int64_t te = tb + frames_per_block < nframes ? tb + frames_per_block : nframes;
     const u4* Pl = Ps + lane;
-    int sidx, st0c;
+    int sidx, st0c, smax;
     {
         const int s0 = (kbase + 4 * i) / G, st = s0 < S ? s0 : S - 1;
         const int st0 = kbase / G < S ? kbase / G : S - 1;
-        st0c = st0 < S - 4 ? st0 : S - 4;
-        sidx = st - st0c;
+        st0c = st0 < S - NS ? st0 : (S > NS ? S - NS : 0);
+        sidx = st - st0c;                                  // (< NS: the host checked the chunks)
+        smax = (S - st0c < NS ? S - st0c : NS) - 1;        // fewer than NS states in all: the last again
     }
     f32x4 sacc[NTC][NQT];
 #pragma unroll
@@ -1769,13 +1778,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
     for (int c = 0; c < NTC; ++c) cnt[c] = 0.f;
 
     const int lr = lane & 31, lh = lane >> 5;
-    f32x4 lsv = f32x4{0, 0, 0, 0};
+    float lsv[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) lsv[j] = 0.f;
     auto issue = [&](int64_t fbn) {
         const int rows_n = (int)(te - fbn < FW ? te - fbn : FW);
         const int64_t rown = fbn + (lr < rows_n ? lr : rows_n - 1);
         const float* src = ((lh && sr) ? sr : log_norm) + rown * S + st0c;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lsv[j] = src[j];
+        for (int j = 0; j < NS; ++j) lsv[j] = src[j < smax ? j : smax];
     };
     const int64_t fb0 = tb + (int64_t)wave * FW;
     if (fb0 < te) issue(fb0);
@@ -1783,18 +1794,21 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
     // when they were issued one batch ahead): a tile's first A fragments during the
     // statistics of the tile before, its first two B fragments when its logits start.
     u4 af[2][NP][MT];
-    u4 bq[3][NP];
+    u4 bq[NBQ][NP];
     bool a0_ready = false;
     for (int64_t fb = fb0; fb < te; fb += WAVES * FW) {
         const int rows = (int)(te - fb < FW ? te - fb : FW);
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
-        *reinterpret_cast<f32x4*>(lsw + (lh * FW + lr) * 4) = lsv;
+#pragma unroll
+        for (int j = 0; j < NS; j += 4)
+            *reinterpret_cast<f32x4*>(lsw + (lh * FW + lr) * NS + j) =
+                f32x4{lsv[j], lsv[j + 1], lsv[j + 2], lsv[j + 3]};
         bool skip = false;
         if (sr) {
             float any = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) any = __builtin_fmaxf(any, __builtin_fabsf(lsv[j]));
+            for (int j = 0; j < NS; ++j) any = __builtin_fmaxf(any, __builtin_fabsf(lsv[j]));
             skip = __builtin_amdgcn_ballot_w64(lh == 1 && lr < rows && any != 0.f) == 0;
         }
         if (fb + WAVES * FW < te) issue(fb + WAVES * FW);
@@ -1862,8 +1876,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
         }
 
         // ---- r sr = exp(l - log_norm) sr, split into the A fragments of the statistics ----
+        if constexpr (NBQ == 3) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) bq[1][q] = ti[(NKU * NP * MT + NP + q) * 64];
+            for (int q = 0; q < NP; ++q) bq[1][q] = ti[(NKU * NP * MT + NP + q) * 64];
+        }
         u4 ar[NTC][NP];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -1873,8 +1889,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
                 const bool ok = row < rows;
                 // (the recomputed logits lack the common constant c0; rows past the end:
                 // weight 0 and a normaliser that keeps the exponential at 0)
-                const float nl2 = (ok ? c0 : -1.0e30f) - lsw[row * 4 + sidx];
-                const float wg = (sr ? lsw[(FW + row) * 4 + sidx] : 1.f) * (ok ? 1.f : 0.f);
+                const float nl2 = (ok ? c0 : -1.0e30f) - lsw[row * NS + sidx];
+                const float wg = (sr ? lsw[(FW + row) * NS + sidx] : 1.f) * (ok ? 1.f : 0.f);
 #pragma unroll
                 for (int nt = 0; nt < NTC; ++nt)
                     acc[m][nt][r] = exp2_valu((acc[m][nt][r] + nl2) * 1.44269504088896340736f) * wg;
@@ -1898,11 +1914,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
         // ---- statistics: sacc[c][uu] += A'(c) x B'(uu), B' from the image two tiles ahead ----
 #pragma unroll
         for (int uu = 0; uu < NQT; ++uu) {
-            if (uu + 2 < NQT) {
+            if (uu + NBQ - 1 < NQT) {
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    bq[(uu + 2) % 3][q] = (BEER_AFI_ABL & 1) ? bq[uu % 3][q] :
-                                          ti[(NKU * NP * MT + (uu + 2) * NP + q) * 64];
+                    bq[(uu + NBQ - 1) % NBQ][q] = (BEER_AFI_ABL & 1) ? bq[uu % NBQ][q] :
+                                                  ti[(NKU * NP * MT + (uu + NBQ - 1) * NP + q) * 64];
             }
             if (uu == NQT - 3) {
                 // (no next tile: this one again, harmlessly)
@@ -1916,9 +1932,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
             for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
                 for (int c = 0; c < NTC; ++c)
-                    sacc[c][uu] = mfma_bf16(ar[c][kProdA[pr]], bq[uu % 3][kProdB[pr]], sacc[c][uu]);
+                    sacc[c][uu] = mfma_bf16(ar[c][kProdA[pr]], bq[uu % NBQ][kProdB[pr]], sacc[c][uu]);
             if (uu == NQT - 3) __builtin_amdgcn_sched_group_barrier(0x020, 9, 0);
-            else if (uu + 2 < NQT) __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+            else if (uu + NBQ - 1 < NQT) __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 6 * NTC, 0);
         }
     }
@@ -2002,13 +2018,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
 // image, a k-step ahead; the next tile's first k-step during the epilogue).  Same
 // products in the same order as llhx_kernel and accfi_kernel: bit-identical logits.
 // ---------------------------------------------------------------------------
-template <int NKU, int G>
+// NT: component tiles per chunk -- 16 (256 components: 48 KiB of LDS per k-step) up to three
+// k-steps, 8 with the four k-steps of D = 41 .. 48 (96 KiB; groups of 4 / 8 stay inside a lane).
+template <int NKU, int G, int NT = 16>
 __global__ __launch_bounds__(512, 2) void lnfi_kernel(
     int64_t nframes, int K, int S, int nk, const u4* __restrict__ img,
     const u4* __restrict__ Pall, float* __restrict__ log_norm, double* __restrict__ llh_sum,
     int64_t frames_per_block, const float* __restrict__ c0p) {
-    constexpr int NT = 16, MT = 2, FW = 32, WAVES = 8, NTHREADS = 64 * WAVES;
-    constexpr int kTileU4 = (NKU * NP * MT + kImgNQT * NP) * 64;
+    constexpr int MT = 2, FW = 32, WAVES = 8, NTHREADS = 64 * WAVES;
+    constexpr int kTileU4 = (NKU * NP * MT + img_nqt(NKU) * NP) * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int64_t bx;
     int by;
@@ -2260,8 +2278,13 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
     // Gaussian per state: 120 states at config 4) is one chunk of 8 / 4 component tiles, not
     // of 16 half of which would be padding
     const bool narrow = S > 1 && Greal == 1 && K <= 128 && !packed && !image;
-    const int NT = narrow ? (K <= 64 ? 4 : 8) : ntx_for(S, K);
-    const int nchunks = nchunksx_for(S, K), nk = nk16_of(cov, D);
+    // (a frame image of four k-steps, D = 41 .. 48: chunks of 8 component tiles, whose packed
+    // parameters -- 96 KiB -- fit the LDS of lnfi_kernel; groups of 4 / 8 stay inside a lane)
+    const bool lnfi8 = image && !narrow && S > 1 && !resps && !packed && cov != BEER_FULL &&
+                       (nslab_of(cov, D) + 7) / 8 == 4 && (G == 4 || G == 8) &&
+                       beer::option(BEER_OPT_LNFI);
+    const int NT = narrow ? (K <= 64 ? 4 : 8) : (lnfi8 ? 8 : ntx_for(S, K));
+    const int nchunks = lnfi8 ? (K + 127) / 128 : nchunksx_for(S, K), nk = nk16_of(cov, D);
     const int kpad = nchunks * NT * 16;
     // a frame fragment image: mixture sets, log-normalisers only, groups of >= 4 (refused
     // here, before anything is launched)
@@ -2278,7 +2301,8 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
     hipLaunchKernelGGL(const_max_kernel, dim3(1), dim3(256), 0, s, cov, D, Kreal, expT, logw, c0);
     // log-normalisers only, groups of 4 / 8 / 16: the image is dealt out lane-major and the
     // log-sum-exp of a state stays inside a lane (lognorm_epilogue_lane_major)
-    const bool lane_major = S > 1 && !resps && !packed && NT == 16 && (G == 4 || G == 8 || G == 16);
+    const bool lane_major = S > 1 && !resps && !packed &&
+                            ((NT == 16 && (G == 4 || G == 8 || G == 16)) || lnfi8);
     hipLaunchKernelGGL(packx_kernel, dim3(kpad), dim3(256),
                        (size_t)stats_dim(cov, D) * sizeof(float), s, cov, D, Kreal, NT, expT, logw,
                        reinterpret_cast<unsigned short*>(P), tab, Greal, G, c0, lane_major ? 1 : 0);
@@ -2353,7 +2377,7 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
             default: BEER_LLHX(16, 2, 2, true, false);
         }
     }
-    if (image && lane_major && (nslab_of(cov, D) + 7) / 8 <= 3 && beer::option(BEER_OPT_LNFI)) {
+    if (image && lane_major && ((nslab_of(cov, D) + 7) / 8 <= 3 || lnfi8) && beer::option(BEER_OPT_LNFI)) {
         // lane-major groups over a frame image: the chunk's parameters in LDS, a workgroup
         // walks a block of frames (lnfi_kernel)
         const int nku = (nslab_of(cov, D) + 7) / 8;
@@ -2365,22 +2389,24 @@ int estep_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float* X, 
             const int64_t cost = (wgs + 255) / 256 * (fpb + 128);
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_fpb = fpb; }
         }
-        const size_t lds = (size_t)nku * 16 * kBlockU4 * 16;
+        const size_t lds = (size_t)nku * NT * kBlockU4 * 16;
         const int64_t gz = (nframes + best_fpb - 1) / best_fpb;
         const dim3 grid(xcd_grid(gz, nchunks, nchunks));
-#define BEER_LNFI(NKU_, G_)                                                                      \
+#define BEER_LNFI(NKU_, G_, NT_)                                                                 \
     do {                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lnfi_kernel<NKU_, G_>),          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lnfi_kernel<NKU_, G_, NT_>),     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds); \
-        hipLaunchKernelGGL((lnfi_kernel<NKU_, G_>), grid, dim3(512), lds, s, nframes, K, S, nk,  \
-                           reinterpret_cast<const u4*>(image), reinterpret_cast<const u4*>(P),   \
+        hipLaunchKernelGGL((lnfi_kernel<NKU_, G_, NT_>), grid, dim3(512), lds, s, nframes, K, S, \
+                           nk, reinterpret_cast<const u4*>(image), reinterpret_cast<const u4*>(P), \
                            log_norm, llh_sum, best_fpb, c0);                                     \
     } while (0)
 #define BEER_LNFI_G(NKU_)                                                                        \
     do {                                                                                         \
-        if (G == 4) BEER_LNFI(NKU_, 4); else if (G == 8) BEER_LNFI(NKU_, 8); else BEER_LNFI(NKU_, 16); \
+        if (G == 4) BEER_LNFI(NKU_, 4, 16); else if (G == 8) BEER_LNFI(NKU_, 8, 16);             \
+        else BEER_LNFI(NKU_, 16, 16);                                                            \
     } while (0)
-        if (nku == 1) BEER_LNFI_G(1); else if (nku == 2) BEER_LNFI_G(2); else BEER_LNFI_G(3);
+        if (lnfi8) { if (G == 4) BEER_LNFI(4, 4, 8); else BEER_LNFI(4, 8, 8); }
+        else if (nku == 1) BEER_LNFI_G(1); else if (nku == 2) BEER_LNFI_G(2); else BEER_LNFI_G(3);
 #undef BEER_LNFI_G
 #undef BEER_LNFI
         BEER_LAUNCH_CHECK();
@@ -2545,13 +2571,17 @@ size_t accf_workspace_bytes(int cov, int D, int S, int G) {
 // 96 columns in at most 3 k-steps (D <= 40; any D: the rows are staged with their padding, a
 // dimension beyond D is a zero column of the tile)
 bool supported_frame_image(int cov, int D) {
-    return cov != BEER_FULL && D >= 1 && accf_nqt(cov, D) == 6 && (nslab_of(cov, D) + 7) / 8 <= 3;
+    // (D <= 48: at most kImgMaxNK k-steps, whose data slabs fill at most img_nqt() tiles)
+    if (cov == BEER_FULL || D < 1) return false;
+    const int nk_used = (nslab_of(cov, D) + 7) / 8;
+    return nk_used <= kImgMaxNK && 2 * d4_of(D) <= 4 * img_nqt(nk_used);
 }
 size_t frame_image_bytes(int cov, int64_t nframes, int D) {
     if (!supported_frame_image(cov, D) || nframes < 0) return 0;
     const int nk = nk16_of(cov, D), nk_used = (nslab_of(cov, D) + 7) / 8;
     const int64_t tiles = (nframes + 31) / 32;
-    return (size_t)tiles * frame_image_tile_u4(nk_used, kImgNQT) * 16 + up256((size_t)(nk + 1) * 8 * sizeof(int));
+    return (size_t)tiles * frame_image_tile_u4(nk_used, img_nqt(nk_used)) * 16 +
+           up256((size_t)(nk + 1) * 8 * sizeof(int));
 }
 __global__ void tabx_kernel(int cov, int D, int nk, int* __restrict__ tab) {
     const int Dp = 4 * d4_of(D);
@@ -2564,12 +2594,12 @@ int frame_image(int cov, int64_t nframes, int D, const float* X, void* image, hi
     const int nk = nk16_of(cov, D), nslab = nslab_of(cov, D), nk_used = (nslab + 7) / 8;
     const int64_t tiles = (nframes + 31) / 32;
     int* tab = reinterpret_cast<int*>(reinterpret_cast<char*>(image) +
-                                      (size_t)tiles * frame_image_tile_u4(nk_used, kImgNQT) * 16);
+                                      (size_t)tiles * frame_image_tile_u4(nk_used, img_nqt(nk_used)) * 16);
     hipLaunchKernelGGL(tabx_kernel, dim3(1), dim3(256), 0, s, cov, D, nk, tab);
     const size_t lds = (size_t)(nk + 1) * 8 * sizeof(int) +
                        (size_t)4 * (32 * ld16_of(D) + (D + 2) * kAfXS) * sizeof(float);
     hipLaunchKernelGGL(frame_image_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), lds, s,
-                       nframes, D, nk, nslab, kImgNQT, X, tab, reinterpret_cast<u4*>(image));
+                       nframes, D, nk, nslab, img_nqt(nk_used), X, tab, reinterpret_cast<u4*>(image));
     BEER_LAUNCH_CHECK();
     return BEER_OK;
 }
@@ -2604,15 +2634,20 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
     BEER_LAUNCH_CHECK();
     // The states of every 64-component chunk fit a block of 4 consecutive ones?
     // (groups are padded to a multiple of 4: a lane's 4 components share their state)
-    bool blk = S >= 4;
-    for (int c = 0; c < nchunks && blk; ++c) {
-        const int lo = c * 16 * NTC / G, hi = (c * 16 * NTC + 60) / G;
-        if ((hi < S ? hi : S - 1) - (lo < S ? lo : S - 1) > 3) blk = false;
-    }
+    auto reach = [&](int ns) {
+        for (int c = 0; c < nchunks; ++c) {
+            const int lo = c * 16 * NTC / G, hi = (c * 16 * NTC + 60) / G;
+            if ((hi < S ? hi : S - 1) - (lo < S ? lo : S - 1) > ns - 1) return false;
+        }
+        return true;
+    };
+    const bool blk = S >= 4 && reach(4);
+    // ... over a frame image: a block of 4, or of 16 (groups of 4 .. 12 Gaussians)
+    const int ns_img = blk ? 4 : (reach(16) ? 16 : 0);
     const int nk_used = (nslab + 7) / 8;
     // waves per workgroup: 8 (two per SIMD) with 64-component chunks, 4 with 128
-    const bool use_image = image && blk && NTC == 4 && NQT == 6 && supported_frame_image(cov, D);
-    const int waves = (NTC == 4 && NQT == 6) ? (use_image ? beer::option(BEER_OPT_ACCFI_WAVES) : 8) : 4;
+    const bool use_image = image && ns_img && NTC == 4 && supported_frame_image(cov, D);
+    const int waves = use_image ? beer::option(BEER_OPT_ACCFI_WAVES) : ((NTC == 4 && NQT == 6) ? 8 : 4);
     // frames per workgroup: <= kAfMaxFramesPerWave per wave, about one workgroup of
     // 8 waves (two of 4) per CU and round
     const int rounds = beer::option(BEER_OPT_ACCF_ROUNDS);
@@ -2637,22 +2672,26 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
     const dim3 grid(xcd_grid(gz, nchunks, nchunks));
     if (use_image) {
         // every fragment that depends on the frames only comes from the caller's image
-        const size_t lds_i = (size_t)nk_used * NTC * kBlockU4 * 16 + (size_t)waves * 256 * sizeof(float);
+        const size_t lds_i = (size_t)nk_used * NTC * kBlockU4 * 16 +
+                             (size_t)waves * 64 * ns_img * sizeof(float);
         const size_t lds_red = (size_t)waves * 16 * 64 * sizeof(float);
         const size_t lds_f = lds_i > lds_red ? lds_i : lds_red;
-#define BEER_ACCFI(NKU_, W_)                                                                     \
+#define BEER_ACCFI(NKU_, W_, NS_)                                                                \
     do {                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(accfi_kernel<NKU_, W_>),         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(accfi_kernel<NKU_, W_, NS_>),    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds); \
-        hipLaunchKernelGGL((accfi_kernel<NKU_, W_>), grid, dim3(64 * W_), lds_f, s, nframes, K,  \
-                           S, G, Greal, nk, nslab, reinterpret_cast<const u4*>(image),           \
+        hipLaunchKernelGGL((accfi_kernel<NKU_, W_, NS_>), grid, dim3(64 * W_), lds_f, s, nframes, \
+                           K, S, G, Greal, nk, nslab, reinterpret_cast<const u4*>(image),        \
                            reinterpret_cast<const u4*>(P), log_norm, sr, fpb, Sp, c0);           \
     } while (0)
-        if (waves == 8) {
-            if (nk_used == 1) BEER_ACCFI(1, 8); else if (nk_used == 2) BEER_ACCFI(2, 8); else BEER_ACCFI(3, 8);
-        } else {
-            if (nk_used == 1) BEER_ACCFI(1, 4); else if (nk_used == 2) BEER_ACCFI(2, 4); else BEER_ACCFI(3, 4);
-        }
+#define BEER_ACCFI_K(W_, NS_)                                                                    \
+    do {                                                                                         \
+        if (nk_used == 1) BEER_ACCFI(1, W_, NS_); else if (nk_used == 2) BEER_ACCFI(2, W_, NS_); \
+        else if (nk_used == 3) BEER_ACCFI(3, W_, NS_); else BEER_ACCFI(4, W_, NS_);              \
+    } while (0)
+        if (waves == 8) { if (ns_img == 4) BEER_ACCFI_K(8, 4); else BEER_ACCFI_K(8, 16); }
+        else { if (ns_img == 4) BEER_ACCFI_K(4, 4); else BEER_ACCFI_K(4, 16); }
+#undef BEER_ACCFI_K
 #undef BEER_ACCFI
         BEER_LAUNCH_CHECK();
         const int64_t total_i = (int64_t)Kreal * stats_dim(cov, D);

@@ -637,7 +637,8 @@ template <int NT, int MT, int G>
 __device__ __forceinline__ void lognorm_epilogue_lane_major(
     f32x4 (&acc)[MT][NT], int64_t fb, int64_t nframes, int kbase, int S, int i, int g, int lane,
     float* __restrict__ log_norm, double* __restrict__ llh_sum, float shift) {
-    static_assert(NT == 16 && (G == 4 || G == 8 || G == 16), "16 logits per lane and row, whole groups");
+    static_assert((NT == 16 || NT == 8) && (G == 4 || G == 8 || G == 16) && NT % G == 0,
+                  "NT logits per lane and row, whole groups");
     constexpr int NG = NT / G;
     constexpr float L2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
     const int s0 = (kbase + NT * i) / G;                 // the lane's first state

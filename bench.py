@@ -60,6 +60,7 @@ from benchlib.baselines import (cpu_baseline_config1, cpu_baseline_config5,     
                                 cpu_baseline_graph_compile, cpu_baseline_hmm,
                                 cpu_baseline_vae_prior, gmm_parity_check, host_cores)
 from benchlib.format import emit, summary                 # noqa: E402,F401
+from benchlib import recipe                               # noqa: E402
 
 
 # --------------------------------------------------------------------------------------------
@@ -724,41 +725,18 @@ def run_config5(args, device, hours=None, epochs=5, n_comp=4, cpu_sample=6):
     mean, var = X.mean(0), X.var(0)
     stage('dataset', t0)
     total, dim = len(X), X.shape[1]
-    # -- model (mkphones / mkphoneloopgraph / mkdecodegraph / mkphoneloop)
+    # -- model (mkphones / mkphoneloopgraph / mkdecodegraph / mkphoneloop with the recipe's own
+    #    configuration: benchlib/recipe.py)
     t0 = time.perf_counter()
-    units, pdf = {}, 0
-    for p in range(phones):
-        u = beer.graph.Graph()
-        for sid in range(5):
-            u.add_state(pdf_id=None if sid in (0, 4) else pdf + sid - 1)
-        u.start_state, u.end_state = 0, 4
-        for arc in TOPO:
-            u.add_arc(*arc)
-        units[p] = u
-        pdf += 3
-    graph = beer.graph.Graph()
-    graph.start_state, graph.end_state = graph.add_state(), graph.add_state()
-    pivot = graph.add_state()
-    u2s = {p: graph.add_state() for p in units}
-    graph.add_arc(graph.start_state, pivot)
-    graph.add_arc(pivot, graph.end_state)
-    for p in units:
-        graph.add_arc(pivot, u2s[p])
-        graph.add_arc(u2s[p], pivot)
-    graph.normalize()
-    for p, hmm in units.items():
-        graph.replace_state(u2s[p], hmm)
-    graph.normalize()
-    torch.manual_seed(5)
-    S = 3 * phones
-    ns = beer.NormalSet.create(mean.cpu(), var.cpu(), size=S * n_comp, prior_strength=1.,
-                               noise_std=.1, cov_type='diagonal')
-    emissions = beer.JointModelSet([beer.MixtureSet.create(S, ns, prior_strength=1.)])
-    ploop = beer.PhoneLoop.create(graph.compile(), {p: 3 * p for p in units},
-                                  {p: 3 * p + 2 for p in units}, emissions).float().to(device)
+    ploop, units = recipe.phone_loop(phones, mean.cpu(), var.cpu(),
+                                     conf=recipe.hmm_conf(n_normal_speech=n_comp), seed=5)
+    ploop = ploop.to(device)
     stage('model', t0)
-    # -- alignment graphs: a transcription of about one phone per ten frames
-    seqs = [[int(v) for v in rng.randint(0, phones, max(2, T // 10))] for T in lengths]
+    sets = ploop.modelset.original_modelset.modelsets
+    n_gauss = sum(len(m) * m.n_comp_per_mixture for m in sets)
+    # -- alignment graphs: sil, about one phone per ten frames, sil
+    seqs = [['sil'] + [int(v) for v in rng.randint(0, phones, max(2, T // 10 - 2))] + ['sil']
+            for T in lengths]
     t0 = time.perf_counter()
     gset = beer.graph.compile_alignments(seqs, units)
     graphs = list(gset)
@@ -798,15 +776,17 @@ def run_config5(args, device, hours=None, epochs=5, n_comp=4, cpu_sample=6):
         if n:
             kern[nm] = {'ms': ms, 'launches': n}
     out = {'workload': f'configs[4]: {total_s / 3600.:.2f} h of synthetic 16 kHz audio in {len(lens)} '
-                       f'utterances -> {dim}-dimensional MFCC+E+deltas ({total} frames) -> monophone '
-                       f'HMM {phones} phones x 3 states x {n_comp} diagonal Gaussians trained for '
+                       f'utterances -> {dim}-dimensional MFCC+E+deltas ({total} frames) -> the recipe\'s '
+                       f'monophone model (recipes/aud/conf/hmm.yml: 1 non-speech unit x 5 states x 10 + '
+                       f'{phones} speech units x 3 states x {n_comp} diagonal Gaussians = {n_gauss}) trained for '
                        f'{epochs} epochs with alignment graphs (~{np.mean([len(q) for q in seqs]):.0f} '
                        'phones per utterance) -> Viterbi alignment; in memory, audio resident on the '
                        'device',
            'unit': 'frames/s', 'value': total / stage_sum, 'wall_s': stage_sum,
            'wall_s_with_synthesis': wall, 'stages_s': walls, 'epoch_s': epoch_s, 'epochs': epochs, 'frames': total,
            'utterances': len(lens), 'audio_bytes': audio_bytes,
-           'training_frames_per_s': total * epochs / walls['training'],
+           'training_frames_per_s': total * epochs / walls['training'], 'gaussians': n_gauss,
+           'training_frame_gaussians_per_s': total * epochs * n_gauss / walls['training'],
            'features_frames_per_s': total / walls['features'],
            'viterbi_frames_per_s': total / walls['viterbi_align'],
            'elbo_per_frame_by_epoch': elbos, 'elbo_monotone': bool(all(b >= a - 1e-7 * abs(a) for a, b in zip(elbos, elbos[1:]))),

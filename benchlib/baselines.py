@@ -266,7 +266,6 @@ def cpu_baseline_config5(signals, seqs, units, ploop, mean, var, epochs, n_comp,
     alignment graph's pdf ids, beer_oracle.best_path), projected to the corpus: stage time x
     (utterances / m) (x epochs for training)."""
     from oracle import beer_oracle as orc, features_oracle as fo, graph_oracle as go, torch_port as tp
-    S = 3 * N_PHONES
     nutt = len(signals)
     pick = list(range(0, nutt, max(1, nutt // m)))[:m]
     t = {}
@@ -278,12 +277,16 @@ def cpu_baseline_config5(signals, seqs, units, ploop, mean, var, epochs, n_comp,
     cgs = [go.compile_graph(go.alignment_graph(seqs[u], units, beer.graph.Graph)) for u in pick]
     t['alignment_graphs'] = time.perf_counter() - t0
     D = feats[0].shape[1]
-    KK = S * n_comp
     gen = torch.Generator().manual_seed(5)
-    prior = (mean.cpu().float().repeat(KK, 1), torch.ones(KK, 1), torch.ones(KK, 1),
-             var.cpu().float().repeat(KK, 1))
-    post = (prior[0] + .1 * torch.randn(KK, D, generator=gen) * var.cpu().float().sqrt(),) + prior[1:]
-    w = torch.ones(S, n_comp)
+    # the model's own groups (the recipe's JointModelSet: one MixtureSet per entry of hmm.yml)
+    groups = []
+    for ms in ploop.modelset.original_modelset.modelsets:
+        KK, S_g, G_g = len(ms) * ms.n_comp_per_mixture, len(ms), ms.n_comp_per_mixture
+        prior = (mean.cpu().float().repeat(KK, 1), torch.ones(KK, 1), torch.ones(KK, 1),
+                 var.cpu().float().repeat(KK, 1))
+        post = (prior[0] + .1 * torch.randn(KK, D, generator=gen) * var.cpu().float().sqrt(),) + prior[1:]
+        w = torch.ones(S_g, G_g)
+        groups.append((post, prior, w, w))
     nt = torch.get_num_threads()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     t0 = time.perf_counter()
@@ -291,8 +294,8 @@ def cpu_baseline_config5(signals, seqs, units, ploop, mean, var, epochs, n_comp,
         Xh = torch.from_numpy(f).float()
         with np.errstate(divide='ignore'):
             init, fin, trans = [torch.from_numpy(np.log(np.asarray(a, dtype=np.float32))) for a in cg[:3]]
-        tp.hmm_elbo(Xh, post, prior, w, w, init, fin, trans, total, trans_posteriors=False,
-                    order=list(cg[3]))
+        tp.hmm_elbo_groups(Xh, groups, init, fin, trans, total, trans_posteriors=False,
+                           order=list(cg[3]))
     t['training_one_epoch'] = time.perf_counter() - t0
     t0 = time.perf_counter()
     for f, cg in zip(feats, cgs):

@@ -277,18 +277,39 @@ def hmm_elbo(X, post, prior, w_post, w_prior, init_lp, final_lp, trans_lp, datas
     accumulate --alis`): the graph's states read the per-pdf log-likelihoods through it
     (modelset.py:140-146) and their posteriors are added back column by column in a Python
     loop (modelset.py:148-154), as the reference does.'''
+    value, accs, xi = hmm_elbo_groups(X, [(post, prior, w_post, w_prior)], init_lp, final_lp,
+                                      trans_lp, datasize, trans_posteriors, order)
+    return value, accs[0][0], accs[0][1], xi
+
+
+def hmm_elbo_groups(X, groups, init_lp, final_lp, trans_lp, datasize, trans_posteriors=True,
+                    order=None):
+    '''`hmm_elbo` for emissions that are a JointModelSet of several MixtureSets (the recipes'
+    models: one group per entry of conf/hmm.yml, mkphones.py:100-113): `groups` =
+    [(post, prior, w_post [S_g, G_g], w_prior)], pdf ids running through the groups in order
+    (modelset.py:71-85: per-group log-likelihoods concatenated, posteriors split back).
+    Returns (value, [(Gaussian stats, weight stats) per group], summed transition posteriors).'''
     T, D = X.shape
-    S, G = w_post.shape
     one = torch.ones(T, 1, dtype=X.dtype)
     stats = torch.cat([X, -.5 * X ** 2, -.5 * one, .5 * one], dim=-1)
-    exp_T = ng_exp_stats(*post)
-    pc = (stats @ exp_T.t() - .5 * D * LOG2PI).reshape(T, S, G)
-    eye = torch.eye(G, dtype=X.dtype)
-    eye[:, -1] = eye.sum(-1)
-    lw = (eye @ dirset_exp_stats(w_post).t()).t()
-    w = pc + lw[None]
-    log_norm = torch.logsumexp(w, dim=-1)
-    comp = torch.exp(w - log_norm[:, :, None])
+    cols, comps, kl = [], [], 0.
+    for post, prior, w_post, w_prior in groups:
+        S, G = w_post.shape
+        exp_T = ng_exp_stats(*post)
+        pc = (stats @ exp_T.t() - .5 * D * LOG2PI).reshape(T, S, G)
+        eye = torch.eye(G, dtype=X.dtype)
+        eye[:, -1] = eye.sum(-1)
+        lw = (eye @ dirset_exp_stats(w_post).t()).t()
+        w = pc + lw[None]
+        ln = torch.logsumexp(w, dim=-1)
+        cols.append(ln)
+        comps.append(torch.exp(w - ln[:, :, None]))
+        kl = kl + (ng_log_norm(*prior) - ng_log_norm(*post)
+                   - torch.sum(exp_T * (ng_natural(*prior) - ng_natural(*post)), dim=-1)).sum()
+        kl = kl + (dirset_log_norm(w_prior) - dirset_log_norm(w_post)
+                   - torch.sum(dirset_exp_stats(w_post) * (dirset_natural(w_prior)
+                                                           - dirset_natural(w_post)), dim=-1)).sum()
+    log_norm = cols[0] if len(cols) == 1 else torch.cat(cols, dim=-1)
     if order is None:
         gamma, xi = hmm_forward_backward(log_norm, init_lp, final_lp, trans_lp)
         exp_llh = (log_norm * gamma).sum(-1)
@@ -300,18 +321,17 @@ def hmm_elbo(X, post, prior, w_post, w_prior, init_lp, final_lp, trans_lp, datas
         gamma = torch.zeros_like(log_norm)
         for i, pdf_id in enumerate(order):
             gamma[:, pdf_id] += g_u[:, i]
-    kl = (ng_log_norm(*prior) - ng_log_norm(*post)
-          - torch.sum(exp_T * (ng_natural(*prior) - ng_natural(*post)), dim=-1)).sum()
-    kl = kl + (dirset_log_norm(w_prior) - dirset_log_norm(w_post)
-               - torch.sum(dirset_exp_stats(w_post) * (dirset_natural(w_prior)
-                                                       - dirset_natural(w_post)), dim=-1)).sum()
     value = (datasize / float(T)) * exp_llh.sum() - kl
-    joint = comp * gamma[:, :, None]
-    wstats = joint.reshape(-1, G).clone()
-    wstats[:, -1] = wstats.sum(-1)
-    wstats = wstats.reshape(T, S, G).sum(0)
-    acc = joint.reshape(T, S * G).t() @ stats
-    return value, acc, wstats, (xi.sum(0) if trans_posteriors else None)
+    accs, first = [], 0
+    for (post, prior, w_post, w_prior), comp in zip(groups, comps):
+        S, G = w_post.shape
+        joint = comp * gamma[:, first:first + S, None]
+        first += S
+        wstats = joint.reshape(-1, G).clone()
+        wstats[:, -1] = wstats.sum(-1)
+        wstats = wstats.reshape(T, S, G).sum(0)
+        accs.append((joint.reshape(T, S * G).t() @ stats, wstats))
+    return value, accs, (xi.sum(0) if trans_posteriors else None)
 
 
 # ---------------------------------------------------------------------------

@@ -1756,7 +1756,15 @@ def test_elbo_round_trip_through_the_flat_device_buffer():
                                          ('isotropic', 20011, 12, 6, 32), ('diagonal', 17000, 8, 40, 8),
                                          # dimensions that are not a multiple of four (39 = 13 MFCCs x 3)
                                          ('diagonal', 30011, 39, 24, 16), ('diagonal', 20000, 13, 12, 4),
-                                         ('isotropic', 17001, 26, 5, 16), ('diagonal', 16500, 3, 7, 8)])
+                                         ('isotropic', 17001, 26, 5, 16), ('diagonal', 16500, 3, 7, 8),
+                                         # the recipes' shapes (recipes/aud/conf/hmm.yml: 4 and 10
+                                         # Gaussians per state; 39 / 42 dimensions): groups of 4 .. 12
+                                         # reach into up to 16 states per chunk, D = 41 .. 48 is the
+                                         # four-k-step image
+                                         ('diagonal', 17000, 39, 30, 4), ('diagonal', 20000, 42, 24, 16),
+                                         ('diagonal', 17000, 42, 40, 4), ('diagonal', 16500, 44, 5, 10),
+                                         ('isotropic', 17001, 48, 9, 8), ('diagonal', 16500, 41, 12, 12),
+                                         ('diagonal', 16600, 13, 5, 4)])
 def test_fused_accumulation_with_frame_image_matches_the_plain_kernel(monkeypatch, cov, T, D, S, G):
     '''beer_frame_image + beer_mixtureset_accumulate_fused(frame_image=...) -- the frames'
     fragments built once and loaded -- against the same call that rebuilds them per

@@ -442,6 +442,44 @@ def test_torch_port_hmm_matches_oracle():
     assert_close(xi.numpy(), ref['trans_resps'].sum(0), 1e-12, 'transition posteriors')
 
 
+def test_torch_port_hmm_with_two_groups_matches_oracle():
+    """bench.py's config-5 cpu_baseline (oracle/torch_port.py: hmm_elbo_groups -- emissions that
+    are a JointModelSet of two MixtureSets, as the recipes build them: mkphones.py:100-113) against
+    the numpy oracle's hmm_elbo_step with the same two groups, through an alignment-style graph
+    whose pdf ids reach into both groups and repeat."""
+    import torch
+    from oracle import torch_port as tp
+    rng = np.random.RandomState(1)
+    D, T = 5, 50
+    shapes = [(2, 5), (6, 3)]                     # (states, Gaussians per state) of the two groups
+    groups, tgroups = [], []
+    t = lambda a: torch.from_numpy(np.asarray(a))        # noqa: E731
+    for S, G in shapes:
+        K = S * G
+        post = (rng.randn(K, D), 1 + rng.rand(K, 1), 2 + rng.rand(K, 1), 1 + rng.rand(K, D))
+        prior = (rng.randn(K, D), np.ones((K, 1)), np.ones((K, 1)), np.ones((K, D)))
+        wp, w0 = 1 + rng.rand(S, G), np.ones((S, G))
+        groups.append(dict(cov_type='diagonal', S=S, G=G, post=post, prior=prior, w_post=wp, w_prior=w0))
+        tgroups.append((tuple(map(t, post)), tuple(map(t, prior)), t(wp), t(w0)))
+    order = np.asarray([0, 1, 5, 6, 7, 2, 3, 4, 5, 6, 7, 0, 1])
+    Sa = len(order)
+    ta = np.full((Sa, Sa), -np.inf)
+    for s_ in range(Sa):
+        ta[s_, s_] = np.log(.75)
+        if s_ + 1 < Sa:
+            ta[s_, s_ + 1] = np.log(.25)
+    ia = np.where(np.arange(Sa) == 0, 0., -np.inf)
+    fa = np.where(np.arange(Sa) == Sa - 1, np.log(.25), -np.inf)
+    X = rng.randn(T, D)
+    ref = orc.hmm_elbo_step(X, groups, dict(init=ia, final=fa, trans=ta, order=order), datasize=777)
+    value, accs, _ = tp.hmm_elbo_groups(t(X), tgroups, t(ia), t(fa), t(ta), 777,
+                                        trans_posteriors=False, order=order.tolist())
+    assert_close(float(value), ref['value'], 1e-12, 'value')
+    for i, (acc, wstats) in enumerate(accs):
+        assert_close(acc.numpy(), ref['acc'][i][0], 1e-12, f'Gaussian statistics, group {i}')
+        assert_close(wstats.numpy(), ref['acc'][i][1], 1e-12, f'weight statistics, group {i}')
+
+
 @pytest.mark.parametrize('cov', ['diagonal', 'full'])
 def test_torch_port_vae_prior_matches_oracle(cov):
     """bench.py's config-4 cpu_baseline (oracle/torch_port.py: vae_hmm_prior_path -- the
