@@ -749,6 +749,7 @@ def run_config5(args, device, hours=None, epochs=5, n_comp=4, cpu_sample=6):
              'beer_normal_accumulate', 'beer_hmm_viterbi', 'beer_hmm_gather')
     elbos = []
     statics = beer.ShardStatics()      # offsets, weights and batch descriptors of the shard: the caller's
+    images = beer.FrameImages(X)       # ... and the frames' fragment images (built in the first epoch)
     with KernelTimer(names) as kt:
         t0 = time.perf_counter()
         epoch_s = []
@@ -756,7 +757,7 @@ def run_config5(args, device, hours=None, epochs=5, n_comp=4, cpu_sample=6):
             te = time.perf_counter()
             optim.init_step()
             elbo = beer.accumulate_elbo(ploop, (X, lengths), datasize=total, inference_graphs=graphs,
-                                        statics=statics)
+                                        statics=statics, frame_images=images)
             elbo.backward()
             optim.step()
             elbos.append(elbo.value)

@@ -27,7 +27,9 @@ KERNELS = {'llhx_kernel': 'llhx_kernel', 'lnfi_kernel': 'lnfi_kernel', 'accx_ker
 # gfx950 (MI355X_MICROARCH.md, HBM section); bench.py doubles the read figure for these
 WIDE_LOADS = {'llhx_kernel': True, 'lnfi_kernel': True, 'accx_kernel': True, 'accf_kernel': True,
               'fb_wave_kernel': False, 'llh_kernel': True, 'acc_kernel': True, 'sgrad_kernel': False,
-              'accd_kernel': False}
+              # (4 B per lane, but 64 consecutive lanes: 128-byte requests all the same -- calibrated on
+              #  its operands, round 5: 0.368 GB counted for the 0.736 GB of weights + samples it reads)
+              'accd_kernel': True}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -44,6 +46,16 @@ def main():
     if dirs and dirs[0].startswith('--skip='):
         a, b = dirs[0][len('--skip='):].split('/')
         skip, dirs = (int(a), int(b)), dirs[1:]
+    # --min-read=kernel:bytes,...: the bytes a launch of a kernel cannot avoid reading (its operands,
+    # once).  A counter read below that is the halved tally of 128-byte requests (the guide's
+    # calibration rule: "calibrate on a known byte count in your own access pattern"): the entry is
+    # flagged `read_below_operands` and its `wide_loads` set, whatever the table above says.
+    min_read = {}
+    if dirs and dirs[0].startswith('--min-read='):
+        for item in dirs[0][len('--min-read='):].split(','):
+            k_, v_ = item.split(':')
+            min_read[k_] = float(v_)
+        dirs = dirs[1:]
     out = collections.defaultdict(dict)
     for i, d in enumerate(dirs, start=1):
         # (gpurun merges a new run's files into the local directory: take the newest)
@@ -82,6 +94,13 @@ def main():
         if 'WRITE_SIZE' in k:
             k['hbm_write_bytes'] = k['WRITE_SIZE'] * 1024
         k['wide_loads'] = WIDE_LOADS.get(key, False)
+        if key in min_read and 'hbm_read_bytes_raw' in k:
+            k['operand_read_bytes'] = min_read[key]
+            if k['hbm_read_bytes_raw'] < .75 * min_read[key]:
+                k['read_below_operands'] = True
+                k['wide_loads'] = True
+                print(f'{tag}{key}: FETCH_SIZE {k["hbm_read_bytes_raw"] / 1e9:.3f} GB is below the '
+                      f'{min_read[key] / 1e9:.3f} GB of operands: counted at half, doubled from here on')
         k['command'] = command
     path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc.json')
     old = json.load(open(path))['kernels'] if os.path.exists(path) else {}
