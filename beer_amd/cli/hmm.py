@@ -53,85 +53,125 @@ def _cpu_elbo(elbo):
     return beer.EvidenceLowerBoundInstance(value, acc, refs, mbsize, elbo._datasize)
 
 
-def parse_topology(topology):
-    state_ids, arcs = set(), set()
-    for arc in topology:
-        start, end, weight = arc['start_id'], arc['end_id'], arc['trans_prob']
-        state_ids.update((start, end))
-        arcs.add((start, end, weight))
-    return sorted(state_ids), arcs
+class UnitTopology:
+    """A unit's HMM topology as conf/hmm.yml writes it (a list of {start_id, end_id, trans_prob})
+    held as arrays: the lowest and the highest state id are the non-emitting entry and exit, the
+    ids between them emit, in order (mkphones.py:12-43).  `graph(first_pdf)` instantiates it."""
+
+    def __init__(self, arcs_conf):
+        arcs = sorted({(int(a['start_id']), int(a['end_id']), float(a['trans_prob'])) for a in arcs_conf})
+        self.src, self.dst = (np.asarray([a[i] for a in arcs], dtype=np.int64) for i in (0, 1))
+        self.weight = np.asarray([a[2] for a in arcs], dtype=np.float64)
+        ids = np.unique(np.concatenate([self.src, self.dst]))
+        if not np.array_equal(ids, np.arange(len(ids))):
+            raise ValueError(f'state ids of a topology must be 0 .. n-1, got {ids.tolist()}')
+        self.n_states, self.n_emitting = len(ids), len(ids) - 2
+
+    def graph(self, first_pdf):
+        g = beer.graph.Graph()
+        last = self.n_states - 1
+        for sid in range(self.n_states):
+            g.add_state(pdf_id=None if sid in (0, last) else first_pdf + sid - 1)
+        g.start_state, g.end_state = 0, last
+        for s, e, w in zip(self.src.tolist(), self.dst.tolist(), self.weight.tolist()):
+            g.add_arc(s, e, w)
+        return g
 
 
-def create_unit_graph(topology, start_pdf_id):
-    'Unit HMM whose first / last states are non-emitting (mkphones.py:27-43).'
-    state_ids, arcs = parse_topology(topology)
+def build_units(groups_conf, grouped_names, mean, var):
+    """`beer hmm mkphones` (mkphones.py:95-113): ({unit name: Graph}, JointModelSet of one
+    MixtureSet per group).  `groups_conf`: {group name: its entry of conf/hmm.yml};
+    `grouped_names`: {group name: [unit names]}, pdf ids running through the groups in order."""
+    units, sets, next_pdf = {}, [], 0
+    for group, names in grouped_names.items():
+        conf = groups_conf[group]
+        topo = UnitTopology(conf['topology'])
+        for name in names:
+            units[name] = topo.graph(next_pdf)
+            next_pdf += topo.n_emitting
+        n_states = topo.n_emitting * len(names)
+        normals = beer.NormalSet.create(
+            mean=mean, cov=var, size=n_states * conf['n_normal_per_state'],
+            prior_strength=conf['prior_strength'], noise_std=conf['noise_std'],
+            cov_type=conf['cov_type'], shared_cov=conf['shared_cov'])
+        sets.append(beer.MixtureSet.create(n_states, normals, prior_strength=conf['prior_strength']))
+    return units, beer.JointModelSet(sets)
+
+
+def loop_graph(unit_names, edge_units=None):
+    """`beer hmm mkphoneloopgraph` (mkphoneloopgraph.py:28-75): start, end and a pivot state, every
+    unit reachable from and returning to the pivot; `edge_units` (the --start-end-group) are the
+    units an utterance starts and ends with, default: the pivot itself.  `graph.symbols` maps a
+    state to its unit (the reference's names for the three special states)."""
     graph = beer.graph.Graph()
-    count = 0
-    for state_id in range(len(state_ids)):
-        if state_id in (state_ids[0], state_ids[-1]):
-            graph.add_state(pdf_id=None)
-        else:
-            graph.add_state(pdf_id=start_pdf_id + count)
-            count += 1
-    graph.start_state, graph.end_state = state_ids[0], state_ids[-1]
-    for arc in arcs:
+    graph.start_state, graph.end_state = graph.add_state(), graph.add_state()
+    pivot = graph.add_state()
+    state_of = {name: graph.add_state() for name in unit_names}
+    edges = [state_of[u] for u in edge_units] if edge_units else [pivot]
+    for arc in [(graph.start_state, e) for e in edges] + [(e, graph.end_state) for e in edges]:
         graph.add_arc(*arc)
-    return graph, start_pdf_id + count
-
-
-def count_emitting_state(graph):
-    return sum(1 for s in graph.states() if graph.state_from_id(s).pdf_id is not None)
-
-
-def create_pdfs(mean, var, tot_emitting_states, conf):
-    modelset = beer.NormalSet.create(
-        mean=mean, cov=var, size=tot_emitting_states * conf['n_normal_per_state'],
-        prior_strength=conf['prior_strength'], noise_std=conf['noise_std'],
-        cov_type=conf['cov_type'], shared_cov=conf['shared_cov'])
-    return beer.MixtureSet.create(tot_emitting_states, modelset,
-                                  prior_strength=conf['prior_strength'])
-
-
-def create_graph_from_seq(seq, phone_graphs):
-    'Linear alignment graph of a phone sequence (mkaligraph.py:18-39).'
-    graph = beer.graph.Graph()
-    graph.start_state = graph.add_state()
-    last, phone_states = graph.start_state, []
-    for _ in seq:
-        state = graph.add_state()
-        phone_states.append(state)
-        graph.add_arc(last, state)
-        last = state
-    graph.end_state = graph.add_state()
-    graph.add_arc(last, graph.end_state)
-    for state, phone in zip(phone_states, seq):
-        graph.replace_state(state, phone_graphs[phone])
+    for state in state_of.values():
+        graph.add_arc(pivot, state)
+        graph.add_arc(state, pivot)
+    graph.symbols = {graph.start_state: '\\<s\\>', graph.end_state: '\\</s\\>', pivot: '#1',
+                     **{state: name for name, state in state_of.items()}}
     graph.normalize()
-    return graph.compile()
+    return graph
 
 
-def _single_pdf(graph, walk):
+def _only_pdf(graph, walk):
     states = [s for s, _ in walk]
     if len(states) != 1:
         raise ValueError(f'expected only one emitting state, got: {len(states)}')
     return graph.state_from_id(states[0]).pdf_id
 
 
-def state2phone(path, start_pdf, per_frame):
-    'Collapse a pdf-id path into phone symbols (decode.py:27-40).'
-    starts = list(start_pdf.values())
-    state2sym = {v: k for k, v in start_pdf.items()}
-    prev = path[0]
-    last = state2sym[prev]
-    phones = [last]
-    for state in path[1:]:
-        if state != prev and state in starts:
-            last = state2sym[state]
-            phones.append(last)
-        elif per_frame:
-            phones.append(last)
-        prev = state
-    return phones
+def decode_graph(loop, units):
+    """`beer hmm mkdecodegraph` (mkdecodegraph.py:19-55): every unit state of the loop replaced by
+    the unit's HMM; (graph, {unit: its first pdf}, {unit: its last pdf})."""
+    state_of = {unit: state for state, unit in loop.symbols.items()}
+    for unit, hmm in units.items():
+        loop.replace_state(state_of[unit], hmm)
+    loop.normalize()
+    first = {u: _only_pdf(h, h.find_next_pdf_ids(h.start_state)) for u, h in units.items()}
+    last = {u: _only_pdf(h, h.find_previous_pdf_ids(h.end_state)) for u, h in units.items()}
+    return loop, first, last
+
+
+PRIORS = ('dirichlet', 'dirichlet_process', 'gamma_dirichlet_process')
+
+
+def phone_loop(graph, start_pdf, end_pdf, emissions, weights_prior='gamma_dirichlet_process',
+               concentration=None):
+    '`beer hmm mkphoneloop` (mkphoneloop.py:30-66).'
+    size = len(start_pdf)
+    conc = concentration if concentration else size / 2
+    if weights_prior == 'dirichlet':
+        cat = beer.Categorical.create(torch.ones(size) / size, prior_strength=conc)
+    elif weights_prior == 'dirichlet_process':
+        cat = beer.SBCategorical.create(truncation=size, prior_strength=conc)
+    elif weights_prior == 'gamma_dirichlet_process':
+        cat = beer.SBCategoricalHyperPrior.create(truncation=size, prior_strength=conc,
+                                                  hyper_prior_strength=1.)
+    else:
+        raise ValueError(f'unknown prior over the weights: {weights_prior!r}')
+    return beer.PhoneLoop.create(graph.compile(), start_pdf, end_pdf, emissions, cat)
+
+
+def phones_of_path(path, start_pdf, per_frame=False):
+    """A pdf-id path as unit symbols (decode.py:27-40): a new unit starts wherever the path ENTERS
+    the first pdf of a unit from another pdf; `per_frame` repeats the running unit for every frame."""
+    path = np.asarray(path, dtype=np.int64).reshape(-1)
+    names = list(start_pdf)
+    firsts = np.asarray([start_pdf[n] for n in names], dtype=np.int64)
+    if path[0] not in firsts:
+        raise KeyError(int(path[0]))                  # (as the reference's dictionary look-up)
+    enters = np.concatenate([[True], (path[1:] != path[:-1]) & np.isin(path[1:], firsts)])
+    which = {int(pdf): n for n, pdf in zip(names, firsts)}
+    heads = [which[int(p)] for p in path[enters]]
+    if not per_frame:
+        return heads
+    return [heads[i] for i in np.cumsum(enters) - 1]
 
 
 # ---------------------------------------------------------------------------
@@ -164,15 +204,7 @@ class mkphones:
             mean, var = dataset.mean, dataset.var
         else:
             mean, var = torch.zeros(args.dimension).float(), torch.ones(args.dimension).float()
-        start_pdf_id, pdfs, units = 0, [], {}
-        for group, names in grouped.items():
-            tot = 0
-            for name in names:
-                graph, start_pdf_id = create_unit_graph(groups[group]['topology'], start_pdf_id)
-                units[name] = graph
-                tot += count_emitting_state(graph)
-            pdfs.append(create_pdfs(mean, var, tot, groups[group]))
-        emissions = beer.JointModelSet(pdfs)
+        units, emissions = build_units(groups, grouped, mean, var)
         _dump((units, emissions), args.out)
         logger.info(f'created {len(units)} HMMs for a total of {len(emissions)} emitting states')
         logger.info(f'expected features dimension: {len(mean)}')
@@ -191,25 +223,9 @@ class mkphoneloopgraph:
     def main(args, logger):
         with open(args.units) as f:
             units = [tuple(line.strip().split()) for line in f if line.strip()]
-        graph = beer.graph.Graph()
-        graph.start_state, graph.end_state = graph.add_state(), graph.add_state()
-        pivot = graph.add_state()
-        unit2state = {'\\<s\\>': graph.start_state, '\\</s\\>': graph.end_state, '#1': pivot}
-        unit2state.update({name: graph.add_state() for name, _ in units})
-        state2unit = {s: u for u, s in unit2state.items()}
-        if args.start_end_group:
-            edge_units = [name for name, group in units if group == args.start_end_group]
-        else:
-            edge_units = [state2unit[pivot]]
-        for unit in edge_units:
-            graph.add_arc(graph.start_state, unit2state[unit])
-        for unit in edge_units:
-            graph.add_arc(unit2state[unit], graph.end_state)
-        for unit, _ in units:
-            graph.add_arc(pivot, unit2state[unit])
-            graph.add_arc(unit2state[unit], pivot)
-        graph.symbols = state2unit
-        graph.normalize()
+        edge_units = [name for name, group in units if group == args.start_end_group] \
+            if args.start_end_group else None
+        graph = loop_graph([name for name, _ in units], edge_units)
         _dump(graph, args.out)
         logger.info(f'created phone-loop graph. # states: {len(list(graph.states()))} '
                     f'# arcs: {len(list(graph.arcs()))} start/end group: {args.start_end_group}')
@@ -228,14 +244,7 @@ class mkdecodegraph:
     def main(args, logger):
         graph = _load(args.phoneloop)
         units, _ = _load(args.hmms)
-        phone2state = {phone: state for state, phone in graph.symbols.items()}
-        for phone, hmm in units.items():
-            graph.replace_state(phone2state[phone], hmm)
-        graph.normalize()
-        start_pdf, end_pdf = {}, {}
-        for phone, hmm in units.items():
-            start_pdf[phone] = _single_pdf(hmm, hmm.find_next_pdf_ids(hmm.start_state))
-            end_pdf[phone] = _single_pdf(hmm, hmm.find_previous_pdf_ids(hmm.end_state))
+        graph, start_pdf, end_pdf = decode_graph(graph, units)
         _dump((graph, start_pdf, end_pdf), args.out)
         logger.info(f'created decoding graph. # states: {len(list(graph.states()))} '
                     f'# arcs: {len(list(graph.arcs()))} ')
@@ -243,7 +252,7 @@ class mkdecodegraph:
 
 class mkphoneloop:
     'create a phone-loop model'
-    PRIORS = ('dirichlet', 'dirichlet_process', 'gamma_dirichlet_process')
+    PRIORS = PRIORS
 
     @staticmethod
     def setup(parser):
@@ -260,15 +269,7 @@ class mkphoneloop:
         graph, start_pdf, end_pdf = _load(args.decode_graph)
         _, emissions = _load(args.hmms)
         size = len(start_pdf)
-        conc = args.concentration if args.concentration else size / 2
-        if args.weights_prior == 'dirichlet':
-            cat = beer.Categorical.create(torch.ones(size) / size, prior_strength=conc)
-        elif args.weights_prior == 'dirichlet_process':
-            cat = beer.SBCategorical.create(truncation=size, prior_strength=conc)
-        else:
-            cat = beer.SBCategoricalHyperPrior.create(truncation=size, prior_strength=conc,
-                                                      hyper_prior_strength=1.)
-        ploop = beer.PhoneLoop.create(graph.compile(), start_pdf, end_pdf, emissions, cat)
+        ploop = phone_loop(graph, start_pdf, end_pdf, emissions, args.weights_prior, args.concentration)
         _dump(ploop, args.out)
         logger.info(f'successfully created a phone-loop model with {size} phones')
 
@@ -482,7 +483,7 @@ class decode:
         paths = beer.decode_batch(model, feats, inference_graphs=use, scale=args.acoustic_scale) \
             if kept else []
         for uttid, path in zip(kept, paths):
-            phones = state2phone([int(p) for p in path.cpu()], model.start_pdf, args.per_frame)
+            phones = phones_of_path(path.cpu().numpy(), model.start_pdf, args.per_frame)
             print(uttid, ' '.join(phones))
         logger.info(f'successfully decoded {len(kept)} utterances.')
 

@@ -294,6 +294,24 @@ def run_gmm(args, rank, world, device, backend):
     out['roofline'].update(profiled(pmc_key, out['roofline']))
     if exact:
         out['f32_exact'] = exact
+    if world == 1:
+        # the same iterations recorded ONCE as a HIP graph and replayed (beer.CapturedIteration:
+        # E-step, statistics, KL and the update as one submission): what the host-side launches of
+        # the loop above cost.  Not the headline: a replay has no per-call HIP events.
+        m2 = make_gmm(device)
+        it = beer.CapturedIteration(m2, beer.VBConjugateOptimizer(m2.mean_field_factorization(), 1.),
+                                    (X, lengths), datasize=datasize)
+        for _ in range(max(4, args.warmup)):
+            it()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            it()
+        torch.cuda.synchronize()
+        c_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+        out['captured'] = {'ms_per_step': c_ms, 'value': datasize / (c_ms * 1e-3), 'mode': it.mode,
+                           'note': 'beer.CapturedIteration: the whole iteration as one HIP graph'}
+        del m2, it
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline_gmm()
     return out

@@ -68,6 +68,9 @@ def summary(out):
     roof = out.get('roofline') or {}
     if roof.get('frac') is not None:
         s['config2_roofline_frac'] = round(roof['frac'], 4)
+    if 'captured' in out:
+        s['config2_captured_frames_per_s'] = round(out['captured']['value'])
+        s['config2_captured_ms_per_step'] = round(out['captured']['ms_per_step'], 3)
     for key in ('config3', 'config3_full', 'config3_shard'):
         if key in out:
             s[key + '_frames_per_s'] = round(out[key]['value'])

@@ -8,7 +8,8 @@ the non-speech group (monophone.sh:75) under a Dirichlet prior over the units.  
 recipes/*/conf/mfcc.yml, 13 x 3 = 39 dimensions (42 with energy as bench config 5 extracts them).
 
 `phone_loop()` walks the steps of monophone.sh:64-82 (`beer hmm mkphones / mkphoneloopgraph /
-mkdecodegraph / mkphoneloop`) with the command line's own building blocks (beer_amd/cli/hmm.py),
+mkdecodegraph / mkphoneloop`) with the command line's own builders (beer_amd/cli/hmm.py: build_units,
+loop_graph, decode_graph, phone_loop),
 without the pickles in between.  The configuration below is the recipe's, as numbers.
 """
 
@@ -47,43 +48,8 @@ def phone_loop(n_speech_units, mean, var, conf=None, n_non_speech_units=1, weigh
     names = {'non-speech-unit': ['sil' + (str(i + 1) if i else '') for i in range(n_non_speech_units)],
              'speech-unit': list(range(n_speech_units))}
     torch.manual_seed(seed)
-    # -- mkphones (mkphones.py:95-113)
-    start_pdf_id, pdfs, units = 0, [], {}
-    for group, gconf in groups.items():
-        tot = 0
-        for name in names[group]:
-            graph, start_pdf_id = cli.create_unit_graph(gconf['topology'], start_pdf_id)
-            units[name] = graph
-            tot += cli.count_emitting_state(graph)
-        pdfs.append(cli.create_pdfs(mean, var, tot, gconf))
-    emissions = beer.JointModelSet(pdfs)
-    # -- mkphoneloopgraph --start-end-group non-speech-unit (mkphoneloopgraph.py)
-    graph = beer.graph.Graph()
-    graph.start_state, graph.end_state = graph.add_state(), graph.add_state()
-    pivot = graph.add_state()
-    unit2state = {name: graph.add_state() for name in units}
-    for name in names['non-speech-unit']:
-        graph.add_arc(graph.start_state, unit2state[name])
-    for name in names['non-speech-unit']:
-        graph.add_arc(unit2state[name], graph.end_state)
-    for name in units:
-        graph.add_arc(pivot, unit2state[name])
-        graph.add_arc(unit2state[name], pivot)
-    graph.normalize()
-    # -- mkdecodegraph (mkdecodegraph.py)
-    for name, hmm in units.items():
-        graph.replace_state(unit2state[name], hmm)
-    graph.normalize()
-    start_pdf = {n: cli._single_pdf(h, h.find_next_pdf_ids(h.start_state)) for n, h in units.items()}
-    end_pdf = {n: cli._single_pdf(h, h.find_previous_pdf_ids(h.end_state)) for n, h in units.items()}
-    # -- mkphoneloop (mkphoneloop.py)
-    size = len(start_pdf)
-    if weights_prior == 'dirichlet':
-        cat = beer.Categorical.create(torch.ones(size) / size, prior_strength=size / 2)
-    elif weights_prior == 'dirichlet_process':
-        cat = beer.SBCategorical.create(truncation=size, prior_strength=size / 2)
-    else:
-        cat = beer.SBCategoricalHyperPrior.create(truncation=size, prior_strength=size / 2,
-                                                  hyper_prior_strength=1.)
-    ploop = beer.PhoneLoop.create(graph.compile(), start_pdf, end_pdf, emissions, cat)
+    units, emissions = cli.build_units(groups, names, mean, var)                         # mkphones
+    loop = cli.loop_graph(list(units), edge_units=names['non-speech-unit'])              # mkphoneloopgraph
+    graph, start_pdf, end_pdf = cli.decode_graph(loop, units)                            # mkdecodegraph
+    ploop = cli.phone_loop(graph, start_pdf, end_pdf, emissions, weights_prior)          # mkphoneloop
     return ploop.float(), units

@@ -181,9 +181,9 @@ def test_cli_accumulate_update_decode_reproduce_the_reference_run(tmp_path):
     assert sorted(lines) == ['utt0', 'utt1', 'utt2']
     # per-frame phones of the reference's own Viterbi path
     ploop = compat.load(open(mdl, 'rb'))
-    from beer_amd.cli.hmm import state2phone
+    from beer_amd.cli.hmm import phones_of_path
     lens = [35, 50, 41]
     off = np.concatenate([[0], np.cumsum(lens)])
     for i, utt in enumerate(sorted(lines)):
         ref_path = g['decode'][off[i]:off[i + 1]].tolist()
-        assert lines[utt].split() == state2phone(ref_path, ploop.start_pdf, True)
+        assert lines[utt].split() == phones_of_path(ref_path, ploop.start_pdf, True)
