@@ -212,7 +212,7 @@ def run_gmm(args, rank, world, device, backend):
     kern = kernel_table(kt, args.steps)
     # the shader clock the iteration's kernels run at on THIS box (a sleeping wave on a side stream)
     # (every rank: the step holds a collective)
-    clock = ClockProbe(device).measure(step, 1e3 * elapsed / args.steps)
+    clock = None if args.no_extras else ClockProbe(device).measure(step, 1e3 * elapsed / args.steps)
     allreduce_ms, mstep_ms = phases.mean_ms('all_reduce'), phases.mean_ms('m_step')
     mode = beer.get_f32_mode()
     # secondary: the same iteration on the exact fp32 MFMA (every product an fmaf)
@@ -294,7 +294,7 @@ def run_gmm(args, rank, world, device, backend):
     out['roofline'].update(profiled(pmc_key, out['roofline']))
     if exact:
         out['f32_exact'] = exact
-    if world == 1:
+    if world == 1 and not args.no_extras:
         # the same iterations recorded ONCE as a HIP graph and replayed (beer.CapturedIteration:
         # E-step, statistics, KL and the update as one submission): what the host-side launches of
         # the loop above cost.  Not the headline: a replay has no per-call HIP events.
@@ -431,7 +431,8 @@ def run_hmm(args, rank, world, device, backend, cov=None, total_frames=None, ste
         fence(world)
         elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, world, device, backend)
-    clock = ClockProbe(device).measure(step, 1e3 * elapsed / steps)    # (every rank: a collective)
+    # (every rank: a collective)
+    clock = None if args.no_extras else ClockProbe(device).measure(step, 1e3 * elapsed / steps)
     if os.environ.get('BEER_BENCH_NO_KT'):
         print('NO_KT ms/step', elapsed / steps * 1e3, file=sys.stderr)
         return None
@@ -1031,6 +1032,9 @@ def main():
     ap.add_argument('--no-check', action='store_true', help='config 2: skip the oracle check')
     ap.add_argument('--no-mstep-graph', action='store_true',
                     help='launch the M-step kernel by kernel instead of replaying its captured HIP graph')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='profiling runs: no clock probe, no captured variant (their launches carry '
+                         'the names of the timed ones)')
     ap.add_argument('--no-config3', action='store_true',
                     help='default line: skip the config3 / config3_full sub-objects')
     ap.add_argument('--no-config4', action='store_true',

@@ -1632,6 +1632,44 @@ def test_fused_accumulation_recomputes_the_responsibilities(cov, S, G, D, T):
     torch.testing.assert_close(again, 2 * got, rtol=1e-9, atol=1e-9 * float(got.abs().max()))
 
 
+@pytest.mark.parametrize('cov,S,G,D,T,images', [
+    # accf_kernel<4, 6, ..., BLK = true / false>: the D <= 40 forms WITHOUT a frame image
+    ('diagonal', 120, 16, 40, 16500, False), ('diagonal', 7, 4, 13, 17000, False),
+    ('isotropic', 30, 8, 40, 16500, False),
+    # accf_kernel<4, 9> (D = 49 .. 56: 120 statistic columns) and <4, 10> (D <= 64): no image exists
+    ('diagonal', 12, 8, 52, 16600, True), ('diagonal', 5, 16, 56, 16450, True),
+    ('diagonal', 3, 32, 64, 16385, True), ('isotropic', 6, 4, 60, 16400, True)])
+def test_fused_accumulation_kernels_without_images_vs_oracle(monkeypatch, cov, S, G, D, T, images):
+    """Every non-image instantiation of the fused accumulation (`accf_kernel<4, 6 | 9 | 10, ...>`)
+    DIRECTLY against the numpy oracle (mixtureset.py:85-112): log-normalisers from the E-step,
+    statistics with and without state posteriors, per block at 1e-5."""
+    from beer_amd import kernels, _hip
+    if not images:
+        monkeypatch.setenv('BEER_FRAME_IMAGE', '0')
+    torch.manual_seed(S + G + D)
+    K = S * G
+    mu = torch.randn(K, D, dtype=torch.float64) * 1.5
+    X = (mu[torch.randint(0, K, (T,))] + torch.randn(T, D, dtype=torch.float64)).float().to(DEV)
+    ns = beer.NormalSet.create(torch.zeros(D), torch.ones(D), size=K, prior_strength=1.,
+                               noise_std=1.5, cov_type=cov)
+    ms = beer.MixtureSet.create(S, ns, prior_strength=1.).float().to(DEV)
+    E, lw = ns.means_precisions.natural_form(), ms._log_weights()
+    st = beer.FrameStats(X, cov)
+    has_image = _hip.lib().beer_frame_image_bytes(_hip.COV_CODE[cov], T, D) > 0
+    assert (st.frame_image() is not None) == (has_image and images)
+    assert kernels.fused_accumulate_ok(st, S, G, cov)
+    ln, _ = kernels.mixtureset_estep(st, E, lw, S, G, cov, want_resps=False)
+    sr = torch.rand(T, S, device=DEV) * (torch.rand(T, S, device=DEV) < .4)
+    sr[3000:9000, ::2] = 0.
+    for state in (sr, None):
+        got = kernels.mixtureset_accumulate_fused(st, E, lw, ln, state, S, G, cov)
+        truth = oracle_mixtureset(X, cov, ns, ms, S, G, state_resps=state)
+        ref32 = oracle_mixtureset(X, cov, ns, ms, S, G, state_resps=state, dtype=np.float32)
+        assert_close(npy(ln), truth['ln'], 1e-5, 'log-normalisers vs oracle')
+        assert_stats_close(npy(got), truth['acc'], D, 1e-5, 'fused statistics vs oracle',
+                           ref32=ref32['acc'])
+
+
 @pytest.mark.parametrize('cov,S,G,D', [('full', 12, 16, 24), ('full', 5, 64, 30), ('full', 9, 12, 40),
                                          ('diagonal', 30, 16, 40), ('full', 1, 200, 24)])
 def test_pack_resps_and_repacked_accumulation(cov, S, G, D):

@@ -5,16 +5,16 @@
 #   bash tools/collect_profiles.sh r05 gpurun_out/r5prof
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r05}; O=${2:-gpurun_out/r5prof}
+R=${1:-r06}; O=${2:-gpurun_out/r6prof}
 rm -f profiles/${R}_pmc.json
-C2="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config3"
-C3="python bench.py --config 3 --steps 6 --warmup 2 --no-cpu-baseline"
-C3F="python bench.py --config 3 --cov full --frames 2000000 --steps 6 --warmup 2 --no-cpu-baseline"
+C2="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-config3 --no-extras"
+C3="python bench.py --config 3 --steps 6 --warmup 2 --no-cpu-baseline --no-extras"
+C3F="python bench.py --config 3 --cov full --frames 2000000 --steps 6 --warmup 2 --no-cpu-baseline --no-extras"
 python tools/pmc_summary.py $R "--command=$C2" --skip=5/25 $O/c2_pmc1 $O/c2_pmc2 $O/c2_pmc3
 python tools/pmc_summary.py $R "--command=$C3" --tag=c3 --skip=2/8 $O/c3_pmc1 $O/c3_pmc2 $O/c3_pmc3
 python tools/pmc_summary.py $R "--command=$C3F" --tag=c3full --skip=2/8 $O/c3full_pmc1 $O/c3full_pmc2 $O/c3full_pmc3
 python tools/pmc_summary.py $R "--command=python tools/probes/c4_prior_path.py full 5" --tag=c4 --skip=2/7 $O/c4_pmc1 $O/c4_pmc2 $O/c4_pmc3
-python tools/pmc_summary.py $R "--command=python tools/probes/c4_prior_path.py diagonal 5" --tag=c4d --skip=2/7 $O/c4d_pmc1 $O/c4d_pmc2 $O/c4d_pmc3
+python tools/pmc_summary.py $R "--command=python tools/probes/c4_prior_path.py diagonal 5" --tag=c4d --skip=2/7 --min-read=accd_kernel:736000000 $O/c4d_pmc1 $O/c4d_pmc2 $O/c4d_pmc3
 cp $O/kernel_times.json profiles/${R}_kernel_times.json
 for n in c2:bench c3:bench_config3 c3full:bench_config3_full c4:config4_prior_path c4d:config4_prior_path_diagonal c5:bench_config5 c4bench:bench_config4; do
   a=${n%%:*}; b=${n#*:}
@@ -28,6 +28,10 @@ done
 cp $O/bench.json profiles/${R}_bench.json
 cp $O/bench_c3.json profiles/${R}_bench_config3.json
 cp $O/bench_c3full.json profiles/${R}_bench_config3_full.json
+for n in bench:bench bench_c3:bench_config3 bench_c3full:bench_config3_full bench_g2_gloo:bench_g2_gloo bench_g8_gloo_config3:bench_g8_gloo_config3; do
+  a=${n%%:*}; b=${n#*:}
+  [ -s $O/${a}_detail.json ] && cp $O/${a}_detail.json profiles/${R}_${b}_detail.json
+done
 for f in bench_c4.json bench_c5.json bench_g2_gloo.json bench_g8_gloo_config3.json; do
   [ -s $O/$f ] && cp $O/$f profiles/${R}_$f
 done
