@@ -61,7 +61,7 @@ def lib():
 OPTIONS = {'ax_max_frames': (0, 'BEER_AX_MAXFRAMES'), 'accf_rounds': (1, 'BEER_ACCF_ROUNDS'),
            'k1_wide': (2, 'BEER_K1_WIDE'), 'accfi_waves': (3, 'BEER_ACCFI_WAVES'),
            'lnfi': (4, 'BEER_LNFI'), 'fb_log': (5, 'BEER_FB_LOG'),
-           'k1_lds': (6, 'BEER_K1_LDS'), 'accfi_persist': (7, 'BEER_ACCFI_PERSIST')}
+           'k1_lds': (6, 'BEER_K1_LDS')}
 
 
 def _options_from_env(l):

@@ -1722,36 +1722,18 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
     int64_t nframes, int K, int S, int G, int Greal, int nk, int nslab,
     const u4* __restrict__ img, const u4* __restrict__ Pall, const float* __restrict__ log_norm,
     const float* __restrict__ sr, int64_t frames_per_block, double* __restrict__ Sp,
-    const float* __restrict__ c0p, unsigned* __restrict__ sync = nullptr) {
+    const float* __restrict__ c0p) {
     constexpr int NTC = 4, NQT = img_nqt(NKU), MT = 2, FW = 32, NTHREADS = 64 * WAVES;
     // (the 6-tile format leaves no registers for a third B fragment in flight)
     constexpr int NBQ = NQT > 5 ? 2 : 3;
     constexpr int kTileU4 = (NKU * NP * MT + NQT * NP) * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // Which frame blocks, which chunk.  One-shot form (`sync` == nullptr): one workgroup per (frame
-    // block, chunk), dealt out by xcd_block().  Persistent form: the grid is ONE round of the chip
-    // (8 XCDs x kSlots workgroups); a workgroup keeps its chunk and walks the frame blocks
-    // gid, gid + ngroups, ... together with the other nch - 1 workgroups of its group, all on one
-    // XCD -- and waits for them before every block (a counter in global memory).  The chunks of a
-    // frame block read the same image; what makes that ONE pass over HBM is that they read it at
-    // the same time.  In the one-shot form nothing keeps them together: a slot is refilled when
-    // its workgroup happens to finish, after a few rounds the 30 chunks of a block start spread
-    // over a whole workgroup's run time, and 29 % of the kernel's L2 requests missed
-    // (TCC_MISS / TCC_REQ, config 3: 126 GB from HBM per 10 M frames for an image of 10.5 GB).
-    int64_t bx, bx_step = 0, nxb = (nframes + frames_per_block - 1) / frames_per_block;
-    int by, gid = 0;
-    const int nch = (K + 16 * NTC - 1) / (16 * NTC);
-    if (sync) {
-        constexpr int kSlots = 512 / NTHREADS * 32;        // workgroups of an XCD's round
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, gpx = kSlots / nch;
-        if (slot >= gpx * nch) return;
-        by = slot % nch;
-        gid = xcd * gpx + slot / nch;
-        bx = gid;
-        bx_step = 8 * gpx;
-        if (bx >= nxb) return;
-    } else if (!xcd_block(nxb, nch, nch, bx, by)) {
-        return;
+    int64_t bx;
+    int by;
+    {
+        const int nch = (K + 16 * NTC - 1) / (16 * NTC);
+        if (!xcd_block((nframes + frames_per_block - 1) / frames_per_block, nch, nch, bx, by))
+            return;
     }
     const int nq = nslab * 4;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1761,24 +1743,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
     constexpr int p_u4 = NKU * NTC * kBlockU4;
     u4* Ps = reinterpret_cast<u4*>(smem);
     float* lsw = reinterpret_cast<float*>(Ps + p_u4) + wave * (2 * FW * NS);
-  for (unsigned round = 0;; ++round) {
     {
         const u4* src = Pall + (size_t)by * nk * NTC * kBlockU4;
         for (int idx = tid; idx < p_u4; idx += NTHREADS) Ps[idx] = src[idx];
-    }
-    if (sync && nch > 1) {
-        // the group's rendezvous before frame block number `round`: every member has arrived
-        // `round` + 1 times.  Bounded: a member that is not resident yet (another kernel holds its
-        // slot) delays the others by at most the bound, it cannot hang them -- the rendezvous is
-        // for locality, nothing that is computed depends on it.
-        if (tid == 0) {
-            __hip_atomic_fetch_add(sync + gid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned want = (unsigned)nch * (round + 1);
-            for (int spin = 0; spin < 4096; ++spin) {
-                if (__hip_atomic_load(sync + gid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
-                __builtin_amdgcn_s_sleep(16);
-            }
-        }
     }
     __syncthreads();
     if (BEER_ACCFI_SLEEP > 0 && (WAVES == 8 ? wave >= 4 : (blockIdx.x >> 3) & 1)) {
@@ -2036,12 +2003,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void accfi_kernel(
         if (slot < K && gi < Greal)
             atomicAdd(Sp + (int64_t)((slot / G) * Greal + gi) * nq + (nslab - 1) * 4, t);
     }
-    // (persistent form: the group's next frame block; the parameters' LDS region was the
-    // reduction's scratch and is filled again at the top)
-    bx += bx_step;
-    if (!sync || bx >= nxb) break;
-    __syncthreads();
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2589,10 +2550,6 @@ int acc_bf16x3_packed(int cov, int64_t nframes, int D, int K, const float* X, co
     return BEER_OK;
 }
 
-// (c0, then the rendezvous counters of the persistent image kernel: one per group of workgroups)
-constexpr size_t kAccfConstBytes = 4096;
-constexpr size_t kAccfSyncOffset = 1024;
-
 // statistics per Gaussian small enough for a wave's register tile: diagonal and
 // isotropic covariances up to D = 64 (nq <= 160)
 bool supported_accf(int cov, int D, int S, int G) {
@@ -2606,7 +2563,7 @@ size_t accf_workspace_bytes(int cov, int D, int S, int G) {
     G = accf_group_pad(S, G);
     const int K = S * G, NTC = accf_ntc(cov, D), nk = nk16_of(cov, D);
     const int nchunks = (K + 16 * NTC - 1) / (16 * NTC), nq = nslab_of(cov, D) * 4;
-    return p_image_bytes(nchunks, nk, NTC) + up256((size_t)(nk + 1) * 8 * sizeof(int)) + kAccfConstBytes +
+    return p_image_bytes(nchunks, nk, NTC) + up256((size_t)(nk + 1) * 8 * sizeof(int)) + 1024 +
            up256((size_t)Kreal * nq * sizeof(double));
 }
 
@@ -2666,12 +2623,9 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
     int* tab = reinterpret_cast<int*>(w);
     w += up256((size_t)(nk + 1) * 8 * sizeof(int));
     float* c0 = reinterpret_cast<float*>(w);
-    unsigned* sync = reinterpret_cast<unsigned*>(w + kAccfSyncOffset);
-    w += kAccfConstBytes;
+    w += 1024;
     double* Sp = reinterpret_cast<double*>(w);
-    // (one memset: the rendezvous counters sit right in front of the statistics image)
-    hipError_t e = hipMemsetAsync(sync, 0, kAccfConstBytes - kAccfSyncOffset +
-                                               (size_t)Kreal * nq * sizeof(double), s);
+    hipError_t e = hipMemsetAsync(Sp, 0, (size_t)Kreal * nq * sizeof(double), s);
     if (e != hipSuccess) return -(int)e;
     hipLaunchKernelGGL(const_max_kernel, dim3(1), dim3(256), 0, s, cov, D, Kreal, expT, logw, c0);
     hipLaunchKernelGGL(packx_kernel, dim3(kpad), dim3(256),
@@ -2722,21 +2676,13 @@ int acc_fused_bf16x3(int cov, int64_t nframes, int D, int S, int G, const float*
                              (size_t)waves * 64 * ns_img * sizeof(float);
         const size_t lds_red = (size_t)waves * 16 * 64 * sizeof(float);
         const size_t lds_f = lds_i > lds_red ? lds_i : lds_red;
-        // persistent, group-synchronised form (accfi_kernel): at least two chunks to keep together,
-        // a whole group inside an XCD's round of workgroups, enough frame blocks for every group
-        const int slots = waves == 8 ? 32 : 64, gpx = nchunks <= slots ? slots / nchunks : 0;
-        const bool persistent = beer::option(BEER_OPT_ACCFI_PERSIST) && nchunks >= 2 && gpx >= 1 &&
-                                gz >= 2 * 8 * gpx;
-        const dim3 pgrid(8 * slots);
 #define BEER_ACCFI(NKU_, W_, NS_)                                                                \
     do {                                                                                         \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(accfi_kernel<NKU_, W_, NS_>),    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, beer::kMaxDynLds); \
-        hipLaunchKernelGGL((accfi_kernel<NKU_, W_, NS_>), persistent ? pgrid : grid,             \
-                           dim3(64 * W_), lds_f, s, nframes,                                     \
+        hipLaunchKernelGGL((accfi_kernel<NKU_, W_, NS_>), grid, dim3(64 * W_), lds_f, s, nframes, \
                            K, S, G, Greal, nk, nslab, reinterpret_cast<const u4*>(image),        \
-                           reinterpret_cast<const u4*>(P), log_norm, sr, fpb, Sp, c0,            \
-                           persistent ? sync : nullptr);                                         \
+                           reinterpret_cast<const u4*>(P), log_norm, sr, fpb, Sp, c0);           \
     } while (0)
 #define BEER_ACCFI_K(W_, NS_)                                                                    \
     do {                                                                                         \

@@ -17,7 +17,6 @@ constexpr OptSpec kOptSpec[BEER_OPT_COUNT] = {
     {1, 0, 1},                // BEER_OPT_LNFI
     {0, 0, 1},                // BEER_OPT_FB_LOG
     {1, 0, 1},                // BEER_OPT_K1_LDS
-    {1, 0, 1},                // BEER_OPT_ACCFI_PERSIST
 };
 static_assert(sizeof(kOptSpec) / sizeof(kOptSpec[0]) == BEER_OPT_COUNT, "one OptSpec per option");
 // every option starts at its spec'd default: filled from the table, never listed by hand

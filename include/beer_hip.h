@@ -80,13 +80,7 @@ int beer_hip_device_count(void);
                                   * ring of two half k-steps) instead of streaming them from L2
                                   * per wave; 0: per wave.  Same products in the same order:
                                   * bit-identical results.  Default 1. */
-#define BEER_OPT_ACCFI_PERSIST 7 /* 1: the fused accumulation over a frame image runs ONE round of
-                                  * persistent workgroups; the workgroups of a frame block's chunks
-                                  * (one XCD) walk the frame blocks together, a rendezvous before
-                                  * each, so that the image is read from HBM once and from L2 by the
-                                  * others; 0: one workgroup per (frame block, chunk).  Same sums,
-                                  * other order of the fp64 atomics.  Default 1. */
-#define BEER_OPT_COUNT 8
+#define BEER_OPT_COUNT 7
 int beer_hip_set_option(int option, int value);
 int beer_hip_get_option(int option);   /* the value, or BEER_EINVAL for an unknown option */
 
