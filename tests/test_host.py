@@ -439,3 +439,61 @@ def test_frames_workspace_of_the_diagonal_accumulation_is_bounded():
     assert q(F32 | _hip.EXACT, DIAG, 1_000_000, 64, 120, 1) == base(F32 | _hip.EXACT, DIAG, 64, 120, 1)
     assert q(F64, DIAG, 1_000_000, 64, 120, 1) == base(F64, DIAG, 64, 120, 1)
     assert q(F32, FULL, 1_000_000, 40, 256, 1) == base(F32, FULL, 40, 256, 1)
+
+
+def test_cli_model_builders_on_the_recipe_configuration():
+    """`beer hmm mkphones / mkphoneloopgraph / mkdecodegraph` as builders (beer_amd/cli/hmm.py) on
+    the configuration of recipes/aud/conf/hmm.yml (benchlib/recipe.py): unit graphs, pdf ids running
+    through the groups, the loop's edge units, first / last pdf of every unit; and
+    `phones_of_path` (decode.py:27-40) against the loop it restates."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from benchlib import recipe
+    from beer_amd.cli import hmm as cli
+    conf = {g['group_name']: g for g in recipe.hmm_conf()}
+    topo = cli.UnitTopology(conf['non-speech-unit']['topology'])
+    assert (topo.n_states, topo.n_emitting, len(topo.src)) == (7, 5, 19)
+    assert cli.UnitTopology(conf['speech-unit']['topology']).n_emitting == 3
+    with pytest.raises(ValueError):
+        cli.UnitTopology([{'start_id': 0, 'end_id': 2, 'trans_prob': 1.}])      # ids with a hole
+    names = {'non-speech-unit': ['sil'], 'speech-unit': ['a', 'b', 'c']}
+    torch.manual_seed(0)
+    units, emissions = cli.build_units(conf, names, torch.zeros(6), torch.ones(6))
+    assert list(units) == ['sil', 'a', 'b', 'c']
+    sets = emissions.modelsets
+    assert [(len(m), m.n_comp_per_mixture) for m in sets] == [(5, 10), (9, 4)]
+    pdfs = {n: [units[n].state_from_id(s).pdf_id for s in units[n].states()] for n in units}
+    assert pdfs['sil'] == [None, 0, 1, 2, 3, 4, None]
+    assert pdfs['a'] == [None, 5, 6, 7, None] and pdfs['c'] == [None, 11, 12, 13, None]
+    loop = cli.loop_graph(list(units), edge_units=['sil'])
+    assert sorted(loop.symbols.values(), key=str) == sorted(['\\<s\\>', '\\</s\\>', '#1', 'sil', 'a', 'b', 'c'], key=str)
+    arcs = {(a.start, a.end) for a in loop.arcs()}
+    state_of = {u: s for s, u in loop.symbols.items()}
+    assert (loop.start_state, state_of['sil']) in arcs and (state_of['sil'], loop.end_state) in arcs
+    assert (loop.start_state, state_of['a']) not in arcs
+    for u in units:
+        assert (state_of['#1'], state_of[u]) in arcs and (state_of[u], state_of['#1']) in arcs
+    graph, first, last = cli.decode_graph(loop, units)
+    assert first == {'sil': 0, 'a': 5, 'b': 8, 'c': 11} and last == {'sil': 4, 'a': 7, 'b': 10, 'c': 13}
+    compiled = graph.compile()
+    assert compiled.n_states == 14
+    # phones_of_path against the reference's loop, written out
+    rng = np.random.RandomState(0)
+    starts = list(first.values())
+    sym = {v: k for k, v in first.items()}
+    for _ in range(20):
+        path = [0] + [int(v) for v in rng.randint(0, 14, 40)]
+        want_per_frame, want = [sym[path[0]]], [sym[path[0]]]
+        prev, cur = path[0], sym[path[0]]
+        for p in path[1:]:
+            if p != prev and p in starts:
+                cur = sym[p]
+                want.append(cur)
+                want_per_frame.append(cur)
+            else:
+                want_per_frame.append(cur)
+            prev = p
+        assert cli.phones_of_path(path, first) == want
+        assert cli.phones_of_path(path, first, per_frame=True) == want_per_frame
+    with pytest.raises(KeyError):
+        cli.phones_of_path([3, 0, 1], first)
