@@ -44,7 +44,7 @@ bash tools/collect_profiles.sh r06 gpurun_out/r6prof --profiles-only > $O/collec
 # (stdout of a bench run is the compact line; the full objects are bench_detail.json, kept per run)
 line() {  # name, command...
   local n=$1; shift
-  timeout 900 "$@" > $O/$n.json 2> $O/$n.stderr
+  timeout 900 "$@" 2> $O/$n.stderr | grep "^{" > $O/$n.json    # (gloo prints its connection lines on stdout)
   cp bench_detail.json $O/${n}_detail.json 2>/dev/null
 }
 line bench python bench.py --steps 20 --warmup 5
