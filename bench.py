@@ -790,6 +790,27 @@ def run_config5(args, device, hours=None, epochs=5, n_comp=4, cpu_sample=6):
     wall = time.perf_counter() - t_all
     stage_sum = sum(walls.values())
     elbos = [float(v) / (len(lengths) * total) for v in elbos]
+    # beside the stages (not in `value`): the same epochs recorded as HIP graphs -- one submission
+    # per epoch instead of ~100 launches behind a host that waits for every epoch's ELBO
+    captured = None
+    if not args.no_extras:
+        try:
+            it = beer.CapturedIteration(ploop, beer.VBConjugateOptimizer(ploop.mean_field_factorization(), 1.),
+                                        (X, lengths), datasize=total, inference_graphs=graphs,
+                                        statics=statics, frame_images=images)
+            modes = []
+            for _ in range(2 * len(ploop.mean_field_factorization()) + 1):
+                it()
+                modes.append(it.mode)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(epochs):
+                it()
+            torch.cuda.synchronize()
+            captured = {'epoch_ms': 1e3 * (time.perf_counter() - t0) / epochs, 'mode': it.mode,
+                        'frames_per_s': total * epochs / (time.perf_counter() - t0)}
+        except Exception as err:                           # noqa: BLE001  (an extra, never the line)
+            captured = {'error': f'{type(err).__name__}: {err}'[:200]}
     kern = {}
     for nm in names:
         ms, n = kt.mean_ms(nm)
@@ -806,6 +827,7 @@ def run_config5(args, device, hours=None, epochs=5, n_comp=4, cpu_sample=6):
            'wall_s_with_synthesis': wall, 'stages_s': walls, 'epoch_s': epoch_s, 'epochs': epochs, 'frames': total,
            'utterances': len(lens), 'audio_bytes': audio_bytes,
            'training_frames_per_s': total * epochs / walls['training'], 'gaussians': n_gauss,
+           'captured_epochs': captured,
            'training_frame_gaussians_per_s': total * epochs * n_gauss / walls['training'],
            'features_frames_per_s': total / walls['features'],
            'viterbi_frames_per_s': total / walls['viterbi_align'],

@@ -107,6 +107,8 @@ def summary(out):
         s['config5_wall_s'] = round(c5['wall_s'], 3)
         if 'training_frames_per_s' in c5:
             s['config5_training_frames_per_s'] = round(c5['training_frames_per_s'])
+        if (c5.get('captured_epochs') or {}).get('epoch_ms'):
+            s['config5_captured_epoch_ms'] = round(c5['captured_epochs']['epoch_ms'], 3)
         cpu = (c5.get('cpu_baseline') or {}).get('value')
         if cpu:
             s['config5_cpu_frames_per_s'] = round(cpu)

@@ -80,12 +80,21 @@ def _oracle(graph_arrays, llhs, dtype=np.float64):
         return orc.posteriors(llhs.astype(dtype), init, final, trans, True)
 
 
+BANDS = []        # (what, error, band, float32 oracle's own error) of every banded comparison of the run
+
+
 def _band(got, truth, f32_ref, what, floor=1e-5):
     'fp32: inside the error of the oracle\'s own float32 run (the reference\'s op sequence) or 1e-5.'
     scale = max(np.abs(truth).max(), 1e-300)
     err = np.abs(np.asarray(got, dtype=np.float64) - truth).max() / scale
     ref = np.abs(np.asarray(f32_ref, dtype=np.float64) - truth).max() / scale
-    assert err <= max(floor, 1.5 * ref), f'{what}: rel err {err:.3e} > band {max(floor, 1.5 * ref):.3e}'
+    band = max(floor, 1.5 * ref)
+    # (the band that was used, for the record: `pytest -s` / the captured output of a failure;
+    #  north_star's flat 1e-5 wherever the reference's own float32 run reaches it)
+    print(f'[band] {what}: rel err {err:.3e}, band {band:.3e} '
+          f'({"flat 1e-5" if band == floor else "1.5 x the float32 oracle run: " + format(ref, ".3e")})')
+    BANDS.append((what, err, band, ref))
+    assert err <= band, f'{what}: rel err {err:.3e} > band {band:.3e}'
 
 
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
@@ -520,3 +529,18 @@ def test_a_nan_in_a_pdf_column_the_graph_does_not_use_is_ignored(dtype, log_spac
         truth = orc.posteriors(npy(pc[off:off + n][:, ids]).astype(np.float64), init, fin, trans)
         assert_close(got[off:off + n][:, ids], truth[0], tol, 'state posteriors')
         off += n
+
+
+
+def test_zz_report_the_bands_that_were_used():
+    """Not a check of the kernels: prints, after the cases above, how many of their float32
+    comparisons were held at north_star's flat 1e-5 and how many at the float32 oracle's own error
+    (x 1.5), with the widest band -- so the record of a run says what `_band` let through."""
+    if not BANDS:
+        pytest.skip('run after the float32 cases of this file')
+    flat = [b for b in BANDS if b[2] <= 1e-5]
+    wide = sorted((b for b in BANDS if b[2] > 1e-5), key=lambda b: -b[2])
+    print(f'[band] {len(flat)} of {len(BANDS)} float32 comparisons at a flat 1e-5; {len(wide)} at 1.5 x the '
+          f'float32 oracle run' + (f', widest {wide[0][2]:.2e} ({wide[0][0]}: error {wide[0][1]:.2e})' if wide else ''))
+    for what, err, band, ref in BANDS:
+        assert err <= band
