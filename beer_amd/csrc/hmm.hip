@@ -855,7 +855,15 @@ __device__ __forceinline__ int expo_field(double v) {
     return (int)((__builtin_bit_cast(unsigned long long, v) >> 52) & 0x7ffull);
 }
 
-template <typename T, int SPL, int DEG, bool FUSED, bool XI, bool ATOMIC>
+// OUTM (fused form): how a frame's posteriors go back to pdf ids -- 0: plain stores (every pdf id
+// of the graph distinct); 1: global atomic adds into a zero-filled array (repeated ids: an alignment
+// graph names a phone twice); 2: through a ROW IN LDS -- the wave adds its states' posteriors into
+// an all-zero row of S_total entries (LDS atomics: repeated ids add up there), writes the whole
+// row out with plain coalesced stores and clears it again.  No zero-filled output, no global
+// atomics (1.07 M frames x 100 states of them cost the recipes' alignment-graph training 0.7 ms of
+// a 6.4 ms epoch); needs S_total <= kWvRowMax.
+constexpr int kWvRowMax = 512;
+template <typename T, int SPL, int DEG, bool FUSED, bool XI, int OUTM>
 __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_wave_kernel(
     beer_batch b, const T* __restrict__ pc, int S_total, T scale, double* __restrict__ alpha_ws,
     double* __restrict__ hubf_ws, T* __restrict__ out, T resp_scale,
@@ -882,6 +890,11 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
     // byte addresses in LDS: cur[NS] (a_{t-1}), lb[NS] (b_{t+1} beta_{t+1})
     const int cur0 = wave * (2 * NS * 8), lb0 = cur0 + NS * 8;
     auto lds = [&](int addr) -> double& { return *reinterpret_cast<double*>(smem + addr); };
+    // (OUTM == 2) the wave's output row, behind the columns of all waves
+    T* orow_lds = reinterpret_cast<T*>(smem + kWvWaves * (2 * NS * 8)) + wave * kWvRowMax;
+    if constexpr (OUTM == 2) {
+        for (int e = lane; e < S_total; e += 64) orow_lds[e] = (T)0;
+    }
     const T* in_w = (const T*)L.in_w;
     const T* out_w = (const T*)L.out_w;
     const T* hsw = (const T*)L.hub_src_w;
@@ -1175,9 +1188,13 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
             g0v[p] = gv;
             if (FUSED) {
                 const T gT = (T)gv;
-                if constexpr (ATOMIC) {
-                    // (repeated pdf ids: added, not stored -- the rare case keeps its branch)
+                if constexpr (OUTM == 1) {
+                    // (repeated pdf ids: added, not stored)
                     if (st[p]) atomicAdd(out + (f0 + t) * (int64_t)S_total + ll_off[p], resp_scale * gT);
+                } else if constexpr (OUTM == 2) {
+                    if (st[p])
+                        __hip_atomic_fetch_add(orow_lds + ll_off[p], resp_scale * gT, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WAVEFRONT);
                 } else {
                     store_word(resp_scale * gT, orow, vo_out[p]);
                 }
@@ -1197,6 +1214,16 @@ __global__ __launch_bounds__(64 * kWvWaves, BEER_FB_OCC * 4 / kWvWaves) void fb_
                 if (has_hub && hub_flow)
                     flow_r[p] = __builtin_fma(hfi * hd_w[p], lb_own[p], flow_r[p]);
             }
+        }
+        if constexpr (FUSED && OUTM == 2) {
+            // the row is complete: out it goes (all S_total entries, zeros included), and clear
+            BEER_WAVE_ORDER();
+            for (int e = lane; e < S_total; e += 64) {
+                const T v = orow_lds[e];
+                orow_lds[e] = (T)0;
+                store_word(v, orow, e * (int)sizeof(T));
+            }
+            BEER_WAVE_ORDER();
         }
         if (FUSED && frame_llh) {
             // the frame's expected log-likelihood sum_s gamma_ts l_ts (hmm.py:87) while both
@@ -1381,6 +1408,21 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
     // byte addresses in LDS: cur[NS] (alpha_{t-1}), lb[NS] (llh_{t+1} + beta_{t+1})
     const int cur0 = wave * (2 * NS * 8), lb0 = cur0 + NS * 8;
     auto lds = [&](int addr) -> double& { return *reinterpret_cast<double*>(smem + addr); };
+    // (atomic_out == 2) the wave's output row, behind the columns of all waves: see fb_wave_kernel
+    const bool rows_out = FUSED && atomic_out == 2;
+    T* orow_lds = reinterpret_cast<T*>(smem + kWvWaves * (2 * NS * 8)) + wave * kWvRowMax;
+    if (rows_out)
+        for (int e = lane; e < S_total; e += 64) orow_lds[e] = (T)0;
+    auto flush_row = [&](int64_t t) {
+        __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+        T* dst = out + (f0 + t) * (int64_t)S_total;
+        for (int e = lane; e < S_total; e += 64) {
+            const T v = orow_lds[e];
+            orow_lds[e] = (T)0;
+            dst[e] = v;
+        }
+        __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+    };
     const T* in_w = (const T*)L.in_w;
     const T* out_w = (const T*)L.out_w;
     const T* hsw = (const T*)L.hub_src_w;
@@ -1470,9 +1512,10 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
         return FUSED ? scale * v : v;
     };
 
-    if (FUSED && atomic_out) {
+    if (FUSED && atomic_out == 1) {
         // (the fast kernel may have added posteriors of some of the utterance's frames
-        // before it gave up: the rows are this utterance's alone)
+        // before it gave up: the rows are this utterance's alone; whole rows -- atomic_out == 2 --
+        // are simply written again)
         for (int64_t e = lane; e < T_ * (int64_t)S_total; e += 64) out[f0 * (int64_t)S_total + e] = (T)0;
         __threadfence();
     }
@@ -1526,18 +1569,21 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
         // posteriors 0 (NaN -> 0, graph.py:319-321), its log-normaliser NaN.  The sparse
         // recursion would let the NaN travel along arcs only; say what the reference says.
         const T nan_t = (T)__builtin_nan("");
-        for (int64_t t = 0; t < T_; ++t)
+        for (int64_t t = 0; t < T_; ++t) {
 #pragma unroll
             for (int p = 0; p < SPL; ++p) {
                 if (!st[p]) continue;
                 if (FUSED) {
                     T* dst = out + (f0 + t) * (int64_t)S_total + ll_off[p];
-                    if (atomic_out) atomicAdd(dst, nan_t);
+                    if (rows_out) orow_lds[ll_off[p]] = nan_t;
+                    else if (atomic_out) atomicAdd(dst, nan_t);
                     else *dst = nan_t;
                 } else {
                     out[b.llh_off[u] + t * S + a_off[p]] = nan_t;
                 }
             }
+            if (rows_out) flush_row(t);
+        }
 #pragma unroll
         for (int p = 0; p < SPL; ++p)
             if (st[p] && gamma0_sum) atomicAdd(gamma0_sum + a_off[p], __builtin_nan(""));
@@ -1582,7 +1628,10 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
                 if (FUSED) {
                     const T gT = (T)gv;
                     T* dst = out + (f0 + t) * (int64_t)S_total + ll_off[p];
-                    if (atomic_out) atomicAdd(dst, resp_scale * gT);
+                    if (rows_out)
+                        __hip_atomic_fetch_add(orow_lds + ll_off[p], resp_scale * gT, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    else if (atomic_out) atomicAdd(dst, resp_scale * gT);
                     else *dst = resp_scale * gT;
                     llh_acc += (double)(lt_cur[p] * gT);
                     fval += lt_cur[p] * gT;
@@ -1606,6 +1655,7 @@ __global__ __launch_bounds__(64 * kWvWaves) void fb_wave_log_kernel(
                 }
             }
         }
+        if (rows_out) flush_row(t);
         if (FUSED && frame_llh) {
             const T fsum = wave_sum(fval);
             if (lane == 0) frame_llh[f0 + t] = fsum;
@@ -1956,7 +2006,10 @@ int wave_fb_launch(const beer_batch* b, const T* pc, int S_total, T scale, doubl
     const bool xi = !FUSED && xi_sum != nullptr;
     const int spl = b->max_states <= 64 ? 1 : (b->max_states <= 128 ? 2 : 4);
     const int deg = b->max_degree <= 2 ? 2 : (b->max_degree <= 4 ? 4 : 8);
-    const size_t lds = (size_t)kWvWaves * 2 * 64 * spl * sizeof(double);
+    const bool rows = FUSED && atomic_out == 2;
+    if (rows && S_total > kWvRowMax) return BEER_EINVAL;
+    const size_t lds = (size_t)kWvWaves * 2 * 64 * spl * sizeof(double) +
+                       (rows ? (size_t)kWvWaves * kWvRowMax * sizeof(T) : 0);
     const bool all_log = beer::option(BEER_OPT_FB_LOG) != 0;
     // the linear-domain kernel, then the log-space one for the utterances it flagged
 #define BEER_WV(SPL_, DEG_, XI_)                                                                \
@@ -1964,13 +2017,18 @@ int wave_fb_launch(const beer_batch* b, const T* pc, int S_total, T scale, doubl
         if (all_log)                                                                            \
             hipLaunchKernelGGL(fb_flag_all_kernel, dim3((unsigned)((b->nutt + 255) / 256)),     \
                                dim3(256), 0, s, *b, hub_ws);                                    \
+        else if (rows)                                                                          \
+            hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_, FUSED ? 2 : 0>), grid, \
+                               block, lds, s, *b, pc, S_total, scale, alpha_ws, hub_ws, out,    \
+                               resp_scale, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean, \
+                               frame_llh);                                                     \
         else if (FUSED && atomic_out)                                                           \
-            hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_, FUSED>), grid, block, \
-                               lds, s, *b, pc, S_total, scale, alpha_ws, hub_ws, out,           \
+            hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_, FUSED ? 1 : 0>), grid, \
+                               block, lds, s, *b, pc, S_total, scale, alpha_ws, hub_ws, out,    \
                                resp_scale, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean, \
                                frame_llh);                                                     \
         else                                                                                    \
-            hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_, false>), grid, block, \
+            hipLaunchKernelGGL((fb_wave_kernel<T, SPL_, DEG_, FUSED, XI_, 0>), grid, block,     \
                                lds, s, *b, pc, S_total, scale, alpha_ws, hub_ws, out,           \
                                resp_scale, xi_sum, gamma0_sum, hub_flow, utt_llh, lognorm_mean, \
                                frame_llh);                                                     \

@@ -249,6 +249,9 @@ def fused_ok(batch):
         1 <= st.max_degree <= _hip.SEG and st.max_hubs <= 1 and st.max_hub_members <= 64
 
 
+FUSED_ROW_MAX = 512          # kWvRowMax of hmm.hip: pdf ids of a set that fit a wave's LDS row
+
+
 def posteriors_fused(batch, pc_all, scale=1., want_counts=False, utt_llh=None, frame_llh=None):
     '''Gather + forward-backward + scatter of a shard in one launch
     (`beer_hmm_posteriors_fused`): (state_resps [n_frames, S_total] = scale *
@@ -261,7 +264,11 @@ def posteriors_fused(batch, pc_all, scale=1., want_counts=False, utt_llh=None, f
     pc_all = _hip.on_device(pc_all, dt)
     S_total = pc_all.shape[1]
     repeats, covers = batch.pdf_ids_profile(S_total)
-    make = torch.zeros if (repeats or not covers) else torch.empty
+    # how the posteriors go back to pdf ids (include/beer_hip.h): whole rows through LDS when a
+    # graph repeats ids or leaves some out (alignment graphs) and a row fits; else atomic adds
+    # into / plain stores over a zero-filled array; plain stores when the ids are a permutation
+    out_mode = 2 if (repeats or not covers) and S_total <= FUSED_ROW_MAX else (1 if repeats else 0)
+    make = torch.empty if (out_mode == 2 or (not repeats and covers)) else torch.zeros
     sr = make(batch.n_frames, S_total, dtype=dt, device=dev)
     alpha = torch.empty(batch.n_elems, dtype=torch.float64, device=dev)
     hub_ws = torch.empty(_hip.MAX_HUBS * batch.n_frames, dtype=torch.float64, device=dev)
@@ -277,7 +284,7 @@ def posteriors_fused(batch, pc_all, scale=1., want_counts=False, utt_llh=None, f
         raise ValueError('frame_llh: a contiguous [n_frames] tensor of the batch\'s dtype and device')
     _hip.call('beer_hmm_posteriors_fused', _hip.dtype_code(dt), batch.ref(), S_total,
               _hip.ptr(pc_all), float(scale), _hip.ptr(alpha), _hip.ptr(hub_ws), _hip.ptr(sr),
-              1 if repeats else 0, _hip.ptr(g0), _hip.ptr(flow), _hip.ptr(utt_llh),
+              out_mode, _hip.ptr(g0), _hip.ptr(flow), _hip.ptr(utt_llh),
               _hip.ptr(frame_llh))
     counting_log_space.note(batch, hub_ws)
     return sr, g0, flow

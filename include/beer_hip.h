@@ -574,8 +574,14 @@ size_t beer_hmm_fb_scratch_doubles(int dtype, const beer_batch* batch_h, int wan
  *   state_resps  [n_frames, S_total]: scale * gamma at the pdf ids
  *                (modelset.py:148-154, hmm.py:95).  atomic_out = 0: plain stores --
  *                every graph's pdf ids are distinct; the caller zero-fills the
- *                array unless they also cover 0 .. S_total-1.  atomic_out != 0:
+ *                array unless they also cover 0 .. S_total-1.  atomic_out = 1:
  *                added atomically into the zero-filled array (repeated ids).
+ *                atomic_out = 2 (S_total <= 512, else BEER_EINVAL): whole rows -- a
+ *                wave adds its states' posteriors into a zero row in LDS (repeated
+ *                ids add up there) and stores all S_total entries of the frame,
+ *                zeros included: the array needs no initialisation and sees no
+ *                atomic.  What alignment-graph training uses (accumulate.py:39-59
+ *                with --alis: a transcription names a phone more than once).
  *   utt_llh      (nullable, [nutt] fp64, +=) sum_t sum_s gamma * scale * pc
  *                (hmm.py:87);  gamma0_sum, hub_flow: as above (graph 0 for all).
  *   frame_llh    (nullable, [n_frames] of dtype, stored) the per-frame value
