@@ -3,6 +3,7 @@
 // MFMA traits, DPP row reductions, the slab enumeration of the contraction
 // index and the in-register softmax epilogue.  See estep_mfma.hip for the design.
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -406,6 +407,18 @@ __device__ __forceinline__ void softmax_epilogue(
     using vec4_t = typename M::vec4_t;
     double llh_local = 0.0;
     const bool vec_ok = (K % 4) == 0;
+    // (the state of the lane's group per group of tiles, and whether this lane writes its
+    // log-normaliser: neither depends on the row -- an integer division by a run-time G each, which
+    // the scheduling barriers below kept inside the row loop, eight times per tile)
+    int state_of[NT / 4 / GQ];
+    bool writer[NT / 4 / GQ];
+#pragma unroll
+    for (int tq = 0; tq < NT / 4 / GQ; ++tq) {
+        state_of[tq] = jw == 4 ? (kbase + 64 * tq * GQ + 4 * (i & ~(gl - 1))) / G : 0;
+        writer[tq] = state_of[tq] < S && (i & (gl - 1)) == 0;
+    }
+    // (frames fb .. fb + 16 MT - 1 all inside the launch: no row needs its index compared)
+    const bool rows_in = fb + 16 * MT <= nframes;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -414,6 +427,7 @@ __device__ __forceinline__ void softmax_epilogue(
             // rows and groups and spills the accumulators to scratch
             __builtin_amdgcn_sched_barrier(0);
             const int64_t f = fb + m * 16 + M::row(g, r);
+            const bool f_in = rows_in || f < nframes;
 #pragma unroll
             for (int tq = 0; tq < NT / 4 / GQ; ++tq) {
                 T e[GQ][4];
@@ -440,9 +454,8 @@ __device__ __forceinline__ void softmax_epilogue(
 #pragma unroll
                             for (int j = 0; j < 4; ++j) e[qq][j] *= inv;
                     }
-                    const int state = (kbase + 64 * tq * GQ + 4 * (i & ~(gl - 1))) / G;
-                    if (f < nframes && state < S && (i & (gl - 1)) == 0) {
-                        if (log_norm) log_norm[f * S + state] = lse;
+                    if (f_in && writer[tq]) {
+                        if (log_norm) log_norm[f * S + state_of[tq]] = lse;
                         llh_local += (double)lse;
                     }
                 } else {
@@ -515,6 +528,12 @@ __device__ __forceinline__ void softmax_epilogue(
         unsigned int* out = reinterpret_cast<unsigned int*>(resps);
         const int nblk = (K + kPackedComps - 1) / kPackedComps;
         const int64_t tiles = (nframes + kPackedFrames - 1) / kPackedFrames;
+        // (a tile inside the frames and the components -- all but the last of a launch -- packs its
+        // values as they are: the per-element `frame < nframes && k < K` was a 64-bit add, a 64-bit
+        // compare and a select for each of a lane's 128 values)
+        const bool inside = rows_in && kbase + 16 * NT <= K;
+        auto pack_tile = [&](auto inside_t) {
+            constexpr bool INSIDE = decltype(inside_t)::value;
 #pragma unroll
         for (int mp = 0; mp < MT / 2; ++mp) {
             // the chunk this lane stores after the exchange
@@ -534,7 +553,7 @@ __device__ __forceinline__ void softmax_epilogue(
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        v[r] = f0 + r < nframes && k < K ? (float)acc[m][nt][r] : 0.f;
+                        v[r] = (INSIDE || (f0 + r < nframes && k < K)) ? (float)acc[m][nt][r] : 0.f;
                     split3(v[0], v[1], pw[mm][0]);
                     split3(v[2], v[3], pw[mm][1]);
                 }
@@ -560,6 +579,9 @@ __device__ __forceinline__ void softmax_epilogue(
                 }
             }
         }
+            };
+        if (inside) pack_tile(std::true_type{});
+        else pack_tile(std::false_type{});
     }
     if (llh_sum) {
         llh_local = wave_sum(llh_local);
