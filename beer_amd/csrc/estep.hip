@@ -415,9 +415,13 @@ int acc_launch(int64_t nframes, int D, int S, int G, const void* X, const void* 
                const void* sr, double* acc, hipStream_t s) {
     const int K = S * G, Q = stats_dim(COV, D);
     const int gx = (Q + kAccThreads - 1) / kAccThreads, gy = (K + kAccKB - 1) / kAccKB;
-    // aim for ~4 workgroups per CU, at least 512 frames per workgroup
+    // aim for ~4 workgroups per CU, at least 512 frames per workgroup -- one frame tile (64) for
+    // inputs so small that the launch is a handful of workgroups either way: a lane walks its
+    // workgroup's frames one by one, and the notebook-sized mixture (1000 frames, 8 x 6 statistics:
+    // BASELINE config 1) spent 66 of its iteration's 142 us in two workgroups of 512 frames
     int64_t gz = (256LL * 4 + (int64_t)gx * gy - 1) / ((int64_t)gx * gy);
-    const int64_t max_z = (nframes + 511) / 512;
+    const int64_t min_frames = nframes >= 65536 ? 512 : kAccTile;
+    const int64_t max_z = (nframes + min_frames - 1) / min_frames;
     if (gz > max_z) gz = max_z;
     if (gz < 1) gz = 1;
     if (gz > 65535) gz = 65535;

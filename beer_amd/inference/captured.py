@@ -180,9 +180,10 @@ class CapturedIteration:
             with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                 elbo = self._iteration()
                 value = elbo.value
-                for p, old in zip(members, home_tensors):
-                    for dst, src in zip(old, p.posterior._tensors()):
-                        dst.copy_(src)
+                # (the group's new posterior back into the tensors the E-step read: ONE launch)
+                dsts = [dst for old in home_tensors for dst in old]
+                srcs = [src for p in members for src in p.posterior._tensors()]
+                torch._foreach_copy_(dsts, srcs)
         except RuntimeError as err:
             refused = not isinstance(err, _hip.HipError) or isinstance(err, _hip.HipInvalid) \
                 or 900 <= -(err.rc or 0) <= 908
